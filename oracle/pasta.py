@@ -1,0 +1,576 @@
+"""CPU oracle (Python big-int) for the Kimchi MSM + NTT hot path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``proof_systems_amd/`` may import this
+module; only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s
+``cpu_baseline`` leg use it, and only as the checker.
+
+It restates, with textbook arithmetic, what the reference computes on the hot
+path.  The reference's arithmetic lives in un-vendored crates (ark-ff / ark-ec /
+ark-poly 0.5.0, Cargo.lock:171-281); MSM and DFT results are unique
+mathematical objects, so parity is defined on results, and this file is pinned
+against every golden vector the reference holds for the path (see
+``tests/test_oracle_kats.py``):
+
+* constants ............ curves/src/pasta/fields/fp.rs:8-80, fq.rs:8-79,
+                         curves/src/pasta/curves/{vesta,pallas}.rs
+* SRS::create .......... poly-commitment/src/ipa.rs:751-778, 234-265,
+                         groupmap/src/lib.rs:74-189
+* point codec .......... utils/src/serialization.rs:67-104 (ark-serialize
+                         compressed SW), poly-commitment/src/precomputed_srs.rs:76-91
+* test RNG ............. utils/src/lib.rs:83-91 (rand 0.8.5 StdRng = ChaCha12)
+* commit / chunk / mask  poly-commitment/src/ipa.rs:605-683
+* commit_evaluations ... poly-commitment/src/ipa.rs:706-728,
+                         poly-commitment/src/commitment.rs:350-394
+* lagrange_basis ....... poly-commitment/src/ipa.rs:1065-1172
+* domains .............. kimchi/src/circuits/domains.rs:40-69
+"""
+from __future__ import annotations
+
+import hashlib
+import struct
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+# ---------------------------------------------------------------------------
+# Fields (curves/src/pasta/fields/fp.rs:8-12, fq.rs:8-12)
+# ---------------------------------------------------------------------------
+FP_MODULUS = 0x40000000000000000000000000000000224698FC094CF91B992D30ED00000001
+FQ_MODULUS = 0x40000000000000000000000000000000224698FC0994A8DD8C46EB2100000001
+TWO_ADICITY = 32
+GENERATOR = 5  # multiplicative generator of both fields (fp.rs:9, fq.rs:9)
+R_BITS = 256   # Montgomery radix 2^256 (4 x u64 limbs)
+
+
+@dataclass(frozen=True)
+class Field:
+    name: str
+    p: int
+
+    @property
+    def t(self) -> int:            # odd part of p-1
+        return (self.p - 1) >> TWO_ADICITY
+
+    @property
+    def two_adic_root(self) -> int:  # 5^T, fp.rs:21-26 / fq.rs:16-24
+        return pow(GENERATOR, self.t, self.p)
+
+    @property
+    def R(self) -> int:
+        return (1 << R_BITS) % self.p
+
+    @property
+    def R2(self) -> int:
+        return (self.R * self.R) % self.p
+
+    @property
+    def inv64(self) -> int:        # -p^{-1} mod 2^64
+        return (-pow(self.p, -1, 1 << 64)) % (1 << 64)
+
+    def inv(self, a: int) -> int:
+        return pow(a, self.p - 2, self.p)
+
+    def is_square(self, a: int) -> bool:
+        return a == 0 or pow(a, (self.p - 1) // 2, self.p) == 1
+
+    def sqrt(self, a: int) -> Optional[int]:
+        """Tonelli-Shanks exactly as ark-ff's SqrtPrecomputation::TonelliShanks
+        (SURVEY Appendix A.2): no sign normalisation of the root."""
+        p = self.p
+        a %= p
+        if a == 0:
+            return 0
+        if pow(a, (p - 1) // 2, p) != 1:
+            return None
+        z = self.two_adic_root
+        w = pow(a, (self.t - 1) // 2, p)
+        x = a * w % p
+        b = x * w % p
+        v = TWO_ADICITY
+        while b != 1:
+            k = 0
+            b2k = b
+            while b2k != 1:
+                b2k = b2k * b2k % p
+                k += 1
+            w = pow(z, 1 << (v - k - 1), p)
+            z = w * w % p
+            b = b * z % p
+            x = x * w % p
+            v = k
+        return x
+
+    def to_mont(self, a: int) -> int:
+        return (a << R_BITS) % self.p
+
+    def from_mont(self, a: int) -> int:
+        return a * pow(1 << R_BITS, -1, self.p) % self.p
+
+    def root_of_unity(self, log2_n: int) -> int:
+        """omega_{2^k} = (5^T)^(2^(32-k)) -- kimchi/src/circuits/domains.rs:40-69,
+        ark-poly Radix2EvaluationDomain::new."""
+        assert 0 <= log2_n <= TWO_ADICITY
+        return pow(self.two_adic_root, 1 << (TWO_ADICITY - log2_n), self.p)
+
+
+Fp = Field("Fp", FP_MODULUS)
+Fq = Field("Fq", FQ_MODULUS)
+
+Affine = Optional[Tuple[int, int]]  # None = point at infinity
+
+
+# ---------------------------------------------------------------------------
+# Curves (curves/src/pasta/curves/vesta.rs:8-43, pallas.rs:8-41): y^2 = x^3 + 5
+# ---------------------------------------------------------------------------
+@dataclass(frozen=True)
+class Curve:
+    name: str
+    cid: int          # C-ABI curve id: 0 = Vesta, 1 = Pallas
+    base: Field       # coordinate field
+    scalar: Field     # scalar field
+    gen: Tuple[int, int]
+    b: int = 5
+
+    # -- affine (textbook) ---------------------------------------------------
+    def is_on_curve(self, P: Affine) -> bool:
+        if P is None:
+            return True
+        x, y = P
+        p = self.base.p
+        return (y * y - x * x * x - self.b) % p == 0
+
+    def neg(self, P: Affine) -> Affine:
+        if P is None:
+            return None
+        return (P[0], (-P[1]) % self.base.p)
+
+    def add(self, P: Affine, Q: Affine) -> Affine:
+        p = self.base.p
+        if P is None:
+            return Q
+        if Q is None:
+            return P
+        x1, y1 = P
+        x2, y2 = Q
+        if x1 == x2:
+            if (y1 + y2) % p == 0:
+                return None
+            lam = 3 * x1 * x1 * pow(2 * y1, p - 2, p) % p
+        else:
+            lam = (y2 - y1) * pow(x2 - x1, p - 2, p) % p
+        x3 = (lam * lam - x1 - x2) % p
+        y3 = (lam * (x1 - x3) - y1) % p
+        return (x3, y3)
+
+    # -- Jacobian (fast path for the oracle's own MSMs) ------------------------
+    def _jdbl(self, P):
+        X, Y, Z = P
+        p = self.base.p
+        if Z == 0 or Y == 0:
+            return (1, 1, 0)
+        A = X * X % p
+        B = Y * Y % p
+        C = B * B % p
+        D = 2 * ((X + B) * (X + B) - A - C) % p
+        E = 3 * A % p
+        F = E * E % p
+        X3 = (F - 2 * D) % p
+        Y3 = (E * (D - X3) - 8 * C) % p
+        Z3 = 2 * Y * Z % p
+        return (X3, Y3, Z3)
+
+    def _jadd(self, P, Q):
+        p = self.base.p
+        X1, Y1, Z1 = P
+        X2, Y2, Z2 = Q
+        if Z1 == 0:
+            return Q
+        if Z2 == 0:
+            return P
+        Z1Z1 = Z1 * Z1 % p
+        Z2Z2 = Z2 * Z2 % p
+        U1 = X1 * Z2Z2 % p
+        U2 = X2 * Z1Z1 % p
+        S1 = Y1 * Z2 * Z2Z2 % p
+        S2 = Y2 * Z1 * Z1Z1 % p
+        if U1 == U2:
+            if S1 == S2:
+                return self._jdbl(P)
+            return (1, 1, 0)
+        H = (U2 - U1) % p
+        Rr = (S2 - S1) % p
+        HH = H * H % p
+        HHH = H * HH % p
+        V = U1 * HH % p
+        X3 = (Rr * Rr - HHH - 2 * V) % p
+        Y3 = (Rr * (V - X3) - S1 * HHH) % p
+        Z3 = Z1 * Z2 * H % p
+        return (X3, Y3, Z3)
+
+    def _to_j(self, P: Affine):
+        return (1, 1, 0) if P is None else (P[0], P[1], 1)
+
+    def _from_j(self, P) -> Affine:
+        X, Y, Z = P
+        if Z == 0:
+            return None
+        p = self.base.p
+        zi = pow(Z, p - 2, p)
+        zi2 = zi * zi % p
+        return (X * zi2 % p, Y * zi2 * zi % p)
+
+    def mul(self, P: Affine, k: int) -> Affine:
+        k %= self.scalar.p
+        acc = (1, 1, 0)
+        base = self._to_j(P)
+        while k:
+            if k & 1:
+                acc = self._jadd(acc, base)
+            base = self._jdbl(base)
+            k >>= 1
+        return self._from_j(acc)
+
+    def msm(self, points: Sequence[Affine], scalars: Sequence[int]) -> Affine:
+        """Sum_i scalars[i] * points[i]; uses min(len) pairs like ark-ec's
+        msm_bigint (poly-commitment/src/ipa.rs:663-676 relies on that).
+        Simple windowed bucket method; result is the unique group element."""
+        n = min(len(points), len(scalars))
+        if n == 0:
+            return None
+        q = self.scalar.p
+        sc = [s % q for s in scalars[:n]]
+        c = 4 if n < 32 else min(12, max(4, n.bit_length() - 2))
+        nwin = (255 + c - 1) // c
+        total = (1, 1, 0)
+        jp = [self._to_j(P) for P in points[:n]]
+        for w in reversed(range(nwin)):
+            for _ in range(c):
+                total = self._jdbl(total)
+            buckets = [(1, 1, 0)] * ((1 << c) - 1)
+            shift = w * c
+            mask = (1 << c) - 1
+            for P, s in zip(jp, sc):
+                d = (s >> shift) & mask
+                if d:
+                    buckets[d - 1] = self._jadd(buckets[d - 1], P)
+            run = (1, 1, 0)
+            acc = (1, 1, 0)
+            for bkt in reversed(buckets):
+                run = self._jadd(run, bkt)
+                acc = self._jadd(acc, run)
+            total = self._jadd(total, acc)
+        return self._from_j(total)
+
+    def msm_naive(self, points: Sequence[Affine], scalars: Sequence[int]) -> Affine:
+        acc: Affine = None
+        for P, s in zip(points, scalars):
+            acc = self.add(acc, self.mul(P, s))
+        return acc
+
+    # -- SvdW group map + SRS generator --------------------------------------
+    def _bw_params(self):
+        F = self.base
+        p = F.p
+        u = 1
+        while (u * u * u + self.b) % p == 0:   # groupmap/src/lib.rs:137-145
+            u += 1
+        fu = (u * u * u + self.b) % p
+        three_u2 = 3 * u * u % p
+        inv_three_u2 = F.inv(three_u2)
+        s = F.sqrt((-three_u2) % p)
+        assert s is not None
+        c1 = (s - u) * F.inv(2) % p
+        return u, fu, c1, s, inv_three_u2
+
+    def to_group(self, t: int) -> Tuple[int, int]:
+        """groupmap/src/lib.rs:74-133,184-188 (BWParameters::to_group)."""
+        F = self.base
+        p = F.p
+        u, fu, c1, s, c2 = self._bw_params()
+        t2 = t * t % p
+        alpha_inv = (t2 + fu) * t2 % p
+        alpha = F.inv(alpha_inv) if alpha_inv else 0
+        x1 = (c1 - t2 * t2 % p * alpha % p * s) % p
+        x2 = (-u - x1) % p
+        tpf = (t2 + fu) % p
+        x3 = (u - tpf * tpf % p * (alpha * tpf % p) % p * c2) % p
+        for x in (x1, x2, x3):
+            y = F.sqrt((x * x * x + self.b) % p)
+            if y is not None:
+                return (x, y)
+        raise AssertionError("get_xy")
+
+    def point_of_random_bytes(self, rb: bytes) -> Tuple[int, int]:
+        """poly-commitment/src/ipa.rs:234-265: 31 bytes -> 248 bits, LSB-first
+        within each byte, consumed big-endian."""
+        t = 0
+        for i in range(31):
+            for j in range(8):
+                t = (t << 1) | ((rb[i] >> j) & 1)
+        return self.to_group(t)
+
+    def srs_g(self, i: int) -> Tuple[int, int]:
+        """poly-commitment/src/ipa.rs:754-762."""
+        return self.point_of_random_bytes(hashlib.blake2b(struct.pack(">I", i), digest_size=64).digest())
+
+    def srs_h(self) -> Tuple[int, int]:
+        """poly-commitment/src/ipa.rs:765-772."""
+        return self.point_of_random_bytes(
+            hashlib.blake2b(b"srs_misc" + struct.pack(">I", 0), digest_size=64).digest())
+
+    def srs_create(self, depth: int) -> List[Tuple[int, int]]:
+        return [self.srs_g(i) for i in range(depth)]
+
+    # -- ark-serialize compressed codec --------------------------
+    def compress(self, P: Affine) -> bytes:
+        if P is None:
+            return bytes(32) + b"\x40"
+        x, y = P
+        flag = 0x80 if y > (self.base.p - 1) // 2 else 0
+        return x.to_bytes(32, "little") + bytes([flag])
+
+    def decompress(self, b: bytes) -> Affine:
+        assert len(b) == 33
+        flag = b[32]
+        if flag & 0x40:
+            return None
+        p = self.base.p
+        x = int.from_bytes(b[:32], "little")
+        y = self.base.sqrt((x * x * x + self.b) % p)
+        assert y is not None, "not on curve"
+        neg = y > (p - 1) // 2
+        if neg != bool(flag & 0x80):
+            y = p - y
+        return (x, y)
+
+
+VESTA = Curve("vesta", 0, Fq, Fp,
+              (1, 11426906929455361843568202299992114520848200991084027513389447476559454104162))
+PALLAS = Curve("pallas", 1, Fp, Fq,
+               (1, 12418654782883325593414442427049395787963493412651469444558597405572177144507))
+CURVES = {0: VESTA, 1: PALLAS, "vesta": VESTA, "pallas": PALLAS}
+
+
+# ---------------------------------------------------------------------------
+# msgpack SRS file (precomputed_srs.rs:76-91)
+# ---------------------------------------------------------------------------
+def read_srs_file(path: str, curve: Curve, limit: Optional[int] = None):
+    """Returns (list of compressed 33-byte g_i, compressed h)."""
+    with open(path, "rb") as f:
+        data = f.read()
+    assert data[0] == 0x92 and data[1] == 0xDD
+    n = struct.unpack(">I", data[2:6])[0]
+    off = 6
+    pts = []
+    for _ in range(n):
+        assert data[off] == 0xC4 and data[off + 1] == 0x21
+        pts.append(data[off + 2: off + 35])
+        off += 35
+    assert data[off] == 0xC4 and data[off + 1] == 0x21
+    h = data[off + 2: off + 35]
+    assert off + 35 == len(data)
+    if limit is not None:
+        pts = pts[:limit]
+    return pts, h
+
+
+def msgpack_polycomm(curve: Curve, chunks: Sequence[Affine]) -> bytes:
+    """PolyComm{chunks} as rmp-serde writes it (tests/commitment.rs:369-383):
+    array(1)[ array(n)[ bin8(33) ... ] ]."""
+    n = len(chunks)
+    assert n < 16
+    out = bytes([0x91, 0x90 | n])
+    for P in chunks:
+        out += b"\xc4\x21" + curve.compress(P)
+    return out
+
+
+# ---------------------------------------------------------------------------
+# rand 0.8.5 StdRng (ChaCha12) + ark-ff 0.5 Fp::rand
+# ---------------------------------------------------------------------------
+class StdRng:
+    def __init__(self, seed: bytes):
+        assert len(seed) == 32
+        self.key = list(struct.unpack("<8I", seed))
+        self.counter = 0
+        self.buf: List[int] = []
+
+    @staticmethod
+    def _rotl(x, n):
+        return ((x << n) | (x >> (32 - n))) & 0xFFFFFFFF
+
+    def _block(self):
+        c = [0x61707865, 0x3320646E, 0x79622D32, 0x6B206574]
+        st = c + self.key + [self.counter & 0xFFFFFFFF, (self.counter >> 32) & 0xFFFFFFFF, 0, 0]
+        x = st[:]
+
+        def qr(a, b, c_, d):
+            x[a] = (x[a] + x[b]) & 0xFFFFFFFF; x[d] = self._rotl(x[d] ^ x[a], 16)
+            x[c_] = (x[c_] + x[d]) & 0xFFFFFFFF; x[b] = self._rotl(x[b] ^ x[c_], 12)
+            x[a] = (x[a] + x[b]) & 0xFFFFFFFF; x[d] = self._rotl(x[d] ^ x[a], 8)
+            x[c_] = (x[c_] + x[d]) & 0xFFFFFFFF; x[b] = self._rotl(x[b] ^ x[c_], 7)
+
+        for _ in range(6):  # 12 rounds
+            qr(0, 4, 8, 12); qr(1, 5, 9, 13); qr(2, 6, 10, 14); qr(3, 7, 11, 15)
+            qr(0, 5, 10, 15); qr(1, 6, 11, 12); qr(2, 7, 8, 13); qr(3, 4, 9, 14)
+        self.counter += 1
+        return [(a + b) & 0xFFFFFFFF for a, b in zip(x, st)]
+
+    def next_u32(self) -> int:
+        if not self.buf:
+            self.buf = self._block()
+        return self.buf.pop(0)
+
+    def next_u64(self) -> int:
+        lo = self.next_u32()
+        hi = self.next_u32()
+        return lo | (hi << 32)
+
+
+def field_rand(F: Field, rng: StdRng) -> int:
+    """ark-ff 0.5 `Fp::rand`: 4 u64 limbs, clear the top bit, accept if < p,
+    the limbs ARE the Montgomery representation.  Returns the canonical value."""
+    while True:
+        limbs = [rng.next_u64() for _ in range(4)]
+        limbs[3] &= (1 << 63) - 1
+        v = limbs[0] | (limbs[1] << 64) | (limbs[2] << 128) | (limbs[3] << 192)
+        if v < F.p:
+            return F.from_mont(v)
+
+
+# ---------------------------------------------------------------------------
+# Commitment semantics (poly-commitment/src/ipa.rs:605-748)
+# ---------------------------------------------------------------------------
+def commit_non_hiding(curve: Curve, g: Sequence[Affine], coeffs: Sequence[int],
+                      num_chunks: int) -> List[Affine]:
+    """ipa.rs:638-683."""
+    q = curve.scalar.p
+    coeffs = [c % q for c in coeffs]
+    while coeffs and coeffs[-1] == 0:     # DensePolynomial is truncated
+        coeffs.pop()
+    n = len(g)
+    if not coeffs:
+        chunks: List[Affine] = [None]
+    else:
+        chunks = [curve.msm(g, coeffs[i:i + n]) for i in range(0, len(coeffs), n)]
+    while len(chunks) < num_chunks:
+        chunks.append(None)
+    return chunks
+
+
+def mask_custom(curve: Curve, h: Affine, com: Sequence[Affine], blinders: Sequence[int]) -> List[Affine]:
+    """ipa.rs:605-622: C_j + w_j * h."""
+    assert len(com) == len(blinders)
+    return [curve.add(curve.mul(h, w), c) for c, w in zip(com, blinders)]
+
+
+def lagrange_basis(curve: Curve, g: Sequence[Affine], log2_n: int) -> List[List[Affine]]:
+    """ipa.rs:1065-1172 by definition: the inverse DFT over curve points.
+    Returns basis[i] = list of chunks.  O(n^2) group ops -- small n only."""
+    n = 1 << log2_n
+    F = curve.scalar
+    w = F.root_of_unity(log2_n)
+    winv = F.inv(w)
+    ninv = F.inv(n)
+    srs_size = len(g)
+    num_elems = (n + srs_size - 1) // srs_size
+    out: List[List[Affine]] = [[] for _ in range(n)]
+    for c in range(num_elems):
+        start = c * srs_size
+        num_terms = min((c + 1) * srs_size, n) - start
+        for i in range(n):
+            # L_i commitment chunk c = n^{-1} sum_j w^{-ij} g[j - start]
+            sc = [ninv * pow(winv, i * (start + j), F.p) % F.p for j in range(num_terms)]
+            out[i].append(curve.msm(g[:num_terms], sc))
+    return out
+
+
+def commit_evaluations_non_hiding(curve: Curve, basis: Sequence[Sequence[Affine]],
+                                  evals: Sequence[int], log2_domain: int) -> List[Affine]:
+    """ipa.rs:706-728 + commitment.rs:350-394."""
+    n = 1 << log2_domain
+    assert len(evals) >= n and len(evals) % n == 0
+    s = len(evals) // n
+    v = [evals[s * i] for i in range(n)]
+    nchunks = max(len(b) for b in basis)
+    return [curve.msm([b[c] for b in basis if c < len(b)],
+                      [x for b, x in zip(basis, v) if c < len(b)]) for c in range(nchunks)]
+
+
+# ---------------------------------------------------------------------------
+# NTT (ark-poly Radix2EvaluationDomain semantics)
+# ---------------------------------------------------------------------------
+def _bitrev(n: int, bits: int) -> int:
+    r = 0
+    for _ in range(bits):
+        r = (r << 1) | (n & 1)
+        n >>= 1
+    return r
+
+
+def ntt(F: Field, a: Sequence[int], log2_n: int, inverse: bool = False) -> List[int]:
+    """Natural order in, natural order out.  Forward: out[j] = sum a_i w^{ij}
+    (input zero-padded to N).  Inverse: c_i = N^{-1} sum e_j w^{-ij}."""
+    n = 1 << log2_n
+    p = F.p
+    assert len(a) <= n
+    x = [v % p for v in a] + [0] * (n - len(a))
+    w = F.root_of_unity(log2_n)
+    if inverse:
+        w = F.inv(w)
+    x = [x[_bitrev(i, log2_n)] for i in range(n)]
+    m = 1
+    while m < n:
+        wm = pow(w, n // (2 * m), p)
+        for k in range(0, n, 2 * m):
+            t = 1
+            for j in range(m):
+                u = x[k + j]
+                v = x[k + j + m] * t % p
+                x[k + j] = (u + v) % p
+                x[k + j + m] = (u - v) % p
+                t = t * wm % p
+        m *= 2
+    if inverse:
+        ninv = F.inv(n)
+        x = [v * ninv % p for v in x]
+    return x
+
+
+def dft_naive(F: Field, a: Sequence[int], log2_n: int, inverse: bool = False) -> List[int]:
+    n = 1 << log2_n
+    p = F.p
+    w = F.root_of_unity(log2_n)
+    if inverse:
+        w = F.inv(w)
+    out = []
+    for j in range(n):
+        wj = pow(w, j, p)
+        acc = 0
+        t = 1
+        for i, v in enumerate(a):
+            acc = (acc + v * t) % p
+            t = t * wj % p
+        out.append(acc)
+    if inverse:
+        ninv = F.inv(n)
+        out = [v * ninv % p for v in out]
+    return out
+
+
+def lde(F: Field, coeffs: Sequence[int], log2_n: int, log2_blowup: int) -> List[int]:
+    """DensePolynomial::evaluate_over_domain_by_ref(d8) (constraints.rs:490-495):
+    zero-extend n coefficients to n<<b and forward-NTT."""
+    return ntt(F, list(coeffs), log2_n + log2_blowup, inverse=False)
+
+
+# ---------------------------------------------------------------------------
+# wire helpers: 4 x u64 little-endian Montgomery limbs (ark-ff in-memory layout;
+# kimchi/src/cached_prover_index.rs:502-539)
+# ---------------------------------------------------------------------------
+def to_limbs(v: int) -> Tuple[int, int, int, int]:
+    m = (1 << 64) - 1
+    return (v & m, (v >> 64) & m, (v >> 128) & m, (v >> 192) & m)
+
+
+def from_limbs(l) -> int:
+    return int(l[0]) | (int(l[1]) << 64) | (int(l[2]) << 128) | (int(l[3]) << 192)
