@@ -1,0 +1,152 @@
+/*
+ * kimchi_hip.h -- C ABI of the MI355X-native MSM + NTT hot path for Kimchi.
+ *
+ * This is the drop-in boundary: a Rust shim crate implements
+ * poly-commitment's `trait SRS<G>` / `trait OpenProof<G>` by delegating the MSMs to
+ * the kh_msm* entry points, and kimchi's evaluation-domain transforms by delegating
+ * to kh_ntt / kh_lde.  Plain C, no exceptions, no torch types.  Every function
+ * returns 0 on success or a negative KH_E_* code; kh_last_error() describes the last
+ * failure on the calling thread.  All functions are thread-safe (the reference calls
+ * SRS::commit_evaluations_non_hiding from 15 rayon workers at once,
+ * kimchi/src/prover.rs:329-351).
+ *
+ * Wire format (zero-copy from Rust):
+ *   field element = 4 x uint64_t little-endian limbs in Montgomery form, R = 2^256,
+ *                   i.e. ark-ff's in-memory Fp256<MontBackend<_,4>> (the reference
+ *                   itself reinterprets Fp as [u64;4]: kimchi/src/cached_prover_index.rs:502-539);
+ *   affine point  = x || y = 8 limbs (64 bytes), infinity passed out of band
+ *                   (ark-ec Affine{x,y,infinity} has no stable layout: the shim packs it);
+ *   curve id      : 0 = Vesta  (coordinates in Fq, scalars in Fp)
+ *                   1 = Pallas (coordinates in Fp, scalars in Fq)
+ *   field id      : 0 = Fp, 1 = Fq.
+ * Results are returned affine because the Fiat-Shamir sponge absorbs affine
+ * coordinates (poly-commitment/src/commitment.rs:503-514).
+ */
+#ifndef KIMCHI_HIP_H
+#define KIMCHI_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KH_OK 0
+#define KH_E_INVALID (-1)    /* bad argument (null pointer, size, id) */
+#define KH_E_DEVICE (-2)     /* HIP runtime error / no device */
+#define KH_E_NOTFOUND (-3)   /* basis not registered on this SRS */
+#define KH_E_NOMEM (-4)
+
+#define KH_CURVE_VESTA 0
+#define KH_CURVE_PALLAS 1
+#define KH_FIELD_FP 0
+#define KH_FIELD_FQ 1
+#define KH_BASIS_G (-1)      /* the monomial basis g of the SRS */
+
+typedef struct kh_srs kh_srs_t;
+
+/* ---- device ------------------------------------------------------------- */
+int kh_device_count(void);
+/* Selects the HIP device used by this process (one process per GPU) and creates
+ * the library's streams.  Idempotent; kh_init(-1) picks LOCAL_RANK or device 0. */
+int kh_init(int device_id);
+const char *kh_last_error(void);
+
+/* ---- SRS: device-resident bases ------------------------------------------
+ * Replaces the `g: Vec<G>` half of `ipa::SRS<G>` (poly-commitment/src/ipa.rs:53-75):
+ * uploads the n monomial-basis points once; Rust keeps owning its own copy. */
+int kh_srs_create(int curve, const uint64_t *g_xy /* n x 8 limbs */, size_t n, kh_srs_t **out);
+void kh_srs_free(kh_srs_t *srs);
+size_t kh_srs_size(const kh_srs_t *srs);
+
+/* Registers chunk `chunk` of the Lagrange basis for the domain of size 2^log2_domain
+ * (`SRS::get_lagrange_basis`, ipa.rs:780-801; entries computed by ipa.rs:1065-1172):
+ * n = 2^log2_domain points, `inf` nullable per-point infinity flags. */
+int kh_srs_set_lagrange(kh_srs_t *srs, unsigned log2_domain, unsigned chunk,
+                        const uint64_t *xy, const uint8_t *inf, size_t n);
+/* Computes the same basis on the device from g (group iNTT + batch normalisation,
+ * ipa.rs:1065-1172) and registers every chunk.  Optional read-back via
+ * kh_srs_get_lagrange (out_xy: n x 8 limbs, out_inf: n bytes). */
+int kh_srs_compute_lagrange(kh_srs_t *srs, unsigned log2_domain);
+int kh_srs_get_lagrange(kh_srs_t *srs, unsigned log2_domain, unsigned chunk,
+                        uint64_t *out_xy, uint8_t *out_inf);
+int kh_srs_lagrange_chunks(const kh_srs_t *srs, unsigned log2_domain);   /* 0 if not registered */
+
+/* ---- MSM ------------------------------------------------------------------
+ * Replaces ark_ec::VariableBaseMSM::{msm, msm_bigint} at the call sites
+ * poly-commitment/src/ipa.rs:649,658-659,672 (commit_non_hiding) and
+ * commitment.rs:382 (PolyComm::multi_scalar_mul, reached from
+ * commit_evaluations_non_hiding ipa.rs:706-728).
+ *
+ * basis = KH_BASIS_G: out = sum_{i<n} scalars[i] * g[offset + i]
+ * basis = log2_domain: out = sum_{i<n} scalars[i] * L_{offset+i}[chunk]
+ * scalars: n x 4 limbs; scalars_are_montgomery selects Fp-in-memory (1) vs
+ * into_bigint() canonical form (0, what msm_bigint receives).  Like msm_bigint,
+ * uses min(n, basis_len - offset) pairs.  Result affine + infinity flag. */
+int kh_msm(kh_srs_t *srs, int basis, unsigned chunk, size_t offset,
+           const uint64_t *scalars, size_t n, int scalars_are_montgomery,
+           uint64_t out_xy[8], uint8_t *out_is_inf);
+
+/* k MSMs over the same basis window [offset, offset+n), scalars = k x n x 4 limbs
+ * (the 15 witness-column commits of prover.rs:329-351, the 7 chunk commits of
+ * ipa.rs:663-676 with per-chunk offsets handled by the host mirror). */
+int kh_msm_batch(kh_srs_t *srs, int basis, unsigned chunk, size_t offset,
+                 const uint64_t *scalars, size_t n, size_t k, int scalars_are_montgomery,
+                 uint64_t *out_xy /* k x 8 */, uint8_t *out_is_inf /* k */);
+
+/* Ad-hoc bases (IPA rounds ipa.rs:943-961, batch verifier ipa.rs:474-499). */
+int kh_msm_points(int curve, const uint64_t *xy /* n x 8 */, const uint8_t *inf /* nullable */,
+                  const uint64_t *scalars, size_t n, int scalars_are_montgomery,
+                  uint64_t out_xy[8], uint8_t *out_is_inf);
+
+/* ---- NTT -------------------------------------------------------------------
+ * Replaces Radix2EvaluationDomain::{fft_in_place, ifft_in_place} behind
+ * Evaluations::interpolate[_by_ref] (kimchi/src/prover.rs:289,377,433,567,614,665,
+ * 907,1163; circuits/polynomials/permutation.rs:571; poly-commitment/src/utils.rs:195-196).
+ * data: batch x 2^log2_n x 4 limbs, Montgomery, natural order in and out, in place;
+ * inverse != 0 includes the 1/N scaling (ark-poly ifft). */
+int kh_ntt(int field, uint64_t *data, unsigned log2_n, int inverse, size_t batch);
+
+/* DensePolynomial::evaluate_over_domain_by_ref(d8/d4) (kimchi/src/circuits/
+ * constraints.rs:490-495; prover.rs:436,617,668): n = 2^log2_n coefficients,
+ * zero-extended to n << log2_blowup and forward-transformed.
+ * coeffs: batch x n x 4 limbs; out: batch x (n << log2_blowup) x 4 limbs. */
+int kh_lde(int field, const uint64_t *coeffs, unsigned log2_n, unsigned log2_blowup,
+           uint64_t *out, size_t batch);
+
+/* ---- device-resident variants (no PCIe in the loop) -----------------------
+ * Same operations on buffers that already live in HBM (hipMalloc'd by the caller or by
+ * kh_dev_alloc).  These are what the benchmark times ("inputs already resident in HBM")
+ * and what a prover that keeps witness columns on the device would call. */
+int kh_dev_alloc(void **ptr, size_t bytes);
+int kh_dev_free(void *ptr);
+int kh_dev_upload(void *dst_dev, const void *src_host, size_t bytes);
+int kh_dev_download(void *dst_host, const void *src_dev, size_t bytes);
+int kh_msm_batch_dev(kh_srs_t *srs, int basis, unsigned chunk, size_t offset,
+                     const uint64_t *scalars_dev, size_t n, size_t k, int scalars_are_montgomery,
+                     uint64_t *out_xy /* host, k x 8 */, uint8_t *out_is_inf /* host, k */);
+int kh_ntt_dev(int field, uint64_t *data_dev, unsigned log2_n, int inverse, size_t batch);
+int kh_lde_dev(int field, const uint64_t *coeffs_dev, unsigned log2_n, unsigned log2_blowup,
+               uint64_t *out_dev, size_t batch);
+int kh_sync(void);
+
+/* ---- instrumentation -------------------------------------------------------
+ * Device time (ms, HIP events on the library's own stream) of the last kh_msm*_dev /
+ * kh_ntt*_dev / kh_lde*_dev call on this thread, split per phase.  names/ms arrays of
+ * capacity cap; returns the number of phases written. */
+int kh_last_timings(const char **names, float *ms, int cap);
+
+/* Test hooks (field ops on the device; op: 0 mul, 1 add, 2 sub, 3 to_mont, 4 from_mont,
+ * 5 sqr, 6 neg).  Used by the parity tests to pin the device arithmetic itself. */
+int kh_debug_field_op(int field, int op, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t n);
+/* Point ops on the device through the XYZZ formulas: op 0 = P + Q (affine in, affine out),
+ * op 1 = 2P, op 2 = P + Q via the mixed addition. inf flags in/out. */
+int kh_debug_point_op(int curve, int op, const uint64_t *p_xy, const uint8_t *p_inf,
+                      const uint64_t *q_xy, const uint8_t *q_inf,
+                      uint64_t *out_xy, uint8_t *out_inf, size_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KIMCHI_HIP_H */

@@ -1,0 +1,360 @@
+// api.hip -- the extern "C" boundary declared in include/kimchi_hip.h.
+#include <stdlib.h>
+#include <map>
+#include <memory>
+
+#include "common.hpp"
+#include "host_ec.hpp"
+#include "msm.hpp"
+
+namespace kh {
+
+static thread_local std::string g_err;
+void set_error(const char* fmt, ...) {
+    char buf[1024];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof(buf), fmt, ap); va_end(ap);
+    g_err = buf;
+}
+
+Context& ctx() { static Context c; return c; }
+
+static int do_init(int device_id) {
+    Context& C = ctx();
+    std::lock_guard<std::mutex> lk(C.mu);
+    if (C.ready) return KH_OK;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        set_error("no HIP device available (%s); libkimchi_hip has no CPU fallback", e == hipSuccess ? "count=0" : hipGetErrorString(e));
+        return KH_E_DEVICE;
+    }
+    if (device_id < 0) {
+        const char* lr = getenv("LOCAL_RANK");
+        device_id = lr ? atoi(lr) % count : 0;
+    }
+    KH_REQUIRE(device_id < count, "device %d out of range (count=%d)", device_id, count);
+    KH_HIP(hipSetDevice(device_id));
+    KH_HIP(hipStreamCreateWithFlags(&C.stream, hipStreamNonBlocking));
+    hipDeviceProp_t prop;
+    KH_HIP(hipGetDeviceProperties(&prop, device_id));
+    C.num_cus = prop.multiProcessorCount;
+    int rc = C.timer.init(); if (rc) return rc;
+    C.device = device_id;
+    C.ready = true;
+    return KH_OK;
+}
+int ensure_init() { return ctx().ready ? KH_OK : do_init(-1); }
+
+void collect_timings(Context& C) {
+    C.last.clear();
+    if (!C.timer.created || !C.timer.enabled) return;
+    for (int i = 0; i < C.timer.n; i++) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, C.timer.ev[i], C.timer.ev[i + 1]) == hipSuccess) C.last.emplace_back(C.timer.names[i], ms);
+    }
+}
+
+struct LagrangeChunk { DevBuf pts; DevBuf inf; bool has_inf = false; size_t n = 0; };
+}  // namespace kh
+
+using namespace kh;
+
+struct kh_srs {
+    int curve = 0;
+    size_t n = 0;
+    DevBuf g;
+    std::map<unsigned, std::vector<std::unique_ptr<LagrangeChunk>>> lagrange;
+    std::mutex mu;
+};
+
+static int resolve_basis(kh_srs_t* srs, int basis, unsigned chunk, MsmBasis& out) {
+    KH_REQUIRE(srs != nullptr, "null SRS handle");
+    if (basis == KH_BASIS_G) {
+        KH_REQUIRE(chunk == 0, "chunk must be 0 for the monomial basis");
+        out.pts = srs->g.p; out.inf = nullptr; out.n = srs->n; out.precomp_c = 0;
+        return KH_OK;
+    }
+    auto it = srs->lagrange.find((unsigned)basis);
+    if (it == srs->lagrange.end() || chunk >= it->second.size() || !it->second[chunk]) {
+        set_error("Lagrange basis for domain 2^%d chunk %u is not registered on this SRS", basis, chunk);
+        return KH_E_NOTFOUND;
+    }
+    LagrangeChunk& L = *it->second[chunk];
+    out.pts = L.pts.p; out.inf = L.has_inf ? L.inf.as<uint8_t>() : nullptr; out.n = L.n; out.precomp_c = 0;
+    return KH_OK;
+}
+
+extern "C" {
+
+int kh_device_count(void) {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess) return 0;
+    return count;
+}
+int kh_init(int device_id) { return do_init(device_id); }
+const char* kh_last_error(void) { return g_err.c_str(); }
+
+int kh_srs_create(int curve, const uint64_t* g_xy, size_t n, kh_srs_t** out) {
+    KH_REQUIRE(out && g_xy && n > 0, "kh_srs_create: null argument or n == 0");
+    KH_REQUIRE(curve == KH_CURVE_VESTA || curve == KH_CURVE_PALLAS, "unknown curve id %d", curve);
+    int rc = ensure_init(); if (rc) return rc;
+    std::unique_ptr<kh_srs> s(new kh_srs);
+    s->curve = curve; s->n = n;
+    Context& C = ctx();
+    std::lock_guard<std::mutex> lk(C.mu);
+    if ((rc = s->g.reserve(n * 64))) return rc;
+    KH_HIP(hipMemcpy(s->g.p, g_xy, n * 64, hipMemcpyHostToDevice));
+    *out = s.release();
+    return KH_OK;
+}
+void kh_srs_free(kh_srs_t* srs) {
+    if (!srs) return;
+    Context& C = ctx();
+    std::lock_guard<std::mutex> lk(C.mu);
+    if (srs->g.p) (void)hipFree(srs->g.p);
+    for (auto& kv : srs->lagrange)
+        for (auto& ch : kv.second)
+            if (ch) { if (ch->pts.p) (void)hipFree(ch->pts.p); if (ch->inf.p) (void)hipFree(ch->inf.p); }
+    delete srs;
+}
+size_t kh_srs_size(const kh_srs_t* srs) { return srs ? srs->n : 0; }
+
+int kh_srs_set_lagrange(kh_srs_t* srs, unsigned log2_domain, unsigned chunk, const uint64_t* xy, const uint8_t* inf, size_t n) {
+    KH_REQUIRE(srs && xy, "kh_srs_set_lagrange: null argument");
+    KH_REQUIRE(log2_domain <= 32 && n == ((size_t)1 << log2_domain), "basis must have 2^log2_domain = %zu points, got %zu", (size_t)1 << log2_domain, n);
+    int rc = ensure_init(); if (rc) return rc;
+    Context& C = ctx();
+    std::lock_guard<std::mutex> lk(C.mu);
+    auto& vec = srs->lagrange[log2_domain];
+    if (vec.size() <= chunk) vec.resize(chunk + 1);
+    std::unique_ptr<LagrangeChunk> L(new LagrangeChunk);
+    L->n = n;
+    if ((rc = L->pts.reserve(n * 64))) return rc;
+    KH_HIP(hipMemcpy(L->pts.p, xy, n * 64, hipMemcpyHostToDevice));
+    if (inf) {
+        bool any = false;
+        for (size_t i = 0; i < n; i++) any |= inf[i] != 0;
+        if (any) {
+            if ((rc = L->inf.reserve(n))) return rc;
+            KH_HIP(hipMemcpy(L->inf.p, inf, n, hipMemcpyHostToDevice));
+            L->has_inf = true;
+        }
+    }
+    vec[chunk] = std::move(L);
+    return KH_OK;
+}
+int kh_srs_lagrange_chunks(const kh_srs_t* srs, unsigned log2_domain) {
+    if (!srs) return 0;
+    auto it = srs->lagrange.find(log2_domain);
+    return it == srs->lagrange.end() ? 0 : (int)it->second.size();
+}
+int kh_srs_compute_lagrange(kh_srs_t* srs, unsigned log2_domain) {
+    (void)srs; (void)log2_domain;
+    set_error("kh_srs_compute_lagrange: device group-iNTT not built yet; register the basis with kh_srs_set_lagrange");
+    return KH_E_INVALID;
+}
+int kh_srs_get_lagrange(kh_srs_t* srs, unsigned log2_domain, unsigned chunk, uint64_t* out_xy, uint8_t* out_inf) {
+    KH_REQUIRE(srs && out_xy, "kh_srs_get_lagrange: null argument");
+    MsmBasis b; int rc = resolve_basis(srs, (int)log2_domain, chunk, b); if (rc) return rc;
+    Context& C = ctx();
+    std::lock_guard<std::mutex> lk(C.mu);
+    KH_HIP(hipMemcpy(out_xy, b.pts, b.n * 64, hipMemcpyDeviceToHost));
+    if (out_inf) {
+        if (b.inf) KH_HIP(hipMemcpy(out_inf, b.inf, b.n, hipMemcpyDeviceToHost));
+        else memset(out_inf, 0, b.n);
+    }
+    return KH_OK;
+}
+
+// ---------------------------------------------------------------------------------- MSM
+static int msm_common(kh_srs_t* srs, int basis, unsigned chunk, size_t offset, const uint64_t* scalars, bool scalars_on_device,
+                      size_t n, size_t k, int mont, uint64_t* out_xy, uint8_t* out_inf) {
+    KH_REQUIRE(out_xy && out_inf, "null output pointer");
+    KH_REQUIRE(scalars || n == 0 || k == 0, "null scalars");
+    int rc = ensure_init(); if (rc) return rc;
+    MsmBasis b; rc = resolve_basis(srs, basis, chunk, b); if (rc) return rc;
+    KH_REQUIRE(offset <= b.n, "offset %zu beyond basis length %zu", offset, b.n);
+    size_t use = n < b.n - offset ? n : b.n - offset;      // msm_bigint semantics: min(len) pairs
+    Context& C = ctx();
+    std::lock_guard<std::mutex> lk(C.mu);
+    const uint64_t* sdev = scalars;
+    if (!scalars_on_device && use > 0 && k > 0) {
+        if ((rc = C.ws_scalars.reserve(k * use * 32))) return rc;
+        if (use == n) KH_HIP(hipMemcpyAsync(C.ws_scalars.p, scalars, k * n * 32, hipMemcpyHostToDevice, C.stream));
+        else for (size_t j = 0; j < k; j++)
+            KH_HIP(hipMemcpyAsync((char*)C.ws_scalars.p + j * use * 32, scalars + j * n * 4, use * 32, hipMemcpyHostToDevice, C.stream));
+        sdev = C.ws_scalars.as<uint64_t>();
+    } else if (scalars_on_device) {
+        KH_REQUIRE(use == n || k == 1, "device-resident batched scalars must not exceed the basis window");
+    }
+    return msm_run(C, srs->curve, b, offset, sdev, use, k, mont, out_xy, out_inf);
+}
+
+int kh_msm(kh_srs_t* srs, int basis, unsigned chunk, size_t offset, const uint64_t* scalars, size_t n,
+           int scalars_are_montgomery, uint64_t out_xy[8], uint8_t* out_is_inf) {
+    return msm_common(srs, basis, chunk, offset, scalars, false, n, 1, scalars_are_montgomery, out_xy, out_is_inf);
+}
+int kh_msm_batch(kh_srs_t* srs, int basis, unsigned chunk, size_t offset, const uint64_t* scalars, size_t n, size_t k,
+                 int scalars_are_montgomery, uint64_t* out_xy, uint8_t* out_is_inf) {
+    return msm_common(srs, basis, chunk, offset, scalars, false, n, k, scalars_are_montgomery, out_xy, out_is_inf);
+}
+int kh_msm_batch_dev(kh_srs_t* srs, int basis, unsigned chunk, size_t offset, const uint64_t* scalars_dev, size_t n, size_t k,
+                     int scalars_are_montgomery, uint64_t* out_xy, uint8_t* out_is_inf) {
+    return msm_common(srs, basis, chunk, offset, scalars_dev, true, n, k, scalars_are_montgomery, out_xy, out_is_inf);
+}
+int kh_msm_points(int curve, const uint64_t* xy, const uint8_t* inf, const uint64_t* scalars, size_t n,
+                  int scalars_are_montgomery, uint64_t out_xy[8], uint8_t* out_is_inf) {
+    KH_REQUIRE(out_xy && out_is_inf, "null output pointer");
+    KH_REQUIRE(curve == KH_CURVE_VESTA || curve == KH_CURVE_PALLAS, "unknown curve id %d", curve);
+    KH_REQUIRE((xy && scalars) || n == 0, "null input");
+    int rc = ensure_init(); if (rc) return rc;
+    Context& C = ctx();
+    std::lock_guard<std::mutex> lk(C.mu);
+    if (n == 0) { memset(out_xy, 0, 64); *out_is_inf = 1; return KH_OK; }
+    if ((rc = C.ws_points.reserve(n * 64 + n))) return rc;
+    if ((rc = C.ws_scalars.reserve(n * 32))) return rc;
+    KH_HIP(hipMemcpyAsync(C.ws_points.p, xy, n * 64, hipMemcpyHostToDevice, C.stream));
+    MsmBasis b; b.pts = C.ws_points.p; b.n = n; b.inf = nullptr;
+    if (inf) {
+        KH_HIP(hipMemcpyAsync((char*)C.ws_points.p + n * 64, inf, n, hipMemcpyHostToDevice, C.stream));
+        b.inf = (const uint8_t*)C.ws_points.p + n * 64;
+    }
+    KH_HIP(hipMemcpyAsync(C.ws_scalars.p, scalars, n * 32, hipMemcpyHostToDevice, C.stream));
+    return msm_run(C, curve, b, 0, C.ws_scalars.as<uint64_t>(), n, 1, scalars_are_montgomery, out_xy, out_is_inf);
+}
+
+// ---------------------------------------------------------------------------------- NTT
+int kh_ntt_dev(int field, uint64_t* data_dev, unsigned log2_n, int inverse, size_t batch) {
+    KH_REQUIRE(field == KH_FIELD_FP || field == KH_FIELD_FQ, "unknown field id %d", field);
+    KH_REQUIRE(log2_n <= 28, "log2_n = %u too large", log2_n);
+    KH_REQUIRE(data_dev || batch == 0, "null data");
+    int rc = ensure_init(); if (rc) return rc;
+    if (batch == 0) return KH_OK;
+    Context& C = ctx();
+    std::lock_guard<std::mutex> lk(C.mu);
+    return ntt_run(C, field, data_dev, log2_n, inverse, batch);
+}
+int kh_lde_dev(int field, const uint64_t* coeffs_dev, unsigned log2_n, unsigned log2_blowup, uint64_t* out_dev, size_t batch) {
+    KH_REQUIRE(field == KH_FIELD_FP || field == KH_FIELD_FQ, "unknown field id %d", field);
+    KH_REQUIRE(log2_n + log2_blowup <= 28, "log2 size %u too large", log2_n + log2_blowup);
+    KH_REQUIRE((coeffs_dev && out_dev) || batch == 0, "null data");
+    int rc = ensure_init(); if (rc) return rc;
+    if (batch == 0) return KH_OK;
+    Context& C = ctx();
+    std::lock_guard<std::mutex> lk(C.mu);
+    return lde_run(C, field, coeffs_dev, log2_n, log2_blowup, out_dev, batch);
+}
+int kh_ntt(int field, uint64_t* data, unsigned log2_n, int inverse, size_t batch) {
+    KH_REQUIRE(field == KH_FIELD_FP || field == KH_FIELD_FQ, "unknown field id %d", field);
+    KH_REQUIRE(log2_n <= 28, "log2_n = %u too large", log2_n);
+    KH_REQUIRE(data || batch == 0, "null data");
+    int rc = ensure_init(); if (rc) return rc;
+    if (batch == 0) return KH_OK;
+    Context& C = ctx();
+    std::lock_guard<std::mutex> lk(C.mu);
+    size_t bytes = (batch << log2_n) * 32;
+    if ((rc = C.ws_ntt_a.reserve(bytes))) return rc;
+    KH_HIP(hipMemcpyAsync(C.ws_ntt_a.p, data, bytes, hipMemcpyHostToDevice, C.stream));
+    if ((rc = ntt_run(C, field, C.ws_ntt_a.as<uint64_t>(), log2_n, inverse, batch))) return rc;
+    KH_HIP(hipMemcpyAsync(data, C.ws_ntt_a.p, bytes, hipMemcpyDeviceToHost, C.stream));
+    KH_HIP(hipStreamSynchronize(C.stream));
+    collect_timings(C);
+    return KH_OK;
+}
+int kh_lde(int field, const uint64_t* coeffs, unsigned log2_n, unsigned log2_blowup, uint64_t* out, size_t batch) {
+    KH_REQUIRE(field == KH_FIELD_FP || field == KH_FIELD_FQ, "unknown field id %d", field);
+    KH_REQUIRE(log2_n + log2_blowup <= 28, "log2 size %u too large", log2_n + log2_blowup);
+    KH_REQUIRE((coeffs && out) || batch == 0, "null data");
+    int rc = ensure_init(); if (rc) return rc;
+    if (batch == 0) return KH_OK;
+    Context& C = ctx();
+    std::lock_guard<std::mutex> lk(C.mu);
+    size_t in_bytes = (batch << log2_n) * 32, out_bytes = in_bytes << log2_blowup;
+    if ((rc = C.ws_ntt_a.reserve(in_bytes))) return rc;
+    if ((rc = C.ws_ntt_b.reserve(out_bytes))) return rc;
+    KH_HIP(hipMemcpyAsync(C.ws_ntt_a.p, coeffs, in_bytes, hipMemcpyHostToDevice, C.stream));
+    if ((rc = lde_run(C, field, C.ws_ntt_a.as<uint64_t>(), log2_n, log2_blowup, C.ws_ntt_b.as<uint64_t>(), batch))) return rc;
+    KH_HIP(hipMemcpyAsync(out, C.ws_ntt_b.p, out_bytes, hipMemcpyDeviceToHost, C.stream));
+    KH_HIP(hipStreamSynchronize(C.stream));
+    collect_timings(C);
+    return KH_OK;
+}
+
+// ---------------------------------------------------------------------------------- device memory helpers
+int kh_dev_alloc(void** ptr, size_t bytes) {
+    KH_REQUIRE(ptr, "null ptr");
+    int rc = ensure_init(); if (rc) return rc;
+    KH_HIP(hipMalloc(ptr, bytes ? bytes : 1));
+    return KH_OK;
+}
+int kh_dev_free(void* ptr) { if (ptr) KH_HIP(hipFree(ptr)); return KH_OK; }
+int kh_dev_upload(void* dst_dev, const void* src_host, size_t bytes) {
+    int rc = ensure_init(); if (rc) return rc;
+    KH_HIP(hipMemcpy(dst_dev, src_host, bytes, hipMemcpyHostToDevice));
+    return KH_OK;
+}
+int kh_dev_download(void* dst_host, const void* src_dev, size_t bytes) {
+    int rc = ensure_init(); if (rc) return rc;
+    KH_HIP(hipMemcpy(dst_host, src_dev, bytes, hipMemcpyDeviceToHost));
+    return KH_OK;
+}
+int kh_sync(void) {
+    int rc = ensure_init(); if (rc) return rc;
+    Context& C = ctx();
+    std::lock_guard<std::mutex> lk(C.mu);
+    KH_HIP(hipStreamSynchronize(C.stream));
+    collect_timings(C);
+    return KH_OK;
+}
+int kh_last_timings(const char** names, float* ms, int cap) {
+    Context& C = ctx();
+    std::lock_guard<std::mutex> lk(C.mu);
+    int n = 0;
+    for (auto& kv : C.last) { if (n >= cap) break; names[n] = kv.first.c_str(); ms[n] = kv.second; n++; }
+    return n;
+}
+
+// ---------------------------------------------------------------------------------- test hooks
+int kh_debug_field_op(int field, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
+    KH_REQUIRE(a && out, "null argument");
+    int rc = ensure_init(); if (rc) return rc;
+    if (n == 0) return KH_OK;
+    Context& C = ctx();
+    std::lock_guard<std::mutex> lk(C.mu);
+    void *da = nullptr, *db = nullptr, *dout = nullptr;
+    KH_HIP(hipMalloc(&da, n * 32)); KH_HIP(hipMalloc(&dout, n * 32));
+    KH_HIP(hipMemcpy(da, a, n * 32, hipMemcpyHostToDevice));
+    if (b) { KH_HIP(hipMalloc(&db, n * 32)); KH_HIP(hipMemcpy(db, b, n * 32, hipMemcpyHostToDevice)); }
+    rc = debug_field_op(C, field, op, (const uint64_t*)da, (const uint64_t*)db, (uint64_t*)dout, n);
+    if (rc == KH_OK) { KH_HIP(hipStreamSynchronize(C.stream)); KH_HIP(hipMemcpy(out, dout, n * 32, hipMemcpyDeviceToHost)); }
+    (void)hipFree(da); (void)hipFree(dout); if (db) (void)hipFree(db);
+    return rc;
+}
+int kh_debug_point_op(int curve, int op, const uint64_t* p_xy, const uint8_t* p_inf, const uint64_t* q_xy, const uint8_t* q_inf,
+                      uint64_t* out_xy, uint8_t* out_inf, size_t n) {
+    KH_REQUIRE(p_xy && q_xy && out_xy && out_inf, "null argument");
+    int rc = ensure_init(); if (rc) return rc;
+    if (n == 0) return KH_OK;
+    Context& C = ctx();
+    std::lock_guard<std::mutex> lk(C.mu);
+    void *dp, *dq, *dpi = nullptr, *dqi = nullptr, *dout;
+    KH_HIP(hipMalloc(&dp, n * 64)); KH_HIP(hipMalloc(&dq, n * 64)); KH_HIP(hipMalloc(&dout, n * 128));
+    KH_HIP(hipMemcpy(dp, p_xy, n * 64, hipMemcpyHostToDevice)); KH_HIP(hipMemcpy(dq, q_xy, n * 64, hipMemcpyHostToDevice));
+    if (p_inf) { KH_HIP(hipMalloc(&dpi, n)); KH_HIP(hipMemcpy(dpi, p_inf, n, hipMemcpyHostToDevice)); }
+    if (q_inf) { KH_HIP(hipMalloc(&dqi, n)); KH_HIP(hipMemcpy(dqi, q_inf, n, hipMemcpyHostToDevice)); }
+    rc = debug_point_op(C, curve, op, (const uint64_t*)dp, (const uint8_t*)dpi, (const uint64_t*)dq, (const uint8_t*)dqi, (uint8_t*)dout, n);
+    if (rc == KH_OK) {
+        std::vector<khost::xyzz> res(n);
+        KH_HIP(hipStreamSynchronize(C.stream));
+        KH_HIP(hipMemcpy(res.data(), dout, n * 128, hipMemcpyDeviceToHost));
+        khost::Crv crv(curve);
+        for (size_t i = 0; i < n; i++) {
+            khost::aff a; bool inf = crv.to_affine(res[i], a);
+            memcpy(out_xy + 8 * i, &a, 64); out_inf[i] = inf ? 1 : 0;
+        }
+    }
+    (void)hipFree(dp); (void)hipFree(dq); (void)hipFree(dout); if (dpi) (void)hipFree(dpi); if (dqi) (void)hipFree(dqi);
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,97 @@
+// common.hpp -- context, error reporting and workspace management shared by the
+// translation units of libkimchi_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/kimchi_hip.h"
+
+namespace kh {
+
+void set_error(const char* fmt, ...);
+
+#define KH_HIP(expr)                                                                         \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            kh::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return KH_E_DEVICE;                                                              \
+        }                                                                                    \
+    } while (0)
+
+#define KH_REQUIRE(cond, ...)                 \
+    do {                                      \
+        if (!(cond)) {                        \
+            kh::set_error(__VA_ARGS__);       \
+            return KH_E_INVALID;              \
+        }                                     \
+    } while (0)
+
+// A grow-only device buffer (workspace).  Not thread-safe by itself: the owner
+// (Context) serialises users with its mutex.
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes) {
+        if (bytes <= cap) return KH_OK;
+        if (p) { hipError_t e = hipFree(p); (void)e; p = nullptr; cap = 0; }
+        size_t want = bytes + bytes / 8;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) { set_error("hipMalloc(%zu) failed: %s", want, hipGetErrorString(e)); p = nullptr; return KH_E_NOMEM; }
+        cap = want;
+        return KH_OK;
+    }
+    template <class T> T* as() const { return (T*)p; }
+};
+
+struct PhaseTimer {
+    static constexpr int MAXP = 24;
+    hipEvent_t ev[MAXP + 1];
+    const char* names[MAXP];
+    int n = 0;
+    bool created = false;
+    bool enabled = true;
+    int init() {
+        if (created) return KH_OK;
+        for (int i = 0; i <= MAXP; i++) KH_HIP(hipEventCreate(&ev[i]));
+        created = true;
+        return KH_OK;
+    }
+    void begin(hipStream_t s) { n = 0; if (enabled && created) (void)hipEventRecord(ev[0], s); }
+    void mark(const char* name, hipStream_t s) {
+        if (!enabled || !created || n >= MAXP) return;
+        names[n] = name; n++;
+        (void)hipEventRecord(ev[n], s);
+    }
+};
+
+struct Context {
+    std::mutex mu;            // serialises device work issued through the C ABI
+    int device = -1;
+    bool ready = false;
+    hipStream_t stream = nullptr;
+    int num_cus = 256;
+    PhaseTimer timer;
+    // last timings (filled after a sync)
+    std::vector<std::pair<std::string, float>> last;
+    // MSM workspace
+    DevBuf ws_scalars, ws_digits, ws_hist, ws_cnt, ws_off, ws_ntask, ws_toff, ws_entries, ws_partial,
+        ws_buckets, ws_seg, ws_out, ws_scan_tmp, ws_biglist, ws_misc, ws_points;
+    // NTT workspace
+    DevBuf ws_ntt_a, ws_ntt_b;
+    void* pinned = nullptr; size_t pinned_cap = 0;
+};
+
+Context& ctx();
+int ensure_init();
+void collect_timings(Context& c);
+
+// device exclusive scan of n u32 values (in may alias out); tmp is workspace
+int exclusive_scan_u32(const uint32_t* in, uint32_t* out, size_t n, DevBuf& tmp, hipStream_t s);
+
+}  // namespace kh

@@ -1,0 +1,24 @@
+// msm.hpp -- internal interface between api.hip and msm.hip
+#pragma once
+#include "common.hpp"
+
+namespace kh {
+
+struct MsmBasis {
+    const void* pts = nullptr;       // device, n x 64 B affine x||y (Montgomery); with precomp: W tables of n points
+    const uint8_t* inf = nullptr;    // device, nullable per-point infinity flags
+    size_t n = 0;                    // points per table
+    int precomp_c = 0;               // 0: plain basis; else window width of the precomputed tables
+};
+
+int msm_pick_window(size_t n);
+int msm_run(Context& C, int curve, const MsmBasis& basis, size_t offset, const uint64_t* scalars_dev, size_t n, size_t k,
+            int mont, uint64_t* out_xy, uint8_t* out_inf);
+int debug_field_op(Context& C, int field, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
+int debug_point_op(Context& C, int curve, int op, const uint64_t* p, const uint8_t* pinf, const uint64_t* q, const uint8_t* qinf, uint8_t* out, size_t n);
+
+// ntt.hip
+int ntt_run(Context& C, int field, uint64_t* data_dev, unsigned log2_n, int inverse, size_t batch);
+int lde_run(Context& C, int field, const uint64_t* coeffs_dev, unsigned log2_n, unsigned log2_blowup, uint64_t* out_dev, size_t batch);
+
+}  // namespace kh

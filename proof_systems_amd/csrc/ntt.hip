@@ -1,0 +1,333 @@
+// ntt.hip -- radix-2 NTT / iNTT / low-degree extension over the Pasta fields on gfx950.
+//
+// Replaces ark-poly's Radix2EvaluationDomain::{fft_in_place, ifft_in_place} reached from
+// Evaluations::interpolate (kimchi/src/prover.rs:289,377,907,1163, permutation.rs:571,
+// poly-commitment/src/utils.rs:195-196) and DensePolynomial::evaluate_over_domain_by_ref(d8)
+// (kimchi/src/circuits/constraints.rs:490-495).  Semantics: natural order in and
+// out, omega_N = (5^T)^(2^(32-k)), forward out[j] = sum_i a_i w^(ij), inverse includes 1/N.
+// A DFT is a unique result, so only outputs are compared with the reference; the schedule
+// is a multi-pass decimation-in-frequency decomposition built for the MI355X:
+//
+//   N = R_1 * R_2 * ... * R_P  (each R <= 256).  Pass p runs R_p-point sub-transforms on
+//   tiles of T columns staged in LDS (R*T = 2048 elements = 64 KiB, limb-plane SoA so every
+//   LDS access is a conflict-free ds_read/write_b64), radix-2 butterflies with stage twiddles
+//   read from LDS, then multiplies by the inter-pass twiddle w_L^(b*k) on the way out.
+//   Global accesses are T*32-byte contiguous runs.  Positions after the passes are
+//   digit-reversed; the LAST pass undoes that while writing (its tiles take T rows with
+//   consecutive top digit so the natural-order stores are T*32-byte runs too).
+//   The low-degree extension n -> n*2^b is the same machinery with a virtual first digit
+//   (the coset index r): the first pass reads the n coefficients and multiplies by
+//   w_(n 2^b)^(i*r) while loading, so the zero-padded 7/8 of the input never exists in HBM.
+#include <map>
+#include <tuple>
+
+#include "common.hpp"
+#include "field.cuh"
+#include "host_ec.hpp"
+#include "msm.hpp"
+
+namespace kh {
+
+static constexpr int NTT_THREADS = 256;
+static constexpr int NTT_LOG_TILE = 11;                 // R*T = 2048 elements per workgroup
+static constexpr int NTT_MAX_LOGR = 8;
+
+struct PassArgs {
+    const u64* src; u64* dst; const u64* tw;
+    u32 log_ntot, log_n, log_blow, log_L, log_R, log_T;
+    u32 first, last, src_is_coeffs, scale;
+    u32 nd; u32 dig[6];          // last pass: log-sizes of the row-index digits, most significant first
+    u32 inv_n[8];                // N^-1 (Montgomery), used when scale != 0
+    u64 batch;
+};
+
+template <class F>
+__device__ __forceinline__ Fe<F> lds_get(const u64* pl, u32 stride, u32 idx) {
+    Fe<F> r;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { u64 w = pl[k * stride + idx]; r.v[2 * k] = (u32)w; r.v[2 * k + 1] = (u32)(w >> 32); }
+    return r;
+}
+template <class F>
+__device__ __forceinline__ void lds_put(u64* pl, u32 stride, u32 idx, const Fe<F>& a) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) pl[k * stride + idx] = (u64)a.v[2 * k] | ((u64)a.v[2 * k + 1] << 32);
+}
+// w^e from the half table (N/2 entries): w^(e) = -w^(e - N/2) for e >= N/2
+template <class F>
+__device__ __forceinline__ Fe<F> tw_get(const u64* tw, u32 log_ntot, u64 e) {
+    u64 half = (u64)1 << (log_ntot - 1);
+    e &= ((u64)1 << log_ntot) - 1;
+    bool ng = e >= half;
+    if (ng) e -= half;
+    Fe<F> w = Fe<F>::load(tw + 4 * e);
+    return ng ? neg<F>(w) : w;
+}
+__device__ __forceinline__ u32 bitrev(u32 x, u32 bits) { return bits ? (__brev(x) >> (32 - bits)) : 0u; }
+
+template <class F>
+__global__ void __launch_bounds__(NTT_THREADS)
+k_ntt_pass(PassArgs A) {
+    extern __shared__ u64 lds[];
+    const u32 R = 1u << A.log_R, T = 1u << A.log_T, RT = R * T;
+    u64* data = lds;                       // 4 planes x RT
+    u64* twl = lds + 4 * RT;               // 4 planes x (R/2) stage twiddles
+    const u32 tid = threadIdx.x;
+    const u64 ntot = (u64)1 << A.log_ntot, n = (u64)1 << A.log_n;
+    const u32 log_B = A.log_L - A.log_R;
+    const u64 B = (u64)1 << log_B;
+
+    // ---- decode the tile
+    u64 tile = blockIdx.x;
+    u64 batch_idx = 0, k0 = 0, sa = 0, bt = 0, rest = 0, dt = 0, Mrows = 1;
+    bool row_mode = A.last != 0;
+    bool flat_rows = row_mode && A.nd == 0;          // single pass, no virtual digit: tiles run across the batch
+    if (!row_mode) {
+        u64 tiles_per_item = ntot >> (A.log_R + A.log_T);
+        batch_idx = tile / tiles_per_item; u64 r = tile % tiles_per_item;
+        u64 bt_count = B >> A.log_T;
+        bt = r % bt_count; r /= bt_count;
+        u64 subs = n >> A.log_L;
+        sa = r % subs; k0 = r / subs;
+    } else if (!flat_rows) {
+        u64 rows = ntot >> A.log_R;
+        u64 tiles_per_item = rows >> A.log_T;
+        batch_idx = tile / tiles_per_item; u64 r = tile % tiles_per_item;
+        Mrows = rows >> A.dig[0];
+        rest = r % Mrows; dt = r / Mrows;
+    }
+    const u64 total_rows_flat = A.batch;             // flat mode: one row per batch item
+
+    // ---- stage twiddles w_R^i = w_Ntot^(i * Ntot/R), i < R/2
+    for (u32 i = tid; i < R / 2; i += NTT_THREADS) {
+        Fe<F> w = Fe<F>::load(A.tw + 4 * ((u64)i << (A.log_ntot - A.log_R)));
+        lds_put<F>(twl, R / 2, i, w);
+    }
+    // ---- load the tile: LDS index n1*T + t
+    for (u32 idx = tid; idx < RT; idx += NTT_THREADS) {
+        u32 n1 = idx >> A.log_T, t = idx & (T - 1);
+        Fe<F> x;
+        if (!row_mode) {
+            u64 inner = sa * ((u64)1 << A.log_L) + (u64)n1 * B + bt * T + t;     // position inside the inner NTT
+            u64 spos = A.src_is_coeffs ? (batch_idx * n + inner) : (batch_idx * ntot + k0 * n + inner);
+            x = Fe<F>::load(A.src + 4 * spos);
+            if (A.first && A.log_blow && k0) x = mul<F>(x, tw_get<F>(A.tw, A.log_ntot, inner * k0));
+        } else if (flat_rows) {
+            u64 g = tile * T + t;
+            if (g < total_rows_flat) x = Fe<F>::load(A.src + 4 * (g * R + n1)); else x = Fe<F>::zero();
+        } else {
+            u64 a = (dt * T + t) * Mrows + rest;                                   // row index, top digit = dt*T+t
+            u64 kk0 = A.log_blow ? (a >> (A.log_n - A.log_R)) : 0;                 // virtual digit of this row
+            u64 inner = (A.log_blow ? (a & ((n >> A.log_R) - 1)) : a) * R + n1;    // position inside the inner NTT
+            u64 spos = A.src_is_coeffs ? (batch_idx * n + inner) : (batch_idx * ntot + a * R + n1);
+            x = Fe<F>::load(A.src + 4 * spos);
+            if (A.first && A.log_blow && kk0) x = mul<F>(x, tw_get<F>(A.tw, A.log_ntot, inner * kk0));
+        }
+        lds_put<F>(data, RT, idx, x);
+    }
+    __syncthreads();
+    // ---- radix-2 DIF stages inside LDS
+    for (u32 lh = A.log_R; lh-- > 0;) {
+        const u32 h = 1u << lh;
+        for (u32 pi = tid; pi < RT / 2; pi += NTT_THREADS) {
+            u32 t = pi & (T - 1), pr = pi >> A.log_T;          // pair index within the column
+            u32 i = pr & (h - 1), grp = pr >> lh;
+            u32 lo = (grp << (lh + 1)) + i;
+            u32 ia = lo * T + t, ib = (lo + h) * T + t;
+            Fe<F> u = lds_get<F>(data, RT, ia), v = lds_get<F>(data, RT, ib);
+            Fe<F> s = add<F>(u, v), d = sub<F>(u, v);
+            if (i) d = mul<F>(d, lds_get<F>(twl, R / 2, i << (A.log_R - 1 - lh)));
+            lds_put<F>(data, RT, ia, s);
+            lds_put<F>(data, RT, ib, d);
+        }
+        __syncthreads();
+    }
+    // ---- write out (LDS position bitrev(k) holds output k)
+    Fe<F> invn;
+#pragma unroll
+    for (int i = 0; i < 8; i++) invn.v[i] = A.inv_n[i];
+    for (u32 idx = tid; idx < RT; idx += NTT_THREADS) {
+        u32 k1 = idx >> A.log_T, t = idx & (T - 1);
+        Fe<F> x = lds_get<F>(data, RT, bitrev(k1, A.log_R) * T + t);
+        if (!row_mode) {
+            u64 b = bt * T + t;
+            if (k1 && b) x = mul<F>(x, tw_get<F>(A.tw, A.log_ntot, ((u64)k1 * b) << (A.log_ntot - A.log_L)));
+            u64 dpos = batch_idx * ntot + k0 * n + sa * ((u64)1 << A.log_L) + (u64)k1 * B + b;
+            x.store(A.dst + 4 * dpos);
+        } else {
+            if (A.scale) x = mul<F>(x, invn);
+            if (flat_rows) {
+                u64 g = tile * T + t;
+                if (g < total_rows_flat) x.store(A.dst + 4 * (g * R + k1));
+            } else {
+                u64 a = (dt * T + t) * Mrows + rest;
+                // digit-reverse the row index (digits most-significant first in A.dig)
+                u64 rev = 0, wgt = 1, rem = a;
+                u32 shift = A.log_ntot - A.log_R;
+                for (u32 d = 0; d < A.nd; d++) {
+                    shift -= A.dig[d];
+                    u64 digit = (rem >> shift) & (((u64)1 << A.dig[d]) - 1);
+                    rev += digit * wgt; wgt <<= A.dig[d];
+                }
+                u64 nat = rev + ((u64)k1 << (A.log_ntot - A.log_R));
+                x.store(A.dst + 4 * (batch_idx * ntot + nat));
+            }
+        }
+    }
+}
+
+// ---- twiddle table w^e, e < N/2, built on the device from the 2^i-th powers
+template <class F>
+__global__ void k_build_twiddles(u64* tw, const u64* pow2 /* w^(2^i), i < 32 */, u64 count) {
+    u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= count) return;
+    Fe<F> acc = Fe<F>::one();
+    for (int i = 0; i < 32 && (e >> i); i++)
+        if ((e >> i) & 1) acc = mul<F>(acc, Fe<F>::load(pow2 + 4 * i));
+    acc.store(tw + 4 * e);
+}
+
+struct TwKey { int field; unsigned logn; int inverse; bool operator<(const TwKey& o) const { return std::tie(field, logn, inverse) < std::tie(o.field, o.logn, o.inverse); } };
+struct TwEntry { DevBuf tab; khost::fe inv_n; };
+static std::map<TwKey, TwEntry> g_tw;
+
+static khost::fe host_root(int field, unsigned logn, int inverse) {
+    // w_{2^k} = (5^T)^(2^(32-k)); T = (p-1) >> 32   (kimchi/src/circuits/domains.rs:40-69)
+    khost::Fld F(field);
+    khost::fe five = {{5, 0, 0, 0}}; five = F.to_mont(five);
+    khost::fe pm1 = F.f.p; pm1.l[0] -= 1;
+    khost::fe Texp;
+    for (int i = 0; i < 4; i++) Texp.l[i] = (pm1.l[i] >> 32) | (i < 3 ? pm1.l[i + 1] << 32 : 0);
+    khost::fe acc = F.f.one, base = five;
+    for (int i = 0; i < 256; i++) { if ((Texp.l[i >> 6] >> (i & 63)) & 1) acc = F.mul(acc, base); base = F.sqr(base); }
+    for (unsigned i = logn; i < 32; i++) acc = F.sqr(acc);
+    if (inverse) acc = F.inv(acc);
+    return acc;
+}
+
+static int get_twiddles(Context& C, int field, unsigned logn, int inverse, TwEntry** out) {
+    TwKey key{field, logn, inverse};
+    auto it = g_tw.find(key);
+    if (it != g_tw.end()) { *out = &it->second; return KH_OK; }
+    TwEntry& E = g_tw[key];
+    khost::Fld F(field);
+    khost::fe w = host_root(field, logn, inverse);
+    khost::fe pow2[32];
+    pow2[0] = w;
+    for (int i = 1; i < 32; i++) pow2[i] = F.sqr(pow2[i - 1]);
+    u64 count = logn ? ((u64)1 << (logn - 1)) : 1;
+    int rc = E.tab.reserve(count * 32 + 32 * 32); if (rc) { g_tw.erase(key); return rc; }
+    u64* dpow = E.tab.as<u64>() + count * 4;
+    KH_HIP(hipMemcpyAsync(dpow, pow2, sizeof(pow2), hipMemcpyHostToDevice, C.stream));
+    KH_HIP(hipStreamSynchronize(C.stream));       // pow2 is a stack buffer
+    dim3 grid((unsigned)((count + 255) / 256));
+    if (field == KH_FIELD_FP) hipLaunchKernelGGL((k_build_twiddles<FpParams>), grid, dim3(256), 0, C.stream, E.tab.as<u64>(), dpow, count);
+    else hipLaunchKernelGGL((k_build_twiddles<FqParams>), grid, dim3(256), 0, C.stream, E.tab.as<u64>(), dpow, count);
+    KH_HIP(hipGetLastError());
+    khost::fe nn = {{(u64)1 << logn, 0, 0, 0}};
+    E.inv_n = F.inv(F.to_mont(nn));
+    *out = &E;
+    return KH_OK;
+}
+
+// split log_n into passes of at most NTT_MAX_LOGR bits, most significant (first pass) first
+static std::vector<unsigned> split_passes(unsigned log_n) {
+    std::vector<unsigned> r;
+    if (log_n == 0) return r;
+    unsigned P = (log_n + NTT_MAX_LOGR - 1) / NTT_MAX_LOGR;
+    unsigned base = log_n / P, extra = log_n % P;
+    for (unsigned i = 0; i < P; i++) r.push_back(base + (i < extra ? 1 : 0));
+    return r;
+}
+
+template <class F>
+static int launch_pass(Context& C, const PassArgs& A, u64 tiles) {
+    size_t lds = ((size_t)4 << (A.log_R + A.log_T)) * 8 + ((size_t)4 << (A.log_R ? A.log_R - 1 : 0)) * 8;
+    static bool attr = false;
+    if (!attr) { KH_HIP(hipFuncSetAttribute((const void*)k_ntt_pass<F>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304)); attr = true; }
+    hipLaunchKernelGGL((k_ntt_pass<F>), dim3((unsigned)tiles), dim3(NTT_THREADS), lds, C.stream, A);
+    KH_HIP(hipGetLastError());
+    return KH_OK;
+}
+
+// Generic driver: `src` holds batch x n coefficients/evaluations; the result (batch x n*2^log_blow,
+// natural order) is written to `dst`; `tmp` (same size as dst) is scratch.  src may equal dst
+// when log_blow == 0.
+template <class F>
+static int transform(Context& C, int field, const u64* src, u64* dst, u64* tmp, unsigned log_n, unsigned log_blow,
+                     int inverse, size_t batch) {
+    const unsigned log_ntot = log_n + log_blow;
+    TwEntry* E; int rc = get_twiddles(C, field, log_ntot, inverse, &E); if (rc) return rc;
+    std::vector<unsigned> passes = split_passes(log_n);
+    const size_t P = passes.size();
+    PassArgs A; memset(&A, 0, sizeof(A));
+    A.tw = E->tab.as<u64>(); A.log_ntot = log_ntot; A.log_n = log_n; A.log_blow = log_blow; A.batch = batch;
+    memcpy(A.inv_n, &E->inv_n, 32);
+    if (P == 0) {
+        // n == 1: each output of the extension equals the single coefficient; plain NTT of size 1 is the identity
+        if (log_blow == 0) { if (src != dst) KH_HIP(hipMemcpyAsync(dst, src, batch * 32, hipMemcpyDeviceToDevice, C.stream)); return KH_OK; }
+        set_error("kh_lde with n == 1 is not supported"); return KH_E_INVALID;
+    }
+    // buffer plan: pass 1 reads src; middle passes run in place on tmp; the last pass writes dst.
+    unsigned log_L = log_n;
+    for (size_t p = 0; p < P; p++) {
+        const bool first = p == 0, last = p + 1 == P;
+        A.log_R = passes[p]; A.log_L = log_L;
+        A.first = first; A.last = last;
+        A.src_is_coeffs = (first && log_blow) ? 1 : 0;
+        A.scale = (last && inverse) ? 1 : 0;
+        A.src = first ? src : tmp;
+        A.dst = last ? dst : tmp;
+        unsigned log_T = NTT_LOG_TILE - A.log_R;
+        u64 tiles;
+        if (!last) {
+            unsigned log_B = log_L - A.log_R;
+            if (log_T > log_B) log_T = log_B;
+            A.log_T = log_T;
+            tiles = (u64)batch << (log_ntot - A.log_R - log_T);
+        } else {
+            A.nd = 0;
+            if (log_blow) A.dig[A.nd++] = log_blow;
+            for (size_t q = 0; q + 1 < P; q++) A.dig[A.nd++] = passes[q];
+            if (A.nd == 0) {          // single pass, tiles run across the batch
+                u64 lt = 0; while (((u64)1 << (lt + 1)) <= batch && lt + 1 <= log_T) lt++;
+                A.log_T = (u32)lt;
+                tiles = (batch + ((u64)1 << lt) - 1) >> lt;
+            } else {
+                if (log_T > A.dig[0]) log_T = A.dig[0];
+                A.log_T = log_T;
+                tiles = (u64)batch << (log_ntot - A.log_R - log_T);
+            }
+        }
+        if ((rc = launch_pass<F>(C, A, tiles))) return rc;
+        log_L -= A.log_R;
+    }
+    return KH_OK;
+}
+
+int ntt_run(Context& C, int field, uint64_t* data_dev, unsigned log2_n, int inverse, size_t batch) {
+    size_t bytes = (batch << log2_n) * 32;
+    int rc = C.ws_ntt_b.reserve(bytes); if (rc) return rc;
+    C.timer.begin(C.stream);
+    if (field == KH_FIELD_FP) rc = transform<FpParams>(C, field, data_dev, data_dev, C.ws_ntt_b.as<u64>(), log2_n, 0, inverse, batch);
+    else rc = transform<FqParams>(C, field, data_dev, data_dev, C.ws_ntt_b.as<u64>(), log2_n, 0, inverse, batch);
+    C.timer.mark(inverse ? "intt" : "ntt", C.stream);
+    return rc;
+}
+int lde_run(Context& C, int field, const uint64_t* coeffs_dev, unsigned log2_n, unsigned log2_blowup, uint64_t* out_dev, size_t batch) {
+    if (log2_blowup == 0) {
+        size_t bytes = (batch << log2_n) * 32;
+        if (coeffs_dev != out_dev) KH_HIP(hipMemcpyAsync(out_dev, coeffs_dev, bytes, hipMemcpyDeviceToDevice, C.stream));
+        return ntt_run(C, field, out_dev, log2_n, 0, batch);
+    }
+    size_t bytes = (batch << (log2_n + log2_blowup)) * 32;
+    static DevBuf lde_tmp;
+    int rc = lde_tmp.reserve(bytes); if (rc) return rc;
+    C.timer.begin(C.stream);
+    if (field == KH_FIELD_FP) rc = transform<FpParams>(C, field, coeffs_dev, out_dev, lde_tmp.as<u64>(), log2_n, log2_blowup, 0, batch);
+    else rc = transform<FqParams>(C, field, coeffs_dev, out_dev, lde_tmp.as<u64>(), log2_n, log2_blowup, 0, batch);
+    C.timer.mark("lde", C.stream);
+    return rc;
+}
+
+}  // namespace kh

@@ -1,0 +1,250 @@
+"""ctypes binding of include/kimchi_hip.h (numpy uint64 limb arrays in, numpy out).
+
+No fallback: if libkimchi_hip.so has not been built this module raises ImportError, and
+every call raises KhError when the library reports a failure (e.g. no GPU).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libkimchi_hip.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                      "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+
+_lib = C.CDLL(LIB_PATH)
+
+U64P = C.POINTER(C.c_uint64)
+U8P = C.POINTER(C.c_uint8)
+VESTA, PALLAS = 0, 1
+FP, FQ = 0, 1
+BASIS_G = -1
+
+# every symbol include/kimchi_hip.h declares
+SYMBOLS = [
+    "kh_device_count", "kh_init", "kh_last_error", "kh_srs_create", "kh_srs_free", "kh_srs_size",
+    "kh_srs_set_lagrange", "kh_srs_compute_lagrange", "kh_srs_get_lagrange", "kh_srs_lagrange_chunks",
+    "kh_msm", "kh_msm_batch", "kh_msm_points", "kh_ntt", "kh_lde",
+    "kh_dev_alloc", "kh_dev_free", "kh_dev_upload", "kh_dev_download",
+    "kh_msm_batch_dev", "kh_ntt_dev", "kh_lde_dev", "kh_sync", "kh_last_timings",
+    "kh_debug_field_op", "kh_debug_point_op",
+]
+
+_lib.kh_last_error.restype = C.c_char_p
+_lib.kh_srs_size.restype = C.c_size_t
+_lib.kh_srs_size.argtypes = [C.c_void_p]
+_lib.kh_srs_free.restype = None
+_lib.kh_srs_free.argtypes = [C.c_void_p]
+_lib.kh_srs_create.argtypes = [C.c_int, U64P, C.c_size_t, C.POINTER(C.c_void_p)]
+_lib.kh_srs_set_lagrange.argtypes = [C.c_void_p, C.c_uint, C.c_uint, U64P, U8P, C.c_size_t]
+_lib.kh_srs_compute_lagrange.argtypes = [C.c_void_p, C.c_uint]
+_lib.kh_srs_get_lagrange.argtypes = [C.c_void_p, C.c_uint, C.c_uint, U64P, U8P]
+_lib.kh_srs_lagrange_chunks.argtypes = [C.c_void_p, C.c_uint]
+_lib.kh_msm.argtypes = [C.c_void_p, C.c_int, C.c_uint, C.c_size_t, U64P, C.c_size_t, C.c_int, U64P, U8P]
+_lib.kh_msm_batch.argtypes = [C.c_void_p, C.c_int, C.c_uint, C.c_size_t, U64P, C.c_size_t, C.c_size_t, C.c_int, U64P, U8P]
+_lib.kh_msm_batch_dev.argtypes = [C.c_void_p, C.c_int, C.c_uint, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, U64P, U8P]
+_lib.kh_msm_points.argtypes = [C.c_int, U64P, U8P, U64P, C.c_size_t, C.c_int, U64P, U8P]
+_lib.kh_ntt.argtypes = [C.c_int, U64P, C.c_uint, C.c_int, C.c_size_t]
+_lib.kh_lde.argtypes = [C.c_int, U64P, C.c_uint, C.c_uint, U64P, C.c_size_t]
+_lib.kh_ntt_dev.argtypes = [C.c_int, C.c_void_p, C.c_uint, C.c_int, C.c_size_t]
+_lib.kh_lde_dev.argtypes = [C.c_int, C.c_void_p, C.c_uint, C.c_uint, C.c_void_p, C.c_size_t]
+_lib.kh_dev_alloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+_lib.kh_dev_free.argtypes = [C.c_void_p]
+_lib.kh_dev_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+_lib.kh_dev_download.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+_lib.kh_last_timings.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int]
+_lib.kh_debug_field_op.argtypes = [C.c_int, C.c_int, U64P, U64P, U64P, C.c_size_t]
+_lib.kh_debug_point_op.argtypes = [C.c_int, C.c_int, U64P, U8P, U64P, U8P, U64P, U8P, C.c_size_t]
+
+
+class KhError(RuntimeError):
+    pass
+
+
+def _check(rc: int):
+    if rc != 0:
+        raise KhError(f"kimchi_hip error {rc}: {_lib.kh_last_error().decode()}")
+
+
+def _p64(a):
+    return a.ctypes.data_as(U64P)
+
+
+def _p8(a):
+    return None if a is None else a.ctypes.data_as(U8P)
+
+
+def _c64(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    return a if shape is None else a.reshape(shape)
+
+
+def raw():
+    return _lib
+
+
+def device_count() -> int:
+    return _lib.kh_device_count()
+
+
+def init(device: int = -1):
+    _check(_lib.kh_init(device))
+
+
+class Srs:
+    """Device-resident SRS bases (the g half of ipa::SRS<G>, poly-commitment/src/ipa.rs:53-75)."""
+
+    def __init__(self, curve: int, g_xy):
+        g = _c64(g_xy, (-1, 8))
+        self.curve = curve
+        self.n = g.shape[0]
+        self._h = C.c_void_p()
+        _check(_lib.kh_srs_create(curve, _p64(g), self.n, C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            _lib.kh_srs_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_lagrange(self, log2_domain: int, xy, inf=None, chunk: int = 0):
+        xy = _c64(xy, (-1, 8))
+        if inf is not None:
+            inf = np.ascontiguousarray(inf, dtype=np.uint8)
+        _check(_lib.kh_srs_set_lagrange(self._h, log2_domain, chunk, _p64(xy), _p8(inf), xy.shape[0]))
+
+    def compute_lagrange(self, log2_domain: int):
+        _check(_lib.kh_srs_compute_lagrange(self._h, log2_domain))
+
+    def get_lagrange(self, log2_domain: int, chunk: int = 0):
+        n = 1 << log2_domain
+        xy = np.zeros((n, 8), dtype=np.uint64)
+        inf = np.zeros(n, dtype=np.uint8)
+        _check(_lib.kh_srs_get_lagrange(self._h, log2_domain, chunk, _p64(xy), _p8(inf)))
+        return xy, inf
+
+    def lagrange_chunks(self, log2_domain: int) -> int:
+        return _lib.kh_srs_lagrange_chunks(self._h, log2_domain)
+
+    def msm(self, scalars, basis: int = BASIS_G, chunk: int = 0, offset: int = 0, mont: bool = True):
+        sc = _c64(scalars, (-1, 4))
+        out = np.zeros(8, dtype=np.uint64)
+        inf = np.zeros(1, dtype=np.uint8)
+        _check(_lib.kh_msm(self._h, basis, chunk, offset, _p64(sc), sc.shape[0], int(mont), _p64(out), _p8(inf)))
+        return out, bool(inf[0])
+
+    def msm_batch(self, scalars, basis: int = BASIS_G, chunk: int = 0, offset: int = 0, mont: bool = True):
+        sc = _c64(scalars)
+        assert sc.ndim == 3 and sc.shape[2] == 4
+        k, n = sc.shape[0], sc.shape[1]
+        out = np.zeros((k, 8), dtype=np.uint64)
+        inf = np.zeros(k, dtype=np.uint8)
+        _check(_lib.kh_msm_batch(self._h, basis, chunk, offset, _p64(sc), n, k, int(mont), _p64(out), _p8(inf)))
+        return out, inf
+
+    def msm_batch_dev(self, scalars_dev: int, n: int, k: int, basis: int = BASIS_G, chunk: int = 0, offset: int = 0, mont: bool = True):
+        out = np.zeros((k, 8), dtype=np.uint64)
+        inf = np.zeros(k, dtype=np.uint8)
+        _check(_lib.kh_msm_batch_dev(self._h, basis, chunk, offset, C.c_void_p(scalars_dev), n, k, int(mont), _p64(out), _p8(inf)))
+        return out, inf
+
+
+def msm_points(curve: int, xy, scalars, inf=None, mont: bool = True):
+    xy = _c64(xy, (-1, 8))
+    sc = _c64(scalars, (-1, 4))
+    n = min(xy.shape[0], sc.shape[0])
+    if inf is not None:
+        inf = np.ascontiguousarray(inf, dtype=np.uint8)
+    out = np.zeros(8, dtype=np.uint64)
+    oinf = np.zeros(1, dtype=np.uint8)
+    _check(_lib.kh_msm_points(curve, _p64(xy), _p8(inf), _p64(sc), n, int(mont), _p64(out), _p8(oinf)))
+    return out, bool(oinf[0])
+
+
+def ntt(field: int, data, log2_n: int, inverse: bool = False):
+    d = np.array(data, dtype=np.uint64, copy=True).reshape(-1, 1 << log2_n, 4)
+    _check(_lib.kh_ntt(field, _p64(d), log2_n, int(inverse), d.shape[0]))
+    return d
+
+
+def lde(field: int, coeffs, log2_n: int, log2_blowup: int):
+    c = _c64(coeffs, (-1, 1 << log2_n, 4))
+    out = np.zeros((c.shape[0], 1 << (log2_n + log2_blowup), 4), dtype=np.uint64)
+    _check(_lib.kh_lde(field, _p64(c), log2_n, log2_blowup, _p64(out), c.shape[0]))
+    return out
+
+
+class DevBuf:
+    """A raw HBM allocation (kh_dev_alloc) for the device-resident entry points."""
+
+    def __init__(self, nbytes: int):
+        self.nbytes = nbytes
+        p = C.c_void_p()
+        _check(_lib.kh_dev_alloc(C.byref(p), nbytes))
+        self.ptr = p.value
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        assert arr.nbytes <= self.nbytes
+        _check(_lib.kh_dev_upload(C.c_void_p(self.ptr), arr.ctypes.data_as(C.c_void_p), arr.nbytes))
+        return self
+
+    def download(self, shape, dtype=np.uint64):
+        out = np.empty(shape, dtype=dtype)
+        assert out.nbytes <= self.nbytes
+        _check(_lib.kh_dev_download(out.ctypes.data_as(C.c_void_p), C.c_void_p(self.ptr), out.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr:
+            _check(_lib.kh_dev_free(C.c_void_p(self.ptr)))
+            self.ptr = None
+
+
+def ntt_dev(field: int, buf: DevBuf, log2_n: int, inverse: bool, batch: int):
+    _check(_lib.kh_ntt_dev(field, C.c_void_p(buf.ptr), log2_n, int(inverse), batch))
+
+
+def lde_dev(field: int, src: DevBuf, log2_n: int, log2_blowup: int, dst: DevBuf, batch: int):
+    _check(_lib.kh_lde_dev(field, C.c_void_p(src.ptr), log2_n, log2_blowup, C.c_void_p(dst.ptr), batch))
+
+
+def sync():
+    _check(_lib.kh_sync())
+
+
+def last_timings():
+    names = (C.c_char_p * 32)()
+    ms = (C.c_float * 32)()
+    n = _lib.kh_last_timings(names, ms, 32)
+    return [(names[i].decode(), float(ms[i])) for i in range(n)]
+
+
+def debug_field_op(field: int, op: str, a, b=None):
+    ops = {"mul": 0, "add": 1, "sub": 2, "to_mont": 3, "from_mont": 4, "sqr": 5, "neg": 6}
+    a = _c64(a, (-1, 4))
+    bb = None if b is None else _c64(b, (-1, 4))
+    out = np.zeros_like(a)
+    _check(_lib.kh_debug_field_op(field, ops[op], _p64(a), None if bb is None else _p64(bb), _p64(out), a.shape[0]))
+    return out
+
+
+def debug_point_op(curve: int, op: int, p, q, p_inf=None, q_inf=None):
+    p = _c64(p, (-1, 8)); q = _c64(q, (-1, 8))
+    n = p.shape[0]
+    pi = None if p_inf is None else np.ascontiguousarray(p_inf, dtype=np.uint8)
+    qi = None if q_inf is None else np.ascontiguousarray(q_inf, dtype=np.uint8)
+    out = np.zeros((n, 8), dtype=np.uint64)
+    oinf = np.zeros(n, dtype=np.uint8)
+    _check(_lib.kh_debug_point_op(curve, op, _p64(p), _p8(pi), _p64(q), _p8(qi), _p64(out), _p8(oinf), n))
+    return out, oinf

@@ -1,0 +1,250 @@
+"""Parity tests proper: the HIP path (through the C ABI of include/kimchi_hip.h) against the
+CPU oracle on the same seeded inputs, bit-exact.  Run on a real MI355X: `pytest -m gpu`."""
+import numpy as np
+import pytest
+
+from oracle import cref
+from oracle import pasta as P
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def khip():
+    import proof_systems_amd.khip as k
+    k.init(0)
+    return k
+
+
+def rand_fe(rng, n, F):
+    """n uniformly random field elements as (n,4) limb arrays (any value < p is a valid
+    Montgomery representation, like ark-ff's Fp::rand)."""
+    out = np.empty((n, 4), dtype=np.uint64)
+    filled = 0
+    while filled < n:
+        m = n - filled
+        c = rng.integers(0, 1 << 64, size=(2 * m + 8, 4), dtype=np.uint64)
+        c[:, 3] &= np.uint64((1 << 63) - 1)
+        vals = [P.from_limbs(r) for r in c]
+        ok = [i for i, v in enumerate(vals) if v < F.p][:m]
+        out[filled:filled + len(ok)] = c[ok]
+        filled += len(ok)
+    return out
+
+
+def rand_fe_fast(rng, n):
+    """Uniform below 2^253 (< p): fast path for big inputs."""
+    c = rng.integers(0, 1 << 64, size=(n, 4), dtype=np.uint64)
+    c[:, 3] &= np.uint64((1 << 61) - 1)
+    return c
+
+
+def edge_fe(F):
+    vals = [0, 1, 2, F.p - 1, F.p - 2, (F.p - 1) // 2, 1 << 254, F.R, F.R2, (1 << 32) - 1, 1 << 32, (1 << 64) - 1,
+            1 << 64, (1 << 128) - 1, (1 << 192) + 5, F.p - (1 << 32), F.p - (1 << 200)]
+    return cref.ints_to_limbs([v % F.p for v in vals])
+
+
+# ------------------------------------------------------------------ field arithmetic on the device
+@pytest.mark.parametrize("fid,F", [(0, P.Fp), (1, P.Fq)])
+def test_field_ops(khip, fid, F):
+    rng = np.random.default_rng(100 + fid)
+    e = edge_fe(F)
+    a = np.concatenate([np.repeat(e, len(e), axis=0), rand_fe(rng, 20000, F)])
+    b = np.concatenate([np.tile(e, (len(e), 1)), rand_fe(rng, 20000, F)])
+    for op in ("mul", "add", "sub"):
+        got = khip.debug_field_op(fid, op, a, b)
+        want = cref.field_op(fid, op, a, b)
+        assert np.array_equal(got, want), op
+    for op in ("to_mont", "from_mont", "sqr"):
+        got = khip.debug_field_op(fid, op, a)
+        want = cref.field_op(fid, op, a)
+        assert np.array_equal(got, want), op
+    got = khip.debug_field_op(fid, "neg", a)
+    want = cref.field_op(fid, "sub", np.zeros_like(a), a)
+    assert np.array_equal(got, want)
+
+
+# ------------------------------------------------------------------ group law on the device
+@pytest.mark.parametrize("cid", [0, 1])
+def test_point_ops(khip, cid):
+    c = P.CURVES[cid]
+    n = 512
+    g = cref.srs_generate(cid, 0, n, threads=8)
+    rng = np.random.default_rng(5 + cid)
+    perm = rng.permutation(n)
+    p, q = g, g[perm].copy()
+    # force exceptional cases: q == p, q == -p, infinity operands
+    q[0] = p[0]
+    q[1] = p[1]
+    negy = cref.field_op(1 - cid if cid == 0 else 0, "sub", np.zeros((1, 4), np.uint64), p[1, 4:].reshape(1, 4))
+    q[1, 4:] = negy[0]
+    pinf = np.zeros(n, np.uint8); qinf = np.zeros(n, np.uint8)
+    pinf[2] = 1; qinf[3] = 1; pinf[4] = 1; qinf[4] = 1
+    for op in (0, 2):
+        got, ginf = khip.debug_point_op(cid, op, p, q, pinf, qinf)
+        for i in range(n):
+            w, winf = cref.point_add(cid, p[i], q[i], bool(pinf[i]), bool(qinf[i]))
+            assert bool(ginf[i]) == winf, (op, i)
+            if not winf:
+                assert np.array_equal(got[i], w), (op, i)
+    got, ginf = khip.debug_point_op(cid, 1, p, q, pinf, qinf)
+    for i in range(0, n, 7):
+        w, winf = cref.point_add(cid, p[i], p[i], bool(pinf[i]), bool(pinf[i]))
+        assert bool(ginf[i]) == winf and (winf or np.array_equal(got[i], w))
+    # 2P - Q through dbl + mixed add with a non-trivial ZZ (includes 2P - P... = P when q == p)
+    got, ginf = khip.debug_point_op(cid, 3, p, q, pinf, qinf)
+    base_fid = 1 if cid == 0 else 0
+    for i in range(0, n, 3):
+        d, dinf = cref.point_add(cid, p[i], p[i], bool(pinf[i]), bool(pinf[i]))
+        if qinf[i]:
+            w, winf = d, dinf
+        else:
+            nq = q[i].copy()
+            nq[4:] = cref.field_op(base_fid, "sub", np.zeros((1, 4), np.uint64), q[i, 4:].reshape(1, 4))[0]
+            w, winf = cref.point_add(cid, d, nq, dinf, False)
+        assert bool(ginf[i]) == winf and (winf or np.array_equal(got[i], w)), i
+
+
+# ------------------------------------------------------------------ MSM
+def _check_msm(khip, cid, g, sc, mont=True, threads=8):
+    srs = khip.Srs(cid, g)
+    got, ginf = srs.msm(sc, mont=mont)
+    want, winf = cref.msm(cid, g, sc, scalars_mont=mont, threads=threads)
+    srs.close()
+    assert ginf == winf
+    if not winf:
+        assert np.array_equal(got, want)
+
+
+def test_msm_kat(khip, golden):
+    """kimchi/src/proof.rs:1160-1204 through the device path."""
+    c = P.VESTA
+    kat = golden["msm_kat"]
+    coeffs = [1, 7, 5, 35, 3, 21, 15, 105, 2, 14, 10, 70, 6, 42, 30, 210]
+    basis = [c.mul(c.gen, i) for i in range(1, 17)]
+    xy = np.zeros((16, 8), np.uint64)
+    for i, (x, y) in enumerate(basis):
+        xy[i, :4] = P.to_limbs(c.base.to_mont(x)); xy[i, 4:] = P.to_limbs(c.base.to_mont(y))
+    for mont in (True, False):
+        sc = cref.ints_to_limbs([P.Fp.to_mont(v) if mont else v for v in coeffs])
+        got, inf = khip.msm_points(0, xy, sc, mont=mont)
+        assert not inf
+        assert c.base.from_mont(P.from_limbs(got[:4])) == int(kat["expected_x"])
+        assert c.base.from_mont(P.from_limbs(got[4:])) == int(kat["expected_y"])
+
+
+@pytest.mark.parametrize("cid", [0, 1])
+@pytest.mark.parametrize("logn", [0, 1, 5, 10, 13])
+def test_msm_uniform(khip, cid, logn):
+    n = 1 << logn
+    F = P.CURVES[cid].scalar
+    rng = np.random.default_rng(1000 * cid + logn)
+    g = cref.srs_generate(cid, 0, n, threads=8)
+    _check_msm(khip, cid, g, rand_fe(rng, n, F))
+    _check_msm(khip, cid, g, cref.field_op(F is P.Fq and 1 or 0, "from_mont", rand_fe(rng, n, F)), mont=False)
+
+
+@pytest.mark.parametrize("cid", [0, 1])
+def test_msm_edge_distributions(khip, cid):
+    """(b) bench-circuit witness (n-10 ones, 7 zeros, 3 random), (c) all zero,
+    (d) repeated points / P and -P in one bucket; plus -1 (every window max), tiny scalars, ragged n."""
+    c = P.CURVES[cid]; F = c.scalar
+    fid = 0 if F is P.Fp else 1
+    n = 3000
+    rng = np.random.default_rng(42 + cid)
+    g = cref.srs_generate(cid, 0, n, threads=8)
+    one = cref.ints_to_limbs([F.R])
+    zero = np.zeros((1, 4), np.uint64)
+    cases = {
+        "bench_circuit": np.concatenate([np.repeat(one, n - 10, 0), np.repeat(zero, 7, 0), rand_fe(rng, 3, F)]),
+        "zeros": np.zeros((n, 4), np.uint64),
+        "minus_one": np.repeat(cref.ints_to_limbs([F.to_mont(F.p - 1)]), n, 0),
+        "small": cref.field_op(fid, "to_mont", cref.ints_to_limbs([int(v) for v in rng.integers(0, 1 << 16, n)])),
+        "same_scalar": np.repeat(rand_fe(rng, 1, F), n, 0),
+        "half_boundary": cref.field_op(fid, "to_mont", cref.ints_to_limbs([(1 << (11 * (i % 20))) * ((1 << 10) + (i & 1)) % F.p for i in range(n)])),
+    }
+    for name, sc in cases.items():
+        _check_msm(khip, cid, g, sc)
+    # repeated points incl. P and -P with equal scalars, and infinity inputs, through kh_msm_points
+    base_fid = 1 - fid
+    pts = np.concatenate([g[:5], g[:5], g[:5]])
+    pts[10:15, 4:] = cref.field_op(base_fid, "sub", np.zeros((5, 4), np.uint64), g[:5, 4:])
+    sc = np.concatenate([rand_fe(rng, 5, F)] * 3)
+    inf = np.zeros(15, np.uint8); inf[7] = 1
+    got, ginf = khip.msm_points(cid, pts, sc, inf=inf)
+    want, winf = cref.msm(cid, pts, sc, inf=inf)
+    assert ginf == winf and (winf or np.array_equal(got, want))
+    got, ginf = khip.msm_points(cid, pts[[0, 10]], sc[[0, 10]])        # P*s + (-P)*s = infinity
+    assert ginf
+    # empty input -> infinity
+    got, ginf = khip.msm_points(cid, np.zeros((0, 8), np.uint64), np.zeros((0, 4), np.uint64))
+    assert ginf
+    # ragged: fewer scalars than bases, offset into the basis (commit_non_hiding's last chunk, ipa.rs:663-676)
+    srs = khip.Srs(cid, g)
+    sc = rand_fe(rng, 777, F)
+    got, ginf = srs.msm(sc, offset=100)
+    want, winf = cref.msm(cid, g[100:877], sc)
+    assert ginf == winf and np.array_equal(got, want)
+    got, ginf = srs.msm(rand_fe(rng, 50, F), offset=n - 20)            # more scalars than remaining bases
+    srs.close()
+
+
+@pytest.mark.parametrize("cid", [0, 1])
+def test_msm_batch_and_lagrange(khip, cid):
+    """15 witness-column commits against a Lagrange basis (prover.rs:329-351, ipa.rs:706-728)."""
+    c = P.CURVES[cid]; F = c.scalar
+    logn = 6; n = 1 << logn
+    rng = np.random.default_rng(9 + cid)
+    g = cref.srs_generate(cid, 0, n, threads=8)
+    bxy, binf = cref.lagrange_basis(cid, g, logn)
+    srs = khip.Srs(cid, g)
+    srs.set_lagrange(logn, bxy, binf)
+    cols = np.stack([rand_fe(rng, n, F) for _ in range(15)])
+    cols[3] = 0
+    cols[4, : n - 10] = cref.ints_to_limbs([F.R])[0]
+    got, ginf = srs.msm_batch(cols, basis=logn)
+    for j in range(15):
+        want, winf = cref.msm(cid, bxy, cols[j], inf=binf)
+        assert bool(ginf[j]) == winf and (winf or np.array_equal(got[j], want)), j
+    # commit_evaluations(e) == commit(interpolate(e))  (poly-commitment/tests/ipa_commitment.rs:26-52)
+    fid = 0 if F is P.Fp else 1
+    coeffs = cref.ntt(fid, cols[0], logn, True)[0]
+    want, winf = srs.msm(coeffs)
+    assert np.array_equal(got[0], want) and not winf
+    srs.close()
+
+
+# ------------------------------------------------------------------ NTT
+@pytest.mark.parametrize("fid", [0, 1])
+@pytest.mark.parametrize("logn", [0, 1, 2, 3, 5, 8, 9, 10, 11, 12, 13, 16, 17])
+def test_ntt_sizes(khip, fid, logn):
+    rng = np.random.default_rng(31 * logn + fid)
+    n = 1 << logn
+    batch = 3 if logn <= 13 else 2
+    x = rand_fe_fast(rng, batch * n).reshape(batch, n, 4)
+    for inverse in (False, True):
+        got = khip.ntt(fid, x, logn, inverse)
+        want = cref.ntt(fid, x, logn, inverse, threads=8)
+        assert np.array_equal(got, want), (logn, inverse)
+    # round trip
+    assert np.array_equal(khip.ntt(fid, khip.ntt(fid, x, logn, False), logn, True), x)
+
+
+@pytest.mark.parametrize("fid", [0, 1])
+@pytest.mark.parametrize("logn,logb", [(1, 3), (3, 3), (6, 3), (8, 2), (10, 3), (12, 3), (13, 1), (16, 3)])
+def test_lde(khip, fid, logn, logb):
+    rng = np.random.default_rng(77 * logn + logb + fid)
+    n = 1 << logn
+    batch = 2
+    c = rand_fe_fast(rng, batch * n).reshape(batch, n, 4)
+    got = khip.lde(fid, c, logn, logb)
+    want = cref.lde(fid, c, logn, logb, threads=8)
+    assert np.array_equal(got, want)
+    # kimchi/tests/test_domain.rs:25-71: the d1 points are every 2^b-th d8 point
+    assert np.array_equal(got[:, :: 1 << logb], cref.ntt(fid, c, logn, False, threads=8))
+
+
+def test_smoke_entry(khip):
+    import __graft_entry__ as ge
+    ge.smoke()
