@@ -480,7 +480,7 @@ __global__ void k_debug_point(int op, const u64* p, const uint8_t* pinf, const u
     if (op == 0) r = add<F>(a, b);
     else if (op == 1) r = dbl<F>(a);
     else if (op == 2) r = (qinf && qinf[i]) ? a : madd<F>(a, Q, false);
-    else r = (qinf && qinf[i]) ? a : madd<F>(dbl<F>(a), Q, true);   // 2P - Q: non-trivial ZZ into madd
+    else { Xyzz<F> d2 = dbl<F>(a); r = (qinf && qinf[i]) ? d2 : madd<F>(d2, Q, true); }   // 2P - Q: non-trivial ZZ into madd
     r.store(out + 128 * i);
 }
 int debug_point_op(Context& C, int curve, int op, const u64* p, const uint8_t* pinf, const u64* q, const uint8_t* qinf, uint8_t* out, size_t n) {
