@@ -60,6 +60,12 @@ int kh_srs_create(int curve, const uint64_t *g_xy /* n x 8 limbs */, size_t n, k
 void kh_srs_free(kh_srs_t *srs);
 size_t kh_srs_size(const kh_srs_t *srs);
 
+/* SRS::create (poly-commitment/src/ipa.rs:751-778) on the host: g_start .. g_{start+count-1}
+ * (Blake2b-512 of the big-endian u32 index -> Shallue-van de Woestijne map, groupmap/src/lib.rs:74-189)
+ * and the blinding base h (ipa.rs:765-772).  Affine x||y, Montgomery.  threads <= 0: all host cores. */
+int kh_srs_generate(int curve, size_t start, size_t count, uint64_t *out_xy, int threads);
+int kh_srs_h(int curve, uint64_t out_xy[8]);
+
 /* Registers chunk `chunk` of the Lagrange basis for the domain of size 2^log2_domain
  * (`SRS::get_lagrange_basis`, ipa.rs:780-801; entries computed by ipa.rs:1065-1172):
  * n = 2^log2_domain points, `inf` nullable per-point infinity flags. */

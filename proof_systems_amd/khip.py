@@ -32,7 +32,7 @@ SYMBOLS = [
     "kh_msm", "kh_msm_batch", "kh_msm_points", "kh_ntt", "kh_lde",
     "kh_dev_alloc", "kh_dev_free", "kh_dev_upload", "kh_dev_download",
     "kh_msm_batch_dev", "kh_ntt_dev", "kh_lde_dev", "kh_sync", "kh_last_timings",
-    "kh_debug_field_op", "kh_debug_point_op",
+    "kh_debug_field_op", "kh_debug_point_op", "kh_srs_generate", "kh_srs_h",
 ]
 
 _lib.kh_last_error.restype = C.c_char_p
@@ -60,6 +60,10 @@ _lib.kh_dev_download.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
 _lib.kh_last_timings.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int]
 _lib.kh_debug_field_op.argtypes = [C.c_int, C.c_int, U64P, U64P, U64P, C.c_size_t]
 _lib.kh_debug_point_op.argtypes = [C.c_int, C.c_int, U64P, U8P, U64P, U8P, U64P, U8P, C.c_size_t]
+
+
+_lib.kh_srs_generate.argtypes = [C.c_int, C.c_size_t, C.c_size_t, U64P, C.c_int]
+_lib.kh_srs_h.argtypes = [C.c_int, U64P]
 
 
 class KhError(RuntimeError):
@@ -157,6 +161,19 @@ class Srs:
         inf = np.zeros(k, dtype=np.uint8)
         _check(_lib.kh_msm_batch_dev(self._h, basis, chunk, offset, C.c_void_p(scalars_dev), n, k, int(mont), _p64(out), _p8(inf)))
         return out, inf
+
+
+def srs_generate(curve: int, start: int, count: int, threads: int = 0):
+    """SRS::create(depth).g[start:start+count] (host-side hash-to-curve, ipa.rs:751-778)."""
+    out = np.empty((count, 8), dtype=np.uint64)
+    _check(_lib.kh_srs_generate(curve, start, count, _p64(out), threads))
+    return out
+
+
+def srs_h(curve: int):
+    out = np.empty(8, dtype=np.uint64)
+    _check(_lib.kh_srs_h(curve, _p64(out)))
+    return out
 
 
 def msm_points(curve: int, xy, scalars, inf=None, mont: bool = True):
