@@ -54,7 +54,7 @@ void collect_timings(Context& C) {
     }
 }
 
-struct LagrangeChunk { DevBuf pts; DevBuf inf; bool has_inf = false; size_t n = 0; };
+struct LagrangeChunk { DevBuf pts; DevBuf inf; bool has_inf = false; size_t n = 0; int precomp_c = 0; };
 }  // namespace kh
 
 using namespace kh;
@@ -63,6 +63,7 @@ struct kh_srs {
     int curve = 0;
     size_t n = 0;
     DevBuf g;
+    int g_precomp_c = 0;
     std::map<unsigned, std::vector<std::unique_ptr<LagrangeChunk>>> lagrange;
     std::mutex mu;
 };
@@ -71,7 +72,7 @@ static int resolve_basis(kh_srs_t* srs, int basis, unsigned chunk, MsmBasis& out
     KH_REQUIRE(srs != nullptr, "null SRS handle");
     if (basis == KH_BASIS_G) {
         KH_REQUIRE(chunk == 0, "chunk must be 0 for the monomial basis");
-        out.pts = srs->g.p; out.inf = nullptr; out.n = srs->n; out.precomp_c = 0;
+        out.pts = srs->g.p; out.inf = nullptr; out.n = srs->n; out.precomp_c = srs->g_precomp_c;
         return KH_OK;
     }
     auto it = srs->lagrange.find((unsigned)basis);
@@ -80,7 +81,7 @@ static int resolve_basis(kh_srs_t* srs, int basis, unsigned chunk, MsmBasis& out
         return KH_E_NOTFOUND;
     }
     LagrangeChunk& L = *it->second[chunk];
-    out.pts = L.pts.p; out.inf = L.has_inf ? L.inf.as<uint8_t>() : nullptr; out.n = L.n; out.precomp_c = 0;
+    out.pts = L.pts.p; out.inf = L.has_inf ? L.inf.as<uint8_t>() : nullptr; out.n = L.n; out.precomp_c = L.precomp_c;
     return KH_OK;
 }
 
@@ -102,8 +103,14 @@ int kh_srs_create(int curve, const uint64_t* g_xy, size_t n, kh_srs_t** out) {
     s->curve = curve; s->n = n;
     Context& C = ctx();
     std::lock_guard<std::mutex> lk(C.mu);
-    if ((rc = s->g.reserve(n * 64))) return rc;
+    const bool pre = n >= MSM_PRECOMP_MIN_N && !getenv("KH_NO_PRECOMP");
+    const int W = (256 + MSM_PRECOMP_C - 1) / MSM_PRECOMP_C;
+    if ((rc = s->g.reserve(n * 64 * (pre ? W : 1)))) return rc;
     KH_HIP(hipMemcpy(s->g.p, g_xy, n * 64, hipMemcpyHostToDevice));
+    if (pre) {
+        if ((rc = msm_precompute(C, curve, s->g.p, nullptr, n, MSM_PRECOMP_C))) return rc;
+        s->g_precomp_c = MSM_PRECOMP_C;
+    }
     *out = s.release();
     return KH_OK;
 }
@@ -129,7 +136,9 @@ int kh_srs_set_lagrange(kh_srs_t* srs, unsigned log2_domain, unsigned chunk, con
     if (vec.size() <= chunk) vec.resize(chunk + 1);
     std::unique_ptr<LagrangeChunk> L(new LagrangeChunk);
     L->n = n;
-    if ((rc = L->pts.reserve(n * 64))) return rc;
+    const bool pre = n >= MSM_PRECOMP_MIN_N && !getenv("KH_NO_PRECOMP");
+    const int W = (256 + MSM_PRECOMP_C - 1) / MSM_PRECOMP_C;
+    if ((rc = L->pts.reserve(n * 64 * (pre ? W : 1)))) return rc;
     KH_HIP(hipMemcpy(L->pts.p, xy, n * 64, hipMemcpyHostToDevice));
     if (inf) {
         bool any = false;
@@ -139,6 +148,10 @@ int kh_srs_set_lagrange(kh_srs_t* srs, unsigned log2_domain, unsigned chunk, con
             KH_HIP(hipMemcpy(L->inf.p, inf, n, hipMemcpyHostToDevice));
             L->has_inf = true;
         }
+    }
+    if (pre) {
+        if ((rc = msm_precompute(C, srs->curve, L->pts.p, L->has_inf ? L->inf.as<uint8_t>() : nullptr, n, MSM_PRECOMP_C))) return rc;
+        L->precomp_c = MSM_PRECOMP_C;
     }
     vec[chunk] = std::move(L);
     return KH_OK;

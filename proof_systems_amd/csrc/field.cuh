@@ -189,4 +189,16 @@ __device__ __forceinline__ Fe<F> from_mont(const Fe<F>& a) {
 template <class F>
 __device__ __forceinline__ Fe<F> to_mont(const Fe<F>& a) { return mul<F>(a, Fe<F>::r2()); }
 
+// a^(p-2) = a^-1 (Fermat).  p - 2 has words [0xffffffff, P1 - 1, P2, P3, 0, 0, 0, 2^30].
+template <class F>
+__device__ __noinline__ Fe<F> inv(const Fe<F>& a) {
+    const u32 e[8] = {0xffffffffu, F::P1 - 1u, F::P2, F::P3, 0u, 0u, 0u, P7W};
+    Fe<F> acc = a;                       // top bit (254) consumed
+    for (int i = 253; i >= 0; i--) {
+        acc = sqr<F>(acc);
+        if ((e[i >> 5] >> (i & 31)) & 1u) acc = mul<F>(acc, a);
+    }
+    return acc;
+}
+
 }  // namespace kh

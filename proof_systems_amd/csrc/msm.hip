@@ -212,7 +212,7 @@ k_accumulate(const u32* __restrict__ entries, const u32* __restrict__ off, const
     acc.store(partial + t * 128);
 }
 // ------------------------------------------------------------------------------------ 6 bucket sums
-static constexpr u32 SMALL_NT = 8;
+static constexpr u32 SMALL_NT = 16;
 template <class BF>
 __global__ void __launch_bounds__(256)
 k_bucket_sum(const u32* __restrict__ toff, size_t nkeys, const uint8_t* __restrict__ partial,
@@ -286,15 +286,11 @@ k_reduce_seg(const uint8_t* __restrict__ buckets, u32 nb, u32 m, size_t ngroups,
     }
     acc.store(seg + gid * 128);
 }
-// block per group: tree-sum of its nseg segment results
+// sum of `count` XYZZ records per group, two launches: level 1 = blocks of 256 threads x SUM_PER_T
+// records (coalesced strided loads, shuffle tree, LDS across the 4 waves), level 2 = one block per group.
+static constexpr u32 SUM_PER_T = 2, SUM_BLK = 256 * SUM_PER_T;
 template <class BF>
-__global__ void __launch_bounds__(256)
-k_reduce_tree(const uint8_t* __restrict__ seg, u32 nseg, uint8_t* __restrict__ out) {
-    __shared__ u32 sh[4 * 32];              // one Xyzz (32 words) per wave
-    size_t q = blockIdx.x;
-    const uint8_t* S = seg + q * (size_t)nseg * 128;
-    Xyzz<BF> acc = Xyzz<BF>::identity();
-    for (u32 k = threadIdx.x; k < nseg; k += blockDim.x) acc = add<BF>(acc, Xyzz<BF>::load(S + (size_t)k * 128));
+__device__ __forceinline__ Xyzz<BF> block_sum(Xyzz<BF> acc, u32* sh) {
     for (int d = 32; d >= 1; d >>= 1) { Xyzz<BF> o = shfl_down<BF>(acc, d); acc = add<BF>(acc, o); }
     int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     u32* mine = sh + wave * 32;
@@ -303,15 +299,75 @@ k_reduce_tree(const uint8_t* __restrict__ seg, u32 nseg, uint8_t* __restrict__ o
         for (int i = 0; i < 8; i++) { mine[i] = acc.x.v[i]; mine[8 + i] = acc.y.v[i]; mine[16 + i] = acc.zz.v[i]; mine[24 + i] = acc.zzz.v[i]; }
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        int nw = blockDim.x >> 6;
-        for (int w2 = 1; w2 < nw; w2++) {
-            Xyzz<BF> o; const u32* p = sh + w2 * 32;
+    int nw = blockDim.x >> 6;
+    if (threadIdx.x < 64) {              // wave 0 folds the (<= 4) wave results
+        Xyzz<BF> o = Xyzz<BF>::identity();
+        if (lane < nw) {
+            const u32* p = sh + lane * 32;
 #pragma unroll
             for (int i = 0; i < 8; i++) { o.x.v[i] = p[i]; o.y.v[i] = p[8 + i]; o.zz.v[i] = p[16 + i]; o.zzz.v[i] = p[24 + i]; }
-            acc = add<BF>(acc, o);
         }
-        acc.store(out + q * 128);
+        for (int d = 2; d >= 1; d >>= 1) { Xyzz<BF> q = shfl_down<BF>(o, d); o = add<BF>(o, q); }
+        acc = o;
+    }
+    return acc;                          // valid in thread 0
+}
+template <class BF>
+__global__ void __launch_bounds__(256)
+k_sum_level(const uint8_t* __restrict__ in, u32 count, u32 out_stride, uint8_t* __restrict__ out) {
+    __shared__ u32 sh[4 * 32];
+    size_t q = blockIdx.y;
+    const uint8_t* S = in + q * (size_t)count * 128;
+    u32 base = blockIdx.x * SUM_BLK;
+    Xyzz<BF> acc = Xyzz<BF>::identity();
+    for (u32 k = base + threadIdx.x; k < count && k < base + SUM_BLK; k += 256) acc = add<BF>(acc, Xyzz<BF>::load(S + (size_t)k * 128));
+    acc = block_sum<BF>(acc, sh);
+    if (threadIdx.x == 0) acc.store(out + (q * out_stride + blockIdx.x) * 128);
+}
+template <class BF>
+__global__ void __launch_bounds__(256)
+k_sum_final(const uint8_t* __restrict__ in, u32 count, uint8_t* __restrict__ out) {
+    __shared__ u32 sh[4 * 32];
+    size_t q = blockIdx.x;
+    const uint8_t* S = in + q * (size_t)count * 128;
+    Xyzz<BF> acc = Xyzz<BF>::identity();
+    for (u32 k = threadIdx.x; k < count; k += blockDim.x) acc = add<BF>(acc, Xyzz<BF>::load(S + (size_t)k * 128));
+    acc = block_sum<BF>(acc, sh);
+    if (threadIdx.x == 0) acc.store(out + q * 128);
+}
+
+// ------------------------------------------------------------------------------------ precomputed window tables
+// tables[w][i] = 2^(c*w) * P_i in affine form (w = 0 is the basis itself).  Thread per point:
+// (W-1) x c doublings in XYZZ, then ONE inversion per point (Montgomery's trick over its W-1
+// ZZZ values) to normalise.  `scratch` holds the (W-1) x n intermediate XYZZ points.
+template <class BF>
+__global__ void __launch_bounds__(256)
+k_precompute(uint8_t* __restrict__ tables, const uint8_t* __restrict__ inf, size_t n, int c, int W, uint8_t* __restrict__ scratch) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (inf && inf[i]) {                   // multiples of the identity: never used (digits are zeroed), keep zeros
+        for (int w = 1; w < W; w++) { Fe<BF> z = Fe<BF>::zero(); z.store(tables + ((size_t)w * n + i) * 64); z.store(tables + ((size_t)w * n + i) * 64 + 32); }
+        return;
+    }
+    Xyzz<BF> P = Xyzz<BF>::from_affine(Aff<BF>::load(tables + i * 64));
+    Fe<BF> prod = Fe<BF>::one();
+    for (int w = 1; w < W; w++) {
+        for (int k = 0; k < c; k++) P = dbl<BF>(P);
+        P.store(scratch + ((size_t)(w - 1) * n + i) * 128);
+        // running product of the ZZZ's, kept in the (now free) slot of the affine table: x-slot of table w
+        prod = mul<BF>(prod, P.zzz);
+        prod.store(tables + ((size_t)w * n + i) * 64);
+    }
+    Fe<BF> iv = inv<BF>(prod);             // 1 / (zzz_1 * ... * zzz_{W-1})
+    for (int w = W - 1; w >= 1; w--) {
+        Xyzz<BF> Q = Xyzz<BF>::load(scratch + ((size_t)(w - 1) * n + i) * 128);
+        Fe<BF> izzz = iv;
+        if (w > 1) izzz = mul<BF>(iv, Fe<BF>::load(tables + ((size_t)(w - 1) * n + i) * 64));   // times prefix product
+        iv = mul<BF>(iv, Q.zzz);
+        Fe<BF> izz = sqr<BF>(mul<BF>(izzz, Q.zz));       // (ZZ/ZZZ)^2 = 1/ZZ
+        Fe<BF> x = mul<BF>(Q.x, izz), y = mul<BF>(Q.y, izzz);
+        x.store(tables + ((size_t)w * n + i) * 64);
+        y.store(tables + ((size_t)w * n + i) * 64 + 32);
     }
 }
 
@@ -357,9 +413,10 @@ static int msm_run_t(Context& C, const MsmBasis& basis, size_t offset, const u64
     if ((rc = C.ws_partial.reserve(max_tasks * 128))) return rc;
     if ((rc = C.ws_buckets.reserve(nkeys * 128))) return rc;
     if ((rc = C.ws_biglist.reserve((nkeys + 1) * sizeof(u32)))) return rc;
-    u32 m = 4; if (nb < m) m = nb;
+    u32 m = precomp ? 1u : 4u; if (nb < m) m = nb;
     const u32 nseg = nb / m;
-    if ((rc = C.ws_seg.reserve(ngroups * nseg * 128))) return rc;
+    const u32 nblk1 = (nseg + SUM_BLK - 1) / SUM_BLK;
+    if ((rc = C.ws_seg.reserve(ngroups * (size_t)(nseg + nblk1) * 128))) return rc;
     if ((rc = C.ws_out.reserve(ngroups * 128))) return rc;
 
     C.timer.begin(s);
@@ -406,7 +463,11 @@ static int msm_run_t(Context& C, const MsmBasis& basis, size_t offset, const u64
     // 7 reduce
     hipLaunchKernelGGL((k_reduce_seg<BF>), dim3((unsigned)((ngroups * nseg + 127) / 128)), dim3(128), 0, s,
                        C.ws_buckets.as<uint8_t>(), nb, m, ngroups, C.ws_seg.as<uint8_t>());
-    hipLaunchKernelGGL((k_reduce_tree<BF>), dim3((unsigned)ngroups), dim3(256), 0, s, C.ws_seg.as<uint8_t>(), nseg, C.ws_out.as<uint8_t>());
+    {
+        uint8_t* lvl1 = C.ws_seg.as<uint8_t>() + ngroups * (size_t)nseg * 128;
+        hipLaunchKernelGGL((k_sum_level<BF>), dim3(nblk1, (unsigned)ngroups), dim3(256), 0, s, C.ws_seg.as<uint8_t>(), nseg, nblk1, lvl1);
+        hipLaunchKernelGGL((k_sum_final<BF>), dim3((unsigned)ngroups), dim3(nblk1 > 64 ? 256 : 64), 0, s, lvl1, nblk1, C.ws_out.as<uint8_t>());
+    }
     C.timer.mark("reduce", s);
     KH_HIP(hipGetLastError());
     // 8 finish on host
@@ -441,6 +502,19 @@ int msm_run(Context& C, int curve, const MsmBasis& basis, size_t offset, const u
     }
     if (curve == KH_CURVE_VESTA) return msm_run_t<VestaCfg>(C, basis, offset, scalars_dev, n, k, mont, curve, out_xy, out_inf);
     return msm_run_t<PallasCfg>(C, basis, offset, scalars_dev, n, k, mont, curve, out_xy, out_inf);
+}
+
+int msm_precompute(Context& C, int curve, void* tables, const uint8_t* inf, size_t n, int c) {
+    const int W = (256 + c - 1) / c;
+    static DevBuf scratch;
+    int rc = scratch.reserve((size_t)(W - 1) * n * 128); if (rc) return rc;
+    dim3 grid((unsigned)((n + 255) / 256));
+    if (curve == KH_CURVE_VESTA) hipLaunchKernelGGL((k_precompute<FqParams>), grid, dim3(256), 0, C.stream, (uint8_t*)tables, inf, n, c, W, scratch.as<uint8_t>());
+    else hipLaunchKernelGGL((k_precompute<FpParams>), grid, dim3(256), 0, C.stream, (uint8_t*)tables, inf, n, c, W, scratch.as<uint8_t>());
+    KH_HIP(hipGetLastError());
+    KH_HIP(hipStreamSynchronize(C.stream));
+    if (scratch.cap > ((size_t)1 << 30)) { (void)hipFree(scratch.p); scratch.p = nullptr; scratch.cap = 0; }   // do not pin GBs of scratch
+    return KH_OK;
 }
 
 // ------------------------------------------------------------------------------------ debug hooks
