@@ -106,6 +106,35 @@ int kh_msm_points(int curve, const uint64_t *xy /* n x 8 */, const uint8_t *inf 
                   const uint64_t *scalars, size_t n, int scalars_are_montgomery,
                   uint64_t out_xy[8], uint8_t *out_is_inf);
 
+/* ---- commitment wrappers (host logic of the SRS trait over the MSM kernels) ----
+ * kh_commit_non_hiding = SRS::commit_non_hiding (poly-commitment/src/ipa.rs:638-683):
+ * coefficients (len x 4 limbs, Montgomery) are split into ceil(len / srs_size) chunks,
+ * chunk j = sum_i coeffs[j*srs_size + i] * g[i]; the zero polynomial (all coefficients zero or
+ * len == 0) commits to ONE point at infinity; the result is padded with infinities up to
+ * num_chunks (never truncated).  out_xy / out_inf must have room for
+ * max(num_chunks, ceil(len / srs_size), 1) entries; *out_count receives the number written. */
+int kh_commit_non_hiding(kh_srs_t *srs, const uint64_t *coeffs, size_t len, size_t num_chunks,
+                         uint64_t *out_xy, uint8_t *out_inf, size_t *out_count);
+/* kh_commit_evaluations_non_hiding = SRS::commit_evaluations_non_hiding (ipa.rs:706-728 +
+ * PolyComm::multi_scalar_mul, commitment.rs:350-394): evals live on a domain of size evals_len
+ * (a power of two, >= 2^log2_domain; sub-sampled with stride evals_len >> log2_domain), and are
+ * committed against the registered Lagrange basis; one output point per basis chunk.
+ * A domain larger than the evaluations' domain is the reference's panic: returns KH_E_INVALID. */
+int kh_commit_evaluations_non_hiding(kh_srs_t *srs, unsigned log2_domain, const uint64_t *evals, size_t evals_len,
+                                     uint64_t *out_xy, uint8_t *out_inf, size_t *out_count);
+/* Blinding base h of the SRS (ipa::SRS::h); defaults to SRS::create's h (ipa.rs:765-772). */
+int kh_srs_set_blinding_base(kh_srs_t *srs, const uint64_t h_xy[8]);
+int kh_srs_get_blinding_base(const kh_srs_t *srs, uint64_t h_xy[8]);
+/* kh_mask_custom = SRS::mask_custom (ipa.rs:605-622): out_j = blinders_j * h + com_j on the host
+ * (one scalar multiplication per chunk: "negligible, stays on host").  A length mismatch is
+ * CommitmentError::BlindersDontMatch: returns KH_E_BLINDERS. */
+#define KH_E_BLINDERS (-5)
+int kh_mask_custom(kh_srs_t *srs, const uint64_t *com_xy, const uint8_t *com_inf, size_t com_len,
+                   const uint64_t *blinders /* Montgomery */, size_t blinders_len,
+                   uint64_t *out_xy, uint8_t *out_inf);
+/* omega_{2^k} of Radix2EvaluationDomain::new(2^k) (kimchi/src/circuits/domains.rs:40-69), Montgomery. */
+int kh_domain_generator(int field, unsigned log2_n, uint64_t out[4]);
+
 /* ---- NTT -------------------------------------------------------------------
  * Replaces Radix2EvaluationDomain::{fft_in_place, ifft_in_place} behind
  * Evaluations::interpolate[_by_ref] (kimchi/src/prover.rs:289,377,433,567,614,665,

@@ -64,6 +64,7 @@ struct kh_srs {
     size_t n = 0;
     DevBuf g;
     int g_precomp_c = 0;
+    uint64_t h[8];
     std::map<unsigned, std::vector<std::unique_ptr<LagrangeChunk>>> lagrange;
     std::mutex mu;
 };
@@ -111,6 +112,7 @@ int kh_srs_create(int curve, const uint64_t* g_xy, size_t n, kh_srs_t** out) {
         if ((rc = msm_precompute(C, curve, s->g.p, nullptr, n, MSM_PRECOMP_C))) return rc;
         s->g_precomp_c = MSM_PRECOMP_C;
     }
+    if ((rc = kh_srs_h(curve, s->h))) return rc;
     *out = s.release();
     return KH_OK;
 }
@@ -236,7 +238,97 @@ int kh_msm_points(int curve, const uint64_t* xy, const uint8_t* inf, const uint6
     return msm_run(C, curve, b, 0, C.ws_scalars.as<uint64_t>(), n, 1, scalars_are_montgomery, out_xy, out_is_inf);
 }
 
+// ---------------------------------------------------------------------------------- commitment wrappers
+static bool limbs_zero(const uint64_t* p) { return (p[0] | p[1] | p[2] | p[3]) == 0; }
+
+int kh_commit_non_hiding(kh_srs_t* srs, const uint64_t* coeffs, size_t len, size_t num_chunks,
+                         uint64_t* out_xy, uint8_t* out_inf, size_t* out_count) {
+    KH_REQUIRE(srs && out_xy && out_inf && out_count, "kh_commit_non_hiding: null argument");
+    KH_REQUIRE(coeffs || len == 0, "null coefficients");
+    while (len > 0 && limbs_zero(coeffs + 4 * (len - 1))) len--;       // DensePolynomial drops leading zero coefficients
+    size_t written = 0;
+    const size_t gsz = srs->n;
+    if (len == 0) {                                                     // is_zero -> vec![G::zero()]
+        memset(out_xy, 0, 64); out_inf[0] = 1; written = 1;
+    } else {
+        size_t full = len / gsz, rem = len % gsz;
+        if (full > 0) {                                                 // whole chunks share the basis window [0, gsz)
+            int rc = kh_msm_batch(srs, KH_BASIS_G, 0, 0, coeffs, gsz, full, 1, out_xy, out_inf);
+            if (rc) return rc;
+            written = full;
+        }
+        if (rem > 0) {                                                  // ragged last chunk: msm(&g[..rem], ..)
+            int rc = kh_msm(srs, KH_BASIS_G, 0, 0, coeffs + 4 * full * gsz, rem, 1, out_xy + 8 * written, out_inf + written);
+            if (rc) return rc;
+            written++;
+        }
+    }
+    for (; written < num_chunks; written++) { memset(out_xy + 8 * written, 0, 64); out_inf[written] = 1; }
+    *out_count = written;
+    return KH_OK;
+}
+
+int kh_commit_evaluations_non_hiding(kh_srs_t* srs, unsigned log2_domain, const uint64_t* evals, size_t evals_len,
+                                     uint64_t* out_xy, uint8_t* out_inf, size_t* out_count) {
+    KH_REQUIRE(srs && evals && out_xy && out_inf && out_count, "kh_commit_evaluations_non_hiding: null argument");
+    const size_t n = (size_t)1 << log2_domain;
+    KH_REQUIRE(evals_len >= n, "desired commitment domain size (%zu) greater than evaluations' domain size (%zu)", n, evals_len);
+    KH_REQUIRE((evals_len & (evals_len - 1)) == 0, "evaluation domain size %zu is not a power of two", evals_len);
+    int chunks = kh_srs_lagrange_chunks(srs, log2_domain);
+    if (chunks <= 0) { set_error("Lagrange basis for domain 2^%u is not registered on this SRS", log2_domain); return KH_E_NOTFOUND; }
+    const size_t stride = evals_len / n;
+    std::vector<uint64_t> sub;
+    const uint64_t* v = evals;
+    if (stride > 1) {
+        sub.resize(n * 4);
+        for (size_t i = 0; i < n; i++) memcpy(&sub[4 * i], evals + 4 * stride * i, 32);
+        v = sub.data();
+    }
+    for (int c = 0; c < chunks; c++) {
+        int rc = kh_msm(srs, (int)log2_domain, (unsigned)c, 0, v, n, 1, out_xy + 8 * c, out_inf + c);
+        if (rc) return rc;
+    }
+    *out_count = (size_t)chunks;
+    return KH_OK;
+}
+
+int kh_srs_set_blinding_base(kh_srs_t* srs, const uint64_t h_xy[8]) {
+    KH_REQUIRE(srs && h_xy, "null argument");
+    memcpy(srs->h, h_xy, 64);
+    return KH_OK;
+}
+int kh_srs_get_blinding_base(const kh_srs_t* srs, uint64_t h_xy[8]) {
+    KH_REQUIRE(srs && h_xy, "null argument");
+    memcpy(h_xy, srs->h, 64);
+    return KH_OK;
+}
+int kh_mask_custom(kh_srs_t* srs, const uint64_t* com_xy, const uint8_t* com_inf, size_t com_len,
+                   const uint64_t* blinders, size_t blinders_len, uint64_t* out_xy, uint8_t* out_inf) {
+    KH_REQUIRE(srs && com_xy && blinders && out_xy && out_inf, "kh_mask_custom: null argument");
+    if (com_len != blinders_len) { set_error("BlindersDontMatch(%zu, %zu)", blinders_len, com_len); return KH_E_BLINDERS; }
+    khost::Crv crv(srs->curve);
+    khost::Fld SF(khost::scalar_field_id(srs->curve));
+    khost::aff h; memcpy(&h, srs->h, 64);
+    khost::xyzz H = crv.from_affine(h);
+    for (size_t j = 0; j < com_len; j++) {
+        khost::fe w; memcpy(&w, blinders + 4 * j, 32);
+        w = SF.from_mont(w);
+        khost::xyzz acc = crv.mul_plain(H, w);
+        if (!(com_inf && com_inf[j])) { khost::aff c; memcpy(&c, com_xy + 8 * j, 64); acc = crv.add(acc, crv.from_affine(c)); }
+        khost::aff r; bool inf = crv.to_affine(acc, r);
+        memcpy(out_xy + 8 * j, &r, 64); out_inf[j] = inf ? 1 : 0;
+    }
+    return KH_OK;
+}
+
 // ---------------------------------------------------------------------------------- NTT
+int kh_domain_generator(int field, unsigned log2_n, uint64_t out[4]) {
+    KH_REQUIRE(field == KH_FIELD_FP || field == KH_FIELD_FQ, "unknown field id %d", field);
+    KH_REQUIRE(log2_n <= 32 && out, "log2_n must be <= 32 (two-adicity of the Pasta fields)");
+    khost::fe w = kh::ntt_host_root(field, log2_n, 0);
+    memcpy(out, &w, 32);
+    return KH_OK;
+}
 int kh_ntt_dev(int field, uint64_t* data_dev, unsigned log2_n, int inverse, size_t batch) {
     KH_REQUIRE(field == KH_FIELD_FP || field == KH_FIELD_FQ, "unknown field id %d", field);
     KH_REQUIRE(log2_n <= 28, "log2_n = %u too large", log2_n);

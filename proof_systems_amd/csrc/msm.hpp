@@ -1,6 +1,7 @@
 // msm.hpp -- internal interface between api.hip and msm.hip
 #pragma once
 #include "common.hpp"
+#include "host_ec.hpp"
 
 namespace kh {
 
@@ -22,6 +23,7 @@ int debug_field_op(Context& C, int field, int op, const uint64_t* a, const uint6
 int debug_point_op(Context& C, int curve, int op, const uint64_t* p, const uint8_t* pinf, const uint64_t* q, const uint8_t* qinf, uint8_t* out, size_t n);
 
 // ntt.hip
+khost::fe ntt_host_root(int field, unsigned logn, int inverse);   // omega_{2^logn} (or its inverse), Montgomery
 int ntt_run(Context& C, int field, uint64_t* data_dev, unsigned log2_n, int inverse, size_t batch);
 int lde_run(Context& C, int field, const uint64_t* coeffs_dev, unsigned log2_n, unsigned log2_blowup, uint64_t* out_dev, size_t batch);
 

@@ -191,7 +191,7 @@ struct TwKey { int field; unsigned logn; int inverse; bool operator<(const TwKey
 struct TwEntry { DevBuf tab; khost::fe inv_n; };
 static std::map<TwKey, TwEntry> g_tw;
 
-static khost::fe host_root(int field, unsigned logn, int inverse) {
+khost::fe ntt_host_root(int field, unsigned logn, int inverse) {
     // w_{2^k} = (5^T)^(2^(32-k)); T = (p-1) >> 32   (kimchi/src/circuits/domains.rs:40-69)
     khost::Fld F(field);
     khost::fe five = {{5, 0, 0, 0}}; five = F.to_mont(five);
@@ -211,7 +211,7 @@ static int get_twiddles(Context& C, int field, unsigned logn, int inverse, TwEnt
     if (it != g_tw.end()) { *out = &it->second; return KH_OK; }
     TwEntry& E = g_tw[key];
     khost::Fld F(field);
-    khost::fe w = host_root(field, logn, inverse);
+    khost::fe w = ntt_host_root(field, logn, inverse);
     khost::fe pow2[32];
     pow2[0] = w;
     for (int i = 1; i < 32; i++) pow2[i] = F.sqr(pow2[i - 1]);

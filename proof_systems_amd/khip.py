@@ -33,6 +33,8 @@ SYMBOLS = [
     "kh_dev_alloc", "kh_dev_free", "kh_dev_upload", "kh_dev_download",
     "kh_msm_batch_dev", "kh_ntt_dev", "kh_lde_dev", "kh_sync", "kh_last_timings",
     "kh_debug_field_op", "kh_debug_point_op", "kh_srs_generate", "kh_srs_h",
+    "kh_commit_non_hiding", "kh_commit_evaluations_non_hiding", "kh_srs_set_blinding_base",
+    "kh_srs_get_blinding_base", "kh_mask_custom", "kh_domain_generator",
 ]
 
 _lib.kh_last_error.restype = C.c_char_p
@@ -66,13 +68,24 @@ _lib.kh_srs_generate.argtypes = [C.c_int, C.c_size_t, C.c_size_t, U64P, C.c_int]
 _lib.kh_srs_h.argtypes = [C.c_int, U64P]
 
 
+_lib.kh_commit_non_hiding.argtypes = [C.c_void_p, U64P, C.c_size_t, C.c_size_t, U64P, U8P, C.POINTER(C.c_size_t)]
+_lib.kh_commit_evaluations_non_hiding.argtypes = [C.c_void_p, C.c_uint, U64P, C.c_size_t, U64P, U8P, C.POINTER(C.c_size_t)]
+_lib.kh_srs_set_blinding_base.argtypes = [C.c_void_p, U64P]
+_lib.kh_srs_get_blinding_base.argtypes = [C.c_void_p, U64P]
+_lib.kh_mask_custom.argtypes = [C.c_void_p, U64P, U8P, C.c_size_t, U64P, C.c_size_t, U64P, U8P]
+_lib.kh_domain_generator.argtypes = [C.c_int, C.c_uint, U64P]
+E_BLINDERS = -5
+
+
 class KhError(RuntimeError):
-    pass
+    def __init__(self, msg, code=None):
+        super().__init__(msg)
+        self.code = code
 
 
 def _check(rc: int):
     if rc != 0:
-        raise KhError(f"kimchi_hip error {rc}: {_lib.kh_last_error().decode()}")
+        raise KhError(f"kimchi_hip error {rc}: {_lib.kh_last_error().decode()}", rc)
 
 
 def _p64(a):
@@ -139,6 +152,53 @@ class Srs:
 
     def lagrange_chunks(self, log2_domain: int) -> int:
         return _lib.kh_srs_lagrange_chunks(self._h, log2_domain)
+
+    # ---- the SRS trait surface (poly-commitment/src/lib.rs:61-241) over the kernels
+    def max_poly_size(self) -> int:
+        return self.n
+
+    def blinding_commitment(self):
+        out = np.zeros(8, dtype=np.uint64)
+        _check(_lib.kh_srs_get_blinding_base(self._h, _p64(out)))
+        return out
+
+    def set_blinding_base(self, h_xy):
+        h = _c64(h_xy, (8,))
+        _check(_lib.kh_srs_set_blinding_base(self._h, _p64(h)))
+
+    def commit_non_hiding(self, coeffs, num_chunks: int):
+        """SRS::commit_non_hiding (ipa.rs:638-683) -> (chunks x 8 limbs, inf flags)."""
+        c = _c64(coeffs, (-1, 4))
+        cap = max(num_chunks, -(-c.shape[0] // self.n), 1)
+        out = np.zeros((cap, 8), dtype=np.uint64)
+        inf = np.zeros(cap, dtype=np.uint8)
+        cnt = C.c_size_t(0)
+        _check(_lib.kh_commit_non_hiding(self._h, _p64(c), c.shape[0], num_chunks, _p64(out), _p8(inf), C.byref(cnt)))
+        return out[:cnt.value], inf[:cnt.value]
+
+    def commit_evaluations_non_hiding(self, log2_domain: int, evals):
+        """SRS::commit_evaluations_non_hiding (ipa.rs:706-728)."""
+        e = _c64(evals, (-1, 4))
+        cap = max(1, self.lagrange_chunks(log2_domain))
+        out = np.zeros((cap, 8), dtype=np.uint64)
+        inf = np.zeros(cap, dtype=np.uint8)
+        cnt = C.c_size_t(0)
+        _check(_lib.kh_commit_evaluations_non_hiding(self._h, log2_domain, _p64(e), e.shape[0], _p64(out), _p8(inf), C.byref(cnt)))
+        return out[:cnt.value], inf[:cnt.value]
+
+    def mask_custom(self, com_xy, com_inf, blinders):
+        """SRS::mask_custom (ipa.rs:605-622); raises KhError(code=E_BLINDERS) on BlindersDontMatch."""
+        com = _c64(com_xy, (-1, 8)); bl = _c64(blinders, (-1, 4))
+        ci = np.ascontiguousarray(com_inf, dtype=np.uint8)
+        out = np.zeros((com.shape[0], 8), dtype=np.uint64)
+        inf = np.zeros(com.shape[0], dtype=np.uint8)
+        _check(_lib.kh_mask_custom(self._h, _p64(com), _p8(ci), com.shape[0], _p64(bl), bl.shape[0], _p64(out), _p8(inf)))
+        return out, inf
+
+    def commit_custom(self, coeffs, num_chunks: int, blinders):
+        """SRS::commit_custom (ipa.rs:686-693) = mask_custom(commit_non_hiding(..), blinders)."""
+        com, inf = self.commit_non_hiding(coeffs, num_chunks)
+        return self.mask_custom(com, inf, blinders)
 
     def msm(self, scalars, basis: int = BASIS_G, chunk: int = 0, offset: int = 0, mont: bool = True):
         sc = _c64(scalars, (-1, 4))
@@ -234,6 +294,12 @@ def ntt_dev(field: int, buf: DevBuf, log2_n: int, inverse: bool, batch: int):
 
 def lde_dev(field: int, src: DevBuf, log2_n: int, log2_blowup: int, dst: DevBuf, batch: int):
     _check(_lib.kh_lde_dev(field, C.c_void_p(src.ptr), log2_n, log2_blowup, C.c_void_p(dst.ptr), batch))
+
+
+def domain_generator(field: int, log2_n: int):
+    out = np.zeros(4, dtype=np.uint64)
+    _check(_lib.kh_domain_generator(field, log2_n, _p64(out)))
+    return out
 
 
 def sync():

@@ -1,0 +1,154 @@
+"""The SRS trait surface (poly-commitment/src/lib.rs:61-241) through the C ABI on the GPU:
+these read like the reference's own tests in poly-commitment/tests/{commitment,ipa_commitment}.rs."""
+import numpy as np
+import pytest
+
+from oracle import cref
+from oracle import pasta as P
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def khip():
+    import proof_systems_amd.khip as k
+    k.init(0)
+    return k
+
+
+def _limbs(F, vals):
+    return cref.ints_to_limbs([F.to_mont(v) for v in vals])
+
+
+def _aff(c, xy, inf):
+    if inf:
+        return None
+    return (c.base.from_mont(P.from_limbs(xy[:4])), c.base.from_mont(P.from_limbs(xy[4:])))
+
+
+def test_ser_regression_canonical_polycomm(khip, golden):
+    """poly-commitment/tests/commitment.rs:348-386 end to end on the device:
+    SRS::<Vesta>::create(128), DensePolynomial::rand(300, rng), srs.commit(&poly, 6, rng) -> expected bytes."""
+    kat = golden["commit_kat"]
+    c = P.VESTA
+    rng = P.StdRng(bytes(kat["seed"]))
+    g = khip.srs_generate(khip.VESTA, 0, kat["srs_depth"])          # SRS::create
+    srs = khip.Srs(khip.VESTA, g)
+    coeffs = [P.field_rand(P.Fp, rng) for _ in range(kat["com_length"] + 1)]
+    blinders = [P.field_rand(P.Fp, rng) for _ in range(kat["num_chunks"])]
+    out, inf = srs.commit_custom(_limbs(P.Fp, coeffs), kat["num_chunks"], _limbs(P.Fp, blinders))
+    got = P.msgpack_polycomm(c, [_aff(c, out[j], inf[j]) for j in range(len(out))])
+    want = bytes(kat["bytes"])
+    assert want[:len(got)] == got and not any(want[len(got):])
+    # blinding base == the h of srs/vesta.srs
+    assert bytes(cref.compress(0, srs.blinding_commitment().reshape(1, 8))[0]).hex() == golden["srs"]["vesta"]["h"]
+    # BlindersDontMatch (ipa.rs:611-613)
+    com, cinf = srs.commit_non_hiding(_limbs(P.Fp, coeffs), kat["num_chunks"])
+    with pytest.raises(khip.KhError) as e:
+        srs.mask_custom(com, cinf, _limbs(P.Fp, blinders[:5]))
+    assert e.value.code == khip.E_BLINDERS
+    srs.close()
+
+
+@pytest.mark.parametrize("cid", [0, 1])
+def test_commit_non_hiding_chunking_rules(khip, cid):
+    """ipa.rs:638-683 and src/pbt_srs.rs:20-84: zero polynomial -> one infinity; shorter than the SRS;
+    exactly the SRS size; several chunks with a ragged tail; padding up to num_chunks; never truncated."""
+    c = P.CURVES[cid]; F = c.scalar
+    n = 64
+    rnd = np.random.default_rng(3 + cid)
+    g = khip.srs_generate(cid, 0, n)
+    gpts = [_aff(c, g[i], False) for i in range(n)]
+    srs = khip.Srs(cid, g)
+    for length, num_chunks in [(0, 1), (0, 3), (10, 1), (n, 1), (n, 2), (n + 1, 2), (3 * n + 17, 4), (3 * n + 17, 2), (2 * n, 5)]:
+        coeffs = [int(rnd.integers(1, 1 << 62)) * 7919 % F.p for _ in range(length)]
+        out, inf = srs.commit_non_hiding(_limbs(F, coeffs).reshape(-1, 4), num_chunks)
+        want = P.commit_non_hiding(c, gpts, coeffs, num_chunks)
+        assert [_aff(c, out[j], inf[j]) for j in range(len(out))] == want, (length, num_chunks)
+    # trailing zero coefficients do not count (DensePolynomial is normalised)
+    coeffs = [5, 6, 7] + [0] * (n + 5)
+    out, inf = srs.commit_non_hiding(_limbs(F, coeffs), 1)
+    assert len(out) == 1 and _aff(c, out[0], inf[0]) == P.commit_non_hiding(c, gpts, coeffs, 1)[0]
+    srs.close()
+
+
+@pytest.mark.parametrize("cid", [0, 1])
+def test_lagrange_commitments(khip, cid):
+    """poly-commitment/tests/ipa_commitment.rs:26-119: commit_evaluations against the Lagrange basis equals
+    commit of the interpolated polynomial, for 1 chunk, for a domain larger than the SRS (2 chunks), and
+    with evaluations on a larger domain (stride sub-sampling, ipa.rs:717-722)."""
+    c = P.CURVES[cid]; F = c.scalar
+    fid = 0 if F is P.Fp else 1
+    k = 5; n = 1 << k
+    rnd = np.random.default_rng(11 + cid)
+    g = khip.srs_generate(cid, 0, n)
+    srs = khip.Srs(cid, g)
+    # one chunk
+    bxy, binf = cref.lagrange_basis(cid, g, k)
+    srs.set_lagrange(k, bxy, binf)
+    ev = cref.ints_to_limbs([int(v) for v in rnd.integers(0, 1 << 62, n)])
+    out, inf = srs.commit_evaluations_non_hiding(k, ev)
+    coeffs = cref.ntt(fid, ev, k, True)[0]
+    want, winf = srs.commit_non_hiding(coeffs, 1)
+    assert len(out) == 1 and np.array_equal(out, want) and not inf[0]
+    # evaluations on the 8x larger domain: only every 8th is used
+    ev8 = cref.ints_to_limbs([int(v) for v in rnd.integers(0, 1 << 62, 8 * n)])
+    out8, _ = srs.commit_evaluations_non_hiding(k, ev8)
+    want8, _ = srs.commit_evaluations_non_hiding(k, ev8[::8].copy())
+    assert np.array_equal(out8, want8)
+    # domain twice the SRS: two chunks per basis element
+    for ch in range(2):
+        bxy2, binf2 = cref.lagrange_basis(cid, g, k + 1, chunk=ch)
+        srs.set_lagrange(k + 1, bxy2, binf2, chunk=ch)
+    assert srs.lagrange_chunks(k + 1) == 2
+    ev2 = cref.ints_to_limbs([int(v) for v in rnd.integers(0, 1 << 62, 2 * n)])
+    out2, inf2 = srs.commit_evaluations_non_hiding(k + 1, ev2)
+    coeffs2 = cref.ntt(fid, ev2, k + 1, True)[0]
+    want2, winf2 = srs.commit_non_hiding(coeffs2, 2)
+    assert np.array_equal(out2, want2) and np.array_equal(inf2, winf2)
+    # desired domain larger than the evaluations' domain is the reference's panic
+    with pytest.raises(khip.KhError):
+        srs.commit_evaluations_non_hiding(k + 1, ev)
+    with pytest.raises(khip.KhError):
+        srs.commit_evaluations_non_hiding(9, ev)        # basis not registered
+    srs.close()
+
+
+@pytest.mark.parametrize("fid,F", [(0, P.Fp), (1, P.Fq)])
+def test_domain_generators(khip, golden, fid, F):
+    """kimchi/src/circuits/domains.rs:40-69: gen(d_{2k})^2 = gen(d_k); omega_{2^32} is the field's
+    TWO_ADIC_ROOT_OF_UNITY constant (curves/src/pasta/fields/{fp,fq}.rs)."""
+    w32 = P.from_limbs(khip.domain_generator(fid, 32))
+    assert w32 == int(golden["fields"]["Fp" if fid == 0 else "Fq"]["TWO_ADIC_ROOT_OF_UNITY"], 16)
+    for k in (1, 3, 11, 16, 19):
+        wk = F.from_mont(P.from_limbs(khip.domain_generator(fid, k)))
+        assert wk == F.root_of_unity(k)
+        w2k = F.from_mont(P.from_limbs(khip.domain_generator(fid, k + 1)))
+        assert w2k * w2k % F.p == wk
+
+
+def test_full_size_properties(khip):
+    """BASELINE-size properties that need no oracle run: linearity of the 2^20 MSM and an
+    NTT round trip / d1-in-d8 nesting at 2^16 -> 2^19 (kimchi/tests/test_domain.rs:25-71)."""
+    n = 1 << 18
+    rng = np.random.default_rng(99)
+    g = khip.srs_generate(khip.VESTA, 0, n)
+    srs = khip.Srs(khip.VESTA, g)
+
+    def rs(m):
+        s = rng.integers(0, 1 << 64, size=(m, 4), dtype=np.uint64)
+        s[:, 3] &= np.uint64((1 << 61) - 1)
+        return s
+
+    a, b = rs(n), rs(n)
+    ab = cref.field_op(0, "add", a, b)
+    pa, ia = srs.msm(a); pb, ib = srs.msm(b); pab, iab = srs.msm(ab)
+    s, sinf = cref.point_add(0, pa, pb, ia, ib)
+    assert sinf == iab and np.array_equal(s, pab)                 # MSM(a) + MSM(b) == MSM(a + b)
+    srs.close()
+    x = rs(2 << 16).reshape(2, 1 << 16, 4)
+    assert np.array_equal(khip.ntt(0, khip.ntt(0, x, 16, True), 16, False), x)
+    e8 = khip.lde(0, x, 16, 3)
+    assert np.array_equal(e8[:, ::8], khip.ntt(0, x, 16, False))
+    assert np.array_equal(khip.ntt(0, e8, 19, True)[:, : 1 << 16], x)
+    assert not khip.ntt(0, e8, 19, True)[:, 1 << 16:].any()
