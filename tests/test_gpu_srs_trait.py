@@ -152,3 +152,13 @@ def test_full_size_properties(khip):
     assert np.array_equal(e8[:, ::8], khip.ntt(0, x, 16, False))
     assert np.array_equal(khip.ntt(0, e8, 19, True)[:, : 1 << 16], x)
     assert not khip.ntt(0, e8, 19, True)[:, 1 << 16:].any()
+
+
+def test_cpp_host_mirror(khip):
+    """include/kimchi_hip.hpp (the C++ mirror of trait SRS / Evaluations / DensePolynomial) on the device."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cpp", "test_mirror")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "MIRROR_OK" in out.stdout, out.stdout + out.stderr
