@@ -27,6 +27,7 @@ typedef uint32_t u32;
 typedef uint64_t u64;
 
 #include "field_cols.inc"
+#include "field_mulasm.inc"
 
 struct FpParams {   // scalar field of Vesta, base field of Pallas
     static constexpr u32 P1 = 0x992d30edu, P2 = 0x094cf91bu, P3 = 0x224698fcu;
@@ -124,9 +125,23 @@ __device__ __forceinline__ Fe<F> neg(const Fe<F>& a) {
 template <class F>
 __device__ __forceinline__ Fe<F> dbl(const Fe<F>& a) { return add<F>(a, a); }
 
-// Montgomery product a*b*2^-256 mod p, fully reduced.
+// Montgomery product a*b*2^-256 mod p, fully reduced: one hand-scheduled asm block
+// (tools/gen_field_asm.py: 254 instructions, 104 v_mad_u64_u32).
 template <class F>
 __device__ __forceinline__ Fe<F> mul(const Fe<F>& a, const Fe<F>& b) {
+    Fe<F> r;
+    const u32 p1 = F::P1, p2 = F::P2, p3 = F::P3;
+    asm(KH_MONT_MUL_ASM
+        : "=&v"(r.v[0]), "=&v"(r.v[1]), "=&v"(r.v[2]), "=&v"(r.v[3]), "=&v"(r.v[4]), "=&v"(r.v[5]), "=&v"(r.v[6]), "=&v"(r.v[7])
+        : "v"(a.v[0]), "v"(a.v[1]), "v"(a.v[2]), "v"(a.v[3]), "v"(a.v[4]), "v"(a.v[5]), "v"(a.v[6]), "v"(a.v[7]),
+          "v"(b.v[0]), "v"(b.v[1]), "v"(b.v[2]), "v"(b.v[3]), "v"(b.v[4]), "v"(b.v[5]), "v"(b.v[6]), "v"(b.v[7]),
+          "v"(p1), "v"(p2), "v"(p3)
+        : KH_MONT_MUL_CLOBBERS);
+    return r;
+}
+// the same product through the per-column blocks (compiler-scheduled glue); kept for from_mont
+template <class F>
+__device__ __forceinline__ Fe<F> mul_cols(const Fe<F>& a, const Fe<F>& b) {
     u32 m[8]; u32 t[8];
     u64 lo = 0; u32 hi;
     const u32* A = a.v; const u32* B = b.v;
