@@ -106,6 +106,13 @@ int kh_msm_points(int curve, const uint64_t *xy /* n x 8 */, const uint8_t *inf 
                   const uint64_t *scalars, size_t n, int scalars_are_montgomery,
                   uint64_t out_xy[8], uint8_t *out_is_inf);
 
+/* k independent MSMs of the same length n with their own bases (xy: k x n x 8, inf: k x n or NULL,
+ * scalars: k x n x 4) in one pass -- the L and R commitments of an IPA round (ipa.rs:943-961) are
+ * two such MSMs that do not depend on each other. */
+int kh_msm_points_batch(int curve, const uint64_t *xy, const uint8_t *inf, const uint64_t *scalars,
+                        size_t n, size_t k, int scalars_are_montgomery,
+                        uint64_t *out_xy /* k x 8 */, uint8_t *out_is_inf /* k */);
+
 /* ---- commitment wrappers (host logic of the SRS trait over the MSM kernels) ----
  * kh_commit_non_hiding = SRS::commit_non_hiding (poly-commitment/src/ipa.rs:638-683):
  * coefficients (len x 4 limbs, Montgomery) are split into ceil(len / srs_size) chunks,

@@ -217,25 +217,30 @@ int kh_msm_batch_dev(kh_srs_t* srs, int basis, unsigned chunk, size_t offset, co
                      int scalars_are_montgomery, uint64_t* out_xy, uint8_t* out_is_inf) {
     return msm_common(srs, basis, chunk, offset, scalars_dev, true, n, k, scalars_are_montgomery, out_xy, out_is_inf);
 }
-int kh_msm_points(int curve, const uint64_t* xy, const uint8_t* inf, const uint64_t* scalars, size_t n,
-                  int scalars_are_montgomery, uint64_t out_xy[8], uint8_t* out_is_inf) {
+int kh_msm_points_batch(int curve, const uint64_t* xy, const uint8_t* inf, const uint64_t* scalars, size_t n, size_t k,
+                        int scalars_are_montgomery, uint64_t* out_xy, uint8_t* out_is_inf) {
     KH_REQUIRE(out_xy && out_is_inf, "null output pointer");
     KH_REQUIRE(curve == KH_CURVE_VESTA || curve == KH_CURVE_PALLAS, "unknown curve id %d", curve);
-    KH_REQUIRE((xy && scalars) || n == 0, "null input");
+    KH_REQUIRE((xy && scalars) || n == 0 || k == 0, "null input");
     int rc = ensure_init(); if (rc) return rc;
     Context& C = ctx();
     std::lock_guard<std::mutex> lk(C.mu);
-    if (n == 0) { memset(out_xy, 0, 64); *out_is_inf = 1; return KH_OK; }
-    if ((rc = C.ws_points.reserve(n * 64 + n))) return rc;
-    if ((rc = C.ws_scalars.reserve(n * 32))) return rc;
-    KH_HIP(hipMemcpyAsync(C.ws_points.p, xy, n * 64, hipMemcpyHostToDevice, C.stream));
-    MsmBasis b; b.pts = C.ws_points.p; b.n = n; b.inf = nullptr;
+    if (n == 0 || k == 0) { for (size_t j = 0; j < k; j++) { memset(out_xy + 8 * j, 0, 64); out_is_inf[j] = 1; } return KH_OK; }
+    const size_t tot = n * k;
+    if ((rc = C.ws_points.reserve(tot * 64 + tot))) return rc;
+    if ((rc = C.ws_scalars.reserve(tot * 32))) return rc;
+    KH_HIP(hipMemcpyAsync(C.ws_points.p, xy, tot * 64, hipMemcpyHostToDevice, C.stream));
+    MsmBasis b; b.pts = C.ws_points.p; b.n = tot; b.inf = nullptr; b.batch_stride = k > 1 ? n : 0;
     if (inf) {
-        KH_HIP(hipMemcpyAsync((char*)C.ws_points.p + n * 64, inf, n, hipMemcpyHostToDevice, C.stream));
-        b.inf = (const uint8_t*)C.ws_points.p + n * 64;
+        KH_HIP(hipMemcpyAsync((char*)C.ws_points.p + tot * 64, inf, tot, hipMemcpyHostToDevice, C.stream));
+        b.inf = (const uint8_t*)C.ws_points.p + tot * 64;
     }
-    KH_HIP(hipMemcpyAsync(C.ws_scalars.p, scalars, n * 32, hipMemcpyHostToDevice, C.stream));
-    return msm_run(C, curve, b, 0, C.ws_scalars.as<uint64_t>(), n, 1, scalars_are_montgomery, out_xy, out_is_inf);
+    KH_HIP(hipMemcpyAsync(C.ws_scalars.p, scalars, tot * 32, hipMemcpyHostToDevice, C.stream));
+    return msm_run(C, curve, b, 0, C.ws_scalars.as<uint64_t>(), n, k, scalars_are_montgomery, out_xy, out_is_inf);
+}
+int kh_msm_points(int curve, const uint64_t* xy, const uint8_t* inf, const uint64_t* scalars, size_t n,
+                  int scalars_are_montgomery, uint64_t out_xy[8], uint8_t* out_is_inf) {
+    return kh_msm_points_batch(curve, xy, inf, scalars, n, 1, scalars_are_montgomery, out_xy, out_is_inf);
 }
 
 // ---------------------------------------------------------------------------------- commitment wrappers

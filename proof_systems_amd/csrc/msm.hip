@@ -86,14 +86,14 @@ int exclusive_scan_u32(const u32* in, u32* out, size_t n, DevBuf& tmp, hipStream
 // ------------------------------------------------------------------------------------ 1 digits
 template <class SF>
 __global__ void k_digits(const u64* __restrict__ scalars, const uint8_t* __restrict__ inf, size_t inf_off,
-                         size_t n, int mont, int c, int W, int32_t* __restrict__ digits) {
+                         size_t inf_batch, size_t n, int mont, int c, int W, int32_t* __restrict__ digits) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     int j = blockIdx.y;
     if (i >= n) return;
     Fe<SF> s = Fe<SF>::load(scalars + ((size_t)j * n + i) * 4);
     if (mont) s = from_mont<SF>(s);
     else s = cond_sub_p<SF>(s.v);                         // tolerate one excess p in canonical input
-    bool skip = inf && inf[inf_off + i];
+    bool skip = inf && inf[inf_off + (size_t)j * inf_batch + i];
     u32 l[8];
 #pragma unroll
     for (int t = 0; t < 8; t++) l[t] = s.v[t];
@@ -120,6 +120,7 @@ struct SortGeom {
     int precomp;    // 1: all windows of an MSM share one bucket group
     size_t pt_stride;   // precomp: points per window table
     size_t pt_offset;   // first basis point used
+    size_t pt_batch;    // index step between the bases of consecutive MSMs of a batch (0: shared basis)
 };
 __device__ __forceinline__ void geom_ids(const SortGeom& g, int s, int w, int j, size_t& q, int& Sq, int& sigma) {
     if (g.precomp) { q = (size_t)j; Sq = g.W * g.S; sigma = w * g.S + s; }
@@ -163,7 +164,7 @@ __global__ void k_scatter(const int32_t* __restrict__ digits, SortGeom g, const 
     __syncthreads();
     size_t lo = g.n * (size_t)s / g.S, hi = g.n * (size_t)(s + 1) / g.S;
     const int32_t* d = digits + ((size_t)j * g.W + w) * g.n;
-    u32 pbase = (u32)(g.pt_offset + (g.precomp ? (size_t)w * g.pt_stride : 0));
+    u32 pbase = (u32)(g.pt_offset + (g.precomp ? (size_t)w * g.pt_stride : 0) + (size_t)j * g.pt_batch);
     for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
         int32_t v = d[i];
         if (v) {
@@ -197,9 +198,11 @@ k_accumulate(const u32* __restrict__ entries, const u32* __restrict__ off, const
     }
     size_t key = lo;
     u32 jt = (u32)t - toff[key];
-    u32 start = off[key] + jt * K;
-    u32 end = off[key + 1];
-    if (end > start + K) end = start + K;
+    // balanced split of the bucket's entries over its nt = ceil(cnt / K) tasks: the lanes of a wave
+    // run (almost) equally long chains instead of nt-1 full tasks + a short remainder
+    u32 o0 = off[key], cnt = off[key + 1] - o0, nt = toff[key + 1] - toff[key];
+    u32 start = o0 + (u32)(((u64)jt * cnt) / nt);
+    u32 end = o0 + (u32)(((u64)(jt + 1) * cnt) / nt);
     u32 e = entries[start];
     Aff<BF> p = Aff<BF>::load(pts + (size_t)(e & 0x7fffffffu) * 64);
     if (e >> 31) p.y = neg<BF>(p.y);
@@ -393,14 +396,24 @@ static int msm_run_t(Context& C, const MsmBasis& basis, size_t offset, const u64
     const u32 nb = 1u << (c - 1);
     const int precomp = basis.precomp_c ? 1 : 0;
     int S = (int)(n / 8192); if (S < 1) S = 1; if (S > 16) S = 16;
-    SortGeom g{n, nb, S, W, precomp, basis.n, offset};
+    SortGeom g{n, nb, S, W, precomp, basis.n, offset, basis.batch_stride};
     const size_t ngroups = precomp ? k : k * (size_t)W;
     const int Sq = precomp ? W * S : S;
     const size_t nkeys = ngroups * nb;
     const size_t M = n * (size_t)W * k;                 // upper bound on entries
-    u32 K = (u32)(M / 131072); if (K < 8) K = 8; if (K > 64) K = 64;
+    // Task size: the accumulation is one long dependent chain per thread, so a launch that needs
+    // 1.1 "rounds" of resident threads pays a whole extra chain at 10 % occupancy (measured: 1.80 ms
+    // instead of 1.72 ms at 2^20).  Size K so that all tasks are resident at once (4 waves/SIMD =
+    // 1024 threads per CU) whenever the bucket count allows it.
+    const size_t cap = (size_t)C.num_cus * 1024;
+    u32 K = 64;
+    if (nkeys < cap / 2) {
+        size_t room = cap - cap / 16 - nkeys / 2;          // ~ half of the buckets add a remainder task
+        K = (u32)((M + room - 1) / room);
+    }
+    if (K < 8) K = 8; if (K > 256) K = 256;
     const size_t max_tasks = M / K + nkeys + 1;
-    KH_REQUIRE(M < ((size_t)1 << 31) && (basis.n * (size_t)(precomp ? W : 1)) < ((size_t)1 << 31), "MSM too large for 31-bit entry indices (n=%zu k=%zu)", n, k);
+    KH_REQUIRE(M < ((size_t)1 << 31) && (basis.n * (size_t)(precomp ? W : 1) + basis.batch_stride * k) < ((size_t)1 << 31), "MSM too large for 31-bit entry indices (n=%zu k=%zu)", n, k);
 
     int rc;
     if ((rc = C.ws_digits.reserve(M * sizeof(int32_t)))) return rc;
@@ -422,7 +435,7 @@ static int msm_run_t(Context& C, const MsmBasis& basis, size_t offset, const u64
     C.timer.begin(s);
     // 1 digits
     hipLaunchKernelGGL((k_digits<SF>), dim3((unsigned)((n + 255) / 256), (unsigned)k), dim3(256), 0, s,
-                       scalars_dev, basis.inf, offset, n, mont, c, W, C.ws_digits.as<int32_t>());
+                       scalars_dev, basis.inf, offset, basis.batch_stride, n, mont, c, W, C.ws_digits.as<int32_t>());
     C.timer.mark("digits", s);
     // 2 histogram
     size_t lds = (size_t)nb * sizeof(u32);

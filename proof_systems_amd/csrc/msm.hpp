@@ -10,6 +10,7 @@ struct MsmBasis {
     const uint8_t* inf = nullptr;    // device, nullable per-point infinity flags
     size_t n = 0;                    // points per table
     int precomp_c = 0;               // 0: plain basis; else window width of the precomputed tables
+    size_t batch_stride = 0;         // >0: MSM j of a batch uses points [j*batch_stride, ...) (independent bases)
 };
 
 int msm_pick_window(size_t n);

@@ -34,7 +34,7 @@ SYMBOLS = [
     "kh_msm_batch_dev", "kh_ntt_dev", "kh_lde_dev", "kh_sync", "kh_last_timings",
     "kh_debug_field_op", "kh_debug_point_op", "kh_srs_generate", "kh_srs_h",
     "kh_commit_non_hiding", "kh_commit_evaluations_non_hiding", "kh_srs_set_blinding_base",
-    "kh_srs_get_blinding_base", "kh_mask_custom", "kh_domain_generator",
+    "kh_srs_get_blinding_base", "kh_mask_custom", "kh_domain_generator", "kh_msm_points_batch",
 ]
 
 _lib.kh_last_error.restype = C.c_char_p
@@ -51,6 +51,7 @@ _lib.kh_msm.argtypes = [C.c_void_p, C.c_int, C.c_uint, C.c_size_t, U64P, C.c_siz
 _lib.kh_msm_batch.argtypes = [C.c_void_p, C.c_int, C.c_uint, C.c_size_t, U64P, C.c_size_t, C.c_size_t, C.c_int, U64P, U8P]
 _lib.kh_msm_batch_dev.argtypes = [C.c_void_p, C.c_int, C.c_uint, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, U64P, U8P]
 _lib.kh_msm_points.argtypes = [C.c_int, U64P, U8P, U64P, C.c_size_t, C.c_int, U64P, U8P]
+_lib.kh_msm_points_batch.argtypes = [C.c_int, U64P, U8P, U64P, C.c_size_t, C.c_size_t, C.c_int, U64P, U8P]
 _lib.kh_ntt.argtypes = [C.c_int, U64P, C.c_uint, C.c_int, C.c_size_t]
 _lib.kh_lde.argtypes = [C.c_int, U64P, C.c_uint, C.c_uint, U64P, C.c_size_t]
 _lib.kh_ntt_dev.argtypes = [C.c_int, C.c_void_p, C.c_uint, C.c_int, C.c_size_t]
@@ -246,6 +247,19 @@ def msm_points(curve: int, xy, scalars, inf=None, mont: bool = True):
     oinf = np.zeros(1, dtype=np.uint8)
     _check(_lib.kh_msm_points(curve, _p64(xy), _p8(inf), _p64(sc), n, int(mont), _p64(out), _p8(oinf)))
     return out, bool(oinf[0])
+
+
+def msm_points_batch(curve: int, xy, scalars, inf=None, mont: bool = True):
+    """k independent MSMs: xy (k, n, 8), scalars (k, n, 4), inf (k, n) or None."""
+    xy = _c64(xy); sc = _c64(scalars)
+    assert xy.ndim == 3 and sc.ndim == 3 and xy.shape[:2] == sc.shape[:2]
+    k, n = xy.shape[0], xy.shape[1]
+    if inf is not None:
+        inf = np.ascontiguousarray(inf, dtype=np.uint8)
+    out = np.zeros((k, 8), dtype=np.uint64)
+    oinf = np.zeros(k, dtype=np.uint8)
+    _check(_lib.kh_msm_points_batch(curve, _p64(xy), _p8(inf), _p64(sc), n, k, int(mont), _p64(out), _p8(oinf)))
+    return out, oinf
 
 
 def ntt(field: int, data, log2_n: int, inverse: bool = False):

@@ -248,3 +248,20 @@ def test_lde(khip, fid, logn, logb):
 def test_smoke_entry(khip):
     import __graft_entry__ as ge
     ge.smoke()
+
+
+@pytest.mark.parametrize("cid", [0, 1])
+def test_msm_points_batch(khip, cid):
+    """Independent bases per MSM in one pass (the L / R pair of an IPA round, ipa.rs:943-961)."""
+    F = P.CURVES[cid].scalar
+    rng = np.random.default_rng(321 + cid)
+    for n, k in [(1, 2), (34, 2), (515, 3), (2050, 2)]:
+        g = cref.srs_generate(cid, 7, n * k, threads=8).reshape(k, n, 8)
+        sc = np.stack([rand_fe(rng, n, F) for _ in range(k)])
+        inf = np.zeros((k, n), np.uint8)
+        if n > 2:
+            inf[1, 2] = 1
+        got, ginf = khip.msm_points_batch(cid, g, sc, inf=inf)
+        for j in range(k):
+            want, winf = cref.msm(cid, g[j], sc[j], inf=inf[j])
+            assert bool(ginf[j]) == winf and (winf or np.array_equal(got[j], want)), (n, k, j)
