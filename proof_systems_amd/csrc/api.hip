@@ -164,9 +164,33 @@ int kh_srs_lagrange_chunks(const kh_srs_t* srs, unsigned log2_domain) {
     return it == srs->lagrange.end() ? 0 : (int)it->second.size();
 }
 int kh_srs_compute_lagrange(kh_srs_t* srs, unsigned log2_domain) {
-    (void)srs; (void)log2_domain;
-    set_error("kh_srs_compute_lagrange: device group-iNTT not built yet; register the basis with kh_srs_set_lagrange");
-    return KH_E_INVALID;
+    KH_REQUIRE(srs, "null SRS handle");
+    KH_REQUIRE(log2_domain <= 28, "log2_domain = %u too large", log2_domain);
+    int rc = ensure_init(); if (rc) return rc;
+    Context& C = ctx();
+    std::lock_guard<std::mutex> lk(C.mu);
+    const size_t n = (size_t)1 << log2_domain;
+    const unsigned num_chunks = (unsigned)((n + srs->n - 1) / srs->n);            // ipa.rs:1143-1144
+    auto& vec = srs->lagrange[log2_domain];
+    vec.clear(); vec.resize(num_chunks);
+    const bool pre = n >= MSM_PRECOMP_MIN_N && !getenv("KH_NO_PRECOMP");
+    const int W = (256 + MSM_PRECOMP_C - 1) / MSM_PRECOMP_C;
+    for (unsigned c = 0; c < num_chunks; c++) {
+        std::unique_ptr<LagrangeChunk> L(new LagrangeChunk);
+        L->n = n;
+        if ((rc = L->pts.reserve(n * 64 * (pre ? W : 1)))) return rc;
+        if ((rc = L->inf.reserve(n))) return rc;
+        if ((rc = lagrange_run(C, srs->curve, srs->g.p, srs->n, log2_domain, c, L->pts.p, L->inf.as<uint8_t>()))) return rc;
+        std::vector<uint8_t> hinf(n);
+        KH_HIP(hipMemcpy(hinf.data(), L->inf.p, n, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < n; i++) if (hinf[i]) { L->has_inf = true; break; }
+        if (pre) {
+            if ((rc = msm_precompute(C, srs->curve, L->pts.p, L->has_inf ? L->inf.as<uint8_t>() : nullptr, n, MSM_PRECOMP_C))) return rc;
+            L->precomp_c = MSM_PRECOMP_C;
+        }
+        vec[c] = std::move(L);
+    }
+    return KH_OK;
 }
 int kh_srs_get_lagrange(kh_srs_t* srs, unsigned log2_domain, unsigned chunk, uint64_t* out_xy, uint8_t* out_inf) {
     KH_REQUIRE(srs && out_xy, "kh_srs_get_lagrange: null argument");

@@ -24,6 +24,9 @@ int debug_field_op(Context& C, int field, int op, const uint64_t* a, const uint6
 int debug_point_op(Context& C, int curve, int op, const uint64_t* p, const uint8_t* pinf, const uint64_t* q, const uint8_t* qinf, uint8_t* out, size_t n);
 
 // ntt.hip
+int ntt_build_twiddles(Context& C, int field, unsigned logn, int inverse, uint64_t* tab);
+// lagrange.hip
+int lagrange_run(Context& C, int curve, const void* g_dev, size_t srs_size, unsigned log_n, unsigned chunk, void* out_xy_dev, uint8_t* out_inf_dev);
 khost::fe ntt_host_root(int field, unsigned logn, int inverse);   // omega_{2^logn} (or its inverse), Montgomery
 int ntt_run(Context& C, int field, uint64_t* data_dev, unsigned log2_n, int inverse, size_t batch);
 int lde_run(Context& C, int field, const uint64_t* coeffs_dev, unsigned log2_n, unsigned log2_blowup, uint64_t* out_dev, size_t batch);

@@ -28,7 +28,7 @@
 
 namespace kh {
 
-static constexpr int NTT_THREADS = 256;
+static constexpr int NTT_THREADS = 512;
 static constexpr int NTT_LOG_TILE = 11;                 // R*T = 2048 elements per workgroup
 static constexpr int NTT_MAX_LOGR = 8;
 
@@ -205,25 +205,32 @@ khost::fe ntt_host_root(int field, unsigned logn, int inverse) {
     return acc;
 }
 
+// w^e (or w^-e), e < max(n/2, 1), into a caller-provided device buffer of (n/2 + 32) x 32 bytes
+int ntt_build_twiddles(Context& C, int field, unsigned logn, int inverse, u64* tab) {
+    khost::Fld F(field);
+    khost::fe pow2[32];
+    pow2[0] = ntt_host_root(field, logn, inverse);
+    for (int i = 1; i < 32; i++) pow2[i] = F.sqr(pow2[i - 1]);
+    u64 count = logn ? ((u64)1 << (logn - 1)) : 1;
+    u64* dpow = tab + count * 4;
+    KH_HIP(hipMemcpyAsync(dpow, pow2, sizeof(pow2), hipMemcpyHostToDevice, C.stream));
+    KH_HIP(hipStreamSynchronize(C.stream));       // pow2 is a stack buffer
+    dim3 grid((unsigned)((count + 255) / 256));
+    if (field == KH_FIELD_FP) hipLaunchKernelGGL((k_build_twiddles<FpParams>), grid, dim3(256), 0, C.stream, tab, dpow, count);
+    else hipLaunchKernelGGL((k_build_twiddles<FqParams>), grid, dim3(256), 0, C.stream, tab, dpow, count);
+    KH_HIP(hipGetLastError());
+    return KH_OK;
+}
+
 static int get_twiddles(Context& C, int field, unsigned logn, int inverse, TwEntry** out) {
     TwKey key{field, logn, inverse};
     auto it = g_tw.find(key);
     if (it != g_tw.end()) { *out = &it->second; return KH_OK; }
     TwEntry& E = g_tw[key];
     khost::Fld F(field);
-    khost::fe w = ntt_host_root(field, logn, inverse);
-    khost::fe pow2[32];
-    pow2[0] = w;
-    for (int i = 1; i < 32; i++) pow2[i] = F.sqr(pow2[i - 1]);
     u64 count = logn ? ((u64)1 << (logn - 1)) : 1;
     int rc = E.tab.reserve(count * 32 + 32 * 32); if (rc) { g_tw.erase(key); return rc; }
-    u64* dpow = E.tab.as<u64>() + count * 4;
-    KH_HIP(hipMemcpyAsync(dpow, pow2, sizeof(pow2), hipMemcpyHostToDevice, C.stream));
-    KH_HIP(hipStreamSynchronize(C.stream));       // pow2 is a stack buffer
-    dim3 grid((unsigned)((count + 255) / 256));
-    if (field == KH_FIELD_FP) hipLaunchKernelGGL((k_build_twiddles<FpParams>), grid, dim3(256), 0, C.stream, E.tab.as<u64>(), dpow, count);
-    else hipLaunchKernelGGL((k_build_twiddles<FqParams>), grid, dim3(256), 0, C.stream, E.tab.as<u64>(), dpow, count);
-    KH_HIP(hipGetLastError());
+    if ((rc = ntt_build_twiddles(C, field, logn, inverse, E.tab.as<u64>()))) { g_tw.erase(key); return rc; }
     khost::fe nn = {{(u64)1 << logn, 0, 0, 0}};
     E.inv_n = F.inv(F.to_mont(nn));
     *out = &E;

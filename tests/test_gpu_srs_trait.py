@@ -162,3 +162,40 @@ def test_cpp_host_mirror(khip):
     assert os.path.exists(exe), "run __graft_entry__.build() first"
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "MIRROR_OK" in out.stdout, out.stdout + out.stderr
+
+
+@pytest.mark.parametrize("cid", [0, 1])
+def test_compute_lagrange_on_device(khip, cid):
+    """SRS::lagrange_basis (ipa.rs:1065-1172) as a device group-iNTT: equal to the oracle's basis point
+    for point (incl. the chunked case n > srs size), and consistent with commit(interpolate(.))
+    at a size where the precomputed window tables are used (tests/ipa_commitment.rs:26-119)."""
+    c = P.CURVES[cid]; F = c.scalar
+    fid = 0 if F is P.Fp else 1
+    g = khip.srs_generate(cid, 0, 256)
+    srs = khip.Srs(cid, g)
+    for k in (0, 1, 4, 8):
+        srs.compute_lagrange(k)
+        assert srs.lagrange_chunks(k) == 1
+        got, ginf = srs.get_lagrange(k)
+        want, winf = cref.lagrange_basis(cid, g[: 1 << k] if (1 << k) <= 256 else g, k)
+        assert np.array_equal(ginf, winf) and np.array_equal(got[winf == 0], want[winf == 0]), k
+    srs.close()
+    small = khip.Srs(cid, g[:32])
+    small.compute_lagrange(7)                         # domain 128 over an SRS of 32: 4 chunks
+    assert small.lagrange_chunks(7) == 4
+    for ch in range(4):
+        got, ginf = small.get_lagrange(7, ch)
+        want, winf = cref.lagrange_basis(cid, g[:32], 7, chunk=ch)
+        assert np.array_equal(ginf, winf) and np.array_equal(got[winf == 0], want[winf == 0]), ch
+    small.close()
+    # 2^11: basis goes through the window-table path; commit_evaluations == commit(interpolate)
+    n = 1 << 11
+    g2 = khip.srs_generate(cid, 0, n)
+    s2 = khip.Srs(cid, g2)
+    s2.compute_lagrange(11)
+    rnd = np.random.default_rng(5 + cid)
+    ev = cref.ints_to_limbs([int(v) for v in rnd.integers(0, 1 << 62, n)])
+    a, ainf = s2.commit_evaluations_non_hiding(11, ev)
+    b, binf = s2.commit_non_hiding(khip.ntt(fid, ev, 11, True)[0], 1)
+    assert np.array_equal(a, b) and not ainf[0] and not binf[0]
+    s2.close()
