@@ -79,6 +79,11 @@ def msm(curve: int, xy, scalars, inf=None, scalars_mont=True, threads=1, naive=F
     return out, bool(oinf.value)
 
 
+def last_threads() -> int:
+    """threads actually used by the last msm() call"""
+    return lib().ko_last_threads()
+
+
 def ntt(field: int, data, log2_n: int, inverse: bool, threads: int = 1):
     d = np.array(data, dtype=np.uint64, copy=True).reshape(-1, 1 << log2_n, 4)
     rc = lib().ko_ntt(field, _p64(d), log2_n, int(inverse), C.c_size_t(d.shape[0]), threads)

@@ -348,18 +348,21 @@ int ko_is_on_curve(int curve, const u64 *xy) {
 /* digits are precomputed once (n * nwin int32): signed digits in [-2^(c-1), 2^(c-1)] */
 typedef struct {
     const field_t *f; const aff *pts; const uint8_t *inf; const int32_t *digits; size_t n;
-    int c, nwin, w_begin, w_end; jac *win_sums;
+    int c, nwin, job_begin, job_end, slices; jac *win_sums;   /* win_sums[w * slices + s] */
 } msm_job2;
 
+/* job = (window w, point slice s): its own bucket set over points [n*s/slices, n*(s+1)/slices) */
 static void *msm_worker2(void *arg) {
     msm_job2 *J = (msm_job2 *)arg;
     const field_t *f = J->f;
     size_t nb = (size_t)1 << (J->c - 1);
     jac *buckets = (jac *)malloc(sizeof(jac) * nb);
-    for (int w = J->w_begin; w < J->w_end; w++) {
+    for (int job = J->job_begin; job < J->job_end; job++) {
+        int w = job / J->slices, sl = job % J->slices;
+        size_t i0 = J->n * (size_t)sl / (size_t)J->slices, i1 = J->n * (size_t)(sl + 1) / (size_t)J->slices;
         for (size_t b = 0; b < nb; b++) j_set_inf(f, &buckets[b]);
         const int32_t *dg = J->digits + (size_t)w * J->n;
-        for (size_t i = 0; i < J->n; i++) {
+        for (size_t i = i0; i < i1; i++) {
             int32_t d = dg[i];
             if (d == 0) continue;
             size_t b = (size_t)(d < 0 ? -d : d) - 1;
@@ -370,11 +373,14 @@ static void *msm_worker2(void *arg) {
             j_add(f, &run, &run, &buckets[b]);
             j_add(f, &acc, &acc, &run);
         }
-        J->win_sums[w] = acc;
+        J->win_sums[job] = acc;
     }
     free(buckets);
     return NULL;
 }
+
+static int g_last_threads = 1;
+int ko_last_threads(void) { return g_last_threads; }
 
 static int pick_window(size_t n) {
     int lg = 0; while (((size_t)1 << (lg + 1)) <= n) lg++;
@@ -416,21 +422,27 @@ int ko_msm(int curve, const u64 *xy, const uint8_t *inf, const u64 *scalars, siz
         }
     }
     if (threads < 1) threads = 1;
-    if (threads > nwin) threads = nwin;
-    jac *win_sums = (jac *)malloc(sizeof(jac) * (size_t)nwin);
+    /* like the reference (rayon over windows, plus the 2-way "vertical" split of ipa.rs:652-662), but
+     * with as many point slices as the thread budget allows */
+    int slices = threads / nwin; if (slices < 1) slices = 1;
+    while (slices > 1 && n / (size_t)slices < (nb << 1)) slices--;    /* keep slices >= 2 * #buckets points */
+    int njobs = nwin * slices;
+    if (threads > njobs) threads = njobs;
+    jac *win_sums = (jac *)malloc(sizeof(jac) * (size_t)njobs);
     pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)threads);
     msm_job2 *jobs = (msm_job2 *)malloc(sizeof(msm_job2) * (size_t)threads);
     for (int t = 0; t < threads; t++) {
         jobs[t] = (msm_job2){f, (const aff *)xy, inf, digits, n, c, nwin,
-                             (int)((long)nwin * t / threads), (int)((long)nwin * (t + 1) / threads), win_sums};
+                             (int)((long)njobs * t / threads), (int)((long)njobs * (t + 1) / threads), slices, win_sums};
         if (threads == 1) msm_worker2(&jobs[t]);
         else pthread_create(&th[t], NULL, msm_worker2, &jobs[t]);
     }
     if (threads > 1) for (int t = 0; t < threads; t++) pthread_join(th[t], NULL);
     for (int w = nwin - 1; w >= 0; w--) {
         for (int k = 0; k < c; k++) j_dbl(f, &total, &total);
-        j_add(f, &total, &total, &win_sums[w]);
+        for (int sl = 0; sl < slices; sl++) j_add(f, &total, &total, &win_sums[w * slices + sl]);
     }
+    g_last_threads = threads;
     store_aff(f, &total, out_xy, out_inf);
     free(jobs); free(th); free(win_sums); free(digits);
     return 0;
