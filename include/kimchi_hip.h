@@ -168,6 +168,15 @@ int kh_dev_download(void *dst_host, const void *src_dev, size_t bytes);
 int kh_msm_batch_dev(kh_srs_t *srs, int basis, unsigned chunk, size_t offset,
                      const uint64_t *scalars_dev, size_t n, size_t k, int scalars_are_montgomery,
                      uint64_t *out_xy /* host, k x 8 */, uint8_t *out_is_inf /* host, k */);
+/* Pipelined form of kh_msm_batch_dev: kh_msm_submit enqueues all device work on one of the
+ * library's two MSM pipeline slots and returns at once; kh_msm_wait blocks for that job and
+ * finishes it (XYZZ -> affine on the host).  With two jobs in flight the latency-bound tail
+ * (bucket reduction) of one MSM overlaps the sort + bucket accumulation of the next.
+ * At most 2 un-waited tickets; a third submit returns KH_E_INVALID. */
+int kh_msm_submit(kh_srs_t *srs, int basis, unsigned chunk, size_t offset,
+                  const uint64_t *scalars_dev, size_t n, size_t k, int scalars_are_montgomery,
+                  uint64_t *ticket);
+int kh_msm_wait(uint64_t ticket, uint64_t *out_xy /* host, k x 8 */, uint8_t *out_is_inf /* host, k */);
 int kh_ntt_dev(int field, uint64_t *data_dev, unsigned log2_n, int inverse, size_t batch);
 int kh_lde_dev(int field, const uint64_t *coeffs_dev, unsigned log2_n, unsigned log2_blowup,
                uint64_t *out_dev, size_t batch);

@@ -425,7 +425,7 @@ int ko_msm(int curve, const u64 *xy, const uint8_t *inf, const u64 *scalars, siz
     /* like the reference (rayon over windows, plus the 2-way "vertical" split of ipa.rs:652-662), but
      * with as many point slices as the thread budget allows */
     int slices = threads / nwin; if (slices < 1) slices = 1;
-    while (slices > 1 && n / (size_t)slices < (nb << 1)) slices--;    /* keep slices >= 2 * #buckets points */
+    while (slices > 1 && n / (size_t)slices < (nb << 3)) slices--;    /* keep >= 8 points per bucket and slice */
     int njobs = nwin * slices;
     if (threads > njobs) threads = njobs;
     jac *win_sums = (jac *)malloc(sizeof(jac) * (size_t)njobs);

@@ -34,7 +34,12 @@ static int do_init(int device_id) {
     }
     KH_REQUIRE(device_id < count, "device %d out of range (count=%d)", device_id, count);
     KH_HIP(hipSetDevice(device_id));
-    KH_HIP(hipStreamCreateWithFlags(&C.stream, hipStreamNonBlocking));
+    for (int i = 0; i < MSM_SLOTS; i++) {
+        KH_HIP(hipStreamCreateWithFlags(&C.slot[i].stream, hipStreamNonBlocking));
+        KH_HIP(hipEventCreateWithFlags(&C.slot[i].done, hipEventDisableTiming));
+        int rc2 = C.slot[i].timer.init(); if (rc2) return rc2;
+    }
+    C.stream = C.slot[0].stream;
     hipDeviceProp_t prop;
     KH_HIP(hipGetDeviceProperties(&prop, device_id));
     C.num_cus = prop.multiProcessorCount;
@@ -45,12 +50,12 @@ static int do_init(int device_id) {
 }
 int ensure_init() { return ctx().ready ? KH_OK : do_init(-1); }
 
-void collect_timings(Context& C) {
+void collect_timings(Context& C, PhaseTimer& T) {
     C.last.clear();
-    if (!C.timer.created || !C.timer.enabled) return;
-    for (int i = 0; i < C.timer.n; i++) {
+    if (!T.created || !T.enabled) return;
+    for (int i = 0; i < T.n; i++) {
         float ms = 0.f;
-        if (hipEventElapsedTime(&ms, C.timer.ev[i], C.timer.ev[i + 1]) == hipSuccess) C.last.emplace_back(C.timer.names[i], ms);
+        if (hipEventElapsedTime(&ms, T.ev[i], T.ev[i + 1]) == hipSuccess) C.last.emplace_back(T.names[i], ms);
     }
 }
 
@@ -206,27 +211,67 @@ int kh_srs_get_lagrange(kh_srs_t* srs, unsigned log2_domain, unsigned chunk, uin
 }
 
 // ---------------------------------------------------------------------------------- MSM
+static int free_slot(Context& C) {
+    for (int i = 0; i < MSM_SLOTS; i++) if (!C.slot[i].busy) return i;
+    return -1;
+}
+// enqueue on a free slot; returns the slot index through *slot_out
+static int msm_submit_locked(Context& C, kh_srs_t* srs, int basis, unsigned chunk, size_t offset, const uint64_t* scalars,
+                             bool scalars_on_device, size_t n, size_t k, int mont, int* slot_out) {
+    MsmBasis b; int rc = resolve_basis(srs, basis, chunk, b); if (rc) return rc;
+    KH_REQUIRE(offset <= b.n, "offset %zu beyond basis length %zu", offset, b.n);
+    size_t use = n < b.n - offset ? n : b.n - offset;      // msm_bigint semantics: min(len) pairs
+    int si = free_slot(C);
+    KH_REQUIRE(si >= 0, "all %d MSM pipeline slots hold an un-waited job (kh_msm_wait first)", MSM_SLOTS);
+    MsmSlot& S = C.slot[si];
+    const uint64_t* sdev = scalars;
+    if (!scalars_on_device && use > 0 && k > 0) {
+        if ((rc = S.ws_scalars.reserve(k * use * 32))) return rc;
+        if (use == n) KH_HIP(hipMemcpyAsync(S.ws_scalars.p, scalars, k * n * 32, hipMemcpyHostToDevice, S.stream));
+        else for (size_t j = 0; j < k; j++)
+            KH_HIP(hipMemcpyAsync((char*)S.ws_scalars.p + j * use * 32, scalars + j * n * 4, use * 32, hipMemcpyHostToDevice, S.stream));
+        sdev = S.ws_scalars.as<uint64_t>();
+    } else if (scalars_on_device) {
+        KH_REQUIRE(use == n || k == 1, "device-resident batched scalars must not exceed the basis window");
+    }
+    rc = msm_enqueue(C, S, srs->curve, b, offset, sdev, use, k, mont);
+    if (rc) return rc;
+    *slot_out = si;
+    return KH_OK;
+}
 static int msm_common(kh_srs_t* srs, int basis, unsigned chunk, size_t offset, const uint64_t* scalars, bool scalars_on_device,
                       size_t n, size_t k, int mont, uint64_t* out_xy, uint8_t* out_inf) {
     KH_REQUIRE(out_xy && out_inf, "null output pointer");
     KH_REQUIRE(scalars || n == 0 || k == 0, "null scalars");
     int rc = ensure_init(); if (rc) return rc;
-    MsmBasis b; rc = resolve_basis(srs, basis, chunk, b); if (rc) return rc;
-    KH_REQUIRE(offset <= b.n, "offset %zu beyond basis length %zu", offset, b.n);
-    size_t use = n < b.n - offset ? n : b.n - offset;      // msm_bigint semantics: min(len) pairs
     Context& C = ctx();
     std::lock_guard<std::mutex> lk(C.mu);
-    const uint64_t* sdev = scalars;
-    if (!scalars_on_device && use > 0 && k > 0) {
-        if ((rc = C.ws_scalars.reserve(k * use * 32))) return rc;
-        if (use == n) KH_HIP(hipMemcpyAsync(C.ws_scalars.p, scalars, k * n * 32, hipMemcpyHostToDevice, C.stream));
-        else for (size_t j = 0; j < k; j++)
-            KH_HIP(hipMemcpyAsync((char*)C.ws_scalars.p + j * use * 32, scalars + j * n * 4, use * 32, hipMemcpyHostToDevice, C.stream));
-        sdev = C.ws_scalars.as<uint64_t>();
-    } else if (scalars_on_device) {
-        KH_REQUIRE(use == n || k == 1, "device-resident batched scalars must not exceed the basis window");
-    }
-    return msm_run(C, srs->curve, b, offset, sdev, use, k, mont, out_xy, out_inf);
+    int si = -1;
+    if ((rc = msm_submit_locked(C, srs, basis, chunk, offset, scalars, scalars_on_device, n, k, mont, &si))) return rc;
+    return msm_finish(C, C.slot[si], out_xy, out_inf);
+}
+
+int kh_msm_submit(kh_srs_t* srs, int basis, unsigned chunk, size_t offset, const uint64_t* scalars_dev, size_t n, size_t k,
+                  int scalars_are_montgomery, uint64_t* ticket) {
+    KH_REQUIRE(ticket, "null ticket pointer");
+    KH_REQUIRE(scalars_dev || n == 0 || k == 0, "null scalars");
+    int rc = ensure_init(); if (rc) return rc;
+    Context& C = ctx();
+    std::lock_guard<std::mutex> lk(C.mu);
+    int si = -1;
+    if ((rc = msm_submit_locked(C, srs, basis, chunk, offset, scalars_dev, true, n, k, scalars_are_montgomery, &si))) return rc;
+    *ticket = C.slot[si].ticket;
+    return KH_OK;
+}
+int kh_msm_wait(uint64_t ticket, uint64_t* out_xy, uint8_t* out_is_inf) {
+    KH_REQUIRE(out_xy && out_is_inf, "null output pointer");
+    int rc = ensure_init(); if (rc) return rc;
+    Context& C = ctx();
+    std::lock_guard<std::mutex> lk(C.mu);
+    for (int i = 0; i < MSM_SLOTS; i++)
+        if (C.slot[i].busy && C.slot[i].ticket == ticket) return msm_finish(C, C.slot[i], out_xy, out_is_inf);
+    set_error("unknown or already waited MSM ticket %llu", (unsigned long long)ticket);
+    return KH_E_INVALID;
 }
 
 int kh_msm(kh_srs_t* srs, int basis, unsigned chunk, size_t offset, const uint64_t* scalars, size_t n,
@@ -251,16 +296,20 @@ int kh_msm_points_batch(int curve, const uint64_t* xy, const uint8_t* inf, const
     std::lock_guard<std::mutex> lk(C.mu);
     if (n == 0 || k == 0) { for (size_t j = 0; j < k; j++) { memset(out_xy + 8 * j, 0, 64); out_is_inf[j] = 1; } return KH_OK; }
     const size_t tot = n * k;
-    if ((rc = C.ws_points.reserve(tot * 64 + tot))) return rc;
-    if ((rc = C.ws_scalars.reserve(tot * 32))) return rc;
-    KH_HIP(hipMemcpyAsync(C.ws_points.p, xy, tot * 64, hipMemcpyHostToDevice, C.stream));
-    MsmBasis b; b.pts = C.ws_points.p; b.n = tot; b.inf = nullptr; b.batch_stride = k > 1 ? n : 0;
+    int si = free_slot(C);
+    KH_REQUIRE(si >= 0, "all %d MSM pipeline slots hold an un-waited job (kh_msm_wait first)", MSM_SLOTS);
+    MsmSlot& S = C.slot[si];
+    if ((rc = S.ws_points.reserve(tot * 64 + tot))) return rc;
+    if ((rc = S.ws_scalars.reserve(tot * 32))) return rc;
+    KH_HIP(hipMemcpyAsync(S.ws_points.p, xy, tot * 64, hipMemcpyHostToDevice, S.stream));
+    MsmBasis b; b.pts = S.ws_points.p; b.n = tot; b.inf = nullptr; b.batch_stride = k > 1 ? n : 0;
     if (inf) {
-        KH_HIP(hipMemcpyAsync((char*)C.ws_points.p + tot * 64, inf, tot, hipMemcpyHostToDevice, C.stream));
-        b.inf = (const uint8_t*)C.ws_points.p + tot * 64;
+        KH_HIP(hipMemcpyAsync((char*)S.ws_points.p + tot * 64, inf, tot, hipMemcpyHostToDevice, S.stream));
+        b.inf = (const uint8_t*)S.ws_points.p + tot * 64;
     }
-    KH_HIP(hipMemcpyAsync(C.ws_scalars.p, scalars, tot * 32, hipMemcpyHostToDevice, C.stream));
-    return msm_run(C, curve, b, 0, C.ws_scalars.as<uint64_t>(), n, k, scalars_are_montgomery, out_xy, out_is_inf);
+    KH_HIP(hipMemcpyAsync(S.ws_scalars.p, scalars, tot * 32, hipMemcpyHostToDevice, S.stream));
+    if ((rc = msm_enqueue(C, S, curve, b, 0, S.ws_scalars.as<uint64_t>(), n, k, scalars_are_montgomery))) return rc;
+    return msm_finish(C, S, out_xy, out_is_inf);
 }
 int kh_msm_points(int curve, const uint64_t* xy, const uint8_t* inf, const uint64_t* scalars, size_t n,
                   int scalars_are_montgomery, uint64_t out_xy[8], uint8_t* out_is_inf) {
@@ -392,7 +441,7 @@ int kh_ntt(int field, uint64_t* data, unsigned log2_n, int inverse, size_t batch
     if ((rc = ntt_run(C, field, C.ws_ntt_a.as<uint64_t>(), log2_n, inverse, batch))) return rc;
     KH_HIP(hipMemcpyAsync(data, C.ws_ntt_a.p, bytes, hipMemcpyDeviceToHost, C.stream));
     KH_HIP(hipStreamSynchronize(C.stream));
-    collect_timings(C);
+    collect_timings(C, C.timer);
     return KH_OK;
 }
 int kh_lde(int field, const uint64_t* coeffs, unsigned log2_n, unsigned log2_blowup, uint64_t* out, size_t batch) {
@@ -410,7 +459,7 @@ int kh_lde(int field, const uint64_t* coeffs, unsigned log2_n, unsigned log2_blo
     if ((rc = lde_run(C, field, C.ws_ntt_a.as<uint64_t>(), log2_n, log2_blowup, C.ws_ntt_b.as<uint64_t>(), batch))) return rc;
     KH_HIP(hipMemcpyAsync(out, C.ws_ntt_b.p, out_bytes, hipMemcpyDeviceToHost, C.stream));
     KH_HIP(hipStreamSynchronize(C.stream));
-    collect_timings(C);
+    collect_timings(C, C.timer);
     return KH_OK;
 }
 
@@ -436,8 +485,9 @@ int kh_sync(void) {
     int rc = ensure_init(); if (rc) return rc;
     Context& C = ctx();
     std::lock_guard<std::mutex> lk(C.mu);
-    KH_HIP(hipStreamSynchronize(C.stream));
-    collect_timings(C);
+    for (int i = 0; i < MSM_SLOTS; i++) KH_HIP(hipStreamSynchronize(C.slot[i].stream));
+    if (C.timer.n > 0) collect_timings(C, C.timer);
+    C.timer.n = 0;
     return KH_OK;
 }
 int kh_last_timings(const char** names, float* ms, int cap) {

@@ -70,18 +70,35 @@ struct PhaseTimer {
     }
 };
 
+// One MSM pipeline slot: its own stream, workspace and result staging, so that two MSMs can be in
+// flight (kh_msm_submit / kh_msm_wait): the latency-bound tail of one overlaps the sort and the
+// bucket accumulation of the next.
+struct MsmSlot {
+    hipStream_t stream = nullptr;
+    PhaseTimer timer;
+    DevBuf ws_scalars, ws_digits, ws_hist, ws_cnt, ws_off, ws_ntask, ws_toff, ws_entries, ws_partial,
+        ws_buckets, ws_seg, ws_out, ws_scan_tmp, ws_biglist, ws_points;
+    void* pinned = nullptr; size_t pinned_cap = 0;      // host staging of the group sums (XYZZ)
+    hipEvent_t done = nullptr;
+    // pending job (set by enqueue, consumed by finish)
+    bool busy = false;
+    uint64_t ticket = 0;
+    int curve = 0, W = 0, c = 0, precomp = 0;
+    size_t k = 0, ngroups = 0;
+};
+static constexpr int MSM_SLOTS = 2;
+
 struct Context {
     std::mutex mu;            // serialises device work issued through the C ABI
     int device = -1;
     bool ready = false;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;      // = slot[0].stream: the library's main stream
     int num_cus = 256;
-    PhaseTimer timer;
+    PhaseTimer timer;                  // NTT / LDE phases (MSM phases are per slot)
     // last timings (filled after a sync)
     std::vector<std::pair<std::string, float>> last;
-    // MSM workspace
-    DevBuf ws_scalars, ws_digits, ws_hist, ws_cnt, ws_off, ws_ntask, ws_toff, ws_entries, ws_partial,
-        ws_buckets, ws_seg, ws_out, ws_scan_tmp, ws_biglist, ws_misc, ws_points;
+    MsmSlot slot[MSM_SLOTS];
+    uint64_t next_ticket = 1;
     // NTT workspace
     DevBuf ws_ntt_a, ws_ntt_b;
     void* pinned = nullptr; size_t pinned_cap = 0;
@@ -89,7 +106,7 @@ struct Context {
 
 Context& ctx();
 int ensure_init();
-void collect_timings(Context& c);
+void collect_timings(Context& c, PhaseTimer& t);
 
 // device exclusive scan of n u32 values (in may alias out); tmp is workspace
 int exclusive_scan_u32(const uint32_t* in, uint32_t* out, size_t n, DevBuf& tmp, hipStream_t s);

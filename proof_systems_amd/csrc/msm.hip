@@ -387,8 +387,8 @@ int msm_pick_window(size_t n) {
 }
 
 template <class CFG>
-static int msm_run_t(Context& C, const MsmBasis& basis, size_t offset, const u64* scalars_dev, size_t n, size_t k,
-                     int mont, int curve, uint64_t* out_xy, uint8_t* out_inf) {
+static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t offset, const u64* scalars_dev, size_t n, size_t k,
+                         int mont, int curve) {
     typedef typename CFG::Base BF; typedef typename CFG::Scalar SF;
     hipStream_t s = C.stream;
     const int c = basis.precomp_c ? basis.precomp_c : msm_pick_window(n);
@@ -405,7 +405,7 @@ static int msm_run_t(Context& C, const MsmBasis& basis, size_t offset, const u64
     // 1.1 "rounds" of resident threads pays a whole extra chain at 10 % occupancy (measured: 1.80 ms
     // instead of 1.72 ms at 2^20).  Size K so that all tasks are resident at once (4 waves/SIMD =
     // 1024 threads per CU) whenever the bucket count allows it.
-    const size_t cap = (size_t)C.num_cus * 1024;
+    const size_t cap = (size_t)Ctx.num_cus * 1024;
     u32 K = 64;
     if (nkeys < cap / 2) {
         size_t room = cap - cap / 16 - nkeys / 2;          // ~ half of the buckets add a remainder task
@@ -483,20 +483,49 @@ static int msm_run_t(Context& C, const MsmBasis& basis, size_t offset, const u64
     }
     C.timer.mark("reduce", s);
     KH_HIP(hipGetLastError());
-    // 8 finish on host
-    std::vector<khost::xyzz> res(ngroups);
-    KH_HIP(hipMemcpyAsync(res.data(), C.ws_out.p, ngroups * 128, hipMemcpyDeviceToHost, s));
-    KH_HIP(hipStreamSynchronize(s));
-    collect_timings(C);
-    khost::Crv crv(curve);
-    for (size_t j = 0; j < k; j++) {
+    // group sums -> pinned host staging; the host part runs in msm_finish
+    if (C.pinned_cap < ngroups * 128) {
+        if (C.pinned) (void)hipHostFree(C.pinned);
+        C.pinned = nullptr; C.pinned_cap = 0;
+        KH_HIP(hipHostMalloc(&C.pinned, ngroups * 128 + 4096, hipHostMallocDefault));
+        C.pinned_cap = ngroups * 128 + 4096;
+    }
+    KH_HIP(hipMemcpyAsync(C.pinned, C.ws_out.p, ngroups * 128, hipMemcpyDeviceToHost, s));
+    KH_HIP(hipEventRecord(C.done, s));
+    C.busy = true; C.ticket = Ctx.next_ticket++;
+    C.curve = curve; C.W = W; C.c = c; C.precomp = precomp; C.k = k; C.ngroups = ngroups;
+    return KH_OK;
+}
+
+int msm_enqueue(Context& C, MsmSlot& S, int curve, const MsmBasis& basis, size_t offset, const uint64_t* scalars_dev, size_t n, size_t k, int mont) {
+    if (n == 0 || k == 0) {          // nothing to launch: finish() emits k identities
+        S.busy = true; S.ticket = C.next_ticket++; S.curve = curve; S.k = k; S.ngroups = 0; S.W = 0; S.c = 0; S.precomp = 1;
+        KH_HIP(hipEventRecord(S.done, S.stream));
+        return KH_OK;
+    }
+    if (curve == KH_CURVE_VESTA) return msm_enqueue_t<VestaCfg>(C, S, basis, offset, scalars_dev, n, k, mont, curve);
+    return msm_enqueue_t<PallasCfg>(C, S, basis, offset, scalars_dev, n, k, mont, curve);
+}
+
+// 8 finish on the host: wait for the slot, Horner over the window sums (plain path), XYZZ -> affine
+int msm_finish(Context& C, MsmSlot& S, uint64_t* out_xy, uint8_t* out_inf) {
+    KH_HIP(hipEventSynchronize(S.done));
+    S.busy = false;
+    collect_timings(C, S.timer);
+    if (S.ngroups == 0) {
+        for (size_t j = 0; j < S.k; j++) { memset(out_xy + 8 * j, 0, 64); out_inf[j] = 1; }
+        return KH_OK;
+    }
+    const khost::xyzz* res = (const khost::xyzz*)S.pinned;
+    khost::Crv crv(S.curve);
+    for (size_t j = 0; j < S.k; j++) {
         khost::xyzz total;
-        if (precomp) total = res[j];
+        if (S.precomp) total = res[j];
         else {
             total = crv.identity();
-            for (int w = W - 1; w >= 0; w--) {
-                for (int t = 0; t < c; t++) total = crv.dbl(total);
-                total = crv.add(total, res[j * W + w]);
+            for (int w = S.W - 1; w >= 0; w--) {
+                for (int t = 0; t < S.c; t++) total = crv.dbl(total);
+                total = crv.add(total, res[j * S.W + w]);
             }
         }
         khost::aff a;
@@ -505,16 +534,6 @@ static int msm_run_t(Context& C, const MsmBasis& basis, size_t offset, const u64
         out_inf[j] = inf ? 1 : 0;
     }
     return KH_OK;
-}
-
-int msm_run(Context& C, int curve, const MsmBasis& basis, size_t offset, const uint64_t* scalars_dev, size_t n, size_t k,
-            int mont, uint64_t* out_xy, uint8_t* out_inf) {
-    if (n == 0 || k == 0) {
-        for (size_t j = 0; j < k; j++) { memset(out_xy + 8 * j, 0, 64); out_inf[j] = 1; }
-        return KH_OK;
-    }
-    if (curve == KH_CURVE_VESTA) return msm_run_t<VestaCfg>(C, basis, offset, scalars_dev, n, k, mont, curve, out_xy, out_inf);
-    return msm_run_t<PallasCfg>(C, basis, offset, scalars_dev, n, k, mont, curve, out_xy, out_inf);
 }
 
 int msm_precompute(Context& C, int curve, void* tables, const uint8_t* inf, size_t n, int c) {

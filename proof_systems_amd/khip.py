@@ -34,7 +34,7 @@ SYMBOLS = [
     "kh_msm_batch_dev", "kh_ntt_dev", "kh_lde_dev", "kh_sync", "kh_last_timings",
     "kh_debug_field_op", "kh_debug_point_op", "kh_srs_generate", "kh_srs_h",
     "kh_commit_non_hiding", "kh_commit_evaluations_non_hiding", "kh_srs_set_blinding_base",
-    "kh_srs_get_blinding_base", "kh_mask_custom", "kh_domain_generator", "kh_msm_points_batch",
+    "kh_srs_get_blinding_base", "kh_mask_custom", "kh_domain_generator", "kh_msm_points_batch", "kh_msm_submit", "kh_msm_wait",
 ]
 
 _lib.kh_last_error.restype = C.c_char_p
@@ -51,6 +51,8 @@ _lib.kh_msm.argtypes = [C.c_void_p, C.c_int, C.c_uint, C.c_size_t, U64P, C.c_siz
 _lib.kh_msm_batch.argtypes = [C.c_void_p, C.c_int, C.c_uint, C.c_size_t, U64P, C.c_size_t, C.c_size_t, C.c_int, U64P, U8P]
 _lib.kh_msm_batch_dev.argtypes = [C.c_void_p, C.c_int, C.c_uint, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, U64P, U8P]
 _lib.kh_msm_points.argtypes = [C.c_int, U64P, U8P, U64P, C.c_size_t, C.c_int, U64P, U8P]
+_lib.kh_msm_submit.argtypes = [C.c_void_p, C.c_int, C.c_uint, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.POINTER(C.c_uint64)]
+_lib.kh_msm_wait.argtypes = [C.c_uint64, U64P, U8P]
 _lib.kh_msm_points_batch.argtypes = [C.c_int, U64P, U8P, U64P, C.c_size_t, C.c_size_t, C.c_int, U64P, U8P]
 _lib.kh_ntt.argtypes = [C.c_int, U64P, C.c_uint, C.c_int, C.c_size_t]
 _lib.kh_lde.argtypes = [C.c_int, U64P, C.c_uint, C.c_uint, U64P, C.c_size_t]
@@ -215,6 +217,20 @@ class Srs:
         out = np.zeros((k, 8), dtype=np.uint64)
         inf = np.zeros(k, dtype=np.uint8)
         _check(_lib.kh_msm_batch(self._h, basis, chunk, offset, _p64(sc), n, k, int(mont), _p64(out), _p8(inf)))
+        return out, inf
+
+    def msm_submit(self, scalars_dev: int, n: int, k: int, basis: int = BASIS_G, chunk: int = 0, offset: int = 0, mont: bool = True):
+        """Enqueue k MSMs (device-resident scalars) on a free pipeline slot; returns a ticket for msm_wait."""
+        t = C.c_uint64(0)
+        _check(_lib.kh_msm_submit(self._h, basis, chunk, offset, C.c_void_p(scalars_dev), n, k, int(mont), C.byref(t)))
+        return (t.value, k)
+
+    @staticmethod
+    def msm_wait(ticket):
+        t, k = ticket
+        out = np.zeros((k, 8), dtype=np.uint64)
+        inf = np.zeros(k, dtype=np.uint8)
+        _check(_lib.kh_msm_wait(t, _p64(out), _p8(inf)))
         return out, inf
 
     def msm_batch_dev(self, scalars_dev: int, n: int, k: int, basis: int = BASIS_G, chunk: int = 0, offset: int = 0, mont: bool = True):
