@@ -96,22 +96,27 @@ __device__ __forceinline__ Fe<F> cond_sub_p(const u32 t[8]) {
     return r;
 }
 
+#define KH_FE_BINOP_OPERANDS                                                                                              \
+    : "=&v"(r.v[0]), "=&v"(r.v[1]), "=&v"(r.v[2]), "=&v"(r.v[3]), "=&v"(r.v[4]), "=&v"(r.v[5]), "=&v"(r.v[6]), "=&v"(r.v[7])   \
+    : "v"(a.v[0]), "v"(a.v[1]), "v"(a.v[2]), "v"(a.v[3]), "v"(a.v[4]), "v"(a.v[5]), "v"(a.v[6]), "v"(a.v[7]),              \
+      "v"(b.v[0]), "v"(b.v[1]), "v"(b.v[2]), "v"(b.v[3]), "v"(b.v[4]), "v"(b.v[5]), "v"(b.v[6]), "v"(b.v[7]),              \
+      "v"(p1), "v"(p2), "v"(p3)
+
+// a + b mod p: carry chain, trial subtraction of p, select (24 instructions; the compiler's
+// rendering of the same C expression was ~55: every madd does seven of these)
 template <class F>
 __device__ __forceinline__ Fe<F> add(const Fe<F>& a, const Fe<F>& b) {
-    u32 t[8]; u32 c = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) { u64 s = (u64)a.v[i] + b.v[i] + c; t[i] = (u32)s; c = (u32)(s >> 32); }
-    return cond_sub_p<F>(t);      // a + b < 2p < 2^256: no carry out
+    Fe<F> r;
+    const u32 p1 = F::P1, p2 = F::P2, p3 = F::P3;
+    asm(KH_FE_ADD_ASM KH_FE_BINOP_OPERANDS : KH_FE_ADD_CLOBBERS);
+    return r;
 }
+// a - b mod p: borrow chain, masked add-back of p (22 instructions)
 template <class F>
 __device__ __forceinline__ Fe<F> sub(const Fe<F>& a, const Fe<F>& b) {
-    u32 t[8]; u32 br = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) { u64 d = (u64)a.v[i] - b.v[i] - br; t[i] = (u32)d; br = (u32)(d >> 63); }
-    u32 mask = 0u - br;          // add p back if we borrowed
-    Fe<F> r; u32 c = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) { u64 s = (u64)t[i] + (Fe<F>::pw(i) & mask) + c; r.v[i] = (u32)s; c = (u32)(s >> 32); }
+    Fe<F> r;
+    const u32 p1 = F::P1, p2 = F::P2, p3 = F::P3;
+    asm(KH_FE_SUB_ASM KH_FE_BINOP_OPERANDS : KH_FE_SUB_CLOBBERS);
     return r;
 }
 template <class F>
