@@ -426,7 +426,14 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
     if ((rc = C.ws_partial.reserve(max_tasks * 128))) return rc;
     if ((rc = C.ws_buckets.reserve(nkeys * 128))) return rc;
     if ((rc = C.ws_biglist.reserve((nkeys + 1) * sizeof(u32)))) return rc;
-    u32 m = precomp ? 1u : 4u; if (nb < m) m = nb;
+    // segment length of the weighted reduction: one bucket per thread (a 15-bit double-and-add each)
+    // is the shortest chain, but its work grows with the bucket count -- for batches use running
+    // sums over m buckets (2 additions per bucket + one double-and-add per segment), keeping about
+    // one wave per SIMD busy
+    u32 m = 1;
+    while (m < 16 && (ngroups * (size_t)nb) / m > 65536) m <<= 1;
+    if (!precomp && m < 4) m = 4;
+    if (nb < m) m = nb;
     const u32 nseg = nb / m;
     const u32 nblk1 = (nseg + SUM_BLK - 1) / SUM_BLK;
     if ((rc = C.ws_seg.reserve(ngroups * (size_t)(nseg + nblk1) * 128))) return rc;
