@@ -175,29 +175,76 @@ __global__ void k_scatter(const int32_t* __restrict__ digits, SortGeom g, const 
     }
 }
 // ------------------------------------------------------------------------------------ tasks
-__global__ void k_ntask(const u32* __restrict__ off, size_t nkeys, u32 K, u32* __restrict__ nt) {
+static constexpr u32 MAX_K = 256;           // upper bound of the task length (length bins of the task ordering)
+__global__ void k_ntask(const u32* __restrict__ off, size_t nkeys, u32 K, u32* __restrict__ nt, u32* __restrict__ len_hist) {
+    __shared__ u32 h[MAX_K + 1];
+    for (u32 i = threadIdx.x; i <= MAX_K; i += blockDim.x) h[i] = 0;
+    __syncthreads();
     size_t key = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (key > nkeys) return;
-    if (key == nkeys) { nt[key] = 0; return; }
-    u32 c = off[key + 1] - off[key];
-    nt[key] = (c + K - 1) / K;
+    if (key <= nkeys) {
+        u32 n_t = 0;
+        if (key < nkeys) {
+            u32 c = off[key + 1] - off[key];
+            n_t = (c + K - 1) / K;
+            u32 len = n_t ? (c + n_t - 1) / n_t : 0;
+            atomicAdd(&h[len], 1u);
+        }
+        nt[key] = n_t;
+    }
+    __syncthreads();
+    for (u32 i = threadIdx.x; i <= MAX_K; i += blockDim.x) if (h[i]) atomicAdd(&len_hist[i], h[i]);
+}
+// Task ordering: keys are ranked by the length of their tasks, longest first, so that the 64 lanes of
+// a wave run chains of (nearly) the same length (bucket sizes are Poisson-distributed: +-20 % at 32
+// entries per bucket) and the short tasks fill the end of the launch.
+// len_hist -> cursor[L] = first rank of length L (descending order)
+__global__ void k_len_starts(const u32* __restrict__ len_hist, u32* __restrict__ cursor) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        u32 run = 0;
+        for (int L = (int)MAX_K; L >= 0; L--) { cursor[L] = run; run += len_hist[L]; }
+    }
+}
+__global__ void __launch_bounds__(256)
+k_len_rank(const u32* __restrict__ off, const u32* __restrict__ nt, size_t nkeys,
+           u32* __restrict__ cursor, u32* __restrict__ order, u32* __restrict__ rnt) {
+    // two levels: rank inside the block with LDS atomics, then ONE global cursor increment per
+    // (block, length) -- per-wave increments serialise on the few hot lengths (measured 0.6 ms)
+    __shared__ u32 cnt[MAX_K + 1], base[MAX_K + 1];
+    for (u32 i = threadIdx.x; i <= MAX_K; i += blockDim.x) cnt[i] = 0;
+    __syncthreads();
+    size_t key = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool active = key < nkeys;
+    u32 n_t = 0, len = 0, local = 0;
+    if (active) {
+        n_t = nt[key];
+        u32 c = off[key + 1] - off[key];
+        len = n_t ? (c + n_t - 1) / n_t : 0;
+        local = atomicAdd(&cnt[len], 1u);
+    }
+    __syncthreads();
+    for (u32 i = threadIdx.x; i <= MAX_K; i += blockDim.x) if (cnt[i]) base[i] = atomicAdd(&cursor[i], cnt[i]);
+    __syncthreads();
+    if (active) { u32 rank = base[len] + local; order[rank] = (u32)key; rnt[rank] = n_t; }
+    if (key == nkeys) rnt[nkeys] = 0;
 }
 // ------------------------------------------------------------------------------------ 5 accumulate
 template <class BF>
 __global__ void __launch_bounds__(256)
 k_accumulate(const u32* __restrict__ entries, const u32* __restrict__ off, const u32* __restrict__ toff,
+             const u32* __restrict__ roff, const u32* __restrict__ order,
              size_t nkeys, u32 K, const uint8_t* __restrict__ pts, uint8_t* __restrict__ partial) {
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    u32 NT = toff[nkeys];
+    u32 NT = roff[nkeys];
     if (t >= NT) return;
-    // binary search: largest key with toff[key] <= t
-    size_t lo = 0, hi = nkeys;           // invariant toff[lo] <= t < toff[hi]
+    // binary search over the length-ranked keys: largest rank with roff[rank] <= t
+    size_t lo = 0, hi = nkeys;           // invariant roff[lo] <= t < roff[hi]
     while (hi - lo > 1) {
         size_t mid = (lo + hi) >> 1;
-        if (toff[mid] <= (u32)t) lo = mid; else hi = mid;
+        if (roff[mid] <= (u32)t) lo = mid; else hi = mid;
     }
-    size_t key = lo;
-    u32 jt = (u32)t - toff[key];
+    size_t key = order[lo];
+    u32 jt = (u32)t - roff[lo];
+    t = (size_t)toff[key] + jt;          // the partial's slot stays in key order (k_bucket_sum)
     // balanced split of the bucket's entries over its nt = ceil(cnt / K) tasks: the lanes of a wave
     // run (almost) equally long chains instead of nt-1 full tasks + a short remainder
     u32 o0 = off[key], cnt = off[key + 1] - o0, nt = toff[key + 1] - toff[key];
@@ -411,7 +458,7 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
         size_t room = cap - cap / 16 - nkeys / 2;          // ~ half of the buckets add a remainder task
         K = (u32)((M + room - 1) / room);
     }
-    if (K < 8) K = 8; if (K > 256) K = 256;
+    if (K < 8) K = 8; if (K > MAX_K) K = MAX_K;
     const size_t max_tasks = M / K + nkeys + 1;
     KH_REQUIRE(M < ((size_t)1 << 31) && (basis.n * (size_t)(precomp ? W : 1) + basis.batch_stride * k) < ((size_t)1 << 31), "MSM too large for 31-bit entry indices (n=%zu k=%zu)", n, k);
 
@@ -426,6 +473,7 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
     if ((rc = C.ws_partial.reserve(max_tasks * 128))) return rc;
     if ((rc = C.ws_buckets.reserve(nkeys * 128))) return rc;
     if ((rc = C.ws_biglist.reserve((nkeys + 1) * sizeof(u32)))) return rc;
+    if ((rc = C.ws_order.reserve((2 * (MAX_K + 1) + 3 * (nkeys + 2)) * sizeof(u32)))) return rc;
     // segment length of the weighted reduction: one bucket per thread (a 15-bit double-and-add each)
     // is the shortest chain, but its work grows with the bucket count -- for batches use running
     // sums over m buckets (2 additions per bucket + one double-and-add per segment), keeping about
@@ -465,13 +513,22 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
                        C.ws_off.as<u32>(), C.ws_entries.as<u32>());
     C.timer.mark("scatter", s);
     // tasks
-    hipLaunchKernelGGL(k_ntask, dim3((unsigned)((nkeys + 1 + 255) / 256)), dim3(256), 0, s, C.ws_off.as<u32>(), nkeys, K, C.ws_ntask.as<u32>());
+    u32* len_hist = C.ws_order.as<u32>();                       // [MAX_K+1] histogram, [MAX_K+1] cursors, then order / rnt / roff
+    u32* cursor = len_hist + (MAX_K + 1);
+    u32* order = cursor + (MAX_K + 1);
+    u32* rnt = order + (nkeys + 2);
+    u32* roff = rnt + (nkeys + 2);
+    KH_HIP(hipMemsetAsync(len_hist, 0, (MAX_K + 1) * sizeof(u32), s));
+    hipLaunchKernelGGL(k_ntask, dim3((unsigned)((nkeys + 1 + 255) / 256)), dim3(256), 0, s, C.ws_off.as<u32>(), nkeys, K, C.ws_ntask.as<u32>(), len_hist);
     if ((rc = exclusive_scan_u32(C.ws_ntask.as<u32>(), C.ws_toff.as<u32>(), nkeys + 1, C.ws_scan_tmp, s))) return rc;
+    hipLaunchKernelGGL(k_len_starts, dim3(1), dim3(64), 0, s, len_hist, cursor);
+    hipLaunchKernelGGL(k_len_rank, dim3((unsigned)((nkeys + 1 + 255) / 256)), dim3(256), 0, s, C.ws_off.as<u32>(), C.ws_ntask.as<u32>(), nkeys, cursor, order, rnt);
+    if ((rc = exclusive_scan_u32(rnt, roff, nkeys + 1, C.ws_scan_tmp, s))) return rc;
     KH_HIP(hipMemsetAsync(C.ws_biglist.p, 0, sizeof(u32), s));
     C.timer.mark("tasks", s);
     // 5 accumulate
     hipLaunchKernelGGL((k_accumulate<BF>), dim3((unsigned)((max_tasks + 255) / 256)), dim3(256), 0, s,
-                       C.ws_entries.as<u32>(), C.ws_off.as<u32>(), C.ws_toff.as<u32>(), nkeys, K,
+                       C.ws_entries.as<u32>(), C.ws_off.as<u32>(), C.ws_toff.as<u32>(), roff, order, nkeys, K,
                        (const uint8_t*)basis.pts, C.ws_partial.as<uint8_t>());
     C.timer.mark("accumulate", s);
     // 6 bucket sums
