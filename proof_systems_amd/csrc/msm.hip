@@ -242,7 +242,7 @@ k_accumulate(const u32* __restrict__ entries, const u32* __restrict__ off, const
         size_t mid = (lo + hi) >> 1;
         if (roff[mid] <= (u32)t) lo = mid; else hi = mid;
     }
-    size_t key = order[lo];
+    size_t key = order ? order[lo] : lo;
     u32 jt = (u32)t - roff[lo];
     t = (size_t)toff[key] + jt;          // the partial's slot stays in key order (k_bucket_sum)
     // balanced split of the bucket's entries over its nt = ceil(cnt / K) tasks: the lanes of a wave
@@ -521,9 +521,13 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
     KH_HIP(hipMemsetAsync(len_hist, 0, (MAX_K + 1) * sizeof(u32), s));
     hipLaunchKernelGGL(k_ntask, dim3((unsigned)((nkeys + 1 + 255) / 256)), dim3(256), 0, s, C.ws_off.as<u32>(), nkeys, K, C.ws_ntask.as<u32>(), len_hist);
     if ((rc = exclusive_scan_u32(C.ws_ntask.as<u32>(), C.ws_toff.as<u32>(), nkeys + 1, C.ws_scan_tmp, s))) return rc;
-    hipLaunchKernelGGL(k_len_starts, dim3(1), dim3(64), 0, s, len_hist, cursor);
-    hipLaunchKernelGGL(k_len_rank, dim3((unsigned)((nkeys + 1 + 255) / 256)), dim3(256), 0, s, C.ws_off.as<u32>(), C.ws_ntask.as<u32>(), nkeys, cursor, order, rnt);
-    if ((rc = exclusive_scan_u32(rnt, roff, nkeys + 1, C.ws_scan_tmp, s))) return rc;
+    if (M >= ((size_t)1 << 18)) {
+        hipLaunchKernelGGL(k_len_starts, dim3(1), dim3(64), 0, s, len_hist, cursor);
+        hipLaunchKernelGGL(k_len_rank, dim3((unsigned)((nkeys + 1 + 255) / 256)), dim3(256), 0, s, C.ws_off.as<u32>(), C.ws_ntask.as<u32>(), nkeys, cursor, order, rnt);
+        if ((rc = exclusive_scan_u32(rnt, roff, nkeys + 1, C.ws_scan_tmp, s))) return rc;
+    } else {                     // small problems are launch-latency bound: keep the key order
+        order = nullptr; roff = C.ws_toff.as<u32>();
+    }
     KH_HIP(hipMemsetAsync(C.ws_biglist.p, 0, sizeof(u32), s));
     C.timer.mark("tasks", s);
     // 5 accumulate
@@ -581,22 +585,24 @@ int msm_finish(Context& C, MsmSlot& S, uint64_t* out_xy, uint8_t* out_inf) {
         return KH_OK;
     }
     const khost::xyzz* res = (const khost::xyzz*)S.pinned;
-    khost::Crv crv(S.curve);
-    for (size_t j = 0; j < S.k; j++) {
+    const MsmSlot* Sp = &S;
+    auto finish_one = [res, Sp, out_xy, out_inf](size_t j) {
+        khost::Crv crv(Sp->curve);
         khost::xyzz total;
-        if (S.precomp) total = res[j];
-        else {
+        if (Sp->precomp) total = res[j];
+        else {                                        // Horner over the window sums: ~256 doublings (~70 us)
             total = crv.identity();
-            for (int w = S.W - 1; w >= 0; w--) {
-                for (int t = 0; t < S.c; t++) total = crv.dbl(total);
-                total = crv.add(total, res[j * S.W + w]);
+            for (int w = Sp->W - 1; w >= 0; w--) {
+                for (int t = 0; t < Sp->c; t++) total = crv.dbl(total);
+                total = crv.add(total, res[j * Sp->W + w]);
             }
         }
         khost::aff a;
         bool inf = crv.to_affine(total, a);
         memcpy(out_xy + 8 * j, &a, 64);
         out_inf[j] = inf ? 1 : 0;
-    }
+    };
+    for (size_t j = 0; j < S.k; j++) finish_one(j);
     return KH_OK;
 }
 
