@@ -292,3 +292,32 @@ def test_msm_submit_wait_pipeline(khip):
     for b in bufs:
         b.free()
     srs.close()
+
+
+def test_concurrent_callers(khip):
+    """The SRS is Sync + Send and is called from 15 rayon workers at once (kimchi/src/prover.rs:329-351):
+    concurrent kh_msm / kh_ntt calls from several host threads give the single-threaded results."""
+    import threading
+    rng = np.random.default_rng(2718)
+    n = 1 << 11
+    g = cref.srs_generate(0, 0, n, threads=8)
+    srs = khip.Srs(0, g)
+    cols = [rand_fe_fast(rng, n) for _ in range(8)]
+    want = [srs.msm(c) for c in cols]
+    want_ntt = [khip.ntt(0, c, 11, True) for c in cols]
+    got = [None] * 8
+    got_ntt = [None] * 8
+
+    def work(j):
+        got[j] = srs.msm(cols[j])
+        got_ntt[j] = khip.ntt(0, cols[j], 11, True)
+
+    th = [threading.Thread(target=work, args=(j,)) for j in range(8)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for j in range(8):
+        assert got[j][1] == want[j][1] and np.array_equal(got[j][0], want[j][0])
+        assert np.array_equal(got_ntt[j], want_ntt[j])
+    srs.close()
