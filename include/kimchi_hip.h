@@ -169,10 +169,11 @@ int kh_msm_batch_dev(kh_srs_t *srs, int basis, unsigned chunk, size_t offset,
                      const uint64_t *scalars_dev, size_t n, size_t k, int scalars_are_montgomery,
                      uint64_t *out_xy /* host, k x 8 */, uint8_t *out_is_inf /* host, k */);
 /* Pipelined form of kh_msm_batch_dev: kh_msm_submit enqueues all device work on one of the
- * library's two MSM pipeline slots and returns at once; kh_msm_wait blocks for that job and
- * finishes it (XYZZ -> affine on the host).  With two jobs in flight the latency-bound tail
- * (bucket reduction) of one MSM overlaps the sort + bucket accumulation of the next.
- * At most 2 un-waited tickets; a third submit returns KH_E_INVALID. */
+ * library's four MSM pipeline slots and returns at once; kh_msm_wait blocks for that job and
+ * finishes it (XYZZ -> affine on the host).  With jobs in flight the sort of one MSM and the
+ * latency-bound tail (bucket reduction) of another run underneath the bucket accumulation of a third.
+ * At most KH_MSM_SLOTS (4) un-waited tickets; a further submit returns KH_E_INVALID. */
+#define KH_MSM_SLOTS 4
 int kh_msm_submit(kh_srs_t *srs, int basis, unsigned chunk, size_t offset,
                   const uint64_t *scalars_dev, size_t n, size_t k, int scalars_are_montgomery,
                   uint64_t *ticket);

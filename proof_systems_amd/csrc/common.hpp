@@ -70,9 +70,10 @@ struct PhaseTimer {
     }
 };
 
-// One MSM pipeline slot: its own stream, workspace and result staging, so that two MSMs can be in
-// flight (kh_msm_submit / kh_msm_wait): the latency-bound tail of one overlaps the sort and the
-// bucket accumulation of the next.
+// One MSM pipeline slot: its own stream, workspace and result staging, so that several MSMs can be in
+// flight (kh_msm_submit / kh_msm_wait).  k_accumulate is held to 112 VGPRs so that the sort kernels
+// (4-16 VGPRs) of the NEXT job fit beside its 4 waves per SIMD: with three slots the sort of job i+2
+// and the latency-bound tail of job i both run underneath the accumulation of job i+1.
 struct MsmSlot {
     hipStream_t stream = nullptr;
     PhaseTimer timer;
@@ -86,7 +87,7 @@ struct MsmSlot {
     int curve = 0, W = 0, c = 0, precomp = 0;
     size_t k = 0, ngroups = 0;
 };
-static constexpr int MSM_SLOTS = 2;
+static constexpr int MSM_SLOTS = 4;
 
 struct Context {
     std::mutex mu;            // serialises device work issued through the C ABI

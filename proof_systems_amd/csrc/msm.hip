@@ -229,7 +229,7 @@ k_len_rank(const u32* __restrict__ off, const u32* __restrict__ nt, size_t nkeys
 }
 // ------------------------------------------------------------------------------------ 5 accumulate
 template <class BF>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(112)))
 k_accumulate(const u32* __restrict__ entries, const u32* __restrict__ off, const u32* __restrict__ toff,
              const u32* __restrict__ roff, const u32* __restrict__ order,
              size_t nkeys, u32 K, const uint8_t* __restrict__ pts, uint8_t* __restrict__ partial) {

@@ -24,6 +24,7 @@ U8P = C.POINTER(C.c_uint8)
 VESTA, PALLAS = 0, 1
 FP, FQ = 0, 1
 BASIS_G = -1
+MSM_SLOTS = 4          # KH_MSM_SLOTS: jobs kh_msm_submit accepts before kh_msm_wait
 
 # every symbol include/kimchi_hip.h declares
 SYMBOLS = [

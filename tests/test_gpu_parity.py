@@ -268,27 +268,29 @@ def test_msm_points_batch(khip, cid):
 
 
 def test_msm_submit_wait_pipeline(khip):
-    """Two MSMs in flight on the two pipeline slots give the same results as the synchronous calls;
-    a third un-waited submit is refused; tickets cannot be waited twice."""
+    """KH_MSM_SLOTS jobs in flight give the same results as the synchronous calls; one more
+    un-waited submit is refused; tickets cannot be waited twice."""
     rng = np.random.default_rng(77)
     n = 1 << 12
+    slots = khip.MSM_SLOTS
     g = cref.srs_generate(0, 0, n, threads=8)
     srs = khip.Srs(0, g)
-    scs = [rand_fe_fast(rng, n) for _ in range(5)]
+    scs = [rand_fe_fast(rng, n) for _ in range(2 * slots + 1)]
     bufs = [khip.DevBuf(s.nbytes).upload(s) for s in scs]
     want = [srs.msm(s) for s in scs]
-    tickets = [srs.msm_submit(bufs[0].ptr, n, 1), srs.msm_submit(bufs[1].ptr, n, 1)]
+    tickets = [srs.msm_submit(bufs[i].ptr, n, 1) for i in range(slots)]
     with pytest.raises(khip.KhError):
-        srs.msm_submit(bufs[2].ptr, n, 1)
+        srs.msm_submit(bufs[slots].ptr, n, 1)
     got = []
-    for i in range(2, 5):
+    for i in range(slots, len(scs)):
         got.append(srs.msm_wait(tickets.pop(0)))
         tickets.append(srs.msm_submit(bufs[i].ptr, n, 1))
+    last = tickets[-1]
     got += [srs.msm_wait(t) for t in tickets]
     for (o, i), (wo, wi) in zip(got, want):
         assert bool(i[0]) == wi and np.array_equal(o[0], wo)
     with pytest.raises(khip.KhError):
-        srs.msm_wait(tickets[0])
+        srs.msm_wait(last)
     for b in bufs:
         b.free()
     srs.close()
