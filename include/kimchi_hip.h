@@ -113,6 +113,17 @@ int kh_msm_points_batch(int curve, const uint64_t *xy, const uint8_t *inf, const
                         size_t n, size_t k, int scalars_are_montgomery,
                         uint64_t *out_xy /* k x 8 */, uint8_t *out_is_inf /* k */);
 
+/* ---- IPA round vector operations (poly-commitment/src/ipa.rs:980-1006) -----
+ * out[i] = lo[i] + u * hi[i]      (a' = a_lo + u^-1 a_hi with u := u^-1; b' = b_lo + u b_hi)          */
+int kh_ipa_fold_scalars(int field, const uint64_t *lo, const uint64_t *hi, const uint64_t u[4], size_t n, uint64_t *out);
+/* <a, b> = sum a_i b_i (utils/src/field_helpers.rs:273-279) */
+int kh_inner_product(int field, const uint64_t *a, const uint64_t *b, size_t n, uint64_t out[4]);
+/* g'[i] = g_lo[i] + [u] g_hi[i], affine: CommitmentCurve::combine_one (commitment.rs:576-579); the
+ * endo variant used by the prover (combine_one_endo, ipa.rs:1006) yields the same group elements for
+ * u = u_pre.to_field(endo_r).  u: Montgomery limbs of the scalar field. */
+int kh_ipa_fold_points(int curve, const uint64_t *g_lo_xy, const uint64_t *g_hi_xy, const uint64_t u[4], size_t n,
+                       uint64_t *out_xy, uint8_t *out_inf);
+
 /* ---- commitment wrappers (host logic of the SRS trait over the MSM kernels) ----
  * kh_commit_non_hiding = SRS::commit_non_hiding (poly-commitment/src/ipa.rs:638-683):
  * coefficients (len x 4 limbs, Montgomery) are split into ceil(len / srs_size) chunks,

@@ -399,6 +399,35 @@ int kh_mask_custom(kh_srs_t* srs, const uint64_t* com_xy, const uint8_t* com_inf
     return KH_OK;
 }
 
+// ---------------------------------------------------------------------------------- IPA round vector operations
+int kh_ipa_fold_scalars(int field, const uint64_t* lo, const uint64_t* hi, const uint64_t u[4], size_t n, uint64_t* out) {
+    KH_REQUIRE(field == KH_FIELD_FP || field == KH_FIELD_FQ, "unknown field id %d", field);
+    KH_REQUIRE((lo && hi && u && out) || n == 0, "null argument");
+    int rc = ensure_init(); if (rc) return rc;
+    if (n == 0) return KH_OK;
+    Context& C = ctx();
+    std::lock_guard<std::mutex> lk(C.mu);
+    return ipa_fold_scalars(C, field, lo, hi, u, n, out);
+}
+int kh_inner_product(int field, const uint64_t* a, const uint64_t* b, size_t n, uint64_t out[4]) {
+    KH_REQUIRE(field == KH_FIELD_FP || field == KH_FIELD_FQ, "unknown field id %d", field);
+    KH_REQUIRE(out && ((a && b) || n == 0), "null argument");
+    int rc = ensure_init(); if (rc) return rc;
+    if (n == 0) { memset(out, 0, 32); return KH_OK; }
+    Context& C = ctx();
+    std::lock_guard<std::mutex> lk(C.mu);
+    return ipa_inner_product(C, field, a, b, n, out);
+}
+int kh_ipa_fold_points(int curve, const uint64_t* g_lo, const uint64_t* g_hi, const uint64_t u[4], size_t n, uint64_t* out_xy, uint8_t* out_inf) {
+    KH_REQUIRE(curve == KH_CURVE_VESTA || curve == KH_CURVE_PALLAS, "unknown curve id %d", curve);
+    KH_REQUIRE((g_lo && g_hi && u && out_xy && out_inf) || n == 0, "null argument");
+    int rc = ensure_init(); if (rc) return rc;
+    if (n == 0) return KH_OK;
+    Context& C = ctx();
+    std::lock_guard<std::mutex> lk(C.mu);
+    return ipa_fold_points(C, curve, g_lo, g_hi, u, n, out_xy, out_inf);
+}
+
 // ---------------------------------------------------------------------------------- NTT
 int kh_domain_generator(int field, unsigned log2_n, uint64_t out[4]) {
     KH_REQUIRE(field == KH_FIELD_FP || field == KH_FIELD_FQ, "unknown field id %d", field);

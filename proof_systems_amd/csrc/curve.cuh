@@ -114,6 +114,22 @@ __device__ __forceinline__ Xyzz<F> add(const Xyzz<F>& a, const Xyzz<F>& b) {
     return r;
 }
 
+// k * P, k a canonical (non-Montgomery) 256-bit integer in eight 32-bit words: left-to-right double-and-add
+template <class F>
+__device__ __forceinline__ Xyzz<F> scalar_mul(const Xyzz<F>& p, const u32 k[8]) {
+    Xyzz<F> acc = Xyzz<F>::identity();
+    int top = 7;
+    while (top > 0 && k[top] == 0) top--;
+    for (int w = top; w >= 0; w--) {
+        u32 word = k[w];
+        for (int b = 31; b >= 0; b--) {
+            acc = dbl<F>(acc);
+            if ((word >> b) & 1u) acc = add<F>(acc, p);
+        }
+    }
+    return acc;
+}
+
 template <class F>
 __device__ __forceinline__ Xyzz<F> negate(const Xyzz<F>& a) { Xyzz<F> r = a; r.y = neg<F>(a.y); return r; }
 

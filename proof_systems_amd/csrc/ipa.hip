@@ -1,0 +1,135 @@
+// ipa.hip -- the per-round vector operations of the IPA prover (poly-commitment/src/ipa.rs:929-1007),
+// what stays on the CPU between the L/R MSMs of consecutive rounds.
+//   fold_scalars : a' = a_lo + u^-1 * a_hi  /  b' = b_lo + u * b_hi          (ipa.rs:980-1003)
+//   fold_points  : g' = g_lo + [u] g_hi  = CommitmentCurve::combine_one       (ipa.rs:1006,
+//                  commitment.rs:576-579; combine_one_endo yields the same group elements)
+//   inner_product: <a, b>                                                      (utils/src/field_helpers.rs:273-279)
+// Element-wise and embarrassingly parallel; the basis fold is one 255-bit double-and-add per point
+// (a ~380-operation dependent chain: ~4 ms whatever the length below ~60k points).
+#include "common.hpp"
+#include "curve.cuh"
+#include "host_ec.hpp"
+#include "msm.hpp"
+
+namespace kh {
+
+template <class F>
+__global__ void k_fold_scalars(const u64* __restrict__ lo, const u64* __restrict__ hi, const u64* __restrict__ u, size_t n, u64* __restrict__ out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fe<F> U = Fe<F>::load(u);
+    add<F>(Fe<F>::load(lo + 4 * i), mul<F>(U, Fe<F>::load(hi + 4 * i))).store(out + 4 * i);
+}
+// per-block partial sums of a_i * b_i (field addition is associative: any order gives the same element)
+template <class F>
+__global__ void __launch_bounds__(256)
+k_inner_product(const u64* __restrict__ a, const u64* __restrict__ b, size_t n, u64* __restrict__ partial) {
+    __shared__ u32 sh[256 * 8];
+    Fe<F> acc = Fe<F>::zero();
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        acc = add<F>(acc, mul<F>(Fe<F>::load(a + 4 * i), Fe<F>::load(b + 4 * i)));
+#pragma unroll
+    for (int k = 0; k < 8; k++) sh[k * 256 + threadIdx.x] = acc.v[k];
+    __syncthreads();
+    for (int s = 128; s >= 1; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            Fe<F> o;
+#pragma unroll
+            for (int k = 0; k < 8; k++) o.v[k] = sh[k * 256 + threadIdx.x + s];
+            acc = add<F>(acc, o);
+#pragma unroll
+            for (int k = 0; k < 8; k++) sh[k * 256 + threadIdx.x] = acc.v[k];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) acc.store(partial + 4 * blockIdx.x);
+}
+template <class BF>
+__global__ void __launch_bounds__(128)
+k_fold_points(const uint8_t* __restrict__ g_lo, const uint8_t* __restrict__ g_hi, const u64* __restrict__ u_plain, size_t n,
+              uint8_t* __restrict__ out_xy, uint8_t* __restrict__ out_inf) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u32 kw[8];
+#pragma unroll
+    for (int w = 0; w < 4; w++) { u64 l = u_plain[w]; kw[2 * w] = (u32)l; kw[2 * w + 1] = (u32)(l >> 32); }
+    Xyzz<BF> v = scalar_mul<BF>(Xyzz<BF>::from_affine(Aff<BF>::load(g_hi + i * 64)), kw);
+    v = madd<BF>(v, Aff<BF>::load(g_lo + i * 64), false);
+    Fe<BF> x = Fe<BF>::zero(), y = Fe<BF>::zero();
+    uint8_t inf = 1;
+    if (!v.is_identity()) {
+        Fe<BF> izzz = inv<BF>(v.zzz);
+        Fe<BF> izz = sqr<BF>(mul<BF>(izzz, v.zz));
+        x = mul<BF>(v.x, izz); y = mul<BF>(v.y, izzz);
+        inf = 0;
+    }
+    x.store(out_xy + i * 64); y.store(out_xy + i * 64 + 32);
+    out_inf[i] = inf;
+}
+
+static DevBuf g_ipa_a, g_ipa_b, g_ipa_c;
+
+int ipa_fold_scalars(Context& C, int field, const uint64_t* lo, const uint64_t* hi, const uint64_t u[4], size_t n, uint64_t* out) {
+    int rc;
+    if ((rc = g_ipa_a.reserve(n * 64 + 32))) return rc;
+    if ((rc = g_ipa_b.reserve(n * 32))) return rc;
+    u64* dlo = g_ipa_a.as<u64>(); u64* dhi = dlo + 4 * n; u64* du = dhi + 4 * n;
+    hipStream_t s = C.stream;
+    KH_HIP(hipMemcpyAsync(dlo, lo, n * 32, hipMemcpyHostToDevice, s));
+    KH_HIP(hipMemcpyAsync(dhi, hi, n * 32, hipMemcpyHostToDevice, s));
+    KH_HIP(hipMemcpyAsync(du, u, 32, hipMemcpyHostToDevice, s));
+    dim3 grid((unsigned)((n + 255) / 256));
+    if (field == KH_FIELD_FP) hipLaunchKernelGGL((k_fold_scalars<FpParams>), grid, dim3(256), 0, s, dlo, dhi, du, n, g_ipa_b.as<u64>());
+    else hipLaunchKernelGGL((k_fold_scalars<FqParams>), grid, dim3(256), 0, s, dlo, dhi, du, n, g_ipa_b.as<u64>());
+    KH_HIP(hipGetLastError());
+    KH_HIP(hipMemcpyAsync(out, g_ipa_b.p, n * 32, hipMemcpyDeviceToHost, s));
+    KH_HIP(hipStreamSynchronize(s));
+    return KH_OK;
+}
+int ipa_inner_product(Context& C, int field, const uint64_t* a, const uint64_t* b, size_t n, uint64_t out[4]) {
+    int rc;
+    const unsigned blocks = (unsigned)std::min<size_t>(256, (n + 255) / 256);
+    if ((rc = g_ipa_a.reserve(n * 64))) return rc;
+    if ((rc = g_ipa_b.reserve((size_t)blocks * 32))) return rc;
+    u64* da = g_ipa_a.as<u64>(); u64* db = da + 4 * n;
+    hipStream_t s = C.stream;
+    KH_HIP(hipMemcpyAsync(da, a, n * 32, hipMemcpyHostToDevice, s));
+    KH_HIP(hipMemcpyAsync(db, b, n * 32, hipMemcpyHostToDevice, s));
+    if (field == KH_FIELD_FP) hipLaunchKernelGGL((k_inner_product<FpParams>), dim3(blocks), dim3(256), 0, s, da, db, n, g_ipa_b.as<u64>());
+    else hipLaunchKernelGGL((k_inner_product<FqParams>), dim3(blocks), dim3(256), 0, s, da, db, n, g_ipa_b.as<u64>());
+    KH_HIP(hipGetLastError());
+    std::vector<khost::fe> part(blocks);
+    KH_HIP(hipMemcpyAsync(part.data(), g_ipa_b.p, (size_t)blocks * 32, hipMemcpyDeviceToHost, s));
+    KH_HIP(hipStreamSynchronize(s));
+    khost::Fld F(field);
+    khost::fe acc; memset(&acc, 0, sizeof(acc));
+    for (unsigned i = 0; i < blocks; i++) acc = F.add(acc, part[i]);
+    memcpy(out, &acc, 32);
+    return KH_OK;
+}
+int ipa_fold_points(Context& C, int curve, const uint64_t* g_lo, const uint64_t* g_hi, const uint64_t u[4], size_t n,
+                    uint64_t* out_xy, uint8_t* out_inf) {
+    int rc;
+    if ((rc = g_ipa_a.reserve(n * 128 + 32))) return rc;
+    if ((rc = g_ipa_b.reserve(n * 64))) return rc;
+    if ((rc = g_ipa_c.reserve(n))) return rc;
+    uint8_t* dlo = g_ipa_a.as<uint8_t>(); uint8_t* dhi = dlo + n * 64; u64* du = (u64*)(dhi + n * 64);
+    khost::Fld SF(khost::scalar_field_id(curve));
+    khost::fe uu; memcpy(&uu, u, 32);
+    uu = SF.from_mont(uu);                                 // canonical integer for the double-and-add
+    hipStream_t s = C.stream;
+    KH_HIP(hipMemcpyAsync(dlo, g_lo, n * 64, hipMemcpyHostToDevice, s));
+    KH_HIP(hipMemcpyAsync(dhi, g_hi, n * 64, hipMemcpyHostToDevice, s));
+    KH_HIP(hipMemcpyAsync(du, &uu, 32, hipMemcpyHostToDevice, s));
+    KH_HIP(hipStreamSynchronize(s));                       // uu is a stack buffer
+    dim3 grid((unsigned)((n + 127) / 128));
+    if (curve == KH_CURVE_VESTA) hipLaunchKernelGGL((k_fold_points<FqParams>), grid, dim3(128), 0, s, dlo, dhi, du, n, g_ipa_b.as<uint8_t>(), g_ipa_c.as<uint8_t>());
+    else hipLaunchKernelGGL((k_fold_points<FpParams>), grid, dim3(128), 0, s, dlo, dhi, du, n, g_ipa_b.as<uint8_t>(), g_ipa_c.as<uint8_t>());
+    KH_HIP(hipGetLastError());
+    KH_HIP(hipMemcpyAsync(out_xy, g_ipa_b.p, n * 64, hipMemcpyDeviceToHost, s));
+    KH_HIP(hipMemcpyAsync(out_inf, g_ipa_c.p, n, hipMemcpyDeviceToHost, s));
+    KH_HIP(hipStreamSynchronize(s));
+    return KH_OK;
+}
+
+}  // namespace kh

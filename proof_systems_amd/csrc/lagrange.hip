@@ -15,21 +15,6 @@
 namespace kh {
 
 template <class BF>
-__device__ __forceinline__ Xyzz<BF> scalar_mul(const Xyzz<BF>& p, const u32 k[8]) {
-    Xyzz<BF> acc = Xyzz<BF>::identity();
-    int top = 7;
-    while (top > 0 && k[top] == 0) top--;
-    for (int w = top; w >= 0; w--) {
-        u32 word = k[w];
-        for (int b = 31; b >= 0; b--) {
-            acc = dbl<BF>(acc);
-            if ((word >> b) & 1u) acc = add<BF>(acc, p);
-        }
-    }
-    return acc;
-}
-
-template <class BF>
 __global__ void k_lag_init(const uint8_t* __restrict__ g, size_t start, size_t num_terms, unsigned log_n, uint8_t* __restrict__ A) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     size_t n = (size_t)1 << log_n;

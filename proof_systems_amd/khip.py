@@ -36,6 +36,7 @@ SYMBOLS = [
     "kh_debug_field_op", "kh_debug_point_op", "kh_srs_generate", "kh_srs_h",
     "kh_commit_non_hiding", "kh_commit_evaluations_non_hiding", "kh_srs_set_blinding_base",
     "kh_srs_get_blinding_base", "kh_mask_custom", "kh_domain_generator", "kh_msm_points_batch", "kh_msm_submit", "kh_msm_wait",
+    "kh_ipa_fold_scalars", "kh_inner_product", "kh_ipa_fold_points",
 ]
 
 _lib.kh_last_error.restype = C.c_char_p
@@ -52,6 +53,9 @@ _lib.kh_msm.argtypes = [C.c_void_p, C.c_int, C.c_uint, C.c_size_t, U64P, C.c_siz
 _lib.kh_msm_batch.argtypes = [C.c_void_p, C.c_int, C.c_uint, C.c_size_t, U64P, C.c_size_t, C.c_size_t, C.c_int, U64P, U8P]
 _lib.kh_msm_batch_dev.argtypes = [C.c_void_p, C.c_int, C.c_uint, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, U64P, U8P]
 _lib.kh_msm_points.argtypes = [C.c_int, U64P, U8P, U64P, C.c_size_t, C.c_int, U64P, U8P]
+_lib.kh_ipa_fold_scalars.argtypes = [C.c_int, U64P, U64P, U64P, C.c_size_t, U64P]
+_lib.kh_inner_product.argtypes = [C.c_int, U64P, U64P, C.c_size_t, U64P]
+_lib.kh_ipa_fold_points.argtypes = [C.c_int, U64P, U64P, U64P, C.c_size_t, U64P, U8P]
 _lib.kh_msm_submit.argtypes = [C.c_void_p, C.c_int, C.c_uint, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.POINTER(C.c_uint64)]
 _lib.kh_msm_wait.argtypes = [C.c_uint64, U64P, U8P]
 _lib.kh_msm_points_batch.argtypes = [C.c_int, U64P, U8P, U64P, C.c_size_t, C.c_size_t, C.c_int, U64P, U8P]
@@ -325,6 +329,27 @@ def ntt_dev(field: int, buf: DevBuf, log2_n: int, inverse: bool, batch: int):
 
 def lde_dev(field: int, src: DevBuf, log2_n: int, log2_blowup: int, dst: DevBuf, batch: int):
     _check(_lib.kh_lde_dev(field, C.c_void_p(src.ptr), log2_n, log2_blowup, C.c_void_p(dst.ptr), batch))
+
+
+def ipa_fold_scalars(field: int, lo, hi, u):
+    lo = _c64(lo, (-1, 4)); hi = _c64(hi, (-1, 4)); u = _c64(u, (4,))
+    out = np.zeros_like(lo)
+    _check(_lib.kh_ipa_fold_scalars(field, _p64(lo), _p64(hi), _p64(u), lo.shape[0], _p64(out)))
+    return out
+
+
+def inner_product(field: int, a, b):
+    a = _c64(a, (-1, 4)); b = _c64(b, (-1, 4))
+    out = np.zeros(4, dtype=np.uint64)
+    _check(_lib.kh_inner_product(field, _p64(a), _p64(b), a.shape[0], _p64(out)))
+    return out
+
+
+def ipa_fold_points(curve: int, g_lo, g_hi, u):
+    g_lo = _c64(g_lo, (-1, 8)); g_hi = _c64(g_hi, (-1, 8)); u = _c64(u, (4,))
+    out = np.zeros_like(g_lo); inf = np.zeros(g_lo.shape[0], dtype=np.uint8)
+    _check(_lib.kh_ipa_fold_points(curve, _p64(g_lo), _p64(g_hi), _p64(u), g_lo.shape[0], _p64(out), _p8(inf)))
+    return out, inf
 
 
 def domain_generator(field: int, log2_n: int):

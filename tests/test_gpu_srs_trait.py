@@ -199,3 +199,53 @@ def test_compute_lagrange_on_device(khip, cid):
     b, binf = s2.commit_non_hiding(khip.ntt(fid, ev, 11, True)[0], 1)
     assert np.array_equal(a, b) and not ainf[0] and not binf[0]
     s2.close()
+
+
+@pytest.mark.parametrize("cid", [0, 1])
+def test_ipa_round_vector_ops(khip, cid):
+    """The per-round folds of the IPA prover (ipa.rs:980-1006) and the inner product against the oracle,
+    then one full round identity: with a' = a_lo + u^-1 a_hi, g' = g_lo + u g_hi,
+    <a', g'> = <a, g> + u^-1 <a_hi, g_lo> + u <a_lo, g_hi>  (the L / R cross terms)."""
+    c = P.CURVES[cid]; F = c.scalar
+    fid = 0 if F is P.Fp else 1
+    rnd = np.random.default_rng(17 + cid)
+    n = 64
+    lo = cref.ints_to_limbs([int(v) for v in rnd.integers(0, 1 << 62, n)])
+    hi = cref.ints_to_limbs([int(v) for v in rnd.integers(0, 1 << 62, n)])
+    u_int = int(rnd.integers(2, 1 << 62)) * 982451653 % F.p
+    u = cref.ints_to_limbs([F.to_mont(u_int)])[0]
+    uinv = cref.ints_to_limbs([F.to_mont(F.inv(u_int))])[0]
+    got = khip.ipa_fold_scalars(fid, lo, hi, u)
+    want = cref.field_op(fid, "add", lo, cref.field_op(fid, "mul", np.tile(u, (n, 1)), hi))
+    assert np.array_equal(got, want)
+    ip = khip.inner_product(fid, lo, hi)
+    acc = np.zeros((1, 4), np.uint64)
+    for row in cref.field_op(fid, "mul", lo, hi):
+        acc = cref.field_op(fid, "add", acc, row.reshape(1, 4))
+    assert np.array_equal(ip, acc[0])
+    # empty inner product is zero; big one exercises the multi-block reduction
+    assert not khip.inner_product(fid, np.zeros((0, 4), np.uint64), np.zeros((0, 4), np.uint64)).any()
+    big_a = cref.ints_to_limbs([int(v) for v in rnd.integers(0, 1 << 62, 70000)])
+    big_b = cref.ints_to_limbs([int(v) for v in rnd.integers(0, 1 << 62, 70000)])
+    prods = cref.limbs_to_ints(cref.field_op(fid, "from_mont", cref.field_op(fid, "mul", big_a, big_b)))
+    assert F.from_mont(P.from_limbs(khip.inner_product(fid, big_a, big_b))) == sum(prods) % F.p
+    # basis fold against the oracle, point by point
+    g = khip.srs_generate(cid, 0, 2 * n)
+    g_lo, g_hi = g[:n], g[n:]
+    fx, finf = khip.ipa_fold_points(cid, g_lo, g_hi, u)
+    for i in range(0, n, 5):
+        t, tinf = cref.point_mul(cid, g_hi[i], u)
+        w, winf = cref.point_add(cid, g_lo[i], t, False, tinf)
+        assert bool(finf[i]) == winf and np.array_equal(fx[i], w)
+    # the round identity through the MSM path
+    a = np.concatenate([lo, hi])
+    a_f = khip.ipa_fold_scalars(fid, lo, hi, uinv)
+    lhs, linf = khip.msm_points(cid, fx, a_f, inf=finf)
+    base, _ = khip.msm_points(cid, g, a)
+    L, _ = khip.msm_points(cid, g_lo, hi)
+    R, _ = khip.msm_points(cid, g_hi, lo)
+    t1, i1 = cref.point_mul(cid, L, uinv)
+    t2, i2 = cref.point_mul(cid, R, u)
+    s1, si = cref.point_add(cid, base, t1, False, i1)
+    s2, si2 = cref.point_add(cid, s1, t2, si, i2)
+    assert not linf and not si2 and np.array_equal(lhs, s2)
