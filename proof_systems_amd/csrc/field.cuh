@@ -6,7 +6,9 @@
 // buffers of 4 x u64 limbs are used as they are.
 //
 // Multiplication is product-scanning (column-wise) Montgomery on eight 32-bit
-// limbs.  Each limb product is ONE v_mad_u64_u32 whose carry-out (VCC) is
+// limbs, emitted as ONE hand-scheduled asm block (tools/gen_field_asm.py ->
+// field_mulasm.inc); from_mont (the reduction half alone) uses the per-column
+// blocks of field_cols.inc (tools/gen_field_cols.py).  Each limb product is ONE v_mad_u64_u32 whose carry-out (VCC) is
 // collected by ONE v_addc_co_u32 into a third accumulator word: 96-bit column
 // accumulator, no 64-bit adds, no compare-for-carry.  Both Pasta primes are
 //     p = 2^254 + t * 2^32 + 1,  t < 2^96
@@ -143,36 +145,6 @@ __device__ __forceinline__ Fe<F> mul(const Fe<F>& a, const Fe<F>& b) {
           "v"(p1), "v"(p2), "v"(p3)
         : KH_MONT_MUL_CLOBBERS);
     return r;
-}
-// the same product through the per-column blocks (compiler-scheduled glue); kept for from_mont
-template <class F>
-__device__ __forceinline__ Fe<F> mul_cols(const Fe<F>& a, const Fe<F>& b) {
-    u32 m[8]; u32 t[8];
-    u64 lo = 0; u32 hi;
-    const u32* A = a.v; const u32* B = b.v;
-    const u32 P1 = F::P1, P2 = F::P2, P3 = F::P3, P7 = P7W;
-    // RED: pick m_k so the column's low word cancels (p0 = 1): low + m_k = 0 or 2^32.
-#define KH_RED(k) { m[k] = 0u - (u32)lo; u32 c_ = ((u32)lo != 0u) ? 1u : 0u; lo = ((lo >> 32) | ((u64)hi << 32)) + c_; }
-#define KH_OUT(k) { t[k - 8] = (u32)lo; lo = (lo >> 32) | ((u64)hi << 32); }
-    col1(lo, hi, A[0],B[0]); KH_RED(0)
-    col3(lo, hi, A[0],B[1], A[1],B[0], m[0],P1); KH_RED(1)
-    col5(lo, hi, A[0],B[2], A[1],B[1], A[2],B[0], m[1],P1, m[0],P2); KH_RED(2)
-    col7(lo, hi, A[0],B[3], A[1],B[2], A[2],B[1], A[3],B[0], m[2],P1, m[1],P2, m[0],P3); KH_RED(3)
-    col8(lo, hi, A[0],B[4], A[1],B[3], A[2],B[2], A[3],B[1], A[4],B[0], m[3],P1, m[2],P2, m[1],P3); KH_RED(4)
-    col9(lo, hi, A[0],B[5], A[1],B[4], A[2],B[3], A[3],B[2], A[4],B[1], A[5],B[0], m[4],P1, m[3],P2, m[2],P3); KH_RED(5)
-    col10(lo, hi, A[0],B[6], A[1],B[5], A[2],B[4], A[3],B[3], A[4],B[2], A[5],B[1], A[6],B[0], m[5],P1, m[4],P2, m[3],P3); KH_RED(6)
-    col12(lo, hi, A[0],B[7], A[1],B[6], A[2],B[5], A[3],B[4], A[4],B[3], A[5],B[2], A[6],B[1], A[7],B[0], m[6],P1, m[5],P2, m[4],P3, m[0],P7); KH_RED(7)
-    col11(lo, hi, A[1],B[7], A[2],B[6], A[3],B[5], A[4],B[4], A[5],B[3], A[6],B[2], A[7],B[1], m[7],P1, m[6],P2, m[5],P3, m[1],P7); KH_OUT(8)
-    col9(lo, hi, A[2],B[7], A[3],B[6], A[4],B[5], A[5],B[4], A[6],B[3], A[7],B[2], m[7],P2, m[6],P3, m[2],P7); KH_OUT(9)
-    col7(lo, hi, A[3],B[7], A[4],B[6], A[5],B[5], A[6],B[4], A[7],B[3], m[7],P3, m[3],P7); KH_OUT(10)
-    col5(lo, hi, A[4],B[7], A[5],B[6], A[6],B[5], A[7],B[4], m[4],P7); KH_OUT(11)
-    col4(lo, hi, A[5],B[7], A[6],B[6], A[7],B[5], m[5],P7); KH_OUT(12)
-    col3(lo, hi, A[6],B[7], A[7],B[6], m[6],P7); KH_OUT(13)
-    col2(lo, hi, A[7],B[7], m[7],P7); KH_OUT(14)
-    t[7] = (u32)lo;              // result < 2p < 2^256: nothing above word 7
-#undef KH_RED
-#undef KH_OUT
-    return cond_sub_p<F>(t);
 }
 template <class F>
 __device__ __forceinline__ Fe<F> sqr(const Fe<F>& a) { return mul<F>(a, a); }

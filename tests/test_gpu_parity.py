@@ -323,3 +323,27 @@ def test_concurrent_callers(khip):
         assert got[j][1] == want[j][1] and np.array_equal(got[j][0], want[j][0])
         assert np.array_equal(got_ntt[j], want_ntt[j])
     srs.close()
+
+
+def test_pallas_vesta_pair_resident(khip):
+    """BASELINE config 5: the recursion pair -- a Vesta SRS (coords Fq, scalars Fp) and a Pallas SRS
+    (coords Fp, scalars Fq) resident in the same process, their MSMs and both fields' NTTs interleaved:
+    all four instantiations MSM<Fq>, MSM<Fp>, NTT<Fp>, NTT<Fq> of one binary, no cross-talk."""
+    rng = np.random.default_rng(55)
+    n = 1 << 12
+    gv = cref.srs_generate(0, 0, n, threads=8)
+    gp = cref.srs_generate(1, 0, n, threads=8)
+    sv, sp = khip.Srs(0, gv), khip.Srs(1, gp)
+    for rep in range(3):
+        a, b = rand_fe_fast(rng, n), rand_fe_fast(rng, n)
+        tv = sv.msm_submit(khip.DevBuf(a.nbytes).upload(a).ptr, n, 1)
+        tp = sp.msm_submit(khip.DevBuf(b.nbytes).upload(b).ptr, n, 1)
+        ev = khip.ntt(0, a, 12, True)                     # Fp transform while both MSMs are in flight
+        eq = khip.ntt(1, b, 12, True)                     # Fq transform
+        (ov, iv), (op, ip_) = sv.msm_wait(tv), sp.msm_wait(tp)
+        wv, wiv = cref.msm(0, gv, a, threads=8)
+        wp, wip = cref.msm(1, gp, b, threads=8)
+        assert bool(iv[0]) == wiv and np.array_equal(ov[0], wv)
+        assert bool(ip_[0]) == wip and np.array_equal(op[0], wp)
+        assert np.array_equal(ev, cref.ntt(0, a, 12, True)) and np.array_equal(eq, cref.ntt(1, b, 12, True))
+    sv.close(); sp.close()
