@@ -30,8 +30,35 @@
 #include "curve.cuh"
 #include "host_ec.hpp"
 #include "msm.hpp"
+#include <condition_variable>
+#include <functional>
+#include <thread>
 
 namespace kh {
+
+// One persistent helper thread for the host part of msm_finish: on the plain (per-window) path every
+// result needs a ~256-doubling Horner fold (~70 us of CPU); the L and R commitments of an IPA round
+// are finished side by side instead of one after the other.
+class HostHelper {
+    std::thread th_; std::mutex m_; std::condition_variable cv_, done_cv_;
+    std::function<void()> job_; bool has_job_ = false, busy_ = false, stop_ = false;
+    void loop() {
+        std::unique_lock<std::mutex> lk(m_);
+        for (;;) {
+            cv_.wait(lk, [&] { return has_job_ || stop_; });
+            if (stop_) return;
+            std::function<void()> j = std::move(job_); has_job_ = false; busy_ = true;
+            lk.unlock(); j(); lk.lock();
+            busy_ = false; done_cv_.notify_all();
+        }
+    }
+  public:
+    HostHelper() : th_([this] { loop(); }) {}
+    ~HostHelper() { { std::lock_guard<std::mutex> lk(m_); stop_ = true; } cv_.notify_all(); th_.join(); }
+    void run(std::function<void()> j) { { std::lock_guard<std::mutex> lk(m_); job_ = std::move(j); has_job_ = true; } cv_.notify_all(); }
+    void wait() { std::unique_lock<std::mutex> lk(m_); done_cv_.wait(lk, [&] { return !has_job_ && !busy_; }); }
+};
+static HostHelper& host_helper() { static HostHelper h; return h; }
 
 // ------------------------------------------------------------------------------------ scan
 static constexpr int SCAN_T = 256, SCAN_I = 8, SCAN_B = SCAN_T * SCAN_I;
@@ -262,11 +289,12 @@ k_accumulate(const u32* __restrict__ entries, const u32* __restrict__ off, const
     acc.store(partial + t * 128);
 }
 // ------------------------------------------------------------------------------------ 6 bucket sums
-static constexpr u32 SMALL_NT = 16;
+// buckets with more partials than this go to the wave-per-bucket tree (k_bucket_big); the threshold is a
+// kernel argument: 16 for large problems (throughput), 4 for small ones (shorter dependent chain)
 template <class BF>
 __global__ void __launch_bounds__(256)
 k_bucket_sum(const u32* __restrict__ toff, size_t nkeys, const uint8_t* __restrict__ partial,
-             uint8_t* __restrict__ buckets, u32* __restrict__ biglist /* [0] = count */) {
+             uint8_t* __restrict__ buckets, u32* __restrict__ biglist /* [0] = count */, u32 SMALL_NT) {
     size_t key = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (key >= nkeys) return;
     u32 t0 = toff[key], nt = toff[key + 1] - t0;
@@ -537,7 +565,8 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
     C.timer.mark("accumulate", s);
     // 6 bucket sums
     hipLaunchKernelGGL((k_bucket_sum<BF>), dim3((unsigned)((nkeys + 255) / 256)), dim3(256), 0, s,
-                       C.ws_toff.as<u32>(), nkeys, C.ws_partial.as<uint8_t>(), C.ws_buckets.as<uint8_t>(), C.ws_biglist.as<u32>());
+                       C.ws_toff.as<u32>(), nkeys, C.ws_partial.as<uint8_t>(), C.ws_buckets.as<uint8_t>(), C.ws_biglist.as<u32>(),
+                       nkeys <= 16384 ? 4u : 16u);
     hipLaunchKernelGGL((k_bucket_big<BF>), dim3(1024), dim3(64), 0, s,
                        C.ws_toff.as<u32>(), C.ws_partial.as<uint8_t>(), C.ws_buckets.as<uint8_t>(), C.ws_biglist.as<u32>());
     C.timer.mark("bucket_sum", s);
@@ -602,7 +631,14 @@ int msm_finish(Context& C, MsmSlot& S, uint64_t* out_xy, uint8_t* out_inf) {
         memcpy(out_xy + 8 * j, &a, 64);
         out_inf[j] = inf ? 1 : 0;
     };
-    for (size_t j = 0; j < S.k; j++) finish_one(j);
+    if (!S.precomp && S.k >= 2) {                     // split the Horner folds with the helper thread
+        const size_t half = S.k / 2, kk = S.k;
+        host_helper().run([finish_one, half, kk] { for (size_t j = half; j < kk; j++) finish_one(j); });
+        for (size_t j = 0; j < half; j++) finish_one(j);
+        host_helper().wait();
+    } else {
+        for (size_t j = 0; j < S.k; j++) finish_one(j);
+    }
     return KH_OK;
 }
 
