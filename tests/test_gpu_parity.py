@@ -347,3 +347,61 @@ def test_pallas_vesta_pair_resident(khip):
         assert bool(ip_[0]) == wip and np.array_equal(op[0], wp)
         assert np.array_equal(ev, cref.ntt(0, a, 12, True)) and np.array_equal(eq, cref.ntt(1, b, 12, True))
     sv.close(); sp.close()
+
+
+def test_msm_randomized_differential(khip):
+    """Seeded differential sweep: random lengths (both the plain and the window-table path), random
+    mixes of scalar classes (uniform, zero, one, minus one, small, repeated), random infinity flags,
+    both curves, single and batched calls -- each compared bit-for-bit with the oracle."""
+    rng = np.random.default_rng(20260925)
+    for case in range(36):
+        cid = case & 1
+        F = P.CURVES[cid].scalar
+        fid = 0 if F is P.Fp else 1
+        n = int(rng.choice([1, 2, 7, 63, 64, 65, 255, 1000, 1023, 1024, 1025, 2500, 4097]))
+        g = cref.srs_generate(cid, int(rng.integers(0, 1000)), n, threads=8)
+        cls = rng.integers(0, 6, size=n)
+        sc = rand_fe_fast(rng, n)
+        one = cref.ints_to_limbs([F.R])[0]
+        m1 = cref.ints_to_limbs([F.to_mont(F.p - 1)])[0]
+        small = cref.field_op(fid, "to_mont", cref.ints_to_limbs([int(v) for v in rng.integers(0, 70000, n)]))
+        sc[cls == 1] = 0
+        sc[cls == 2] = one
+        sc[cls == 3] = m1
+        sc[cls == 4] = small[cls == 4]
+        sc[cls == 5] = sc[0]
+        if case % 3 == 0:                                     # ad-hoc bases with infinity flags
+            inf = (rng.random(n) < 0.1).astype(np.uint8)
+            got, ginf = khip.msm_points(cid, g, sc, inf=inf)
+            want, winf = cref.msm(cid, g, sc, inf=inf, threads=4)
+        elif case % 3 == 1:                                   # SRS path (tables when n >= 1024), with an offset
+            srs = khip.Srs(cid, g)
+            off = int(rng.integers(0, n))
+            got, ginf = srs.msm(sc[: n - off], offset=off)
+            want, winf = cref.msm(cid, g[off:], sc[: n - off], threads=4)
+            srs.close()
+        else:                                                 # batch of 3 over the same bases
+            srs = khip.Srs(cid, g)
+            batch = np.stack([sc, np.roll(sc, 1, axis=0), rand_fe_fast(rng, n)])
+            gots, ginfs = srs.msm_batch(batch)
+            srs.close()
+            for j in range(3):
+                w, wi = cref.msm(cid, g, batch[j], threads=4)
+                assert bool(ginfs[j]) == wi and (wi or np.array_equal(gots[j], w)), (case, j)
+            continue
+        assert ginf == winf and (winf or np.array_equal(got, want)), case
+
+
+def test_ntt_randomized_differential(khip):
+    rng = np.random.default_rng(777)
+    for case in range(24):
+        fid = case & 1
+        logn = int(rng.integers(0, 15))
+        batch = int(rng.integers(1, 6))
+        x = rand_fe_fast(rng, batch << logn).reshape(batch, 1 << logn, 4)
+        x[rng.random(x.shape[:2]) < 0.2] = 0
+        inv = bool(rng.integers(0, 2))
+        assert np.array_equal(khip.ntt(fid, x, logn, inv), cref.ntt(fid, x, logn, inv, threads=4)), (case, logn, batch, inv)
+        if 1 <= logn <= 12:
+            logb = int(rng.integers(1, 4))
+            assert np.array_equal(khip.lde(fid, x, logn, logb), cref.lde(fid, x, logn, logb, threads=4)), (case, logn, logb)
