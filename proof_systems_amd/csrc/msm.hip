@@ -470,7 +470,10 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
     const int W = (256 + c - 1) / c;
     const u32 nb = 1u << (c - 1);
     const int precomp = basis.precomp_c ? 1 : 0;
+    // slices per (window, msm): enough blocks to fill the chip (~512), no more -- the per-slice histograms
+    // cost nkeys x W x S words of traffic in k_key_totals, which dominates the sort of a batch
     int S = (int)(n / 8192); if (S < 1) S = 1; if (S > 16) S = 16;
+    { int want = (int)(512 / ((size_t)W * k)); if (want < 1) want = 1; if (S > want) S = want; }
     SortGeom g{n, nb, S, W, precomp, basis.n, offset, basis.batch_stride};
     const size_t ngroups = precomp ? k : k * (size_t)W;
     const int Sq = precomp ? W * S : S;
