@@ -79,6 +79,73 @@ def emit(name, lines):
     return f'#define {name} \\\n    "' + "\\n\\t\" \\\n    \"".join(lines) + '"\n'
 
 
+def gen_sqr():
+    """r = a^2 * 2^-256 mod p with 36 instead of 64 limb products:
+         a^2 = sum_i a_i^2 B^(2i) + sum_i a_i B^i * (2 * A_{>i}),   A_{>i} = sum_{j>i} a_j B^j.
+    Words of 2*A_{>i}: E_{i+1} = a_{i+1} << 1 at position i+1 (no carry-in: a_i is not part of A_{>i}),
+    D_j = (a_j << 1) | (a_{j-1} >> 31) for j > i+1 (a < 2^255, so nothing spills into word 8).
+    Operands: %0-7 r, %8-15 a, %16-18 P1..P3.  Scratch: v2-v13 as in the product, v14-v19 = D_2..D_7, v20 = E."""
+    a_ = lambda i: f"%{8 + i}"
+    t_ = lambda i: f"%{i}"
+    Pq = {1: "%16", 2: "%17", 3: "%18"}
+    D = {j: f"v{12 + j}" for j in range(2, 8)}       # D_2..D_7 -> v14..v19
+    E = "v20"
+    L = []
+    X, Y = A, B
+    have_D = set()
+    for k in range(15):
+        prods = []           # (x, y, pre) pre = instruction emitted before the MAC
+        for i in range(8):
+            j = k - i
+            if not (0 <= j < 8) or i > j:
+                continue
+            if i == j:
+                prods.append((a_(i), a_(i), None))
+            elif j == i + 1:
+                prods.append((a_(i), E, f"v_lshlrev_b32 {E}, 1, {a_(j)}"))
+            else:
+                pre = None
+                if j not in have_D:
+                    pre = f"v_alignbit_b32 {D[j]}, {a_(j)}, {a_(j - 1)}, 31"
+                    have_D.add(j)
+                prods.append((a_(i), D[j], pre))
+        for pj in (1, 2, 3):
+            if 0 <= k - pj < 8:
+                prods.append((M[k - pj], Pq[pj], None))
+        if 0 <= k - 7 < 8:
+            prods.append((M[k - 7], "2.0", None))
+        first = True
+        for (x, y, pre) in prods:
+            if pre:
+                L.append(pre)
+            if k == 0 and first:
+                L.append(f"v_mad_u64_u32 {X[0]}, vcc, {x}, {y}, 0")
+            else:
+                L.append(f"v_mad_u64_u32 {X[0]}, vcc, {x}, {y}, {X[0]}")
+            L.append(f"v_addc_co_u32 {Y[2]}, vcc, 0, {'0' if first else Y[2]}, vcc")
+            first = False
+        if k < 8:
+            L.append(f"v_sub_u32 {M[k]}, 0, {X[1]}")
+            L.append(f"v_mad_u64_u32 {X[0]}, vcc, {M[k]}, 1, {X[0]}")
+            L.append(f"v_addc_co_u32 {Y[2]}, vcc, 0, {Y[2]}, vcc")
+        else:
+            L.append(f"v_mov_b32 {t_(k - 8)}, {X[1]}")
+        if k < 14:
+            L.append(f"v_mov_b32 {Y[1]}, {X[2]}")
+            X, Y = Y, X
+        else:
+            L.append(f"v_mov_b32 {t_(7)}, {X[2]}")
+    L.append(f"v_subrev_co_u32 {M[0]}, vcc, 1, {t_(0)}")
+    for i in (1, 2, 3):
+        L.append(f"v_subb_co_u32 {M[i]}, vcc, {t_(i)}, {Pq[i]}, vcc")
+    for i in (4, 5, 6):
+        L.append(f"v_subbrev_co_u32 {M[i]}, vcc, 0, {t_(i)}, vcc")
+    L.append(f"v_subbrev_co_u32 {M[7]}, vcc, 2.0, {t_(7)}, vcc")
+    for i in range(8):
+        L.append(f"v_cndmask_b32 {t_(i)}, {M[i]}, {t_(i)}, vcc")
+    return L
+
+
 def gen_sub():
     """r = a - b mod p.  %0-7 r (early clobber), %8-15 a, %16-23 b, %24-26 P1..P3.  Scratch v2-v7."""
     r = lambda i: f"%{i}"; a_ = lambda i: f"%{8 + i}"; b_ = lambda i: f"%{16 + i}"
@@ -123,6 +190,9 @@ out = ["// GENERATED by tools/gen_field_asm.py -- do not edit.  See that file fo
        f"// {len(gen_mul())} instructions per Montgomery product.",
        emit("KH_MONT_MUL_ASM", gen_mul()),
        '#define KH_MONT_MUL_CLOBBERS "vcc", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13"',
+       f"// Montgomery squaring: {len(gen_sqr())} instructions (36 limb products instead of 64)",
+       emit("KH_MONT_SQR_ASM", gen_sqr()),
+       '#define KH_MONT_SQR_CLOBBERS "vcc", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19", "v20"',
        f"// modular subtraction ({len(gen_sub())} instructions) and addition ({len(gen_add())} instructions)",
        emit("KH_FE_SUB_ASM", gen_sub()),
        '#define KH_FE_SUB_CLOBBERS "vcc", "v2", "v3", "v4", "v5", "v6", "v7"',
