@@ -113,6 +113,10 @@ int kh_msm_points_batch(int curve, const uint64_t *xy, const uint8_t *inf, const
                         size_t n, size_t k, int scalars_are_montgomery,
                         uint64_t *out_xy /* k x 8 */, uint8_t *out_is_inf /* k */);
 
+/* Sum of n affine points on the host (a handful of group additions): the fold of the per-GPU partial
+ * sums of a point-range-sharded MSM after the all-gather, or `(r1 + r2).into_affine()` of ipa.rs:661. */
+int kh_points_sum(int curve, const uint64_t *xy, const uint8_t *inf, size_t n, uint64_t out_xy[8], uint8_t *out_is_inf);
+
 /* ---- IPA round vector operations (poly-commitment/src/ipa.rs:980-1006) -----
  * out[i] = lo[i] + u * hi[i]      (a' = a_lo + u^-1 a_hi with u := u^-1; b' = b_lo + u b_hi)          */
 int kh_ipa_fold_scalars(int field, const uint64_t *lo, const uint64_t *hi, const uint64_t u[4], size_t n, uint64_t *out);

@@ -399,6 +399,22 @@ int kh_mask_custom(kh_srs_t* srs, const uint64_t* com_xy, const uint8_t* com_inf
     return KH_OK;
 }
 
+// ---------------------------------------------------------------------------------- host-side group sum
+int kh_points_sum(int curve, const uint64_t* xy, const uint8_t* inf, size_t n, uint64_t out_xy[8], uint8_t* out_is_inf) {
+    KH_REQUIRE(curve == KH_CURVE_VESTA || curve == KH_CURVE_PALLAS, "unknown curve id %d", curve);
+    KH_REQUIRE(out_xy && out_is_inf && (xy || n == 0), "null argument");
+    khost::Crv crv(curve);
+    khost::xyzz acc = crv.identity();
+    for (size_t i = 0; i < n; i++) {
+        if (inf && inf[i]) continue;
+        khost::aff p; memcpy(&p, xy + 8 * i, 64);
+        acc = crv.add(acc, crv.from_affine(p));
+    }
+    khost::aff r; bool isinf = crv.to_affine(acc, r);
+    memcpy(out_xy, &r, 64); *out_is_inf = isinf ? 1 : 0;
+    return KH_OK;
+}
+
 // ---------------------------------------------------------------------------------- IPA round vector operations
 int kh_ipa_fold_scalars(int field, const uint64_t* lo, const uint64_t* hi, const uint64_t u[4], size_t n, uint64_t* out) {
     KH_REQUIRE(field == KH_FIELD_FP || field == KH_FIELD_FQ, "unknown field id %d", field);

@@ -36,7 +36,7 @@ SYMBOLS = [
     "kh_debug_field_op", "kh_debug_point_op", "kh_srs_generate", "kh_srs_h",
     "kh_commit_non_hiding", "kh_commit_evaluations_non_hiding", "kh_srs_set_blinding_base",
     "kh_srs_get_blinding_base", "kh_mask_custom", "kh_domain_generator", "kh_msm_points_batch", "kh_msm_submit", "kh_msm_wait",
-    "kh_ipa_fold_scalars", "kh_inner_product", "kh_ipa_fold_points",
+    "kh_ipa_fold_scalars", "kh_inner_product", "kh_ipa_fold_points", "kh_points_sum",
 ]
 
 _lib.kh_last_error.restype = C.c_char_p
@@ -56,6 +56,7 @@ _lib.kh_msm_points.argtypes = [C.c_int, U64P, U8P, U64P, C.c_size_t, C.c_int, U6
 _lib.kh_ipa_fold_scalars.argtypes = [C.c_int, U64P, U64P, U64P, C.c_size_t, U64P]
 _lib.kh_inner_product.argtypes = [C.c_int, U64P, U64P, C.c_size_t, U64P]
 _lib.kh_ipa_fold_points.argtypes = [C.c_int, U64P, U64P, U64P, C.c_size_t, U64P, U8P]
+_lib.kh_points_sum.argtypes = [C.c_int, U64P, U8P, C.c_size_t, U64P, U8P]
 _lib.kh_msm_submit.argtypes = [C.c_void_p, C.c_int, C.c_uint, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.POINTER(C.c_uint64)]
 _lib.kh_msm_wait.argtypes = [C.c_uint64, U64P, U8P]
 _lib.kh_msm_points_batch.argtypes = [C.c_int, U64P, U8P, U64P, C.c_size_t, C.c_size_t, C.c_int, U64P, U8P]
@@ -329,6 +330,16 @@ def ntt_dev(field: int, buf: DevBuf, log2_n: int, inverse: bool, batch: int):
 
 def lde_dev(field: int, src: DevBuf, log2_n: int, log2_blowup: int, dst: DevBuf, batch: int):
     _check(_lib.kh_lde_dev(field, C.c_void_p(src.ptr), log2_n, log2_blowup, C.c_void_p(dst.ptr), batch))
+
+
+def points_sum(curve: int, xy, inf=None):
+    """Host-side sum of a few affine points (fold of per-GPU partial MSM results)."""
+    xy = _c64(xy, (-1, 8))
+    if inf is not None:
+        inf = np.ascontiguousarray(inf, dtype=np.uint8)
+    out = np.zeros(8, dtype=np.uint64); oinf = np.zeros(1, dtype=np.uint8)
+    _check(_lib.kh_points_sum(curve, _p64(xy), _p8(inf), xy.shape[0], _p64(out), _p8(oinf)))
+    return out, bool(oinf[0])
 
 
 def ipa_fold_scalars(field: int, lo, hi, u):

@@ -249,3 +249,22 @@ def test_ipa_round_vector_ops(khip, cid):
     s1, si = cref.point_add(cid, base, t1, False, i1)
     s2, si2 = cref.point_add(cid, s1, t2, si, i2)
     assert not linf and not si2 and np.array_equal(lhs, s2)
+
+
+def test_points_sum_matches_oracle(khip):
+    """kh_points_sum (host fold of per-GPU partial sums) incl. infinity inputs, P + (-P) and doubling."""
+    for cid in (0, 1):
+        g = khip.srs_generate(cid, 0, 6)
+        base_fid = 1 if cid == 0 else 0
+        pts = np.concatenate([g, g[:1], g[1:2]])
+        pts[7, 4:] = cref.field_op(base_fid, "sub", np.zeros((1, 4), np.uint64), g[1, 4:].reshape(1, 4))[0]   # -g1
+        inf = np.zeros(8, np.uint8); inf[3] = 1
+        got, ginf = khip.points_sum(cid, pts, inf)
+        acc, ainf = pts[0].copy(), False
+        for i in range(1, 8):
+            if inf[i]:
+                continue
+            acc, ainf = cref.point_add(cid, acc, pts[i], ainf, False)
+        assert ginf == ainf and np.array_equal(got, acc)
+        z, zinf = khip.points_sum(cid, pts[[1, 7]])
+        assert zinf
