@@ -405,3 +405,35 @@ def test_ntt_randomized_differential(khip):
         if 1 <= logn <= 12:
             logb = int(rng.integers(1, 4))
             assert np.array_equal(khip.lde(fid, x, logn, logb), cref.lde(fid, x, logn, logb, threads=4)), (case, logn, logb)
+
+
+@pytest.mark.parametrize("cid", [0, 1])
+def test_msm_table_path_exceptional_cases(khip, cid):
+    """Window-table path (n >= 1024) with bases that collide on purpose: the second half of the SRS repeats
+    the first half (every bucket meets P + P: doubling branch of the mixed addition) or its negation
+    (P + (-P): the accumulator passes through the identity and keeps going)."""
+    F = P.CURVES[cid].scalar
+    base_fid = 1 if cid == 0 else 0
+    rng = np.random.default_rng(31 + cid)
+    h = 1024
+    g = cref.srs_generate(cid, 0, h, threads=8)
+    sc_half = rand_fe(rng, h, F)
+    sc = np.concatenate([sc_half, sc_half])
+    dup = np.concatenate([g, g])
+    neg = dup.copy()
+    neg[h:, 4:] = cref.field_op(base_fid, "sub", np.zeros((h, 4), np.uint64), g[:, 4:])
+    for pts, expect_inf in ((dup, False), (neg, True)):
+        srs = khip.Srs(cid, pts)
+        got, ginf = srs.msm(sc)
+        want, winf = cref.msm(cid, pts, sc, threads=8)
+        srs.close()
+        assert ginf == winf == expect_inf and (winf or np.array_equal(got, want))
+    # mixed: a third of the pairs cancel, a third double, the rest are unrelated
+    mix = dup.copy()
+    mix[h: h + h // 3] = neg[h: h + h // 3]
+    mix[h + 2 * (h // 3):] = cref.srs_generate(cid, 5000, h - 2 * (h // 3), threads=8)
+    srs = khip.Srs(cid, mix)
+    got, ginf = srs.msm(sc)
+    want, winf = cref.msm(cid, mix, sc, threads=8)
+    srs.close()
+    assert ginf == winf and np.array_equal(got, want)
