@@ -437,3 +437,30 @@ def test_msm_table_path_exceptional_cases(khip, cid):
     want, winf = cref.msm(cid, mix, sc, threads=8)
     srs.close()
     assert ginf == winf and np.array_equal(got, want)
+
+
+def test_hip_path_against_derived_vectors(khip):
+    """Fixed bytes committed under tests/golden/derived_vectors.json (definition-level big-int results)."""
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "derived_vectors.json")) as f:
+        d = json.load(f)
+    for v in d["ntt"]:
+        F = P.Fp if v["field"] == "Fp" else P.Fq
+        fid = 0 if v["field"] == "Fp" else 1
+        A = cref.ints_to_limbs([F.to_mont(int(x, 16)) for x in v["input"]])
+        assert [F.from_mont(x) for x in cref.limbs_to_ints(khip.ntt(fid, A, v["log2_n"], False))] == [int(x, 16) for x in v["forward"]]
+        assert [F.from_mont(x) for x in cref.limbs_to_ints(khip.ntt(fid, A, v["log2_n"], True))] == [int(x, 16) for x in v["inverse"]]
+    for v in d["lde"]:
+        F = P.Fp if v["field"] == "Fp" else P.Fq
+        fid = 0 if v["field"] == "Fp" else 1
+        c = cref.ints_to_limbs([F.to_mont(int(x, 16)) for x in v["coeffs"]])
+        assert [F.from_mont(x) for x in cref.limbs_to_ints(khip.lde(fid, c, v["log2_n"], v["log2_blowup"]))] == [int(x, 16) for x in v["evals"]]
+    for v in d["msm"]:
+        c = P.CURVES[v["curve"]]
+        g = khip.srs_generate(c.cid, 0, 12)
+        sc = cref.ints_to_limbs([c.scalar.to_mont(int(x, 16)) for x in v["scalars"]])
+        out, inf = khip.msm_points(c.cid, g, sc)
+        assert not inf
+        assert c.base.from_mont(P.from_limbs(out[:4])) == int(v["result"][0], 16)
+        assert c.base.from_mont(P.from_limbs(out[4:])) == int(v["result"][1], 16)

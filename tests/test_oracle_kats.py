@@ -294,3 +294,34 @@ def test_lagrange_basis_identity():
     rnd = random.Random(3)
     ev = [rnd.randrange(F.p) for _ in range(n)]
     assert P.commit_evaluations_non_hiding(c, basis, ev, k) == P.commit_non_hiding(c, g, P.ntt(F, ev, k, inverse=True), 1)
+
+
+# ---------------------------------------------------------------- derived fixed vectors (tests/golden/make_derived.py)
+def _derived():
+    import json, os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "derived_vectors.json")) as f:
+        return json.load(f)
+
+
+def test_c_oracle_against_derived_vectors():
+    d = _derived()
+    for v in d["ntt"]:
+        F = P.Fp if v["field"] == "Fp" else P.Fq
+        fid = 0 if v["field"] == "Fp" else 1
+        a = [int(x, 16) for x in v["input"]]
+        A = cref.ints_to_limbs([F.to_mont(x) for x in a])
+        assert [F.from_mont(x) for x in cref.limbs_to_ints(cref.ntt(fid, A, v["log2_n"], False))] == [int(x, 16) for x in v["forward"]]
+        assert [F.from_mont(x) for x in cref.limbs_to_ints(cref.ntt(fid, A, v["log2_n"], True))] == [int(x, 16) for x in v["inverse"]]
+        assert P.ntt(F, a, v["log2_n"]) == [int(x, 16) for x in v["forward"]]
+    for v in d["lde"]:
+        F = P.Fp if v["field"] == "Fp" else P.Fq
+        fid = 0 if v["field"] == "Fp" else 1
+        c = cref.ints_to_limbs([F.to_mont(int(x, 16)) for x in v["coeffs"]])
+        got = cref.lde(fid, c, v["log2_n"], v["log2_blowup"])
+        assert [F.from_mont(x) for x in cref.limbs_to_ints(got)] == [int(x, 16) for x in v["evals"]]
+    for v in d["msm"]:
+        c = P.CURVES[v["curve"]]
+        g = cref.srs_generate(c.cid, 0, 12)
+        sc = _sc_limbs(c.scalar, [int(x, 16) for x in v["scalars"]])
+        out, inf = cref.msm(c.cid, g, sc)
+        assert not inf and _pt_from_limbs(c, out) == (int(v["result"][0], 16), int(v["result"][1], 16))
