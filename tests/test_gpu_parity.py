@@ -464,3 +464,23 @@ def test_hip_path_against_derived_vectors(khip):
         assert not inf
         assert c.base.from_mont(P.from_limbs(out[:4])) == int(v["result"][0], 16)
         assert c.base.from_mont(P.from_limbs(out[4:])) == int(v["result"][1], 16)
+
+
+def test_ntt_large_sizes(khip):
+    """Three-pass decompositions: 2^20 against the oracle, 2^22 by round trip + linearity, LDE 2^18 -> 2^21."""
+    rng = np.random.default_rng(4242)
+    x = rand_fe_fast(rng, 1 << 20).reshape(1, 1 << 20, 4)
+    f = khip.ntt(1, x, 20, False)
+    assert np.array_equal(f, cref.ntt(1, x, 20, False, threads=8))
+    assert np.array_equal(khip.ntt(1, f, 20, True), x)
+    y = rand_fe_fast(rng, 1 << 22).reshape(1, 1 << 22, 4)
+    z = rand_fe_fast(rng, 1 << 22).reshape(1, 1 << 22, 4)
+    fy, fz = khip.ntt(0, y, 22, False), khip.ntt(0, z, 22, False)
+    assert np.array_equal(khip.ntt(0, fy, 22, True), y)
+    s = cref.field_op(0, "add", y.reshape(-1, 4), z.reshape(-1, 4)).reshape(1, 1 << 22, 4)
+    assert np.array_equal(khip.ntt(0, s, 22, False).reshape(-1, 4), cref.field_op(0, "add", fy.reshape(-1, 4), fz.reshape(-1, 4)))
+    c = rand_fe_fast(rng, 1 << 18).reshape(1, 1 << 18, 4)
+    e = khip.lde(0, c, 18, 3)
+    assert np.array_equal(e[:, ::8], khip.ntt(0, c, 18, False))
+    back = khip.ntt(0, e, 21, True)
+    assert np.array_equal(back[:, : 1 << 18], c) and not back[:, 1 << 18:].any()
