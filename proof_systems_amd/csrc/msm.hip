@@ -203,10 +203,18 @@ __global__ void k_scatter(const int32_t* __restrict__ digits, SortGeom g, const 
 }
 // ------------------------------------------------------------------------------------ tasks
 static constexpr u32 MAX_K = 256;           // upper bound of the task length (length bins of the task ordering)
-__global__ void k_ntask(const u32* __restrict__ off, size_t nkeys, u32 K, u32* __restrict__ nt, u32* __restrict__ len_hist) {
+// K (entries per task) is chosen HERE from the actual number of entries off[nkeys]: zero digits
+// produce no entry, and the reference's own benchmark witness is almost all ones (one non-zero
+// digit per scalar) -- sizing K from the n*W upper bound left the chip 5 % occupied on it.
+__device__ __forceinline__ u32 pick_K(u32 total, u32 room) {
+    u32 K = (total + room - 1) / room;
+    return K < 8 ? 8u : (K > MAX_K ? MAX_K : K);
+}
+__global__ void k_ntask(const u32* __restrict__ off, size_t nkeys, u32 room, u32* __restrict__ nt, u32* __restrict__ len_hist) {
     __shared__ u32 h[MAX_K + 1];
     for (u32 i = threadIdx.x; i <= MAX_K; i += blockDim.x) h[i] = 0;
     __syncthreads();
+    const u32 K = pick_K(off[nkeys], room);
     size_t key = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (key <= nkeys) {
         u32 n_t = 0;
@@ -259,7 +267,7 @@ template <class BF>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(112)))
 k_accumulate(const u32* __restrict__ entries, const u32* __restrict__ off, const u32* __restrict__ toff,
              const u32* __restrict__ roff, const u32* __restrict__ order,
-             size_t nkeys, u32 K, const uint8_t* __restrict__ pts, uint8_t* __restrict__ partial) {
+             size_t nkeys, const uint8_t* __restrict__ pts, uint8_t* __restrict__ partial) {
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     u32 NT = roff[nkeys];
     if (t >= NT) return;
@@ -291,17 +299,23 @@ k_accumulate(const u32* __restrict__ entries, const u32* __restrict__ off, const
 // ------------------------------------------------------------------------------------ 6 bucket sums
 // buckets with more partials than this go to the wave-per-bucket tree (k_bucket_big); the threshold is a
 // kernel argument: 16 for large problems (throughput), 4 for small ones (shorter dependent chain)
+// hot-bucket bookkeeping in `big`: [0] = #big buckets, [1] = #chunk items, then four arrays of `cap` words:
+// bigkey[], bigcbase[] (first chunk item of that bucket), itemkey[], itemj[]
+static constexpr u32 CHUNK = 512;            // partials per chunk item = 8 per lane of a wave
 template <class BF>
 __global__ void __launch_bounds__(256)
 k_bucket_sum(const u32* __restrict__ toff, size_t nkeys, const uint8_t* __restrict__ partial,
-             uint8_t* __restrict__ buckets, u32* __restrict__ biglist /* [0] = count */, u32 SMALL_NT) {
+             uint8_t* __restrict__ buckets, u32* __restrict__ big, size_t cap, u32 SMALL_NT) {
     size_t key = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (key >= nkeys) return;
     u32 t0 = toff[key], nt = toff[key + 1] - t0;
     Xyzz<BF> acc = Xyzz<BF>::identity();
     if (nt > SMALL_NT) {
-        u32 slot = atomicAdd(&biglist[0], 1u);
-        biglist[1 + slot] = (u32)key;
+        u32 nch = (nt + CHUNK - 1) / CHUNK;
+        u32 slot = atomicAdd(&big[0], 1u);
+        u32 cbase = atomicAdd(&big[1], nch);
+        big[2 + slot] = (u32)key; big[2 + cap + slot] = cbase;
+        for (u32 j = 0; j < nch; j++) { big[2 + 2 * cap + cbase + j] = (u32)key; big[2 + 3 * cap + cbase + j] = j; }
     } else if (nt > 0) {
         acc = Xyzz<BF>::load(partial + (size_t)t0 * 128);
         for (u32 k = 1; k < nt; k++) acc = add<BF>(acc, Xyzz<BF>::load(partial + (size_t)(t0 + k) * 128));
@@ -318,22 +332,38 @@ __device__ __forceinline__ Xyzz<F> shfl_down(const Xyzz<F>& a, int delta) {
     }
     return r;
 }
-// one wave per "big" bucket: lanes stride over the partials, then a shuffle tree
+// Hot buckets in two phases, so that one bucket holding most of the entries (the all-ones witness) is
+// summed by many waves: phase A = one wave per chunk of <= 512 partials (8 per lane + shuffle tree),
+// phase B = one wave per hot bucket over its chunk sums.
 template <class BF>
 __global__ void __launch_bounds__(64)
-k_bucket_big(const u32* __restrict__ toff, const uint8_t* __restrict__ partial,
-             uint8_t* __restrict__ buckets, const u32* __restrict__ biglist) {
-    u32 nbig = biglist[0];
+k_bucket_chunk(const u32* __restrict__ toff, const uint8_t* __restrict__ partial, const u32* __restrict__ big, size_t cap,
+               uint8_t* __restrict__ chunk_out) {
+    u32 nitems = big[1];
+    int lane = threadIdx.x;
+    for (u32 it = blockIdx.x; it < nitems; it += gridDim.x) {
+        u32 key = big[2 + 2 * cap + it], j = big[2 + 3 * cap + it];
+        u32 t0 = toff[key], nt = toff[key + 1] - t0;
+        u32 lo = j * CHUNK, hi = lo + CHUNK < nt ? lo + CHUNK : nt;
+        Xyzz<BF> acc = Xyzz<BF>::identity();
+        for (u32 k = lo + lane; k < hi; k += 64) acc = add<BF>(acc, Xyzz<BF>::load(partial + (size_t)(t0 + k) * 128));
+        for (int d = 32; d >= 1; d >>= 1) { Xyzz<BF> o = shfl_down<BF>(acc, d); acc = add<BF>(acc, o); }
+        if (lane == 0) acc.store(chunk_out + (size_t)it * 128);
+    }
+}
+template <class BF>
+__global__ void __launch_bounds__(64)
+k_bucket_big(const u32* __restrict__ toff, const uint8_t* __restrict__ chunk_out, uint8_t* __restrict__ buckets,
+             const u32* __restrict__ big, size_t cap) {
+    u32 nbig = big[0];
     int lane = threadIdx.x;
     for (u32 bi = blockIdx.x; bi < nbig; bi += gridDim.x) {
-        u32 key = biglist[1 + bi];
-        u32 t0 = toff[key], nt = toff[key + 1] - t0;
+        u32 key = big[2 + bi], cbase = big[2 + cap + bi];
+        u32 nt = toff[key + 1] - toff[key];
+        u32 nch = (nt + CHUNK - 1) / CHUNK;
         Xyzz<BF> acc = Xyzz<BF>::identity();
-        for (u32 k = lane; k < nt; k += 64) acc = add<BF>(acc, Xyzz<BF>::load(partial + (size_t)(t0 + k) * 128));
-        for (int d = 32; d >= 1; d >>= 1) {
-            Xyzz<BF> o = shfl_down<BF>(acc, d);
-            acc = add<BF>(acc, o);
-        }
+        for (u32 k = lane; k < nch; k += 64) acc = add<BF>(acc, Xyzz<BF>::load(chunk_out + (size_t)(cbase + k) * 128));
+        if (nch > 1) for (int d = 32; d >= 1; d >>= 1) { Xyzz<BF> o = shfl_down<BF>(acc, d); acc = add<BF>(acc, o); }
         if (lane == 0) acc.store(buckets + (size_t)key * 128);
     }
 }
@@ -484,13 +514,10 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
     // instead of 1.72 ms at 2^20).  Size K so that all tasks are resident at once (4 waves/SIMD =
     // 1024 threads per CU) whenever the bucket count allows it.
     const size_t cap = (size_t)Ctx.num_cus * 1024;
-    u32 K = 64;
-    if (nkeys < cap / 2) {
-        size_t room = cap - cap / 16 - nkeys / 2;          // ~ half of the buckets add a remainder task
-        K = (u32)((M + room - 1) / room);
-    }
-    if (K < 8) K = 8; if (K > MAX_K) K = MAX_K;
-    const size_t max_tasks = M / K + nkeys + 1;
+    size_t room_sz = cap / 4;                              // many buckets: about one task per bucket anyway
+    if (nkeys < cap / 2) room_sz = cap - cap / 16 - nkeys / 2;   // ~ half of the buckets add a remainder task
+    const u32 room = (u32)room_sz;                          // K = clamp(ceil(entries / room), 8, MAX_K), on the device
+    const size_t max_tasks = M / 8 + nkeys + 1;             // bound for the smallest K
     KH_REQUIRE(M < ((size_t)1 << 31) && (basis.n * (size_t)(precomp ? W : 1) + basis.batch_stride * k) < ((size_t)1 << 31), "MSM too large for 31-bit entry indices (n=%zu k=%zu)", n, k);
 
     int rc;
@@ -503,7 +530,9 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
     if ((rc = C.ws_entries.reserve((M + 1) * sizeof(u32)))) return rc;
     if ((rc = C.ws_partial.reserve(max_tasks * 128))) return rc;
     if ((rc = C.ws_buckets.reserve(nkeys * 128))) return rc;
-    if ((rc = C.ws_biglist.reserve((nkeys + 1) * sizeof(u32)))) return rc;
+    const size_t bigcap = nkeys + max_tasks / CHUNK + 2;      // big buckets <= nkeys; chunk items <= tasks/512 + nkeys
+    if ((rc = C.ws_biglist.reserve((2 + 4 * bigcap) * sizeof(u32)))) return rc;
+    if ((rc = C.ws_chunks.reserve(bigcap * 128))) return rc;
     if ((rc = C.ws_order.reserve((2 * (MAX_K + 1) + 3 * (nkeys + 2)) * sizeof(u32)))) return rc;
     // segment length of the weighted reduction: one bucket per thread (a 15-bit double-and-add each)
     // is the shortest chain, but its work grows with the bucket count -- for batches use running
@@ -550,7 +579,7 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
     u32* rnt = order + (nkeys + 2);
     u32* roff = rnt + (nkeys + 2);
     KH_HIP(hipMemsetAsync(len_hist, 0, (MAX_K + 1) * sizeof(u32), s));
-    hipLaunchKernelGGL(k_ntask, dim3((unsigned)((nkeys + 1 + 255) / 256)), dim3(256), 0, s, C.ws_off.as<u32>(), nkeys, K, C.ws_ntask.as<u32>(), len_hist);
+    hipLaunchKernelGGL(k_ntask, dim3((unsigned)((nkeys + 1 + 255) / 256)), dim3(256), 0, s, C.ws_off.as<u32>(), nkeys, room, C.ws_ntask.as<u32>(), len_hist);
     if ((rc = exclusive_scan_u32(C.ws_ntask.as<u32>(), C.ws_toff.as<u32>(), nkeys + 1, C.ws_scan_tmp, s))) return rc;
     if (M >= ((size_t)1 << 18)) {
         hipLaunchKernelGGL(k_len_starts, dim3(1), dim3(64), 0, s, len_hist, cursor);
@@ -559,19 +588,21 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
     } else {                     // small problems are launch-latency bound: keep the key order
         order = nullptr; roff = C.ws_toff.as<u32>();
     }
-    KH_HIP(hipMemsetAsync(C.ws_biglist.p, 0, sizeof(u32), s));
+    KH_HIP(hipMemsetAsync(C.ws_biglist.p, 0, 2 * sizeof(u32), s));
     C.timer.mark("tasks", s);
     // 5 accumulate
     hipLaunchKernelGGL((k_accumulate<BF>), dim3((unsigned)((max_tasks + 255) / 256)), dim3(256), 0, s,
-                       C.ws_entries.as<u32>(), C.ws_off.as<u32>(), C.ws_toff.as<u32>(), roff, order, nkeys, K,
+                       C.ws_entries.as<u32>(), C.ws_off.as<u32>(), C.ws_toff.as<u32>(), roff, order, nkeys,
                        (const uint8_t*)basis.pts, C.ws_partial.as<uint8_t>());
     C.timer.mark("accumulate", s);
     // 6 bucket sums
     hipLaunchKernelGGL((k_bucket_sum<BF>), dim3((unsigned)((nkeys + 255) / 256)), dim3(256), 0, s,
                        C.ws_toff.as<u32>(), nkeys, C.ws_partial.as<uint8_t>(), C.ws_buckets.as<uint8_t>(), C.ws_biglist.as<u32>(),
-                       nkeys <= 16384 ? 4u : 16u);
+                       bigcap, nkeys <= 16384 ? 4u : 16u);
+    hipLaunchKernelGGL((k_bucket_chunk<BF>), dim3(2048), dim3(64), 0, s,
+                       C.ws_toff.as<u32>(), C.ws_partial.as<uint8_t>(), C.ws_biglist.as<u32>(), bigcap, C.ws_chunks.as<uint8_t>());
     hipLaunchKernelGGL((k_bucket_big<BF>), dim3(1024), dim3(64), 0, s,
-                       C.ws_toff.as<u32>(), C.ws_partial.as<uint8_t>(), C.ws_buckets.as<uint8_t>(), C.ws_biglist.as<u32>());
+                       C.ws_toff.as<u32>(), C.ws_chunks.as<uint8_t>(), C.ws_buckets.as<uint8_t>(), C.ws_biglist.as<u32>(), bigcap);
     C.timer.mark("bucket_sum", s);
     // 7 reduce
     hipLaunchKernelGGL((k_reduce_seg<BF>), dim3((unsigned)((ngroups * nseg + 127) / 128)), dim3(128), 0, s,
