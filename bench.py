@@ -2,7 +2,7 @@
 """bench.py -- headline benchmark of the MI355X-native Kimchi hot path.
 
 Workload at N=1 (BASELINE.json configs[1]): ONE 2^20-point Pippenger MSM over the Vesta SRS
-(bases = SRS::<Vesta>::create(1<<20).g, generated by the product's own kh_srs_generate;
+(bases = SRS::<Vesta>::create(1<<20).g, generated on the device by kh_srs_create_device;
 scalars = uniform 254-bit Fp Montgomery limbs from a fixed-seed PRNG), inputs resident in HBM
 when the timed region starts.  A "step" is one such MSM through the C ABI
 (kh_msm_batch_dev: digits -> sort -> bucket accumulation -> reduction -> host finish).
@@ -141,9 +141,9 @@ def main():
     # bases: this rank's slice of SRS::<Vesta>::create(world << log_n).g
     t0 = time.perf_counter()
     CID = khip.VESTA if args.curve == "vesta" else khip.PALLAS
-    g = khip.srs_generate(CID, rank * n, n, gen_threads)
+    srs = khip.Srs.create(CID, n, start=rank * n)      # SRS::create on the device (+ window tables)
     t_gen = time.perf_counter() - t0
-    srs = khip.Srs(CID, g)
+    g = None
     sc = rand_scalars(np.random.default_rng(1234 + rank), n)
     d_sc = khip.DevBuf(sc.nbytes).upload(sc)
     R_FP = [0x34786d38fffffffd, 0x992c350be41914ad, 0xffffffffffffffff, 0x3fffffffffffffff]     # 1 in Montgomery form
@@ -238,11 +238,12 @@ def main():
                    "scalars": "uniform 254-bit, seed 1234+rank", "parallelism": "point-range x%d" % world},
         "roofline": roofline,
         "phases_ms": phase_avg, "ms_per_step_synchronous": float(np.median(sync_ms)), "msm_in_flight": depth,
-        "srs_generate_s": t_gen,
+        "srs_create_device_s": t_gen,
     }
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import cref          # cpu_baseline leg only: the oracle as the timed CPU port + checker
+        g = srs.get_g()
         t0 = time.perf_counter()
         want, winf = cref.msm(CID, g, sc, scalars_mont=True, threads=cores)
         t_cpu = time.perf_counter() - t0
@@ -254,7 +255,7 @@ def main():
             line["parity_error"] = "GPU result differs from the CPU oracle"
 
     if rank == 0 and world == 1 and not args.no_oplist and args.curve == "vesta":
-        g16 = g[: 1 << 16]
+        g16 = srs.get_g(0, 1 << 16)
         srs16 = khip.Srs(khip.VESTA, g16)
         t0 = time.perf_counter()
         srs16.compute_lagrange(16)            # SRS::lagrange_basis as a device group-iNTT (index time, ipa.rs:1065-1172)

@@ -66,6 +66,14 @@ size_t kh_srs_size(const kh_srs_t *srs);
 int kh_srs_generate(int curve, size_t start, size_t count, uint64_t *out_xy, int threads);
 int kh_srs_h(int curve, uint64_t out_xy[8]);
 
+/* SRS::create(depth) entirely on the device (csrc/srs_gen.hip: Blake2b + group map + Tonelli-Shanks per
+ * thread; ~15 ms for 2^20 points), already expanded to the MSM window tables; kh_srs_get_g reads
+ * g[offset .. offset+count) back for the caller's own `g: Vec<G>`. */
+int kh_srs_create_device(int curve, size_t depth, kh_srs_t **out);
+/* the slice g[start .. start+count) of a larger SRS (one rank of a point-range-sharded MSM) */
+int kh_srs_create_device_range(int curve, size_t start, size_t count, kh_srs_t **out);
+int kh_srs_get_g(kh_srs_t *srs, size_t offset, size_t count, uint64_t *out_xy);
+
 /* Registers chunk `chunk` of the Lagrange basis for the domain of size 2^log2_domain
  * (`SRS::get_lagrange_basis`, ipa.rs:780-801; entries computed by ipa.rs:1065-1172):
  * n = 2^log2_domain points, `inf` nullable per-point infinity flags. */

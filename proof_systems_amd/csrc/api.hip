@@ -121,6 +121,36 @@ int kh_srs_create(int curve, const uint64_t* g_xy, size_t n, kh_srs_t** out) {
     *out = s.release();
     return KH_OK;
 }
+int kh_srs_create_device(int curve, size_t depth, kh_srs_t** out) { return kh_srs_create_device_range(curve, 0, depth, out); }
+int kh_srs_create_device_range(int curve, size_t start, size_t depth, kh_srs_t** out) {
+    KH_REQUIRE(out && depth > 0, "kh_srs_create_device: null argument or depth == 0");
+    KH_REQUIRE(curve == KH_CURVE_VESTA || curve == KH_CURVE_PALLAS, "unknown curve id %d", curve);
+    KH_REQUIRE(start + depth <= ((size_t)1 << 32), "SRS index must fit u32 (ipa.rs:758)");
+    int rc = ensure_init(); if (rc) return rc;
+    std::unique_ptr<kh_srs> s(new kh_srs);
+    s->curve = curve; s->n = depth;
+    Context& C = ctx();
+    std::lock_guard<std::mutex> lk(C.mu);
+    const bool pre = depth >= MSM_PRECOMP_MIN_N && !getenv("KH_NO_PRECOMP");
+    const int W = (256 + MSM_PRECOMP_C - 1) / MSM_PRECOMP_C;
+    if ((rc = s->g.reserve(depth * 64 * (pre ? W : 1)))) return rc;
+    if ((rc = srs_generate_device(C, curve, start, depth, s->g.p))) return rc;
+    if (pre) {
+        if ((rc = msm_precompute(C, curve, s->g.p, nullptr, depth, MSM_PRECOMP_C))) return rc;
+        s->g_precomp_c = MSM_PRECOMP_C;
+    }
+    if ((rc = kh_srs_h(curve, s->h))) return rc;
+    *out = s.release();
+    return KH_OK;
+}
+int kh_srs_get_g(kh_srs_t* srs, size_t offset, size_t count, uint64_t* out_xy) {
+    KH_REQUIRE(srs && (out_xy || count == 0), "kh_srs_get_g: null argument");
+    KH_REQUIRE(offset + count <= srs->n, "range [%zu, %zu) beyond the SRS size %zu", offset, offset + count, srs->n);
+    Context& C = ctx();
+    std::lock_guard<std::mutex> lk(C.mu);
+    if (count) KH_HIP(hipMemcpy(out_xy, (const char*)srs->g.p + offset * 64, count * 64, hipMemcpyDeviceToHost));
+    return KH_OK;
+}
 void kh_srs_free(kh_srs_t* srs) {
     if (!srs) return;
     Context& C = ctx();

@@ -30,6 +30,8 @@ int ntt_build_twiddles(Context& C, int field, unsigned logn, int inverse, uint64
 int ipa_fold_scalars(Context& C, int field, const uint64_t* lo, const uint64_t* hi, const uint64_t u[4], size_t n, uint64_t* out);
 int ipa_inner_product(Context& C, int field, const uint64_t* a, const uint64_t* b, size_t n, uint64_t out[4]);
 int ipa_fold_points(Context& C, int curve, const uint64_t* g_lo, const uint64_t* g_hi, const uint64_t u[4], size_t n, uint64_t* out_xy, uint8_t* out_inf);
+// srs_gen.hip
+int srs_generate_device(Context& C, int curve, size_t start, size_t count, void* out_xy_dev);
 // lagrange.hip
 int lagrange_run(Context& C, int curve, const void* g_dev, size_t srs_size, unsigned log_n, unsigned chunk, void* out_xy_dev, uint8_t* out_inf_dev);
 khost::fe ntt_host_root(int field, unsigned logn, int inverse);   // omega_{2^logn} (or its inverse), Montgomery

@@ -36,7 +36,7 @@ SYMBOLS = [
     "kh_debug_field_op", "kh_debug_point_op", "kh_srs_generate", "kh_srs_h",
     "kh_commit_non_hiding", "kh_commit_evaluations_non_hiding", "kh_srs_set_blinding_base",
     "kh_srs_get_blinding_base", "kh_mask_custom", "kh_domain_generator", "kh_msm_points_batch", "kh_msm_submit", "kh_msm_wait",
-    "kh_ipa_fold_scalars", "kh_inner_product", "kh_ipa_fold_points", "kh_points_sum",
+    "kh_ipa_fold_scalars", "kh_inner_product", "kh_ipa_fold_points", "kh_points_sum", "kh_srs_create_device", "kh_srs_create_device_range", "kh_srs_get_g",
 ]
 
 _lib.kh_last_error.restype = C.c_char_p
@@ -56,6 +56,9 @@ _lib.kh_msm_points.argtypes = [C.c_int, U64P, U8P, U64P, C.c_size_t, C.c_int, U6
 _lib.kh_ipa_fold_scalars.argtypes = [C.c_int, U64P, U64P, U64P, C.c_size_t, U64P]
 _lib.kh_inner_product.argtypes = [C.c_int, U64P, U64P, C.c_size_t, U64P]
 _lib.kh_ipa_fold_points.argtypes = [C.c_int, U64P, U64P, U64P, C.c_size_t, U64P, U8P]
+_lib.kh_srs_create_device.argtypes = [C.c_int, C.c_size_t, C.POINTER(C.c_void_p)]
+_lib.kh_srs_create_device_range.argtypes = [C.c_int, C.c_size_t, C.c_size_t, C.POINTER(C.c_void_p)]
+_lib.kh_srs_get_g.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, U64P]
 _lib.kh_points_sum.argtypes = [C.c_int, U64P, U8P, C.c_size_t, U64P, U8P]
 _lib.kh_msm_submit.argtypes = [C.c_void_p, C.c_int, C.c_uint, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.POINTER(C.c_uint64)]
 _lib.kh_msm_wait.argtypes = [C.c_uint64, U64P, U8P]
@@ -125,12 +128,28 @@ def init(device: int = -1):
 class Srs:
     """Device-resident SRS bases (the g half of ipa::SRS<G>, poly-commitment/src/ipa.rs:53-75)."""
 
-    def __init__(self, curve: int, g_xy):
-        g = _c64(g_xy, (-1, 8))
+    def __init__(self, curve: int, g_xy=None, depth: int = 0, start: int = 0):
+        """Upload the bases g_xy, or (g_xy is None) run SRS::create on the device for g[start, start+depth)."""
         self.curve = curve
-        self.n = g.shape[0]
         self._h = C.c_void_p()
-        _check(_lib.kh_srs_create(curve, _p64(g), self.n, C.byref(self._h)))
+        if g_xy is None:
+            self.n = depth
+            _check(_lib.kh_srs_create_device_range(curve, start, depth, C.byref(self._h)))
+        else:
+            g = _c64(g_xy, (-1, 8))
+            self.n = g.shape[0]
+            _check(_lib.kh_srs_create(curve, _p64(g), self.n, C.byref(self._h)))
+
+    @classmethod
+    def create(cls, curve: int, depth: int, start: int = 0):
+        """SRS::create(depth) (ipa.rs:751-778) on the device; start > 0 gives the slice g[start, start+depth)."""
+        return cls(curve, None, depth, start)
+
+    def get_g(self, offset: int = 0, count: int = None):
+        count = self.n - offset if count is None else count
+        out = np.zeros((count, 8), dtype=np.uint64)
+        _check(_lib.kh_srs_get_g(self._h, offset, count, _p64(out)))
+        return out
 
     def close(self):
         if self._h:

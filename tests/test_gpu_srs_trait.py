@@ -268,3 +268,28 @@ def test_points_sum_matches_oracle(khip):
         assert ginf == ainf and np.array_equal(got, acc)
         z, zinf = khip.points_sum(cid, pts[[1, 7]])
         assert zinf
+
+
+@pytest.mark.parametrize("name", ["vesta", "pallas"])
+def test_srs_create_on_device(khip, golden, name):
+    """SRS::create on the device reproduces srs/{vesta,pallas}.srs: all 65,536 points by digest
+    (precomputed_srs.rs:229-234) plus the sampled points, and agrees with the host generator beyond 2^16."""
+    import hashlib
+    c = P.CURVES[name]
+    srs = khip.Srs.create(c.cid, 1 << 16)
+    g = srs.get_g()
+    comp = cref.compress(c.cid, g)
+    assert hashlib.blake2b(comp.tobytes(), digest_size=32).hexdigest() == golden["srs"][name]["prefix_digest_blake2b256"]["16"]
+    for idx, hx in golden["srs"][name]["samples"].items():
+        assert bytes(comp[int(idx)]).hex() == hx
+    # the generated SRS commits like an uploaded one
+    rng = np.random.default_rng(3)
+    sc = rng.integers(0, 1 << 64, size=(1 << 16, 4), dtype=np.uint64); sc[:, 3] &= np.uint64((1 << 61) - 1)
+    a, ai = srs.msm(sc)
+    w, wi = cref.msm(c.cid, g, sc, threads=8)
+    assert ai == wi and np.array_equal(a, w)
+    srs.close()
+    big = khip.Srs.create(c.cid, (1 << 16) + 777)
+    tail = big.get_g(1 << 16, 777)
+    assert np.array_equal(tail, khip.srs_generate(c.cid, 1 << 16, 777))
+    big.close()
