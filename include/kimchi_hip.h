@@ -135,6 +135,15 @@ int kh_inner_product(int field, const uint64_t *a, const uint64_t *b, size_t n, 
  * u = u_pre.to_field(endo_r).  u: Montgomery limbs of the scalar field. */
 int kh_ipa_fold_points(int curve, const uint64_t *g_lo_xy, const uint64_t *g_hi_xy, const uint64_t u[4], size_t n,
                        uint64_t *out_xy, uint8_t *out_inf);
+/* CommitmentCurve::combine_one_endo (commitment.rs:581-589 -> combine.rs:292-340; prover call site
+ * ipa.rs:1006): g'[i] = g_lo[i] + [chal.to_field(endo_r)] g_hi[i] by the Halo endo ladder -- 64 x
+ * (doubling + mixed addition with +-g_hi or +-phi(g_hi)) instead of a 255-bit double-and-add.
+ * chal: the 128-bit ScalarChallenge prechallenge as two canonical (non-Montgomery) LE limbs. */
+int kh_ipa_fold_points_endo(int curve, const uint64_t *g_lo_xy, const uint64_t *g_hi_xy, const uint64_t chal[2], size_t n,
+                            uint64_t *out_xy, uint8_t *out_inf);
+/* endos::<G>() (ipa.rs:214-231): endo_q in the base field, endo_r in the scalar field (Montgomery limbs)
+ * with phi(P) = (endo_q x, y) = [endo_r] P.  Host-only, needs no device. */
+int kh_endos(int curve, uint64_t endo_q[4], uint64_t endo_r[4]);
 
 /* ---- commitment wrappers (host logic of the SRS trait over the MSM kernels) ----
  * kh_commit_non_hiding = SRS::commit_non_hiding (poly-commitment/src/ipa.rs:638-683):

@@ -351,6 +351,60 @@ CURVES = {0: VESTA, 1: PALLAS, "vesta": VESTA, "pallas": PALLAS}
 
 
 # ---------------------------------------------------------------------------
+# Endomorphism constants and scalar challenges (poly-commitment/src/ipa.rs:214-231,
+# poseidon/src/sponge.rs:110-114, 190-226)
+# ---------------------------------------------------------------------------
+def endo_coefficient(F: Field) -> int:
+    """GENERATOR^((p-1)/3): a primitive cube root of unity (sponge.rs:110-114)."""
+    return pow(GENERATOR, (F.p - 1) // 3, F.p)
+
+
+def endos(curve: Curve) -> Tuple[int, int]:
+    """(endo_q in the base field, endo_r in the scalar field) with phi(P) = (endo_q x, y) = [endo_r] P
+    (ipa.rs:214-231)."""
+    eq = endo_coefficient(curve.base)
+    er = endo_coefficient(curve.scalar)
+    g = curve.gen
+    phi = (g[0] * eq % curve.base.p, g[1])
+    if curve.mul(g, er) != phi:
+        er = er * er % curve.scalar.p
+        assert curve.mul(g, er) == phi
+    return eq, er
+
+
+def challenge_to_field(F: Field, chal: int, endo: int, length_in_bits: int = 128) -> int:
+    """ScalarChallenge::to_field_with_length (sponge.rs:190-215): k = a * endo + b."""
+    a = b = 2
+    for i in reversed(range(length_in_bits // 2)):
+        a = 2 * a % F.p
+        b = 2 * b % F.p
+        s = 1 if (chal >> (2 * i)) & 1 else F.p - 1
+        if (chal >> (2 * i + 1)) & 1 == 0:
+            b = (b + s) % F.p
+        else:
+            a = (a + s) % F.p
+    return (a * endo + b) % F.p
+
+
+def combine_one_endo(curve: Curve, g1: Sequence[Affine], g2: Sequence[Affine], chal: int) -> List[Affine]:
+    """CommitmentCurve::combine_one_endo (commitment.rs:581-589 -> combine.rs:292-340): the Halo endo ladder,
+    acc = 2 (phi(g2) + g2); for each 2-bit chunk: s = +-g2 [phi'd]; acc = (acc + s) + acc; result g1 + acc."""
+    eq, _ = endos(curve)
+    p = curve.base.p
+    out = []
+    for P1, P2 in zip(g1, g2):
+        phi = (P2[0] * eq % p, P2[1])
+        acc = curve.add(curve.add(phi, P2), curve.add(phi, P2))
+        for i in reversed(range(64)):
+            S = P2 if (chal >> (2 * i)) & 1 else curve.neg(P2)
+            if (chal >> (2 * i + 1)) & 1:
+                S = (S[0] * eq % p, S[1])
+            acc = curve.add(curve.add(acc, S), acc)
+        out.append(curve.add(P1, acc))
+    return out
+
+
+# ---------------------------------------------------------------------------
 # msgpack SRS file (precomputed_srs.rs:76-91; SURVEY A.1)
 # ---------------------------------------------------------------------------
 def read_srs_file(path: str, curve: Curve, limit: Optional[int] = None):

@@ -474,6 +474,23 @@ int kh_ipa_fold_points(int curve, const uint64_t* g_lo, const uint64_t* g_hi, co
     return ipa_fold_points(C, curve, g_lo, g_hi, u, n, out_xy, out_inf);
 }
 
+int kh_ipa_fold_points_endo(int curve, const uint64_t* g_lo, const uint64_t* g_hi, const uint64_t chal[2], size_t n, uint64_t* out_xy, uint8_t* out_inf) {
+    KH_REQUIRE(curve == KH_CURVE_VESTA || curve == KH_CURVE_PALLAS, "unknown curve id %d", curve);
+    KH_REQUIRE((g_lo && g_hi && out_xy && out_inf) || n == 0, "null argument");
+    KH_REQUIRE(chal, "null challenge");
+    int rc = ensure_init(); if (rc) return rc;
+    if (n == 0) return KH_OK;
+    Context& C = ctx();
+    std::lock_guard<std::mutex> lk(C.mu);
+    return ipa_fold_points_endo(C, curve, g_lo, g_hi, chal, n, out_xy, out_inf);
+}
+int kh_endos(int curve, uint64_t endo_q[4], uint64_t endo_r[4]) {
+    KH_REQUIRE(curve == KH_CURVE_VESTA || curve == KH_CURVE_PALLAS, "unknown curve id %d", curve);
+    KH_REQUIRE(endo_q && endo_r, "null argument");
+    curve_endos(curve, endo_q, endo_r);
+    return KH_OK;
+}
+
 // ---------------------------------------------------------------------------------- NTT
 int kh_domain_generator(int field, unsigned log2_n, uint64_t out[4]) {
     KH_REQUIRE(field == KH_FIELD_FP || field == KH_FIELD_FQ, "unknown field id %d", field);

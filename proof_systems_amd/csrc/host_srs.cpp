@@ -120,6 +120,40 @@ struct GroupMap {          // BWParameters::setup for a = 0, b = 5: u = 1 (group
 const GroupMap& group_map(int curve) { static const GroupMap M[2] = {GroupMap(0), GroupMap(1)}; return M[curve & 1]; }
 }  // namespace
 
+namespace kh {
+// GENERATOR^((p-1)/3), GENERATOR = 5: a primitive cube root of unity, Montgomery form (poseidon/src/sponge.rs:110-114)
+void endo_coefficient(int field, uint64_t out[4]) {
+    SqrtCtx S(field);
+    fe pm1 = S.F.f.p; pm1.l[0] -= 1;
+    fe e; unsigned __int128 rem = 0;
+    for (int i = 3; i >= 0; i--) { unsigned __int128 cur = (rem << 64) | pm1.l[i]; e.l[i] = (u64)(cur / 3); rem = cur % 3; }
+    fe r = S.pow(S.five, e);
+    memcpy(out, &r, 32);
+}
+// (endo_q, endo_r) of ipa.rs:214-231: phi(P) = (endo_q x, y) = [endo_r] P. endo_q is the base field's coefficient as is;
+// endo_r is the scalar field's coefficient or its square, whichever acts as phi. The reference decides on the curve
+// generator; the eigenvalue of phi is the same on every point of the prime-order group, so the first curve point with
+// x = 1, 2, 3, ... decides here (no generator constant needed on this side).
+void curve_endos(int curve, uint64_t endo_q[4], uint64_t endo_r[4]) {
+    const int bf = khost::base_field_id(curve), sf = khost::scalar_field_id(curve);
+    SqrtCtx SB(bf); Fld FS(sf);
+    const Fld& FB = SB.F;
+    fe eq, er;
+    endo_coefficient(bf, eq.l); endo_coefficient(sf, er.l);
+    khost::aff g; g.x = FB.f.one;
+    for (;;) {
+        fe rhs = FB.add(FB.mul(FB.sqr(g.x), g.x), SB.five);
+        if (SB.sqrt(rhs, g.y)) break;
+        g.x = FB.add(g.x, FB.f.one);
+    }
+    khost::Crv crv(curve);
+    khost::aff lhs;
+    crv.to_affine(crv.mul_plain(crv.from_affine(g), FS.from_mont(er)), lhs);
+    if (!(khost::eq(lhs.x, FB.mul(g.x, eq)) && khost::eq(lhs.y, g.y))) er = FS.sqr(er);
+    memcpy(endo_q, &eq, 32); memcpy(endo_r, &er, 32);
+}
+}  // namespace kh
+
 extern "C" {
 int kh_srs_generate(int curve, size_t start, size_t count, uint64_t* out_xy, int threads) {
     KH_REQUIRE(curve == KH_CURVE_VESTA || curve == KH_CURVE_PALLAS, "unknown curve id %d", curve);

@@ -29,6 +29,9 @@ int ntt_build_twiddles(Context& C, int field, unsigned logn, int inverse, uint64
 // ipa.hip
 int ipa_fold_scalars(Context& C, int field, const uint64_t* lo, const uint64_t* hi, const uint64_t u[4], size_t n, uint64_t* out);
 int ipa_inner_product(Context& C, int field, const uint64_t* a, const uint64_t* b, size_t n, uint64_t out[4]);
+int ipa_fold_points_endo(Context& C, int curve, const uint64_t* g_lo, const uint64_t* g_hi, const uint64_t chal[2], size_t n, uint64_t* out_xy, uint8_t* out_inf);
+void endo_coefficient(int field, uint64_t out[4]);
+void curve_endos(int curve, uint64_t endo_q[4], uint64_t endo_r[4]);
 int ipa_fold_points(Context& C, int curve, const uint64_t* g_lo, const uint64_t* g_hi, const uint64_t u[4], size_t n, uint64_t* out_xy, uint8_t* out_inf);
 // srs_gen.hip
 int srs_generate_device(Context& C, int curve, size_t start, size_t count, void* out_xy_dev);

@@ -36,7 +36,7 @@ SYMBOLS = [
     "kh_debug_field_op", "kh_debug_point_op", "kh_srs_generate", "kh_srs_h",
     "kh_commit_non_hiding", "kh_commit_evaluations_non_hiding", "kh_srs_set_blinding_base",
     "kh_srs_get_blinding_base", "kh_mask_custom", "kh_domain_generator", "kh_msm_points_batch", "kh_msm_submit", "kh_msm_wait",
-    "kh_ipa_fold_scalars", "kh_inner_product", "kh_ipa_fold_points", "kh_points_sum", "kh_srs_create_device", "kh_srs_create_device_range", "kh_srs_get_g",
+    "kh_ipa_fold_scalars", "kh_inner_product", "kh_ipa_fold_points", "kh_ipa_fold_points_endo", "kh_endos", "kh_points_sum", "kh_srs_create_device", "kh_srs_create_device_range", "kh_srs_get_g",
 ]
 
 _lib.kh_last_error.restype = C.c_char_p
@@ -56,6 +56,8 @@ _lib.kh_msm_points.argtypes = [C.c_int, U64P, U8P, U64P, C.c_size_t, C.c_int, U6
 _lib.kh_ipa_fold_scalars.argtypes = [C.c_int, U64P, U64P, U64P, C.c_size_t, U64P]
 _lib.kh_inner_product.argtypes = [C.c_int, U64P, U64P, C.c_size_t, U64P]
 _lib.kh_ipa_fold_points.argtypes = [C.c_int, U64P, U64P, U64P, C.c_size_t, U64P, U8P]
+_lib.kh_ipa_fold_points_endo.argtypes = [C.c_int, U64P, U64P, U64P, C.c_size_t, U64P, U8P]
+_lib.kh_endos.argtypes = [C.c_int, U64P, U64P]
 _lib.kh_srs_create_device.argtypes = [C.c_int, C.c_size_t, C.POINTER(C.c_void_p)]
 _lib.kh_srs_create_device_range.argtypes = [C.c_int, C.c_size_t, C.c_size_t, C.POINTER(C.c_void_p)]
 _lib.kh_srs_get_g.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, U64P]
@@ -380,6 +382,22 @@ def ipa_fold_points(curve: int, g_lo, g_hi, u):
     out = np.zeros_like(g_lo); inf = np.zeros(g_lo.shape[0], dtype=np.uint8)
     _check(_lib.kh_ipa_fold_points(curve, _p64(g_lo), _p64(g_hi), _p64(u), g_lo.shape[0], _p64(out), _p8(inf)))
     return out, inf
+
+
+def ipa_fold_points_endo(curve: int, g_lo, g_hi, chal: int):
+    """combine_one_endo: chal is the 128-bit prechallenge as a Python int."""
+    g_lo = _c64(g_lo, (-1, 8)); g_hi = _c64(g_hi, (-1, 8))
+    c = np.array([chal & (2**64 - 1), (chal >> 64) & (2**64 - 1)], dtype=np.uint64)
+    out = np.zeros_like(g_lo); inf = np.zeros(g_lo.shape[0], dtype=np.uint8)
+    _check(_lib.kh_ipa_fold_points_endo(curve, _p64(g_lo), _p64(g_hi), _p64(c), g_lo.shape[0], _p64(out), _p8(inf)))
+    return out, inf
+
+
+def endos(curve: int):
+    """(endo_q, endo_r) as Montgomery limb arrays; host-only."""
+    q = np.zeros(4, dtype=np.uint64); r = np.zeros(4, dtype=np.uint64)
+    _check(_lib.kh_endos(curve, _p64(q), _p64(r)))
+    return q, r
 
 
 def domain_generator(field: int, log2_n: int):

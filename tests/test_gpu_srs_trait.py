@@ -251,6 +251,37 @@ def test_ipa_round_vector_ops(khip, cid):
     assert not linf and not si2 and np.array_equal(lhs, s2)
 
 
+@pytest.mark.parametrize("cid", [0, 1])
+def test_ipa_fold_points_endo(khip, cid):
+    """combine_one_endo (commitment.rs:581-589 -> combine.rs:292-340) on the device against (1) the oracle's
+    restatement of the ladder, point by point, and (2) the generic fold with u = chal.to_field(endo_r)
+    (sponge.rs:190-226) -- the equivalence the prover relies on at ipa.rs:1006 / the verifier at ipa.rs:99-136."""
+    c = P.CURVES[cid]; F = c.scalar
+    rnd = np.random.default_rng(99 + cid)
+    n = 300                                              # three blocks, ragged tail
+    g = khip.srs_generate(cid, 0, 2 * n)
+    g_lo, g_hi = g[:n], g[n:]
+    _, endo_r = P.endos(c)
+    chals = [int.from_bytes(rnd.bytes(16), "little"), 0, (1 << 128) - 1, 1, 1 << 127]
+    for chal in chals:
+        fx, finf = khip.ipa_fold_points_endo(cid, g_lo, g_hi, chal)
+        assert not finf.any()
+        u = cref.ints_to_limbs([F.to_mont(P.challenge_to_field(F, chal, endo_r))])[0]
+        gx, ginf = khip.ipa_fold_points(cid, g_lo, g_hi, u)
+        assert np.array_equal(fx, gx) and np.array_equal(finf, ginf)
+        idx = [0, 1, 127, 128, 299]
+        want = P.combine_one_endo(c, [_aff(c, g_lo[i], 0) for i in idx], [_aff(c, g_hi[i], 0) for i in idx], chal)
+        for k, i in enumerate(idx):
+            assert _aff(c, fx[i], finf[i]) == want[k]
+    # g_hi = -g_lo-like exceptional inputs: folding a point with itself must stay exact (doubling inside madd)
+    fx, finf = khip.ipa_fold_points_endo(cid, g_lo[:4], g_lo[:4], chals[0])
+    want = P.combine_one_endo(c, [_aff(c, x, 0) for x in g_lo[:4]], [_aff(c, x, 0) for x in g_lo[:4]], chals[0])
+    assert [_aff(c, fx[i], finf[i]) for i in range(4)] == want
+    # empty input is a no-op
+    e, einf = khip.ipa_fold_points_endo(cid, np.zeros((0, 8), np.uint64), np.zeros((0, 8), np.uint64), 5)
+    assert e.shape[0] == 0 and einf.shape[0] == 0
+
+
 def test_points_sum_matches_oracle(khip):
     """kh_points_sum (host fold of per-GPU partial sums) incl. infinity inputs, P + (-P) and doubling."""
     for cid in (0, 1):
