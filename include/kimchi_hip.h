@@ -144,6 +144,33 @@ int kh_ipa_fold_points_endo(int curve, const uint64_t *g_lo_xy, const uint64_t *
 /* endos::<G>() (ipa.rs:214-231): endo_q in the base field, endo_r in the scalar field (Montgomery limbs)
  * with phi(P) = (endo_q x, y) = [endo_r] P.  Host-only, needs no device. */
 int kh_endos(int curve, uint64_t endo_q[4], uint64_t endo_r[4]);
+/* ScalarChallenge::to_field(&endo_r) (poseidon/src/sponge.rs:190-226) for the curve's scalar field:
+ * chal = the 128-bit prechallenge (two canonical LE limbs), out = Montgomery limbs.  Host-only. */
+int kh_scalar_challenge_to_field(int curve, const uint64_t chal[2], uint64_t out[4]);
+
+/* ---- the folding loop of SRS::open on the device (poly-commitment/src/ipa.rs:929-1007) ----
+ * The caller keeps the sponge and the RNG (ipa.rs:940-941, 966-971); everything between two squeezes runs here
+ * on device-resident vectors, so a round costs one host<->device hop of 2 points + 1 challenge:
+ *
+ *   kh_ipa_begin(srs, a = p.coeffs (a_len <= srs size, zero-padded as ipa.rs:918-920), b = b_init
+ *                (padded_length entries), u_base = U)                                  -> state
+ *   per round:  kh_ipa_round_lr(state, rand_l, rand_r) -> (L, R)      ipa.rs:943-961
+ *               kh_ipa_round_fold(state, u_pre)        -> (u, u^-1)   ipa.rs:972-1006, u = u_pre.to_field(endo_r)
+ *   kh_ipa_finish(state) -> a0 = a[0], b0 = b[0], sg = g[0]                             ipa.rs:1009-1018
+ *
+ * L, R and sg are the reference's group elements (bit-identical affine coordinates); the basis is never folded:
+ * round j's L / R are MSMs over the SRS's resident window tables with the scalars a (x) (challenge tensor), and
+ * sg = <challenge tensor, G>.  The blinding base H is the handle's (kh_srs_set_blinding_base);
+ * the SRS size must be a power of two; one opening at a time per SRS handle (KH_E_INVALID otherwise).
+ * All field elements Montgomery limbs; u_pre as in kh_ipa_fold_points_endo. */
+typedef struct kh_ipa kh_ipa_t;
+int kh_ipa_begin(kh_srs_t *srs, const uint64_t *a, size_t a_len, const uint64_t *b, size_t b_len,
+                 const uint64_t u_base_xy[8], kh_ipa_t **out);
+int kh_ipa_rounds_left(const kh_ipa_t *st);
+int kh_ipa_round_lr(kh_ipa_t *st, const uint64_t rand_l[4], const uint64_t rand_r[4], uint64_t lr_xy[16], uint8_t lr_inf[2]);
+int kh_ipa_round_fold(kh_ipa_t *st, const uint64_t chal[2], uint64_t u_out[4], uint64_t u_inv_out[4]);
+int kh_ipa_finish(kh_ipa_t *st, uint64_t a0[4], uint64_t b0[4], uint64_t sg_xy[8], uint8_t *sg_inf);
+void kh_ipa_free(kh_ipa_t *st);
 
 /* ---- commitment wrappers (host logic of the SRS trait over the MSM kernels) ----
  * kh_commit_non_hiding = SRS::commit_non_hiding (poly-commitment/src/ipa.rs:638-683):

@@ -404,6 +404,41 @@ def combine_one_endo(curve: Curve, g1: Sequence[Affine], g2: Sequence[Affine], c
     return out
 
 
+def ipa_open_rounds(curve: Curve, g: Sequence[Affine], h: Affine, u_base: Affine, a: Sequence[int], b: Sequence[int],
+                    rands: Sequence[Tuple[int, int]], chals: Sequence[int], msm=None):
+    """The folding loop of SRS::open, literally (ipa.rs:929-1018): per round L = <a_hi, g_lo> + rand_l H + <a_hi, b_lo> U,
+    R = <a_lo, g_hi> + rand_r H + <a_lo, b_hi> U, u = u_pre.to_field(endo_r), a = a_lo + u^-1 a_hi, b = b_lo + u b_hi,
+    g = combine_one_endo(g_lo, g_hi, u_pre).  The sponge is the caller's: the prechallenges are inputs.
+    Returns (lr, us, a0, b0, g0).  `msm(points, scalars)` may be supplied to speed up the L/R sums."""
+    F = curve.scalar
+    _, endo_r = endos(curve)
+    if msm is None:
+        def msm(pts, sc):
+            acc = None
+            for pt, k in zip(pts, sc):
+                acc = curve.add(acc, curve.mul(pt, k))
+            return acc
+    g = list(g); a = list(a) + [0] * (len(g) - len(a)); b = list(b)
+    assert len(g) == len(b) and len(g) & (len(g) - 1) == 0
+    lr, us = [], []
+    for (rand_l, rand_r), u_pre in zip(rands, chals):
+        n = len(g) // 2
+        g_lo, g_hi, a_lo, a_hi, b_lo, b_hi = g[:n], g[n:], a[:n], a[n:], b[:n], b[n:]
+        ip_l = sum(x * y for x, y in zip(a_hi, b_lo)) % F.p
+        ip_r = sum(x * y for x, y in zip(a_lo, b_hi)) % F.p
+        L = msm(g_lo + [h, u_base], a_hi + [rand_l, ip_l])
+        R = msm(g_hi + [h, u_base], a_lo + [rand_r, ip_r])
+        lr.append((L, R))
+        u = challenge_to_field(F, u_pre, endo_r)
+        u_inv = F.inv(u)
+        us.append(u)
+        a = [(lo + u_inv * hi) % F.p for lo, hi in zip(a_lo, a_hi)]
+        b = [(lo + u * hi) % F.p for lo, hi in zip(b_lo, b_hi)]
+        g = combine_one_endo(curve, g_lo, g_hi, u_pre)
+    assert len(g) == 1
+    return lr, us, a[0], b[0], g[0]
+
+
 # ---------------------------------------------------------------------------
 # msgpack SRS file (precomputed_srs.rs:76-91; SURVEY A.1)
 # ---------------------------------------------------------------------------

@@ -67,18 +67,27 @@ using namespace kh;
 struct kh_srs {
     int curve = 0;
     size_t n = 0;
-    DevBuf g;
+    DevBuf g;                 // window tables of g_stride = n + 2 points: g[0..n), then the slots of H and U
+    size_t g_stride = 0;      // (the two extra bases of the opening rounds, written by kh_ipa_begin)
     int g_precomp_c = 0;
+    bool ipa_live = false;    // the U slot belongs to one opening at a time
     uint64_t h[8];
     std::map<unsigned, std::vector<std::unique_ptr<LagrangeChunk>>> lagrange;
     std::mutex mu;
 };
 
+struct EndoPair { uint64_t q[4], r[4]; };
+static const EndoPair& cached_endos(int curve) {
+    static EndoPair E[2]; static std::once_flag once[2];
+    std::call_once(once[curve & 1], [curve] { curve_endos(curve & 1, E[curve & 1].q, E[curve & 1].r); });
+    return E[curve & 1];
+}
+
 static int resolve_basis(kh_srs_t* srs, int basis, unsigned chunk, MsmBasis& out) {
     KH_REQUIRE(srs != nullptr, "null SRS handle");
     if (basis == KH_BASIS_G) {
         KH_REQUIRE(chunk == 0, "chunk must be 0 for the monomial basis");
-        out.pts = srs->g.p; out.inf = nullptr; out.n = srs->n; out.precomp_c = srs->g_precomp_c;
+        out.pts = srs->g.p; out.inf = nullptr; out.n = srs->n; out.stride = srs->g_stride; out.precomp_c = srs->g_precomp_c;
         return KH_OK;
     }
     auto it = srs->lagrange.find((unsigned)basis);
@@ -111,10 +120,13 @@ int kh_srs_create(int curve, const uint64_t* g_xy, size_t n, kh_srs_t** out) {
     std::lock_guard<std::mutex> lk(C.mu);
     const bool pre = n >= MSM_PRECOMP_MIN_N && !getenv("KH_NO_PRECOMP");
     const int W = (256 + MSM_PRECOMP_C - 1) / MSM_PRECOMP_C;
-    if ((rc = s->g.reserve(n * 64 * (pre ? W : 1)))) return rc;
+    s->g_stride = n + 2;
+    if ((rc = s->g.reserve(s->g_stride * 64 * (pre ? W : 1)))) return rc;
     KH_HIP(hipMemcpy(s->g.p, g_xy, n * 64, hipMemcpyHostToDevice));
+    KH_HIP(hipMemcpy((char*)s->g.p + n * 64, g_xy, 64, hipMemcpyHostToDevice));          // placeholders: valid points
+    KH_HIP(hipMemcpy((char*)s->g.p + (n + 1) * 64, g_xy, 64, hipMemcpyHostToDevice));
     if (pre) {
-        if ((rc = msm_precompute(C, curve, s->g.p, nullptr, n, MSM_PRECOMP_C))) return rc;
+        if ((rc = msm_precompute(C, curve, s->g.p, nullptr, s->g_stride, MSM_PRECOMP_C))) return rc;
         s->g_precomp_c = MSM_PRECOMP_C;
     }
     if ((rc = kh_srs_h(curve, s->h))) return rc;
@@ -133,10 +145,13 @@ int kh_srs_create_device_range(int curve, size_t start, size_t depth, kh_srs_t**
     std::lock_guard<std::mutex> lk(C.mu);
     const bool pre = depth >= MSM_PRECOMP_MIN_N && !getenv("KH_NO_PRECOMP");
     const int W = (256 + MSM_PRECOMP_C - 1) / MSM_PRECOMP_C;
-    if ((rc = s->g.reserve(depth * 64 * (pre ? W : 1)))) return rc;
+    s->g_stride = depth + 2;
+    if ((rc = s->g.reserve(s->g_stride * 64 * (pre ? W : 1)))) return rc;
     if ((rc = srs_generate_device(C, curve, start, depth, s->g.p))) return rc;
+    KH_HIP(hipMemcpyAsync((char*)s->g.p + depth * 64, s->g.p, 64, hipMemcpyDeviceToDevice, C.stream));
+    KH_HIP(hipMemcpyAsync((char*)s->g.p + (depth + 1) * 64, s->g.p, 64, hipMemcpyDeviceToDevice, C.stream));
     if (pre) {
-        if ((rc = msm_precompute(C, curve, s->g.p, nullptr, depth, MSM_PRECOMP_C))) return rc;
+        if ((rc = msm_precompute(C, curve, s->g.p, nullptr, s->g_stride, MSM_PRECOMP_C))) return rc;
         s->g_precomp_c = MSM_PRECOMP_C;
     }
     if ((rc = kh_srs_h(curve, s->h))) return rc;
@@ -487,8 +502,144 @@ int kh_ipa_fold_points_endo(int curve, const uint64_t* g_lo, const uint64_t* g_h
 int kh_endos(int curve, uint64_t endo_q[4], uint64_t endo_r[4]) {
     KH_REQUIRE(curve == KH_CURVE_VESTA || curve == KH_CURVE_PALLAS, "unknown curve id %d", curve);
     KH_REQUIRE(endo_q && endo_r, "null argument");
-    curve_endos(curve, endo_q, endo_r);
+    const EndoPair& e = cached_endos(curve);
+    memcpy(endo_q, e.q, 32); memcpy(endo_r, e.r, 32);
     return KH_OK;
+}
+
+int kh_scalar_challenge_to_field(int curve, const uint64_t chal[2], uint64_t out[4]) {
+    KH_REQUIRE(curve == KH_CURVE_VESTA || curve == KH_CURVE_PALLAS, "unknown curve id %d", curve);
+    KH_REQUIRE(chal && out, "null argument");
+    scalar_challenge_to_field(khost::scalar_field_id(curve), chal, cached_endos(curve).r, out);
+    return KH_OK;
+}
+
+// ---------------------------------------------------------------------------------- device-resident opening rounds
+struct kh_ipa {
+    kh_srs_t* srs = nullptr;
+    int curve = 0, field = 0;
+    size_t n = 0, cur = 0, ncoef = 1;     // basis size, current vector length N_j, challenge tensor length 2^j
+    DevBuf a[2], b[2], coef[2], sc, partial;
+    int pp = 0;
+    hipEvent_t ev = nullptr;              // orders the fold (library stream) before the next round's MSM (slot stream)
+    bool lr_done = false;
+    ~kh_ipa() {
+        for (int i = 0; i < 2; i++) { a[i].release(); b[i].release(); coef[i].release(); }
+        sc.release(); partial.release();
+        if (ev) (void)hipEventDestroy(ev);
+    }
+};
+
+int kh_ipa_begin(kh_srs_t* srs, const uint64_t* a, size_t a_len, const uint64_t* b, size_t b_len, const uint64_t u_base_xy[8], kh_ipa_t** out) {
+    KH_REQUIRE(srs && out && a && b && u_base_xy, "kh_ipa_begin: null argument");
+    const size_t n = srs->n;
+    KH_REQUIRE((n & (n - 1)) == 0, "the opening rounds need a power-of-two SRS (size %zu)", n);
+    KH_REQUIRE(a_len <= n && a_len > 0, "polynomial of %zu coefficients does not fit the SRS (%zu)", a_len, n);
+    KH_REQUIRE(b_len == n, "b must hold padded_length = %zu evaluation-point powers (got %zu)", n, b_len);
+    int rc = ensure_init(); if (rc) return rc;
+    Context& C = ctx();
+    std::lock_guard<std::mutex> lk(C.mu);
+    KH_REQUIRE(!srs->ipa_live, "another opening is in progress on this SRS (kh_ipa_free it first)");
+    std::unique_ptr<kh_ipa> st(new kh_ipa);
+    st->srs = srs; st->curve = srs->curve; st->field = khost::scalar_field_id(srs->curve); st->n = n; st->cur = n;
+    for (int i = 0; i < 2; i++) {
+        if ((rc = st->a[i].reserve(n * 32))) return rc;
+        if ((rc = st->b[i].reserve(n * 32))) return rc;
+        if ((rc = st->coef[i].reserve(n * 32))) return rc;
+    }
+    if ((rc = st->sc.reserve(2 * (n + 2) * 32))) return rc;
+    if ((rc = st->partial.reserve(2 * 64 * 32))) return rc;
+    KH_HIP(hipEventCreateWithFlags(&st->ev, hipEventDisableTiming));
+    // H and U into the two extra slots of every window table
+    const int W = srs->g_precomp_c ? (256 + srs->g_precomp_c - 1) / srs->g_precomp_c : 1;
+    std::vector<uint64_t> tab((size_t)W * 16), col((size_t)W * 8);
+    host_window_multiples(srs->curve, srs->h, W, srs->g_precomp_c, col.data());
+    for (int w = 0; w < W; w++) memcpy(&tab[16 * w], &col[8 * w], 64);
+    host_window_multiples(srs->curve, u_base_xy, W, srs->g_precomp_c, col.data());
+    for (int w = 0; w < W; w++) memcpy(&tab[16 * w + 8], &col[8 * w], 64);
+    hipStream_t s = C.stream;
+    KH_HIP(hipMemcpy2DAsync((char*)srs->g.p + n * 64, srs->g_stride * 64, tab.data(), 128, 128, W, hipMemcpyHostToDevice, s));
+    KH_HIP(hipMemsetAsync(st->a[0].p, 0, n * 32, s));
+    KH_HIP(hipMemcpyAsync(st->a[0].p, a, a_len * 32, hipMemcpyHostToDevice, s));
+    KH_HIP(hipMemcpyAsync(st->b[0].p, b, n * 32, hipMemcpyHostToDevice, s));
+    const khost::fe one = khost::field(st->field).one;
+    KH_HIP(hipMemcpyAsync(st->coef[0].p, &one, 32, hipMemcpyHostToDevice, s));
+    KH_HIP(hipStreamSynchronize(s));                       // the staging vectors above are locals
+    KH_HIP(hipEventRecord(st->ev, s));
+    srs->ipa_live = true;
+    *out = st.release();
+    return KH_OK;
+}
+int kh_ipa_rounds_left(const kh_ipa_t* st) {
+    if (!st) return -1;
+    int r = 0; for (size_t c = st->cur; c > 1; c >>= 1) r++;
+    return r;
+}
+int kh_ipa_round_lr(kh_ipa_t* st, const uint64_t rand_l[4], const uint64_t rand_r[4], uint64_t lr_xy[16], uint8_t lr_inf[2]) {
+    KH_REQUIRE(st && rand_l && rand_r && lr_xy && lr_inf, "kh_ipa_round_lr: null argument");
+    KH_REQUIRE(st->cur > 1, "no round left: the vectors are folded to length 1");
+    KH_REQUIRE(!st->lr_done, "kh_ipa_round_fold must follow kh_ipa_round_lr");
+    Context& C = ctx();
+    std::lock_guard<std::mutex> lk(C.mu);
+    int si = free_slot(C);
+    KH_REQUIRE(si >= 0, "all %d MSM pipeline slots hold an un-waited job (kh_msm_wait first)", MSM_SLOTS);
+    MsmSlot& S = C.slot[si];
+    KH_HIP(hipStreamWaitEvent(S.stream, st->ev, 0));
+    const int p = st->pp;
+    int rc = ipa_round_prepare(S.stream, st->field, st->a[p].as<uint64_t>(), st->b[p].as<uint64_t>(), st->coef[p].as<uint64_t>(),
+                               st->n, st->cur, rand_l, rand_r, st->sc.as<uint64_t>(), st->partial.as<uint64_t>());
+    if (rc) return rc;
+    kh_srs_t* srs = st->srs;
+    MsmBasis bs; bs.pts = srs->g.p; bs.inf = nullptr; bs.n = srs->g_stride; bs.stride = srs->g_stride; bs.precomp_c = srs->g_precomp_c;
+    if ((rc = msm_enqueue(C, S, st->curve, bs, 0, st->sc.as<uint64_t>(), st->n + 2, 2, 1))) return rc;
+    if ((rc = msm_finish(C, S, lr_xy, lr_inf))) return rc;
+    st->lr_done = true;
+    return KH_OK;
+}
+int kh_ipa_round_fold(kh_ipa_t* st, const uint64_t chal[2], uint64_t u_out[4], uint64_t u_inv_out[4]) {
+    KH_REQUIRE(st && chal, "kh_ipa_round_fold: null argument");
+    KH_REQUIRE(st->lr_done, "kh_ipa_round_lr must precede kh_ipa_round_fold");
+    uint64_t u[4], ui[4];
+    scalar_challenge_to_field(st->field, chal, cached_endos(st->curve).r, u);
+    KH_REQUIRE((u[0] | u[1] | u[2] | u[3]) != 0, "challenge maps to zero (u.inverse().unwrap() in ipa.rs:975)");
+    host_field_inverse(st->field, u, ui);
+    Context& C = ctx();
+    std::lock_guard<std::mutex> lk(C.mu);
+    const int p = st->pp, q = p ^ 1;
+    int rc = ipa_round_fold(C.stream, st->field, st->a[p].as<uint64_t>(), st->b[p].as<uint64_t>(), st->coef[p].as<uint64_t>(), st->cur, st->ncoef,
+                            u, ui, st->a[q].as<uint64_t>(), st->b[q].as<uint64_t>(), st->coef[q].as<uint64_t>());
+    if (rc) return rc;
+    KH_HIP(hipEventRecord(st->ev, C.stream));
+    st->pp = q; st->cur /= 2; st->ncoef *= 2; st->lr_done = false;
+    if (u_out) memcpy(u_out, u, 32);
+    if (u_inv_out) memcpy(u_inv_out, ui, 32);
+    return KH_OK;
+}
+int kh_ipa_finish(kh_ipa_t* st, uint64_t a0[4], uint64_t b0[4], uint64_t sg_xy[8], uint8_t* sg_inf) {
+    KH_REQUIRE(st && a0 && b0 && sg_xy && sg_inf, "kh_ipa_finish: null argument");
+    KH_REQUIRE(st->cur == 1, "%d rounds still to run", kh_ipa_rounds_left(st));
+    Context& C = ctx();
+    std::lock_guard<std::mutex> lk(C.mu);
+    int si = free_slot(C);
+    KH_REQUIRE(si >= 0, "all %d MSM pipeline slots hold an un-waited job (kh_msm_wait first)", MSM_SLOTS);
+    MsmSlot& S = C.slot[si];
+    KH_HIP(hipStreamWaitEvent(S.stream, st->ev, 0));
+    const int p = st->pp;
+    KH_HIP(hipMemcpyAsync(a0, st->a[p].p, 32, hipMemcpyDeviceToHost, S.stream));
+    KH_HIP(hipMemcpyAsync(b0, st->b[p].p, 32, hipMemcpyDeviceToHost, S.stream));
+    kh_srs_t* srs = st->srs;
+    MsmBasis bs; bs.pts = srs->g.p; bs.inf = nullptr; bs.n = srs->n; bs.stride = srs->g_stride; bs.precomp_c = srs->g_precomp_c;
+    int rc;
+    if ((rc = msm_enqueue(C, S, st->curve, bs, 0, st->coef[p].as<uint64_t>(), st->n, 1, 1))) return rc;   // sg = <coef, G>
+    return msm_finish(C, S, sg_xy, sg_inf);
+}
+void kh_ipa_free(kh_ipa_t* st) {
+    if (!st) return;
+    Context& C = ctx();
+    std::lock_guard<std::mutex> lk(C.mu);
+    (void)hipDeviceSynchronize();
+    if (st->srs) st->srs->ipa_live = false;
+    delete st;
 }
 
 // ---------------------------------------------------------------------------------- NTT

@@ -46,6 +46,7 @@ struct DevBuf {
         cap = want;
         return KH_OK;
     }
+    void release() { if (p) { hipError_t e = hipFree(p); (void)e; } p = nullptr; cap = 0; }
     template <class T> T* as() const { return (T*)p; }
 };
 

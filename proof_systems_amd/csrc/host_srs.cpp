@@ -152,6 +152,43 @@ void curve_endos(int curve, uint64_t endo_q[4], uint64_t endo_r[4]) {
     if (!(khost::eq(lhs.x, FB.mul(g.x, eq)) && khost::eq(lhs.y, g.y))) er = FS.sqr(er);
     memcpy(endo_q, &eq, 32); memcpy(endo_r, &er, 32);
 }
+// ScalarChallenge::to_field_with_length(128, endo) (poseidon/src/sponge.rs:190-226): a = b = 2; for the 64 two-bit
+// chunks high to low: a, b doubled, s = +-1 by bit 2i, added to b if bit 2i+1 is clear, else to a; a * endo + b
+void scalar_challenge_to_field(int field, const uint64_t chal[2], const uint64_t endo[4], uint64_t out[4]) {
+    Fld F(field);
+    fe a = F.add(F.f.one, F.f.one), b = a, e;
+    memcpy(&e, endo, 32);
+    const fe one = F.f.one, mone = F.neg(F.f.one);
+    for (int i = 63; i >= 0; i--) {
+        a = F.dbl(a); b = F.dbl(b);
+        const u64 w = chal[i >> 5]; const int sh = 2 * (i & 31);
+        const fe& s = ((w >> sh) & 1) ? one : mone;
+        if ((w >> (sh + 1)) & 1) a = F.add(a, s); else b = F.add(b, s);
+    }
+    fe r = F.add(F.mul(a, e), b);
+    memcpy(out, &r, 32);
+}
+void host_field_inverse(int field, const uint64_t a[4], uint64_t out[4]) {
+    Fld F(field); fe x; memcpy(&x, a, 32); x = F.inv(x); memcpy(out, &x, 32);
+}
+// out[w] = 2^(c w) P for w < W, affine (one shared inversion): the entries a point occupies in the window tables
+void host_window_multiples(int curve, const uint64_t xy[8], int W, int c, uint64_t* out_xy) {
+    khost::Crv crv(curve); const Fld& F = crv.F;
+    khost::aff p; memcpy(&p, xy, 64);
+    std::vector<khost::xyzz> v(W);
+    v[0] = crv.from_affine(p);
+    for (int w = 1; w < W; w++) { v[w] = v[w - 1]; for (int k = 0; k < c; k++) v[w] = crv.dbl(v[w]); }
+    // prefix products of zzz, one inversion, then 1/zzz_w and 1/zz_w = (zz_w / zzz_w)^2
+    std::vector<fe> pre(W + 1); pre[0] = F.f.one;
+    for (int w = 0; w < W; w++) pre[w + 1] = F.mul(pre[w], v[w].zzz);
+    fe inv = F.inv(pre[W]);
+    for (int w = W - 1; w >= 0; w--) {
+        fe izzz = F.mul(inv, pre[w]); inv = F.mul(inv, v[w].zzz);
+        fe izz = F.sqr(F.mul(izzz, v[w].zz));
+        fe x = F.mul(v[w].x, izz), y = F.mul(v[w].y, izzz);
+        memcpy(out_xy + 8 * w, &x, 32); memcpy(out_xy + 8 * w + 4, &y, 32);
+    }
+}
 }  // namespace kh
 
 extern "C" {

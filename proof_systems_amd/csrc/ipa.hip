@@ -1,8 +1,9 @@
 // ipa.hip -- the per-round vector operations of the IPA prover (poly-commitment/src/ipa.rs:929-1007),
 // what stays on the CPU between the L/R MSMs of consecutive rounds.
 //   fold_scalars : a' = a_lo + u^-1 * a_hi  /  b' = b_lo + u * b_hi          (ipa.rs:980-1003)
-//   fold_points  : g' = g_lo + [u] g_hi  = CommitmentCurve::combine_one       (ipa.rs:1006,
-//                  commitment.rs:576-579; combine_one_endo yields the same group elements)
+//   fold_points  : g' = g_lo + [u] g_hi  = CommitmentCurve::combine_one       (ipa.rs:1006, commitment.rs:576-579)
+//   fold_points_endo : the same by the endo ladder of combine_one_endo       (combine.rs:292-340)
+//   round_prepare / round_fold : the device-resident opening loop (no basis folding, see below)
 //   inner_product: <a, b>                                                      (utils/src/field_helpers.rs:273-279)
 // Element-wise and embarrassingly parallel; the basis fold is one 255-bit double-and-add per point
 // (a ~380-operation dependent chain: ~4 ms whatever the length below ~60k points).
@@ -100,6 +101,135 @@ k_fold_points_endo(const uint8_t* __restrict__ g_lo, const uint8_t* __restrict__
     }
     x.store(out_xy + i * 64); y.store(out_xy + i * 64 + 32);
     out_inf[i] = inf;
+}
+
+// ---------------------------------------------------------------- device-resident opening rounds
+// The folding loop of SRS::open (ipa.rs:929-1007) without ever folding the basis.  After j rounds the folded
+// basis is  g_j[i] = sum_{t = i mod N_j} coef_j[t div N_j] * G_t  (N_j = N / 2^j, coef_j = the tensor of the
+// challenges so far), so  L_j = <a_hi, g_j,lo> + [rand_l] H + [<a_hi, b_lo>] U  is ONE MSM over the ORIGINAL
+// basis (whose window tables are already resident) with the expanded scalars  a_hi[t mod N_j - 0] * coef_j[t div N_j]
+// on the points of the low halves and zero elsewhere; R_j likewise on the high halves.  A size-N MSM per round is
+// throughput work (the path this library is fastest at); folding N_j points by the endo ladder is a ~1400-product
+// dependent chain per point, i.e. ~0.9 ms of latency per round however few points are left.  The final basis
+// element sg = g_16[0] = <coef_16, G> is one more MSM.  Group elements are equal to the reference's, hence
+// bit-identical after normalisation.
+struct Fe4 { u64 l[4]; };
+
+// side 0 (L): <a[m..2m), b[0..m)>; side 1 (R): <a[0..m), b[m..2m)>; per-block partial sums
+template <class F>
+__global__ void __launch_bounds__(256)
+k_ipa_ip(const u64* __restrict__ a, const u64* __restrict__ b, size_t m, u64* __restrict__ partial) {
+    __shared__ u32 sh[256 * 8];
+    const int side = blockIdx.y;
+    const u64* pa = side == 0 ? a + 4 * m : a;
+    const u64* pb = side == 0 ? b : b + 4 * m;
+    Fe<F> acc = Fe<F>::zero();
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (size_t)gridDim.x * blockDim.x)
+        acc = add<F>(acc, mul<F>(Fe<F>::load(pa + 4 * i), Fe<F>::load(pb + 4 * i)));
+#pragma unroll
+    for (int k = 0; k < 8; k++) sh[k * 256 + threadIdx.x] = acc.v[k];
+    __syncthreads();
+    for (int s = 128; s >= 1; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            Fe<F> o;
+#pragma unroll
+            for (int k = 0; k < 8; k++) o.v[k] = sh[k * 256 + threadIdx.x + s];
+            acc = add<F>(acc, o);
+#pragma unroll
+            for (int k = 0; k < 8; k++) sh[k * 256 + threadIdx.x] = acc.v[k];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) acc.store(partial + 4 * ((size_t)side * gridDim.x + blockIdx.x));
+}
+// block = side: sums the <= 64 partials and fills the two extra scalar slots of that side's MSM:
+// sc[side][n] = rand (the H term), sc[side][n + 1] = the inner product (the U term)
+template <class F>
+__global__ void __launch_bounds__(64)
+k_ipa_ip_fin(const u64* __restrict__ partial, unsigned nblk, Fe4 rand_l, Fe4 rand_r, size_t n, u64* __restrict__ sc) {
+    __shared__ u32 sh[64 * 8];
+    const int side = blockIdx.x;
+    Fe<F> acc = Fe<F>::zero();
+    if (threadIdx.x < nblk) acc = Fe<F>::load(partial + 4 * ((size_t)side * nblk + threadIdx.x));
+#pragma unroll
+    for (int k = 0; k < 8; k++) sh[k * 64 + threadIdx.x] = acc.v[k];
+    __syncthreads();
+    for (int s = 32; s >= 1; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            Fe<F> o;
+#pragma unroll
+            for (int k = 0; k < 8; k++) o.v[k] = sh[k * 64 + threadIdx.x + s];
+            acc = add<F>(acc, o);
+#pragma unroll
+            for (int k = 0; k < 8; k++) sh[k * 64 + threadIdx.x] = acc.v[k];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        u64* dst = sc + 4 * ((size_t)side * (n + 2) + n);
+        const Fe4& r = side == 0 ? rand_l : rand_r;
+        dst[0] = r.l[0]; dst[1] = r.l[1]; dst[2] = r.l[2]; dst[3] = r.l[3];
+        acc.store(dst + 4);
+    }
+}
+// the two expanded scalar vectors over the original basis (N_j = 2m = 2^logN)
+template <class F>
+__global__ void k_ipa_expand(const u64* __restrict__ a, const u64* __restrict__ coef, size_t n, size_t m, unsigned logN, u64* __restrict__ sc) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const size_t r = t & (2 * m - 1), q = t >> logN;
+    const bool lo = r < m;
+    Fe<F> v = mul<F>(Fe<F>::load(a + 4 * (lo ? r + m : r - m)), Fe<F>::load(coef + 4 * q));
+    const Fe<F> z = Fe<F>::zero();
+    (lo ? v : z).store(sc + 4 * t);
+    (lo ? z : v).store(sc + 4 * ((n + 2) + t));
+}
+// a' = a_lo + u^-1 a_hi, b' = b_lo + u b_hi (ipa.rs:980-1003); coef' = coef (x) (1, u)  (combine_one_endo's scalar, ipa.rs:1006)
+template <class F>
+__global__ void k_ipa_fold(const u64* __restrict__ a, const u64* __restrict__ b, const u64* __restrict__ coef, size_t m, size_t ncoef,
+                           Fe4 u4, Fe4 uinv4, u64* __restrict__ a2, u64* __restrict__ b2, u64* __restrict__ coef2) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const Fe<F> u = Fe<F>::load(u4.l);
+    if (i < m) {
+        const Fe<F> ui = Fe<F>::load(uinv4.l);
+        add<F>(Fe<F>::load(a + 4 * i), mul<F>(ui, Fe<F>::load(a + 4 * (i + m)))).store(a2 + 4 * i);
+        add<F>(Fe<F>::load(b + 4 * i), mul<F>(u, Fe<F>::load(b + 4 * (i + m)))).store(b2 + 4 * i);
+    }
+    if (i < ncoef) {
+        const Fe<F> c = Fe<F>::load(coef + 4 * i);
+        c.store(coef2 + 8 * i);
+        mul<F>(c, u).store(coef2 + 8 * i + 4);
+    }
+}
+
+int ipa_round_prepare(hipStream_t s, int field, const uint64_t* a, const uint64_t* b, const uint64_t* coef, size_t n, size_t Nj,
+                      const uint64_t rand_l[4], const uint64_t rand_r[4], uint64_t* sc, uint64_t* partial) {
+    const size_t m = Nj / 2;
+    unsigned logN = 0; while (((size_t)1 << logN) < Nj) logN++;
+    const unsigned nblk = (unsigned)std::min<size_t>(64, (m + 255) / 256);
+    Fe4 rl, rr; memcpy(rl.l, rand_l, 32); memcpy(rr.l, rand_r, 32);
+    dim3 eg((unsigned)((n + 255) / 256));
+    if (field == KH_FIELD_FP) {
+        hipLaunchKernelGGL((k_ipa_ip<FpParams>), dim3(nblk, 2), dim3(256), 0, s, a, b, m, partial);
+        hipLaunchKernelGGL((k_ipa_ip_fin<FpParams>), dim3(2), dim3(64), 0, s, partial, nblk, rl, rr, n, sc);
+        hipLaunchKernelGGL((k_ipa_expand<FpParams>), eg, dim3(256), 0, s, a, coef, n, m, logN, sc);
+    } else {
+        hipLaunchKernelGGL((k_ipa_ip<FqParams>), dim3(nblk, 2), dim3(256), 0, s, a, b, m, partial);
+        hipLaunchKernelGGL((k_ipa_ip_fin<FqParams>), dim3(2), dim3(64), 0, s, partial, nblk, rl, rr, n, sc);
+        hipLaunchKernelGGL((k_ipa_expand<FqParams>), eg, dim3(256), 0, s, a, coef, n, m, logN, sc);
+    }
+    KH_HIP(hipGetLastError());
+    return KH_OK;
+}
+int ipa_round_fold(hipStream_t s, int field, const uint64_t* a, const uint64_t* b, const uint64_t* coef, size_t Nj, size_t ncoef,
+                   const uint64_t u[4], const uint64_t uinv[4], uint64_t* a2, uint64_t* b2, uint64_t* coef2) {
+    const size_t m = Nj / 2, thr = std::max(m, ncoef);
+    Fe4 u4, ui4; memcpy(u4.l, u, 32); memcpy(ui4.l, uinv, 32);
+    dim3 g((unsigned)((thr + 255) / 256));
+    if (field == KH_FIELD_FP) hipLaunchKernelGGL((k_ipa_fold<FpParams>), g, dim3(256), 0, s, a, b, coef, m, ncoef, u4, ui4, a2, b2, coef2);
+    else hipLaunchKernelGGL((k_ipa_fold<FqParams>), g, dim3(256), 0, s, a, b, coef, m, ncoef, u4, ui4, a2, b2, coef2);
+    KH_HIP(hipGetLastError());
+    return KH_OK;
 }
 
 static DevBuf g_ipa_a, g_ipa_b, g_ipa_c;

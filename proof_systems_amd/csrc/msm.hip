@@ -504,7 +504,8 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
     // cost nkeys x W x S words of traffic in k_key_totals, which dominates the sort of a batch
     int S = (int)(n / 8192); if (S < 1) S = 1; if (S > 16) S = 16;
     { int want = (int)(512 / ((size_t)W * k)); if (want < 1) want = 1; if (S > want) S = want; }
-    SortGeom g{n, nb, S, W, precomp, basis.n, offset, basis.batch_stride};
+    const size_t tab_stride = basis.stride ? basis.stride : basis.n;
+    SortGeom g{n, nb, S, W, precomp, tab_stride, offset, basis.batch_stride};
     const size_t ngroups = precomp ? k : k * (size_t)W;
     const int Sq = precomp ? W * S : S;
     const size_t nkeys = ngroups * nb;
@@ -518,7 +519,7 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
     if (nkeys < cap / 2) room_sz = cap - cap / 16 - nkeys / 2;   // ~ half of the buckets add a remainder task
     const u32 room = (u32)room_sz;                          // K = clamp(ceil(entries / room), 8, MAX_K), on the device
     const size_t max_tasks = M / 8 + nkeys + 1;             // bound for the smallest K
-    KH_REQUIRE(M < ((size_t)1 << 31) && (basis.n * (size_t)(precomp ? W : 1) + basis.batch_stride * k) < ((size_t)1 << 31), "MSM too large for 31-bit entry indices (n=%zu k=%zu)", n, k);
+    KH_REQUIRE(M < ((size_t)1 << 31) && (tab_stride * (size_t)(precomp ? W : 1) + basis.batch_stride * k) < ((size_t)1 << 31), "MSM too large for 31-bit entry indices (n=%zu k=%zu)", n, k);
 
     int rc;
     if ((rc = C.ws_digits.reserve(M * sizeof(int32_t)))) return rc;

@@ -10,6 +10,7 @@ struct MsmBasis {
     const uint8_t* inf = nullptr;    // device, nullable per-point infinity flags
     size_t n = 0;                    // points per table
     int precomp_c = 0;               // 0: plain basis; else window width of the precomputed tables
+    size_t stride = 0;               // points between consecutive window tables (0: = n)
     size_t batch_stride = 0;         // >0: MSM j of a batch uses points [j*batch_stride, ...) (independent bases)
 };
 
@@ -30,6 +31,14 @@ int ntt_build_twiddles(Context& C, int field, unsigned logn, int inverse, uint64
 int ipa_fold_scalars(Context& C, int field, const uint64_t* lo, const uint64_t* hi, const uint64_t u[4], size_t n, uint64_t* out);
 int ipa_inner_product(Context& C, int field, const uint64_t* a, const uint64_t* b, size_t n, uint64_t out[4]);
 int ipa_fold_points_endo(Context& C, int curve, const uint64_t* g_lo, const uint64_t* g_hi, const uint64_t chal[2], size_t n, uint64_t* out_xy, uint8_t* out_inf);
+int ipa_round_prepare(hipStream_t s, int field, const uint64_t* a, const uint64_t* b, const uint64_t* coef, size_t n, size_t Nj,
+                      const uint64_t rand_l[4], const uint64_t rand_r[4], uint64_t* sc, uint64_t* partial);
+int ipa_round_fold(hipStream_t s, int field, const uint64_t* a, const uint64_t* b, const uint64_t* coef, size_t Nj, size_t ncoef,
+                   const uint64_t u[4], const uint64_t uinv[4], uint64_t* a2, uint64_t* b2, uint64_t* coef2);
+// host_srs.cpp
+void scalar_challenge_to_field(int field, const uint64_t chal[2], const uint64_t endo[4], uint64_t out[4]);
+void host_window_multiples(int curve, const uint64_t xy[8], int W, int c, uint64_t* out_xy);   // out[w] = 2^(c w) P, affine
+void host_field_inverse(int field, const uint64_t a[4], uint64_t out[4]);
 void endo_coefficient(int field, uint64_t out[4]);
 void curve_endos(int curve, uint64_t endo_q[4], uint64_t endo_r[4]);
 int ipa_fold_points(Context& C, int curve, const uint64_t* g_lo, const uint64_t* g_hi, const uint64_t u[4], size_t n, uint64_t* out_xy, uint8_t* out_inf);

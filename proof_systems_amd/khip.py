@@ -36,7 +36,8 @@ SYMBOLS = [
     "kh_debug_field_op", "kh_debug_point_op", "kh_srs_generate", "kh_srs_h",
     "kh_commit_non_hiding", "kh_commit_evaluations_non_hiding", "kh_srs_set_blinding_base",
     "kh_srs_get_blinding_base", "kh_mask_custom", "kh_domain_generator", "kh_msm_points_batch", "kh_msm_submit", "kh_msm_wait",
-    "kh_ipa_fold_scalars", "kh_inner_product", "kh_ipa_fold_points", "kh_ipa_fold_points_endo", "kh_endos", "kh_points_sum", "kh_srs_create_device", "kh_srs_create_device_range", "kh_srs_get_g",
+    "kh_ipa_fold_scalars", "kh_inner_product", "kh_ipa_fold_points", "kh_ipa_fold_points_endo", "kh_endos", "kh_scalar_challenge_to_field",
+    "kh_ipa_begin", "kh_ipa_rounds_left", "kh_ipa_round_lr", "kh_ipa_round_fold", "kh_ipa_finish", "kh_ipa_free", "kh_points_sum", "kh_srs_create_device", "kh_srs_create_device_range", "kh_srs_get_g",
 ]
 
 _lib.kh_last_error.restype = C.c_char_p
@@ -58,6 +59,14 @@ _lib.kh_inner_product.argtypes = [C.c_int, U64P, U64P, C.c_size_t, U64P]
 _lib.kh_ipa_fold_points.argtypes = [C.c_int, U64P, U64P, U64P, C.c_size_t, U64P, U8P]
 _lib.kh_ipa_fold_points_endo.argtypes = [C.c_int, U64P, U64P, U64P, C.c_size_t, U64P, U8P]
 _lib.kh_endos.argtypes = [C.c_int, U64P, U64P]
+_lib.kh_scalar_challenge_to_field.argtypes = [C.c_int, U64P, U64P]
+_lib.kh_ipa_begin.argtypes = [C.c_void_p, U64P, C.c_size_t, U64P, C.c_size_t, U64P, C.POINTER(C.c_void_p)]
+_lib.kh_ipa_rounds_left.argtypes = [C.c_void_p]
+_lib.kh_ipa_round_lr.argtypes = [C.c_void_p, U64P, U64P, U64P, U8P]
+_lib.kh_ipa_round_fold.argtypes = [C.c_void_p, U64P, U64P, U64P]
+_lib.kh_ipa_finish.argtypes = [C.c_void_p, U64P, U64P, U64P, U8P]
+_lib.kh_ipa_free.argtypes = [C.c_void_p]
+_lib.kh_ipa_free.restype = None
 _lib.kh_srs_create_device.argtypes = [C.c_int, C.c_size_t, C.POINTER(C.c_void_p)]
 _lib.kh_srs_create_device_range.argtypes = [C.c_int, C.c_size_t, C.c_size_t, C.POINTER(C.c_void_p)]
 _lib.kh_srs_get_g.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, U64P]
@@ -391,6 +400,56 @@ def ipa_fold_points_endo(curve: int, g_lo, g_hi, chal: int):
     out = np.zeros_like(g_lo); inf = np.zeros(g_lo.shape[0], dtype=np.uint8)
     _check(_lib.kh_ipa_fold_points_endo(curve, _p64(g_lo), _p64(g_hi), _p64(c), g_lo.shape[0], _p64(out), _p8(inf)))
     return out, inf
+
+
+def _chal_limbs(chal: int):
+    return np.array([chal & (2**64 - 1), (chal >> 64) & (2**64 - 1)], dtype=np.uint64)
+
+
+def scalar_challenge_to_field(curve: int, chal: int):
+    out = np.zeros(4, dtype=np.uint64)
+    _check(_lib.kh_scalar_challenge_to_field(curve, _p64(_chal_limbs(chal)), _p64(out)))
+    return out
+
+
+class IpaOpening:
+    """The folding loop of SRS::open (ipa.rs:929-1007) on device-resident vectors; see include/kimchi_hip.h."""
+
+    def __init__(self, srs, a, b, u_base):
+        a = _c64(a, (-1, 4)); b = _c64(b, (-1, 4)); u_base = _c64(u_base, (8,))
+        h = C.c_void_p()
+        _check(_lib.kh_ipa_begin(srs._h, _p64(a), a.shape[0], _p64(b), b.shape[0], _p64(u_base), C.byref(h)))
+        self._h = h
+
+    def rounds_left(self) -> int:
+        return _lib.kh_ipa_rounds_left(self._h)
+
+    def round_lr(self, rand_l, rand_r):
+        rand_l = _c64(rand_l, (4,)); rand_r = _c64(rand_r, (4,))
+        xy = np.zeros((2, 8), dtype=np.uint64); inf = np.zeros(2, dtype=np.uint8)
+        _check(_lib.kh_ipa_round_lr(self._h, _p64(rand_l), _p64(rand_r), _p64(xy), _p8(inf)))
+        return xy, inf
+
+    def round_fold(self, chal: int):
+        u = np.zeros(4, dtype=np.uint64); ui = np.zeros(4, dtype=np.uint64)
+        _check(_lib.kh_ipa_round_fold(self._h, _p64(_chal_limbs(chal)), _p64(u), _p64(ui)))
+        return u, ui
+
+    def finish(self):
+        a0 = np.zeros(4, dtype=np.uint64); b0 = np.zeros(4, dtype=np.uint64)
+        sg = np.zeros(8, dtype=np.uint64); inf = np.zeros(1, dtype=np.uint8)
+        _check(_lib.kh_ipa_finish(self._h, _p64(a0), _p64(b0), _p64(sg), _p8(inf)))
+        return a0, b0, sg, bool(inf[0])
+
+    def free(self):
+        if self._h:
+            _lib.kh_ipa_free(self._h); self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
 
 
 def endos(curve: int):

@@ -282,6 +282,157 @@ def test_ipa_fold_points_endo(khip, cid):
     assert e.shape[0] == 0 and einf.shape[0] == 0
 
 
+def _pt_limbs(c, pt):
+    return cref.ints_to_limbs([c.base.to_mont(pt[0]), c.base.to_mont(pt[1])]).reshape(8)
+
+
+def _run_opening(khip, srs, cid, a_l, b_l, U_l, rands_l, chals):
+    op = khip.IpaOpening(srs, a_l, b_l, U_l)
+    lr, us = [], []
+    assert op.rounds_left() == len(chals)
+    for (rl, rr), ch in zip(rands_l, chals):
+        xy, inf = op.round_lr(rl, rr)
+        u, ui = op.round_fold(ch)
+        lr.append((xy.copy(), inf.copy())); us.append((u, ui))
+    assert op.rounds_left() == 0
+    a0, b0, sg, sginf = op.finish()
+    op.free()
+    return lr, us, a0, b0, sg, sginf
+
+
+@pytest.mark.parametrize("cid,logn", [(0, 5), (1, 5), (0, 10), (1, 3)])
+def test_ipa_opening_rounds_match_oracle(khip, cid, logn):
+    """The device-resident folding loop of SRS::open (ipa.rs:929-1018) against the oracle's literal restatement
+    (which folds the basis with combine_one_endo): every L, R, every challenge image, a0, b0 and sg bit for bit.
+    2^10 runs on the precomputed-table path, the others on the per-window path; the polynomial is shorter than the
+    SRS (zero padding, ipa.rs:918-920)."""
+    c = P.CURVES[cid]; F = c.scalar
+    n = 1 << logn
+    rnd = np.random.default_rng(1000 + 7 * cid + logn)
+    srs = khip.Srs.create(cid, n)
+    g_l = srs.get_g(0, n)
+    g = [_aff(c, row, 0) for row in g_l]
+    h = _aff(c, khip.srs_h(cid), 0)
+    U_l = khip.srs_generate(cid, 1 << 20, 1)[0]
+    U = _aff(c, U_l, 0)
+    a_len = n - 3
+    ri = lambda: int.from_bytes(rnd.bytes(40), "little") % F.p
+    a = [ri() for _ in range(a_len)]
+    x = ri()
+    b = [pow(x, i, F.p) for i in range(n)]
+    rands = [(ri(), ri()) for _ in range(logn)]
+    chals = [int.from_bytes(rnd.bytes(16), "little") for _ in range(logn)]
+
+    def msm(pts, sc):
+        xy = np.stack([_pt_limbs(c, pt) for pt in pts])
+        out, inf = cref.msm(cid, xy, cref.ints_to_limbs(list(sc)), scalars_mont=False)
+        return _aff(c, out, inf)
+    want_lr, want_us, want_a0, want_b0, want_g0 = P.ipa_open_rounds(c, g, h, U, a, b, rands, chals, msm=msm)
+    lr, us, a0, b0, sg, sginf = _run_opening(khip, srs, cid, _limbs(F, a), _limbs(F, b), U_l,
+                                             [(_limbs(F, [rl])[0], _limbs(F, [rr])[0]) for rl, rr in rands], chals)
+    for j in range(logn):
+        xy, inf = lr[j]
+        assert (_aff(c, xy[0], inf[0]), _aff(c, xy[1], inf[1])) == want_lr[j], f"round {j}"
+        assert F.from_mont(P.from_limbs(us[j][0])) == want_us[j]
+        assert F.from_mont(P.from_limbs(us[j][1])) == F.inv(want_us[j])
+        assert np.array_equal(us[j][0], khip.scalar_challenge_to_field(cid, chals[j]))
+    assert F.from_mont(P.from_limbs(a0)) == want_a0
+    assert F.from_mont(P.from_limbs(b0)) == want_b0
+    assert _aff(c, sg, sginf) == want_g0
+    # b0 = b_poly(chals, x) (ipa.rs:1011-1016; commitment.rs b_poly): prod_i (1 + u_{k-i} x^{2^i})
+    bp = 1
+    for i, u in enumerate(reversed(want_us)):
+        bp = bp * (1 + u * pow(x, 1 << i, F.p)) % F.p
+    assert want_b0 == bp
+    # the SRS is usable for commitments afterwards and a second opening can start once the first is freed
+    got, ginf = srs.msm(_limbs(F, a))
+    w, winf = cref.msm(cid, g_l[:a_len], _limbs(F, a))
+    assert np.array_equal(got, w) and bool(ginf) == bool(winf)
+    srs.close()
+
+
+def test_ipa_opening_protocol_errors(khip):
+    """Misuse is reported, not undefined: two openings on one SRS, fold before L/R, finish with rounds left,
+    a non power-of-two SRS, a b vector of the wrong length."""
+    c = P.CURVES[0]; F = c.scalar
+    srs = khip.Srs.create(0, 8)
+    U = khip.srs_generate(0, 99, 1)[0]
+    a = _limbs(F, [1, 2, 3]); b = _limbs(F, list(range(8)))
+    op = khip.IpaOpening(srs, a, b, U)
+    with pytest.raises(khip.KhError):
+        khip.IpaOpening(srs, a, b, U)
+    with pytest.raises(khip.KhError):
+        op.round_fold(5)
+    with pytest.raises(khip.KhError):
+        op.finish()
+    one = _limbs(F, [1])[0]
+    op.round_lr(one, one)
+    with pytest.raises(khip.KhError):
+        op.round_lr(one, one)
+    op.free()
+    with pytest.raises(khip.KhError):
+        khip.IpaOpening(srs, a, _limbs(F, [1, 2]), U)
+    op2 = khip.IpaOpening(srs, a, b, U); op2.free()
+    srs.close()
+    srs6 = khip.Srs.create(0, 6)
+    with pytest.raises(khip.KhError):
+        khip.IpaOpening(srs6, a, _limbs(F, list(range(6))), U)
+    srs6.close()
+
+
+def test_ipa_opening_full_size_verifier_identity(khip):
+    """2^16 (the bench circuit's SRS): no oracle run of the loop at this size, so the size-independent property is
+    the verifier's own equation (ipa.rs:301-502 in its unbatched form):
+    P + sum_j (u_j^-1 L_j + u_j R_j) = [a0] sg + [a0 b0] U + [r'] H,  P = <a, G> + <a, b> U,
+    r' = sum_j (rand_l u_j^-1 + rand_r u_j) (ipa.rs:1030-1034), with every point operation outside the opening
+    done by the C oracle."""
+    cid = 0; c = P.CURVES[cid]; F = c.scalar
+    logn = 16; n = 1 << logn
+    rnd = np.random.default_rng(4242)
+    srs = khip.Srs.create(cid, n)
+    U_l = khip.srs_generate(cid, 1 << 21, 1)[0]
+    h_l = khip.srs_h(cid)
+    ri = lambda: int.from_bytes(rnd.bytes(40), "little") % F.p
+    a = [ri() for _ in range(n)]
+    x = ri()
+    b = [1]
+    for _ in range(n - 1):
+        b.append(b[-1] * x % F.p)
+    rands = [(ri(), ri()) for _ in range(logn)]
+    chals = [int.from_bytes(rnd.bytes(16), "little") for _ in range(logn)]
+    a_l = _limbs(F, a)
+    lr, us, a0, b0, sg, sginf = _run_opening(khip, srs, cid, a_l, _limbs(F, b), U_l,
+                                             [(_limbs(F, [rl])[0], _limbs(F, [rr])[0]) for rl, rr in rands], chals)
+    ip = sum(p * q for p, q in zip(a, b)) % F.p
+    Pc, Pinf = srs.msm(a_l)
+    t, tinf = cref.point_mul(cid, U_l, _limbs(F, [ip])[0])
+    lhs, linf = cref.point_add(cid, Pc, t, bool(Pinf), tinf)
+    rp = 0
+    for j in range(logn):
+        u = F.from_mont(P.from_limbs(us[j][0])); ui = F.inv(u)
+        assert F.from_mont(P.from_limbs(us[j][1])) == ui
+        xy, inf = lr[j]
+        t1, i1 = cref.point_mul(cid, xy[0], us[j][1], p_inf=bool(inf[0]))
+        t2, i2 = cref.point_mul(cid, xy[1], us[j][0], p_inf=bool(inf[1]))
+        lhs, linf = cref.point_add(cid, lhs, t1, linf, i1)
+        lhs, linf = cref.point_add(cid, lhs, t2, linf, i2)
+        rp = (rp + rands[j][0] * ui + rands[j][1] * u) % F.p
+    a0i = F.from_mont(P.from_limbs(a0)); b0i = F.from_mont(P.from_limbs(b0))
+    r1, ri1 = cref.point_mul(cid, sg, a0, p_inf=sginf)
+    r2, ri2 = cref.point_mul(cid, U_l, _limbs(F, [a0i * b0i % F.p])[0])
+    r3, ri3 = cref.point_mul(cid, h_l, _limbs(F, [rp])[0])
+    rhs, rinf = cref.point_add(cid, r1, r2, ri1, ri2)
+    rhs, rinf = cref.point_add(cid, rhs, r3, rinf, ri3)
+    assert not linf and not rinf and np.array_equal(lhs, rhs)
+    # b0 is the challenge polynomial at x, sg its commitment (the verifier's sg check, ipa.rs:99-136 + 452-470)
+    bp = 1
+    for i in range(logn):
+        u = F.from_mont(P.from_limbs(us[logn - 1 - i][0]))
+        bp = bp * (1 + u * pow(x, 1 << i, F.p)) % F.p
+    assert b0i == bp
+    srs.close()
+
+
 def test_points_sum_matches_oracle(khip):
     """kh_points_sum (host fold of per-GPU partial sums) incl. infinity inputs, P + (-P) and doubling."""
     for cid in (0, 1):
