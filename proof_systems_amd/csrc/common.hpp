@@ -85,7 +85,7 @@ struct MsmSlot {
     // pending job (set by enqueue, consumed by finish)
     bool busy = false;
     uint64_t ticket = 0;
-    int curve = 0, W = 0, c = 0, precomp = 0;
+    int curve = 0, W = 0, c = 0, precomp = 0, planes = 0, plane_shift[2] = {0, 0};
     size_t k = 0, ngroups = 0;
 };
 static constexpr int MSM_SLOTS = 4;

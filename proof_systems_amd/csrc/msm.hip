@@ -444,6 +444,50 @@ k_sum_final(const uint8_t* __restrict__ in, u32 count, uint8_t* __restrict__ out
     if (threadIdx.x == 0) acc.store(out + q * 128);
 }
 
+// Latency path of the weighted reduction for one to four MSMs over the tables (the per-round L / R of an opening,
+// a lone commitment).  Bucket t has weight t + 1; with t = (a, b, c) split into three digit fields,
+//   sum_t (t+1) B_t = 2^(f0+f1) sum_a a A_a + 2^f0 sum_b b B_b + sum_c (c+1) C_c ,
+// A_a / B_b / C_c = the marginal sums of the buckets over the other two digits.  The marginals are plain tree
+// sums of nb / 32 buckets each (k_marginals: 4 sequential additions + the block tree), the digit weights then need
+// 5-bit ladders on 3 x 32 points only (k_marginal_fin), and the host folds the three results with f0 + f1 doublings.
+// Chain ~380 field products instead of ~630 (15-bit ladder per bucket + two tree levels), and a tenth of the work.
+struct MargGeom { u32 nb; u32 sh[3]; u32 wd[3]; };
+template <class BF>
+__global__ void __launch_bounds__(256)
+k_marginals(const uint8_t* __restrict__ buckets, MargGeom g, uint8_t* __restrict__ out) {
+    __shared__ u32 sh[4 * 32];
+    const u32 v = blockIdx.x, j = blockIdx.y; const size_t q = blockIdx.z;
+    const u32 s = g.sh[j], f = g.wd[j];
+    if (v >= (1u << f)) return;
+    const uint8_t* B = buckets + q * (size_t)g.nb * 128;
+    const u32 cnt = g.nb >> f, lowmask = (1u << s) - 1u;
+    Xyzz<BF> acc = Xyzz<BF>::identity();
+    for (u32 e = threadIdx.x; e < cnt; e += 256) {
+        const u32 t = ((e >> s) << (s + f)) | (v << s) | (e & lowmask);
+        acc = add<BF>(acc, Xyzz<BF>::load(B + (size_t)t * 128));
+    }
+    acc = block_sum<BF>(acc, sh);
+    if (threadIdx.x == 0) acc.store(out + ((q * 3 + j) * 32 + v) * 128);
+}
+// block (j, q): sum_v (v + [j == 0]) M_v over the <= 32 marginals of digit j
+template <class BF>
+__global__ void __launch_bounds__(64)
+k_marginal_fin(const uint8_t* __restrict__ marg, MargGeom g, uint8_t* __restrict__ out) {
+    const u32 j = blockIdx.x; const size_t q = blockIdx.y;
+    const u32 v = threadIdx.x, f = g.wd[j];
+    Xyzz<BF> r = Xyzz<BF>::identity();
+    if (v < (1u << f)) {
+        const Xyzz<BF> X = Xyzz<BF>::load(marg + ((q * 3 + j) * 32 + v) * 128);
+        const u32 w = v + (j == 0 ? 1u : 0u);
+        for (int bit = (int)f; bit >= 0; bit--) {
+            r = dbl<BF>(r);
+            if ((w >> bit) & 1u) r = add<BF>(r, X);
+        }
+    }
+    for (int d = 16; d >= 1; d >>= 1) { Xyzz<BF> o = shfl_down<BF>(r, d); r = add<BF>(r, o); }
+    if (threadIdx.x == 0) r.store(out + (q * 3 + j) * 128);
+}
+
 // ------------------------------------------------------------------------------------ precomputed window tables
 // tables[w][i] = 2^(c*w) * P_i in affine form (w = 0 is the basis itself).  Thread per point:
 // (W-1) x c doublings in XYZZ, then ONE inversion per point (Montgomery's trick over its W-1
@@ -545,8 +589,16 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
     if (nb < m) m = nb;
     const u32 nseg = nb / m;
     const u32 nblk1 = (nseg + SUM_BLK - 1) / SUM_BLK;
-    if ((rc = C.ws_seg.reserve(ngroups * (size_t)(nseg + nblk1) * 128))) return rc;
-    if ((rc = C.ws_out.reserve(ngroups * 128))) return rc;
+    // one to four MSMs over the tables: digit marginals instead (k_marginals), three fields of <= 5 bits
+    const u32 planes = (precomp && ngroups <= 4 && m == 1 && c >= 7 && c <= 16 && !getenv("KH_NO_PLANES")) ? 3u : 0u;
+    MargGeom mg{};
+    if (planes) {
+        const u32 bits = (u32)c - 1, f0 = (bits + 2) / 3, f1 = (bits - f0 + 1) / 2, f2 = bits - f0 - f1;
+        mg.nb = nb; mg.sh[0] = 0; mg.wd[0] = f0; mg.sh[1] = f0; mg.wd[1] = f1; mg.sh[2] = f0 + f1; mg.wd[2] = f2;
+    }
+    const size_t nout = planes ? ngroups * planes : ngroups;
+    if ((rc = C.ws_seg.reserve(std::max(ngroups * (size_t)(nseg + nblk1), nout * (size_t)32) * 128))) return rc;
+    if ((rc = C.ws_out.reserve(nout * 128))) return rc;
 
     C.timer.begin(s);
     // 1 digits
@@ -606,6 +658,10 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
                        C.ws_toff.as<u32>(), C.ws_chunks.as<uint8_t>(), C.ws_buckets.as<uint8_t>(), C.ws_biglist.as<u32>(), bigcap);
     C.timer.mark("bucket_sum", s);
     // 7 reduce
+    if (planes) {
+        hipLaunchKernelGGL((k_marginals<BF>), dim3(32, 3, (unsigned)ngroups), dim3(256), 0, s, C.ws_buckets.as<uint8_t>(), mg, C.ws_seg.as<uint8_t>());
+        hipLaunchKernelGGL((k_marginal_fin<BF>), dim3(3, (unsigned)ngroups), dim3(64), 0, s, C.ws_seg.as<uint8_t>(), mg, C.ws_out.as<uint8_t>());
+    } else {
     hipLaunchKernelGGL((k_reduce_seg<BF>), dim3((unsigned)((ngroups * nseg + 127) / 128)), dim3(128), 0, s,
                        C.ws_buckets.as<uint8_t>(), nb, m, ngroups, C.ws_seg.as<uint8_t>());
     {
@@ -613,25 +669,26 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
         hipLaunchKernelGGL((k_sum_level<BF>), dim3(nblk1, (unsigned)ngroups), dim3(256), 0, s, C.ws_seg.as<uint8_t>(), nseg, nblk1, lvl1);
         hipLaunchKernelGGL((k_sum_final<BF>), dim3((unsigned)ngroups), dim3(nblk1 > 64 ? 256 : 64), 0, s, lvl1, nblk1, C.ws_out.as<uint8_t>());
     }
+    }
     C.timer.mark("reduce", s);
     KH_HIP(hipGetLastError());
     // group sums -> pinned host staging; the host part runs in msm_finish
-    if (C.pinned_cap < ngroups * 128) {
+    if (C.pinned_cap < nout * 128) {
         if (C.pinned) (void)hipHostFree(C.pinned);
         C.pinned = nullptr; C.pinned_cap = 0;
-        KH_HIP(hipHostMalloc(&C.pinned, ngroups * 128 + 4096, hipHostMallocDefault));
-        C.pinned_cap = ngroups * 128 + 4096;
+        KH_HIP(hipHostMalloc(&C.pinned, nout * 128 + 4096, hipHostMallocDefault));
+        C.pinned_cap = nout * 128 + 4096;
     }
-    KH_HIP(hipMemcpyAsync(C.pinned, C.ws_out.p, ngroups * 128, hipMemcpyDeviceToHost, s));
+    KH_HIP(hipMemcpyAsync(C.pinned, C.ws_out.p, nout * 128, hipMemcpyDeviceToHost, s));
     KH_HIP(hipEventRecord(C.done, s));
     C.busy = true; C.ticket = Ctx.next_ticket++;
-    C.curve = curve; C.W = W; C.c = c; C.precomp = precomp; C.k = k; C.ngroups = ngroups;
+    C.curve = curve; C.W = W; C.c = c; C.precomp = precomp; C.k = k; C.ngroups = ngroups; C.planes = (int)planes; C.plane_shift[0] = (int)mg.wd[0]; C.plane_shift[1] = (int)mg.wd[1];
     return KH_OK;
 }
 
 int msm_enqueue(Context& C, MsmSlot& S, int curve, const MsmBasis& basis, size_t offset, const uint64_t* scalars_dev, size_t n, size_t k, int mont) {
     if (n == 0 || k == 0) {          // nothing to launch: finish() emits k identities
-        S.busy = true; S.ticket = C.next_ticket++; S.curve = curve; S.k = k; S.ngroups = 0; S.W = 0; S.c = 0; S.precomp = 1;
+        S.busy = true; S.ticket = C.next_ticket++; S.curve = curve; S.k = k; S.ngroups = 0; S.W = 0; S.c = 0; S.precomp = 1; S.planes = 0;
         KH_HIP(hipEventRecord(S.done, S.stream));
         return KH_OK;
     }
@@ -653,7 +710,13 @@ int msm_finish(Context& C, MsmSlot& S, uint64_t* out_xy, uint8_t* out_inf) {
     auto finish_one = [res, Sp, out_xy, out_inf](size_t j) {
         khost::Crv crv(Sp->curve);
         khost::xyzz total;
-        if (Sp->precomp) total = res[j];
+        if (Sp->precomp && Sp->planes) {              // (M2 2^f1 + M1) 2^f0 + M0 over the three digit marginals
+            total = res[j * 3 + 2];
+            for (int t = 0; t < Sp->plane_shift[1]; t++) total = crv.dbl(total);
+            total = crv.add(total, res[j * 3 + 1]);
+            for (int t = 0; t < Sp->plane_shift[0]; t++) total = crv.dbl(total);
+            total = crv.add(total, res[j * 3]);
+        } else if (Sp->precomp) total = res[j];
         else {                                        // Horner over the window sums: ~256 doublings (~70 us)
             total = crv.identity();
             for (int w = Sp->W - 1; w >= 0; w--) {
@@ -666,7 +729,7 @@ int msm_finish(Context& C, MsmSlot& S, uint64_t* out_xy, uint8_t* out_inf) {
         memcpy(out_xy + 8 * j, &a, 64);
         out_inf[j] = inf ? 1 : 0;
     };
-    if (!S.precomp && S.k >= 2) {                     // split the Horner folds with the helper thread
+    if ((!S.precomp || S.planes) && S.k >= 2) {                     // split the Horner folds with the helper thread
         const size_t half = S.k / 2, kk = S.k;
         host_helper().run([finish_one, half, kk] { for (size_t j = half; j < kk; j++) finish_one(j); });
         for (size_t j = 0; j < half; j++) finish_one(j);
