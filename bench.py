@@ -44,7 +44,8 @@ def rand_scalars(rng, n):
 
 def oplist_replay(khip, g16, srs16, reps=2):
     """SURVEY 3.1 totals at n = 2^16 (bench circuit): 15 Lagrange-basis commits (witness),
-    1 + 7 monomial commits (z, t), 32 shrinking IPA MSMs, 19 iNTT(n), 16 LDE(n->8n),
+    1 + 7 monomial commits (z, t), the 16 opening rounds (L/R MSMs, a/b folds, challenge tensor; the basis
+    fold is replaced by MSMs over the resident tables) + sg, 19 iNTT(n), 16 LDE(n->8n),
     iNTT(4n), iNTT(8n).  Device-resident inputs; returns seconds per replay (best of reps)."""
     n = 1 << 16
     rng = np.random.default_rng(2024)
@@ -60,8 +61,9 @@ def oplist_replay(khip, g16, srs16, reps=2):
     d_lde_out = khip.DevBuf(16 * 8 * n * 32)
     d_t4 = khip.DevBuf(4 * n * 32).upload(rand_scalars(rng, 4 * n))
     d_t8 = khip.DevBuf(8 * n * 32).upload(rand_scalars(rng, 8 * n))
-    ipa_sc = [rand_scalars(rng, 2 * ((n >> (r + 1)) + 2)).reshape(2, -1, 4) for r in range(16)]
-    ipa_pts = [np.stack([g16[: (n >> (r + 1)) + 2], g16[(n >> 1) - 2: (n >> 1) + (n >> (r + 1))]]) for r in range(16)]
+    ipa_a = rand_scalars(rng, n); ipa_b = rand_scalars(rng, n); ipa_rand = rand_scalars(rng, 2)
+    ipa_chals = [int.from_bytes(rng.bytes(16), "little") for _ in range(16)]
+    u_base = khip.srs_generate(0, 1 << 21, 1)[0]
     best = None
     phases = {}
     for _ in range(reps):
@@ -71,9 +73,12 @@ def oplist_replay(khip, g16, srs16, reps=2):
         srs16.msm_batch_dev(d_wit.ptr, n, 15, basis=16)                       # witness commits
         srs16.msm_batch_dev(d_zt.ptr, n, 8)                                   # z + 7 t chunks
         tb = time.perf_counter()
-        for r in range(16):                                                   # IPA L, R (ipa.rs:943-961)
-            m = (n >> (r + 1)) + 2                                            # L and R are independent: one batched call
-            khip.msm_points_batch(0, ipa_pts[r], ipa_sc[r])
+        op = khip.IpaOpening(srs16, ipa_a, ipa_b, u_base)                     # SRS::open rounds (ipa.rs:929-1018)
+        for ch in ipa_chals:
+            op.round_lr(ipa_rand[0], ipa_rand[1])                             # the caller's sponge absorbs L, R here
+            op.round_fold(ch)
+        op.finish()
+        op.free()
         tc = time.perf_counter()
         khip.ntt_dev(khip.FP, d_cols, 16, True, 19)
         khip.lde_dev(khip.FP, d_lde_in, 16, 3, d_lde_out, 16)
@@ -83,7 +88,7 @@ def oplist_replay(khip, g16, srs16, reps=2):
         t1 = time.perf_counter()
         if best is None or t1 - t0 < best:
             best = t1 - t0
-            phases = {"commit_msm_s": tb - ta, "ipa_msm_s": tc - tb, "ntt_s": t1 - tc}
+            phases = {"commit_msm_s": tb - ta, "ipa_open_s": tc - tb, "ntt_s": t1 - tc}
     # NTT kernels on their own (HIP events on the library stream): algorithmic bytes of SURVEY 8d
     def dev_ms(fn, reps=5):
         ts = []
@@ -261,7 +266,7 @@ def main():
         srs16.compute_lagrange(16)            # SRS::lagrange_basis as a device group-iNTT (index time, ipa.rs:1065-1172)
         t_lag = time.perf_counter() - t0
         t_op, ph = oplist_replay(khip, g16, srs16)
-        line["oplist"] = {"workload": "ProverProof::create op list at 2^16 gates (23 MSM(n) + 32 IPA MSMs + 19 iNTT(n) + 16 LDE(n->8n) + iNTT(4n) + iNTT(8n))",
+        line["oplist"] = {"workload": "ProverProof::create op list at 2^16 gates (23 MSM(n) + the 16 opening rounds of SRS::open incl. folds and sg + 19 iNTT(n) + 16 LDE(n->8n) + iNTT(4n) + iNTT(8n))",
                           "seconds": t_op, "constraints_per_s": (1 << 16) / t_op, **ph, "lagrange_basis_index_time_s": t_lag,
                           "note": "MSM+NTT hot path only; gate evaluation / sponge stay on the host (SURVEY 8d cfg 3)"}
 

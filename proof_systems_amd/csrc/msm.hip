@@ -469,21 +469,22 @@ k_marginals(const uint8_t* __restrict__ buckets, MargGeom g, uint8_t* __restrict
     acc = block_sum<BF>(acc, sh);
     if (threadIdx.x == 0) acc.store(out + ((q * 3 + j) * 32 + v) * 128);
 }
-// block (j, q): sum_v (v + [j == 0]) M_v over the <= 32 marginals of digit j
+// block (j, q): sum_v (v + [j == 0]) M_v over the <= 32 marginals of digit j, as the sum of the suffix sums
+// S_k = sum_{v >= k} M_v over k >= 1 (k >= 0 for j == 0): a 5-step scan and a 5-step tree, no doublings
 template <class BF>
 __global__ void __launch_bounds__(64)
 k_marginal_fin(const uint8_t* __restrict__ marg, MargGeom g, uint8_t* __restrict__ out) {
     const u32 j = blockIdx.x; const size_t q = blockIdx.y;
     const u32 v = threadIdx.x, f = g.wd[j];
     Xyzz<BF> r = Xyzz<BF>::identity();
-    if (v < (1u << f)) {
-        const Xyzz<BF> X = Xyzz<BF>::load(marg + ((q * 3 + j) * 32 + v) * 128);
-        const u32 w = v + (j == 0 ? 1u : 0u);
-        for (int bit = (int)f; bit >= 0; bit--) {
-            r = dbl<BF>(r);
-            if ((w >> bit) & 1u) r = add<BF>(r, X);
-        }
+    if (v < (1u << f)) r = Xyzz<BF>::load(marg + ((q * 3 + j) * 32 + v) * 128);
+    for (u32 d = 1; d < 32; d <<= 1) {                    // inclusive suffix scan over lanes 0..31 (lanes >= 32 hold the identity)
+        Xyzz<BF> o = shfl_down<BF>(r, (int)d);
+        if (v + d >= 64) o = Xyzz<BF>::identity();
+        r = add<BF>(r, o);
     }
+    if (v == 0 && j != 0) r = Xyzz<BF>::identity();       // weight of digit value 0
+    if (v >= 32) r = Xyzz<BF>::identity();
     for (int d = 16; d >= 1; d >>= 1) { Xyzz<BF> o = shfl_down<BF>(r, d); r = add<BF>(r, o); }
     if (threadIdx.x == 0) r.store(out + (q * 3 + j) * 128);
 }
@@ -546,7 +547,8 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
     const int precomp = basis.precomp_c ? 1 : 0;
     // slices per (window, msm): enough blocks to fill the chip (~512), no more -- the per-slice histograms
     // cost nkeys x W x S words of traffic in k_key_totals, which dominates the sort of a batch
-    int S = (int)(n / 8192); if (S < 1) S = 1; if (S > 16) S = 16;
+    static const size_t slice_div = getenv("KH_SLICE_DIV") ? (size_t)atol(getenv("KH_SLICE_DIV")) : 32768;
+    int S = (int)(n / slice_div); if (S < 1) S = 1; if (S > 16) S = 16;
     { int want = (int)(512 / ((size_t)W * k)); if (want < 1) want = 1; if (S > want) S = want; }
     const size_t tab_stride = basis.stride ? basis.stride : basis.n;
     SortGeom g{n, nb, S, W, precomp, tab_stride, offset, basis.batch_stride};
@@ -634,7 +636,8 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
     KH_HIP(hipMemsetAsync(len_hist, 0, (MAX_K + 1) * sizeof(u32), s));
     hipLaunchKernelGGL(k_ntask, dim3((unsigned)((nkeys + 1 + 255) / 256)), dim3(256), 0, s, C.ws_off.as<u32>(), nkeys, room, C.ws_ntask.as<u32>(), len_hist);
     if ((rc = exclusive_scan_u32(C.ws_ntask.as<u32>(), C.ws_toff.as<u32>(), nkeys + 1, C.ws_scan_tmp, s))) return rc;
-    if (M >= ((size_t)1 << 18)) {
+    static const int rank_min_log = getenv("KH_RANK_MIN_LOG") ? atoi(getenv("KH_RANK_MIN_LOG")) : 22;   // below ~4M entries the three extra launches cost more than the ordering saves
+    if (M >= ((size_t)1 << rank_min_log)) {
         hipLaunchKernelGGL(k_len_starts, dim3(1), dim3(64), 0, s, len_hist, cursor);
         hipLaunchKernelGGL(k_len_rank, dim3((unsigned)((nkeys + 1 + 255) / 256)), dim3(256), 0, s, C.ws_off.as<u32>(), C.ws_ntask.as<u32>(), nkeys, cursor, order, rnt);
         if ((rc = exclusive_scan_u32(rnt, roff, nkeys + 1, C.ws_scan_tmp, s))) return rc;

@@ -1,0 +1,21 @@
+"""Synchronous latency of single / paired MSMs over the resident tables at several sizes (ms, median of 9)."""
+import sys, time
+import numpy as np
+sys.path.insert(0, '.')
+from proof_systems_amd import khip
+khip.init(0)
+rng = np.random.default_rng(1)
+def rs(k):
+    a = rng.integers(0, 1 << 63, size=(k, 4), dtype=np.uint64); a[:, 3] &= np.uint64((1 << 61) - 1); return a
+for logn in (14, 16, 18, 20):
+    n = 1 << logn
+    srs = khip.Srs.create(0, n)
+    for k in (1, 2):
+        sc = rs(n * k)
+        d = khip.DevBuf(sc.nbytes).upload(sc)
+        ts = []
+        for _ in range(9):
+            khip.sync(); t = time.perf_counter(); srs.msm_batch_dev(d.ptr, n, k); ts.append(time.perf_counter() - t)
+        print(f"2^{logn} k={k}: {1e3*np.median(ts):.3f} ms", [(a, round(b, 3)) for a, b in khip.last_timings()])
+        d.free()
+    srs.close()
