@@ -45,7 +45,7 @@ def rand_scalars(rng, n):
 def oplist_replay(khip, g16, srs16, reps=2):
     """SURVEY 3.1 totals at n = 2^16 (bench circuit): 15 Lagrange-basis commits (witness),
     1 + 7 monomial commits (z, t), the 16 opening rounds (L/R MSMs, a/b folds, challenge tensor; the basis
-    fold is replaced by MSMs over the resident tables, DESIGN.md section 6) + sg, 19 iNTT(n), 16 LDE(n->8n),
+    fold is replaced by MSMs over the resident tables, DESIGN.md section 4b) + sg, 19 iNTT(n), 16 LDE(n->8n),
     iNTT(4n), iNTT(8n).  Device-resident inputs; returns seconds per replay (best of reps)."""
     n = 1 << 16
     rng = np.random.default_rng(2024)

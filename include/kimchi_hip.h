@@ -160,7 +160,7 @@ int kh_scalar_challenge_to_field(int curve, const uint64_t chal[2], uint64_t out
  *
  * L, R and sg are the reference's group elements (bit-identical affine coordinates); the basis is never folded:
  * round j's L / R are MSMs over the SRS's resident window tables with the scalars a (x) (challenge tensor), and
- * sg = <challenge tensor, G> (DESIGN.md section 6).  The blinding base H is the handle's (kh_srs_set_blinding_base);
+ * sg = <challenge tensor, G> (DESIGN.md section 4b).  The blinding base H is the handle's (kh_srs_set_blinding_base);
  * the SRS size must be a power of two; one opening at a time per SRS handle (KH_E_INVALID otherwise).
  * All field elements Montgomery limbs; u_pre as in kh_ipa_fold_points_endo. */
 typedef struct kh_ipa kh_ipa_t;

@@ -18,6 +18,7 @@
 #include <cstdint>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "kimchi_hip.h"
@@ -139,6 +140,44 @@ class SRS {                                  // trait SRS<G> (lib.rs:61-241) bac
         return mask_custom(commit_evaluations_non_hiding(d, plnm), blinders);
     }
     kh_srs_t* raw() const { return h_; }
+};
+
+// The folding loop of SRS::open (ipa.rs:929-1018) on device-resident vectors.  The caller owns the sponge and the RNG:
+//   OpeningRounds st(srs, p.coeffs, b_init, u_base);
+//   while (st.rounds_left()) { auto [l, r] = st.round_lr(rand_l, rand_r); absorb(l, r); auto [u, u_inv] = st.round_fold(squeeze()); }
+//   auto fin = st.finish();   // a0, b0, sg
+class OpeningRounds {
+    kh_ipa_t* st_ = nullptr;
+    static Affine point(const uint64_t* xy, uint8_t inf) { Affine a; a.infinity = inf != 0; if (!inf) { std::copy(xy, xy + 4, a.x.begin()); std::copy(xy + 4, xy + 8, a.y.begin()); } return a; }
+public:
+    struct Final { Fe a0, b0; Affine sg; };
+    OpeningRounds(const SRS& srs, const std::vector<Fe>& a, const std::vector<Fe>& b, const Affine& u_base) {
+        std::vector<uint64_t> av(4 * a.size()), bv(4 * b.size());
+        for (size_t i = 0; i < a.size(); i++) std::copy(a[i].begin(), a[i].end(), &av[4 * i]);
+        for (size_t i = 0; i < b.size(); i++) std::copy(b[i].begin(), b[i].end(), &bv[4 * i]);
+        uint64_t u[8]; std::copy(u_base.x.begin(), u_base.x.end(), u); std::copy(u_base.y.begin(), u_base.y.end(), u + 4);
+        check(kh_ipa_begin(srs.raw(), av.data(), a.size(), bv.data(), b.size(), u, &st_));
+    }
+    OpeningRounds(const OpeningRounds&) = delete; OpeningRounds& operator=(const OpeningRounds&) = delete;
+    ~OpeningRounds() { kh_ipa_free(st_); }
+    int rounds_left() const { return kh_ipa_rounds_left(st_); }
+    std::pair<Affine, Affine> round_lr(const Fe& rand_l, const Fe& rand_r) {                      // ipa.rs:940-961
+        uint64_t xy[16]; uint8_t inf[2];
+        check(kh_ipa_round_lr(st_, rand_l.data(), rand_r.data(), xy, inf));
+        return {point(xy, inf[0]), point(xy + 8, inf[1])};
+    }
+    // u_pre: the 128-bit prechallenge (low limb first); returns (u, u^-1) = (u_pre.to_field(endo_r), its inverse), ipa.rs:972-978
+    std::pair<Fe, Fe> round_fold(uint64_t u_pre_lo, uint64_t u_pre_hi) {
+        const uint64_t c[2] = {u_pre_lo, u_pre_hi}; Fe u, ui;
+        check(kh_ipa_round_fold(st_, c, u.data(), ui.data()));
+        return {u, ui};
+    }
+    Final finish() {                                                                                 // ipa.rs:1009-1018
+        Final f; uint64_t sg[8]; uint8_t inf = 0;
+        check(kh_ipa_finish(st_, f.a0.data(), f.b0.data(), sg, &inf));
+        f.sg = point(sg, inf);
+        return f;
+    }
 };
 
 }  // namespace kimchi_hip

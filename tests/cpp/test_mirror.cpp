@@ -52,6 +52,29 @@ int main() {
     bool threw = false;
     try { ScalarPolyComm two; two.chunks.assign(2, Fe{}); srs.mask_custom(cp, two); } catch (const Error& e) { threw = e.code == KH_E_BLINDERS; }
     REQUIRE(threw);
+    // opening rounds with a = b = e_0 and zero blinders: a_hi = 0 so L_0 is the identity, R_0 = <a_lo, g_hi> + <a_lo, b_hi> U
+    // = g[n/2] exactly; a and b stay e_0 through every fold, so a0 = b0 = 1
+    {
+        uint64_t one[4]; check(kh_domain_generator(int(Field::Fp), 0, one));      // omega_1 = 1 in Montgomery form
+        Fe fone{one[0], one[1], one[2], one[3]};
+        std::vector<Fe> a(1, fone), b(n, Fe{}); b[0] = fone;
+        std::vector<uint64_t> g(8 * n); check(kh_srs_get_g(srs.raw(), 0, n, g.data()));
+        Affine u_base = srs.blinding_commitment();
+        OpeningRounds st(srs, a, b, u_base);
+        REQUIRE(st.rounds_left() == 7);
+        auto lr = st.round_lr(Fe{}, Fe{});
+        REQUIRE(lr.first.infinity && !lr.second.infinity);
+        REQUIRE(std::equal(lr.second.x.begin(), lr.second.x.end(), &g[8 * (n / 2)]) && std::equal(lr.second.y.begin(), lr.second.y.end(), &g[8 * (n / 2) + 4]));
+        bool order = false;
+        try { st.round_lr(Fe{}, Fe{}); } catch (const Error& e) { order = e.code == KH_E_INVALID; }
+        REQUIRE(order);                                                            // fold must follow L/R
+        uint64_t ch = 0x9e3779b97f4a7c15ull;
+        auto uu = st.round_fold(ch, ch ^ 0x55);
+        REQUIRE(uu.first != uu.second);
+        while (st.rounds_left()) { st.round_lr(Fe{}, Fe{}); ch = ch * 6364136223846793005ull + 1; st.round_fold(ch, ~ch); }
+        auto fin = st.finish();
+        REQUIRE(fin.a0 == fone && fin.b0 == fone && !fin.sg.infinity);
+    }
     std::printf("MIRROR_OK\n");
     return 0;
 }
