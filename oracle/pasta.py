@@ -663,3 +663,137 @@ def to_limbs(v: int) -> Tuple[int, int, int, int]:
 
 def from_limbs(l) -> int:
     return int(l[0]) | (int(l[1]) << 64) | (int(l[2]) << 128) | (int(l[3]) << 192)
+
+
+# ---------------------------------------------------------------------------
+# SRS::open end to end (poly-commitment/src/ipa.rs:811-1063) and the opening-proof KAT generator
+# (poly-commitment/tests/commitment.rs:119-231, 388-440).  The heavy steps are injectable so that the same
+# transcript logic can drive either the oracle's own arithmetic or the device (tests/test_gpu_open_kat.py).
+# ---------------------------------------------------------------------------
+def shift_scalar(curve: Curve, x: int) -> int:
+    """commitment.rs:273-288."""
+    F = curve.scalar
+    two_pow = pow(2, F.p.bit_length(), F.p)
+    if F.p < curve.base.p:
+        return (x - (two_pow + 1)) * F.inv(2) % F.p
+    return (x - two_pow) % F.p
+
+
+def combine_polys(curve: Curve, plnms, polyscale: int, srs_length: int):
+    """utils.rs:103-206 for polynomials in coefficient form: p = sum polyscale^i * chunk_i, and the combined blinder."""
+    F = curve.scalar
+    acc: List[int] = []
+    combined_comm, scale = 0, 1
+    for coeffs, blinders in plnms:
+        offset = 0
+        for w in blinders:
+            seg = coeffs[min(offset, len(coeffs)): min(offset + srs_length, len(coeffs))]
+            if len(seg) > len(acc):
+                acc += [0] * (len(seg) - len(acc))
+            for i, c in enumerate(seg):
+                acc[i] = (acc[i] + scale * c) % F.p
+            combined_comm = (combined_comm + w * scale) % F.p
+            scale = scale * polyscale % F.p
+            offset += srs_length
+    while acc and acc[-1] == 0:
+        acc.pop()
+    return acc, combined_comm
+
+
+def ipa_open(curve: Curve, g: Sequence[Affine], h: Affine, plnms, elm: Sequence[int], polyscale: int, evalscale: int,
+             sponge, rng, rounds_backend=None):
+    """SRS::open (ipa.rs:824-1063) for a power-of-two SRS.  `plnms` = [(coefficients, blinder chunks)], `sponge` an
+    oracle.poseidon.DefaultFqSponge, `rng` a StdRng.  rounds_backend(a, b, u_base) may return an object with
+    round_lr(rand_l, rand_r) -> (L, R), round_fold(u_pre) -> u and finish() -> (a0, b0, g0) (the device loop);
+    by default the rounds are the literal ones of ipa_open_rounds.  Returns the OpeningProof as a dict."""
+    F = curve.scalar
+    _, endo_r = endos(curve)
+    n = len(g)
+    rounds = n.bit_length() - 1
+    assert 1 << rounds == n
+    p, blinding_factor = combine_polys(curve, plnms, polyscale, n)
+    b_init = [0] * n
+    scale = 1
+    for e in elm:
+        t = 1
+        for i in range(n):
+            b_init[i] = (b_init[i] + scale * t) % F.p
+            t = t * e % F.p
+        scale = scale * evalscale % F.p
+    cip = sum(x * y for x, y in zip(p, b_init)) % F.p
+    sponge.absorb_fr([shift_scalar(curve, cip)])
+    u_base = curve.to_group(sponge.challenge_fq())
+    a = list(p) + [0] * (n - len(p))
+
+    class _Literal:
+        def __init__(self):
+            self.g, self.a, self.b = list(g), list(a), list(b_init)
+        def round_lr(self, rand_l, rand_r):
+            m = len(self.g) // 2
+            ip_l = sum(x * y for x, y in zip(self.a[m:], self.b[:m])) % F.p
+            ip_r = sum(x * y for x, y in zip(self.a[:m], self.b[m:])) % F.p
+            L = curve.msm(self.g[:m] + [h, u_base], self.a[m:] + [rand_l, ip_l])
+            R = curve.msm(self.g[m:] + [h, u_base], self.a[:m] + [rand_r, ip_r])
+            return L, R
+        def round_fold(self, u_pre):
+            m = len(self.g) // 2
+            u = challenge_to_field(F, u_pre, endo_r); ui = F.inv(u)
+            self.a = [(lo + ui * hi) % F.p for lo, hi in zip(self.a[:m], self.a[m:])]
+            self.b = [(lo + u * hi) % F.p for lo, hi in zip(self.b[:m], self.b[m:])]
+            self.g = combine_one_endo(curve, self.g[:m], self.g[m:], u_pre)
+            return u
+        def finish(self):
+            return self.a[0], self.b[0], self.g[0]
+
+    st = rounds_backend(a, b_init, u_base) if rounds_backend else _Literal()
+    lr, blinders, chals = [], [], []
+    for _ in range(rounds):
+        rand_l = field_rand(F, rng); rand_r = field_rand(F, rng)
+        L, R = st.round_lr(rand_l, rand_r)
+        lr.append((L, R)); blinders.append((rand_l, rand_r))
+        sponge.absorb_g([L]); sponge.absorb_g([R])
+        u_pre = sponge.challenge()
+        chals.append(st.round_fold(u_pre))
+    a0, b0, g0 = st.finish()
+    r_prime = blinding_factor
+    for (rl, rr), u in zip(blinders, chals):
+        r_prime = (r_prime + rl * F.inv(u) + rr * u) % F.p
+    d = field_rand(F, rng); r_delta = field_rand(F, rng)
+    delta = curve.add(curve.mul(curve.add(g0, curve.mul(u_base, b0)), d), curve.mul(h, r_delta))
+    sponge.absorb_g([delta])
+    c = challenge_to_field(F, sponge.challenge(), endo_r)
+    return {"lr": lr, "delta": delta, "z1": (a0 * c + d) % F.p, "z2": (r_prime * c + r_delta) % F.p, "sg": g0,
+            "chals": chals, "u_base": u_base}
+
+
+def msgpack_opening_proof(curve: Curve, proof) -> bytes:
+    """OpeningProof{lr, delta, z1, z2, sg} (ipa.rs:1175-1191) as rmp-serde writes it: array(5)[array(k)[array(2)[bin L, bin R]...],
+    bin delta, bin32 z1, bin32 z2, bin sg]."""
+    k = len(proof["lr"])
+    assert k < 16
+    out = bytes([0x95, 0x90 | k])
+    for L, R in proof["lr"]:
+        out += b"\x92\xc4\x21" + curve.compress(L) + b"\xc4\x21" + curve.compress(R)
+    out += b"\xc4\x21" + curve.compress(proof["delta"])
+    out += b"\xc4\x20" + proof["z1"].to_bytes(32, "little") + b"\xc4\x20" + proof["z2"].to_bytes(32, "little")
+    out += b"\xc4\x21" + curve.compress(proof["sg"])
+    return out
+
+
+def first_random_opening_proof(curve: Curve, g, h, rng, sponge, commit=None, rounds_backend=None):
+    """proofs[0] of generate_random_opening_proof (tests/commitment.rs:119-231): 7 evaluation points, 11 polynomials of
+    random length < 500 committed with srs.commit(.., 1, rng), then open().  commit(coeffs) -> chunks may be injected."""
+    F = curve.scalar
+    n = len(g)
+    elm = [field_rand(F, rng) for _ in range(7)]
+    plnms, comms = [], []
+    for _ in range(11):
+        ln = rng.next_u64() % 500
+        coeffs = [] if ln == 0 else [field_rand(F, rng) for _ in range(ln + 1)]
+        chunks = commit(coeffs) if commit else commit_non_hiding(curve, g, coeffs, 1)
+        blinders = [field_rand(F, rng) for _ in chunks]                      # SRS::mask (ipa.rs:628-635)
+        comms.append(mask_custom(curve, h, chunks, blinders))
+        plnms.append((coeffs, blinders))
+    polymask = field_rand(F, rng); evalmask = field_rand(F, rng)
+    proof = ipa_open(curve, g, h, plnms, elm, polymask, evalmask, sponge, rng, rounds_backend)
+    return proof, comms

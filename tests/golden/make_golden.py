@@ -116,6 +116,10 @@ def main():
             "seed": [0] * 32,
             "bytes": vec_u8_after(ctest, "ser_regression_canonical_polycomm", 0),
         },
+        "opening_proof_kat": {  # tests/commitment.rs:388-440: proofs[0] of generate_random_opening_proof, seed [0;32], SRS 2^7
+            "curve": "vesta", "srs_depth": 128, "seed": [0] * 32,
+            "bytes": vec_u8_after(ctest, "ser_regression_canonical_opening_proof", 0),
+        },
         "srs": {
             "vesta": srs_file("srs/vesta.srs"),
             "pallas": srs_file("srs/pallas.srs"),

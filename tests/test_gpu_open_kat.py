@@ -1,0 +1,60 @@
+"""The reference's opening-proof known-answer test (poly-commitment/tests/commitment.rs:388-440) with the device
+doing the work: the 11 commitments through kh_commit_non_hiding, the 7 folding rounds through kh_ipa_*; the oracle
+only supplies what stays on the host in the reference integration as well (RNG, sponge, transcript, serialisation)."""
+import numpy as np
+import pytest
+
+from oracle import cref
+from oracle import pasta as P
+from oracle import poseidon as S
+
+pytestmark = pytest.mark.gpu
+
+
+def _aff(c, xy, inf):
+    if inf:
+        return None
+    return (c.base.from_mont(P.from_limbs(xy[:4])), c.base.from_mont(P.from_limbs(xy[4:])))
+
+
+def _limbs(F, vals):
+    return cref.ints_to_limbs([F.to_mont(v) for v in vals])
+
+
+def test_opening_proof_kat_on_device(golden):
+    import proof_systems_amd.khip as khip
+    khip.init(0)
+    k = golden["opening_proof_kat"]
+    cid = 0; c = P.CURVES[cid]; F = c.scalar
+    n = k["srs_depth"]
+    srs = khip.Srs.create(cid, n)                       # SRS::create on the device
+    g = [_aff(c, row, 0) for row in srs.get_g(0, n)]
+    h = _aff(c, khip.srs_h(cid), 0)
+
+    def commit(coeffs):
+        if not coeffs:
+            return [None]
+        xy, inf = srs.commit_non_hiding(_limbs(F, coeffs), 1)
+        return [_aff(c, xy[j], inf[j]) for j in range(len(inf))]
+
+    class DeviceRounds:
+        def __init__(self, a, b, u_base):
+            u_l = cref.ints_to_limbs([c.base.to_mont(u_base[0]), c.base.to_mont(u_base[1])]).reshape(8)
+            self.op = khip.IpaOpening(srs, _limbs(F, a), _limbs(F, b), u_l)
+        def round_lr(self, rand_l, rand_r):
+            xy, inf = self.op.round_lr(_limbs(F, [rand_l])[0], _limbs(F, [rand_r])[0])
+            return _aff(c, xy[0], inf[0]), _aff(c, xy[1], inf[1])
+        def round_fold(self, u_pre):
+            u, _ = self.op.round_fold(u_pre)
+            return F.from_mont(P.from_limbs(u))
+        def finish(self):
+            a0, b0, sg, sginf = self.op.finish()
+            self.op.free()
+            return F.from_mont(P.from_limbs(a0)), F.from_mont(P.from_limbs(b0)), _aff(c, sg, sginf)
+
+    proof, _ = P.first_random_opening_proof(c, g, h, P.StdRng(bytes(k["seed"])), S.DefaultFqSponge(c),
+                                            commit=commit, rounds_backend=DeviceRounds)
+    buf = P.msgpack_opening_proof(c, proof)
+    want = bytes(k["bytes"])
+    assert buf == want[:len(buf)] and not any(want[len(buf):])
+    srs.close()

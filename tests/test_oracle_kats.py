@@ -353,3 +353,32 @@ def test_host_endos_match_oracle(cid):
     c = P.CURVES[cid]
     q, r = khip.endos(cid)
     assert (c.base.from_mont(P.from_limbs(q)), c.scalar.from_mont(P.from_limbs(r))) == P.endos(c)
+
+
+def test_poseidon_sponge_kats():
+    """The oracle's Kimchi Poseidon / Fq-sponge against the reference's own pins: poseidon/tests/test_vectors/kimchi.json
+    and the empty-challenge regressions (poseidon/tests/poseidon_tests.rs:74-108)."""
+    import json, os
+    from oracle import poseidon as S
+    k = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "poseidon_kimchi_params.json")))["kats"]
+    assert len(k["kimchi_fp_hash"]) >= 5
+    for v in k["kimchi_fp_hash"]:
+        sp = S.ArithmeticSponge(P.Fp)
+        sp.absorb([int.from_bytes(bytes.fromhex(x), "little") for x in v["input"]])
+        assert sp.squeeze() == int.from_bytes(bytes.fromhex(v["output"]), "little")
+    assert S.DefaultFqSponge(P.VESTA).challenge() == int.from_bytes(bytes.fromhex(k["challenge_empty_vesta"]), "little")
+    assert S.DefaultFqSponge(P.PALLAS).challenge() == int.from_bytes(bytes.fromhex(k["challenge_empty_pallas"]), "little")
+
+
+def test_opening_proof_kat(golden):
+    """SRS::open end to end (ipa.rs:811-1063) through the oracle reproduces the reference's opening-proof bytes
+    (tests/commitment.rs:388-440): pins endos, ScalarChallenge::to_field, combine_one_endo, the round structure,
+    the RNG draw order and the sponge."""
+    from oracle import poseidon as S
+    k = golden["opening_proof_kat"]
+    c = P.VESTA
+    g = c.srs_create(k["srs_depth"]); h = c.srs_h()
+    proof, _ = P.first_random_opening_proof(c, g, h, P.StdRng(bytes(k["seed"])), S.DefaultFqSponge(c))
+    buf = P.msgpack_opening_proof(c, proof)
+    want = bytes(k["bytes"])
+    assert buf == want[:len(buf)] and not any(want[len(buf):])
