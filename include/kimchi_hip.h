@@ -148,6 +148,21 @@ int kh_endos(int curve, uint64_t endo_q[4], uint64_t endo_r[4]);
  * chal = the 128-bit prechallenge (two canonical LE limbs), out = Montgomery limbs.  Host-only. */
 int kh_scalar_challenge_to_field(int curve, const uint64_t chal[2], uint64_t out[4]);
 
+/* ---- challenge polynomials (verifier side) ----
+ * kh_b_poly_coefficients = b_poly_coefficients (poly-commitment/src/commitment.rs:464-476) for k challenge sets of
+ * `rounds` challenges each (k x rounds x 4 limbs, Montgomery): out[j][i] = prod_{bit b of i} chals[j][rounds-1-b],
+ * k x 2^rounds x 4 limbs.
+ * kh_batch_dlog_accumulator_generate (utils.rs:282-312): comms[j] = <b_poly_coefficients(chals_j), g>, coefficient
+ * vectors built and consumed on the device (one batched MSM over the resident tables).
+ * kh_batch_dlog_accumulator_check (utils.rs:212-273): *ok = [ sum_j r^j (C_j - <s_j, g>) == 0 ]; the reference draws
+ * r from OsRng inside the function, here the caller passes it (Montgomery limbs).  Size mismatches that are
+ * assert!s in the reference return KH_E_INVALID. */
+int kh_b_poly_coefficients(int field, const uint64_t *chals, unsigned rounds, size_t k, uint64_t *out);
+int kh_batch_dlog_accumulator_generate(kh_srs_t *srs, size_t num_comms, const uint64_t *chals, size_t chals_len,
+                                       uint64_t *out_xy, uint8_t *out_inf);
+int kh_batch_dlog_accumulator_check(kh_srs_t *srs, const uint64_t *comms_xy, const uint8_t *comms_inf, size_t k,
+                                    const uint64_t *chals, size_t chals_len, const uint64_t r[4], int *ok);
+
 /* ---- the folding loop of SRS::open on the device (poly-commitment/src/ipa.rs:929-1007) ----
  * The caller keeps the sponge and the RNG (ipa.rs:940-941, 966-971); everything between two squeezes runs here
  * on device-resident vectors, so a round costs one host<->device hop of 2 points + 1 challenge:

@@ -404,6 +404,19 @@ def combine_one_endo(curve: Curve, g1: Sequence[Affine], g2: Sequence[Affine], c
     return out
 
 
+def b_poly_coefficients(F: Field, chals: Sequence[int]) -> List[int]:
+    """commitment.rs:464-476, literally: s[i] = s[i - 2^(k-1)] * chals[rounds - k], k = position of i's top bit + 1."""
+    rounds = len(chals)
+    s = [1] * (1 << rounds)
+    k, pw = 0, 1
+    for i in range(1, 1 << rounds):
+        if i == pw:
+            k += 1
+            pw <<= 1
+        s[i] = s[i - (pw >> 1)] * chals[rounds - 1 - (k - 1)] % F.p
+    return s
+
+
 def ipa_open_rounds(curve: Curve, g: Sequence[Affine], h: Affine, u_base: Affine, a: Sequence[int], b: Sequence[int],
                     rands: Sequence[Tuple[int, int]], chals: Sequence[int], msm=None):
     """The folding loop of SRS::open, literally (ipa.rs:929-1018): per round L = <a_hi, g_lo> + rand_l H + <a_hi, b_lo> U,

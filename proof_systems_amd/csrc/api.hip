@@ -514,6 +514,81 @@ int kh_scalar_challenge_to_field(int curve, const uint64_t chal[2], uint64_t out
     return KH_OK;
 }
 
+// ---------------------------------------------------------------------------------- challenge polynomials (verifier side)
+static DevBuf g_bp_chals, g_bp_out;
+static int bpoly_to_device(Context& C, int field, const uint64_t* chals, unsigned rounds, size_t k, const uint64_t* rs, bool reduce) {
+    const size_t len = (size_t)1 << rounds;
+    int rc;
+    if ((rc = g_bp_chals.reserve((k * rounds + k + 1) * 32))) return rc;
+    if ((rc = g_bp_out.reserve((reduce ? 1 : k) * len * 32))) return rc;
+    hipStream_t s = C.stream;
+    if (k * rounds) KH_HIP(hipMemcpyAsync(g_bp_chals.p, chals, k * rounds * 32, hipMemcpyHostToDevice, s));
+    uint64_t* rs_dev = nullptr;
+    if (rs) { rs_dev = g_bp_chals.as<uint64_t>() + 4 * k * rounds; KH_HIP(hipMemcpyAsync(rs_dev, rs, k * 32, hipMemcpyHostToDevice, s)); }
+    if ((rc = bpoly_run(s, field, g_bp_chals.as<uint64_t>(), rounds, k, rs_dev, g_bp_out.as<uint64_t>()))) return rc;
+    KH_HIP(hipStreamSynchronize(s));                       // callers' buffers are released; the MSM may run on another slot's stream
+    return KH_OK;
+}
+int kh_b_poly_coefficients(int field, const uint64_t* chals, unsigned rounds, size_t k, uint64_t* out) {
+    KH_REQUIRE(field == KH_FIELD_FP || field == KH_FIELD_FQ, "unknown field id %d", field);
+    KH_REQUIRE(rounds <= 28, "2^%u coefficients is beyond any SRS", rounds);
+    KH_REQUIRE(out && (chals || rounds == 0 || k == 0), "null argument");
+    if (k == 0) return KH_OK;
+    int rc = ensure_init(); if (rc) return rc;
+    Context& C = ctx();
+    std::lock_guard<std::mutex> lk(C.mu);
+    if ((rc = bpoly_to_device(C, field, chals, rounds, k, nullptr, false))) return rc;
+    KH_HIP(hipMemcpy(out, g_bp_out.p, (k << rounds) * 32, hipMemcpyDeviceToHost));
+    return KH_OK;
+}
+int kh_batch_dlog_accumulator_generate(kh_srs_t* srs, size_t num_comms, const uint64_t* chals, size_t chals_len, uint64_t* out_xy, uint8_t* out_inf) {
+    KH_REQUIRE(srs, "null SRS handle");
+    if (num_comms == 0) { KH_REQUIRE(chals_len == 0, "chals must be empty when num_comms is 0 (utils.rs:290-293)"); return KH_OK; }
+    KH_REQUIRE(chals && out_xy && out_inf, "null argument");
+    const size_t rounds = chals_len / num_comms;
+    KH_REQUIRE(rounds > 0 && rounds <= 28 && rounds * num_comms == chals_len, "chals.len() = %zu is not a multiple of the round count (utils.rs:295-296)", chals_len);
+    const size_t len = (size_t)1 << rounds;
+    int rc = ensure_init(); if (rc) return rc;
+    {
+        Context& C = ctx();
+        std::lock_guard<std::mutex> lk(C.mu);
+        if ((rc = bpoly_to_device(C, khost::scalar_field_id(srs->curve), chals, (unsigned)rounds, num_comms, nullptr, false))) return rc;
+    }
+    // msm_bigint pairs min(|g|, 2^rounds) terms; the k coefficient vectors are k x len contiguous on the device
+    if (len <= srs->n) return kh_msm_batch_dev(srs, KH_BASIS_G, 0, 0, g_bp_out.as<uint64_t>(), len, num_comms, 1, out_xy, out_inf);
+    for (size_t j = 0; j < num_comms; j++)
+        if ((rc = kh_msm_batch_dev(srs, KH_BASIS_G, 0, 0, g_bp_out.as<uint64_t>() + 4 * j * len, srs->n, 1, 1, out_xy + 8 * j, out_inf + j))) return rc;
+    return KH_OK;
+}
+int kh_batch_dlog_accumulator_check(kh_srs_t* srs, const uint64_t* comms_xy, const uint8_t* comms_inf, size_t k,
+                                    const uint64_t* chals, size_t chals_len, const uint64_t r[4], int* ok) {
+    KH_REQUIRE(srs && ok, "null argument");
+    if (k == 0) { KH_REQUIRE(chals_len == 0, "chals must be empty without commitments (utils.rs:219-222)"); *ok = 1; return KH_OK; }
+    KH_REQUIRE(comms_xy && chals && r, "null argument");
+    const size_t rounds = chals_len / k;
+    KH_REQUIRE(rounds > 0 && rounds <= 28 && rounds * k == chals_len, "chals.len() = %zu is not a multiple of the round count (utils.rs:224-225)", chals_len);
+    KH_REQUIRE(((size_t)1 << rounds) == srs->n, "2^rounds = %zu terms against an SRS of %zu (assert_eq at utils.rs:264)", (size_t)1 << rounds, srs->n);
+    int rc = ensure_init(); if (rc) return rc;
+    const int field = khost::scalar_field_id(srs->curve);
+    khost::Fld F(field);
+    std::vector<khost::fe> rs(k);
+    rs[0] = F.f.one;
+    khost::fe rr; memcpy(&rr, r, 32);
+    for (size_t i = 1; i < k; i++) rs[i] = F.mul(rs[i - 1], rr);
+    {
+        Context& C = ctx();
+        std::lock_guard<std::mutex> lk(C.mu);
+        if ((rc = bpoly_to_device(C, field, chals, (unsigned)rounds, k, (const uint64_t*)rs.data(), true))) return rc;
+    }
+    uint64_t part[16]; uint8_t pinf[2];
+    if ((rc = kh_msm_batch_dev(srs, KH_BASIS_G, 0, 0, g_bp_out.as<uint64_t>(), srs->n, 1, 1, part, pinf))) return rc;        // - sum_j r^j <s_j, G>
+    if ((rc = kh_msm_points(srs->curve, comms_xy, comms_inf, (const uint64_t*)rs.data(), k, 1, part + 8, pinf + 1))) return rc; // + sum_j r^j C_j
+    uint64_t tot[8]; uint8_t tinf = 0;
+    if ((rc = kh_points_sum(srs->curve, part, pinf, 2, tot, &tinf))) return rc;
+    *ok = tinf ? 1 : 0;
+    return KH_OK;
+}
+
 // ---------------------------------------------------------------------------------- device-resident opening rounds
 struct kh_ipa {
     kh_srs_t* srs = nullptr;

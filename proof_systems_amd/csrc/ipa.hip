@@ -232,6 +232,33 @@ int ipa_round_fold(hipStream_t s, int field, const uint64_t* a, const uint64_t* 
     return KH_OK;
 }
 
+// ---------------------------------------------------------------- challenge polynomial coefficients
+// b_poly_coefficients (commitment.rs:464-476): s[i] = prod_{j : bit j of i} chals[rounds - 1 - j].  One thread per
+// coefficient, <= rounds products.  With `rs`: out[i] = - sum_j rs[j] * s_j[i] over the k challenge sets, the
+// scalar vector of batch_dlog_accumulator_check (utils.rs:212-273).
+template <class F>
+__global__ void k_bpoly(const u64* __restrict__ chals, unsigned rounds, size_t k, const u64* __restrict__ rs, u64* __restrict__ out) {
+    const size_t len = (size_t)1 << rounds;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= len) return;
+    Fe<F> acc = Fe<F>::zero();
+    for (size_t j = 0; j < k; j++) {
+        Fe<F> prod = rs ? Fe<F>::load(rs + 4 * j) : Fe<F>::one();
+        for (unsigned b = 0; b < rounds; b++)
+            if ((i >> b) & 1) prod = mul<F>(prod, Fe<F>::load(chals + 4 * (j * rounds + (rounds - 1 - b))));
+        if (rs) acc = sub<F>(acc, prod);
+        else prod.store(out + 4 * (j * len + i));
+    }
+    if (rs) acc.store(out + 4 * i);
+}
+int bpoly_run(hipStream_t s, int field, const uint64_t* chals_dev, unsigned rounds, size_t k, const uint64_t* rs_dev, uint64_t* out_dev) {
+    dim3 g((unsigned)((((size_t)1 << rounds) + 255) / 256));
+    if (field == KH_FIELD_FP) hipLaunchKernelGGL((k_bpoly<FpParams>), g, dim3(256), 0, s, chals_dev, rounds, k, rs_dev, out_dev);
+    else hipLaunchKernelGGL((k_bpoly<FqParams>), g, dim3(256), 0, s, chals_dev, rounds, k, rs_dev, out_dev);
+    KH_HIP(hipGetLastError());
+    return KH_OK;
+}
+
 static DevBuf g_ipa_a, g_ipa_b, g_ipa_c;
 
 int ipa_fold_scalars(Context& C, int field, const uint64_t* lo, const uint64_t* hi, const uint64_t u[4], size_t n, uint64_t* out) {

@@ -35,6 +35,7 @@ int ipa_round_prepare(hipStream_t s, int field, const uint64_t* a, const uint64_
                       const uint64_t rand_l[4], const uint64_t rand_r[4], uint64_t* sc, uint64_t* partial);
 int ipa_round_fold(hipStream_t s, int field, const uint64_t* a, const uint64_t* b, const uint64_t* coef, size_t Nj, size_t ncoef,
                    const uint64_t u[4], const uint64_t uinv[4], uint64_t* a2, uint64_t* b2, uint64_t* coef2);
+int bpoly_run(hipStream_t s, int field, const uint64_t* chals_dev, unsigned rounds, size_t k, const uint64_t* rs_dev, uint64_t* out_dev);
 // host_srs.cpp
 void scalar_challenge_to_field(int field, const uint64_t chal[2], const uint64_t endo[4], uint64_t out[4]);
 void host_window_multiples(int curve, const uint64_t xy[8], int W, int c, uint64_t* out_xy);   // out[w] = 2^(c w) P, affine

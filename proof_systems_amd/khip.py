@@ -37,6 +37,7 @@ SYMBOLS = [
     "kh_commit_non_hiding", "kh_commit_evaluations_non_hiding", "kh_srs_set_blinding_base",
     "kh_srs_get_blinding_base", "kh_mask_custom", "kh_domain_generator", "kh_msm_points_batch", "kh_msm_submit", "kh_msm_wait",
     "kh_ipa_fold_scalars", "kh_inner_product", "kh_ipa_fold_points", "kh_ipa_fold_points_endo", "kh_endos", "kh_scalar_challenge_to_field",
+    "kh_b_poly_coefficients", "kh_batch_dlog_accumulator_generate", "kh_batch_dlog_accumulator_check",
     "kh_ipa_begin", "kh_ipa_rounds_left", "kh_ipa_round_lr", "kh_ipa_round_fold", "kh_ipa_finish", "kh_ipa_free", "kh_points_sum", "kh_srs_create_device", "kh_srs_create_device_range", "kh_srs_get_g",
 ]
 
@@ -60,6 +61,9 @@ _lib.kh_ipa_fold_points.argtypes = [C.c_int, U64P, U64P, U64P, C.c_size_t, U64P,
 _lib.kh_ipa_fold_points_endo.argtypes = [C.c_int, U64P, U64P, U64P, C.c_size_t, U64P, U8P]
 _lib.kh_endos.argtypes = [C.c_int, U64P, U64P]
 _lib.kh_scalar_challenge_to_field.argtypes = [C.c_int, U64P, U64P]
+_lib.kh_b_poly_coefficients.argtypes = [C.c_int, U64P, C.c_uint, C.c_size_t, U64P]
+_lib.kh_batch_dlog_accumulator_generate.argtypes = [C.c_void_p, C.c_size_t, U64P, C.c_size_t, U64P, U8P]
+_lib.kh_batch_dlog_accumulator_check.argtypes = [C.c_void_p, U64P, U8P, C.c_size_t, U64P, C.c_size_t, U64P, C.POINTER(C.c_int)]
 _lib.kh_ipa_begin.argtypes = [C.c_void_p, U64P, C.c_size_t, U64P, C.c_size_t, U64P, C.POINTER(C.c_void_p)]
 _lib.kh_ipa_rounds_left.argtypes = [C.c_void_p]
 _lib.kh_ipa_round_lr.argtypes = [C.c_void_p, U64P, U64P, U64P, U8P]
@@ -400,6 +404,31 @@ def ipa_fold_points_endo(curve: int, g_lo, g_hi, chal: int):
     out = np.zeros_like(g_lo); inf = np.zeros(g_lo.shape[0], dtype=np.uint8)
     _check(_lib.kh_ipa_fold_points_endo(curve, _p64(g_lo), _p64(g_hi), _p64(c), g_lo.shape[0], _p64(out), _p8(inf)))
     return out, inf
+
+
+def b_poly_coefficients(field: int, chals, rounds: int):
+    """chals: (k * rounds, 4) Montgomery limbs -> (k, 2^rounds, 4)."""
+    ch = _c64(chals, (-1, 4))
+    k = ch.shape[0] // rounds if rounds else 1
+    out = np.zeros((k, 1 << rounds, 4), dtype=np.uint64)
+    _check(_lib.kh_b_poly_coefficients(field, _p64(ch), rounds, k, _p64(out)))
+    return out
+
+
+def batch_dlog_accumulator_generate(srs, num_comms: int, chals):
+    ch = _c64(chals, (-1, 4))
+    out = np.zeros((num_comms, 8), dtype=np.uint64); inf = np.zeros(num_comms, dtype=np.uint8)
+    _check(_lib.kh_batch_dlog_accumulator_generate(srs._h, num_comms, _p64(ch), ch.shape[0], _p64(out), _p8(inf)))
+    return out, inf
+
+
+def batch_dlog_accumulator_check(srs, comms, chals, r, inf=None) -> bool:
+    cm = _c64(comms, (-1, 8)); ch = _c64(chals, (-1, 4)); r = _c64(r, (4,))
+    if inf is None:
+        inf = np.zeros(cm.shape[0], dtype=np.uint8)
+    ok = C.c_int(0)
+    _check(_lib.kh_batch_dlog_accumulator_check(srs._h, _p64(cm), _p8(inf), cm.shape[0], _p64(ch), ch.shape[0], _p64(r), C.byref(ok)))
+    return bool(ok.value)
 
 
 def _chal_limbs(chal: int):

@@ -433,6 +433,58 @@ def test_ipa_opening_full_size_verifier_identity(khip):
     srs.close()
 
 
+def test_b_poly_coefficients_and_recursion_challenge_kat(khip, golden):
+    """b_poly_coefficients on the device (commitment.rs:464-476) and the reference's recursion-challenge commitment
+    known answer (kimchi/src/proof.rs:1160-1204) through kh_batch_dlog_accumulator_generate: basis (i+1)G, chals 2,3,5,7."""
+    kat = golden["msm_kat"]
+    c = P.VESTA; F = c.scalar
+    got = khip.b_poly_coefficients(khip.FP, _limbs(F, kat["chals"]), 4)
+    assert [F.from_mont(v) for v in cref.limbs_to_ints(got[0])] == [1, 7, 5, 35, 3, 21, 15, 105, 2, 14, 10, 70, 6, 42, 30, 210]
+    basis = np.stack([_pt_limbs(c, c.mul(c.gen, i)) for i in range(1, 17)])
+    srs = khip.Srs(0, basis)
+    xy, inf = khip.batch_dlog_accumulator_generate(srs, 1, _limbs(F, kat["chals"]))
+    assert _aff(c, xy[0], inf[0]) == (int(kat["expected_x"]), int(kat["expected_y"]))
+    srs.close()
+    # several challenge sets, both fields, against the oracle's literal loop
+    rnd = np.random.default_rng(77)
+    for fid, Fd in ((khip.FP, P.Fp), (khip.FQ, P.Fq)):
+        ch = [[int.from_bytes(rnd.bytes(40), "little") % Fd.p for _ in range(9)] for _ in range(3)]
+        got = khip.b_poly_coefficients(fid, _limbs(Fd, sum(ch, [])), 9)
+        for j in range(3):
+            assert [Fd.from_mont(v) for v in cref.limbs_to_ints(got[j])] == P.b_poly_coefficients(Fd, ch[j])
+    assert khip.b_poly_coefficients(khip.FP, np.zeros((0, 4), np.uint64), 0).shape == (1, 1, 4)
+
+
+@pytest.mark.parametrize("cid", [0, 1])
+def test_batch_dlog_accumulator(khip, cid):
+    """batch_dlog_accumulator_generate / _check (poly-commitment/src/utils.rs:212-312) at 2^10 (table path):
+    generated accumulators equal the oracle's <b_poly_coefficients(chals), g>, pass the check, and a wrong
+    commitment or a wrong challenge fails it."""
+    c = P.CURVES[cid]; F = c.scalar
+    rounds, k = 10, 3
+    n = 1 << rounds
+    rnd = np.random.default_rng(500 + cid)
+    srs = khip.Srs.create(cid, n)
+    g_l = srs.get_g(0, n)
+    ri = lambda: int.from_bytes(rnd.bytes(40), "little") % F.p
+    chals = [ri() for _ in range(rounds * k)]
+    ch_l = _limbs(F, chals)
+    comms, cinf = khip.batch_dlog_accumulator_generate(srs, k, ch_l)
+    for j in range(k):
+        w, winf = cref.msm(cid, g_l, cref.ints_to_limbs(P.b_poly_coefficients(F, chals[j * rounds:(j + 1) * rounds])), scalars_mont=False)
+        assert not cinf[j] and not winf and np.array_equal(comms[j], w)
+    r = _limbs(F, [ri()])[0]
+    assert khip.batch_dlog_accumulator_check(srs, comms, ch_l, r)
+    bad = comms.copy(); bad[1] = comms[0]
+    assert not khip.batch_dlog_accumulator_check(srs, bad, ch_l, r)
+    ch2 = ch_l.copy(); ch2[5] = ch_l[6]
+    assert not khip.batch_dlog_accumulator_check(srs, comms, ch2, r)
+    assert khip.batch_dlog_accumulator_check(srs, np.zeros((0, 8), np.uint64), np.zeros((0, 4), np.uint64), r)   # k == 0
+    with pytest.raises(khip.KhError):                      # 2^9 terms against an SRS of 2^10: the reference's assert_eq
+        khip.batch_dlog_accumulator_check(srs, comms, ch_l[: 9 * k], r)
+    srs.close()
+
+
 def test_points_sum_matches_oracle(khip):
     """kh_points_sum (host fold of per-GPU partial sums) incl. infinity inputs, P + (-P) and doubling."""
     for cid in (0, 1):

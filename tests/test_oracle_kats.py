@@ -86,17 +86,7 @@ def test_c_field_ops_vs_bigint(fid, F):
 
 # ---------------------------------------------------------------- MSM KAT (kimchi/src/proof.rs:1160-1204)
 def _b_poly_coefficients(chals, p):
-    # poly-commitment/src/commitment.rs:464-476
-    rounds = len(chals)
-    s = [1] * (1 << rounds)
-    k = 0
-    pw = 1
-    for i in range(1, 1 << rounds):
-        if i == pw:
-            k += 1
-            pw <<= 1
-        s[i] = s[i - (pw >> 1)] * chals[rounds - 1 - (k - 1)] % p
-    return s
+    return P.b_poly_coefficients(P.Fp if p == P.Fp.p else P.Fq, chals)
 
 
 def test_msm_kat(golden):
