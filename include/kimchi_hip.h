@@ -148,6 +148,25 @@ int kh_endos(int curve, uint64_t endo_q[4], uint64_t endo_r[4]);
  * chal = the 128-bit prechallenge (two canonical LE limbs), out = Montgomery limbs.  Host-only. */
 int kh_scalar_challenge_to_field(int curve, const uint64_t chal[2], uint64_t out[4]);
 
+/* ---- coefficient vectors between the transforms / commitments and the opening, device-resident ----
+ * kh_combine_polys_dev = combine_polys for polynomials in coefficient form (poly-commitment/src/utils.rs:103-206):
+ *   polynomial i (device pointer, lens[i] coefficients) is cut into num_chunks[i] chunks of srs_length (the length
+ *   of its blinder PolyComm); chunk number t overall is scaled by polyscale^t; out_dev receives srs_length
+ *   coefficients (zero above *out_len = the longest chunk), ready for kh_ipa_begin_dev.  The combined blinder
+ *   (a sum of m scalars) stays with the caller.
+ * kh_b_init_dev: b[j] = sum_i evalscale^i elm_i^j, j < padded_len (poly-commitment/src/ipa.rs:863-888).
+ * kh_evaluate_chunks_dev: to_chunked_polynomial(num_chunks, chunk_size).evaluate_chunks(x) for each of npts points
+ *   (utils/src/dense_polynomial.rs:50-69, chunked_polynomial.rs:21-28; the zeta / zeta*omega evaluations of
+ *   kimchi/src/prover.rs:1000-1170): out[p][c] = chunk_c(points[p]), npts x num_chunks x 4 limbs on the host.
+ * kh_divide_by_vanishing_poly_dev: f = q (x^n - 1) + r (kimchi/src/prover.rs:903): q_dev gets len - n coefficients
+ *   (none if len <= n), r_dev n coefficients. */
+int kh_combine_polys_dev(int field, const uint64_t *const *polys_dev, const size_t *lens, const size_t *num_chunks, size_t m,
+                         const uint64_t polyscale[4], size_t srs_length, uint64_t *out_dev, size_t *out_len);
+int kh_b_init_dev(int field, const uint64_t *elm, size_t k, const uint64_t evalscale[4], size_t padded_len, uint64_t *out_dev);
+int kh_evaluate_chunks_dev(int field, const uint64_t *coeffs_dev, size_t len, size_t chunk_size, size_t num_chunks,
+                           const uint64_t *points, size_t npts, uint64_t *out);
+int kh_divide_by_vanishing_poly_dev(int field, const uint64_t *f_dev, size_t len, unsigned log2_n, uint64_t *q_dev, uint64_t *r_dev);
+
 /* ---- challenge polynomials (verifier side) ----
  * kh_b_poly_coefficients = b_poly_coefficients (poly-commitment/src/commitment.rs:464-476) for k challenge sets of
  * `rounds` challenges each (k x rounds x 4 limbs, Montgomery): out[j][i] = prod_{bit b of i} chals[j][rounds-1-b],
@@ -181,6 +200,9 @@ int kh_batch_dlog_accumulator_check(kh_srs_t *srs, const uint64_t *comms_xy, con
 typedef struct kh_ipa kh_ipa_t;
 int kh_ipa_begin(kh_srs_t *srs, const uint64_t *a, size_t a_len, const uint64_t *b, size_t b_len,
                  const uint64_t u_base_xy[8], kh_ipa_t **out);
+/* same with a and b already in device memory (e.g. the outputs of kh_combine_polys_dev / kh_b_init_dev) */
+int kh_ipa_begin_dev(kh_srs_t *srs, const uint64_t *a_dev, size_t a_len, const uint64_t *b_dev, size_t b_len,
+                     const uint64_t u_base_xy[8], kh_ipa_t **out);
 int kh_ipa_rounds_left(const kh_ipa_t *st);
 int kh_ipa_round_lr(kh_ipa_t *st, const uint64_t rand_l[4], const uint64_t rand_r[4], uint64_t lr_xy[16], uint8_t lr_inf[2]);
 int kh_ipa_round_fold(kh_ipa_t *st, const uint64_t chal[2], uint64_t u_out[4], uint64_t u_inv_out[4]);

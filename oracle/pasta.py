@@ -713,26 +713,38 @@ def combine_polys(curve: Curve, plnms, polyscale: int, srs_length: int):
     return acc, combined_comm
 
 
+def b_init_vector(F: Field, elm: Sequence[int], evalscale: int, n: int) -> List[int]:
+    """ipa.rs:863-888: b[j] = sum_i evalscale^i * elm_i^j."""
+    b = [0] * n
+    scale = 1
+    for e in elm:
+        t = 1
+        for i in range(n):
+            b[i] = (b[i] + scale * t) % F.p
+            t = t * e % F.p
+        scale = scale * evalscale % F.p
+    return b
+
+
 def ipa_open(curve: Curve, g: Sequence[Affine], h: Affine, plnms, elm: Sequence[int], polyscale: int, evalscale: int,
-             sponge, rng, rounds_backend=None):
+             sponge, rng, rounds_backend=None, vectors_backend=None):
     """SRS::open (ipa.rs:824-1063) for a power-of-two SRS.  `plnms` = [(coefficients, blinder chunks)], `sponge` an
     oracle.poseidon.DefaultFqSponge, `rng` a StdRng.  rounds_backend(a, b, u_base) may return an object with
     round_lr(rand_l, rand_r) -> (L, R), round_fold(u_pre) -> u and finish() -> (a0, b0, g0) (the device loop);
-    by default the rounds are the literal ones of ipa_open_rounds.  Returns the OpeningProof as a dict."""
+    by default the rounds are the literal ones of ipa_open_rounds.  vectors_backend(plnms, polyscale, elm, evalscale, n)
+    may supply (p, b_init) computed elsewhere (the device's combine_polys / b_init); rounds_backend then receives
+    whatever third value it returns.  Returns the OpeningProof as a dict."""
     F = curve.scalar
     _, endo_r = endos(curve)
     n = len(g)
     rounds = n.bit_length() - 1
     assert 1 << rounds == n
     p, blinding_factor = combine_polys(curve, plnms, polyscale, n)
-    b_init = [0] * n
-    scale = 1
-    for e in elm:
-        t = 1
-        for i in range(n):
-            b_init[i] = (b_init[i] + scale * t) % F.p
-            t = t * e % F.p
-        scale = scale * evalscale % F.p
+    handle = None
+    if vectors_backend:
+        p, b_init, handle = vectors_backend(plnms, polyscale, elm, evalscale, n)
+    else:
+        b_init = b_init_vector(F, elm, evalscale, n)
     cip = sum(x * y for x, y in zip(p, b_init)) % F.p
     sponge.absorb_fr([shift_scalar(curve, cip)])
     u_base = curve.to_group(sponge.challenge_fq())
@@ -758,7 +770,10 @@ def ipa_open(curve: Curve, g: Sequence[Affine], h: Affine, plnms, elm: Sequence[
         def finish(self):
             return self.a[0], self.b[0], self.g[0]
 
-    st = rounds_backend(a, b_init, u_base) if rounds_backend else _Literal()
+    if rounds_backend:
+        st = rounds_backend(a, b_init, u_base, handle) if vectors_backend else rounds_backend(a, b_init, u_base)
+    else:
+        st = _Literal()
     lr, blinders, chals = [], [], []
     for _ in range(rounds):
         rand_l = field_rand(F, rng); rand_r = field_rand(F, rng)
@@ -793,7 +808,7 @@ def msgpack_opening_proof(curve: Curve, proof) -> bytes:
     return out
 
 
-def first_random_opening_proof(curve: Curve, g, h, rng, sponge, commit=None, rounds_backend=None):
+def first_random_opening_proof(curve: Curve, g, h, rng, sponge, commit=None, rounds_backend=None, vectors_backend=None):
     """proofs[0] of generate_random_opening_proof (tests/commitment.rs:119-231): 7 evaluation points, 11 polynomials of
     random length < 500 committed with srs.commit(.., 1, rng), then open().  commit(coeffs) -> chunks may be injected."""
     F = curve.scalar
@@ -808,5 +823,5 @@ def first_random_opening_proof(curve: Curve, g, h, rng, sponge, commit=None, rou
         comms.append(mask_custom(curve, h, chunks, blinders))
         plnms.append((coeffs, blinders))
     polymask = field_rand(F, rng); evalmask = field_rand(F, rng)
-    proof = ipa_open(curve, g, h, plnms, elm, polymask, evalmask, sponge, rng, rounds_backend)
+    proof = ipa_open(curve, g, h, plnms, elm, polymask, evalmask, sponge, rng, rounds_backend, vectors_backend)
     return proof, comms

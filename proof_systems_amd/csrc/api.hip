@@ -514,8 +514,69 @@ int kh_scalar_challenge_to_field(int curve, const uint64_t chal[2], uint64_t out
     return KH_OK;
 }
 
+// ---------------------------------------------------------------------------------- coefficient-vector operations around the opening
+int kh_combine_polys_dev(int field, const uint64_t* const* polys_dev, const size_t* lens, const size_t* num_chunks, size_t m,
+                         const uint64_t polyscale[4], size_t srs_length, uint64_t* out_dev, size_t* out_len) {
+    KH_REQUIRE(field == KH_FIELD_FP || field == KH_FIELD_FQ, "unknown field id %d", field);
+    KH_REQUIRE(out_dev && polyscale && srs_length > 0 && (m == 0 || (polys_dev && lens && num_chunks)), "kh_combine_polys_dev: bad argument");
+    int rc = ensure_init(); if (rc) return rc;
+    khost::Fld F(field);
+    khost::fe ps; memcpy(&ps, polyscale, 32);
+    khost::fe scale = F.f.one;
+    std::vector<const uint64_t*> segs; std::vector<size_t> slen; std::vector<khost::fe> scales;
+    size_t longest = 0;
+    for (size_t i = 0; i < m; i++) {                                  // utils.rs:164-176
+        size_t offset = 0;
+        for (size_t c = 0; c < num_chunks[i]; c++) {
+            const size_t lo = std::min(offset, lens[i]), hi = std::min(offset + srs_length, lens[i]);
+            if (hi > lo) { segs.push_back(polys_dev[i] + 4 * lo); slen.push_back(hi - lo); scales.push_back(scale); longest = std::max(longest, hi - lo); }
+            scale = F.mul(scale, ps);
+            offset += srs_length;
+        }
+    }
+    Context& C = ctx();
+    std::lock_guard<std::mutex> lk(C.mu);
+    if ((rc = poly_lincomb(C, field, segs.data(), slen.data(), (const uint64_t*)scales.data(), segs.size(), out_dev, srs_length))) return rc;
+    if (out_len) *out_len = longest;
+    return KH_OK;
+}
+int kh_b_init_dev(int field, const uint64_t* elm, size_t k, const uint64_t evalscale[4], size_t padded_len, uint64_t* out_dev) {
+    KH_REQUIRE(field == KH_FIELD_FP || field == KH_FIELD_FQ, "unknown field id %d", field);
+    KH_REQUIRE(out_dev && evalscale && (elm || k == 0), "kh_b_init_dev: null argument");
+    int rc = ensure_init(); if (rc) return rc;
+    khost::Fld F(field);
+    khost::fe es; memcpy(&es, evalscale, 32);
+    std::vector<khost::fe> scales(k);
+    khost::fe sc = F.f.one;
+    for (size_t i = 0; i < k; i++) { scales[i] = sc; sc = F.mul(sc, es); }
+    Context& C = ctx();
+    std::lock_guard<std::mutex> lk(C.mu);
+    return poly_b_init(C, field, elm, (const uint64_t*)scales.data(), k, padded_len, out_dev);
+}
+int kh_evaluate_chunks_dev(int field, const uint64_t* coeffs_dev, size_t len, size_t chunk_size, size_t num_chunks,
+                           const uint64_t* points, size_t npts, uint64_t* out) {
+    KH_REQUIRE(field == KH_FIELD_FP || field == KH_FIELD_FQ, "unknown field id %d", field);
+    KH_REQUIRE(chunk_size > 0 && (coeffs_dev || len == 0) && (points || npts == 0) && (out || npts * num_chunks == 0), "kh_evaluate_chunks_dev: bad argument");
+    KH_REQUIRE((len + chunk_size - 1) / chunk_size <= num_chunks, "%zu coefficients need more than %zu chunks of %zu (assert_eq at utils/src/dense_polynomial.rs:63)", len, num_chunks, chunk_size);
+    int rc = ensure_init(); if (rc) return rc;
+    Context& C = ctx();
+    std::lock_guard<std::mutex> lk(C.mu);
+    return poly_eval_chunks(C, field, coeffs_dev, len, chunk_size, num_chunks, points, npts, out);
+}
+int kh_divide_by_vanishing_poly_dev(int field, const uint64_t* f_dev, size_t len, unsigned log2_n, uint64_t* q_dev, uint64_t* r_dev) {
+    KH_REQUIRE(field == KH_FIELD_FP || field == KH_FIELD_FQ, "unknown field id %d", field);
+    KH_REQUIRE(log2_n <= 32 && r_dev && (f_dev || len == 0), "kh_divide_by_vanishing_poly_dev: bad argument");
+    const size_t n = (size_t)1 << log2_n;
+    KH_REQUIRE(q_dev || len <= n, "null quotient buffer");
+    int rc = ensure_init(); if (rc) return rc;
+    Context& C = ctx();
+    std::lock_guard<std::mutex> lk(C.mu);
+    return poly_div_vanishing(C, field, f_dev, len, n, q_dev, r_dev);
+}
+
 // ---------------------------------------------------------------------------------- challenge polynomials (verifier side)
 static DevBuf g_bp_chals, g_bp_out;
+static std::mutex g_bp_mu;      // the coefficient buffer is shared: one challenge-polynomial call at a time
 static int bpoly_to_device(Context& C, int field, const uint64_t* chals, unsigned rounds, size_t k, const uint64_t* rs, bool reduce) {
     const size_t len = (size_t)1 << rounds;
     int rc;
@@ -535,6 +596,7 @@ int kh_b_poly_coefficients(int field, const uint64_t* chals, unsigned rounds, si
     KH_REQUIRE(out && (chals || rounds == 0 || k == 0), "null argument");
     if (k == 0) return KH_OK;
     int rc = ensure_init(); if (rc) return rc;
+    std::lock_guard<std::mutex> bl(g_bp_mu);
     Context& C = ctx();
     std::lock_guard<std::mutex> lk(C.mu);
     if ((rc = bpoly_to_device(C, field, chals, rounds, k, nullptr, false))) return rc;
@@ -549,6 +611,7 @@ int kh_batch_dlog_accumulator_generate(kh_srs_t* srs, size_t num_comms, const ui
     KH_REQUIRE(rounds > 0 && rounds <= 28 && rounds * num_comms == chals_len, "chals.len() = %zu is not a multiple of the round count (utils.rs:295-296)", chals_len);
     const size_t len = (size_t)1 << rounds;
     int rc = ensure_init(); if (rc) return rc;
+    std::lock_guard<std::mutex> bl(g_bp_mu);
     {
         Context& C = ctx();
         std::lock_guard<std::mutex> lk(C.mu);
@@ -575,6 +638,7 @@ int kh_batch_dlog_accumulator_check(kh_srs_t* srs, const uint64_t* comms_xy, con
     rs[0] = F.f.one;
     khost::fe rr; memcpy(&rr, r, 32);
     for (size_t i = 1; i < k; i++) rs[i] = F.mul(rs[i - 1], rr);
+    std::lock_guard<std::mutex> bl(g_bp_mu);
     {
         Context& C = ctx();
         std::lock_guard<std::mutex> lk(C.mu);
@@ -605,7 +669,8 @@ struct kh_ipa {
     }
 };
 
-int kh_ipa_begin(kh_srs_t* srs, const uint64_t* a, size_t a_len, const uint64_t* b, size_t b_len, const uint64_t u_base_xy[8], kh_ipa_t** out) {
+static int ipa_begin_common(kh_srs_t* srs, const uint64_t* a, size_t a_len, const uint64_t* b, size_t b_len, const uint64_t u_base_xy[8], kh_ipa_t** out,
+                            hipMemcpyKind kind) {
     KH_REQUIRE(srs && out && a && b && u_base_xy, "kh_ipa_begin: null argument");
     const size_t n = srs->n;
     KH_REQUIRE((n & (n - 1)) == 0, "the opening rounds need a power-of-two SRS (size %zu)", n);
@@ -635,8 +700,8 @@ int kh_ipa_begin(kh_srs_t* srs, const uint64_t* a, size_t a_len, const uint64_t*
     hipStream_t s = C.stream;
     KH_HIP(hipMemcpy2DAsync((char*)srs->g.p + n * 64, srs->g_stride * 64, tab.data(), 128, 128, W, hipMemcpyHostToDevice, s));
     KH_HIP(hipMemsetAsync(st->a[0].p, 0, n * 32, s));
-    KH_HIP(hipMemcpyAsync(st->a[0].p, a, a_len * 32, hipMemcpyHostToDevice, s));
-    KH_HIP(hipMemcpyAsync(st->b[0].p, b, n * 32, hipMemcpyHostToDevice, s));
+    KH_HIP(hipMemcpyAsync(st->a[0].p, a, a_len * 32, kind, s));
+    KH_HIP(hipMemcpyAsync(st->b[0].p, b, n * 32, kind, s));
     const khost::fe one = khost::field(st->field).one;
     KH_HIP(hipMemcpyAsync(st->coef[0].p, &one, 32, hipMemcpyHostToDevice, s));
     KH_HIP(hipStreamSynchronize(s));                       // the staging vectors above are locals
@@ -644,6 +709,12 @@ int kh_ipa_begin(kh_srs_t* srs, const uint64_t* a, size_t a_len, const uint64_t*
     srs->ipa_live = true;
     *out = st.release();
     return KH_OK;
+}
+int kh_ipa_begin(kh_srs_t* srs, const uint64_t* a, size_t a_len, const uint64_t* b, size_t b_len, const uint64_t u_base_xy[8], kh_ipa_t** out) {
+    return ipa_begin_common(srs, a, a_len, b, b_len, u_base_xy, out, hipMemcpyHostToDevice);
+}
+int kh_ipa_begin_dev(kh_srs_t* srs, const uint64_t* a_dev, size_t a_len, const uint64_t* b_dev, size_t b_len, const uint64_t u_base_xy[8], kh_ipa_t** out) {
+    return ipa_begin_common(srs, a_dev, a_len, b_dev, b_len, u_base_xy, out, hipMemcpyDeviceToDevice);
 }
 int kh_ipa_rounds_left(const kh_ipa_t* st) {
     if (!st) return -1;

@@ -36,6 +36,11 @@ int ipa_round_prepare(hipStream_t s, int field, const uint64_t* a, const uint64_
 int ipa_round_fold(hipStream_t s, int field, const uint64_t* a, const uint64_t* b, const uint64_t* coef, size_t Nj, size_t ncoef,
                    const uint64_t u[4], const uint64_t uinv[4], uint64_t* a2, uint64_t* b2, uint64_t* coef2);
 int bpoly_run(hipStream_t s, int field, const uint64_t* chals_dev, unsigned rounds, size_t k, const uint64_t* rs_dev, uint64_t* out_dev);
+// poly.hip
+int poly_lincomb(Context& C, int field, const uint64_t* const* segs_dev, const size_t* lens, const uint64_t* scales, size_t m, uint64_t* out_dev, size_t out_len);
+int poly_b_init(Context& C, int field, const uint64_t* elm, const uint64_t* scales, size_t k, size_t n, uint64_t* out_dev);
+int poly_eval_chunks(Context& C, int field, const uint64_t* coeffs_dev, size_t len, size_t chunk, size_t num_chunks, const uint64_t* points, size_t npts, uint64_t* out);
+int poly_div_vanishing(Context& C, int field, const uint64_t* f_dev, size_t len, size_t n, uint64_t* q_dev, uint64_t* r_dev);
 // host_srs.cpp
 void scalar_challenge_to_field(int field, const uint64_t chal[2], const uint64_t endo[4], uint64_t out[4]);
 void host_window_multiples(int curve, const uint64_t xy[8], int W, int c, uint64_t* out_xy);   // out[w] = 2^(c w) P, affine

@@ -38,7 +38,7 @@ SYMBOLS = [
     "kh_srs_get_blinding_base", "kh_mask_custom", "kh_domain_generator", "kh_msm_points_batch", "kh_msm_submit", "kh_msm_wait",
     "kh_ipa_fold_scalars", "kh_inner_product", "kh_ipa_fold_points", "kh_ipa_fold_points_endo", "kh_endos", "kh_scalar_challenge_to_field",
     "kh_b_poly_coefficients", "kh_batch_dlog_accumulator_generate", "kh_batch_dlog_accumulator_check",
-    "kh_ipa_begin", "kh_ipa_rounds_left", "kh_ipa_round_lr", "kh_ipa_round_fold", "kh_ipa_finish", "kh_ipa_free", "kh_points_sum", "kh_srs_create_device", "kh_srs_create_device_range", "kh_srs_get_g",
+    "kh_ipa_begin", "kh_ipa_begin_dev", "kh_combine_polys_dev", "kh_b_init_dev", "kh_evaluate_chunks_dev", "kh_divide_by_vanishing_poly_dev", "kh_ipa_rounds_left", "kh_ipa_round_lr", "kh_ipa_round_fold", "kh_ipa_finish", "kh_ipa_free", "kh_points_sum", "kh_srs_create_device", "kh_srs_create_device_range", "kh_srs_get_g",
 ]
 
 _lib.kh_last_error.restype = C.c_char_p
@@ -65,6 +65,12 @@ _lib.kh_b_poly_coefficients.argtypes = [C.c_int, U64P, C.c_uint, C.c_size_t, U64
 _lib.kh_batch_dlog_accumulator_generate.argtypes = [C.c_void_p, C.c_size_t, U64P, C.c_size_t, U64P, U8P]
 _lib.kh_batch_dlog_accumulator_check.argtypes = [C.c_void_p, U64P, U8P, C.c_size_t, U64P, C.c_size_t, U64P, C.POINTER(C.c_int)]
 _lib.kh_ipa_begin.argtypes = [C.c_void_p, U64P, C.c_size_t, U64P, C.c_size_t, U64P, C.POINTER(C.c_void_p)]
+_lib.kh_ipa_begin_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, U64P, C.POINTER(C.c_void_p)]
+_lib.kh_combine_polys_dev.argtypes = [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.c_size_t, U64P, C.c_size_t,
+                                      C.c_void_p, C.POINTER(C.c_size_t)]
+_lib.kh_b_init_dev.argtypes = [C.c_int, U64P, C.c_size_t, U64P, C.c_size_t, C.c_void_p]
+_lib.kh_evaluate_chunks_dev.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, U64P, C.c_size_t, U64P]
+_lib.kh_divide_by_vanishing_poly_dev.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_uint, C.c_void_p, C.c_void_p]
 _lib.kh_ipa_rounds_left.argtypes = [C.c_void_p]
 _lib.kh_ipa_round_lr.argtypes = [C.c_void_p, U64P, U64P, U64P, U8P]
 _lib.kh_ipa_round_fold.argtypes = [C.c_void_p, U64P, U64P, U64P]
@@ -406,6 +412,32 @@ def ipa_fold_points_endo(curve: int, g_lo, g_hi, chal: int):
     return out, inf
 
 
+def combine_polys_dev(field: int, polys, lens, num_chunks, polyscale, srs_length: int, out):
+    """polys: list of DevBuf; out: DevBuf of srs_length elements.  Returns the length of the combined polynomial."""
+    m = len(polys)
+    ptrs = (C.c_void_p * max(m, 1))(*[C.c_void_p(p.ptr) for p in polys])
+    ls = (C.c_size_t * max(m, 1))(*lens); cs = (C.c_size_t * max(m, 1))(*num_chunks)
+    ol = C.c_size_t(0)
+    _check(_lib.kh_combine_polys_dev(field, ptrs, ls, cs, m, _p64(_c64(polyscale, (4,))), srs_length, C.c_void_p(out.ptr), C.byref(ol)))
+    return ol.value
+
+
+def b_init_dev(field: int, elm, evalscale, padded_len: int, out):
+    e = _c64(elm, (-1, 4))
+    _check(_lib.kh_b_init_dev(field, _p64(e), e.shape[0], _p64(_c64(evalscale, (4,))), padded_len, C.c_void_p(out.ptr)))
+
+
+def evaluate_chunks_dev(field: int, coeffs, length: int, chunk_size: int, num_chunks: int, points):
+    pts = _c64(points, (-1, 4))
+    out = np.zeros((pts.shape[0], num_chunks, 4), dtype=np.uint64)
+    _check(_lib.kh_evaluate_chunks_dev(field, C.c_void_p(coeffs.ptr), length, chunk_size, num_chunks, _p64(pts), pts.shape[0], _p64(out)))
+    return out
+
+
+def divide_by_vanishing_poly_dev(field: int, f, length: int, log2_n: int, q, r):
+    _check(_lib.kh_divide_by_vanishing_poly_dev(field, C.c_void_p(f.ptr), length, log2_n, C.c_void_p(q.ptr if q is not None else 0), C.c_void_p(r.ptr)))
+
+
 def b_poly_coefficients(field: int, chals, rounds: int):
     """chals: (k * rounds, 4) Montgomery limbs -> (k, 2^rounds, 4)."""
     ch = _c64(chals, (-1, 4))
@@ -444,10 +476,15 @@ def scalar_challenge_to_field(curve: int, chal: int):
 class IpaOpening:
     """The folding loop of SRS::open (ipa.rs:929-1007) on device-resident vectors; see include/kimchi_hip.h."""
 
-    def __init__(self, srs, a, b, u_base):
-        a = _c64(a, (-1, 4)); b = _c64(b, (-1, 4)); u_base = _c64(u_base, (8,))
+    def __init__(self, srs, a, b, u_base, a_len: int = None, b_len: int = None):
+        """a, b: host limb arrays, or DevBuf objects with a_len / b_len elements (kh_ipa_begin_dev)."""
+        u_base = _c64(u_base, (8,))
         h = C.c_void_p()
-        _check(_lib.kh_ipa_begin(srs._h, _p64(a), a.shape[0], _p64(b), b.shape[0], _p64(u_base), C.byref(h)))
+        if isinstance(a, DevBuf):
+            _check(_lib.kh_ipa_begin_dev(srs._h, C.c_void_p(a.ptr), a_len, C.c_void_p(b.ptr), b_len, _p64(u_base), C.byref(h)))
+        else:
+            a = _c64(a, (-1, 4)); b = _c64(b, (-1, 4))
+            _check(_lib.kh_ipa_begin(srs._h, _p64(a), a.shape[0], _p64(b), b.shape[0], _p64(u_base), C.byref(h)))
         self._h = h
 
     def rounds_left(self) -> int:

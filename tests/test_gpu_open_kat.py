@@ -1,5 +1,6 @@
 """The reference's opening-proof known-answer test (poly-commitment/tests/commitment.rs:388-440) with the device
-doing the work: the 11 commitments through kh_commit_non_hiding, the 7 folding rounds through kh_ipa_*; the oracle
+doing the work: the 11 commitments through kh_commit_non_hiding, combine_polys and b_init through
+kh_combine_polys_dev / kh_b_init_dev, the 7 folding rounds through kh_ipa_begin_dev + kh_ipa_round_*; the oracle
 only supplies what stays on the host in the reference integration as well (RNG, sponge, transcript, serialisation)."""
 import numpy as np
 import pytest
@@ -37,10 +38,29 @@ def test_opening_proof_kat_on_device(golden):
         xy, inf = srs.commit_non_hiding(_limbs(F, coeffs), 1)
         return [_aff(c, xy[j], inf[j]) for j in range(len(inf))]
 
+    def device_vectors(plnms, polyscale, elm, evalscale, n_):
+        bufs, lens, chunks = [], [], []
+        for coeffs, blinders in plnms:
+            d = khip.DevBuf(max(len(coeffs), 1) * 32)
+            if coeffs:
+                d.upload(_limbs(F, coeffs))
+            bufs.append(d); lens.append(len(coeffs)); chunks.append(len(blinders))
+        a_dev = khip.DevBuf(n_ * 32); b_dev = khip.DevBuf(n_ * 32)
+        plen = khip.combine_polys_dev(khip.FP, bufs, lens, chunks, _limbs(F, [polyscale])[0], n_, a_dev)
+        khip.b_init_dev(khip.FP, _limbs(F, elm), _limbs(F, [evalscale])[0], n_, b_dev)
+        p_all = [F.from_mont(v) for v in cref.limbs_to_ints(a_dev.download((n_, 4)))]
+        assert not any(p_all[plen:])
+        b = [F.from_mont(v) for v in cref.limbs_to_ints(b_dev.download((n_, 4)))]
+        for d in bufs:
+            d.free()
+        return p_all[:plen], b, (a_dev, b_dev)
+
     class DeviceRounds:
-        def __init__(self, a, b, u_base):
+        def __init__(self, a, b, u_base, handle):
             u_l = cref.ints_to_limbs([c.base.to_mont(u_base[0]), c.base.to_mont(u_base[1])]).reshape(8)
-            self.op = khip.IpaOpening(srs, _limbs(F, a), _limbs(F, b), u_l)
+            a_dev, b_dev = handle
+            self.op = khip.IpaOpening(srs, a_dev, b_dev, u_l, a_len=n, b_len=n)
+            a_dev.free(); b_dev.free()
         def round_lr(self, rand_l, rand_r):
             xy, inf = self.op.round_lr(_limbs(F, [rand_l])[0], _limbs(F, [rand_r])[0])
             return _aff(c, xy[0], inf[0]), _aff(c, xy[1], inf[1])
@@ -53,7 +73,7 @@ def test_opening_proof_kat_on_device(golden):
             return F.from_mont(P.from_limbs(a0)), F.from_mont(P.from_limbs(b0)), _aff(c, sg, sginf)
 
     proof, _ = P.first_random_opening_proof(c, g, h, P.StdRng(bytes(k["seed"])), S.DefaultFqSponge(c),
-                                            commit=commit, rounds_backend=DeviceRounds)
+                                            commit=commit, rounds_backend=DeviceRounds, vectors_backend=device_vectors)
     buf = P.msgpack_opening_proof(c, proof)
     want = bytes(k["bytes"])
     assert buf == want[:len(buf)] and not any(want[len(buf):])
