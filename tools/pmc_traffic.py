@@ -33,6 +33,13 @@ if acc:
     # to this access pattern (it slightly over-counts: 128-B line fills for 64-B needs).
     out["k_accumulate_hbm_bytes_per_launch"] = acc[0]["fetch_raw_bytes"] + acc[0]["write_bytes"]
     out["k_accumulate_note"] = "raw FETCH_SIZE + WRITE_SIZE; 2x correction not applied (64-B gathers, calibrated)"
+try:                                    # keep the SQ_INSTS_VALU figures of an earlier, separate pass
+    old = json.load(open(sys.argv[3]))
+    for k in ("k_accumulate_valu_wave_instructions_per_launch", "k_accumulate_sq_note"):
+        if k in old:
+            out[k] = old[k]
+except (OSError, ValueError):
+    pass
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 for k, v in out["kernels"].items():
     print(f"{k[:48]:48s} fetch(raw) {v['fetch_raw_bytes']/1e6:10.2f} MB  write {v['write_bytes']/1e6:10.2f} MB")
