@@ -209,6 +209,13 @@ int kh_ipa_round_fold(kh_ipa_t *st, const uint64_t chal[2], uint64_t u_out[4], u
 int kh_ipa_finish(kh_ipa_t *st, uint64_t a0[4], uint64_t b0[4], uint64_t sg_xy[8], uint8_t *sg_inf);
 void kh_ipa_free(kh_ipa_t *st);
 
+/* PolyComm::multi_scalar_mul (poly-commitment/src/commitment.rs:350-394): m commitments with num_chunks[i] chunks each
+ * (chunks_xy / chunks_inf: the chunk lists concatenated, sum(num_chunks) points), m scalars (Montgomery).
+ * out chunk j = sum_{i : num_chunks[i] > j} scalars[i] * com_i.chunks[j]; *out_count = max(num_chunks), or 1 point
+ * at infinity when m == 0 (the reference's empty case).  out_xy / out_inf need room for max(num_chunks, 1) points. */
+int kh_polycomm_multi_scalar_mul(int curve, const uint64_t *chunks_xy, const uint8_t *chunks_inf, const size_t *num_chunks, size_t m,
+                                 const uint64_t *scalars, uint64_t *out_xy, uint8_t *out_inf, size_t *out_count);
+
 /* ---- commitment wrappers (host logic of the SRS trait over the MSM kernels) ----
  * kh_commit_non_hiding = SRS::commit_non_hiding (poly-commitment/src/ipa.rs:638-683):
  * coefficients (len x 4 limbs, Montgomery) are split into ceil(len / srs_size) chunks,

@@ -361,6 +361,35 @@ int kh_msm_points(int curve, const uint64_t* xy, const uint8_t* inf, const uint6
     return kh_msm_points_batch(curve, xy, inf, scalars, n, 1, scalars_are_montgomery, out_xy, out_is_inf);
 }
 
+// PolyComm::multi_scalar_mul (commitment.rs:350-394): chunk j of the result = sum over the commitments that HAVE a
+// chunk j of scalar_i * com_i.chunks[j].  Ragged chunk lists become one batched MSM with the missing chunks flagged
+// as points at infinity (which contribute nothing, exactly like the reference's filter_map).
+int kh_polycomm_multi_scalar_mul(int curve, const uint64_t* chunks_xy, const uint8_t* chunks_inf, const size_t* num_chunks, size_t m,
+                                 const uint64_t* scalars, uint64_t* out_xy, uint8_t* out_inf, size_t* out_count) {
+    KH_REQUIRE(curve == KH_CURVE_VESTA || curve == KH_CURVE_PALLAS, "unknown curve id %d", curve);
+    KH_REQUIRE(out_xy && out_inf && out_count, "kh_polycomm_multi_scalar_mul: null output");
+    if (m == 0) { memset(out_xy, 0, 64); out_inf[0] = 1; *out_count = 1; return KH_OK; }      // vec![C::zero()]
+    KH_REQUIRE(chunks_xy && num_chunks && scalars, "kh_polycomm_multi_scalar_mul: null input");
+    size_t width = 0, total = 0;
+    for (size_t i = 0; i < m; i++) { width = std::max(width, num_chunks[i]); total += num_chunks[i]; }
+    if (width == 0) { *out_count = 0; return KH_OK; }
+    std::vector<uint64_t> pts(width * m * 8, 0), sc(width * m * 4);
+    std::vector<uint8_t> inf(width * m, 1);
+    size_t pos = 0;
+    for (size_t i = 0; i < m; i++) {
+        for (size_t j = 0; j < num_chunks[i]; j++, pos++) {
+            memcpy(&pts[(j * m + i) * 8], chunks_xy + 8 * pos, 64);
+            inf[j * m + i] = chunks_inf ? chunks_inf[pos] : 0;
+        }
+        for (size_t j = 0; j < width; j++) memcpy(&sc[(j * m + i) * 4], scalars + 4 * i, 32);
+    }
+    (void)total;
+    int rc = kh_msm_points_batch(curve, pts.data(), inf.data(), sc.data(), m, width, 1, out_xy, out_inf);
+    if (rc) return rc;
+    *out_count = width;
+    return KH_OK;
+}
+
 // ---------------------------------------------------------------------------------- commitment wrappers
 static bool limbs_zero(const uint64_t* p) { return (p[0] | p[1] | p[2] | p[3]) == 0; }
 

@@ -37,7 +37,7 @@ SYMBOLS = [
     "kh_commit_non_hiding", "kh_commit_evaluations_non_hiding", "kh_srs_set_blinding_base",
     "kh_srs_get_blinding_base", "kh_mask_custom", "kh_domain_generator", "kh_msm_points_batch", "kh_msm_submit", "kh_msm_wait",
     "kh_ipa_fold_scalars", "kh_inner_product", "kh_ipa_fold_points", "kh_ipa_fold_points_endo", "kh_endos", "kh_scalar_challenge_to_field",
-    "kh_b_poly_coefficients", "kh_batch_dlog_accumulator_generate", "kh_batch_dlog_accumulator_check",
+    "kh_polycomm_multi_scalar_mul", "kh_b_poly_coefficients", "kh_batch_dlog_accumulator_generate", "kh_batch_dlog_accumulator_check",
     "kh_ipa_begin", "kh_ipa_begin_dev", "kh_combine_polys_dev", "kh_b_init_dev", "kh_evaluate_chunks_dev", "kh_divide_by_vanishing_poly_dev", "kh_ipa_rounds_left", "kh_ipa_round_lr", "kh_ipa_round_fold", "kh_ipa_finish", "kh_ipa_free", "kh_points_sum", "kh_srs_create_device", "kh_srs_create_device_range", "kh_srs_get_g",
 ]
 
@@ -61,6 +61,7 @@ _lib.kh_ipa_fold_points.argtypes = [C.c_int, U64P, U64P, U64P, C.c_size_t, U64P,
 _lib.kh_ipa_fold_points_endo.argtypes = [C.c_int, U64P, U64P, U64P, C.c_size_t, U64P, U8P]
 _lib.kh_endos.argtypes = [C.c_int, U64P, U64P]
 _lib.kh_scalar_challenge_to_field.argtypes = [C.c_int, U64P, U64P]
+_lib.kh_polycomm_multi_scalar_mul.argtypes = [C.c_int, U64P, U8P, C.POINTER(C.c_size_t), C.c_size_t, U64P, U64P, U8P, C.POINTER(C.c_size_t)]
 _lib.kh_b_poly_coefficients.argtypes = [C.c_int, U64P, C.c_uint, C.c_size_t, U64P]
 _lib.kh_batch_dlog_accumulator_generate.argtypes = [C.c_void_p, C.c_size_t, U64P, C.c_size_t, U64P, U8P]
 _lib.kh_batch_dlog_accumulator_check.argtypes = [C.c_void_p, U64P, U8P, C.c_size_t, U64P, C.c_size_t, U64P, C.POINTER(C.c_int)]
@@ -410,6 +411,22 @@ def ipa_fold_points_endo(curve: int, g_lo, g_hi, chal: int):
     out = np.zeros_like(g_lo); inf = np.zeros(g_lo.shape[0], dtype=np.uint8)
     _check(_lib.kh_ipa_fold_points_endo(curve, _p64(g_lo), _p64(g_hi), _p64(c), g_lo.shape[0], _p64(out), _p8(inf)))
     return out, inf
+
+
+def polycomm_multi_scalar_mul(curve: int, comms, scalars):
+    """comms: list of (chunks (k_i, 8) limbs, inf (k_i,) flags); scalars (m, 4).  Returns (chunks, inf)."""
+    m = len(comms)
+    counts = [np.asarray(c[0]).reshape(-1, 8).shape[0] for c in comms]
+    xy = np.concatenate([np.asarray(c[0], dtype=np.uint64).reshape(-1, 8) for c in comms]) if m else np.zeros((0, 8), np.uint64)
+    inf = np.concatenate([np.asarray(c[1], dtype=np.uint8).reshape(-1) for c in comms]) if m else np.zeros(0, np.uint8)
+    xy = np.ascontiguousarray(xy); inf = np.ascontiguousarray(inf)
+    sc = _c64(scalars, (-1, 4))
+    width = max(counts + [1])
+    out = np.zeros((width, 8), dtype=np.uint64); oinf = np.zeros(width, dtype=np.uint8)
+    cnt = C.c_size_t(0)
+    nc = (C.c_size_t * max(m, 1))(*counts)
+    _check(_lib.kh_polycomm_multi_scalar_mul(curve, _p64(xy), _p8(inf), nc, m, _p64(sc), _p64(out), _p8(oinf), C.byref(cnt)))
+    return out[:cnt.value], oinf[:cnt.value]
 
 
 def combine_polys_dev(field: int, polys, lens, num_chunks, polyscale, srs_length: int, out):

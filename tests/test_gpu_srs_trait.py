@@ -485,6 +485,31 @@ def test_batch_dlog_accumulator(khip, cid):
     srs.close()
 
 
+@pytest.mark.parametrize("cid", [0, 1])
+def test_polycomm_multi_scalar_mul(khip, cid):
+    """PolyComm::multi_scalar_mul (commitment.rs:350-394) with ragged chunk lists and a point at infinity inside."""
+    c = P.CURVES[cid]; F = c.scalar
+    rnd = np.random.default_rng(900 + cid)
+    g = khip.srs_generate(cid, 5, 12)
+    counts = [1, 3, 2, 1, 3]
+    comms, k = [], 0
+    for n_ch in counts:
+        inf = np.zeros(n_ch, np.uint8)
+        comms.append((g[k:k + n_ch].copy(), inf)); k += n_ch
+    comms[2][1][0] = 1                                    # an explicit zero chunk
+    sc = [int.from_bytes(rnd.bytes(40), "little") % F.p for _ in counts]
+    got, ginf = khip.polycomm_multi_scalar_mul(cid, comms, _limbs(F, sc))
+    assert got.shape[0] == 3
+    for j in range(3):
+        acc = None
+        for (xy, inf), s, n_ch in zip(comms, sc, counts):
+            if j < n_ch and not inf[j]:
+                acc = c.add(acc, c.mul(_aff(c, xy[j], 0), s))
+        assert _aff(c, got[j], ginf[j]) == acc
+    e, einf = khip.polycomm_multi_scalar_mul(cid, [], np.zeros((0, 4), np.uint64))
+    assert e.shape[0] == 1 and einf[0] == 1
+
+
 def test_points_sum_matches_oracle(khip):
     """kh_points_sum (host fold of per-GPU partial sums) incl. infinity inputs, P + (-P) and doubling."""
     for cid in (0, 1):
