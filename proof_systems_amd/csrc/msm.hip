@@ -462,7 +462,7 @@ k_marginals(const uint8_t* __restrict__ buckets, MargGeom g, uint8_t* __restrict
     const uint8_t* B = buckets + q * (size_t)g.nb * 128;
     const u32 cnt = g.nb >> f, lowmask = (1u << s) - 1u;
     Xyzz<BF> acc = Xyzz<BF>::identity();
-    for (u32 e = threadIdx.x; e < cnt; e += 256) {
+    for (u32 e = threadIdx.x; e < cnt; e += blockDim.x) {
         const u32 t = ((e >> s) << (s + f)) | (v << s) | (e & lowmask);
         acc = add<BF>(acc, Xyzz<BF>::load(B + (size_t)t * 128));
     }
@@ -592,7 +592,8 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
     const u32 nseg = nb / m;
     const u32 nblk1 = (nseg + SUM_BLK - 1) / SUM_BLK;
     // one to four MSMs over the tables: digit marginals instead (k_marginals), three fields of <= 5 bits
-    const u32 planes = (precomp && ngroups <= 4 && m == 1 && c >= 7 && c <= 16 && !getenv("KH_NO_PLANES")) ? 3u : 0u;
+    static const size_t marg_max = getenv("KH_MARG_MAX") ? (size_t)atol(getenv("KH_MARG_MAX")) : 4096;
+    const u32 planes = (precomp && ngroups <= marg_max && c >= 7 && c <= 16 && !getenv("KH_NO_PLANES")) ? 3u : 0u;
     MargGeom mg{};
     if (planes) {
         const u32 bits = (u32)c - 1, f0 = (bits + 2) / 3, f1 = (bits - f0 + 1) / 2, f2 = bits - f0 - f1;
@@ -662,7 +663,9 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
     C.timer.mark("bucket_sum", s);
     // 7 reduce
     if (planes) {
-        hipLaunchKernelGGL((k_marginals<BF>), dim3(32, 3, (unsigned)ngroups), dim3(256), 0, s, C.ws_buckets.as<uint8_t>(), mg, C.ws_seg.as<uint8_t>());
+        // few groups: 256 threads per marginal (4 sequential additions + the tree: shortest chain); batches: one wave
+        // per marginal (16 + 6 additions deep, but 2.2x less issue work -- batches are throughput-bound)
+        hipLaunchKernelGGL((k_marginals<BF>), dim3(32, 3, (unsigned)ngroups), dim3(ngroups <= 4 ? 256 : 64), 0, s, C.ws_buckets.as<uint8_t>(), mg, C.ws_seg.as<uint8_t>());
         hipLaunchKernelGGL((k_marginal_fin<BF>), dim3(3, (unsigned)ngroups), dim3(64), 0, s, C.ws_seg.as<uint8_t>(), mg, C.ws_out.as<uint8_t>());
     } else {
     hipLaunchKernelGGL((k_reduce_seg<BF>), dim3((unsigned)((ngroups * nseg + 127) / 128)), dim3(128), 0, s,
