@@ -181,6 +181,13 @@ int kh_batch_dlog_accumulator_generate(kh_srs_t *srs, size_t num_comms, const ui
                                        uint64_t *out_xy, uint8_t *out_inf);
 int kh_batch_dlog_accumulator_check(kh_srs_t *srs, const uint64_t *comms_xy, const uint8_t *comms_inf, size_t k,
                                     const uint64_t *chals, size_t chals_len, const uint64_t r[4], int *ok);
+/* The single MSM of the batch verifier SRS::verify (poly-commitment/src/ipa.rs:301-502):
+ *   sum_i sg_weights[i] <b_poly_coefficients(chals_i), g>  +  sum_j extra_scalars[j] extra_j   == 0 ?
+ * The k challenge polynomials (k x rounds challenges, 2^rounds = SRS size) are expanded on the device and multiplied
+ * into the resident tables (ipa.rs:402-420); the proof-specific terms (H, sg, U, L/R, the commitments, delta with the
+ * scalars of ipa.rs:405-470, all computed by the caller next to its sponge) go through the ad-hoc MSM. */
+int kh_ipa_verify_msm(kh_srs_t *srs, const uint64_t *chals, size_t chals_len, const uint64_t *sg_weights, size_t k,
+                      const uint64_t *extra_xy, const uint8_t *extra_inf, const uint64_t *extra_scalars, size_t m, int *is_zero);
 
 /* ---- the folding loop of SRS::open on the device (poly-commitment/src/ipa.rs:929-1007) ----
  * The caller keeps the sponge and the RNG (ipa.rs:940-941, 966-971); everything between two squeezes runs here

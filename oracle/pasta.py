@@ -823,5 +823,114 @@ def first_random_opening_proof(curve: Curve, g, h, rng, sponge, commit=None, rou
         comms.append(mask_custom(curve, h, chunks, blinders))
         plnms.append((coeffs, blinders))
     polymask = field_rand(F, rng); evalmask = field_rand(F, rng)
+    verifier_sponge = sponge.clone()
     proof = ipa_open(curve, g, h, plnms, elm, polymask, evalmask, sponge, rng, rounds_backend, vectors_backend)
+    # what the verifier is handed (tests/commitment.rs:162-227): chunked evaluations at the 7 points
+    evaluations = []
+    for (coeffs, _w), com in zip(plnms, comms):
+        nch = max(1, -(-len(coeffs) // n))
+        ev = []
+        for pt in elm:
+            row = []
+            for ci in range(nch):
+                acc = 0
+                for v in reversed(coeffs[ci * n:(ci + 1) * n]):
+                    acc = (acc * pt + v) % F.p
+                row.append(acc)
+            ev.append(row)
+        evaluations.append((com, ev))
+    proof["verifier_input"] = {"sponge": verifier_sponge, "evaluation_points": elm, "polyscale": polymask, "evalscale": evalmask,
+                               "evaluations": evaluations, "opening": proof,
+                               "combined_inner_product": combined_inner_product(F, polymask, evalmask, [e for _, e in evaluations])}
     return proof, comms
+
+
+# ---------------------------------------------------------------------------
+# SRS::verify (poly-commitment/src/ipa.rs:301-502)
+# ---------------------------------------------------------------------------
+def b_poly(F: Field, chals: Sequence[int], x: int) -> int:
+    """commitment.rs:426-436."""
+    k = len(chals)
+    pw = [x]
+    for _ in range(1, k):
+        pw.append(pw[-1] * pw[-1] % F.p)
+    r = 1
+    for i in range(k):
+        r = r * (1 + chals[i] * pw[k - 1 - i]) % F.p
+    return r
+
+
+def combined_inner_product(F: Field, polyscale: int, evalscale: int, polys) -> int:
+    """commitment.rs:622-657.  polys[t][j][i] = evaluation of chunk i of polynomial t at point j."""
+    res, ps = 0, 1
+    for evals_tr in polys:
+        if not evals_tr[0]:
+            continue
+        for i in range(len(evals_tr[0])):
+            term = 0
+            for j in reversed(range(len(evals_tr))):
+                term = (term * evalscale + evals_tr[j][i]) % F.p
+            res = (res + ps * term) % F.p
+            ps = ps * polyscale % F.p
+    return res
+
+
+def ipa_verify_terms(curve: Curve, n: int, h: Affine, batch, rng):
+    """The scalars and points SRS::verify (ipa.rs:301-502) feeds to its one MSM, split into the SRS part and the rest:
+    returns (g_terms, extra_points, extra_scalars) with g_terms = [(weight, chals)], i.e. the scalar of g_j is
+    sum weight * b_poly_coefficients(chals)[j]; H is extra_points[0].  batch items: dicts with sponge,
+    evaluation_points, polyscale, evalscale, evaluations [(commitment chunks, evals[point][chunk])], opening,
+    combined_inner_product."""
+    F = curve.scalar
+    _, endo_r = endos(curve)
+    rounds = n.bit_length() - 1
+    rand_base = field_rand(F, rng); sg_rand_base = field_rand(F, rng)
+    rb_i, sg_i = 1, 1
+    pts: List[Affine] = [h]
+    sc: List[int] = [0]
+    g_terms = []
+    for it in batch:
+        sponge, op = it["sponge"], it["opening"]
+        assert len(op["lr"]) == rounds
+        sponge.absorb_fr([shift_scalar(curve, it["combined_inner_product"])])
+        u_base = curve.to_group(sponge.challenge_fq())
+        chal = []
+        for L, R in op["lr"]:
+            sponge.absorb_g([L]); sponge.absorb_g([R])
+            chal.append(challenge_to_field(F, sponge.challenge(), endo_r))
+        chal_inv = [F.inv(u) for u in chal]
+        sponge.absorb_g([op["delta"]])
+        c = challenge_to_field(F, sponge.challenge(), endo_r)
+        b0, scale = 0, 1
+        for e in it["evaluation_points"]:
+            b0 = (b0 + scale * b_poly(F, chal, e)) % F.p
+            scale = scale * it["evalscale"] % F.p
+        pts.append(op["sg"]); sc.append((-rb_i * op["z1"] - sg_i) % F.p)
+        g_terms.append((sg_i, chal))
+        sc[0] = (sc[0] - rb_i * op["z2"]) % F.p
+        pts.append(u_base); sc.append(-rb_i * (op["z1"] * b0) % F.p)
+        rc = c * rb_i % F.p
+        for (L, R), ui, u in zip(op["lr"], chal_inv, chal):
+            pts.append(L); sc.append(rc * ui % F.p)
+            pts.append(R); sc.append(rc * u % F.p)
+        ps = 1                                           # combine_commitments (commitment.rs:724-744)
+        for chunks, _ev in it["evaluations"]:
+            for ch in chunks:
+                pts.append(ch); sc.append(rc * ps % F.p)
+                ps = ps * it["polyscale"] % F.p
+        pts.append(u_base); sc.append(rc * it["combined_inner_product"] % F.p)
+        pts.append(op["delta"]); sc.append(rb_i)
+        rb_i = rb_i * rand_base % F.p
+        sg_i = sg_i * sg_rand_base % F.p
+    return g_terms, pts, sc
+
+
+def ipa_verify(curve: Curve, g: Sequence[Affine], h: Affine, batch, rng) -> bool:
+    """SRS::verify with the final MSM done by the oracle."""
+    F = curve.scalar
+    g_terms, pts, sc = ipa_verify_terms(curve, len(g), h, batch, rng)
+    gs = [0] * len(g)
+    for w, chal in g_terms:
+        for j, s in enumerate(b_poly_coefficients(F, chal)):
+            gs[j] = (gs[j] + w * s) % F.p
+    return curve.msm(list(g) + pts, gs + sc) is None

@@ -667,11 +667,13 @@ int kh_batch_dlog_accumulator_check(kh_srs_t* srs, const uint64_t* comms_xy, con
     rs[0] = F.f.one;
     khost::fe rr; memcpy(&rr, r, 32);
     for (size_t i = 1; i < k; i++) rs[i] = F.mul(rs[i - 1], rr);
+    std::vector<khost::fe> neg(k);
+    for (size_t i = 0; i < k; i++) neg[i] = F.neg(rs[i]);
     std::lock_guard<std::mutex> bl(g_bp_mu);
     {
         Context& C = ctx();
         std::lock_guard<std::mutex> lk(C.mu);
-        if ((rc = bpoly_to_device(C, field, chals, (unsigned)rounds, k, (const uint64_t*)rs.data(), true))) return rc;
+        if ((rc = bpoly_to_device(C, field, chals, (unsigned)rounds, k, (const uint64_t*)neg.data(), true))) return rc;
     }
     uint64_t part[16]; uint8_t pinf[2];
     if ((rc = kh_msm_batch_dev(srs, KH_BASIS_G, 0, 0, g_bp_out.as<uint64_t>(), srs->n, 1, 1, part, pinf))) return rc;        // - sum_j r^j <s_j, G>
@@ -679,6 +681,36 @@ int kh_batch_dlog_accumulator_check(kh_srs_t* srs, const uint64_t* comms_xy, con
     uint64_t tot[8]; uint8_t tinf = 0;
     if ((rc = kh_points_sum(srs->curve, part, pinf, 2, tot, &tinf))) return rc;
     *ok = tinf ? 1 : 0;
+    return KH_OK;
+}
+
+// The one MSM of the batch verifier (SRS::verify, ipa.rs:301-502): sum_i w_i <s_i, g> over the resident tables, with the
+// s_i = b_poly_coefficients(chals_i) built on the device, plus the proof-specific points (H, sg, U, L/R, commitments,
+// delta with the scalars of ipa.rs:405-470) as an ad-hoc MSM; *is_zero = the verifier's `msm_res == zero` test.
+int kh_ipa_verify_msm(kh_srs_t* srs, const uint64_t* chals, size_t chals_len, const uint64_t* sg_weights, size_t k,
+                      const uint64_t* extra_xy, const uint8_t* extra_inf, const uint64_t* extra_scalars, size_t m, int* is_zero) {
+    KH_REQUIRE(srs && is_zero, "null argument");
+    KH_REQUIRE(k == 0 || (chals && sg_weights), "null challenges");
+    KH_REQUIRE(m == 0 || (extra_xy && extra_scalars), "null extra points");
+    int rc = ensure_init(); if (rc) return rc;
+    uint64_t part[16]; uint8_t pinf[2] = {1, 1};
+    memset(part, 0, sizeof(part));
+    if (k) {
+        const size_t rounds = chals_len / k;
+        KH_REQUIRE(rounds > 0 && rounds <= 28 && rounds * k == chals_len, "chals_len = %zu is not k x rounds", chals_len);
+        KH_REQUIRE(((size_t)1 << rounds) == srs->n, "2^rounds = %zu against an SRS of %zu (padded_length, ipa.rs:340-345)", (size_t)1 << rounds, srs->n);
+        std::lock_guard<std::mutex> bl(g_bp_mu);
+        {
+            Context& C = ctx();
+            std::lock_guard<std::mutex> lk(C.mu);
+            if ((rc = bpoly_to_device(C, khost::scalar_field_id(srs->curve), chals, (unsigned)rounds, k, sg_weights, true))) return rc;
+        }
+        if ((rc = kh_msm_batch_dev(srs, KH_BASIS_G, 0, 0, g_bp_out.as<uint64_t>(), srs->n, 1, 1, part, pinf))) return rc;
+    }
+    if (m && (rc = kh_msm_points(srs->curve, extra_xy, extra_inf, extra_scalars, m, 1, part + 8, pinf + 1))) return rc;
+    uint64_t tot[8]; uint8_t tinf = 0;
+    if ((rc = kh_points_sum(srs->curve, part, pinf, 2, tot, &tinf))) return rc;
+    *is_zero = tinf ? 1 : 0;
     return KH_OK;
 }
 

@@ -234,8 +234,9 @@ int ipa_round_fold(hipStream_t s, int field, const uint64_t* a, const uint64_t* 
 
 // ---------------------------------------------------------------- challenge polynomial coefficients
 // b_poly_coefficients (commitment.rs:464-476): s[i] = prod_{j : bit j of i} chals[rounds - 1 - j].  One thread per
-// coefficient, <= rounds products.  With `rs`: out[i] = - sum_j rs[j] * s_j[i] over the k challenge sets, the
-// scalar vector of batch_dlog_accumulator_check (utils.rs:212-273).
+// coefficient, <= rounds products.  With `rs`: out[i] = sum_j rs[j] * s_j[i] over the k challenge sets, the
+// weighted sum of challenge polynomials that batch_dlog_accumulator_check (utils.rs:212-273, weights -r^j) and the
+// batch verifier (ipa.rs:402-420, weights sg_rand_base^j) multiply into the SRS.
 template <class F>
 __global__ void k_bpoly(const u64* __restrict__ chals, unsigned rounds, size_t k, const u64* __restrict__ rs, u64* __restrict__ out) {
     const size_t len = (size_t)1 << rounds;
@@ -246,7 +247,7 @@ __global__ void k_bpoly(const u64* __restrict__ chals, unsigned rounds, size_t k
         Fe<F> prod = rs ? Fe<F>::load(rs + 4 * j) : Fe<F>::one();
         for (unsigned b = 0; b < rounds; b++)
             if ((i >> b) & 1) prod = mul<F>(prod, Fe<F>::load(chals + 4 * (j * rounds + (rounds - 1 - b))));
-        if (rs) acc = sub<F>(acc, prod);
+        if (rs) acc = add<F>(acc, prod);
         else prod.store(out + 4 * (j * len + i));
     }
     if (rs) acc.store(out + 4 * i);

@@ -37,7 +37,7 @@ SYMBOLS = [
     "kh_commit_non_hiding", "kh_commit_evaluations_non_hiding", "kh_srs_set_blinding_base",
     "kh_srs_get_blinding_base", "kh_mask_custom", "kh_domain_generator", "kh_msm_points_batch", "kh_msm_submit", "kh_msm_wait",
     "kh_ipa_fold_scalars", "kh_inner_product", "kh_ipa_fold_points", "kh_ipa_fold_points_endo", "kh_endos", "kh_scalar_challenge_to_field",
-    "kh_polycomm_multi_scalar_mul", "kh_b_poly_coefficients", "kh_batch_dlog_accumulator_generate", "kh_batch_dlog_accumulator_check",
+    "kh_polycomm_multi_scalar_mul", "kh_b_poly_coefficients", "kh_batch_dlog_accumulator_generate", "kh_batch_dlog_accumulator_check", "kh_ipa_verify_msm",
     "kh_ipa_begin", "kh_ipa_begin_dev", "kh_combine_polys_dev", "kh_b_init_dev", "kh_evaluate_chunks_dev", "kh_divide_by_vanishing_poly_dev", "kh_ipa_rounds_left", "kh_ipa_round_lr", "kh_ipa_round_fold", "kh_ipa_finish", "kh_ipa_free", "kh_points_sum", "kh_srs_create_device", "kh_srs_create_device_range", "kh_srs_get_g",
 ]
 
@@ -65,6 +65,7 @@ _lib.kh_polycomm_multi_scalar_mul.argtypes = [C.c_int, U64P, U8P, C.POINTER(C.c_
 _lib.kh_b_poly_coefficients.argtypes = [C.c_int, U64P, C.c_uint, C.c_size_t, U64P]
 _lib.kh_batch_dlog_accumulator_generate.argtypes = [C.c_void_p, C.c_size_t, U64P, C.c_size_t, U64P, U8P]
 _lib.kh_batch_dlog_accumulator_check.argtypes = [C.c_void_p, U64P, U8P, C.c_size_t, U64P, C.c_size_t, U64P, C.POINTER(C.c_int)]
+_lib.kh_ipa_verify_msm.argtypes = [C.c_void_p, U64P, C.c_size_t, U64P, C.c_size_t, U64P, U8P, U64P, C.c_size_t, C.POINTER(C.c_int)]
 _lib.kh_ipa_begin.argtypes = [C.c_void_p, U64P, C.c_size_t, U64P, C.c_size_t, U64P, C.POINTER(C.c_void_p)]
 _lib.kh_ipa_begin_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, U64P, C.POINTER(C.c_void_p)]
 _lib.kh_combine_polys_dev.argtypes = [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.c_size_t, U64P, C.c_size_t,
@@ -478,6 +479,16 @@ def batch_dlog_accumulator_check(srs, comms, chals, r, inf=None) -> bool:
     ok = C.c_int(0)
     _check(_lib.kh_batch_dlog_accumulator_check(srs._h, _p64(cm), _p8(inf), cm.shape[0], _p64(ch), ch.shape[0], _p64(r), C.byref(ok)))
     return bool(ok.value)
+
+
+def ipa_verify_msm(srs, chals, sg_weights, extra_xy, extra_scalars, extra_inf=None) -> bool:
+    ch = _c64(chals, (-1, 4)); w = _c64(sg_weights, (-1, 4)); ex = _c64(extra_xy, (-1, 8)); es = _c64(extra_scalars, (-1, 4))
+    if extra_inf is None:
+        extra_inf = np.zeros(ex.shape[0], dtype=np.uint8)
+    z = C.c_int(0)
+    _check(_lib.kh_ipa_verify_msm(srs._h, _p64(ch), ch.shape[0], _p64(w), w.shape[0], _p64(ex), _p8(np.ascontiguousarray(extra_inf, dtype=np.uint8)),
+                                  _p64(es), ex.shape[0], C.byref(z)))
+    return bool(z.value)
 
 
 def _chal_limbs(chal: int):

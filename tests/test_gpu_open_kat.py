@@ -78,3 +78,37 @@ def test_opening_proof_kat_on_device(golden):
     want = bytes(k["bytes"])
     assert buf == want[:len(buf)] and not any(want[len(buf):])
     srs.close()
+
+
+def test_batch_verifier_msm_on_device(golden):
+    """SRS::verify (ipa.rs:301-502) on two proofs (the KAT proof and one from another seed): the transcript side runs
+    in the oracle, the one big MSM through kh_ipa_verify_msm (challenge polynomials expanded on the device and
+    multiplied into the resident tables).  Valid batch -> zero; a tampered z1 or a swapped L -> non-zero."""
+    import proof_systems_amd.khip as khip
+    khip.init(0)
+    cid = 0; c = P.CURVES[cid]; F = c.scalar
+    n = 128
+    srs = khip.Srs.create(cid, n)
+    g = [_aff(c, row, 0) for row in srs.get_g(0, n)]
+    h = _aff(c, khip.srs_h(cid), 0)
+    items = []
+    for seed in (bytes(32), bytes([7] * 32)):
+        proof, _ = P.first_random_opening_proof(c, g, h, P.StdRng(seed), S.DefaultFqSponge(c))
+        items.append(proof["verifier_input"])
+
+    def device_verify(batch):
+        fresh = [dict(it, sponge=it["sponge"].clone()) for it in batch]
+        g_terms, pts, sc = P.ipa_verify_terms(c, n, h, fresh, P.StdRng(bytes([3] * 32)))
+        chals = sum((ch for _, ch in g_terms), [])
+        xy = np.stack([cref.ints_to_limbs([c.base.to_mont(p[0]), c.base.to_mont(p[1])]).reshape(8) if p else np.zeros(8, np.uint64) for p in pts])
+        inf = np.array([0 if p else 1 for p in pts], dtype=np.uint8)
+        return khip.ipa_verify_msm(srs, _limbs(F, chals), _limbs(F, [w for w, _ in g_terms]), xy, _limbs(F, sc), inf)
+
+    assert device_verify(items)
+    assert device_verify(items[:1])
+    assert P.ipa_verify(c, g, h, [dict(it, sponge=it["sponge"].clone()) for it in items], P.StdRng(bytes([3] * 32)))
+    bad = dict(items[1], opening=dict(items[1]["opening"], z1=(items[1]["opening"]["z1"] + 1) % F.p))
+    assert not device_verify([items[0], bad])
+    lr = list(items[0]["opening"]["lr"]); lr[2] = (lr[2][1], lr[2][0])
+    assert not device_verify([dict(items[0], opening=dict(items[0]["opening"], lr=lr))])
+    srs.close()

@@ -372,3 +372,17 @@ def test_opening_proof_kat(golden):
     buf = P.msgpack_opening_proof(c, proof)
     want = bytes(k["bytes"])
     assert buf == want[:len(buf)] and not any(want[len(buf):])
+
+
+def test_verifier_accepts_reference_proof(golden):
+    """The oracle's SRS::verify (ipa.rs:301-502) accepts the byte-pinned opening proof of the reference's KAT and
+    rejects it with one scalar changed -- the reference's own test_randomised property (tests/commitment.rs:233-260)."""
+    from oracle import poseidon as S
+    c = P.VESTA
+    g = c.srs_create(128); h = c.srs_h()
+    rng = P.StdRng(bytes(golden["opening_proof_kat"]["seed"]))
+    proof, _ = P.first_random_opening_proof(c, g, h, rng, S.DefaultFqSponge(c))
+    vi = proof["verifier_input"]
+    assert P.ipa_verify(c, g, h, [dict(vi, sponge=vi["sponge"].clone())], rng)
+    bad = dict(vi, sponge=vi["sponge"].clone(), opening=dict(proof, z2=(proof["z2"] + 1) % c.scalar.p))
+    assert not P.ipa_verify(c, g, h, [bad], rng)
