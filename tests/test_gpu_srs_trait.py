@@ -300,7 +300,7 @@ def _run_opening(khip, srs, cid, a_l, b_l, U_l, rands_l, chals):
     return lr, us, a0, b0, sg, sginf
 
 
-@pytest.mark.parametrize("cid,logn", [(0, 5), (1, 5), (0, 10), (1, 3)])
+@pytest.mark.parametrize("cid,logn", [(0, 5), (1, 5), (0, 10), (1, 10), (1, 3), (0, 1), (0, 0)])
 def test_ipa_opening_rounds_match_oracle(khip, cid, logn):
     """The device-resident folding loop of SRS::open (ipa.rs:929-1018) against the oracle's literal restatement
     (which folds the basis with combine_one_endo): every L, R, every challenge image, a0, b0 and sg bit for bit.
@@ -315,7 +315,7 @@ def test_ipa_opening_rounds_match_oracle(khip, cid, logn):
     h = _aff(c, khip.srs_h(cid), 0)
     U_l = khip.srs_generate(cid, 1 << 20, 1)[0]
     U = _aff(c, U_l, 0)
-    a_len = n - 3
+    a_len = max(1, n - 3)
     ri = lambda: int.from_bytes(rnd.bytes(40), "little") % F.p
     a = [ri() for _ in range(a_len)]
     x = ri()
