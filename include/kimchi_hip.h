@@ -167,6 +167,26 @@ int kh_evaluate_chunks_dev(int field, const uint64_t *coeffs_dev, size_t len, si
                            const uint64_t *points, size_t npts, uint64_t *out);
 int kh_divide_by_vanishing_poly_dev(int field, const uint64_t *f_dev, size_t len, unsigned log2_n, uint64_t *q_dev, uint64_t *r_dev);
 
+/* ---- constraint expressions over resident columns (first slice) ----
+ * kh_expr_evaluations_dev = Expr::evaluations (kimchi/src/circuits/expr.rs:1938-2190) for an expression lowered to the
+ * reference's reverse Polish form (PolishToken, expr.rs:815-836, produced by Expr::to_polish); the machine is
+ * PolishToken::evaluate (expr.rs:856-937) run per row.  tokens: ntok pairs (opcode, argument):
+ *   KH_TOK_CONST k   push constants[k]     (Literal / Challenge / Mds / EndoCoefficient, resolved by the caller)
+ *   KH_TOK_CELL  a   push column[a >> 1] at this row (a & 1 = 0, Curr) or the next one (a & 1 = 1, Next):
+ *                    element (stride * i + next * next_shift) mod col_len  (the SubEvals rule, expr.rs:1972-1987;
+ *                    d8 columns into a d8 result: stride 1, next_shift 8; into a d4 result: stride 2, next_shift 8)
+ *                    -- VanishesOnZeroKnowledgeAndPreviousRows and UnnormalizedLagrangeBasis(i) are such columns
+ *   KH_TOK_DUP, KH_TOK_POW n, KH_TOK_ADD, KH_TOK_MUL, KH_TOK_SUB, KH_TOK_STORE, KH_TOK_LOAD i   as in the reference
+ *   (SkipIf / SkipIfNot are resolved by the caller: feature flags are fixed per index).
+ * out_dev[i] (= or +=, `accumulate`) the value of the expression on row i, i < rows.  A malformed program (stack
+ * underflow, Load before Store, final stack length != 1: ExprError::EmptyStack / the assert at expr.rs:935) returns
+ * KH_E_INVALID before anything is launched. */
+enum { KH_TOK_CONST = 0, KH_TOK_CELL = 1, KH_TOK_DUP = 2, KH_TOK_POW = 3, KH_TOK_ADD = 4, KH_TOK_MUL = 5, KH_TOK_SUB = 6,
+       KH_TOK_STORE = 7, KH_TOK_LOAD = 8 };
+int kh_expr_evaluations_dev(int field, const uint32_t *tokens, size_t ntok, const uint64_t *const *cols_dev, const size_t *col_len,
+                            size_t ncols, const uint64_t *constants, size_t nconsts, size_t rows, unsigned stride,
+                            unsigned next_shift, int accumulate, uint64_t *out_dev);
+
 /* ---- challenge polynomials (verifier side) ----
  * kh_b_poly_coefficients = b_poly_coefficients (poly-commitment/src/commitment.rs:464-476) for k challenge sets of
  * `rounds` challenges each (k x rounds x 4 limbs, Montgomery): out[j][i] = prod_{bit b of i} chals[j][rounds-1-b],

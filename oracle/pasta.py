@@ -934,3 +934,60 @@ def ipa_verify(curve: Curve, g: Sequence[Affine], h: Affine, batch, rng) -> bool
         for j, s in enumerate(b_poly_coefficients(F, chal)):
             gs[j] = (gs[j] + w * s) % F.p
     return curve.msm(list(g) + pts, gs + sc) is None
+
+
+# ---------------------------------------------------------------------------
+# PolishToken machine per row (kimchi/src/circuits/expr.rs:856-937 with the column addressing of
+# Expr::evaluations, expr.rs:1972-1987).  Opcodes as in include/kimchi_hip.h.
+# ---------------------------------------------------------------------------
+TOK_CONST, TOK_CELL, TOK_DUP, TOK_POW, TOK_ADD, TOK_MUL, TOK_SUB, TOK_STORE, TOK_LOAD = range(9)
+
+
+def polish_evaluate_rows(F: Field, tokens, cols, consts, rows: int, stride: int = 1, next_shift: int = 8) -> List[int]:
+    out = []
+    for i in range(rows):
+        stack, cache = [], []
+        for op, arg in tokens:
+            if op == TOK_CONST:
+                stack.append(consts[arg])
+            elif op == TOK_CELL:
+                col = cols[arg >> 1]
+                stack.append(col[(stride * i + (next_shift if arg & 1 else 0)) % len(col)])
+            elif op == TOK_DUP:
+                stack.append(stack[-1])
+            elif op == TOK_POW:
+                stack[-1] = pow(stack[-1], arg, F.p)
+            elif op in (TOK_ADD, TOK_MUL, TOK_SUB):
+                y = stack.pop(); x = stack.pop()
+                stack.append((x + y) % F.p if op == TOK_ADD else (x * y) % F.p if op == TOK_MUL else (x - y) % F.p)
+            elif op == TOK_STORE:
+                cache.append(stack[-1])
+            elif op == TOK_LOAD:
+                stack.append(cache[arg])
+            else:
+                raise ValueError(op)
+        assert len(stack) == 1
+        out.append(stack[0])
+    return out
+
+
+def generic_gate_tokens(w0: int, c0: int, sel: int, alpha0: int, alpha1: int):
+    """index(Generic) * (alpha^a0 * constraint1 + alpha^a1 * constraint2) of the double generic gate
+    (kimchi/src/circuits/polynomials/generic.rs:83-120, argument.rs:201-214) in reverse Polish form.
+    w0 = column index of witness 0 (witness columns w0..w0+5), c0 = column index of coefficient 0 (c0..c0+9),
+    sel = the selector column, alpha0/alpha1 = indices of the two alpha powers in the constants table."""
+    C_ = lambda col: (TOK_CELL, 2 * col)
+    t = [C_(sel)]
+    for g, alpha in ((0, alpha0), (1, alpha1)):
+        w, c = w0 + 3 * g, c0 + 5 * g
+        t += [(TOK_CONST, alpha)]
+        t += [C_(c), C_(w), (TOK_MUL, 0)]                                  # left_coeff * left
+        t += [C_(c + 1), C_(w + 1), (TOK_MUL, 0), (TOK_ADD, 0)]            # + right_coeff * right
+        t += [C_(c + 2), C_(w + 2), (TOK_MUL, 0), (TOK_ADD, 0)]            # + out_coeff * out
+        t += [C_(c + 3), C_(w), (TOK_MUL, 0), C_(w + 1), (TOK_MUL, 0), (TOK_ADD, 0)]   # + mul_coeff * left * right
+        t += [C_(c + 4), (TOK_ADD, 0)]                                     # + constant
+        t += [(TOK_MUL, 0)]                                                # alpha^a * constraint
+        if g == 1:
+            t += [(TOK_ADD, 0)]
+    t += [(TOK_MUL, 0)]                                                    # selector * (...)
+    return t

@@ -603,6 +603,18 @@ int kh_divide_by_vanishing_poly_dev(int field, const uint64_t* f_dev, size_t len
     return poly_div_vanishing(C, field, f_dev, len, n, q_dev, r_dev);
 }
 
+int kh_expr_evaluations_dev(int field, const uint32_t* tokens, size_t ntok, const uint64_t* const* cols_dev, const size_t* col_len, size_t ncols,
+                            const uint64_t* constants, size_t nconsts, size_t rows, unsigned stride, unsigned next_shift, int accumulate,
+                            uint64_t* out_dev) {
+    KH_REQUIRE(field == KH_FIELD_FP || field == KH_FIELD_FQ, "unknown field id %d", field);
+    KH_REQUIRE(tokens && ntok > 0 && (out_dev || rows == 0) && stride > 0, "kh_expr_evaluations_dev: bad argument");
+    KH_REQUIRE((ncols == 0 || (cols_dev && col_len)) && (nconsts == 0 || constants), "kh_expr_evaluations_dev: null table");
+    int rc = ensure_init(); if (rc) return rc;
+    Context& C = ctx();
+    std::lock_guard<std::mutex> lk(C.mu);
+    return expr_run(C, field, tokens, ntok, cols_dev, col_len, ncols, constants, nconsts, rows, stride, next_shift, accumulate, out_dev);
+}
+
 // ---------------------------------------------------------------------------------- challenge polynomials (verifier side)
 static DevBuf g_bp_chals, g_bp_out;
 static std::mutex g_bp_mu;      // the coefficient buffer is shared: one challenge-polynomial call at a time

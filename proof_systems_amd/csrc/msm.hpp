@@ -41,6 +41,9 @@ int poly_lincomb(Context& C, int field, const uint64_t* const* segs_dev, const s
 int poly_b_init(Context& C, int field, const uint64_t* elm, const uint64_t* scales, size_t k, size_t n, uint64_t* out_dev);
 int poly_eval_chunks(Context& C, int field, const uint64_t* coeffs_dev, size_t len, size_t chunk, size_t num_chunks, const uint64_t* points, size_t npts, uint64_t* out);
 int poly_div_vanishing(Context& C, int field, const uint64_t* f_dev, size_t len, size_t n, uint64_t* q_dev, uint64_t* r_dev);
+// expr.hip
+int expr_run(Context& C, int field, const uint32_t* prog, size_t ntok, const uint64_t* const* cols_dev, const size_t* col_len, size_t ncols,
+             const uint64_t* consts, size_t nconsts, size_t rows, unsigned stride, unsigned next_shift, int accumulate, uint64_t* out_dev);
 // host_srs.cpp
 void scalar_challenge_to_field(int field, const uint64_t chal[2], const uint64_t endo[4], uint64_t out[4]);
 void host_window_multiples(int curve, const uint64_t xy[8], int W, int c, uint64_t* out_xy);   // out[w] = 2^(c w) P, affine

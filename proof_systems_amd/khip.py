@@ -37,7 +37,7 @@ SYMBOLS = [
     "kh_commit_non_hiding", "kh_commit_evaluations_non_hiding", "kh_srs_set_blinding_base",
     "kh_srs_get_blinding_base", "kh_mask_custom", "kh_domain_generator", "kh_msm_points_batch", "kh_msm_submit", "kh_msm_wait",
     "kh_ipa_fold_scalars", "kh_inner_product", "kh_ipa_fold_points", "kh_ipa_fold_points_endo", "kh_endos", "kh_scalar_challenge_to_field",
-    "kh_polycomm_multi_scalar_mul", "kh_b_poly_coefficients", "kh_batch_dlog_accumulator_generate", "kh_batch_dlog_accumulator_check", "kh_ipa_verify_msm",
+    "kh_polycomm_multi_scalar_mul", "kh_expr_evaluations_dev", "kh_b_poly_coefficients", "kh_batch_dlog_accumulator_generate", "kh_batch_dlog_accumulator_check", "kh_ipa_verify_msm",
     "kh_ipa_begin", "kh_ipa_begin_dev", "kh_combine_polys_dev", "kh_b_init_dev", "kh_evaluate_chunks_dev", "kh_divide_by_vanishing_poly_dev", "kh_ipa_rounds_left", "kh_ipa_round_lr", "kh_ipa_round_fold", "kh_ipa_finish", "kh_ipa_free", "kh_points_sum", "kh_srs_create_device", "kh_srs_create_device_range", "kh_srs_get_g",
 ]
 
@@ -61,6 +61,8 @@ _lib.kh_ipa_fold_points.argtypes = [C.c_int, U64P, U64P, U64P, C.c_size_t, U64P,
 _lib.kh_ipa_fold_points_endo.argtypes = [C.c_int, U64P, U64P, U64P, C.c_size_t, U64P, U8P]
 _lib.kh_endos.argtypes = [C.c_int, U64P, U64P]
 _lib.kh_scalar_challenge_to_field.argtypes = [C.c_int, U64P, U64P]
+_lib.kh_expr_evaluations_dev.argtypes = [C.c_int, C.POINTER(C.c_uint32), C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_size_t,
+                                         U64P, C.c_size_t, C.c_size_t, C.c_uint, C.c_uint, C.c_int, C.c_void_p]
 _lib.kh_polycomm_multi_scalar_mul.argtypes = [C.c_int, U64P, U8P, C.POINTER(C.c_size_t), C.c_size_t, U64P, U64P, U8P, C.POINTER(C.c_size_t)]
 _lib.kh_b_poly_coefficients.argtypes = [C.c_int, U64P, C.c_uint, C.c_size_t, U64P]
 _lib.kh_batch_dlog_accumulator_generate.argtypes = [C.c_void_p, C.c_size_t, U64P, C.c_size_t, U64P, U8P]
@@ -412,6 +414,20 @@ def ipa_fold_points_endo(curve: int, g_lo, g_hi, chal: int):
     out = np.zeros_like(g_lo); inf = np.zeros(g_lo.shape[0], dtype=np.uint8)
     _check(_lib.kh_ipa_fold_points_endo(curve, _p64(g_lo), _p64(g_hi), _p64(c), g_lo.shape[0], _p64(out), _p8(inf)))
     return out, inf
+
+
+TOK_CONST, TOK_CELL, TOK_DUP, TOK_POW, TOK_ADD, TOK_MUL, TOK_SUB, TOK_STORE, TOK_LOAD = range(9)
+
+
+def expr_evaluations_dev(field: int, tokens, cols, col_len, constants, rows: int, out, stride: int = 1, next_shift: int = 8, accumulate: bool = False):
+    """tokens: list of (opcode, arg); cols: list of DevBuf; constants: (k, 4) Montgomery limbs; out: DevBuf of `rows` elements."""
+    tk = np.ascontiguousarray(np.array(tokens, dtype=np.uint32).reshape(-1, 2))
+    m = len(cols)
+    ptrs = (C.c_void_p * max(m, 1))(*[C.c_void_p(c.ptr) for c in cols])
+    lens = (C.c_size_t * max(m, 1))(*col_len)
+    cs = _c64(constants, (-1, 4))
+    _check(_lib.kh_expr_evaluations_dev(field, tk.ctypes.data_as(C.POINTER(C.c_uint32)), tk.shape[0], ptrs, lens, m, _p64(cs), cs.shape[0],
+                                        rows, stride, next_shift, int(accumulate), C.c_void_p(out.ptr)))
 
 
 def polycomm_multi_scalar_mul(curve: int, comms, scalars):
