@@ -187,6 +187,18 @@ int kh_expr_evaluations_dev(int field, const uint32_t *tokens, size_t ntok, cons
                             size_t ncols, const uint64_t *constants, size_t nconsts, size_t rows, unsigned stride,
                             unsigned next_shift, int accumulate, uint64_t *out_dev);
 
+/* ---- scans, batch inversion, division by a linear factor: the permutation argument's vector steps ----
+ * kh_field_scan_dev: in-place inclusive prefix (reverse = 0) or suffix (reverse = 1) scan under + or *
+ *   (the running product z[j+1] = z[j] * ..., kimchi/src/circuits/polynomials/permutation.rs:556-563).
+ * kh_batch_inversion_dev = ark_ff::batch_inversion (permutation.rs:533): non-zero entries inverted, zeros kept.
+ * kh_divide_by_linear_dev: f = q (x - a) + rem (the two boundary quotients (z - 1)/(x - 1), (z - 1)/(x - sid[n - zk])
+ *   of perm_quot, permutation.rs:300-327): q_dev gets len - 1 coefficients, rem = f(a) comes back to the host
+ *   (the reference returns an error when it is non-zero). */
+enum { KH_SCAN_ADD = 0, KH_SCAN_MUL = 1 };
+int kh_field_scan_dev(int field, int op, int reverse, uint64_t *data_dev, size_t n);
+int kh_batch_inversion_dev(int field, uint64_t *v_dev, size_t n);
+int kh_divide_by_linear_dev(int field, const uint64_t *f_dev, size_t len, const uint64_t a[4], uint64_t *q_dev, uint64_t rem[4]);
+
 /* ---- challenge polynomials (verifier side) ----
  * kh_b_poly_coefficients = b_poly_coefficients (poly-commitment/src/commitment.rs:464-476) for k challenge sets of
  * `rounds` challenges each (k x rounds x 4 limbs, Montgomery): out[j][i] = prod_{bit b of i} chals[j][rounds-1-b],

@@ -991,3 +991,46 @@ def generic_gate_tokens(w0: int, c0: int, sel: int, alpha0: int, alpha1: int):
             t += [(TOK_ADD, 0)]
     t += [(TOK_MUL, 0)]                                                    # selector * (...)
     return t
+
+
+# ---------------------------------------------------------------------------
+# Permutation argument (kimchi/src/circuits/polynomials/permutation.rs)
+# ---------------------------------------------------------------------------
+def perm_aggreg(F: Field, witness, sigma, shifts, sid, beta: int, gamma: int, zk_rows: int, rands):
+    """perm_aggreg (permutation.rs:447-577), literally: z[0] = 1, z[j+1] = z[j] * prod_i (w_i[j] + sid[j] beta shift_i + gamma)
+    / prod_i (w_i[j] + sigma_i[j] beta + gamma), except that z[n - zk_rows + 1] and z[n - zk_rows + 2] are random.
+    witness / sigma: PERMUTS columns of n values on d1; rands: the two random values, in draw order."""
+    n = len(sid)
+    den = [1] * n; num = [1] * n
+    for w, s_col, sh in zip(witness, sigma, shifts):
+        for j in range(n - 1):
+            den[j + 1] = den[j + 1] * (w[j] + s_col[j] * beta + gamma) % F.p
+            num[j + 1] = num[j + 1] * (w[j] + sid[j] * beta * sh + gamma) % F.p
+    z = [1] + [F.inv(d) if d else 0 for d in den[1:]]
+    it = iter(rands)
+    for j in range(n - 1):
+        if j != n - zk_rows and j != n - zk_rows + 1:
+            z[j + 1] = z[j + 1] * num[j + 1] * z[j] % F.p
+        else:
+            z[j + 1] = next(it)
+    return z
+
+
+def perm_quot_tokens(w0: int, s0: int, z: int, x: int, zkpm: int, gamma: int, beta: int, bshift0: int, alpha0: int, permuts: int = 7):
+    """The `perm` part of perm_quot (permutation.rs:237-283) in reverse Polish form:
+    alpha0 * zkpm(x) * ( z(x) prod_i (w_i + gamma + x beta shift_i)  -  z(x w) prod_i (w_i + gamma + sigma_i beta) ).
+    Column indices: witness w0.., sigma s0.., z, x (poly_x_d1), zkpm (permutation_vanishing_polynomial_l); constants:
+    gamma, beta, beta*shift_i at bshift0.., alpha0."""
+    C_ = lambda col, nxt=0: (TOK_CELL, 2 * col + nxt)
+    t = []
+    for i in range(permuts):                                # shifts
+        t += [C_(w0 + i), (TOK_CONST, gamma), (TOK_ADD, 0), C_(x), (TOK_CONST, bshift0 + i), (TOK_MUL, 0), (TOK_ADD, 0)]
+        if i:
+            t += [(TOK_MUL, 0)]
+    t += [C_(z), (TOK_MUL, 0)]
+    for i in range(permuts):                                # sigmas
+        t += [C_(w0 + i), (TOK_CONST, gamma), C_(s0 + i), (TOK_CONST, beta), (TOK_MUL, 0), (TOK_ADD, 0), (TOK_ADD, 0)]
+        if i:
+            t += [(TOK_MUL, 0)]
+    t += [C_(z, 1), (TOK_MUL, 0), (TOK_SUB, 0), (TOK_CONST, alpha0), (TOK_MUL, 0), C_(zkpm), (TOK_MUL, 0)]
+    return t

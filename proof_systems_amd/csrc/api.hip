@@ -603,6 +603,30 @@ int kh_divide_by_vanishing_poly_dev(int field, const uint64_t* f_dev, size_t len
     return poly_div_vanishing(C, field, f_dev, len, n, q_dev, r_dev);
 }
 
+int kh_field_scan_dev(int field, int op, int reverse, uint64_t* data_dev, size_t n) {
+    KH_REQUIRE(field == KH_FIELD_FP || field == KH_FIELD_FQ, "unknown field id %d", field);
+    KH_REQUIRE((op == KH_SCAN_ADD || op == KH_SCAN_MUL) && (data_dev || n == 0), "kh_field_scan_dev: bad argument");
+    int rc = ensure_init(); if (rc) return rc;
+    Context& C = ctx();
+    std::lock_guard<std::mutex> lk(C.mu);
+    return poly_scan(C, field, op, reverse ? 1 : 0, data_dev, n);
+}
+int kh_batch_inversion_dev(int field, uint64_t* v_dev, size_t n) {
+    KH_REQUIRE(field == KH_FIELD_FP || field == KH_FIELD_FQ, "unknown field id %d", field);
+    KH_REQUIRE(v_dev || n == 0, "null vector");
+    int rc = ensure_init(); if (rc) return rc;
+    Context& C = ctx();
+    std::lock_guard<std::mutex> lk(C.mu);
+    return poly_batch_inversion(C, field, v_dev, n);
+}
+int kh_divide_by_linear_dev(int field, const uint64_t* f_dev, size_t len, const uint64_t a[4], uint64_t* q_dev, uint64_t rem[4]) {
+    KH_REQUIRE(field == KH_FIELD_FP || field == KH_FIELD_FQ, "unknown field id %d", field);
+    KH_REQUIRE(a && rem && (f_dev || len == 0) && (q_dev || len <= 1), "kh_divide_by_linear_dev: null argument");
+    int rc = ensure_init(); if (rc) return rc;
+    Context& C = ctx();
+    std::lock_guard<std::mutex> lk(C.mu);
+    return poly_divide_by_linear(C, field, f_dev, len, a, q_dev, rem);
+}
 int kh_expr_evaluations_dev(int field, const uint32_t* tokens, size_t ntok, const uint64_t* const* cols_dev, const size_t* col_len, size_t ncols,
                             const uint64_t* constants, size_t nconsts, size_t rows, unsigned stride, unsigned next_shift, int accumulate,
                             uint64_t* out_dev) {

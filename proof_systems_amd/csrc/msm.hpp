@@ -41,6 +41,9 @@ int poly_lincomb(Context& C, int field, const uint64_t* const* segs_dev, const s
 int poly_b_init(Context& C, int field, const uint64_t* elm, const uint64_t* scales, size_t k, size_t n, uint64_t* out_dev);
 int poly_eval_chunks(Context& C, int field, const uint64_t* coeffs_dev, size_t len, size_t chunk, size_t num_chunks, const uint64_t* points, size_t npts, uint64_t* out);
 int poly_div_vanishing(Context& C, int field, const uint64_t* f_dev, size_t len, size_t n, uint64_t* q_dev, uint64_t* r_dev);
+int poly_scan(Context& C, int field, int op, int rev, uint64_t* data_dev, size_t n);
+int poly_batch_inversion(Context& C, int field, uint64_t* v_dev, size_t n);
+int poly_divide_by_linear(Context& C, int field, const uint64_t* f_dev, size_t len, const uint64_t a[4], uint64_t* q_dev, uint64_t rem[4]);
 // expr.hip
 int expr_run(Context& C, int field, const uint32_t* prog, size_t ntok, const uint64_t* const* cols_dev, const size_t* col_len, size_t ncols,
              const uint64_t* consts, size_t nconsts, size_t rows, unsigned stride, unsigned next_shift, int accumulate, uint64_t* out_dev);

@@ -9,6 +9,7 @@
 #include "common.hpp"
 #include "field.cuh"
 #include "msm.hpp"
+#include "host_ec.hpp"
 
 namespace kh {
 
@@ -94,6 +95,129 @@ __global__ void k_div_vanishing(const u64* __restrict__ f, size_t len, size_t n,
     acc.store(r + 4 * i);
 }
 
+// ---------------------------------------------------------------- scans over field elements
+// Inclusive prefix (or suffix, `rev`) scan under + or *: the building block of ark_ff::batch_inversion
+// (permutation.rs:533), of the running product z of perm_aggreg (permutation.rs:556-563) and of division by a
+// linear factor (permutation.rs:300-327).  Three launches: 2048-element tiles (8 per thread, sequential, then a
+// Hillis-Steele pass over the 256 thread totals in LDS), a single-block scan of the tile totals, the fix-up.
+static constexpr int SCAN_E = 8, SCAN_T = 256, SCAN_TILE = SCAN_E * SCAN_T;
+template <class F, int OP> __device__ __forceinline__ Fe<F> scan_op(const Fe<F>& a, const Fe<F>& b) { return OP == 0 ? add<F>(a, b) : mul<F>(a, b); }
+template <class F, int OP> __device__ __forceinline__ Fe<F> scan_id() { return OP == 0 ? Fe<F>::zero() : Fe<F>::one(); }
+
+// scans the SCAN_T values held one per thread (inclusive); returns this thread's exclusive prefix
+template <class F, int OP>
+__device__ __forceinline__ Fe<F> block_exclusive(Fe<F> v, u32* sh, Fe<F>* total) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < 8; k++) sh[k * SCAN_T + t] = v.v[k];
+    __syncthreads();
+    for (int d = 1; d < SCAN_T; d <<= 1) {
+        Fe<F> o = scan_id<F, OP>();
+        if (t >= d) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) o.v[k] = sh[k * SCAN_T + t - d];
+        }
+        __syncthreads();
+        if (t >= d) {
+            v = scan_op<F, OP>(o, v);
+#pragma unroll
+            for (int k = 0; k < 8; k++) sh[k * SCAN_T + t] = v.v[k];
+        }
+        __syncthreads();
+    }
+    Fe<F> ex = scan_id<F, OP>();
+    if (t > 0) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) ex.v[k] = sh[k * SCAN_T + t - 1];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) total->v[k] = sh[k * SCAN_T + SCAN_T - 1];
+    __syncthreads();
+    return ex;
+}
+template <class F, int OP>
+__global__ void __launch_bounds__(SCAN_T)
+k_scan_tiles(u64* __restrict__ data, size_t n, int rev, u64* __restrict__ totals) {
+    __shared__ u32 sh[8 * SCAN_T];
+    const size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)threadIdx.x * SCAN_E;
+    Fe<F> loc[SCAN_E];
+    Fe<F> run = scan_id<F, OP>();
+#pragma unroll
+    for (int e = 0; e < SCAN_E; e++) {
+        const size_t i = base + e;
+        loc[e] = i < n ? Fe<F>::load(data + 4 * (rev ? n - 1 - i : i)) : scan_id<F, OP>();
+        run = scan_op<F, OP>(run, loc[e]);
+        loc[e] = run;
+    }
+    Fe<F> total;
+    const Fe<F> ex = block_exclusive<F, OP>(run, sh, &total);
+#pragma unroll
+    for (int e = 0; e < SCAN_E; e++) {
+        const size_t i = base + e;
+        if (i < n) scan_op<F, OP>(ex, loc[e]).store(data + 4 * (rev ? n - 1 - i : i));
+    }
+    if (threadIdx.x == 0) total.store(totals + 4 * blockIdx.x);
+}
+// exclusive scan of the tile totals in place (one block; <= SCAN_TILE tiles = 4M elements)
+template <class F, int OP>
+__global__ void __launch_bounds__(SCAN_T)
+k_scan_totals(u64* __restrict__ totals, size_t ntiles) {
+    __shared__ u32 sh[8 * SCAN_T];
+    const size_t base = (size_t)threadIdx.x * SCAN_E;
+    Fe<F> loc[SCAN_E];
+    Fe<F> run = scan_id<F, OP>();
+#pragma unroll
+    for (int e = 0; e < SCAN_E; e++) {
+        loc[e] = run;                                       // exclusive
+        if (base + e < ntiles) run = scan_op<F, OP>(run, Fe<F>::load(totals + 4 * (base + e)));
+    }
+    Fe<F> total;
+    const Fe<F> ex = block_exclusive<F, OP>(run, sh, &total);
+#pragma unroll
+    for (int e = 0; e < SCAN_E; e++)
+        if (base + e < ntiles) scan_op<F, OP>(ex, loc[e]).store(totals + 4 * (base + e));
+}
+template <class F, int OP>
+__global__ void k_scan_fix(u64* __restrict__ data, size_t n, int rev, const u64* __restrict__ totals) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || i < SCAN_TILE) return;
+    const size_t pos = rev ? n - 1 - i : i;
+    scan_op<F, OP>(Fe<F>::load(totals + 4 * (i / SCAN_TILE)), Fe<F>::load(data + 4 * pos)).store(data + 4 * pos);
+}
+// elementwise helpers of batch inversion and division by (x - a)
+template <class F>
+__global__ void k_zero_to_one(const u64* __restrict__ v, size_t n, u64* __restrict__ out) {       // zeros are skipped by batch_inversion
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fe<F> x = Fe<F>::load(v + 4 * i);
+    (x.is_zero() ? Fe<F>::one() : x).store(out + 4 * i);
+}
+// v_i^-1 = inv_total * prefix_{i-1} * suffix_{i+1}
+template <class F>
+__global__ void k_batch_inv_finish(u64* __restrict__ v, const u64* __restrict__ pre, const u64* __restrict__ suf, Fe4p inv_total, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (Fe<F>::load(v + 4 * i).is_zero()) return;
+    Fe<F> r = Fe<F>::load(inv_total.l);
+    if (i > 0) r = mul<F>(r, Fe<F>::load(pre + 4 * (i - 1)));
+    if (i + 1 < n) r = mul<F>(r, Fe<F>::load(suf + 4 * (i + 1)));
+    r.store(v + 4 * i);
+}
+// t_k = c_k a^k
+template <class F>
+__global__ void k_scale_powers(const u64* __restrict__ c, Fe4p a, size_t n, size_t shift, u64* __restrict__ out) {
+    const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    mul<F>(Fe<F>::load(c + 4 * k), pow_u64<F>(Fe<F>::load(a.l), k + shift)).store(out + 4 * k);
+}
+// q_i = S_{i+1} a^-(i+1), i < n - 1, from the suffix sums S of c_k a^k
+template <class F>
+__global__ void k_linear_quotient(const u64* __restrict__ S, Fe4p a_inv, size_t n, u64* __restrict__ q) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i + 1 >= n) return;
+    mul<F>(Fe<F>::load(S + 4 * (i + 1)), pow_u64<F>(Fe<F>::load(a_inv.l), i + 1)).store(q + 4 * i);
+}
+
 #define KH_FIELD_DISPATCH(KERNEL, grid, block, stream, ...)                                             \
     do {                                                                                                \
         if (field == KH_FIELD_FP) hipLaunchKernelGGL((KERNEL<FpParams>), grid, block, 0, stream, __VA_ARGS__); \
@@ -151,6 +275,77 @@ int poly_eval_chunks(Context& C, int field, const uint64_t* coeffs_dev, size_t l
 int poly_div_vanishing(Context& C, int field, const uint64_t* f_dev, size_t len, size_t n, uint64_t* q_dev, uint64_t* r_dev) {
     hipStream_t s = C.stream;
     KH_FIELD_DISPATCH(k_div_vanishing, dim3((unsigned)((n + 255) / 256)), dim3(256), s, f_dev, len, n, q_dev, r_dev);
+    KH_HIP(hipStreamSynchronize(s));
+    return KH_OK;
+}
+
+#define KH_SCAN_DISPATCH(KERNEL, grid, block, stream, ...)                                                              \
+    do {                                                                                                                 \
+        if (field == KH_FIELD_FP) { if (op == 0) hipLaunchKernelGGL((KERNEL<FpParams, 0>), grid, block, 0, stream, __VA_ARGS__); \
+                                    else hipLaunchKernelGGL((KERNEL<FpParams, 1>), grid, block, 0, stream, __VA_ARGS__); }          \
+        else { if (op == 0) hipLaunchKernelGGL((KERNEL<FqParams, 0>), grid, block, 0, stream, __VA_ARGS__);                     \
+               else hipLaunchKernelGGL((KERNEL<FqParams, 1>), grid, block, 0, stream, __VA_ARGS__); }                           \
+        KH_HIP(hipGetLastError());                                                                                       \
+    } while (0)
+
+static DevBuf g_scan_tot, g_scan_a, g_scan_b;
+
+static int scan_enqueue(hipStream_t s, int field, int op, int rev, uint64_t* data_dev, size_t n) {
+    if (n == 0) return KH_OK;
+    const size_t ntiles = (n + SCAN_TILE - 1) / SCAN_TILE;
+    KH_REQUIRE(ntiles <= (size_t)SCAN_TILE, "scan of %zu elements: more than %d tiles", n, SCAN_TILE);
+    int rc;
+    if ((rc = g_scan_tot.reserve(ntiles * 32))) return rc;
+    KH_SCAN_DISPATCH(k_scan_tiles, dim3((unsigned)ntiles), dim3(SCAN_T), s, data_dev, n, rev, g_scan_tot.as<u64>());
+    if (ntiles > 1) {
+        KH_SCAN_DISPATCH(k_scan_totals, dim3(1), dim3(SCAN_T), s, g_scan_tot.as<u64>(), ntiles);
+        KH_SCAN_DISPATCH(k_scan_fix, dim3((unsigned)((n + 255) / 256)), dim3(256), s, data_dev, n, rev, (const u64*)g_scan_tot.as<u64>());
+    }
+    return KH_OK;
+}
+int poly_scan(Context& C, int field, int op, int rev, uint64_t* data_dev, size_t n) {
+    int rc = scan_enqueue(C.stream, field, op, rev, data_dev, n); if (rc) return rc;
+    KH_HIP(hipStreamSynchronize(C.stream));
+    return KH_OK;
+}
+// ark_ff::batch_inversion: every non-zero element replaced by its inverse, zeros untouched
+int poly_batch_inversion(Context& C, int field, uint64_t* v_dev, size_t n) {
+    if (n == 0) return KH_OK;
+    int rc;
+    if ((rc = g_scan_a.reserve(n * 32))) return rc;
+    if ((rc = g_scan_b.reserve(n * 32))) return rc;
+    hipStream_t s = C.stream;
+    dim3 g((unsigned)((n + 255) / 256));
+    KH_FIELD_DISPATCH(k_zero_to_one, g, dim3(256), s, (const u64*)v_dev, n, g_scan_a.as<u64>());
+    KH_HIP(hipMemcpyAsync(g_scan_b.p, g_scan_a.p, n * 32, hipMemcpyDeviceToDevice, s));
+    if ((rc = scan_enqueue(s, field, 1, 0, g_scan_a.as<u64>(), n))) return rc;        // prefix products
+    if ((rc = scan_enqueue(s, field, 1, 1, g_scan_b.as<u64>(), n))) return rc;        // suffix products
+    khost::fe total;
+    KH_HIP(hipMemcpyAsync(&total, g_scan_a.as<char>() + (n - 1) * 32, 32, hipMemcpyDeviceToHost, s));
+    KH_HIP(hipStreamSynchronize(s));
+    Fe4p inv; host_field_inverse(field, total.l, inv.l);   // one inversion, on the host (20 us against ~0.2 ms for a lone GPU thread)
+    KH_FIELD_DISPATCH(k_batch_inv_finish, g, dim3(256), s, v_dev, (const u64*)g_scan_a.as<u64>(), (const u64*)g_scan_b.as<u64>(), inv, n);
+    KH_HIP(hipStreamSynchronize(s));
+    return KH_OK;
+}
+// f = q (x - a) + rem, rem = f(a): q_i = a^-(i+1) sum_{k > i} c_k a^k
+int poly_divide_by_linear(Context& C, int field, const uint64_t* f_dev, size_t len, const uint64_t a[4], uint64_t* q_dev, uint64_t rem[4]) {
+    if (len == 0) { memset(rem, 0, 32); return KH_OK; }
+    hipStream_t s = C.stream;
+    if ((a[0] | a[1] | a[2] | a[3]) == 0) {                 // division by x: a shift
+        if (len > 1) KH_HIP(hipMemcpyAsync(q_dev, f_dev + 4, (len - 1) * 32, hipMemcpyDeviceToDevice, s));
+        KH_HIP(hipMemcpyAsync(rem, f_dev, 32, hipMemcpyDeviceToHost, s));
+        KH_HIP(hipStreamSynchronize(s));
+        return KH_OK;
+    }
+    int rc;
+    if ((rc = g_scan_a.reserve(len * 32))) return rc;
+    Fe4p av, ai; memcpy(av.l, a, 32); host_field_inverse(field, a, ai.l);
+    dim3 g((unsigned)((len + 255) / 256));
+    KH_FIELD_DISPATCH(k_scale_powers, g, dim3(256), s, f_dev, av, len, (size_t)0, g_scan_a.as<u64>());
+    if ((rc = scan_enqueue(s, field, 0, 1, g_scan_a.as<u64>(), len))) return rc;      // suffix sums
+    if (len > 1) KH_FIELD_DISPATCH(k_linear_quotient, g, dim3(256), s, (const u64*)g_scan_a.as<u64>(), ai, len, q_dev);
+    KH_HIP(hipMemcpyAsync(rem, g_scan_a.p, 32, hipMemcpyDeviceToHost, s));
     KH_HIP(hipStreamSynchronize(s));
     return KH_OK;
 }

@@ -37,7 +37,7 @@ SYMBOLS = [
     "kh_commit_non_hiding", "kh_commit_evaluations_non_hiding", "kh_srs_set_blinding_base",
     "kh_srs_get_blinding_base", "kh_mask_custom", "kh_domain_generator", "kh_msm_points_batch", "kh_msm_submit", "kh_msm_wait",
     "kh_ipa_fold_scalars", "kh_inner_product", "kh_ipa_fold_points", "kh_ipa_fold_points_endo", "kh_endos", "kh_scalar_challenge_to_field",
-    "kh_polycomm_multi_scalar_mul", "kh_expr_evaluations_dev", "kh_b_poly_coefficients", "kh_batch_dlog_accumulator_generate", "kh_batch_dlog_accumulator_check", "kh_ipa_verify_msm",
+    "kh_polycomm_multi_scalar_mul", "kh_expr_evaluations_dev", "kh_field_scan_dev", "kh_batch_inversion_dev", "kh_divide_by_linear_dev", "kh_b_poly_coefficients", "kh_batch_dlog_accumulator_generate", "kh_batch_dlog_accumulator_check", "kh_ipa_verify_msm",
     "kh_ipa_begin", "kh_ipa_begin_dev", "kh_combine_polys_dev", "kh_b_init_dev", "kh_evaluate_chunks_dev", "kh_divide_by_vanishing_poly_dev", "kh_ipa_rounds_left", "kh_ipa_round_lr", "kh_ipa_round_fold", "kh_ipa_finish", "kh_ipa_free", "kh_points_sum", "kh_srs_create_device", "kh_srs_create_device_range", "kh_srs_get_g",
 ]
 
@@ -63,6 +63,9 @@ _lib.kh_endos.argtypes = [C.c_int, U64P, U64P]
 _lib.kh_scalar_challenge_to_field.argtypes = [C.c_int, U64P, U64P]
 _lib.kh_expr_evaluations_dev.argtypes = [C.c_int, C.POINTER(C.c_uint32), C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_size_t,
                                          U64P, C.c_size_t, C.c_size_t, C.c_uint, C.c_uint, C.c_int, C.c_void_p]
+_lib.kh_field_scan_dev.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
+_lib.kh_batch_inversion_dev.argtypes = [C.c_int, C.c_void_p, C.c_size_t]
+_lib.kh_divide_by_linear_dev.argtypes = [C.c_int, C.c_void_p, C.c_size_t, U64P, C.c_void_p, U64P]
 _lib.kh_polycomm_multi_scalar_mul.argtypes = [C.c_int, U64P, U8P, C.POINTER(C.c_size_t), C.c_size_t, U64P, U64P, U8P, C.POINTER(C.c_size_t)]
 _lib.kh_b_poly_coefficients.argtypes = [C.c_int, U64P, C.c_uint, C.c_size_t, U64P]
 _lib.kh_batch_dlog_accumulator_generate.argtypes = [C.c_void_p, C.c_size_t, U64P, C.c_size_t, U64P, U8P]
@@ -416,18 +419,38 @@ def ipa_fold_points_endo(curve: int, g_lo, g_hi, chal: int):
     return out, inf
 
 
+SCAN_ADD, SCAN_MUL = 0, 1
+
+
+def field_scan_dev(field: int, op: int, buf, n: int, reverse: bool = False, offset: int = 0):
+    """In-place inclusive scan of n elements starting `offset` elements into the DevBuf."""
+    _check(_lib.kh_field_scan_dev(field, op, int(reverse), C.c_void_p(buf.ptr + 32 * offset), n))
+
+
+def batch_inversion_dev(field: int, buf, n: int, offset: int = 0):
+    _check(_lib.kh_batch_inversion_dev(field, C.c_void_p(buf.ptr + 32 * offset), n))
+
+
+def divide_by_linear_dev(field: int, f, length: int, a, q):
+    rem = np.zeros(4, dtype=np.uint64)
+    _check(_lib.kh_divide_by_linear_dev(field, C.c_void_p(f.ptr), length, _p64(_c64(a, (4,))), C.c_void_p(q.ptr if q is not None else 0), _p64(rem)))
+    return rem
+
+
 TOK_CONST, TOK_CELL, TOK_DUP, TOK_POW, TOK_ADD, TOK_MUL, TOK_SUB, TOK_STORE, TOK_LOAD = range(9)
 
 
-def expr_evaluations_dev(field: int, tokens, cols, col_len, constants, rows: int, out, stride: int = 1, next_shift: int = 8, accumulate: bool = False):
-    """tokens: list of (opcode, arg); cols: list of DevBuf; constants: (k, 4) Montgomery limbs; out: DevBuf of `rows` elements."""
+def expr_evaluations_dev(field: int, tokens, cols, col_len, constants, rows: int, out, stride: int = 1, next_shift: int = 8, accumulate: bool = False,
+                         out_offset: int = 0):
+    """tokens: list of (opcode, arg); cols: list of DevBuf; constants: (k, 4) Montgomery limbs; out: DevBuf receiving `rows`
+    elements starting `out_offset` elements in."""
     tk = np.ascontiguousarray(np.array(tokens, dtype=np.uint32).reshape(-1, 2))
     m = len(cols)
     ptrs = (C.c_void_p * max(m, 1))(*[C.c_void_p(c.ptr) for c in cols])
     lens = (C.c_size_t * max(m, 1))(*col_len)
     cs = _c64(constants, (-1, 4))
     _check(_lib.kh_expr_evaluations_dev(field, tk.ctypes.data_as(C.POINTER(C.c_uint32)), tk.shape[0], ptrs, lens, m, _p64(cs), cs.shape[0],
-                                        rows, stride, next_shift, int(accumulate), C.c_void_p(out.ptr)))
+                                        rows, stride, next_shift, int(accumulate), C.c_void_p(out.ptr + 32 * out_offset)))
 
 
 def polycomm_multi_scalar_mul(curve: int, comms, scalars):
