@@ -162,6 +162,10 @@ int kh_scalar_challenge_to_field(int curve, const uint64_t chal[2], uint64_t out
  *   (none if len <= n), r_dev n coefficients. */
 int kh_combine_polys_dev(int field, const uint64_t *const *polys_dev, const size_t *lens, const size_t *num_chunks, size_t m,
                          const uint64_t polyscale[4], size_t srs_length, uint64_t *out_dev, size_t *out_len);
+/* out[i] = sum_j scalars[j] * poly_j[i], i < out_len (lens[j] <= out_len): the linearisation / ft polynomial of
+ * kimchi/src/prover.rs:1180-1260 (f = sum of evaluated-constant x column polynomial terms, minus Z_H(zeta) t). */
+int kh_poly_lincomb_dev(int field, const uint64_t *const *polys_dev, const size_t *lens, const uint64_t *scalars, size_t m,
+                        uint64_t *out_dev, size_t out_len);
 int kh_b_init_dev(int field, const uint64_t *elm, size_t k, const uint64_t evalscale[4], size_t padded_len, uint64_t *out_dev);
 int kh_evaluate_chunks_dev(int field, const uint64_t *coeffs_dev, size_t len, size_t chunk_size, size_t num_chunks,
                            const uint64_t *points, size_t npts, uint64_t *out);

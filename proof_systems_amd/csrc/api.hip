@@ -569,6 +569,16 @@ int kh_combine_polys_dev(int field, const uint64_t* const* polys_dev, const size
     if (out_len) *out_len = longest;
     return KH_OK;
 }
+int kh_poly_lincomb_dev(int field, const uint64_t* const* polys_dev, const size_t* lens, const uint64_t* scalars, size_t m,
+                        uint64_t* out_dev, size_t out_len) {
+    KH_REQUIRE(field == KH_FIELD_FP || field == KH_FIELD_FQ, "unknown field id %d", field);
+    KH_REQUIRE((out_dev || out_len == 0) && (m == 0 || (polys_dev && lens && scalars)), "kh_poly_lincomb_dev: null argument");
+    for (size_t i = 0; i < m; i++) KH_REQUIRE(lens[i] <= out_len, "polynomial %zu has %zu coefficients, the output %zu", i, lens[i], out_len);
+    int rc = ensure_init(); if (rc) return rc;
+    Context& C = ctx();
+    std::lock_guard<std::mutex> lk(C.mu);
+    return poly_lincomb(C, field, polys_dev, lens, scalars, m, out_dev, out_len);
+}
 int kh_b_init_dev(int field, const uint64_t* elm, size_t k, const uint64_t evalscale[4], size_t padded_len, uint64_t* out_dev) {
     KH_REQUIRE(field == KH_FIELD_FP || field == KH_FIELD_FQ, "unknown field id %d", field);
     KH_REQUIRE(out_dev && evalscale && (elm || k == 0), "kh_b_init_dev: null argument");

@@ -38,7 +38,7 @@ SYMBOLS = [
     "kh_srs_get_blinding_base", "kh_mask_custom", "kh_domain_generator", "kh_msm_points_batch", "kh_msm_submit", "kh_msm_wait",
     "kh_ipa_fold_scalars", "kh_inner_product", "kh_ipa_fold_points", "kh_ipa_fold_points_endo", "kh_endos", "kh_scalar_challenge_to_field",
     "kh_polycomm_multi_scalar_mul", "kh_expr_evaluations_dev", "kh_field_scan_dev", "kh_batch_inversion_dev", "kh_divide_by_linear_dev", "kh_b_poly_coefficients", "kh_batch_dlog_accumulator_generate", "kh_batch_dlog_accumulator_check", "kh_ipa_verify_msm",
-    "kh_ipa_begin", "kh_ipa_begin_dev", "kh_combine_polys_dev", "kh_b_init_dev", "kh_evaluate_chunks_dev", "kh_divide_by_vanishing_poly_dev", "kh_ipa_rounds_left", "kh_ipa_round_lr", "kh_ipa_round_fold", "kh_ipa_finish", "kh_ipa_free", "kh_points_sum", "kh_srs_create_device", "kh_srs_create_device_range", "kh_srs_get_g",
+    "kh_ipa_begin", "kh_ipa_begin_dev", "kh_combine_polys_dev", "kh_poly_lincomb_dev", "kh_b_init_dev", "kh_evaluate_chunks_dev", "kh_divide_by_vanishing_poly_dev", "kh_ipa_rounds_left", "kh_ipa_round_lr", "kh_ipa_round_fold", "kh_ipa_finish", "kh_ipa_free", "kh_points_sum", "kh_srs_create_device", "kh_srs_create_device_range", "kh_srs_get_g",
 ]
 
 _lib.kh_last_error.restype = C.c_char_p
@@ -75,6 +75,7 @@ _lib.kh_ipa_begin.argtypes = [C.c_void_p, U64P, C.c_size_t, U64P, C.c_size_t, U6
 _lib.kh_ipa_begin_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, U64P, C.POINTER(C.c_void_p)]
 _lib.kh_combine_polys_dev.argtypes = [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.c_size_t, U64P, C.c_size_t,
                                       C.c_void_p, C.POINTER(C.c_size_t)]
+_lib.kh_poly_lincomb_dev.argtypes = [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), U64P, C.c_size_t, C.c_void_p, C.c_size_t]
 _lib.kh_b_init_dev.argtypes = [C.c_int, U64P, C.c_size_t, U64P, C.c_size_t, C.c_void_p]
 _lib.kh_evaluate_chunks_dev.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, U64P, C.c_size_t, U64P]
 _lib.kh_divide_by_vanishing_poly_dev.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_uint, C.c_void_p, C.c_void_p]
@@ -477,6 +478,13 @@ def combine_polys_dev(field: int, polys, lens, num_chunks, polyscale, srs_length
     ol = C.c_size_t(0)
     _check(_lib.kh_combine_polys_dev(field, ptrs, ls, cs, m, _p64(_c64(polyscale, (4,))), srs_length, C.c_void_p(out.ptr), C.byref(ol)))
     return ol.value
+
+
+def poly_lincomb_dev(field: int, polys, lens, scalars, out, out_len: int):
+    m = len(polys)
+    ptrs = (C.c_void_p * max(m, 1))(*[C.c_void_p(p.ptr) for p in polys])
+    ls = (C.c_size_t * max(m, 1))(*lens)
+    _check(_lib.kh_poly_lincomb_dev(field, ptrs, ls, _p64(_c64(scalars, (-1, 4))), m, C.c_void_p(out.ptr), out_len))
 
 
 def b_init_dev(field: int, elm, evalscale, padded_len: int, out):

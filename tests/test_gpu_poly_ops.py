@@ -118,3 +118,22 @@ def test_divide_by_vanishing_poly(khip, fid, F):
     assert _ints(F, qd.download((5 * n, 4))) == q0 and not rd.download((n, 4)).any()
     for d in (fd, qd, rd):
         d.free()
+
+
+def test_poly_lincomb(khip):
+    F = P.Fp; rnd = np.random.default_rng(111)
+    lens = [100, 37, 0, 100, 1]
+    polys = [_rand(rnd, F, ln) for ln in lens]
+    sc = _rand(rnd, F, len(lens))
+    bufs = [khip.DevBuf(max(ln, 1) * 32) for ln in lens]
+    for b, p in zip(bufs, polys):
+        if p:
+            b.upload(_limbs(F, p))
+    out = khip.DevBuf(120 * 32)
+    khip.poly_lincomb_dev(0, bufs, lens, _limbs(F, sc), out, 120)
+    want = [sum(s * p[i] for s, p in zip(sc, polys) if i < len(p)) % F.p for i in range(120)]
+    assert _ints(F, out.download((120, 4))) == want
+    with pytest.raises(khip.KhError):
+        khip.poly_lincomb_dev(0, bufs, lens, _limbs(F, sc), out, 50)
+    for b in bufs + [out]:
+        b.free()
