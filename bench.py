@@ -46,7 +46,9 @@ def oplist_replay(khip, g16, srs16, reps=2):
     """SURVEY 3.1 totals at n = 2^16 (bench circuit): 15 Lagrange-basis commits (witness),
     1 + 7 monomial commits (z, t), the 16 opening rounds (L/R MSMs, a/b folds, challenge tensor; the basis
     fold is replaced by MSMs over the resident tables) + sg, 19 iNTT(n), 16 LDE(n->8n),
-    iNTT(4n), iNTT(8n).  Device-resident inputs; returns seconds per replay (best of reps)."""
+    iNTT(4n), iNTT(8n); plus the vector steps between them on the device (z accumulator, generic-gate and permutation
+    constraint rows on d4 / d8, division by Z_H and the boundary quotients, chunked evaluations at two points, ft and
+    opening input combinations).  Device-resident synthetic inputs; returns seconds per replay (best of reps)."""
     n = 1 << 16
     rng = np.random.default_rng(2024)
     F_R = np.array([0x34786d38fffffffd, 0x992c350be41914ad, 0xffffffffffffffff, 0x3fffffffffffffff], dtype=np.uint64)
@@ -64,6 +66,40 @@ def oplist_replay(khip, g16, srs16, reps=2):
     ipa_a = rand_scalars(rng, n); ipa_b = rand_scalars(rng, n); ipa_rand = rand_scalars(rng, 2)
     ipa_chals = [int.from_bytes(rng.bytes(16), "little") for _ in range(16)]
     u_base = khip.srs_generate(0, 1 << 21, 1)[0]
+    # ---- the vector steps around the hot path (timing only: random columns; parity lives in tests/test_gpu_{expr,permutation,poly_ops}.py)
+    import proof_systems_amd.polish as OP               # token streams of the generic gate / permutation constraints
+    fid = khip.FP
+    d1 = [khip.DevBuf(n * 32).upload(rand_scalars(rng, n)) for _ in range(15)]             # w0..6, sigma0..6, sid
+    one = np.tile(F_R, (1, 1))
+    num = khip.DevBuf(n * 32); den = khip.DevBuf(n * 32); ratio = khip.DevBuf(n * 32)
+    k17 = rand_scalars(rng, 17)
+    cell = OP.cell
+    num_t, den_t = OP.perm_aggreg_tokens()
+    d8cols = [khip.DevBuf(8 * n * 32).upload(rand_scalars(rng, 8 * n)) for _ in range(17)]
+    gen_t = OP.generic_gate_tokens(0, 6, 16, 0, 1)
+    perm_t = OP.perm_quot_tokens(w0=0, s0=7, z=14, x=15, zkpm=16, gamma=0, beta=1, bshift0=3, alpha0=2)
+    t4 = khip.DevBuf(4 * n * 32); t8 = khip.DevBuf(8 * n * 32); tq = khip.DevBuf(7 * n * 32); tr = khip.DevBuf(n * 32); bq = khip.DevBuf(n * 32)
+    polys = [khip.DevBuf(n * 32).upload(rand_scalars(rng, n)) for _ in range(44)] + [tq]      # ~45 polynomials enter the opening (prover.rs:1272-1477)
+    plens = [n] * 44 + [7 * n]; pchunks = [1] * 44 + [7]
+    pts2 = rand_scalars(rng, 2); sc45 = rand_scalars(rng, 45)
+    a_dev = khip.DevBuf(n * 32); b_dev = khip.DevBuf(n * 32); ft = khip.DevBuf(n * 32)
+
+    def vector_steps():
+        khip.expr_evaluations_dev(fid, num_t, d1, [n] * 15, k17, n - 1, num, out_offset=1)        # perm_aggreg (permutation.rs:447-577)
+        khip.expr_evaluations_dev(fid, den_t, d1, [n] * 15, k17, n - 1, den, out_offset=1)
+        khip.batch_inversion_dev(fid, den, n - 1, offset=1)
+        khip.expr_evaluations_dev(fid, [cell(0), cell(1), (OP.TOK_MUL, 0)], [num, den], [n, n], one, n, ratio)
+        khip.field_scan_dev(fid, khip.SCAN_MUL, ratio, n - 2)
+        khip.expr_evaluations_dev(fid, gen_t, d8cols, [8 * n] * 17, k17, 4 * n, t4, stride=2, next_shift=8)    # generic gate on d4 (prover.rs:806-812)
+        khip.expr_evaluations_dev(fid, perm_t, d8cols, [8 * n] * 17, k17, 8 * n, t8, stride=1, next_shift=8)   # perm_quot on d8 (permutation.rs:237-283)
+        khip.divide_by_linear_dev(fid, ratio, n, F_R, bq)                                         # bnd (permutation.rs:291-327)
+        khip.divide_by_linear_dev(fid, ratio, n, k17[3], bq)
+        khip.divide_by_vanishing_poly_dev(fid, t8, 8 * n, 16, tq, tr)                             # prover.rs:903
+        khip.evaluate_chunks_batch_dev(fid, polys, plens, pchunks, n, pts2)                       # evaluations at zeta, zeta*omega (prover.rs:1028-1128)
+        khip.poly_lincomb_dev(fid, polys[:20], [n] * 20, sc45[:20], ft, n)                        # ft (prover.rs:1147-1188)
+        khip.combine_polys_dev(fid, polys, plens, pchunks, k17[0], n, a_dev)                      # SRS::open inputs (ipa.rs:852-888)
+        khip.b_init_dev(fid, pts2, k17[1], n, b_dev)
+
     best = None
     phases = {}
     for _ in range(reps):
@@ -85,10 +121,13 @@ def oplist_replay(khip, g16, srs16, reps=2):
         khip.ntt_dev(khip.FP, d_t4, 18, True, 1)
         khip.ntt_dev(khip.FP, d_t8, 19, True, 1)
         khip.sync()
+        td = time.perf_counter()
+        vector_steps()
+        khip.sync()
         t1 = time.perf_counter()
         if best is None or t1 - t0 < best:
             best = t1 - t0
-            phases = {"commit_msm_s": tb - ta, "ipa_open_s": tc - tb, "ntt_s": t1 - tc}
+            phases = {"commit_msm_s": tb - ta, "ipa_open_s": tc - tb, "ntt_s": td - tc, "vector_steps_s": t1 - td}
     # NTT kernels on their own (HIP events on the library stream): algorithmic bytes of SURVEY 8d
     def dev_ms(fn, reps=5):
         ts = []
@@ -102,7 +141,7 @@ def oplist_replay(khip, g16, srs16, reps=2):
         "intt_2^16_x19": {"ms": t_intt, "algorithmic_GBps": 64.0 * n * 19 / (t_intt * 1e-3) / 1e9, "hbm_frac": 64.0 * n * 19 / (t_intt * 1e-3) / 1e9 / HBM_PEAK_GBS},
         "lde_2^16_to_2^19_x16": {"ms": t_lde, "algorithmic_GBps": 288.0 * n * 16 / (t_lde * 1e-3) / 1e9, "hbm_frac": 288.0 * n * 16 / (t_lde * 1e-3) / 1e9 / HBM_PEAK_GBS},
         "note": "VALU-issue bound like the MSM (about log2(N)/2 + 2 Montgomery products per element), see DESIGN.md section 4"}
-    for b in (d_wit, d_zt, d_cols, d_lde_in, d_lde_out, d_t4, d_t8):
+    for b in [d_wit, d_zt, d_cols, d_lde_in, d_lde_out, d_t4, d_t8, num, den, ratio, t4, t8, tq, tr, bq, a_dev, b_dev, ft] + d1 + d8cols + polys[:44]:
         b.free()
     return best, phases
 
@@ -268,7 +307,7 @@ def main():
         t_op, ph = oplist_replay(khip, g16, srs16)
         line["oplist"] = {"workload": "ProverProof::create op list at 2^16 gates (23 MSM(n) + the 16 opening rounds of SRS::open incl. folds and sg + 19 iNTT(n) + 16 LDE(n->8n) + iNTT(4n) + iNTT(8n))",
                           "seconds": t_op, "constraints_per_s": (1 << 16) / t_op, **ph, "lagrange_basis_index_time_s": t_lag,
-                          "note": "MSM+NTT hot path only; gate evaluation / sponge stay on the host (SURVEY 8d cfg 3)"}
+                          "note": "MSM + NTT + opening rounds + the vector steps between them (z accumulator, generic-gate and permutation rows, divisions, chunked evaluations, combinations) on synthetic columns; sponge, RNG and the closed-form Lagrange evaluations stay on the host (SURVEY 8d cfg 3)"}
 
     if rank == 0:
         print(json.dumps(line))

@@ -169,6 +169,10 @@ int kh_poly_lincomb_dev(int field, const uint64_t *const *polys_dev, const size_
 int kh_b_init_dev(int field, const uint64_t *elm, size_t k, const uint64_t evalscale[4], size_t padded_len, uint64_t *out_dev);
 int kh_evaluate_chunks_dev(int field, const uint64_t *coeffs_dev, size_t len, size_t chunk_size, size_t num_chunks,
                            const uint64_t *points, size_t npts, uint64_t *out);
+/* all polynomials of a proof in one launch: polynomial j has lens[j] coefficients and num_chunks[j] chunks; out receives, polynomial
+ * after polynomial, npts x num_chunks[j] values (out_j[p][c]). */
+int kh_evaluate_chunks_batch_dev(int field, const uint64_t *const *polys_dev, const size_t *lens, const size_t *num_chunks, size_t m,
+                                 size_t chunk_size, const uint64_t *points, size_t npts, uint64_t *out);
 int kh_divide_by_vanishing_poly_dev(int field, const uint64_t *f_dev, size_t len, unsigned log2_n, uint64_t *q_dev, uint64_t *r_dev);
 
 /* ---- constraint expressions over resident columns (first slice) ----

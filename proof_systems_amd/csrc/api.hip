@@ -592,15 +592,25 @@ int kh_b_init_dev(int field, const uint64_t* elm, size_t k, const uint64_t evals
     std::lock_guard<std::mutex> lk(C.mu);
     return poly_b_init(C, field, elm, (const uint64_t*)scales.data(), k, padded_len, out_dev);
 }
-int kh_evaluate_chunks_dev(int field, const uint64_t* coeffs_dev, size_t len, size_t chunk_size, size_t num_chunks,
-                           const uint64_t* points, size_t npts, uint64_t* out) {
+int kh_evaluate_chunks_batch_dev(int field, const uint64_t* const* polys_dev, const size_t* lens, const size_t* num_chunks, size_t m,
+                                 size_t chunk_size, const uint64_t* points, size_t npts, uint64_t* out) {
     KH_REQUIRE(field == KH_FIELD_FP || field == KH_FIELD_FQ, "unknown field id %d", field);
-    KH_REQUIRE(chunk_size > 0 && (coeffs_dev || len == 0) && (points || npts == 0) && (out || npts * num_chunks == 0), "kh_evaluate_chunks_dev: bad argument");
-    KH_REQUIRE((len + chunk_size - 1) / chunk_size <= num_chunks, "%zu coefficients need more than %zu chunks of %zu (assert_eq at utils/src/dense_polynomial.rs:63)", len, num_chunks, chunk_size);
+    KH_REQUIRE(chunk_size > 0 && (m == 0 || (polys_dev && lens && num_chunks)) && (points || npts == 0), "kh_evaluate_chunks_batch_dev: bad argument");
+    size_t total = 0;
+    for (size_t j = 0; j < m; j++) {
+        KH_REQUIRE(polys_dev[j] || lens[j] == 0, "polynomial %zu: null pointer", j);
+        KH_REQUIRE((lens[j] + chunk_size - 1) / chunk_size <= num_chunks[j], "polynomial %zu: %zu coefficients need more than %zu chunks of %zu (assert_eq at utils/src/dense_polynomial.rs:63)", j, lens[j], num_chunks[j], chunk_size);
+        total += num_chunks[j];
+    }
+    KH_REQUIRE(out || total * npts == 0, "null output");
     int rc = ensure_init(); if (rc) return rc;
     Context& C = ctx();
     std::lock_guard<std::mutex> lk(C.mu);
-    return poly_eval_chunks(C, field, coeffs_dev, len, chunk_size, num_chunks, points, npts, out);
+    return poly_eval_chunks(C, field, polys_dev, lens, num_chunks, m, chunk_size, points, npts, out);
+}
+int kh_evaluate_chunks_dev(int field, const uint64_t* coeffs_dev, size_t len, size_t chunk_size, size_t num_chunks,
+                           const uint64_t* points, size_t npts, uint64_t* out) {
+    return kh_evaluate_chunks_batch_dev(field, &coeffs_dev, &len, &num_chunks, 1, chunk_size, points, npts, out);
 }
 int kh_divide_by_vanishing_poly_dev(int field, const uint64_t* f_dev, size_t len, unsigned log2_n, uint64_t* q_dev, uint64_t* r_dev) {
     KH_REQUIRE(field == KH_FIELD_FP || field == KH_FIELD_FQ, "unknown field id %d", field);

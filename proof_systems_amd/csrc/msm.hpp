@@ -39,7 +39,8 @@ int bpoly_run(hipStream_t s, int field, const uint64_t* chals_dev, unsigned roun
 // poly.hip
 int poly_lincomb(Context& C, int field, const uint64_t* const* segs_dev, const size_t* lens, const uint64_t* scales, size_t m, uint64_t* out_dev, size_t out_len);
 int poly_b_init(Context& C, int field, const uint64_t* elm, const uint64_t* scales, size_t k, size_t n, uint64_t* out_dev);
-int poly_eval_chunks(Context& C, int field, const uint64_t* coeffs_dev, size_t len, size_t chunk, size_t num_chunks, const uint64_t* points, size_t npts, uint64_t* out);
+int poly_eval_chunks(Context& C, int field, const uint64_t* const* polys_dev, const size_t* lens, const size_t* num_chunks, size_t m, size_t chunk,
+                     const uint64_t* points, size_t npts, uint64_t* out);
 int poly_div_vanishing(Context& C, int field, const uint64_t* f_dev, size_t len, size_t n, uint64_t* q_dev, uint64_t* r_dev);
 int poly_scan(Context& C, int field, int op, int rev, uint64_t* data_dev, size_t n);
 int poly_batch_inversion(Context& C, int field, uint64_t* v_dev, size_t n);

@@ -42,13 +42,16 @@ __global__ void k_b_init(const u64* __restrict__ elm, const u64* __restrict__ sc
     acc.store(out + 4 * j);
 }
 // one block per (chunk, point): sum_{j < len} c[j] x^j with thread t running Horner over j = t, t+T, ... in y = x^T
+// (T = 1024: 64 steps for a 2^16-coefficient chunk), then x^t and a block tree.  The chunk table (pointer, length,
+// output slot) lets one launch cover every polynomial of a proof.
+struct ChunkDesc { const u64* ptr; u64 len; u64 out; u64 pstride; };   // result slot = out + point * pstride
 template <class F>
-__global__ void __launch_bounds__(256)
-k_eval_chunks(const u64* __restrict__ coeffs, size_t total_len, size_t chunk, const u64* __restrict__ points, u64* __restrict__ out) {
-    __shared__ u32 sh[256 * 8];
-    const size_t c = blockIdx.x, p = blockIdx.y;
-    const size_t base = c * chunk;
-    const size_t len = base >= total_len ? 0 : (total_len - base < chunk ? total_len - base : chunk);
+__global__ void __launch_bounds__(1024)
+k_eval_chunks(const ChunkDesc* __restrict__ tab, const u64* __restrict__ points, u64* __restrict__ out) {
+    __shared__ u32 sh[1024 * 8];
+    const ChunkDesc d = tab[blockIdx.x];
+    const size_t p = blockIdx.y;
+    const size_t len = d.len;
     const Fe<F> x = Fe<F>::load(points + 4 * p);
     const u32 T = blockDim.x, t = threadIdx.x;
     Fe<F> acc = Fe<F>::zero();
@@ -56,26 +59,26 @@ k_eval_chunks(const u64* __restrict__ coeffs, size_t total_len, size_t chunk, co
         const Fe<F> y = pow_u64<F>(x, T);
         size_t last = t + ((len - 1 - t) / T) * T;           // highest index of this thread's residue class
         for (size_t j = last;; j -= T) {
-            acc = add<F>(mul<F>(acc, y), Fe<F>::load(coeffs + 4 * (base + j)));
+            acc = add<F>(mul<F>(acc, y), Fe<F>::load(d.ptr + 4 * j));
             if (j < T) break;
         }
         acc = mul<F>(acc, pow_u64<F>(x, t));
     }
 #pragma unroll
-    for (int k = 0; k < 8; k++) sh[k * 256 + t] = acc.v[k];
+    for (int k = 0; k < 8; k++) sh[k * 1024 + t] = acc.v[k];
     __syncthreads();
-    for (int s = 128; s >= 1; s >>= 1) {
+    for (int s = 512; s >= 1; s >>= 1) {
         if ((int)t < s) {
             Fe<F> o;
 #pragma unroll
-            for (int k = 0; k < 8; k++) o.v[k] = sh[k * 256 + t + s];
+            for (int k = 0; k < 8; k++) o.v[k] = sh[k * 1024 + t + s];
             acc = add<F>(acc, o);
 #pragma unroll
-            for (int k = 0; k < 8; k++) sh[k * 256 + t] = acc.v[k];
+            for (int k = 0; k < 8; k++) sh[k * 1024 + t] = acc.v[k];
         }
         __syncthreads();
     }
-    if (t == 0) acc.store(out + 4 * (p * gridDim.x + c));
+    if (t == 0) acc.store(out + 4 * (d.out + p * d.pstride));
 }
 // f = q (x^n - 1) + r:  q[i] = sum_{k >= 1} f[i + k n],  r[i] = sum_{k >= 0} f[i + k n] (i < n).
 // Thread per residue i: suffix sums down the class.
@@ -259,16 +262,30 @@ int poly_b_init(Context& C, int field, const uint64_t* elm, const uint64_t* scal
     KH_HIP(hipStreamSynchronize(s));
     return KH_OK;
 }
-int poly_eval_chunks(Context& C, int field, const uint64_t* coeffs_dev, size_t len, size_t chunk, size_t num_chunks,
+// polynomial j (polys_dev[j], lens[j] coefficients) is cut into num_chunks[j] chunks of `chunk`; out (host) receives, per
+// polynomial in order, npts x num_chunks[j] values: out_j[p][c] = chunk_c(points[p])
+int poly_eval_chunks(Context& C, int field, const uint64_t* const* polys_dev, const size_t* lens, const size_t* num_chunks, size_t m, size_t chunk,
                      const uint64_t* points, size_t npts, uint64_t* out) {
-    if (num_chunks == 0 || npts == 0) return KH_OK;
+    std::vector<ChunkDesc> tab;
+    size_t base = 0;
+    for (size_t j = 0; j < m; j++) {
+        for (size_t c = 0; c < num_chunks[j]; c++) {
+            const size_t off = c * chunk;
+            const size_t len = off >= lens[j] ? 0 : std::min(chunk, lens[j] - off);
+            tab.push_back(ChunkDesc{polys_dev[j] + 4 * off, (u64)len, (u64)(base + c), (u64)num_chunks[j]});
+        }
+        base += npts * num_chunks[j];
+    }
+    if (tab.empty() || npts == 0) return KH_OK;
     int rc;
-    if ((rc = g_poly_tab.reserve(npts * 32 + num_chunks * npts * 32 + 64))) return rc;
+    const size_t tab_bytes = tab.size() * sizeof(ChunkDesc);
+    if ((rc = g_poly_tab.reserve(tab_bytes + npts * 32 + base * 32 + 64))) return rc;
     hipStream_t s = C.stream;
-    u64* pts = g_poly_tab.as<u64>(); u64* res = pts + 4 * npts;
+    char* d_tab = g_poly_tab.as<char>(); u64* pts = (u64*)(d_tab + tab_bytes); u64* res = pts + 4 * npts;
+    KH_HIP(hipMemcpyAsync(d_tab, tab.data(), tab_bytes, hipMemcpyHostToDevice, s));
     KH_HIP(hipMemcpyAsync(pts, points, npts * 32, hipMemcpyHostToDevice, s));
-    KH_FIELD_DISPATCH(k_eval_chunks, dim3((unsigned)num_chunks, (unsigned)npts), dim3(256), s, coeffs_dev, len, chunk, (const u64*)pts, res);
-    KH_HIP(hipMemcpyAsync(out, res, num_chunks * npts * 32, hipMemcpyDeviceToHost, s));
+    KH_FIELD_DISPATCH(k_eval_chunks, dim3((unsigned)tab.size(), (unsigned)npts), dim3(1024), s, (const ChunkDesc*)d_tab, (const u64*)pts, res);
+    KH_HIP(hipMemcpyAsync(out, res, base * 32, hipMemcpyDeviceToHost, s));
     KH_HIP(hipStreamSynchronize(s));
     return KH_OK;
 }

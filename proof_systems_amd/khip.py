@@ -38,7 +38,7 @@ SYMBOLS = [
     "kh_srs_get_blinding_base", "kh_mask_custom", "kh_domain_generator", "kh_msm_points_batch", "kh_msm_submit", "kh_msm_wait",
     "kh_ipa_fold_scalars", "kh_inner_product", "kh_ipa_fold_points", "kh_ipa_fold_points_endo", "kh_endos", "kh_scalar_challenge_to_field",
     "kh_polycomm_multi_scalar_mul", "kh_expr_evaluations_dev", "kh_field_scan_dev", "kh_batch_inversion_dev", "kh_divide_by_linear_dev", "kh_b_poly_coefficients", "kh_batch_dlog_accumulator_generate", "kh_batch_dlog_accumulator_check", "kh_ipa_verify_msm",
-    "kh_ipa_begin", "kh_ipa_begin_dev", "kh_combine_polys_dev", "kh_poly_lincomb_dev", "kh_b_init_dev", "kh_evaluate_chunks_dev", "kh_divide_by_vanishing_poly_dev", "kh_ipa_rounds_left", "kh_ipa_round_lr", "kh_ipa_round_fold", "kh_ipa_finish", "kh_ipa_free", "kh_points_sum", "kh_srs_create_device", "kh_srs_create_device_range", "kh_srs_get_g",
+    "kh_ipa_begin", "kh_ipa_begin_dev", "kh_combine_polys_dev", "kh_poly_lincomb_dev", "kh_b_init_dev", "kh_evaluate_chunks_dev", "kh_evaluate_chunks_batch_dev", "kh_divide_by_vanishing_poly_dev", "kh_ipa_rounds_left", "kh_ipa_round_lr", "kh_ipa_round_fold", "kh_ipa_finish", "kh_ipa_free", "kh_points_sum", "kh_srs_create_device", "kh_srs_create_device_range", "kh_srs_get_g",
 ]
 
 _lib.kh_last_error.restype = C.c_char_p
@@ -78,6 +78,8 @@ _lib.kh_combine_polys_dev.argtypes = [C.c_int, C.POINTER(C.c_void_p), C.POINTER(
 _lib.kh_poly_lincomb_dev.argtypes = [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), U64P, C.c_size_t, C.c_void_p, C.c_size_t]
 _lib.kh_b_init_dev.argtypes = [C.c_int, U64P, C.c_size_t, U64P, C.c_size_t, C.c_void_p]
 _lib.kh_evaluate_chunks_dev.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, U64P, C.c_size_t, U64P]
+_lib.kh_evaluate_chunks_batch_dev.argtypes = [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.c_size_t, C.c_size_t,
+                                              U64P, C.c_size_t, U64P]
 _lib.kh_divide_by_vanishing_poly_dev.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_uint, C.c_void_p, C.c_void_p]
 _lib.kh_ipa_rounds_left.argtypes = [C.c_void_p]
 _lib.kh_ipa_round_lr.argtypes = [C.c_void_p, U64P, U64P, U64P, U8P]
@@ -497,6 +499,19 @@ def evaluate_chunks_dev(field: int, coeffs, length: int, chunk_size: int, num_ch
     out = np.zeros((pts.shape[0], num_chunks, 4), dtype=np.uint64)
     _check(_lib.kh_evaluate_chunks_dev(field, C.c_void_p(coeffs.ptr), length, chunk_size, num_chunks, _p64(pts), pts.shape[0], _p64(out)))
     return out
+
+
+def evaluate_chunks_batch_dev(field: int, polys, lens, num_chunks, chunk_size: int, points):
+    """Returns a list of (npts, num_chunks[j], 4) arrays, one per polynomial."""
+    pts = _c64(points, (-1, 4)); m = len(polys)
+    ptrs = (C.c_void_p * max(m, 1))(*[C.c_void_p(p.ptr) for p in polys])
+    ls = (C.c_size_t * max(m, 1))(*lens); cs = (C.c_size_t * max(m, 1))(*num_chunks)
+    out = np.zeros((pts.shape[0] * sum(num_chunks), 4), dtype=np.uint64)
+    _check(_lib.kh_evaluate_chunks_batch_dev(field, ptrs, ls, cs, m, chunk_size, _p64(pts), pts.shape[0], _p64(out)))
+    res, pos = [], 0
+    for c in num_chunks:
+        res.append(out[pos:pos + pts.shape[0] * c].reshape(pts.shape[0], c, 4)); pos += pts.shape[0] * c
+    return res
 
 
 def divide_by_vanishing_poly_dev(field: int, f, length: int, log2_n: int, q, r):

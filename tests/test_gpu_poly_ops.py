@@ -137,3 +137,23 @@ def test_poly_lincomb(khip):
         khip.poly_lincomb_dev(0, bufs, lens, _limbs(F, sc), out, 50)
     for b in bufs + [out]:
         b.free()
+
+
+def test_evaluate_chunks_batch(khip):
+    """All polynomials of a proof in one launch: same values as one call per polynomial (prover.rs:1028-1128)."""
+    F = P.Fp; rnd = np.random.default_rng(121)
+    shapes = [(500, 4), (128, 1), (0, 1), (300, 3), (1, 1)]
+    polys = [_rand(rnd, F, ln) for ln, _ in shapes]
+    bufs = []
+    for p in polys:
+        b = khip.DevBuf(max(len(p), 1) * 32)
+        if p:
+            b.upload(_limbs(F, p))
+        bufs.append(b)
+    pts = _rand(rnd, F, 2)
+    got = khip.evaluate_chunks_batch_dev(0, bufs, [ln for ln, _ in shapes], [c for _, c in shapes], 128, _limbs(F, pts))
+    for j, (b, (ln, c)) in enumerate(zip(bufs, shapes)):
+        one = khip.evaluate_chunks_dev(0, b, ln, 128, c, _limbs(F, pts))
+        assert np.array_equal(got[j], one)
+    for b in bufs:
+        b.free()

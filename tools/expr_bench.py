@@ -4,7 +4,7 @@ import sys, time
 import numpy as np
 sys.path.insert(0, '.')
 from proof_systems_amd import khip
-from oracle import pasta as P
+import proof_systems_amd.polish as P
 khip.init(0)
 rows = 1 << 19
 rng = np.random.default_rng(3)
