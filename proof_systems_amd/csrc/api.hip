@@ -71,6 +71,9 @@ struct kh_srs {
     size_t g_stride = 0;      // (the two extra bases of the opening rounds, written by kh_ipa_begin)
     int g_precomp_c = 0;
     bool ipa_live = false;    // the U slot belongs to one opening at a time
+    // workspace of the opening rounds, kept across openings (hipMalloc / hipFree cost ~0.1 ms each: 1 ms per proof)
+    DevBuf ipa_a[2], ipa_b[2], ipa_coef[2], ipa_sc, ipa_partial;
+    hipEvent_t ipa_ev = nullptr;
     uint64_t h[8];
     std::map<unsigned, std::vector<std::unique_ptr<LagrangeChunk>>> lagrange;
     std::mutex mu;
@@ -171,6 +174,9 @@ void kh_srs_free(kh_srs_t* srs) {
     Context& C = ctx();
     std::lock_guard<std::mutex> lk(C.mu);
     if (srs->g.p) (void)hipFree(srs->g.p);
+    for (int i = 0; i < 2; i++) { srs->ipa_a[i].release(); srs->ipa_b[i].release(); srs->ipa_coef[i].release(); }
+    srs->ipa_sc.release(); srs->ipa_partial.release();
+    if (srs->ipa_ev) (void)hipEventDestroy(srs->ipa_ev);
     for (auto& kv : srs->lagrange)
         for (auto& ch : kv.second)
             if (ch) { if (ch->pts.p) (void)hipFree(ch->pts.p); if (ch->inf.p) (void)hipFree(ch->inf.p); }
@@ -775,15 +781,11 @@ struct kh_ipa {
     kh_srs_t* srs = nullptr;
     int curve = 0, field = 0;
     size_t n = 0, cur = 0, ncoef = 1;     // basis size, current vector length N_j, challenge tensor length 2^j
-    DevBuf a[2], b[2], coef[2], sc, partial;
+    DevBuf *a = nullptr, *b = nullptr, *coef = nullptr;   // the SRS handle's workspace (ping-pong pairs)
+    DevBuf sc, partial;                                   // views of srs->ipa_sc / ipa_partial
     int pp = 0;
     hipEvent_t ev = nullptr;              // orders the fold (library stream) before the next round's MSM (slot stream)
     bool lr_done = false;
-    ~kh_ipa() {
-        for (int i = 0; i < 2; i++) { a[i].release(); b[i].release(); coef[i].release(); }
-        sc.release(); partial.release();
-        if (ev) (void)hipEventDestroy(ev);
-    }
 };
 
 static int ipa_begin_common(kh_srs_t* srs, const uint64_t* a, size_t a_len, const uint64_t* b, size_t b_len, const uint64_t u_base_xy[8], kh_ipa_t** out,
@@ -800,13 +802,14 @@ static int ipa_begin_common(kh_srs_t* srs, const uint64_t* a, size_t a_len, cons
     std::unique_ptr<kh_ipa> st(new kh_ipa);
     st->srs = srs; st->curve = srs->curve; st->field = khost::scalar_field_id(srs->curve); st->n = n; st->cur = n;
     for (int i = 0; i < 2; i++) {
-        if ((rc = st->a[i].reserve(n * 32))) return rc;
-        if ((rc = st->b[i].reserve(n * 32))) return rc;
-        if ((rc = st->coef[i].reserve(n * 32))) return rc;
+        if ((rc = srs->ipa_a[i].reserve(n * 32))) return rc;
+        if ((rc = srs->ipa_b[i].reserve(n * 32))) return rc;
+        if ((rc = srs->ipa_coef[i].reserve(n * 32))) return rc;
     }
-    if ((rc = st->sc.reserve(2 * (n + 2) * 32))) return rc;
-    if ((rc = st->partial.reserve(2 * 64 * 32))) return rc;
-    KH_HIP(hipEventCreateWithFlags(&st->ev, hipEventDisableTiming));
+    if ((rc = srs->ipa_sc.reserve(2 * (n + 2) * 32))) return rc;
+    if ((rc = srs->ipa_partial.reserve(2 * 64 * 32))) return rc;
+    if (!srs->ipa_ev) KH_HIP(hipEventCreateWithFlags(&srs->ipa_ev, hipEventDisableTiming));
+    st->a = srs->ipa_a; st->b = srs->ipa_b; st->coef = srs->ipa_coef; st->sc = srs->ipa_sc; st->partial = srs->ipa_partial; st->ev = srs->ipa_ev;
     // H and U into the two extra slots of every window table
     const int W = srs->g_precomp_c ? (256 + srs->g_precomp_c - 1) / srs->g_precomp_c : 1;
     std::vector<uint64_t> tab((size_t)W * 16), col((size_t)W * 8);
@@ -900,7 +903,7 @@ void kh_ipa_free(kh_ipa_t* st) {
     if (!st) return;
     Context& C = ctx();
     std::lock_guard<std::mutex> lk(C.mu);
-    (void)hipDeviceSynchronize();
+    (void)hipStreamSynchronize(C.stream);                 // a fold may still be in flight on the library stream
     if (st->srs) st->srs->ipa_live = false;
     delete st;
 }

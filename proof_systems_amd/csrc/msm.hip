@@ -206,15 +206,15 @@ static constexpr u32 MAX_K = 256;           // upper bound of the task length (l
 // K (entries per task) is chosen HERE from the actual number of entries off[nkeys]: zero digits
 // produce no entry, and the reference's own benchmark witness is almost all ones (one non-zero
 // digit per scalar) -- sizing K from the n*W upper bound left the chip 5 % occupied on it.
-__device__ __forceinline__ u32 pick_K(u32 total, u32 room) {
+__device__ __forceinline__ u32 pick_K(u32 total, u32 room, u32 kmin) {
     u32 K = (total + room - 1) / room;
-    return K < 8 ? 8u : (K > MAX_K ? MAX_K : K);
+    return K < kmin ? kmin : (K > MAX_K ? MAX_K : K);
 }
-__global__ void k_ntask(const u32* __restrict__ off, size_t nkeys, u32 room, u32* __restrict__ nt, u32* __restrict__ len_hist) {
+__global__ void k_ntask(const u32* __restrict__ off, size_t nkeys, u32 room, u32 kmin, u32* __restrict__ nt, u32* __restrict__ len_hist) {
     __shared__ u32 h[MAX_K + 1];
     for (u32 i = threadIdx.x; i <= MAX_K; i += blockDim.x) h[i] = 0;
     __syncthreads();
-    const u32 K = pick_K(off[nkeys], room);
+    const u32 K = pick_K(off[nkeys], room, kmin);
     size_t key = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (key <= nkeys) {
         u32 n_t = 0;
@@ -564,7 +564,8 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
     size_t room_sz = cap / 4;                              // many buckets: about one task per bucket anyway
     if (nkeys < cap / 2) room_sz = cap - cap / 16 - nkeys / 2;   // ~ half of the buckets add a remainder task
     const u32 room = (u32)room_sz;                          // K = clamp(ceil(entries / room), 8, MAX_K), on the device
-    const size_t max_tasks = M / 8 + nkeys + 1;             // bound for the smallest K
+    static const u32 kmin = getenv("KH_KMIN") ? (u32)atoi(getenv("KH_KMIN")) : 8u;
+    const size_t max_tasks = M / kmin + nkeys + 1;          // bound for the smallest K
     KH_REQUIRE(M < ((size_t)1 << 31) && (tab_stride * (size_t)(precomp ? W : 1) + basis.batch_stride * k) < ((size_t)1 << 31), "MSM too large for 31-bit entry indices (n=%zu k=%zu)", n, k);
 
     int rc;
@@ -635,7 +636,7 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
     u32* rnt = order + (nkeys + 2);
     u32* roff = rnt + (nkeys + 2);
     KH_HIP(hipMemsetAsync(len_hist, 0, (MAX_K + 1) * sizeof(u32), s));
-    hipLaunchKernelGGL(k_ntask, dim3((unsigned)((nkeys + 1 + 255) / 256)), dim3(256), 0, s, C.ws_off.as<u32>(), nkeys, room, C.ws_ntask.as<u32>(), len_hist);
+    hipLaunchKernelGGL(k_ntask, dim3((unsigned)((nkeys + 1 + 255) / 256)), dim3(256), 0, s, C.ws_off.as<u32>(), nkeys, room, kmin, C.ws_ntask.as<u32>(), len_hist);
     if ((rc = exclusive_scan_u32(C.ws_ntask.as<u32>(), C.ws_toff.as<u32>(), nkeys + 1, C.ws_scan_tmp, s))) return rc;
     static const int rank_min_log = getenv("KH_RANK_MIN_LOG") ? atoi(getenv("KH_RANK_MIN_LOG")) : 22;   // below ~4M entries the three extra launches cost more than the ordering saves
     if (M >= ((size_t)1 << rank_min_log)) {
