@@ -857,7 +857,7 @@ int kh_ipa_round_lr(kh_ipa_t* st, const uint64_t rand_l[4], const uint64_t rand_
     if (rc) return rc;
     kh_srs_t* srs = st->srs;
     MsmBasis bs; bs.pts = srs->g.p; bs.inf = nullptr; bs.n = srs->g_stride; bs.stride = srs->g_stride; bs.precomp_c = srs->g_precomp_c;
-    if ((rc = msm_enqueue(C, S, st->curve, bs, 0, st->sc.as<uint64_t>(), st->n + 2, 2, 1))) return rc;
+    if ((rc = msm_enqueue(C, S, st->curve, bs, 0, st->sc.as<uint64_t>(), st->n + 2, 2, 1, /*use_graph=*/1))) return rc;
     if ((rc = msm_finish(C, S, lr_xy, lr_inf))) return rc;
     st->lr_done = true;
     return KH_OK;

@@ -87,6 +87,13 @@ struct MsmSlot {
     uint64_t ticket = 0;
     int curve = 0, W = 0, c = 0, precomp = 0, planes = 0, plane_shift[2] = {0, 0};
     size_t k = 0, ngroups = 0;
+    // hipGraph of one MSM's launch sequence (the opening rounds repeat the same MSM -- same basis, scalar buffer, sizes --
+    // 16 times: ~22 launches per round replayed as one graph).  Keyed by every pointer and size the launches bake in.
+    hipGraphExec_t gexec = nullptr;
+    uint64_t gkey = 0, gseen = 0;
+    size_t gnout = 0;
+    int g_W = 0, g_c = 0, g_precomp = 0, g_planes = 0, g_shift[2] = {0, 0};
+    size_t g_ngroups = 0;
 };
 static constexpr int MSM_SLOTS = 4;
 

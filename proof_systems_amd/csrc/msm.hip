@@ -536,9 +536,15 @@ int msm_pick_window(size_t n) {
     return c;
 }
 
+struct CaptureGuard {              // never leave a stream in capture mode on an error path
+    hipStream_t s; bool active = false;
+    ~CaptureGuard() { if (active) { hipGraph_t g = nullptr; (void)hipStreamEndCapture(s, &g); if (g) (void)hipGraphDestroy(g); } }
+};
+static inline uint64_t fnv(uint64_t h, uint64_t v) { for (int i = 0; i < 8; i++) { h ^= (v >> (8 * i)) & 0xff; h *= 0x100000001b3ull; } return h; }
+
 template <class CFG>
 static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t offset, const u64* scalars_dev, size_t n, size_t k,
-                         int mont, int curve) {
+                         int mont, int curve, int use_graph) {
     typedef typename CFG::Base BF; typedef typename CFG::Scalar SF;
     hipStream_t s = C.stream;
     const int c = basis.precomp_c ? basis.precomp_c : msm_pick_window(n);
@@ -603,6 +609,50 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
     const size_t nout = planes ? ngroups * planes : ngroups;
     if ((rc = C.ws_seg.reserve(std::max(ngroups * (size_t)(nseg + nblk1), nout * (size_t)32) * 128))) return rc;
     if ((rc = C.ws_out.reserve(nout * 128))) return rc;
+    if (C.pinned_cap < nout * 128) {                     // host staging of the group sums; the host part runs in msm_finish
+        if (C.pinned) (void)hipHostFree(C.pinned);
+        C.pinned = nullptr; C.pinned_cap = 0;
+        KH_HIP(hipHostMalloc(&C.pinned, nout * 128 + 4096, hipHostMallocDefault));
+        C.pinned_cap = nout * 128 + 4096;
+    }
+    static bool attr_set = false;
+    if (!attr_set) {
+        KH_HIP(hipFuncSetAttribute((const void*)k_hist, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+        KH_HIP(hipFuncSetAttribute((const void*)k_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+        attr_set = true;
+    }
+    // hipGraph replay / capture (opt-in by the caller; the key covers everything the launches bake in)
+    static const bool graphs_off = getenv("KH_NO_GRAPH") != nullptr;
+    uint64_t key = 0;
+    CaptureGuard gcap{s};
+    const bool timers_were = C.timer.enabled;
+    if (use_graph && !graphs_off) {
+        key = 0xcbf29ce484222325ull;
+        const uint64_t parts[] = {(uint64_t)(uintptr_t)basis.pts, (uint64_t)(uintptr_t)basis.inf, basis.n, basis.stride, basis.batch_stride, (uint64_t)basis.precomp_c,
+                                  offset, (uint64_t)(uintptr_t)scalars_dev, n, k, (uint64_t)mont, (uint64_t)curve, (uint64_t)(uintptr_t)C.pinned,
+                                  (uint64_t)(uintptr_t)C.ws_digits.p, (uint64_t)(uintptr_t)C.ws_hist.p, (uint64_t)(uintptr_t)C.ws_cnt.p, (uint64_t)(uintptr_t)C.ws_off.p,
+                                  (uint64_t)(uintptr_t)C.ws_ntask.p, (uint64_t)(uintptr_t)C.ws_toff.p, (uint64_t)(uintptr_t)C.ws_entries.p, (uint64_t)(uintptr_t)C.ws_partial.p,
+                                  (uint64_t)(uintptr_t)C.ws_buckets.p, (uint64_t)(uintptr_t)C.ws_seg.p, (uint64_t)(uintptr_t)C.ws_out.p, (uint64_t)(uintptr_t)C.ws_scan_tmp.p,
+                                  (uint64_t)(uintptr_t)C.ws_biglist.p, (uint64_t)(uintptr_t)C.ws_order.p, (uint64_t)(uintptr_t)C.ws_chunks.p};
+        for (uint64_t v : parts) key = fnv(key, v);
+        if (C.gexec && C.gkey == key) {                    // replay
+            KH_HIP(hipGraphLaunch(C.gexec, s));
+            KH_HIP(hipEventRecord(C.done, s));
+            C.busy = true; C.ticket = Ctx.next_ticket++;
+            C.curve = curve; C.W = C.g_W; C.c = C.g_c; C.precomp = C.g_precomp; C.k = k; C.ngroups = C.g_ngroups; C.planes = C.g_planes;
+            C.plane_shift[0] = C.g_shift[0]; C.plane_shift[1] = C.g_shift[1];
+            C.timer.n = 0;                                 // no per-phase events inside a graph
+            return KH_OK;
+        }
+        if (C.gseen == key) {                              // second time: every workspace is sized, capture this one
+            if (C.gexec) { (void)hipGraphExecDestroy(C.gexec); C.gexec = nullptr; }
+            C.timer.enabled = false;
+            if (hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed) == hipSuccess) gcap.active = true;
+            else { (void)hipGetLastError(); C.timer.enabled = timers_were; }
+        } else {
+            C.gseen = key;
+        }
+    }
 
     C.timer.begin(s);
     // 1 digits
@@ -611,12 +661,6 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
     C.timer.mark("digits", s);
     // 2 histogram
     size_t lds = (size_t)nb * sizeof(u32);
-    static bool attr_set = false;
-    if (!attr_set) {
-        KH_HIP(hipFuncSetAttribute((const void*)k_hist, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
-        KH_HIP(hipFuncSetAttribute((const void*)k_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
-        attr_set = true;
-    }
     dim3 sgrid((unsigned)S, (unsigned)W, (unsigned)k);
     hipLaunchKernelGGL(k_hist, sgrid, dim3(1024), lds, s, C.ws_digits.as<int32_t>(), g, C.ws_hist.as<u32>());
     hipLaunchKernelGGL(k_key_totals, dim3((unsigned)((nkeys + 1 + 255) / 256)), dim3(256), 0, s,
@@ -679,28 +723,35 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
     }
     C.timer.mark("reduce", s);
     KH_HIP(hipGetLastError());
-    // group sums -> pinned host staging; the host part runs in msm_finish
-    if (C.pinned_cap < nout * 128) {
-        if (C.pinned) (void)hipHostFree(C.pinned);
-        C.pinned = nullptr; C.pinned_cap = 0;
-        KH_HIP(hipHostMalloc(&C.pinned, nout * 128 + 4096, hipHostMallocDefault));
-        C.pinned_cap = nout * 128 + 4096;
-    }
+    // group sums -> pinned host staging
     KH_HIP(hipMemcpyAsync(C.pinned, C.ws_out.p, nout * 128, hipMemcpyDeviceToHost, s));
+    if (gcap.active) {
+        hipGraph_t g = nullptr;
+        gcap.active = false;
+        C.timer.enabled = timers_were; C.timer.n = 0;
+        hipError_t e = hipStreamEndCapture(s, &g);
+        if (e == hipSuccess && g) e = hipGraphInstantiate(&C.gexec, g, nullptr, nullptr, 0);
+        if (g) (void)hipGraphDestroy(g);
+        if (e != hipSuccess) { C.gexec = nullptr; set_error("hipGraph capture of the MSM launch sequence failed: %s", hipGetErrorString(e)); return KH_E_DEVICE; }
+        C.gkey = key; C.gnout = nout;
+        C.g_W = W; C.g_c = c; C.g_precomp = precomp; C.g_planes = (int)planes; C.g_shift[0] = (int)mg.wd[0]; C.g_shift[1] = (int)mg.wd[1]; C.g_ngroups = ngroups;
+        KH_HIP(hipGraphLaunch(C.gexec, s));
+    }
     KH_HIP(hipEventRecord(C.done, s));
     C.busy = true; C.ticket = Ctx.next_ticket++;
     C.curve = curve; C.W = W; C.c = c; C.precomp = precomp; C.k = k; C.ngroups = ngroups; C.planes = (int)planes; C.plane_shift[0] = (int)mg.wd[0]; C.plane_shift[1] = (int)mg.wd[1];
     return KH_OK;
 }
 
-int msm_enqueue(Context& C, MsmSlot& S, int curve, const MsmBasis& basis, size_t offset, const uint64_t* scalars_dev, size_t n, size_t k, int mont) {
+int msm_enqueue(Context& C, MsmSlot& S, int curve, const MsmBasis& basis, size_t offset, const uint64_t* scalars_dev, size_t n, size_t k, int mont,
+                int use_graph) {
     if (n == 0 || k == 0) {          // nothing to launch: finish() emits k identities
         S.busy = true; S.ticket = C.next_ticket++; S.curve = curve; S.k = k; S.ngroups = 0; S.W = 0; S.c = 0; S.precomp = 1; S.planes = 0;
         KH_HIP(hipEventRecord(S.done, S.stream));
         return KH_OK;
     }
-    if (curve == KH_CURVE_VESTA) return msm_enqueue_t<VestaCfg>(C, S, basis, offset, scalars_dev, n, k, mont, curve);
-    return msm_enqueue_t<PallasCfg>(C, S, basis, offset, scalars_dev, n, k, mont, curve);
+    if (curve == KH_CURVE_VESTA) return msm_enqueue_t<VestaCfg>(C, S, basis, offset, scalars_dev, n, k, mont, curve, use_graph);
+    return msm_enqueue_t<PallasCfg>(C, S, basis, offset, scalars_dev, n, k, mont, curve, use_graph);
 }
 
 // 8 finish on the host: wait for the slot, Horner over the window sums (plain path), XYZZ -> affine

@@ -20,7 +20,10 @@ int msm_precompute(Context& C, int curve, void* tables, const uint8_t* inf, size
 static constexpr int MSM_PRECOMP_C = 16;          // window width of the precomputed tables
 static constexpr size_t MSM_PRECOMP_MIN_N = 1024; // smaller bases keep the plain per-window path
 // enqueue all device work of k MSMs on slot S (returns immediately); msm_finish waits for it and does the host part
-int msm_enqueue(Context& C, MsmSlot& S, int curve, const MsmBasis& basis, size_t offset, const uint64_t* scalars_dev, size_t n, size_t k, int mont);
+// use_graph: the caller repeats this exact MSM (same buffers and sizes): from the second call on the launch sequence is
+// captured once into a hipGraph and replayed
+int msm_enqueue(Context& C, MsmSlot& S, int curve, const MsmBasis& basis, size_t offset, const uint64_t* scalars_dev, size_t n, size_t k, int mont,
+                int use_graph = 0);
 int msm_finish(Context& C, MsmSlot& S, uint64_t* out_xy, uint8_t* out_inf);
 int debug_field_op(Context& C, int field, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
 int debug_point_op(Context& C, int curve, int op, const uint64_t* p, const uint8_t* pinf, const uint64_t* q, const uint8_t* qinf, uint8_t* out, size_t n);
