@@ -266,13 +266,22 @@ static int free_slot(Context& C) {
     for (int i = 0; i < MSM_SLOTS; i++) if (!C.slot[i].busy) return i;
     return -1;
 }
+// a synchronous entry point may wait for a slot that another thread is blocked on (it will be released); slots held by
+// un-waited kh_msm_submit tickets never free up by themselves, so with only those busy the answer is still -1
+static int acquire_slot(std::unique_lock<std::mutex>* lk, Context& C) {
+    for (;;) {
+        int si = free_slot(C);
+        if (si >= 0 || !lk || C.sync_inflight == 0) return si;
+        C.cv.wait(*lk);
+    }
+}
 // enqueue on a free slot; returns the slot index through *slot_out
 static int msm_submit_locked(Context& C, kh_srs_t* srs, int basis, unsigned chunk, size_t offset, const uint64_t* scalars,
-                             bool scalars_on_device, size_t n, size_t k, int mont, int* slot_out) {
+                             bool scalars_on_device, size_t n, size_t k, int mont, int* slot_out, std::unique_lock<std::mutex>* lk = nullptr) {
     MsmBasis b; int rc = resolve_basis(srs, basis, chunk, b); if (rc) return rc;
     KH_REQUIRE(offset <= b.n, "offset %zu beyond basis length %zu", offset, b.n);
     size_t use = n < b.n - offset ? n : b.n - offset;      // msm_bigint semantics: min(len) pairs
-    int si = free_slot(C);
+    int si = acquire_slot(lk, C);
     KH_REQUIRE(si >= 0, "all %d MSM pipeline slots hold an un-waited job (kh_msm_wait first)", MSM_SLOTS);
     MsmSlot& S = C.slot[si];
     const uint64_t* sdev = scalars;
@@ -290,16 +299,32 @@ static int msm_submit_locked(Context& C, kh_srs_t* srs, int basis, unsigned chun
     *slot_out = si;
     return KH_OK;
 }
+// The GPU wait happens WITHOUT the library lock: the slot stays busy (nobody else can take it), other threads can
+// enqueue on the remaining slots meanwhile (15 rayon workers call into the reference's SRS at once, prover.rs:329-351;
+// two provers can run their opening rounds side by side).  The short host part runs under the lock again.
+static int wait_then_finish(std::unique_lock<std::mutex>& lk, Context& C, MsmSlot& S, uint64_t* out_xy, uint8_t* out_inf) {
+    hipEvent_t ev = S.done;
+    C.sync_inflight++;
+    lk.unlock();
+    hipError_t e = hipEventSynchronize(ev);
+    lk.lock();
+    C.sync_inflight--;
+    int rc;
+    if (e != hipSuccess) { set_error("hipEventSynchronize: %s", hipGetErrorString(e)); S.busy = false; rc = KH_E_DEVICE; }
+    else rc = msm_finish(C, S, out_xy, out_inf);
+    C.cv.notify_all();
+    return rc;
+}
 static int msm_common(kh_srs_t* srs, int basis, unsigned chunk, size_t offset, const uint64_t* scalars, bool scalars_on_device,
                       size_t n, size_t k, int mont, uint64_t* out_xy, uint8_t* out_inf) {
     KH_REQUIRE(out_xy && out_inf, "null output pointer");
     KH_REQUIRE(scalars || n == 0 || k == 0, "null scalars");
     int rc = ensure_init(); if (rc) return rc;
     Context& C = ctx();
-    std::lock_guard<std::mutex> lk(C.mu);
+    std::unique_lock<std::mutex> lk(C.mu);
     int si = -1;
-    if ((rc = msm_submit_locked(C, srs, basis, chunk, offset, scalars, scalars_on_device, n, k, mont, &si))) return rc;
-    return msm_finish(C, C.slot[si], out_xy, out_inf);
+    if ((rc = msm_submit_locked(C, srs, basis, chunk, offset, scalars, scalars_on_device, n, k, mont, &si, &lk))) return rc;
+    return wait_then_finish(lk, C, C.slot[si], out_xy, out_inf);
 }
 
 int kh_msm_submit(kh_srs_t* srs, int basis, unsigned chunk, size_t offset, const uint64_t* scalars_dev, size_t n, size_t k,
@@ -318,9 +343,9 @@ int kh_msm_wait(uint64_t ticket, uint64_t* out_xy, uint8_t* out_is_inf) {
     KH_REQUIRE(out_xy && out_is_inf, "null output pointer");
     int rc = ensure_init(); if (rc) return rc;
     Context& C = ctx();
-    std::lock_guard<std::mutex> lk(C.mu);
+    std::unique_lock<std::mutex> lk(C.mu);
     for (int i = 0; i < MSM_SLOTS; i++)
-        if (C.slot[i].busy && C.slot[i].ticket == ticket) return msm_finish(C, C.slot[i], out_xy, out_is_inf);
+        if (C.slot[i].busy && C.slot[i].ticket == ticket) return wait_then_finish(lk, C, C.slot[i], out_xy, out_is_inf);
     set_error("unknown or already waited MSM ticket %llu", (unsigned long long)ticket);
     return KH_E_INVALID;
 }
@@ -344,10 +369,10 @@ int kh_msm_points_batch(int curve, const uint64_t* xy, const uint8_t* inf, const
     KH_REQUIRE((xy && scalars) || n == 0 || k == 0, "null input");
     int rc = ensure_init(); if (rc) return rc;
     Context& C = ctx();
-    std::lock_guard<std::mutex> lk(C.mu);
+    std::unique_lock<std::mutex> lk(C.mu);
     if (n == 0 || k == 0) { for (size_t j = 0; j < k; j++) { memset(out_xy + 8 * j, 0, 64); out_is_inf[j] = 1; } return KH_OK; }
     const size_t tot = n * k;
-    int si = free_slot(C);
+    int si = acquire_slot(&lk, C);
     KH_REQUIRE(si >= 0, "all %d MSM pipeline slots hold an un-waited job (kh_msm_wait first)", MSM_SLOTS);
     MsmSlot& S = C.slot[si];
     if ((rc = S.ws_points.reserve(tot * 64 + tot))) return rc;
@@ -360,7 +385,7 @@ int kh_msm_points_batch(int curve, const uint64_t* xy, const uint8_t* inf, const
     }
     KH_HIP(hipMemcpyAsync(S.ws_scalars.p, scalars, tot * 32, hipMemcpyHostToDevice, S.stream));
     if ((rc = msm_enqueue(C, S, curve, b, 0, S.ws_scalars.as<uint64_t>(), n, k, scalars_are_montgomery))) return rc;
-    return msm_finish(C, S, out_xy, out_is_inf);
+    return wait_then_finish(lk, C, S, out_xy, out_is_inf);
 }
 int kh_msm_points(int curve, const uint64_t* xy, const uint8_t* inf, const uint64_t* scalars, size_t n,
                   int scalars_are_montgomery, uint64_t out_xy[8], uint8_t* out_is_inf) {
@@ -846,8 +871,8 @@ int kh_ipa_round_lr(kh_ipa_t* st, const uint64_t rand_l[4], const uint64_t rand_
     KH_REQUIRE(st->cur > 1, "no round left: the vectors are folded to length 1");
     KH_REQUIRE(!st->lr_done, "kh_ipa_round_fold must follow kh_ipa_round_lr");
     Context& C = ctx();
-    std::lock_guard<std::mutex> lk(C.mu);
-    int si = free_slot(C);
+    std::unique_lock<std::mutex> lk(C.mu);
+    int si = acquire_slot(&lk, C);
     KH_REQUIRE(si >= 0, "all %d MSM pipeline slots hold an un-waited job (kh_msm_wait first)", MSM_SLOTS);
     MsmSlot& S = C.slot[si];
     KH_HIP(hipStreamWaitEvent(S.stream, st->ev, 0));
@@ -858,7 +883,7 @@ int kh_ipa_round_lr(kh_ipa_t* st, const uint64_t rand_l[4], const uint64_t rand_
     kh_srs_t* srs = st->srs;
     MsmBasis bs; bs.pts = srs->g.p; bs.inf = nullptr; bs.n = srs->g_stride; bs.stride = srs->g_stride; bs.precomp_c = srs->g_precomp_c;
     if ((rc = msm_enqueue(C, S, st->curve, bs, 0, st->sc.as<uint64_t>(), st->n + 2, 2, 1, /*use_graph=*/1))) return rc;
-    if ((rc = msm_finish(C, S, lr_xy, lr_inf))) return rc;
+    if ((rc = wait_then_finish(lk, C, S, lr_xy, lr_inf))) return rc;
     st->lr_done = true;
     return KH_OK;
 }
@@ -885,8 +910,8 @@ int kh_ipa_finish(kh_ipa_t* st, uint64_t a0[4], uint64_t b0[4], uint64_t sg_xy[8
     KH_REQUIRE(st && a0 && b0 && sg_xy && sg_inf, "kh_ipa_finish: null argument");
     KH_REQUIRE(st->cur == 1, "%d rounds still to run", kh_ipa_rounds_left(st));
     Context& C = ctx();
-    std::lock_guard<std::mutex> lk(C.mu);
-    int si = free_slot(C);
+    std::unique_lock<std::mutex> lk(C.mu);
+    int si = acquire_slot(&lk, C);
     KH_REQUIRE(si >= 0, "all %d MSM pipeline slots hold an un-waited job (kh_msm_wait first)", MSM_SLOTS);
     MsmSlot& S = C.slot[si];
     KH_HIP(hipStreamWaitEvent(S.stream, st->ev, 0));
@@ -897,7 +922,7 @@ int kh_ipa_finish(kh_ipa_t* st, uint64_t a0[4], uint64_t b0[4], uint64_t sg_xy[8
     MsmBasis bs; bs.pts = srs->g.p; bs.inf = nullptr; bs.n = srs->n; bs.stride = srs->g_stride; bs.precomp_c = srs->g_precomp_c;
     int rc;
     if ((rc = msm_enqueue(C, S, st->curve, bs, 0, st->coef[p].as<uint64_t>(), st->n, 1, 1))) return rc;   // sg = <coef, G>
-    return msm_finish(C, S, sg_xy, sg_inf);
+    return wait_then_finish(lk, C, S, sg_xy, sg_inf);
 }
 void kh_ipa_free(kh_ipa_t* st) {
     if (!st) return;

@@ -5,6 +5,7 @@
 #include <stdarg.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <condition_variable>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -98,7 +99,9 @@ struct MsmSlot {
 static constexpr int MSM_SLOTS = 4;
 
 struct Context {
-    std::mutex mu;            // serialises device work issued through the C ABI
+    std::mutex mu;            // serialises the host side of the C ABI (GPU waits happen outside it)
+    std::condition_variable cv;        // a synchronous caller that finds every slot busy waits here for one to finish
+    int sync_inflight = 0;             // slots some thread is currently blocked on (they WILL free up)
     int device = -1;
     bool ready = false;
     hipStream_t stream = nullptr;      // = slot[0].stream: the library's main stream

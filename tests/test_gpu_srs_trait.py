@@ -351,6 +351,42 @@ def test_ipa_opening_rounds_match_oracle(khip, cid, logn):
     srs.close()
 
 
+def test_two_openings_side_by_side(khip):
+    """Two provers on two SRS handles run their opening rounds from two host threads at once (the library lock is
+    released while a round's MSM runs): same L, R, a0, b0, sg as when run alone."""
+    import threading
+    cid = 0; c = P.CURVES[cid]; F = c.scalar
+    logn = 10; n = 1 << logn
+    rnd = np.random.default_rng(2024)
+    ri = lambda: int.from_bytes(rnd.bytes(40), "little") % F.p
+    jobs = []
+    for t in range(2):
+        srs = khip.Srs.create(cid, n, start=t * n)
+        U_l = khip.srs_generate(cid, (1 << 20) + t, 1)[0]
+        a_l = _limbs(F, [ri() for _ in range(n)]); b_l = _limbs(F, [ri() for _ in range(n)])
+        rands = [(_limbs(F, [ri()])[0], _limbs(F, [ri()])[0]) for _ in range(logn)]
+        chals = [int.from_bytes(rnd.bytes(16), "little") for _ in range(logn)]
+        jobs.append((srs, a_l, b_l, U_l, rands, chals))
+    alone = [_run_opening(khip, *j[:1], cid, *j[1:]) for j in jobs]
+    res = [None, None]
+
+    def work(t):
+        j = jobs[t]
+        for _ in range(3):
+            res[t] = _run_opening(khip, j[0], cid, *j[1:])
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for t in range(2):
+        lr0, us0, a0, b0, sg0, i0 = alone[t]; lr1, us1, a1, b1, sg1, i1 = res[t]
+        assert all(np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1]) for x, y in zip(lr0, lr1))
+        assert np.array_equal(a0, a1) and np.array_equal(b0, b1) and np.array_equal(sg0, sg1) and i0 == i1
+        jobs[t][0].close()
+
+
 def test_ipa_opening_protocol_errors(khip):
     """Misuse is reported, not undefined: two openings on one SRS, fold before L/R, finish with rounds left,
     a non power-of-two SRS, a b vector of the wrong length."""
