@@ -47,6 +47,8 @@ def test_random_programs_match_oracle(khip, fid, F):
         # a lone constant, Pow(0) and Pow(1)
         ([(T.TOK_CONST, 4), (T.TOK_POW, 0), cell(4), (T.TOK_POW, 1), (T.TOK_ADD, 0)], 1, 3),
         ([(T.TOK_CONST, 5)], 1, 8),
+        # 24 operands on the stack before the first operation: 96 KB of LDS (above the 64 KB default limit)
+        ([cell(k % 4, k & 1) for k in range(24)] + [(T.TOK_MUL if k % 3 == 0 else T.TOK_ADD, 0) for k in range(23)], 1, 8),
     ]
     bufs = [khip.DevBuf(len(c) * 32).upload(_limbs(F, c)) for c in cols]
     out = khip.DevBuf(rows * 32)
@@ -62,6 +64,9 @@ def test_random_programs_match_oracle(khip, fid, F):
     b = P.polish_evaluate_rows(F, programs[0][0], cols, consts, rows, 2, 8)
     assert _ints(F, out.download((rows, 4))) == [(x + y) % F.p for x, y in zip(a, b)]
     # malformed programs are rejected before launch
+    too_deep = [cell(0)] * 45 + [(T.TOK_ADD, 0)] * 44      # 45 stack slots = 180 KB: more LDS than a CU has
+    with pytest.raises(khip.KhError):
+        khip.expr_evaluations_dev(fid, too_deep, bufs, [len(c) for c in cols], _limbs(F, consts), rows, out)
     for bad in ([(T.TOK_ADD, 0)], [cell(0), cell(1)], [cell(0), (T.TOK_LOAD, 0)], [cell(9)], [(T.TOK_CONST, 99)], [(42, 0)]):
         with pytest.raises(khip.KhError):
             khip.expr_evaluations_dev(fid, bad, bufs, [len(c) for c in cols], _limbs(F, consts), rows, out)
