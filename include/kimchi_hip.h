@@ -310,7 +310,12 @@ int kh_lde(int field, const uint64_t *coeffs, unsigned log2_n, unsigned log2_blo
 /* ---- device-resident variants (no PCIe in the loop) -----------------------
  * Same operations on buffers that already live in HBM (hipMalloc'd by the caller or by
  * kh_dev_alloc).  These are what the benchmark times ("inputs already resident in HBM")
- * and what a prover that keeps witness columns on the device would call. */
+ * and what a prover that keeps witness columns on the device would call.
+ * Ordering: kh_ntt_dev / kh_lde_dev return as soon as their kernels are queued on the library's main stream; every
+ * other entry point that consumes a device buffer either runs on that same stream or waits for it on the device
+ * (MSMs on another pipeline slot's stream wait for an event recorded on the main stream), so a producer followed by a
+ * consumer needs no kh_sync in between.  Host-visible results (points, evaluations) are complete when the call
+ * returns; kh_sync() is only needed before the HOST reads a device buffer through its own means. */
 int kh_dev_alloc(void **ptr, size_t bytes);
 int kh_dev_free(void *ptr);
 int kh_dev_upload(void *dst_dev, const void *src_host, size_t bytes);

@@ -40,6 +40,7 @@ static int do_init(int device_id) {
         int rc2 = C.slot[i].timer.init(); if (rc2) return rc2;
     }
     C.stream = C.slot[0].stream;
+    KH_HIP(hipEventCreateWithFlags(&C.order_ev, hipEventDisableTiming));
     hipDeviceProp_t prop;
     KH_HIP(hipGetDeviceProperties(&prop, device_id));
     C.num_cus = prop.multiProcessorCount;
@@ -293,6 +294,10 @@ static int msm_submit_locked(Context& C, kh_srs_t* srs, int basis, unsigned chun
         sdev = S.ws_scalars.as<uint64_t>();
     } else if (scalars_on_device) {
         KH_REQUIRE(use == n || k == 1, "device-resident batched scalars must not exceed the basis window");
+        if (S.stream != C.stream) {     // the scalars may be the output of kh_ntt_dev / kh_lde_dev / a vector step still running on the main stream
+            KH_HIP(hipEventRecord(C.order_ev, C.stream));
+            KH_HIP(hipStreamWaitEvent(S.stream, C.order_ev, 0));
+        }
     }
     rc = msm_enqueue(C, S, srs->curve, b, offset, sdev, use, k, mont);
     if (rc) return rc;

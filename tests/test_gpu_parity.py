@@ -296,6 +296,29 @@ def test_msm_submit_wait_pipeline(khip):
     srs.close()
 
 
+def test_device_producer_then_msm_on_another_slot(khip):
+    """An MSM whose device-resident scalars are still being produced on the library's main stream (kh_ntt_dev is
+    asynchronous) must wait for them even when it runs on another pipeline slot's stream: slot 0 (= the main stream) is
+    kept busy by an un-waited submit, the iNTT queues behind it, the commitment of its output lands on slot 1."""
+    rng = np.random.default_rng(99)
+    logn = 16; n = 1 << logn
+    srs = khip.Srs.create(0, n)
+    big = khip.DevBuf(n * 32).upload(rand_fe_fast(rng, n))
+    x = rand_fe_fast(rng, n)
+    want_coeffs = khip.ntt(0, x, logn, True)[0]
+    want, winf = srs.msm(want_coeffs)
+    for _ in range(3):
+        col = khip.DevBuf(n * 32).upload(x)
+        ticket = srs.msm_submit(big.ptr, n, 1)            # occupies slot 0 and its stream
+        khip.ntt_dev(0, col, logn, True, 1)               # queued on the same stream, returns immediately
+        got, ginf = srs.msm_batch_dev(col.ptr, n, 1)      # slot 1: must see the iNTT output
+        srs.msm_wait(ticket)
+        assert bool(ginf[0]) == bool(winf) and np.array_equal(got[0], want)
+        col.free()
+    big.free()
+    srs.close()
+
+
 def test_concurrent_callers(khip):
     """The SRS is Sync + Send and is called from 15 rayon workers at once (kimchi/src/prover.rs:329-351):
     concurrent kh_msm / kh_ntt calls from several host threads give the single-threaded results."""
