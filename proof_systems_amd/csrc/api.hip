@@ -1010,13 +1010,18 @@ int kh_dev_alloc(void** ptr, size_t bytes) {
     return KH_OK;
 }
 int kh_dev_free(void* ptr) { if (ptr) KH_HIP(hipFree(ptr)); return KH_OK; }
+// The library's streams are non-blocking (they do not synchronise with the null stream hipMemcpy uses), so both copies
+// first wait for the main stream: an asynchronous kh_ntt_dev / kh_lde_dev on this buffer is complete before it is read
+// or overwritten.
 int kh_dev_upload(void* dst_dev, const void* src_host, size_t bytes) {
     int rc = ensure_init(); if (rc) return rc;
+    KH_HIP(hipStreamSynchronize(ctx().stream));
     KH_HIP(hipMemcpy(dst_dev, src_host, bytes, hipMemcpyHostToDevice));
     return KH_OK;
 }
 int kh_dev_download(void* dst_host, const void* src_dev, size_t bytes) {
     int rc = ensure_init(); if (rc) return rc;
+    KH_HIP(hipStreamSynchronize(ctx().stream));
     KH_HIP(hipMemcpy(dst_host, src_dev, bytes, hipMemcpyDeviceToHost));
     return KH_OK;
 }
