@@ -336,6 +336,11 @@ int kh_msm_wait(uint64_t ticket, uint64_t *out_xy /* host, k x 8 */, uint8_t *ou
 int kh_ntt_dev(int field, uint64_t *data_dev, unsigned log2_n, int inverse, size_t batch);
 int kh_lde_dev(int field, const uint64_t *coeffs_dev, unsigned log2_n, unsigned log2_blowup,
                uint64_t *out_dev, size_t batch);
+/* One coset of an extension: out[r][i] = f_r(shift * w_n^i), i < n = 2^log2_n, for `batch` coefficient vectors (out may
+ * alias coeffs).  The d8 extension of kh_lde_dev is 8 such cosets interleaved, lde[8 i + r] = coset_r[i] with
+ * shift = w_{8n}^r: with one coset per GPU every later row-wise step of the quotient (expressions, z(x w) = the next row
+ * of the same coset) stays local to a GPU.  Asynchronous on the main stream like kh_ntt_dev. */
+int kh_coset_ntt_dev(int field, const uint64_t *coeffs_dev, unsigned log2_n, const uint64_t shift[4], uint64_t *out_dev, size_t batch);
 int kh_sync(void);
 
 /* ---- instrumentation -------------------------------------------------------

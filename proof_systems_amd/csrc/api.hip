@@ -966,6 +966,16 @@ int kh_lde_dev(int field, const uint64_t* coeffs_dev, unsigned log2_n, unsigned 
     std::lock_guard<std::mutex> lk(C.mu);
     return lde_run(C, field, coeffs_dev, log2_n, log2_blowup, out_dev, batch);
 }
+int kh_coset_ntt_dev(int field, const uint64_t* coeffs_dev, unsigned log2_n, const uint64_t shift[4], uint64_t* out_dev, size_t batch) {
+    KH_REQUIRE(field == KH_FIELD_FP || field == KH_FIELD_FQ, "unknown field id %d", field);
+    KH_REQUIRE(log2_n <= 28 && shift, "kh_coset_ntt_dev: bad argument");
+    KH_REQUIRE((coeffs_dev && out_dev) || batch == 0, "null data");
+    int rc = ensure_init(); if (rc) return rc;
+    if (batch == 0) return KH_OK;
+    Context& C = ctx();
+    std::lock_guard<std::mutex> lk(C.mu);
+    return poly_coset_ntt(C, field, coeffs_dev, log2_n, shift, out_dev, batch);
+}
 int kh_ntt(int field, uint64_t* data, unsigned log2_n, int inverse, size_t batch) {
     KH_REQUIRE(field == KH_FIELD_FP || field == KH_FIELD_FQ, "unknown field id %d", field);
     KH_REQUIRE(log2_n <= 28, "log2_n = %u too large", log2_n);

@@ -45,6 +45,7 @@ int poly_b_init(Context& C, int field, const uint64_t* elm, const uint64_t* scal
 int poly_eval_chunks(Context& C, int field, const uint64_t* const* polys_dev, const size_t* lens, const size_t* num_chunks, size_t m, size_t chunk,
                      const uint64_t* points, size_t npts, uint64_t* out);
 int poly_div_vanishing(Context& C, int field, const uint64_t* f_dev, size_t len, size_t n, uint64_t* q_dev, uint64_t* r_dev);
+int poly_coset_ntt(Context& C, int field, const uint64_t* coeffs_dev, unsigned log2_n, const uint64_t shift[4], uint64_t* out_dev, size_t batch);
 int poly_scan(Context& C, int field, int op, int rev, uint64_t* data_dev, size_t n);
 int poly_batch_inversion(Context& C, int field, uint64_t* v_dev, size_t n);
 int poly_divide_by_linear(Context& C, int field, const uint64_t* f_dev, size_t len, const uint64_t a[4], uint64_t* q_dev, uint64_t rem[4]);

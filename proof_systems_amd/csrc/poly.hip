@@ -213,6 +213,13 @@ __global__ void k_scale_powers(const u64* __restrict__ c, Fe4p a, size_t n, size
     if (k >= n) return;
     mul<F>(Fe<F>::load(c + 4 * k), pow_u64<F>(Fe<F>::load(a.l), k + shift)).store(out + 4 * k);
 }
+// out[r][j] = in[r][j] * a^j: the coefficient twist of a coset evaluation, f(a w^i) = NTT_n(c_j a^j)[i]
+template <class F>
+__global__ void k_coset_scale(const u64* __restrict__ in, Fe4p a, size_t n, size_t total, u64* __restrict__ out) {
+    const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= total) return;
+    mul<F>(Fe<F>::load(in + 4 * k), pow_u64<F>(Fe<F>::load(a.l), k % n)).store(out + 4 * k);
+}
 // q_i = S_{i+1} a^-(i+1), i < n - 1, from the suffix sums S of c_k a^k
 template <class F>
 __global__ void k_linear_quotient(const u64* __restrict__ S, Fe4p a_inv, size_t n, u64* __restrict__ q) {
@@ -319,6 +326,16 @@ static int scan_enqueue(hipStream_t s, int field, int op, int rev, uint64_t* dat
         KH_SCAN_DISPATCH(k_scan_fix, dim3((unsigned)((n + 255) / 256)), dim3(256), s, data_dev, n, rev, (const u64*)g_scan_tot.as<u64>());
     }
     return KH_OK;
+}
+// evaluations of `batch` polynomials of n = 2^log2_n coefficients on the coset shift * <w_n> (natural order); asynchronous
+// on the main stream like kh_ntt_dev
+int poly_coset_ntt(Context& C, int field, const uint64_t* coeffs_dev, unsigned log2_n, const uint64_t shift[4], uint64_t* out_dev, size_t batch) {
+    const size_t n = (size_t)1 << log2_n, total = n * batch;
+    if (total == 0) return KH_OK;
+    Fe4p a; memcpy(a.l, shift, 32);
+    hipStream_t s = C.stream;
+    KH_FIELD_DISPATCH(k_coset_scale, dim3((unsigned)((total + 255) / 256)), dim3(256), s, coeffs_dev, a, n, total, out_dev);
+    return ntt_run(C, field, out_dev, log2_n, 0, batch);
 }
 int poly_scan(Context& C, int field, int op, int rev, uint64_t* data_dev, size_t n) {
     int rc = scan_enqueue(C.stream, field, op, rev, data_dev, n); if (rc) return rc;

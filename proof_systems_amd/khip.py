@@ -32,7 +32,7 @@ SYMBOLS = [
     "kh_srs_set_lagrange", "kh_srs_compute_lagrange", "kh_srs_get_lagrange", "kh_srs_lagrange_chunks",
     "kh_msm", "kh_msm_batch", "kh_msm_points", "kh_ntt", "kh_lde",
     "kh_dev_alloc", "kh_dev_free", "kh_dev_upload", "kh_dev_download",
-    "kh_msm_batch_dev", "kh_ntt_dev", "kh_lde_dev", "kh_sync", "kh_last_timings",
+    "kh_msm_batch_dev", "kh_ntt_dev", "kh_lde_dev", "kh_coset_ntt_dev", "kh_sync", "kh_last_timings",
     "kh_debug_field_op", "kh_debug_point_op", "kh_srs_generate", "kh_srs_h",
     "kh_commit_non_hiding", "kh_commit_evaluations_non_hiding", "kh_srs_set_blinding_base",
     "kh_srs_get_blinding_base", "kh_mask_custom", "kh_domain_generator", "kh_msm_points_batch", "kh_msm_submit", "kh_msm_wait",
@@ -98,6 +98,7 @@ _lib.kh_ntt.argtypes = [C.c_int, U64P, C.c_uint, C.c_int, C.c_size_t]
 _lib.kh_lde.argtypes = [C.c_int, U64P, C.c_uint, C.c_uint, U64P, C.c_size_t]
 _lib.kh_ntt_dev.argtypes = [C.c_int, C.c_void_p, C.c_uint, C.c_int, C.c_size_t]
 _lib.kh_lde_dev.argtypes = [C.c_int, C.c_void_p, C.c_uint, C.c_uint, C.c_void_p, C.c_size_t]
+_lib.kh_coset_ntt_dev.argtypes = [C.c_int, C.c_void_p, C.c_uint, U64P, C.c_void_p, C.c_size_t]
 _lib.kh_dev_alloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
 _lib.kh_dev_free.argtypes = [C.c_void_p]
 _lib.kh_dev_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
@@ -376,6 +377,10 @@ class DevBuf:
 
 def ntt_dev(field: int, buf: DevBuf, log2_n: int, inverse: bool, batch: int):
     _check(_lib.kh_ntt_dev(field, C.c_void_p(buf.ptr), log2_n, int(inverse), batch))
+
+
+def coset_ntt_dev(field: int, src: DevBuf, log2_n: int, shift, dst: DevBuf, batch: int):
+    _check(_lib.kh_coset_ntt_dev(field, C.c_void_p(src.ptr), log2_n, _p64(_c64(shift, (4,))), C.c_void_p(dst.ptr), batch))
 
 
 def lde_dev(field: int, src: DevBuf, log2_n: int, log2_blowup: int, dst: DevBuf, batch: int):

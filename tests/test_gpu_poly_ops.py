@@ -157,3 +157,23 @@ def test_evaluate_chunks_batch(khip):
         assert np.array_equal(got[j], one)
     for b in bufs:
         b.free()
+
+
+@pytest.mark.parametrize("fid,F", [(0, P.Fp), (1, P.Fq)])
+def test_coset_ntt_is_one_eighth_of_the_lde(khip, fid, F):
+    """The multi-GPU decomposition of the d8 extension: coset r = kh_coset_ntt_dev with shift w_{8n}^r, and
+    lde[8 i + r] = coset_r[i]; a coset's "next row" is its own next element (z(x w) stays inside the coset)."""
+    rnd = np.random.default_rng(131 + fid)
+    logn = 9; n = 1 << logn; batch = 3
+    coeffs = _limbs(F, _rand(rnd, F, batch * n)).reshape(batch, n, 4)
+    want = khip.lde(fid, coeffs, logn, 3)                                  # batch x 8n
+    om8 = F.root_of_unity(logn + 3)
+    src = khip.DevBuf(coeffs.nbytes).upload(coeffs); dst = khip.DevBuf(coeffs.nbytes)
+    for r in range(8):
+        khip.coset_ntt_dev(fid, src, logn, _limbs(F, [pow(om8, r, F.p)])[0], dst, batch)
+        got = dst.download((batch, n, 4))
+        assert np.array_equal(got, want[:, r::8])
+    # in place, and the trivial coset is the plain NTT
+    khip.coset_ntt_dev(fid, src, logn, _limbs(F, [1])[0], src, batch)
+    assert np.array_equal(src.download((batch, n, 4)), khip.ntt(fid, coeffs, logn, False))
+    src.free(); dst.free()
