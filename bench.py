@@ -4,8 +4,10 @@
 Workload at N=1 (BASELINE.json configs[1]): ONE 2^20-point Pippenger MSM over the Vesta SRS
 (bases = SRS::<Vesta>::create(1<<20).g, generated on the device by kh_srs_create_device;
 scalars = uniform 254-bit Fp Montgomery limbs from a fixed-seed PRNG), inputs resident in HBM
-when the timed region starts.  A "step" is one such MSM through the C ABI
-(kh_msm_batch_dev: digits -> sort -> bucket accumulation -> reduction -> host finish).
+when the timed region starts.  A "step" is one such MSM through the C ABI (digits -> sort ->
+bucket accumulation -> reduction -> host finish); the timed loop keeps four of them in flight
+(kh_msm_submit / kh_msm_wait), the warm-up steps are synchronous and give the latency and the
+per-phase HIP-event timings.
 `value` = Mscalar/s (whole job).  For N>1 (one process per GPU, RCCL) rank r owns the bases
 g[r*2^20 .. (r+1)*2^20) of a (N*2^20)-point MSM (point-range sharding): every step
 each rank reduces its slice, the partial sums are all-gathered (N x 72 bytes) and folded on
@@ -17,8 +19,9 @@ Extra objects on the JSON line:
   cpu_baseline  the oracle's C Pippenger (oracle/pasta_ref.c, "port") on this box's host cores,
                 same bases and scalars, on rank 0 at N=1; its result also cross-checks the
                 GPU result bit-for-bit at full size
-  oplist        (N=1) the MSM+NTT op list of ProverProof::create at 2^16 gates (SURVEY 3.1,
-                BASELINE config 3) replayed through the C ABI -> constraints/s of the hot path
+  oplist        (N=1) the op list of ProverProof::create at 2^16 gates (SURVEY 3.1, BASELINE
+                config 3) replayed through the C ABI on synthetic columns: commitments, the opening
+                rounds, NTTs and the vector steps between them -> constraints/s of the device side
 """
 import argparse
 import json
