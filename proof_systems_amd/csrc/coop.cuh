@@ -1,0 +1,85 @@
+// coop.cuh -- XYZZ addition by four cooperating lanes ("quad"), for the latency-bound tree phases of the bucket reduction.
+//
+// In a tree reduction half of the lanes go idle at every level and what is left is one long dependent chain of additions
+// per wave; a lone wave issues one VALU instruction per ~5.6 cycles whatever its ILP, so the chain length in
+// INSTRUCTIONS is the time.  The 14 products of add-2008-s have depth 5 when spread over four lanes:
+//
+//   quad layout: lane role r = lane & 3 holds ONE coordinate of each operand (0: X, 1: Y, 2: ZZ, 3: ZZZ), 8 VGPRs
+//   instead of 32 per point; a 128-byte XYZZ record is loaded by its quad as four consecutive 32-byte pieces.
+//
+//   round 1   t1 = a * partner(b)            role0: U1 = X1 ZZ2   role2: U2 = X2 ZZ1   role1: S1 = Y1 ZZZ2   role3: S2 = Y2 ZZZ1
+//   round 2   roles 0,1: d = partner(t1) - t1 (P, R), d^2 (PP, RR)        roles 2,3: a * b (ZZ1 ZZ2, ZZZ1 ZZZ2)
+//   round 3   role0: PPP = P PP   role1: Q = U1 PP   role2: ZZ3 = ZZ12 PP   role3: PPP (again, locally)
+//   round 4   role1: S1 PPP   role3: ZZZ3 = ZZZ12 PPP   role0: X3 = RR - PPP - 2Q (no product)
+//   round 5   role1: Y3 = R (Q - X3) - S1 PPP
+//
+// 5 product rounds + ~120 cross-lane moves against 14 products: a 2.3x shorter chain.  Exactness: identity operands are
+// selected through (flags broadcast from the ZZ lane), P = 0 with R != 0 gives ZZ3 = 0 = identity by itself, and the
+// doubling case P = R = 0 (equal points) falls back to every lane of the quad running the ordinary dbl() on the
+// gathered operand -- rare, wave-uniformly guarded.
+#pragma once
+#include "curve.cuh"
+
+namespace kh {
+
+// value of `v` in the lane of this quad whose role is `role` (all 64 lanes execute)
+template <class F>
+__device__ __forceinline__ Fe<F> quad_get(const Fe<F>& v, int role) {
+    const int src = ((int)(threadIdx.x & 63u) & ~3) | role;
+    Fe<F> r;
+#pragma unroll
+    for (int k = 0; k < 8; k++) r.v[k] = (u32)__shfl((int)v.v[k], src, 64);
+    return r;
+}
+__device__ __forceinline__ bool quad_flag(bool f, int role) {
+    const int src = ((int)(threadIdx.x & 63u) & ~3) | role;
+    return __shfl((int)f, src, 64) != 0;
+}
+
+// this lane's coordinate of A + B, given its coordinate of A (a) and of B (b)
+template <class F>
+__device__ __forceinline__ Fe<F> quad_add(const Fe<F>& a, const Fe<F>& b) {
+    const int role = (int)(threadIdx.x & 3u);
+    const bool a_id = quad_flag(a.is_zero(), 2), b_id = quad_flag(b.is_zero(), 2);
+    // round 1
+    const Fe<F> t1 = mul<F>(a, quad_get<F>(b, role ^ 2));
+    // round 2
+    const Fe<F> d = sub<F>(quad_get<F>(t1, role ^ 2), t1);              // role0: P, role1: R (roles 2,3: unused)
+    const bool lo = role < 2;
+    const Fe<F> m2 = mul<F>(lo ? d : a, lo ? d : b);                    // PP | RR | ZZ1 ZZ2 | ZZZ1 ZZZ2
+    const bool p0 = quad_flag(d.is_zero(), 0), r0 = quad_flag(d.is_zero(), 1);
+    // round 3
+    const Fe<F> PPb = quad_get<F>(m2, 0), Pb = quad_get<F>(d, 0), U1b = quad_get<F>(t1, 0);
+    Fe<F> x3 = role == 0 ? d : (role == 1 ? U1b : (role == 2 ? m2 : Pb));
+    Fe<F> y3 = role == 0 ? m2 : PPb;
+    const Fe<F> m3 = mul<F>(x3, y3);                                     // PPP | Q | ZZ3 | PPP
+    // round 4
+    const Fe<F> PPPb = quad_get<F>(m3, 0), RRb = quad_get<F>(m2, 1), Qb = quad_get<F>(m3, 1);
+    const Fe<F> m4 = mul<F>(role == 1 ? t1 : m2, role == 1 ? PPPb : m3);   // role1: S1 PPP, role3: ZZZ3 (roles 0,2: unused)
+    const Fe<F> X3 = sub<F>(sub<F>(sub<F>(RRb, PPPb), Qb), Qb);            // meaningful in every lane (all inputs broadcast)
+    // round 5
+    const Fe<F> m5 = mul<F>(d, sub<F>(m3, X3));                          // role1: R (Q - X3)
+    Fe<F> res = role == 0 ? X3 : (role == 1 ? sub<F>(m5, m4) : (role == 2 ? m3 : m4));
+    // equal points: the formulas above give 0/0 -- double A instead (rare; every lane of the quad does the whole dbl)
+    const bool need_dbl = p0 && r0 && !a_id && !b_id;
+    if (__ballot(need_dbl) != 0ull) {
+        Xyzz<F> A;
+        A.x = quad_get<F>(a, 0); A.y = quad_get<F>(a, 1); A.zz = quad_get<F>(a, 2); A.zzz = quad_get<F>(a, 3);
+        if (need_dbl) {
+            const Xyzz<F> D = dbl<F>(A);
+            res = role == 0 ? D.x : (role == 1 ? D.y : (role == 2 ? D.zz : D.zzz));
+        }
+    }
+    if (b_id) res = a;
+    if (a_id) res = b;
+    return res;
+}
+// the quad's piece of a 128-byte XYZZ record (x | y | zz | zzz, 32 bytes each)
+template <class F>
+__device__ __forceinline__ Fe<F> quad_load(const uint8_t* rec) { return Fe<F>::load(rec + 32 * (threadIdx.x & 3u)); }
+template <class F>
+__device__ __forceinline__ void quad_store(uint8_t* rec, const Fe<F>& v) { v.store(rec + 32 * (threadIdx.x & 3u)); }
+template <class F>
+__device__ __forceinline__ Fe<F> quad_identity() { return Fe<F>::zero(); }     // all-zero record = identity (ZZ = 0)
+
+}  // namespace kh

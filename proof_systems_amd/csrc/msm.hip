@@ -28,6 +28,7 @@
 // all windows share one bucket set and step 8's Horner disappears.
 #include "common.hpp"
 #include "curve.cuh"
+#include "coop.cuh"
 #include "host_ec.hpp"
 #include "msm.hpp"
 #include <condition_variable>
@@ -867,7 +868,31 @@ __global__ void k_debug_point(int op, const u64* p, const uint8_t* pinf, const u
     else { Xyzz<F> d2 = dbl<F>(a); r = (qinf && qinf[i]) ? d2 : madd<F>(d2, Q, true); }   // 2P - Q: non-trivial ZZ into madd
     r.store(out + 128 * i);
 }
+// ops 4, 5: the lane-cooperative addition (coop.cuh), four threads per pair; op 5 doubles both operands first so that the
+// inputs have non-trivial ZZ / ZZZ
+template <class F>
+__global__ void k_debug_quad(int op, const u64* p, const uint8_t* pinf, const u64* q, const uint8_t* qinf, uint8_t* out, size_t n) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t i = t >> 2; const int role = (int)(t & 3);
+    const bool live = i < n;
+    if (!live) i = n - 1;                                  // keep whole quads / waves in the shuffles
+    Aff<F> P = Aff<F>::load(p + 8 * i), Q = Aff<F>::load(q + 8 * i);
+    Xyzz<F> a = (pinf && pinf[i]) ? Xyzz<F>::identity() : Xyzz<F>::from_affine(P);
+    Xyzz<F> b = (qinf && qinf[i]) ? Xyzz<F>::identity() : Xyzz<F>::from_affine(Q);
+    if (op == 5) { a = dbl<F>(a); b = dbl<F>(b); }
+    const Fe<F> ac = role == 0 ? a.x : (role == 1 ? a.y : (role == 2 ? a.zz : a.zzz));
+    const Fe<F> bc = role == 0 ? b.x : (role == 1 ? b.y : (role == 2 ? b.zz : b.zzz));
+    const Fe<F> r = quad_add<F>(ac, bc);
+    if (live) quad_store<F>(out + 128 * i, r);
+}
 int debug_point_op(Context& C, int curve, int op, const u64* p, const uint8_t* pinf, const u64* q, const uint8_t* qinf, uint8_t* out, size_t n) {
+    if (op == 4 || op == 5) {
+        dim3 qgrid((unsigned)((4 * n + 255) / 256));
+        if (curve == KH_CURVE_VESTA) hipLaunchKernelGGL((k_debug_quad<FqParams>), qgrid, dim3(256), 0, C.stream, op, p, pinf, q, qinf, out, n);
+        else hipLaunchKernelGGL((k_debug_quad<FpParams>), qgrid, dim3(256), 0, C.stream, op, p, pinf, q, qinf, out, n);
+        KH_HIP(hipGetLastError());
+        return KH_OK;
+    }
     dim3 grid((unsigned)((n + 255) / 256));
     if (curve == KH_CURVE_VESTA) hipLaunchKernelGGL((k_debug_point<FqParams>), grid, dim3(256), 0, C.stream, op, p, pinf, q, qinf, out, n);
     else hipLaunchKernelGGL((k_debug_point<FpParams>), grid, dim3(256), 0, C.stream, op, p, pinf, q, qinf, out, n);

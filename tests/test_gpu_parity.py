@@ -106,6 +106,35 @@ def test_point_ops(khip, cid):
         assert bool(ginf[i]) == winf and (winf or np.array_equal(got[i], w)), i
 
 
+@pytest.mark.parametrize("cid", [0, 1])
+def test_lane_cooperative_addition(khip, cid):
+    """coop.cuh: the XYZZ addition spread over four lanes (used by the tree phases of the bucket reduction) equals the
+    oracle's group law on generic, equal (doubling fallback), opposite and identity operands, with trivial (op 4) and
+    non-trivial (op 5: both operands doubled first) ZZ / ZZZ; 517 pairs leave a ragged last wave."""
+    n = 517
+    g = cref.srs_generate(cid, 0, n, threads=8)
+    rng = np.random.default_rng(15 + cid)
+    p, q = g, g[rng.permutation(n)].copy()
+    base_fid = 1 if cid == 0 else 0
+    for i in (0, 7, 64, 65, 300, 516):
+        q[i] = p[i]                                        # equal points
+    for i in (1, 66, 301, 515):
+        q[i] = p[i]
+        q[i, 4:] = cref.field_op(base_fid, "sub", np.zeros((1, 4), np.uint64), p[i, 4:].reshape(1, 4))[0]   # opposite points
+    pinf = np.zeros(n, np.uint8); qinf = np.zeros(n, np.uint8)
+    pinf[[2, 67, 302]] = 1; qinf[[3, 68, 303]] = 1; pinf[[4, 69]] = 1; qinf[[4, 69]] = 1
+    got, ginf = khip.debug_point_op(cid, 4, p, q, pinf, qinf)
+    for i in range(n):
+        w, winf = cref.point_add(cid, p[i], q[i], bool(pinf[i]), bool(qinf[i]))
+        assert bool(ginf[i]) == winf and (winf or np.array_equal(got[i], w)), ("op4", i)
+    got, ginf = khip.debug_point_op(cid, 5, p, q, pinf, qinf)
+    for i in range(n):
+        a, ai = cref.point_add(cid, p[i], p[i], bool(pinf[i]), bool(pinf[i]))
+        b, bi = cref.point_add(cid, q[i], q[i], bool(qinf[i]), bool(qinf[i]))
+        w, winf = cref.point_add(cid, a, b, ai, bi)
+        assert bool(ginf[i]) == winf and (winf or np.array_equal(got[i], w)), ("op5", i)
+
+
 # ------------------------------------------------------------------ MSM
 def _check_msm(khip, cid, g, sc, mont=True, threads=8):
     srs = khip.Srs(cid, g)
