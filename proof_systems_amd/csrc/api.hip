@@ -39,7 +39,7 @@ static int do_init(int device_id) {
         KH_HIP(hipEventCreateWithFlags(&C.slot[i].done, hipEventDisableTiming));
         int rc2 = C.slot[i].timer.init(); if (rc2) return rc2;
     }
-    C.stream = C.slot[0].stream;
+    C.stream = C.slot[0].stream;         // four streams = the four hardware queues HIP gives a process by default; a fifth would share one
     KH_HIP(hipEventCreateWithFlags(&C.order_ev, hipEventDisableTiming));
     hipDeviceProp_t prop;
     KH_HIP(hipGetDeviceProperties(&prop, device_id));
@@ -294,10 +294,9 @@ static int msm_submit_locked(Context& C, kh_srs_t* srs, int basis, unsigned chun
         sdev = S.ws_scalars.as<uint64_t>();
     } else if (scalars_on_device) {
         KH_REQUIRE(use == n || k == 1, "device-resident batched scalars must not exceed the basis window");
-        if (S.stream != C.stream) {     // the scalars may be the output of kh_ntt_dev / kh_lde_dev / a vector step still running on the main stream
-            KH_HIP(hipEventRecord(C.order_ev, C.stream));
-            KH_HIP(hipStreamWaitEvent(S.stream, C.order_ev, 0));
-        }
+        // the scalars may be the output of an asynchronous kh_ntt_dev / kh_lde_dev still running on the main stream: wait for
+        // the event recorded right behind the last such producer (NOT for whatever else slot 0's stream has queued since)
+        if (C.main_dirty && S.stream != C.stream) KH_HIP(hipStreamWaitEvent(S.stream, C.order_ev, 0));
     }
     rc = msm_enqueue(C, S, srs->curve, b, offset, sdev, use, k, mont);
     if (rc) return rc;
@@ -954,7 +953,9 @@ int kh_ntt_dev(int field, uint64_t* data_dev, unsigned log2_n, int inverse, size
     if (batch == 0) return KH_OK;
     Context& C = ctx();
     std::lock_guard<std::mutex> lk(C.mu);
-    return ntt_run(C, field, data_dev, log2_n, inverse, batch);
+    rc = ntt_run(C, field, data_dev, log2_n, inverse, batch);
+    if (rc == KH_OK && hipEventRecord(C.order_ev, C.stream) == hipSuccess) C.main_dirty = true;   // a later MSM on another slot waits for this point
+    return rc;
 }
 int kh_lde_dev(int field, const uint64_t* coeffs_dev, unsigned log2_n, unsigned log2_blowup, uint64_t* out_dev, size_t batch) {
     KH_REQUIRE(field == KH_FIELD_FP || field == KH_FIELD_FQ, "unknown field id %d", field);
@@ -964,7 +965,9 @@ int kh_lde_dev(int field, const uint64_t* coeffs_dev, unsigned log2_n, unsigned 
     if (batch == 0) return KH_OK;
     Context& C = ctx();
     std::lock_guard<std::mutex> lk(C.mu);
-    return lde_run(C, field, coeffs_dev, log2_n, log2_blowup, out_dev, batch);
+    rc = lde_run(C, field, coeffs_dev, log2_n, log2_blowup, out_dev, batch);
+    if (rc == KH_OK && hipEventRecord(C.order_ev, C.stream) == hipSuccess) C.main_dirty = true;
+    return rc;
 }
 int kh_coset_ntt_dev(int field, const uint64_t* coeffs_dev, unsigned log2_n, const uint64_t shift[4], uint64_t* out_dev, size_t batch) {
     KH_REQUIRE(field == KH_FIELD_FP || field == KH_FIELD_FQ, "unknown field id %d", field);
@@ -974,7 +977,9 @@ int kh_coset_ntt_dev(int field, const uint64_t* coeffs_dev, unsigned log2_n, con
     if (batch == 0) return KH_OK;
     Context& C = ctx();
     std::lock_guard<std::mutex> lk(C.mu);
-    return poly_coset_ntt(C, field, coeffs_dev, log2_n, shift, out_dev, batch);
+    rc = poly_coset_ntt(C, field, coeffs_dev, log2_n, shift, out_dev, batch);
+    if (rc == KH_OK && hipEventRecord(C.order_ev, C.stream) == hipSuccess) C.main_dirty = true;
+    return rc;
 }
 int kh_ntt(int field, uint64_t* data, unsigned log2_n, int inverse, size_t batch) {
     KH_REQUIRE(field == KH_FIELD_FP || field == KH_FIELD_FQ, "unknown field id %d", field);
@@ -1040,6 +1045,7 @@ int kh_sync(void) {
     Context& C = ctx();
     std::lock_guard<std::mutex> lk(C.mu);
     for (int i = 0; i < MSM_SLOTS; i++) KH_HIP(hipStreamSynchronize(C.slot[i].stream));
+    C.main_dirty = false;
     if (C.timer.n > 0) collect_timings(C, C.timer);
     C.timer.n = 0;
     return KH_OK;

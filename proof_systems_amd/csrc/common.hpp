@@ -104,7 +104,8 @@ struct Context {
     int sync_inflight = 0;             // slots some thread is currently blocked on (they WILL free up)
     int device = -1;
     bool ready = false;
-    hipStream_t stream = nullptr;      // = slot[0].stream: the library's main stream (NTT / LDE / vector steps)
+    hipStream_t stream = nullptr;      // = slot[0].stream: the library's main stream (NTT / LDE / vector steps / opening folds)
+    bool main_dirty = false;           // asynchronous work was queued on the main stream since the last kh_sync
     hipEvent_t order_ev = nullptr;     // orders device-resident producers on the main stream before an MSM on another slot's stream
     int num_cus = 256;
     PhaseTimer timer;                  // NTT / LDE phases (MSM phases are per slot)

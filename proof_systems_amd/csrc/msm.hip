@@ -490,6 +490,86 @@ k_marginal_fin(const uint8_t* __restrict__ marg, MargGeom g, uint8_t* __restrict
     if (threadIdx.x == 0) r.store(out + (q * 3 + j) * 128);
 }
 
+// Quad versions of the two reduction kernels for the latency path (<= 4 MSMs): the same marginal sums with the
+// lane-cooperative addition of coop.cuh -- every addition of the chain costs 5 product rounds instead of 14 products.
+template <class BF>
+__device__ __forceinline__ Fe<BF> quad_shfl_down(const Fe<BF>& v, int quads) {      // the same coordinate, `quads` quads further up; identity beyond the wave
+    Fe<BF> r;
+#pragma unroll
+    for (int k = 0; k < 8; k++) r.v[k] = (u32)__shfl_down((int)v.v[k], 4 * quads, 64);
+    if ((int)(threadIdx.x & 63u) + 4 * quads >= 64) r = Fe<BF>::zero();
+    return r;
+}
+template <class BF>
+__global__ void __launch_bounds__(1024)
+k_marginals_q(const uint8_t* __restrict__ buckets, MargGeom g, uint8_t* __restrict__ out) {
+    __shared__ u32 sh[16 * 32];
+    const u32 v = blockIdx.x, j = blockIdx.y; const size_t q = blockIdx.z;
+    const u32 s = g.sh[j], f = g.wd[j];
+    if (v >= (1u << f)) return;
+    const uint8_t* B = buckets + q * (size_t)g.nb * 128;
+    const u32 cnt = g.nb >> f, lowmask = (1u << s) - 1u;
+    const u32 quad = threadIdx.x >> 2, nquads = blockDim.x >> 2, role = threadIdx.x & 3u;
+    Fe<BF> acc = Fe<BF>::zero();
+    for (u32 e = quad; e < cnt; e += nquads) {
+        const u32 t = ((e >> s) << (s + f)) | (v << s) | (e & lowmask);
+        acc = quad_add<BF>(acc, quad_load<BF>(B + (size_t)t * 128));
+    }
+    for (int d = 8; d >= 1; d >>= 1) acc = quad_add<BF>(acc, quad_shfl_down<BF>(acc, d));       // 16 quads of the wave
+    const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u, nw = blockDim.x >> 6;
+    if (lane < 4) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) sh[(wave * 4 + role) * 8 + k] = acc.v[k];
+    }
+    __syncthreads();
+    if (wave == 0) {                                        // quad w of wave 0 takes wave w's sum
+        Fe<BF> o = Fe<BF>::zero();
+        if (quad < nw) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) o.v[k] = sh[(quad * 4 + role) * 8 + k];
+        }
+        acc = o;
+        for (int d = 8; d >= 1; d >>= 1) if ((u32)d < nw) acc = quad_add<BF>(acc, quad_shfl_down<BF>(acc, d));
+        if (threadIdx.x < 4) quad_store<BF>(out + ((q * 3 + j) * 32 + v) * 128, acc);
+    }
+}
+// block (j, q), 128 threads = 32 quads, one per marginal: suffix scan + sum as in k_marginal_fin, exchanges through LDS
+template <class BF>
+__global__ void __launch_bounds__(128)
+k_marginal_fin_q(const uint8_t* __restrict__ marg, MargGeom g, uint8_t* __restrict__ out) {
+    __shared__ u32 sh[32 * 32];
+    const u32 j = blockIdx.x; const size_t q = blockIdx.y;
+    const u32 v = threadIdx.x >> 2, role = threadIdx.x & 3u, f = g.wd[j];
+    Fe<BF> r = Fe<BF>::zero();
+    if (v < (1u << f)) r = quad_load<BF>(marg + ((q * 3 + j) * 32 + v) * 128);
+    auto put = [&](const Fe<BF>& x) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) sh[(v * 4 + role) * 8 + k] = x.v[k];
+    };
+    auto get = [&](u32 from) {
+        Fe<BF> o = Fe<BF>::zero();
+        if (from < 32) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) o.v[k] = sh[(from * 4 + role) * 8 + k];
+        }
+        return o;
+    };
+    for (u32 d = 1; d < 32; d <<= 1) {                     // inclusive suffix scan over the 32 quads
+        put(r); __syncthreads();
+        const Fe<BF> o = get(v + d);
+        __syncthreads();
+        r = quad_add<BF>(r, o);
+    }
+    if (v == 0 && j != 0) r = Fe<BF>::zero();              // weight of digit value 0
+    for (u32 d = 16; d >= 1; d >>= 1) {
+        put(r); __syncthreads();
+        const Fe<BF> o = v < d ? get(v + d) : Fe<BF>::zero();
+        __syncthreads();
+        r = quad_add<BF>(r, o);
+    }
+    if (threadIdx.x < 4) quad_store<BF>(out + (q * 3 + j) * 128, r);
+}
+
 // ------------------------------------------------------------------------------------ precomputed window tables
 // tables[w][i] = 2^(c*w) * P_i in affine form (w = 0 is the basis itself).  Thread per point:
 // (W-1) x c doublings in XYZZ, then ONE inversion per point (Montgomery's trick over its W-1
@@ -711,8 +791,14 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
     if (planes) {
         // few groups: 256 threads per marginal (4 sequential additions + the tree: shortest chain); batches: one wave
         // per marginal (16 + 6 additions deep, but 2.2x less issue work -- batches are throughput-bound)
+        static const int quad_threads = getenv("KH_QUAD") ? atoi(getenv("KH_QUAD")) : 256;   // 0: scalar additions
+        if (ngroups <= 4 && quad_threads > 0) {            // latency path: lane-cooperative additions (coop.cuh)
+            hipLaunchKernelGGL((k_marginals_q<BF>), dim3(32, 3, (unsigned)ngroups), dim3(quad_threads), 0, s, C.ws_buckets.as<uint8_t>(), mg, C.ws_seg.as<uint8_t>());
+            hipLaunchKernelGGL((k_marginal_fin_q<BF>), dim3(3, (unsigned)ngroups), dim3(128), 0, s, C.ws_seg.as<uint8_t>(), mg, C.ws_out.as<uint8_t>());
+        } else {
         hipLaunchKernelGGL((k_marginals<BF>), dim3(32, 3, (unsigned)ngroups), dim3(ngroups <= 4 ? 256 : 64), 0, s, C.ws_buckets.as<uint8_t>(), mg, C.ws_seg.as<uint8_t>());
         hipLaunchKernelGGL((k_marginal_fin<BF>), dim3(3, (unsigned)ngroups), dim3(64), 0, s, C.ws_seg.as<uint8_t>(), mg, C.ws_out.as<uint8_t>());
+        }
     } else {
     hipLaunchKernelGGL((k_reduce_seg<BF>), dim3((unsigned)((ngroups * nseg + 127) / 128)), dim3(128), 0, s,
                        C.ws_buckets.as<uint8_t>(), nb, m, ngroups, C.ws_seg.as<uint8_t>());
