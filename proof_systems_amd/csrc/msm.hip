@@ -490,6 +490,32 @@ k_marginal_fin(const uint8_t* __restrict__ marg, MargGeom g, uint8_t* __restrict
     if (threadIdx.x == 0) r.store(out + (q * 3 + j) * 128);
 }
 
+// quad per bucket: the bucket's task partials summed with the cooperative addition (latency path)
+template <class BF>
+__global__ void __launch_bounds__(256)
+k_bucket_sum_q(const u32* __restrict__ toff, size_t nkeys, const uint8_t* __restrict__ partial,
+               uint8_t* __restrict__ buckets, u32* __restrict__ big, size_t cap, u32 SMALL_NT) {
+    size_t key = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
+    const bool live = key < nkeys;
+    if (!live) key = nkeys - 1;
+    const u32 role = threadIdx.x & 3u;
+    u32 t0 = toff[key], nt = toff[key + 1] - t0;
+    Fe<BF> acc = Fe<BF>::zero();
+    if (nt > SMALL_NT) {
+        if (live && role == 0) {
+            u32 nch = (nt + CHUNK - 1) / CHUNK;
+            u32 slot = atomicAdd(&big[0], 1u);
+            u32 cbase = atomicAdd(&big[1], nch);
+            big[2 + slot] = (u32)key; big[2 + cap + slot] = cbase;
+            for (u32 j = 0; j < nch; j++) { big[2 + 2 * cap + cbase + j] = (u32)key; big[2 + 3 * cap + cbase + j] = j; }
+        }
+        nt = 0;
+    }
+    // the trip count may differ between the quads of a wave: quad_add's shuffles stay inside the quad, its ballot is only a hint
+    for (u32 k = 0; k < nt; k++) acc = quad_add<BF>(acc, quad_load<BF>(partial + (size_t)(t0 + k) * 128));
+    if (live) quad_store<BF>(buckets + key * 128, acc);
+}
+
 // Quad versions of the two reduction kernels for the latency path (<= 4 MSMs): the same marginal sums with the
 // lane-cooperative addition of coop.cuh -- every addition of the chain costs 5 product rounds instead of 14 products.
 template <class BF>
@@ -779,6 +805,12 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
                        (const uint8_t*)basis.pts, C.ws_partial.as<uint8_t>());
     C.timer.mark("accumulate", s);
     // 6 bucket sums
+    static const bool bsum_quad = !getenv("KH_NO_BSUM_QUAD");
+    if (precomp && ngroups <= 4 && bsum_quad)
+        hipLaunchKernelGGL((k_bucket_sum_q<BF>), dim3((unsigned)((4 * nkeys + 255) / 256)), dim3(256), 0, s,
+                           C.ws_toff.as<u32>(), nkeys, C.ws_partial.as<uint8_t>(), C.ws_buckets.as<uint8_t>(), C.ws_biglist.as<u32>(),
+                           bigcap, 16u);
+    else
     hipLaunchKernelGGL((k_bucket_sum<BF>), dim3((unsigned)((nkeys + 255) / 256)), dim3(256), 0, s,
                        C.ws_toff.as<u32>(), nkeys, C.ws_partial.as<uint8_t>(), C.ws_buckets.as<uint8_t>(), C.ws_biglist.as<u32>(),
                        bigcap, nkeys <= 16384 ? 4u : 16u);
