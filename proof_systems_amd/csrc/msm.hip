@@ -806,7 +806,8 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
     C.timer.mark("accumulate", s);
     // 6 bucket sums
     static const bool bsum_quad = !getenv("KH_NO_BSUM_QUAD");
-    if (precomp && ngroups <= 4 && bsum_quad)
+    static const size_t bsum_maxg = getenv("KH_QUAD_MAXG") ? (size_t)atol(getenv("KH_QUAD_MAXG")) : 4;
+    if (precomp && ngroups <= bsum_maxg && bsum_quad)
         hipLaunchKernelGGL((k_bucket_sum_q<BF>), dim3((unsigned)((4 * nkeys + 255) / 256)), dim3(256), 0, s,
                            C.ws_toff.as<u32>(), nkeys, C.ws_partial.as<uint8_t>(), C.ws_buckets.as<uint8_t>(), C.ws_biglist.as<u32>(),
                            bigcap, 16u);
@@ -824,7 +825,8 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
         // few groups: 256 threads per marginal (4 sequential additions + the tree: shortest chain); batches: one wave
         // per marginal (16 + 6 additions deep, but 2.2x less issue work -- batches are throughput-bound)
         static const int quad_threads = getenv("KH_QUAD") ? atoi(getenv("KH_QUAD")) : 256;   // 0: scalar additions
-        if (ngroups <= 4 && quad_threads > 0) {            // latency path: lane-cooperative additions (coop.cuh)
+        static const size_t quad_maxg = getenv("KH_QUAD_MAXG") ? (size_t)atol(getenv("KH_QUAD_MAXG")) : 4;
+        if (ngroups <= quad_maxg && quad_threads > 0) {    // latency path: lane-cooperative additions (coop.cuh)
             hipLaunchKernelGGL((k_marginals_q<BF>), dim3(32, 3, (unsigned)ngroups), dim3(quad_threads), 0, s, C.ws_buckets.as<uint8_t>(), mg, C.ws_seg.as<uint8_t>());
             hipLaunchKernelGGL((k_marginal_fin_q<BF>), dim3(3, (unsigned)ngroups), dim3(128), 0, s, C.ws_seg.as<uint8_t>(), mg, C.ws_out.as<uint8_t>());
         } else {
