@@ -52,3 +52,13 @@ def test_fails_loudly_without_gpu(khip):
     import numpy as np
     with pytest.raises(khip.KhError):
         khip.ntt(khip.FP, np.zeros((4, 4), np.uint64), 2)
+
+
+def test_header_is_plain_c99(tmp_path):
+    """The drop-in boundary is a C ABI: include/kimchi_hip.h must compile as strict C99 (a cgo / bindgen / ctypes consumer
+    sees exactly this file)."""
+    import subprocess
+    src = tmp_path / "hdr.c"
+    src.write_text('#include "kimchi_hip.h"\nint main(void) { return KH_OK + KH_TOK_LOAD - KH_TOK_LOAD + KH_SCAN_ADD; }\n')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(root, "include"), "-fsyntax-only", str(src)])
