@@ -79,6 +79,15 @@ template <class F>
 __device__ __forceinline__ Fe<F> quad_load(const uint8_t* rec) { return Fe<F>::load(rec + 32 * (threadIdx.x & 3u)); }
 template <class F>
 __device__ __forceinline__ void quad_store(uint8_t* rec, const Fe<F>& v) { v.store(rec + 32 * (threadIdx.x & 3u)); }
+// the same coordinate of the point held `quads` quads further up in the wave; the identity beyond the wave's last quad
+template <class BF>
+__device__ __forceinline__ Fe<BF> quad_shfl_down(const Fe<BF>& v, int quads) {
+    Fe<BF> r;
+#pragma unroll
+    for (int k = 0; k < 8; k++) r.v[k] = (u32)__shfl_down((int)v.v[k], 4 * quads, 64);
+    if ((int)(threadIdx.x & 63u) + 4 * quads >= 64) r = Fe<BF>::zero();
+    return r;
+}
 template <class F>
 __device__ __forceinline__ Fe<F> quad_identity() { return Fe<F>::zero(); }     // all-zero record = identity (ZZ = 0)
 

@@ -302,7 +302,7 @@ k_accumulate(const u32* __restrict__ entries, const u32* __restrict__ off, const
 // kernel argument: 16 for large problems (throughput), 4 for small ones (shorter dependent chain)
 // hot-bucket bookkeeping in `big`: [0] = #big buckets, [1] = #chunk items, then four arrays of `cap` words:
 // bigkey[], bigcbase[] (first chunk item of that bucket), itemkey[], itemj[]
-static constexpr u32 CHUNK = 512;            // partials per chunk item = 8 per lane of a wave
+static constexpr u32 CHUNK = 128;            // partials per chunk item = 8 per quad of a wave (cooperative additions)
 template <class BF>
 __global__ void __launch_bounds__(256)
 k_bucket_sum(const u32* __restrict__ toff, size_t nkeys, const uint8_t* __restrict__ partial,
@@ -340,32 +340,50 @@ template <class BF>
 __global__ void __launch_bounds__(64)
 k_bucket_chunk(const u32* __restrict__ toff, const uint8_t* __restrict__ partial, const u32* __restrict__ big, size_t cap,
                uint8_t* __restrict__ chunk_out) {
+    // one wave = 16 quads per chunk item; every addition is the lane-cooperative one (coop.cuh): 8 sequential + 4 tree levels
     u32 nitems = big[1];
-    int lane = threadIdx.x;
+    const u32 quad = threadIdx.x >> 2;
     for (u32 it = blockIdx.x; it < nitems; it += gridDim.x) {
         u32 key = big[2 + 2 * cap + it], j = big[2 + 3 * cap + it];
         u32 t0 = toff[key], nt = toff[key + 1] - t0;
         u32 lo = j * CHUNK, hi = lo + CHUNK < nt ? lo + CHUNK : nt;
-        Xyzz<BF> acc = Xyzz<BF>::identity();
-        for (u32 k = lo + lane; k < hi; k += 64) acc = add<BF>(acc, Xyzz<BF>::load(partial + (size_t)(t0 + k) * 128));
-        for (int d = 32; d >= 1; d >>= 1) { Xyzz<BF> o = shfl_down<BF>(acc, d); acc = add<BF>(acc, o); }
-        if (lane == 0) acc.store(chunk_out + (size_t)it * 128);
+        Fe<BF> acc = Fe<BF>::zero();
+        for (u32 k = lo + quad; k < hi; k += 16) acc = quad_add<BF>(acc, quad_load<BF>(partial + (size_t)(t0 + k) * 128));
+        for (int d = 8; d >= 1; d >>= 1) acc = quad_add<BF>(acc, quad_shfl_down<BF>(acc, d));
+        if (threadIdx.x < 4) quad_store<BF>(chunk_out + (size_t)it * 128, acc);
     }
 }
 template <class BF>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(256)
 k_bucket_big(const u32* __restrict__ toff, const uint8_t* __restrict__ chunk_out, uint8_t* __restrict__ buckets,
              const u32* __restrict__ big, size_t cap) {
+    // one 256-thread block = 64 quads per hot bucket: a bucket holding 2^20 entries has ~1000 chunk sums
+    __shared__ u32 sh[4 * 32];
     u32 nbig = big[0];
-    int lane = threadIdx.x;
+    const u32 quad = threadIdx.x >> 2, role = threadIdx.x & 3u, wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     for (u32 bi = blockIdx.x; bi < nbig; bi += gridDim.x) {
         u32 key = big[2 + bi], cbase = big[2 + cap + bi];
         u32 nt = toff[key + 1] - toff[key];
         u32 nch = (nt + CHUNK - 1) / CHUNK;
-        Xyzz<BF> acc = Xyzz<BF>::identity();
-        for (u32 k = lane; k < nch; k += 64) acc = add<BF>(acc, Xyzz<BF>::load(chunk_out + (size_t)(cbase + k) * 128));
-        if (nch > 1) for (int d = 32; d >= 1; d >>= 1) { Xyzz<BF> o = shfl_down<BF>(acc, d); acc = add<BF>(acc, o); }
-        if (lane == 0) acc.store(buckets + (size_t)key * 128);
+        Fe<BF> acc = Fe<BF>::zero();
+        for (u32 k = quad; k < nch; k += 64) acc = quad_add<BF>(acc, quad_load<BF>(chunk_out + (size_t)(cbase + k) * 128));
+        for (int d = 8; d >= 1; d >>= 1) acc = quad_add<BF>(acc, quad_shfl_down<BF>(acc, d));
+        __syncthreads();                                    // sh is reused across iterations
+        if (lane < 4) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) sh[(wave * 4 + role) * 8 + k] = acc.v[k];
+        }
+        __syncthreads();
+        if (wave == 0) {
+            Fe<BF> o = Fe<BF>::zero();
+            if (quad < 4) {
+#pragma unroll
+                for (int k = 0; k < 8; k++) o.v[k] = sh[(quad * 4 + role) * 8 + k];
+            }
+            acc = o;
+            for (int d = 2; d >= 1; d >>= 1) acc = quad_add<BF>(acc, quad_shfl_down<BF>(acc, d));
+            if (threadIdx.x < 4) quad_store<BF>(buckets + (size_t)key * 128, acc);
+        }
     }
 }
 // ------------------------------------------------------------------------------------ 7 reduce
@@ -518,14 +536,6 @@ k_bucket_sum_q(const u32* __restrict__ toff, size_t nkeys, const uint8_t* __rest
 
 // Quad versions of the two reduction kernels for the latency path (<= 4 MSMs): the same marginal sums with the
 // lane-cooperative addition of coop.cuh -- every addition of the chain costs 5 product rounds instead of 14 products.
-template <class BF>
-__device__ __forceinline__ Fe<BF> quad_shfl_down(const Fe<BF>& v, int quads) {      // the same coordinate, `quads` quads further up; identity beyond the wave
-    Fe<BF> r;
-#pragma unroll
-    for (int k = 0; k < 8; k++) r.v[k] = (u32)__shfl_down((int)v.v[k], 4 * quads, 64);
-    if ((int)(threadIdx.x & 63u) + 4 * quads >= 64) r = Fe<BF>::zero();
-    return r;
-}
 template <class BF>
 __global__ void __launch_bounds__(1024)
 k_marginals_q(const uint8_t* __restrict__ buckets, MargGeom g, uint8_t* __restrict__ out) {
@@ -817,7 +827,7 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
                        bigcap, nkeys <= 16384 ? 4u : 16u);
     hipLaunchKernelGGL((k_bucket_chunk<BF>), dim3(2048), dim3(64), 0, s,
                        C.ws_toff.as<u32>(), C.ws_partial.as<uint8_t>(), C.ws_biglist.as<u32>(), bigcap, C.ws_chunks.as<uint8_t>());
-    hipLaunchKernelGGL((k_bucket_big<BF>), dim3(1024), dim3(64), 0, s,
+    hipLaunchKernelGGL((k_bucket_big<BF>), dim3(1024), dim3(256), 0, s,
                        C.ws_toff.as<u32>(), C.ws_chunks.as<uint8_t>(), C.ws_buckets.as<uint8_t>(), C.ws_biglist.as<u32>(), bigcap);
     C.timer.mark("bucket_sum", s);
     // 7 reduce
