@@ -58,6 +58,8 @@ void collect_timings(Context& C, PhaseTimer& T) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, T.ev[i], T.ev[i + 1]) == hipSuccess) C.last.emplace_back(T.names[i], ms);
     }
+    float kms = 0.f;
+    if (T.kname && hipEventElapsedTime(&kms, T.k0, T.k1) == hipSuccess) C.last.emplace_back(T.kname, kms);
 }
 
 struct LagrangeChunk { DevBuf pts; DevBuf inf; bool has_inf = false; size_t n = 0; int precomp_c = 0; };

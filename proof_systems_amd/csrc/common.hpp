@@ -53,6 +53,8 @@ struct DevBuf {
 
 struct PhaseTimer {
     static constexpr int MAXP = 24;
+    hipEvent_t k0 = nullptr, k1 = nullptr;    // start / stop of ONE kernel of interest (hipExtLaunchKernelGGL): its own duration,
+    const char* kname = nullptr;              // without the barrier / dispatch gaps an event pair around the launch includes
     hipEvent_t ev[MAXP + 1];
     const char* names[MAXP];
     int n = 0;
@@ -61,10 +63,11 @@ struct PhaseTimer {
     int init() {
         if (created) return KH_OK;
         for (int i = 0; i <= MAXP; i++) KH_HIP(hipEventCreate(&ev[i]));
+        KH_HIP(hipEventCreate(&k0)); KH_HIP(hipEventCreate(&k1));
         created = true;
         return KH_OK;
     }
-    void begin(hipStream_t s) { n = 0; if (enabled && created) (void)hipEventRecord(ev[0], s); }
+    void begin(hipStream_t s) { n = 0; kname = nullptr; if (enabled && created) (void)hipEventRecord(ev[0], s); }
     void mark(const char* name, hipStream_t s) {
         if (!enabled || !created || n >= MAXP) return;
         names[n] = name; n++;
