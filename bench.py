@@ -6,8 +6,9 @@ Workload at N=1 (BASELINE.json configs[1]): ONE 2^20-point Pippenger MSM over th
 scalars = uniform 254-bit Fp Montgomery limbs from a fixed-seed PRNG), inputs resident in HBM
 when the timed region starts.  A "step" is one such MSM through the C ABI (digits -> sort ->
 bucket accumulation -> reduction -> host finish); the timed loop keeps four of them in flight
-(kh_msm_submit / kh_msm_wait), the warm-up steps are synchronous and give the latency and the
-per-phase HIP-event timings.
+(kh_msm_submit / kh_msm_wait); the warm-up steps are synchronous and give the latency, five more
+synchronous steps after the timed loop give the per-phase HIP-event timings and the dominant
+kernel's own duration at the clocks the loop ran at.
 `value` = Mscalar/s (whole job).  For N>1 (one process per GPU, RCCL) rank r owns the bases
 g[r*2^20 .. (r+1)*2^20) of a (N*2^20)-point MSM (point-range sharding): every step
 each rank reduces its slice, the partial sums are all-gathered (N x 72 bytes) and folded on
