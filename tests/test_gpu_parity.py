@@ -491,6 +491,36 @@ def test_msm_table_path_exceptional_cases(khip, cid):
     assert ginf == winf and np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("cid", [0, 1])
+def test_degenerate_bases_through_the_tree_kernels(khip, cid):
+    """One point repeated / two points / P, -P pairs as the whole basis, with 3-bit, 20-bit and full scalars, single and
+    paired MSMs: every bucket, marginal and hot-bucket tree (incl. the lane-cooperative additions and their doubling
+    fallback) meets equal points, cancellations and identities; results equal the C oracle's."""
+    rng = np.random.default_rng(77 + cid)
+    base = khip.srs_generate(cid, 0, 2)
+    fid = 1 if cid == 0 else 0
+    negp = base[0].copy()
+    negp[4:] = cref.field_op(fid, "sub", np.zeros((1, 4), np.uint64), base[0, 4:].reshape(1, 4))[0]
+    n = 1 << 12
+    for other in (base[0], base[1], negp):
+        g = np.tile(base[0], (n, 1)); g[1::2] = other
+        srs = khip.Srs(cid, g)
+        for bits in (253, 20, 3):
+            sc = rng.integers(0, 1 << 63, size=(2 * n, 4), dtype=np.uint64)
+            if bits <= 64:
+                sc[:, 1:] = 0; sc[:, 0] &= np.uint64((1 << bits) - 1)
+            else:
+                sc[:, 3] &= np.uint64((1 << 61) - 1)
+            d = khip.DevBuf(sc.nbytes).upload(sc)
+            for k in (1, 2):
+                got, ginf = srs.msm_batch_dev(d.ptr, n, k, mont=False)
+                for j in range(k):
+                    w, winf = cref.msm(cid, g, sc[j * n:(j + 1) * n], scalars_mont=False, threads=8)
+                    assert bool(ginf[j]) == bool(winf) and (winf or np.array_equal(got[j], w)), (bits, k, j)
+            d.free()
+        srs.close()
+
+
 def test_hip_path_against_derived_vectors(khip):
     """Fixed bytes committed under tests/golden/derived_vectors.json (definition-level big-int results)."""
     import json
