@@ -1095,6 +1095,10 @@ int kh_debug_point_op(int curve, int op, const uint64_t* p_xy, const uint8_t* p_
         KH_HIP(hipMemcpy(res.data(), dout, n * 128, hipMemcpyDeviceToHost));
         khost::Crv crv(curve);
         for (size_t i = 0; i < n; i++) {
+            const unsigned char* raw = (const unsigned char*)&res[i];
+            bool handed = true;                                   // op 6: a record of 0xff bytes = madd29 declined (exceptional case possible)
+            for (int k = 0; k < 128; k++) handed &= raw[k] == 0xff;
+            if (handed) { memset(out_xy + 8 * i, 0, 64); out_inf[i] = 2; continue; }
             khost::aff a; bool inf = crv.to_affine(res[i], a);
             memcpy(out_xy + 8 * i, &a, 64); out_inf[i] = inf ? 1 : 0;
         }

@@ -30,6 +30,7 @@
 #include "common.hpp"
 #include "curve.cuh"
 #include "coop.cuh"
+#include "field29.cuh"
 #include "host_ec.hpp"
 #include "msm.hpp"
 #include <condition_variable>
@@ -269,10 +270,11 @@ template <class BF>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(112)))
 k_accumulate(const u32* __restrict__ entries, const u32* __restrict__ off, const u32* __restrict__ toff,
              const u32* __restrict__ roff, const u32* __restrict__ order,
-             size_t nkeys, const uint8_t* __restrict__ pts, uint8_t* __restrict__ partial) {
+             size_t nkeys, const uint8_t* __restrict__ pts, uint8_t* __restrict__ partial, const uint8_t* __restrict__ only) {
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     u32 NT = roff[nkeys];
     if (t >= NT) return;
+    if (only && !only[t]) return;        // second pass behind k_accumulate29: just the tasks it handed over
     // binary search over the length-ranked keys: largest rank with roff[rank] <= t
     size_t lo = 0, hi = nkeys;           // invariant roff[lo] <= t < roff[hi]
     while (hi - lo > 1) {
@@ -297,6 +299,52 @@ k_accumulate(const u32* __restrict__ entries, const u32* __restrict__ off, const
         acc = madd<BF>(acc, p, (e >> 31) != 0);
     }
     acc.store(partial + t * 128);
+}
+// The same task in the lazy 29-bit-limb arithmetic of field29.cuh (186 instead of 254 instructions per product, no
+// carry chains in the subtractions).  Its values are not canonical, so it cannot decide the exceptional cases of the
+// group law; it only notices that one cannot be excluded (probability ~2^-25 per addition on random inputs), abandons
+// the task and flags it in handed[]: k_accumulate then redoes exactly those tasks with the exact formulas.  Finished
+// tasks are converted to the canonical wire form, so everything downstream is unchanged and the result stays bit-exact.
+template <class BF>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(112)))
+k_accumulate29(const u32* __restrict__ entries, const u32* __restrict__ off, const u32* __restrict__ toff,
+               const u32* __restrict__ roff, const u32* __restrict__ order,
+               size_t nkeys, const uint8_t* __restrict__ pts, uint8_t* __restrict__ partial, uint8_t* __restrict__ handed) {
+    const size_t t0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    u32 NT = roff[nkeys];
+    if (t0 >= NT) return;
+    size_t lo = 0, hi = nkeys;           // invariant roff[lo] <= t0 < roff[hi]
+    while (hi - lo > 1) {
+        size_t mid = (lo + hi) >> 1;
+        if (roff[mid] <= (u32)t0) lo = mid; else hi = mid;
+    }
+    size_t key = order ? order[lo] : lo;
+    u32 jt = (u32)t0 - roff[lo];
+    const size_t t = (size_t)toff[key] + jt;
+    u32 o0 = off[key], cnt = off[key + 1] - o0, nt = toff[key + 1] - toff[key];
+    u32 start = o0 + (u32)(((u64)jt * cnt) / nt);
+    u32 end = o0 + (u32)(((u64)(jt + 1) * cnt) / nt);
+    u32 e = entries[start];
+    Aff<BF> p = Aff<BF>::load(pts + (size_t)(e & 0x7fffffffu) * 64);
+    if (e >> 31) p.y = neg<BF>(p.y);
+    typedef typename C29<BF>::T K29;
+    Acc29<BF> acc;
+    acc.x = to29<BF>(p.x); acc.y = to29<BF>(p.y);
+#pragma unroll
+    for (int i = 0; i < 9; i++) { acc.zz.v[i] = K29::one(i); acc.zzz.v[i] = K29::one(i); }
+    bool ok = true;
+    for (u32 k = start + 1; k < end; k++) {
+        e = entries[k];
+        p = Aff<BF>::load(pts + (size_t)(e & 0x7fffffffu) * 64);
+        if (e >> 31) p.y = neg<BF>(p.y);
+        ok = madd29<BF>(acc, pack29<BF, 5>(p.x), pack29<BF, 5>(p.y));
+        if (!ok) break;
+    }
+    handed[t0] = ok ? 0 : 1;             // indexed like the second pass's thread id
+    if (!ok) return;
+    Xyzz<BF> r;
+    r.x = from29<BF>(acc.x); r.y = from29<BF>(acc.y); r.zz = from29<BF>(acc.zz); r.zzz = from29<BF>(acc.zzz);
+    r.store(partial + t * 128);
 }
 // ------------------------------------------------------------------------------------ 6 bucket sums
 // buckets with more partials than this go to the wave-per-bucket tree (k_bucket_big); the threshold is a
@@ -701,6 +749,7 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
     if ((rc = C.ws_toff.reserve((nkeys + 2) * sizeof(u32)))) return rc;
     if ((rc = C.ws_entries.reserve((M + 1) * sizeof(u32)))) return rc;
     if ((rc = C.ws_partial.reserve(max_tasks * 128))) return rc;
+    if ((rc = C.ws_handed.reserve(max_tasks + 256))) return rc;
     if ((rc = C.ws_buckets.reserve(nkeys * 128))) return rc;
     const size_t bigcap = nkeys + max_tasks / CHUNK + 2;      // big buckets <= nkeys; chunk items <= tasks/512 + nkeys
     if ((rc = C.ws_biglist.reserve((2 + 4 * bigcap) * sizeof(u32)))) return rc;
@@ -751,7 +800,8 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
                                   (uint64_t)(uintptr_t)C.ws_digits.p, (uint64_t)(uintptr_t)C.ws_hist.p, (uint64_t)(uintptr_t)C.ws_cnt.p, (uint64_t)(uintptr_t)C.ws_off.p,
                                   (uint64_t)(uintptr_t)C.ws_ntask.p, (uint64_t)(uintptr_t)C.ws_toff.p, (uint64_t)(uintptr_t)C.ws_entries.p, (uint64_t)(uintptr_t)C.ws_partial.p,
                                   (uint64_t)(uintptr_t)C.ws_buckets.p, (uint64_t)(uintptr_t)C.ws_seg.p, (uint64_t)(uintptr_t)C.ws_out.p, (uint64_t)(uintptr_t)C.ws_scan_tmp.p,
-                                  (uint64_t)(uintptr_t)C.ws_biglist.p, (uint64_t)(uintptr_t)C.ws_order.p, (uint64_t)(uintptr_t)C.ws_chunks.p};
+                                  (uint64_t)(uintptr_t)C.ws_biglist.p, (uint64_t)(uintptr_t)C.ws_order.p, (uint64_t)(uintptr_t)C.ws_chunks.p,
+                                  (uint64_t)(uintptr_t)C.ws_handed.p};
         for (uint64_t v : parts) key = fnv(key, v);
         if (C.gexec && C.gkey == key) {                    // replay
             KH_HIP(hipGraphLaunch(C.gexec, s));
@@ -810,16 +860,32 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
     }
     KH_HIP(hipMemsetAsync(C.ws_biglist.p, 0, 2 * sizeof(u32), s));
     C.timer.mark("tasks", s);
-    // 5 accumulate
-    if (C.timer.enabled && C.timer.created && !gcap.active) {     // the dominant kernel's own start / stop timestamps (bench.py roofline)
-        hipExtLaunchKernelGGL((k_accumulate<BF>), dim3((unsigned)((max_tasks + 255) / 256)), dim3(256), 0, s, C.timer.k0, C.timer.k1, 0,
+    // 5 accumulate: the lazy 29-bit-limb kernel, then the exact kernel over the (almost always zero) tasks it handed over
+    static const bool acc29 = !(getenv("KH_ACC29") && atoi(getenv("KH_ACC29")) == 0);
+    const uint8_t* handed = acc29 ? C.ws_handed.as<uint8_t>() : nullptr;
+    const dim3 agrid((unsigned)((max_tasks + 255) / 256));
+    if (acc29) {
+        if (C.timer.enabled && C.timer.created && !gcap.active) {     // the dominant kernel's own start / stop timestamps (bench.py roofline)
+            hipExtLaunchKernelGGL((k_accumulate29<BF>), agrid, dim3(256), 0, s, C.timer.k0, C.timer.k1, 0,
+                                  C.ws_entries.as<u32>(), C.ws_off.as<u32>(), C.ws_toff.as<u32>(), roff, order, nkeys,
+                                  (const uint8_t*)basis.pts, C.ws_partial.as<uint8_t>(), C.ws_handed.as<uint8_t>());
+            C.timer.kname = "k_accumulate29";
+        } else
+        hipLaunchKernelGGL((k_accumulate29<BF>), agrid, dim3(256), 0, s,
+                           C.ws_entries.as<u32>(), C.ws_off.as<u32>(), C.ws_toff.as<u32>(), roff, order, nkeys,
+                           (const uint8_t*)basis.pts, C.ws_partial.as<uint8_t>(), C.ws_handed.as<uint8_t>());
+        hipLaunchKernelGGL((k_accumulate<BF>), agrid, dim3(256), 0, s,
+                           C.ws_entries.as<u32>(), C.ws_off.as<u32>(), C.ws_toff.as<u32>(), roff, order, nkeys,
+                           (const uint8_t*)basis.pts, C.ws_partial.as<uint8_t>(), handed);
+    } else if (C.timer.enabled && C.timer.created && !gcap.active) {
+        hipExtLaunchKernelGGL((k_accumulate<BF>), agrid, dim3(256), 0, s, C.timer.k0, C.timer.k1, 0,
                               C.ws_entries.as<u32>(), C.ws_off.as<u32>(), C.ws_toff.as<u32>(), roff, order, nkeys,
-                              (const uint8_t*)basis.pts, C.ws_partial.as<uint8_t>());
+                              (const uint8_t*)basis.pts, C.ws_partial.as<uint8_t>(), handed);
         C.timer.kname = "k_accumulate";
     } else
-    hipLaunchKernelGGL((k_accumulate<BF>), dim3((unsigned)((max_tasks + 255) / 256)), dim3(256), 0, s,
+    hipLaunchKernelGGL((k_accumulate<BF>), agrid, dim3(256), 0, s,
                        C.ws_entries.as<u32>(), C.ws_off.as<u32>(), C.ws_toff.as<u32>(), roff, order, nkeys,
-                       (const uint8_t*)basis.pts, C.ws_partial.as<uint8_t>());
+                       (const uint8_t*)basis.pts, C.ws_partial.as<uint8_t>(), handed);
     C.timer.mark("accumulate", s);
     // 6 bucket sums
     static const bool bsum_quad = !getenv("KH_NO_BSUM_QUAD");
@@ -979,6 +1045,10 @@ __global__ void k_debug_field(int op, const u64* a, const u64* b, u64* out, size
         case 3: r = to_mont<F>(x); break;
         case 4: r = from_mont<F>(x); break;
         case 5: r = sqr<F>(x); break;
+        case 7: r = from29<F>(mul29<F>(to29<F>(x), to29<F>(y))); break;        // the 29-bit-limb arithmetic of field29.cuh
+        case 8: r = from29<F>(sqr29<F>(to29<F>(x))); break;
+        case 9: r = unpack29<F>(pack29<F, 0>(x)); break;
+        case 10: r = from29<F>(mul29<F>(pack29<F, 5>(x), to29<F>(y))); break;     // the unreduced 32 X form of a table point
         default: r = neg<F>(x); break;
     }
     r.store(out + 4 * i);
@@ -1002,7 +1072,14 @@ __global__ void k_debug_point(int op, const u64* p, const uint8_t* pinf, const u
     if (op == 0) r = add<F>(a, b);
     else if (op == 1) r = dbl<F>(a);
     else if (op == 2) r = (qinf && qinf[i]) ? a : madd<F>(a, Q, false);
-    else { Xyzz<F> d2 = dbl<F>(a); r = (qinf && qinf[i]) ? d2 : madd<F>(d2, Q, true); }   // 2P - Q: non-trivial ZZ into madd
+    else if (op == 3) { Xyzz<F> d2 = dbl<F>(a); r = (qinf && qinf[i]) ? d2 : madd<F>(d2, Q, true); }   // 2P - Q: non-trivial ZZ into madd
+    else {        // op 6: (2P + Q) through madd29 (non-trivial ZZ); a record of 0xff bytes = "handed to the exact path"
+        Xyzz<F> d2 = dbl<F>(a);
+        Acc29<F> A; A.x = to29<F>(d2.x); A.y = to29<F>(d2.y); A.zz = to29<F>(d2.zz); A.zzz = to29<F>(d2.zzz);
+        const bool ok = madd29<F>(A, pack29<F, 5>(Q.x), pack29<F, 5>(Q.y));
+        r.x = from29<F>(A.x); r.y = from29<F>(A.y); r.zz = from29<F>(A.zz); r.zzz = from29<F>(A.zzz);
+        if (!ok) { Fe<F> ff; _Pragma("unroll") for (int k = 0; k < 8; k++) ff.v[k] = 0xffffffffu; r.x = ff; r.y = ff; r.zz = ff; r.zzz = ff; }
+    }
     r.store(out + 128 * i);
 }
 // ops 4, 5: the lane-cooperative addition (coop.cuh), four threads per pair; op 5 doubles both operands first so that the

@@ -638,7 +638,8 @@ def last_timings():
 
 
 def debug_field_op(field: int, op: str, a, b=None):
-    ops = {"mul": 0, "add": 1, "sub": 2, "to_mont": 3, "from_mont": 4, "sqr": 5, "neg": 6}
+    ops = {"mul": 0, "add": 1, "sub": 2, "to_mont": 3, "from_mont": 4, "sqr": 5, "neg": 6,
+           "mul29": 7, "sqr29": 8, "pack29": 9, "mul29_32x": 10}      # field29.cuh (nine 29-bit limbs, lazy reduction)
     a = _c64(a, (-1, 4))
     bb = None if b is None else _c64(b, (-1, 4))
     out = np.zeros_like(a)

@@ -1,0 +1,154 @@
+"""BASELINE.json configurations at FULL size inside `pytest -m gpu` ("next" item 1): every parity
+claim DESIGN.md makes about the 2^20 / 2^22 MSMs is a collected test here, bit-exact against the C oracle
+(oracle/pasta_ref.c: Jacobian Pippenger, pinned on the reference's vectors by tests/test_oracle_kats.py).
+
+  * config 2: 2^20-point MSM over SRS::<Vesta>::create(2^20).g -- uniform scalars, the bench circuit's witness
+    (n - 10 ones, 7 zeros, 3 random: kimchi/src/bench.rs:106), all-equal scalars, 20-bit scalars (the hot-bucket paths of
+    csrc/msm.hip), Montgomery and canonical scalar input;
+  * config 4: ONE 2^22-point MSM as 8 point-range shards of 2^19 (kh_srs_create_device_range per shard, kh_points_sum
+    for the fold -- exactly what 8 ranks do, run one after the other on one GPU), against one oracle MSM;
+  * the degenerate-basis stress (equal points, two points, P / -P pairs) at 2^12 and 2^16.
+The bases come from the device generator, which tests/test_gpu_srs_trait.py pins on srs/vesta.srs; the oracle gets the
+SAME points (downloaded), so a generator bug cannot hide a kernel bug or vice versa."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import cref
+from oracle import pasta as P
+
+pytestmark = pytest.mark.gpu
+THREADS = min(64, os.cpu_count() or 8)
+
+
+@pytest.fixture(scope="module")
+def khip():
+    import proof_systems_amd.khip as k
+    k.init(0)
+    return k
+
+
+@pytest.fixture(scope="module")
+def vesta20(khip):
+    srs = khip.Srs.create(khip.VESTA, 1 << 20)
+    g = srs.get_g()
+    yield srs, g
+    srs.close()
+
+
+def _rand_fe(rng, n):
+    c = rng.integers(0, 1 << 64, size=(n, 4), dtype=np.uint64)
+    c[:, 3] &= np.uint64((1 << 61) - 1)                     # < 2^253 < p: a valid element in either representation
+    return c
+
+
+def _scalars(kind, n, rng):
+    F = P.Fp
+    one = cref.ints_to_limbs([F.R])
+    if kind == "uniform":
+        return _rand_fe(rng, n), True
+    if kind == "uniform_canonical":
+        return _rand_fe(rng, n), False
+    if kind == "bench_witness":                             # kimchi/src/bench.rs:106 + the zero-knowledge rows
+        return np.concatenate([np.repeat(one, n - 10, 0), np.zeros((7, 4), np.uint64), _rand_fe(rng, 3)]), True
+    if kind == "all_equal":
+        return np.repeat(_rand_fe(rng, 1), n, 0), True
+    if kind == "bits20":
+        s = np.zeros((n, 4), np.uint64)
+        s[:, 0] = rng.integers(0, 1 << 20, n).astype(np.uint64)
+        return s, False
+    raise KeyError(kind)
+
+
+@pytest.mark.parametrize("kind", ["uniform", "uniform_canonical", "bench_witness", "all_equal", "bits20"])
+def test_config2_msm_2_20(khip, vesta20, kind):
+    srs, g = vesta20
+    n = 1 << 20
+    sc, mont = _scalars(kind, n, np.random.default_rng(20 + len(kind)))
+    got, ginf = srs.msm(sc, mont=mont)                                     # host buffers through kh_msm
+    want, winf = cref.msm(0, g, sc, scalars_mont=mont, threads=THREADS)
+    assert bool(ginf) == winf and (winf or np.array_equal(got, want)), kind
+    buf = khip.DevBuf(sc.nbytes).upload(sc)                                # resident scalars, the benchmarked entry point
+    got2, ginf2 = srs.msm_batch_dev(buf.ptr, n, 1, mont=mont)
+    buf.free()
+    assert bool(ginf2[0]) == winf and (winf or np.array_equal(got2[0], want)), kind
+
+
+def test_config2_pallas_2_20(khip):
+    """The other curve at the same size (config 5 keeps both resident): MSM<Fp coordinates>."""
+    n = 1 << 20
+    srs = khip.Srs.create(khip.PALLAS, n)
+    g = srs.get_g()
+    sc = _rand_fe(np.random.default_rng(77), n)
+    got, ginf = srs.msm(sc)
+    want, winf = cref.msm(1, g, sc, threads=THREADS)
+    srs.close()
+    assert bool(ginf) == winf and np.array_equal(got, want)
+
+
+def test_config4_msm_2_22_as_8_shards(khip):
+    """2^22 points, 8 ranks x 2^19: rank r owns g[r 2^19, (r+1) 2^19) and the matching scalars, emits one partial; the
+    partials are folded with kh_points_sum (RCCL has no group-addition reduction: all-gather + local fold)."""
+    R, per = 8, 1 << 19
+    rng = np.random.default_rng(4)
+    sc = _rand_fe(rng, R * per)
+    parts = np.zeros((R, 8), np.uint64); pinf = np.zeros(R, np.uint8)
+    gs = []
+    for r in range(R):
+        srs = khip.Srs.create(khip.VESTA, per, start=r * per)
+        gs.append(srs.get_g())
+        parts[r], inf = srs.msm(sc[r * per:(r + 1) * per])
+        pinf[r] = inf
+        srs.close()
+    got, ginf = khip.points_sum(khip.VESTA, parts, pinf)
+    g = np.concatenate(gs)
+    assert np.array_equal(g[:4], cref.srs_generate(0, 0, 4, threads=1)) and np.array_equal(g[per:per + 2], cref.srs_generate(0, per, 2, threads=1))
+    want, winf = cref.msm(0, g, sc, threads=THREADS)
+    assert bool(ginf) == winf and np.array_equal(got, want)
+    # and the same MSM unsharded on one GPU (config 4 on a single device)
+    srs = khip.Srs.create(khip.VESTA, R * per)
+    got1, inf1 = srs.msm(sc)
+    srs.close()
+    assert not inf1 and np.array_equal(got1, want)
+
+
+@pytest.mark.parametrize("cid", [0, 1])
+@pytest.mark.parametrize("logn", [12, 16])
+def test_degenerate_bases_stress(khip, cid, logn):
+    """MSMs over degenerate bases (one point repeated, two points, P / -P pairs) with full, 20-bit and 3-bit scalars force
+    equal-point doublings, cancellations and identities through the accumulation (incl. the hand-over from the lazy
+    29-bit kernel to the exact one), the bucket sums and the tree reductions; singles and k = 2 batches."""
+    rng = np.random.default_rng(7 + cid + logn)
+    n = 1 << logn
+    base = khip.srs_generate(cid, 0, 8)
+    fid = 1 if cid == 0 else 0
+
+    def rs(k, bits):
+        a = rng.integers(0, 1 << 63, size=(k, 4), dtype=np.uint64)
+        if bits <= 64:
+            a[:, 1:] = 0; a[:, 0] &= np.uint64((1 << bits) - 1)
+        else:
+            a[:, 3] &= np.uint64((1 << 61) - 1)
+        return a
+
+    for variant in ("all_same", "two_points", "pairs_opposite"):
+        g = np.tile(base[0], (n, 1))
+        if variant == "two_points":
+            g[1::2] = base[1]
+        if variant == "pairs_opposite":
+            neg = base[0].copy()
+            neg[4:] = cref.field_op(fid, "sub", np.zeros((1, 4), np.uint64), base[0, 4:].reshape(1, 4))[0]
+            g[1::2] = neg
+        srs = khip.Srs(cid, g)
+        for bits in (253, 20, 3):
+            sc = rs(n, bits)
+            for k in (1, 2):
+                scs = np.concatenate([sc, sc[::-1]]) if k == 2 else sc
+                d = khip.DevBuf(scs.nbytes).upload(scs)
+                got, ginf = srs.msm_batch_dev(d.ptr, n, k, mont=False)
+                d.free()
+                for j in range(k):
+                    w, winf = cref.msm(cid, g, scs[j * n:(j + 1) * n], scalars_mont=False, threads=8)
+                    assert bool(ginf[j]) == bool(winf) and (winf or np.array_equal(got[j], w)), (variant, bits, k, j)
+        srs.close()

@@ -65,6 +65,50 @@ def test_field_ops(khip, fid, F):
     assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("fid,F", [(0, P.Fp), (1, P.Fq)])
+def test_field29_ops(khip, fid, F):
+    """field29.cuh (nine 29-bit limbs, R' = 2^261, lazy reduction -- the arithmetic of k_accumulate29): product, squaring,
+    the repacking, and the unreduced 32 X form of a table coordinate, bit-exact against the oracle after conversion back."""
+    rng = np.random.default_rng(300 + fid)
+    e = edge_fe(F)
+    a = np.concatenate([np.repeat(e, len(e), axis=0), rand_fe(rng, 30000, F)])
+    b = np.concatenate([np.tile(e, (len(e), 1)), rand_fe(rng, 30000, F)])
+    want = cref.field_op(fid, "mul", a, b)
+    assert np.array_equal(khip.debug_field_op(fid, "mul29", a, b), want)
+    assert np.array_equal(khip.debug_field_op(fid, "mul29_32x", a, b), want)
+    assert np.array_equal(khip.debug_field_op(fid, "sqr29", a), cref.field_op(fid, "sqr", a))
+    assert np.array_equal(khip.debug_field_op(fid, "pack29", a), a)
+
+
+@pytest.mark.parametrize("cid", [0, 1])
+def test_madd29(khip, cid):
+    """The lazy mixed addition of field29.cuh: 2P + Q equals the oracle's group law on generic operands, and every
+    exceptional case (Q = 2P, Q = -2P, identity accumulator) is DECLINED (flag 2) instead of computed -- the accumulation
+    kernel hands such tasks to the exact path."""
+    n = 2048
+    g = cref.srs_generate(cid, 0, n, threads=8)
+    rng = np.random.default_rng(25 + cid)
+    p, q = g, g[rng.permutation(n)].copy()
+    base_fid = 1 if cid == 0 else 0
+    pinf = np.zeros(n, np.uint8); qinf = np.zeros(n, np.uint8)
+    q[0] = p[0]                                                           # 2P + P: generic
+    for i in (5, 70):                                                     # Q = 2P
+        q[i] = cref.point_add(cid, p[i], p[i], False, False)[0]
+    for i in (6, 71):                                                     # Q = -2P
+        d = cref.point_add(cid, p[i], p[i], False, False)[0]
+        d[4:] = cref.field_op(base_fid, "sub", np.zeros((1, 4), np.uint64), d[4:].reshape(1, 4))[0]
+        q[i] = d
+    pinf[[7, 72]] = 1                                                     # accumulator = identity
+    got, flag = khip.debug_point_op(cid, 6, p, q, pinf, qinf)
+    for i in range(n):
+        if i in (5, 70, 6, 71, 7, 72):
+            assert flag[i] == 2, i
+            continue
+        d, _ = cref.point_add(cid, p[i], p[i], False, False)
+        w, winf = cref.point_add(cid, d, q[i], False, False)
+        assert flag[i] == 0 and not winf and np.array_equal(got[i], w), i
+
+
 # ------------------------------------------------------------------ group law on the device
 @pytest.mark.parametrize("cid", [0, 1])
 def test_point_ops(khip, cid):
