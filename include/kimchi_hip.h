@@ -48,9 +48,19 @@ typedef struct kh_srs kh_srs_t;
 
 /* ---- device ------------------------------------------------------------- */
 int kh_device_count(void);
-/* Selects the HIP device used by this process (one process per GPU) and creates
- * the library's streams.  Idempotent; kh_init(-1) picks LOCAL_RANK or device 0. */
+/* Initialises a device (streams, workspaces) and makes it the calling thread's current device; the FIRST device
+ * initialised is also the process default, i.e. what every other thread uses until it chooses otherwise.  Idempotent;
+ * kh_init(-1) picks the current choice, else LOCAL_RANK, else device 0.  One process per GPU (torch.distributed
+ * ranks) needs nothing else.  A single process may also drive SEVERAL GPUs: each device has its own context (streams,
+ * four MSM pipeline slots, caches); an SRS handle lives on the device that was current when it was created and every
+ * entry point taking a handle (kh_msm*, kh_commit*, kh_ipa_*, ...) runs on the handle's device whatever the calling
+ * thread's current device is -- a Rust prover holds Vesta on GPU 0 and Pallas on GPU 1 (BASELINE config 5), or shards
+ * one MSM over 8 handles created with kh_srs_create_device_range (config 4), from ordinary rayon threads.  Entry points
+ * WITHOUT a handle (kh_ntt*, kh_lde*, kh_dev_alloc, the vector steps) use the calling thread's current device. */
 int kh_init(int device_id);
+int kh_set_device(int device_id);     /* thread-local: this thread's current device from now on (initialised on first use) */
+int kh_get_device(void);              /* the calling thread's current device (-1 before any initialisation) */
+int kh_trim(void);                    /* current device: free cached twiddle tables, scratch and idle MSM workspaces (rebuilt on demand) */
 const char *kh_last_error(void);
 
 /* ---- SRS: device-resident bases ------------------------------------------
@@ -59,6 +69,7 @@ const char *kh_last_error(void);
 int kh_srs_create(int curve, const uint64_t *g_xy /* n x 8 limbs */, size_t n, kh_srs_t **out);
 void kh_srs_free(kh_srs_t *srs);
 size_t kh_srs_size(const kh_srs_t *srs);
+int kh_srs_device(const kh_srs_t *srs);   /* the device the handle's tables live on */
 
 /* SRS::create (poly-commitment/src/ipa.rs:751-778) on the host: g_start .. g_{start+count-1}
  * (Blake2b-512 of the big-endian u32 index -> Shallue-van de Woestijne map, groupmap/src/lib.rs:74-189)

@@ -16,40 +16,79 @@ void set_error(const char* fmt, ...) {
     g_err = buf;
 }
 
-Context& ctx() { static Context c; return c; }
+// One context per device, created on first use and never destroyed (a destructor running after the HIP runtime has shut
+// down would call into it).  A single process can therefore hold Vesta on GPU 0 and Pallas on GPU 1 (BASELINE config 5)
+// or shard one MSM over all GPUs of the node (config 4) from its own threads; one-process-per-GPU works as before.
+static Context* g_ctx[KH_MAX_DEVICES];
+static std::mutex g_ctx_mu;
+static int g_default_dev = -1;                 // first device initialised (guarded by g_ctx_mu)
+static thread_local int tl_dev = -1;           // this thread's choice (kh_set_device / kh_init / DeviceScope); -1: process default
+static thread_local int tl_hip_dev = -1;       // what this thread last passed to hipSetDevice
+
+static int current_device() {
+    if (tl_dev >= 0) return tl_dev;
+    std::lock_guard<std::mutex> lk(g_ctx_mu);
+    return g_default_dev;
+}
+static Context& ctx_of(int dev) {
+    if (dev < 0 || dev >= KH_MAX_DEVICES) dev = 0;
+    std::lock_guard<std::mutex> lk(g_ctx_mu);
+    if (!g_ctx[dev]) g_ctx[dev] = new Context;
+    return *g_ctx[dev];
+}
+Context& ctx() { return ctx_of(current_device()); }
+
+static int bind_thread(int dev) {
+    if (tl_hip_dev != dev) { KH_HIP(hipSetDevice(dev)); tl_hip_dev = dev; }
+    return KH_OK;
+}
+DeviceScope::DeviceScope(int device) : prev(tl_dev) {
+    if (device >= 0) { tl_dev = device; if (tl_hip_dev != device && hipSetDevice(device) == hipSuccess) tl_hip_dev = device; }
+}
+DeviceScope::~DeviceScope() { tl_dev = prev; }
 
 static int do_init(int device_id) {
-    Context& C = ctx();
-    std::lock_guard<std::mutex> lk(C.mu);
-    if (C.ready) return KH_OK;
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
     if (e != hipSuccess || count <= 0) {
         set_error("no HIP device available (%s); libkimchi_hip has no CPU fallback", e == hipSuccess ? "count=0" : hipGetErrorString(e));
         return KH_E_DEVICE;
     }
+    if (device_id < 0) device_id = current_device();
     if (device_id < 0) {
         const char* lr = getenv("LOCAL_RANK");
         device_id = lr ? atoi(lr) % count : 0;
     }
-    KH_REQUIRE(device_id < count, "device %d out of range (count=%d)", device_id, count);
-    KH_HIP(hipSetDevice(device_id));
-    for (int i = 0; i < MSM_SLOTS; i++) {
-        KH_HIP(hipStreamCreateWithFlags(&C.slot[i].stream, hipStreamNonBlocking));
-        KH_HIP(hipEventCreateWithFlags(&C.slot[i].done, hipEventDisableTiming));
-        int rc2 = C.slot[i].timer.init(); if (rc2) return rc2;
+    KH_REQUIRE(device_id < count && device_id < KH_MAX_DEVICES, "device %d out of range (count=%d)", device_id, count);
+    Context& C = ctx_of(device_id);
+    std::lock_guard<std::mutex> lk(C.mu);
+    int rc = bind_thread(device_id); if (rc) return rc;
+    if (!C.ready) {
+        for (int i = 0; i < MSM_SLOTS; i++) {
+            KH_HIP(hipStreamCreateWithFlags(&C.slot[i].stream, hipStreamNonBlocking));
+            KH_HIP(hipEventCreateWithFlags(&C.slot[i].done, hipEventDisableTiming));
+            int rc2 = C.slot[i].timer.init(); if (rc2) return rc2;
+        }
+        C.stream = C.slot[0].stream;         // four streams = the four hardware queues HIP gives a process by default; a fifth would share one
+        KH_HIP(hipEventCreateWithFlags(&C.order_ev, hipEventDisableTiming));
+        hipDeviceProp_t prop;
+        KH_HIP(hipGetDeviceProperties(&prop, device_id));
+        C.num_cus = prop.multiProcessorCount;
+        if ((rc = C.timer.init())) return rc;
+        C.device = device_id;
+        C.ready = true;
     }
-    C.stream = C.slot[0].stream;         // four streams = the four hardware queues HIP gives a process by default; a fifth would share one
-    KH_HIP(hipEventCreateWithFlags(&C.order_ev, hipEventDisableTiming));
-    hipDeviceProp_t prop;
-    KH_HIP(hipGetDeviceProperties(&prop, device_id));
-    C.num_cus = prop.multiProcessorCount;
-    int rc = C.timer.init(); if (rc) return rc;
-    C.device = device_id;
-    C.ready = true;
+    {
+        std::lock_guard<std::mutex> g(g_ctx_mu);
+        if (g_default_dev < 0) g_default_dev = device_id;
+    }
     return KH_OK;
 }
-int ensure_init() { return ctx().ready ? KH_OK : do_init(-1); }
+int ensure_init() {
+    const int dev = current_device();
+    if (dev < 0 || !ctx_of(dev).ready) return do_init(dev);
+    return bind_thread(dev);
+}
 
 void collect_timings(Context& C, PhaseTimer& T) {
     C.last.clear();
@@ -69,6 +108,7 @@ using namespace kh;
 
 struct kh_srs {
     int curve = 0;
+    int device = -1;          // the device its tables live on: every entry point taking this handle runs there
     size_t n = 0;
     DevBuf g;                 // window tables of g_stride = n + 2 points: g[0..n), then the slots of H and U
     size_t g_stride = 0;      // (the two extra bases of the opening rounds, written by kh_ipa_begin)
@@ -79,8 +119,9 @@ struct kh_srs {
     hipEvent_t ipa_ev = nullptr;
     uint64_t h[8];
     std::map<unsigned, std::vector<std::unique_ptr<LagrangeChunk>>> lagrange;
-    std::mutex mu;
+    ~kh_srs() { if (ipa_ev) (void)hipEventDestroy(ipa_ev); }      // the DevBufs free themselves
 };
+#define KH_ON_DEVICE_OF(srs) kh::DeviceScope dev_scope_((srs) ? (srs)->device : -1)
 
 struct EndoPair { uint64_t q[4], r[4]; };
 static const EndoPair& cached_endos(int curve) {
@@ -113,7 +154,40 @@ int kh_device_count(void) {
     if (hipGetDeviceCount(&count) != hipSuccess) return 0;
     return count;
 }
-int kh_init(int device_id) { return do_init(device_id); }
+int kh_init(int device_id) {
+    int rc = do_init(device_id); if (rc) return rc;
+    if (device_id >= 0) tl_dev = device_id;          // an explicit choice also becomes this thread's current device
+    return KH_OK;
+}
+int kh_set_device(int device_id) {
+    KH_REQUIRE(device_id >= 0, "kh_set_device: negative device id");
+    int rc = do_init(device_id); if (rc) return rc;
+    tl_dev = device_id;
+    return KH_OK;
+}
+int kh_get_device(void) { return current_device(); }
+int kh_srs_device(const kh_srs_t* srs) { return srs ? srs->device : -1; }
+// releases the caches a long-lived process accumulates on the current device: twiddle tables, LDE / scan / expression
+// scratch, the slots' MSM workspaces (everything is re-created on demand)
+int kh_trim(void) {
+    int rc = ensure_init(); if (rc) return rc;
+    Context& C = ctx();
+    std::lock_guard<std::mutex> lk(C.mu);
+    for (int i = 0; i < MSM_SLOTS; i++) {
+        KH_REQUIRE(!C.slot[i].busy, "kh_trim: an MSM is in flight (kh_msm_wait first)");
+        KH_HIP(hipStreamSynchronize(C.slot[i].stream));
+    }
+    for (int i = 0; i < MSM_SLOTS; i++) {
+        MsmSlot& S = C.slot[i];
+        if (S.gexec) { (void)hipGraphExecDestroy(S.gexec); S.gexec = nullptr; S.gkey = 0; S.gseen = 0; }
+        for (DevBuf* b : {&S.ws_scalars, &S.ws_digits, &S.ws_hist, &S.ws_cnt, &S.ws_off, &S.ws_ntask, &S.ws_toff, &S.ws_entries, &S.ws_partial, &S.ws_buckets,
+                          &S.ws_seg, &S.ws_out, &S.ws_scan_tmp, &S.ws_biglist, &S.ws_points, &S.ws_order, &S.ws_chunks, &S.ws_handed}) b->release();
+    }
+    C.ws_ntt_a.release(); C.ws_ntt_b.release();
+    C.trim_scratch();
+    ntt_trim(C);
+    return KH_OK;
+}
 const char* kh_last_error(void) { return g_err.c_str(); }
 
 int kh_srs_create(int curve, const uint64_t* g_xy, size_t n, kh_srs_t** out) {
@@ -123,6 +197,7 @@ int kh_srs_create(int curve, const uint64_t* g_xy, size_t n, kh_srs_t** out) {
     std::unique_ptr<kh_srs> s(new kh_srs);
     s->curve = curve; s->n = n;
     Context& C = ctx();
+    s->device = C.device;
     std::lock_guard<std::mutex> lk(C.mu);
     const bool pre = n >= MSM_PRECOMP_MIN_N && !getenv("KH_NO_PRECOMP");
     const int W = (256 + MSM_PRECOMP_C - 1) / MSM_PRECOMP_C;
@@ -148,6 +223,7 @@ int kh_srs_create_device_range(int curve, size_t start, size_t depth, kh_srs_t**
     std::unique_ptr<kh_srs> s(new kh_srs);
     s->curve = curve; s->n = depth;
     Context& C = ctx();
+    s->device = C.device;
     std::lock_guard<std::mutex> lk(C.mu);
     const bool pre = depth >= MSM_PRECOMP_MIN_N && !getenv("KH_NO_PRECOMP");
     const int W = (256 + MSM_PRECOMP_C - 1) / MSM_PRECOMP_C;
@@ -165,6 +241,7 @@ int kh_srs_create_device_range(int curve, size_t start, size_t depth, kh_srs_t**
     return KH_OK;
 }
 int kh_srs_get_g(kh_srs_t* srs, size_t offset, size_t count, uint64_t* out_xy) {
+    KH_ON_DEVICE_OF(srs);
     KH_REQUIRE(srs && (out_xy || count == 0), "kh_srs_get_g: null argument");
     KH_REQUIRE(offset + count <= srs->n, "range [%zu, %zu) beyond the SRS size %zu", offset, offset + count, srs->n);
     Context& C = ctx();
@@ -174,20 +251,16 @@ int kh_srs_get_g(kh_srs_t* srs, size_t offset, size_t count, uint64_t* out_xy) {
 }
 void kh_srs_free(kh_srs_t* srs) {
     if (!srs) return;
+    KH_ON_DEVICE_OF(srs);
     Context& C = ctx();
     std::lock_guard<std::mutex> lk(C.mu);
-    if (srs->g.p) (void)hipFree(srs->g.p);
-    for (int i = 0; i < 2; i++) { srs->ipa_a[i].release(); srs->ipa_b[i].release(); srs->ipa_coef[i].release(); }
-    srs->ipa_sc.release(); srs->ipa_partial.release();
-    if (srs->ipa_ev) (void)hipEventDestroy(srs->ipa_ev);
-    for (auto& kv : srs->lagrange)
-        for (auto& ch : kv.second)
-            if (ch) { if (ch->pts.p) (void)hipFree(ch->pts.p); if (ch->inf.p) (void)hipFree(ch->inf.p); }
-    delete srs;
+    for (int i = 0; i < MSM_SLOTS; i++) if (C.slot[i].stream) (void)hipStreamSynchronize(C.slot[i].stream);   // nothing may still read its tables
+    delete srs;                       // the handle's buffers (tables, Lagrange chunks, opening workspace) free themselves
 }
 size_t kh_srs_size(const kh_srs_t* srs) { return srs ? srs->n : 0; }
 
 int kh_srs_set_lagrange(kh_srs_t* srs, unsigned log2_domain, unsigned chunk, const uint64_t* xy, const uint8_t* inf, size_t n) {
+    KH_ON_DEVICE_OF(srs);
     KH_REQUIRE(srs && xy, "kh_srs_set_lagrange: null argument");
     KH_REQUIRE(log2_domain <= 32 && n == ((size_t)1 << log2_domain), "basis must have 2^log2_domain = %zu points, got %zu", (size_t)1 << log2_domain, n);
     int rc = ensure_init(); if (rc) return rc;
@@ -219,10 +292,14 @@ int kh_srs_set_lagrange(kh_srs_t* srs, unsigned log2_domain, unsigned chunk, con
 }
 int kh_srs_lagrange_chunks(const kh_srs_t* srs, unsigned log2_domain) {
     if (!srs) return 0;
+    KH_ON_DEVICE_OF(srs);
+    Context& C = ctx();
+    std::lock_guard<std::mutex> lk(C.mu);              // kh_srs_set_lagrange / kh_srs_compute_lagrange mutate the map under it
     auto it = srs->lagrange.find(log2_domain);
     return it == srs->lagrange.end() ? 0 : (int)it->second.size();
 }
 int kh_srs_compute_lagrange(kh_srs_t* srs, unsigned log2_domain) {
+    KH_ON_DEVICE_OF(srs);
     KH_REQUIRE(srs, "null SRS handle");
     KH_REQUIRE(log2_domain <= 28, "log2_domain = %u too large", log2_domain);
     int rc = ensure_init(); if (rc) return rc;
@@ -252,10 +329,11 @@ int kh_srs_compute_lagrange(kh_srs_t* srs, unsigned log2_domain) {
     return KH_OK;
 }
 int kh_srs_get_lagrange(kh_srs_t* srs, unsigned log2_domain, unsigned chunk, uint64_t* out_xy, uint8_t* out_inf) {
+    KH_ON_DEVICE_OF(srs);
     KH_REQUIRE(srs && out_xy, "kh_srs_get_lagrange: null argument");
-    MsmBasis b; int rc = resolve_basis(srs, (int)log2_domain, chunk, b); if (rc) return rc;
     Context& C = ctx();
     std::lock_guard<std::mutex> lk(C.mu);
+    MsmBasis b; int rc = resolve_basis(srs, (int)log2_domain, chunk, b); if (rc) return rc;
     KH_HIP(hipMemcpy(out_xy, b.pts, b.n * 64, hipMemcpyDeviceToHost));
     if (out_inf) {
         if (b.inf) KH_HIP(hipMemcpy(out_inf, b.inf, b.n, hipMemcpyDeviceToHost));
@@ -323,6 +401,7 @@ static int wait_then_finish(std::unique_lock<std::mutex>& lk, Context& C, MsmSlo
 }
 static int msm_common(kh_srs_t* srs, int basis, unsigned chunk, size_t offset, const uint64_t* scalars, bool scalars_on_device,
                       size_t n, size_t k, int mont, uint64_t* out_xy, uint8_t* out_inf) {
+    KH_ON_DEVICE_OF(srs);
     KH_REQUIRE(out_xy && out_inf, "null output pointer");
     KH_REQUIRE(scalars || n == 0 || k == 0, "null scalars");
     int rc = ensure_init(); if (rc) return rc;
@@ -335,6 +414,7 @@ static int msm_common(kh_srs_t* srs, int basis, unsigned chunk, size_t offset, c
 
 int kh_msm_submit(kh_srs_t* srs, int basis, unsigned chunk, size_t offset, const uint64_t* scalars_dev, size_t n, size_t k,
                   int scalars_are_montgomery, uint64_t* ticket) {
+    KH_ON_DEVICE_OF(srs);
     KH_REQUIRE(ticket, "null ticket pointer");
     KH_REQUIRE(scalars_dev || n == 0 || k == 0, "null scalars");
     int rc = ensure_init(); if (rc) return rc;
@@ -342,16 +422,18 @@ int kh_msm_submit(kh_srs_t* srs, int basis, unsigned chunk, size_t offset, const
     std::lock_guard<std::mutex> lk(C.mu);
     int si = -1;
     if ((rc = msm_submit_locked(C, srs, basis, chunk, offset, scalars_dev, true, n, k, scalars_are_montgomery, &si))) return rc;
-    *ticket = C.slot[si].ticket;
+    *ticket = C.slot[si].ticket | ((uint64_t)C.device << 56);      // the device rides in the top byte: kh_msm_wait may run on any thread
     return KH_OK;
 }
 int kh_msm_wait(uint64_t ticket, uint64_t* out_xy, uint8_t* out_is_inf) {
     KH_REQUIRE(out_xy && out_is_inf, "null output pointer");
+    kh::DeviceScope dev_scope_((int)(ticket >> 56));
     int rc = ensure_init(); if (rc) return rc;
     Context& C = ctx();
     std::unique_lock<std::mutex> lk(C.mu);
+    const uint64_t seq = ticket & (((uint64_t)1 << 56) - 1);
     for (int i = 0; i < MSM_SLOTS; i++)
-        if (C.slot[i].busy && C.slot[i].ticket == ticket) return wait_then_finish(lk, C, C.slot[i], out_xy, out_is_inf);
+        if (C.slot[i].busy && C.slot[i].ticket == seq) return wait_then_finish(lk, C, C.slot[i], out_xy, out_is_inf);
     set_error("unknown or already waited MSM ticket %llu", (unsigned long long)ticket);
     return KH_E_INVALID;
 }
@@ -432,6 +514,7 @@ static bool limbs_zero(const uint64_t* p) { return (p[0] | p[1] | p[2] | p[3]) =
 
 int kh_commit_non_hiding(kh_srs_t* srs, const uint64_t* coeffs, size_t len, size_t num_chunks,
                          uint64_t* out_xy, uint8_t* out_inf, size_t* out_count) {
+    KH_ON_DEVICE_OF(srs);
     KH_REQUIRE(srs && out_xy && out_inf && out_count, "kh_commit_non_hiding: null argument");
     KH_REQUIRE(coeffs || len == 0, "null coefficients");
     while (len > 0 && limbs_zero(coeffs + 4 * (len - 1))) len--;       // DensePolynomial drops leading zero coefficients
@@ -459,6 +542,7 @@ int kh_commit_non_hiding(kh_srs_t* srs, const uint64_t* coeffs, size_t len, size
 
 int kh_commit_evaluations_non_hiding(kh_srs_t* srs, unsigned log2_domain, const uint64_t* evals, size_t evals_len,
                                      uint64_t* out_xy, uint8_t* out_inf, size_t* out_count) {
+    KH_ON_DEVICE_OF(srs);
     KH_REQUIRE(srs && evals && out_xy && out_inf && out_count, "kh_commit_evaluations_non_hiding: null argument");
     const size_t n = (size_t)1 << log2_domain;
     KH_REQUIRE(evals_len >= n, "desired commitment domain size (%zu) greater than evaluations' domain size (%zu)", n, evals_len);
@@ -697,7 +781,8 @@ int kh_expr_evaluations_dev(int field, const uint32_t* tokens, size_t ntok, cons
 }
 
 // ---------------------------------------------------------------------------------- challenge polynomials (verifier side)
-static DevBuf g_bp_chals, g_bp_out;
+#define g_bp_chals (kh::ctx().scratch("bp_chals"))
+#define g_bp_out (kh::ctx().scratch("bp_out"))
 static std::mutex g_bp_mu;      // the coefficient buffer is shared: one challenge-polynomial call at a time
 static int bpoly_to_device(Context& C, int field, const uint64_t* chals, unsigned rounds, size_t k, const uint64_t* rs, bool reduce) {
     const size_t len = (size_t)1 << rounds;
@@ -726,6 +811,7 @@ int kh_b_poly_coefficients(int field, const uint64_t* chals, unsigned rounds, si
     return KH_OK;
 }
 int kh_batch_dlog_accumulator_generate(kh_srs_t* srs, size_t num_comms, const uint64_t* chals, size_t chals_len, uint64_t* out_xy, uint8_t* out_inf) {
+    KH_ON_DEVICE_OF(srs);
     KH_REQUIRE(srs, "null SRS handle");
     if (num_comms == 0) { KH_REQUIRE(chals_len == 0, "chals must be empty when num_comms is 0 (utils.rs:290-293)"); return KH_OK; }
     KH_REQUIRE(chals && out_xy && out_inf, "null argument");
@@ -747,6 +833,7 @@ int kh_batch_dlog_accumulator_generate(kh_srs_t* srs, size_t num_comms, const ui
 }
 int kh_batch_dlog_accumulator_check(kh_srs_t* srs, const uint64_t* comms_xy, const uint8_t* comms_inf, size_t k,
                                     const uint64_t* chals, size_t chals_len, const uint64_t r[4], int* ok) {
+    KH_ON_DEVICE_OF(srs);
     KH_REQUIRE(srs && ok, "null argument");
     if (k == 0) { KH_REQUIRE(chals_len == 0, "chals must be empty without commitments (utils.rs:219-222)"); *ok = 1; return KH_OK; }
     KH_REQUIRE(comms_xy && chals && r, "null argument");
@@ -782,6 +869,7 @@ int kh_batch_dlog_accumulator_check(kh_srs_t* srs, const uint64_t* comms_xy, con
 // delta with the scalars of ipa.rs:405-470) as an ad-hoc MSM; *is_zero = the verifier's `msm_res == zero` test.
 int kh_ipa_verify_msm(kh_srs_t* srs, const uint64_t* chals, size_t chals_len, const uint64_t* sg_weights, size_t k,
                       const uint64_t* extra_xy, const uint8_t* extra_inf, const uint64_t* extra_scalars, size_t m, int* is_zero) {
+    KH_ON_DEVICE_OF(srs);
     KH_REQUIRE(srs && is_zero, "null argument");
     KH_REQUIRE(k == 0 || (chals && sg_weights), "null challenges");
     KH_REQUIRE(m == 0 || (extra_xy && extra_scalars), "null extra points");
@@ -813,7 +901,7 @@ struct kh_ipa {
     int curve = 0, field = 0;
     size_t n = 0, cur = 0, ncoef = 1;     // basis size, current vector length N_j, challenge tensor length 2^j
     DevBuf *a = nullptr, *b = nullptr, *coef = nullptr;   // the SRS handle's workspace (ping-pong pairs)
-    DevBuf sc, partial;                                   // views of srs->ipa_sc / ipa_partial
+    DevBuf *sc = nullptr, *partial = nullptr;             // srs->ipa_sc / ipa_partial
     int pp = 0;
     hipEvent_t ev = nullptr;              // orders the fold (library stream) before the next round's MSM (slot stream)
     bool lr_done = false;
@@ -821,6 +909,7 @@ struct kh_ipa {
 
 static int ipa_begin_common(kh_srs_t* srs, const uint64_t* a, size_t a_len, const uint64_t* b, size_t b_len, const uint64_t u_base_xy[8], kh_ipa_t** out,
                             hipMemcpyKind kind) {
+    KH_ON_DEVICE_OF(srs);
     KH_REQUIRE(srs && out && a && b && u_base_xy, "kh_ipa_begin: null argument");
     const size_t n = srs->n;
     KH_REQUIRE((n & (n - 1)) == 0, "the opening rounds need a power-of-two SRS (size %zu)", n);
@@ -840,7 +929,7 @@ static int ipa_begin_common(kh_srs_t* srs, const uint64_t* a, size_t a_len, cons
     if ((rc = srs->ipa_sc.reserve(2 * (n + 2) * 32))) return rc;
     if ((rc = srs->ipa_partial.reserve(2 * 64 * 32))) return rc;
     if (!srs->ipa_ev) KH_HIP(hipEventCreateWithFlags(&srs->ipa_ev, hipEventDisableTiming));
-    st->a = srs->ipa_a; st->b = srs->ipa_b; st->coef = srs->ipa_coef; st->sc = srs->ipa_sc; st->partial = srs->ipa_partial; st->ev = srs->ipa_ev;
+    st->a = srs->ipa_a; st->b = srs->ipa_b; st->coef = srs->ipa_coef; st->sc = &srs->ipa_sc; st->partial = &srs->ipa_partial; st->ev = srs->ipa_ev;
     // H and U into the two extra slots of every window table
     const int W = srs->g_precomp_c ? (256 + srs->g_precomp_c - 1) / srs->g_precomp_c : 1;
     std::vector<uint64_t> tab((size_t)W * 16), col((size_t)W * 8);
@@ -873,6 +962,7 @@ int kh_ipa_rounds_left(const kh_ipa_t* st) {
     return r;
 }
 int kh_ipa_round_lr(kh_ipa_t* st, const uint64_t rand_l[4], const uint64_t rand_r[4], uint64_t lr_xy[16], uint8_t lr_inf[2]) {
+    kh::DeviceScope dev_scope_((st && st->srs) ? st->srs->device : -1);
     KH_REQUIRE(st && rand_l && rand_r && lr_xy && lr_inf, "kh_ipa_round_lr: null argument");
     KH_REQUIRE(st->cur > 1, "no round left: the vectors are folded to length 1");
     KH_REQUIRE(!st->lr_done, "kh_ipa_round_fold must follow kh_ipa_round_lr");
@@ -884,16 +974,17 @@ int kh_ipa_round_lr(kh_ipa_t* st, const uint64_t rand_l[4], const uint64_t rand_
     KH_HIP(hipStreamWaitEvent(S.stream, st->ev, 0));
     const int p = st->pp;
     int rc = ipa_round_prepare(S.stream, st->field, st->a[p].as<uint64_t>(), st->b[p].as<uint64_t>(), st->coef[p].as<uint64_t>(),
-                               st->n, st->cur, rand_l, rand_r, st->sc.as<uint64_t>(), st->partial.as<uint64_t>());
+                               st->n, st->cur, rand_l, rand_r, st->sc->as<uint64_t>(), st->partial->as<uint64_t>());
     if (rc) return rc;
     kh_srs_t* srs = st->srs;
     MsmBasis bs; bs.pts = srs->g.p; bs.inf = nullptr; bs.n = srs->g_stride; bs.stride = srs->g_stride; bs.precomp_c = srs->g_precomp_c;
-    if ((rc = msm_enqueue(C, S, st->curve, bs, 0, st->sc.as<uint64_t>(), st->n + 2, 2, 1, /*use_graph=*/1))) return rc;
+    if ((rc = msm_enqueue(C, S, st->curve, bs, 0, st->sc->as<uint64_t>(), st->n + 2, 2, 1, /*use_graph=*/1))) return rc;
     if ((rc = wait_then_finish(lk, C, S, lr_xy, lr_inf))) return rc;
     st->lr_done = true;
     return KH_OK;
 }
 int kh_ipa_round_fold(kh_ipa_t* st, const uint64_t chal[2], uint64_t u_out[4], uint64_t u_inv_out[4]) {
+    kh::DeviceScope dev_scope_((st && st->srs) ? st->srs->device : -1);
     KH_REQUIRE(st && chal, "kh_ipa_round_fold: null argument");
     KH_REQUIRE(st->lr_done, "kh_ipa_round_lr must precede kh_ipa_round_fold");
     uint64_t u[4], ui[4];
@@ -913,6 +1004,7 @@ int kh_ipa_round_fold(kh_ipa_t* st, const uint64_t chal[2], uint64_t u_out[4], u
     return KH_OK;
 }
 int kh_ipa_finish(kh_ipa_t* st, uint64_t a0[4], uint64_t b0[4], uint64_t sg_xy[8], uint8_t* sg_inf) {
+    kh::DeviceScope dev_scope_((st && st->srs) ? st->srs->device : -1);
     KH_REQUIRE(st && a0 && b0 && sg_xy && sg_inf, "kh_ipa_finish: null argument");
     KH_REQUIRE(st->cur == 1, "%d rounds still to run", kh_ipa_rounds_left(st));
     Context& C = ctx();
@@ -932,6 +1024,7 @@ int kh_ipa_finish(kh_ipa_t* st, uint64_t a0[4], uint64_t b0[4], uint64_t sg_xy[8
 }
 void kh_ipa_free(kh_ipa_t* st) {
     if (!st) return;
+    kh::DeviceScope dev_scope_(st->srs ? st->srs->device : -1);
     Context& C = ctx();
     std::lock_guard<std::mutex> lk(C.mu);
     (void)hipStreamSynchronize(C.stream);                 // a fold may still be in flight on the library stream
@@ -1056,7 +1149,7 @@ int kh_last_timings(const char** names, float* ms, int cap) {
     Context& C = ctx();
     std::lock_guard<std::mutex> lk(C.mu);
     int n = 0;
-    for (auto& kv : C.last) { if (n >= cap) break; names[n] = kv.first.c_str(); ms[n] = kv.second; n++; }
+    for (auto& kv : C.last) { if (n >= cap) break; names[n] = kv.first; ms[n] = kv.second; n++; }     // string literals: valid forever
     return n;
 }
 

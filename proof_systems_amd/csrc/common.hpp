@@ -6,7 +6,9 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <condition_variable>
+#include <map>
 #include <mutex>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -33,11 +35,17 @@ void set_error(const char* fmt, ...);
         }                                     \
     } while (0)
 
-// A grow-only device buffer (workspace).  Not thread-safe by itself: the owner
-// (Context) serialises users with its mutex.
+// A grow-only device buffer (workspace), owning its allocation (move-only; freed with its owner).  Not thread-safe
+// by itself: the owner (Context / SRS handle) serialises users with its mutex.
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    DevBuf(DevBuf&& o) noexcept : p(o.p), cap(o.cap) { o.p = nullptr; o.cap = 0; }
+    DevBuf& operator=(DevBuf&& o) noexcept { if (this != &o) { release(); p = o.p; cap = o.cap; o.p = nullptr; o.cap = 0; } return *this; }
+    ~DevBuf() { release(); }
     int reserve(size_t bytes) {
         if (bytes <= cap) return KH_OK;
         if (p) { hipError_t e = hipFree(p); (void)e; p = nullptr; cap = 0; }
@@ -113,16 +121,35 @@ struct Context {
     int num_cus = 256;
     PhaseTimer timer;                  // NTT / LDE phases (MSM phases are per slot)
     // last timings (filled after a sync)
-    std::vector<std::pair<std::string, float>> last;
+    std::vector<std::pair<const char*, float>> last;      // names are string literals (kh_last_timings hands them out)
     MsmSlot slot[MSM_SLOTS];
     uint64_t next_ticket = 1;
     // NTT workspace
     DevBuf ws_ntt_a, ws_ntt_b;
     void* pinned = nullptr; size_t pinned_cap = 0;
+    // named scratch buffers / one-time flags of the other translation units (what used to be function-local statics:
+    // a static is process-wide, these belong to ONE device).  References stay valid (std::map nodes do not move).
+    std::mutex scratch_mu;
+    std::map<std::string, DevBuf> scratch_bufs;
+    std::set<std::string> done_flags;
+    DevBuf& scratch(const char* name) { std::lock_guard<std::mutex> lk(scratch_mu); return scratch_bufs[name]; }
+    bool once(const char* name) { std::lock_guard<std::mutex> lk(scratch_mu); return done_flags.insert(name).second; }   // true the first time
+    void trim_scratch() { std::lock_guard<std::mutex> lk(scratch_mu); for (auto& kv : scratch_bufs) kv.second.release(); }
 };
+static constexpr int KH_MAX_DEVICES = 16;
 
+// The context of the calling thread's CURRENT device: the one an enclosing DeviceScope selected (entry points that
+// take an SRS / opening handle run on the handle's device), else the thread's kh_set_device / kh_init choice, else
+// the process default (the first device initialised).
 Context& ctx();
+// initialises the current device's context on first use and binds the calling thread to it (hipSetDevice is
+// per-thread state: every entry point must do this, not just the thread that ran kh_init)
 int ensure_init();
+struct DeviceScope {               // run the rest of this scope on `device` (no-op for device < 0)
+    int prev;
+    explicit DeviceScope(int device);
+    ~DeviceScope();
+};
 void collect_timings(Context& c, PhaseTimer& t);
 
 // device exclusive scan of n u32 values (in may alias out); tmp is workspace

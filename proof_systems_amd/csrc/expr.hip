@@ -82,7 +82,7 @@ k_expr(const u32* __restrict__ prog, u32 ntok, const u64* const* __restrict__ co
     }
 }
 
-static DevBuf g_expr_tab;
+#define g_expr_tab (kh::ctx().scratch("expr_tab"))
 
 // validates the program the way PolishToken::evaluate would fail (EmptyStack, final stack length != 1, Load of a
 // value never stored) and returns the LDS slots it needs
@@ -128,11 +128,9 @@ int expr_run(Context& C, int field, const uint32_t* prog, size_t ntok, const uin
     }
     if (nconsts) KH_HIP(hipMemcpyAsync(d_consts, consts, nconsts * 32, hipMemcpyHostToDevice, s));
     KH_HIP(hipMemcpyAsync(d_prog, prog, ntok * 8, hipMemcpyHostToDevice, s));
-    static bool attr_set = false;
-    if (!attr_set) {
+    if (C.once("expr_attr")) {
         KH_HIP(hipFuncSetAttribute((const void*)k_expr<FpParams>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         KH_HIP(hipFuncSetAttribute((const void*)k_expr<FqParams>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
     }
     dim3 grid((unsigned)((rows + EXPR_T - 1) / EXPR_T));
     C.timer.begin(s);

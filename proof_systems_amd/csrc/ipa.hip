@@ -260,7 +260,9 @@ int bpoly_run(hipStream_t s, int field, const uint64_t* chals_dev, unsigned roun
     return KH_OK;
 }
 
-static DevBuf g_ipa_a, g_ipa_b, g_ipa_c;
+#define g_ipa_a (kh::ctx().scratch("ipa_a"))
+#define g_ipa_b (kh::ctx().scratch("ipa_b"))
+#define g_ipa_c (kh::ctx().scratch("ipa_c"))
 
 int ipa_fold_scalars(Context& C, int field, const uint64_t* lo, const uint64_t* hi, const uint64_t u[4], size_t n, uint64_t* out) {
     int rc;

@@ -83,7 +83,7 @@ static int lagrange_t(Context& C, int sfield, const void* g_dev, size_t srs_size
     const size_t start = (size_t)chunk * srs_size;
     KH_REQUIRE(start < n, "chunk %u is beyond the domain", chunk);
     const size_t num_terms = ((size_t)(chunk + 1) * srs_size < n ? (size_t)(chunk + 1) * srs_size : n) - start;
-    static DevBuf A, tw;
+    DevBuf &A = C.scratch("lagrange_points"), &tw = C.scratch("lagrange_twiddles");
     int rc;
     if ((rc = A.reserve(n * 128))) return rc;
     const size_t half = n > 1 ? n / 2 : 1;

@@ -35,6 +35,7 @@
 #include "msm.hpp"
 #include <condition_variable>
 #include <functional>
+#include <memory>
 #include <thread>
 
 namespace kh {
@@ -61,7 +62,13 @@ class HostHelper {
     void run(std::function<void()> j) { { std::lock_guard<std::mutex> lk(m_); job_ = std::move(j); has_job_ = true; } cv_.notify_all(); }
     void wait() { std::unique_lock<std::mutex> lk(m_); done_cv_.wait(lk, [&] { return !has_job_ && !busy_; }); }
 };
-static HostHelper& host_helper() { static HostHelper h; return h; }
+static HostHelper& host_helper(int device) {           // one per device context (msm_finish runs under that context's lock)
+    static std::unique_ptr<HostHelper> h[KH_MAX_DEVICES]; static std::mutex mu;
+    std::lock_guard<std::mutex> lk(mu);
+    const int d = device >= 0 && device < KH_MAX_DEVICES ? device : 0;
+    if (!h[d]) h[d].reset(new HostHelper);
+    return *h[d];
+}
 
 // ------------------------------------------------------------------------------------ scan
 static constexpr int SCAN_T = 256, SCAN_I = 8, SCAN_B = SCAN_T * SCAN_I;
@@ -782,11 +789,9 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
         KH_HIP(hipHostMalloc(&C.pinned, nout * 128 + 4096, hipHostMallocDefault));
         C.pinned_cap = nout * 128 + 4096;
     }
-    static bool attr_set = false;
-    if (!attr_set) {
+    if (Ctx.once("msm_attr")) {
         KH_HIP(hipFuncSetAttribute((const void*)k_hist, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
         KH_HIP(hipFuncSetAttribute((const void*)k_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
-        attr_set = true;
     }
     // hipGraph replay / capture (opt-in by the caller; the key covers everything the launches bake in)
     static const bool graphs_off = getenv("KH_NO_GRAPH") != nullptr;
@@ -992,9 +997,10 @@ int msm_finish(Context& C, MsmSlot& S, uint64_t* out_xy, uint8_t* out_inf) {
     };
     if ((!S.precomp || S.planes) && S.k >= 2) {                     // split the Horner folds with the helper thread
         const size_t half = S.k / 2, kk = S.k;
-        host_helper().run([finish_one, half, kk] { for (size_t j = half; j < kk; j++) finish_one(j); });
+        HostHelper& hh = host_helper(C.device);
+        hh.run([finish_one, half, kk] { for (size_t j = half; j < kk; j++) finish_one(j); });
         for (size_t j = 0; j < half; j++) finish_one(j);
-        host_helper().wait();
+        hh.wait();
     } else {
         for (size_t j = 0; j < S.k; j++) finish_one(j);
     }
@@ -1020,14 +1026,14 @@ int msm_finish(Context& C, MsmSlot& S, uint64_t* out_xy, uint8_t* out_inf) {
 
 int msm_precompute(Context& C, int curve, void* tables, const uint8_t* inf, size_t n, int c) {
     const int W = (256 + c - 1) / c;
-    static DevBuf scratch;
+    DevBuf& scratch = C.scratch("precompute");
     int rc = scratch.reserve((size_t)(W - 1) * n * 128); if (rc) return rc;
     dim3 grid((unsigned)((n + 255) / 256));
     if (curve == KH_CURVE_VESTA) hipLaunchKernelGGL((k_precompute<FqParams>), grid, dim3(256), 0, C.stream, (uint8_t*)tables, inf, n, c, W, scratch.as<uint8_t>());
     else hipLaunchKernelGGL((k_precompute<FpParams>), grid, dim3(256), 0, C.stream, (uint8_t*)tables, inf, n, c, W, scratch.as<uint8_t>());
     KH_HIP(hipGetLastError());
     KH_HIP(hipStreamSynchronize(C.stream));
-    if (scratch.cap > ((size_t)1 << 30)) { (void)hipFree(scratch.p); scratch.p = nullptr; scratch.cap = 0; }   // do not pin GBs of scratch
+    if (scratch.cap > ((size_t)1 << 30)) scratch.release();     // do not pin GBs of scratch
     return KH_OK;
 }
 

@@ -30,6 +30,7 @@ int debug_point_op(Context& C, int curve, int op, const uint64_t* p, const uint8
 
 // ntt.hip
 int ntt_build_twiddles(Context& C, int field, unsigned logn, int inverse, uint64_t* tab);
+void ntt_trim(Context& C);
 // ipa.hip
 int ipa_fold_scalars(Context& C, int field, const uint64_t* lo, const uint64_t* hi, const uint64_t u[4], size_t n, uint64_t* out);
 int ipa_inner_product(Context& C, int field, const uint64_t* a, const uint64_t* b, size_t n, uint64_t out[4]);

@@ -187,9 +187,14 @@ __global__ void k_build_twiddles(u64* tw, const u64* pow2 /* w^(2^i), i < 32 */,
     acc.store(tw + 4 * e);
 }
 
-struct TwKey { int field; unsigned logn; int inverse; bool operator<(const TwKey& o) const { return std::tie(field, logn, inverse) < std::tie(o.field, o.logn, o.inverse); } };
+struct TwKey { int device; int field; unsigned logn; int inverse; bool operator<(const TwKey& o) const { return std::tie(device, field, logn, inverse) < std::tie(o.device, o.field, o.logn, o.inverse); } };
 struct TwEntry { DevBuf tab; khost::fe inv_n; };
-static std::map<TwKey, TwEntry> g_tw;
+static std::map<TwKey, TwEntry> g_tw;          // twiddle tables per (device, field, size, direction); guarded by the device context's mutex
+static std::mutex g_tw_mu;                      // ... and this one for the map itself (contexts of different devices share it)
+void ntt_trim(Context& C) {                     // kh_trim: drop this device's tables (rebuilt on demand, ~20 us per table)
+    std::lock_guard<std::mutex> lk(g_tw_mu);
+    for (auto it = g_tw.begin(); it != g_tw.end();) { if (it->first.device == C.device) it = g_tw.erase(it); else ++it; }
+}
 
 khost::fe ntt_host_root(int field, unsigned logn, int inverse) {
     // w_{2^k} = (5^T)^(2^(32-k)); T = (p-1) >> 32   (kimchi/src/circuits/domains.rs:40-69)
@@ -223,7 +228,8 @@ int ntt_build_twiddles(Context& C, int field, unsigned logn, int inverse, u64* t
 }
 
 static int get_twiddles(Context& C, int field, unsigned logn, int inverse, TwEntry** out) {
-    TwKey key{field, logn, inverse};
+    TwKey key{C.device, field, logn, inverse};
+    std::lock_guard<std::mutex> lk(g_tw_mu);
     auto it = g_tw.find(key);
     if (it != g_tw.end()) { *out = &it->second; return KH_OK; }
     TwEntry& E = g_tw[key];
@@ -250,8 +256,7 @@ static std::vector<unsigned> split_passes(unsigned log_n) {
 template <class F>
 static int launch_pass(Context& C, const PassArgs& A, u64 tiles) {
     size_t lds = ((size_t)4 << (A.log_R + A.log_T)) * 8 + ((size_t)4 << (A.log_R ? A.log_R - 1 : 0)) * 8;
-    static bool attr = false;
-    if (!attr) { KH_HIP(hipFuncSetAttribute((const void*)k_ntt_pass<F>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304)); attr = true; }
+    if (C.once(__PRETTY_FUNCTION__)) KH_HIP(hipFuncSetAttribute((const void*)k_ntt_pass<F>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304));
     hipLaunchKernelGGL((k_ntt_pass<F>), dim3((unsigned)tiles), dim3(NTT_THREADS), lds, C.stream, A);
     KH_HIP(hipGetLastError());
     return KH_OK;
@@ -328,7 +333,7 @@ int lde_run(Context& C, int field, const uint64_t* coeffs_dev, unsigned log2_n, 
         return ntt_run(C, field, out_dev, log2_n, 0, batch);
     }
     size_t bytes = (batch << (log2_n + log2_blowup)) * 32;
-    static DevBuf lde_tmp;
+    DevBuf& lde_tmp = C.scratch("lde_tmp");
     int rc = lde_tmp.reserve(bytes); if (rc) return rc;
     C.timer.begin(C.stream);
     if (field == KH_FIELD_FP) rc = transform<FpParams>(C, field, coeffs_dev, out_dev, lde_tmp.as<u64>(), log2_n, log2_blowup, 0, batch);

@@ -235,7 +235,7 @@ __global__ void k_linear_quotient(const u64* __restrict__ S, Fe4p a_inv, size_t 
         KH_HIP(hipGetLastError());                                                                      \
     } while (0)
 
-static DevBuf g_poly_tab;
+#define g_poly_tab (kh::ctx().scratch("poly_tab"))
 
 int poly_lincomb(Context& C, int field, const uint64_t* const* segs_dev, const size_t* lens, const uint64_t* scales, size_t m,
                  uint64_t* out_dev, size_t out_len) {
@@ -312,7 +312,9 @@ int poly_div_vanishing(Context& C, int field, const uint64_t* f_dev, size_t len,
         KH_HIP(hipGetLastError());                                                                                       \
     } while (0)
 
-static DevBuf g_scan_tot, g_scan_a, g_scan_b;
+#define g_scan_tot (kh::ctx().scratch("scan_tot"))
+#define g_scan_a (kh::ctx().scratch("scan_a"))
+#define g_scan_b (kh::ctx().scratch("scan_b"))
 
 static int scan_enqueue(hipStream_t s, int field, int op, int rev, uint64_t* data_dev, size_t n) {
     if (n == 0) return KH_OK;

@@ -28,7 +28,7 @@ MSM_SLOTS = 4          # KH_MSM_SLOTS: jobs kh_msm_submit accepts before kh_msm_
 
 # every symbol include/kimchi_hip.h declares
 SYMBOLS = [
-    "kh_device_count", "kh_init", "kh_last_error", "kh_srs_create", "kh_srs_free", "kh_srs_size",
+    "kh_device_count", "kh_init", "kh_set_device", "kh_get_device", "kh_trim", "kh_srs_device", "kh_last_error", "kh_srs_create", "kh_srs_free", "kh_srs_size",
     "kh_srs_set_lagrange", "kh_srs_compute_lagrange", "kh_srs_get_lagrange", "kh_srs_lagrange_chunks",
     "kh_msm", "kh_msm_batch", "kh_msm_points", "kh_ntt", "kh_lde",
     "kh_dev_alloc", "kh_dev_free", "kh_dev_upload", "kh_dev_download",
@@ -42,6 +42,8 @@ SYMBOLS = [
 ]
 
 _lib.kh_last_error.restype = C.c_char_p
+_lib.kh_set_device.argtypes = [C.c_int]
+_lib.kh_srs_device.argtypes = [C.c_void_p]
 _lib.kh_srs_size.restype = C.c_size_t
 _lib.kh_srs_size.argtypes = [C.c_void_p]
 _lib.kh_srs_free.restype = None
@@ -155,6 +157,19 @@ def device_count() -> int:
 
 def init(device: int = -1):
     _check(_lib.kh_init(device))
+
+
+def set_device(device: int):
+    """This THREAD's current device from now on (kh_set_device); handles keep running on the device they were created on."""
+    _check(_lib.kh_set_device(device))
+
+
+def get_device() -> int:
+    return _lib.kh_get_device()
+
+
+def trim():
+    _check(_lib.kh_trim())
 
 
 class Srs:
