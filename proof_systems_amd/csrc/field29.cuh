@@ -3,7 +3,7 @@
 // field.cuh keeps elements as eight 32-bit limbs, always fully reduced: every limb product costs a v_mad_u64_u32
 // PLUS a v_addc_co_u32 (the 64-bit column accumulator overflows), 254 instructions per Montgomery product.  Here a
 // 29 x 29-bit limb product is 58 bits, a whole column of the product scan fits one 64-bit accumulator, and the
-// product is 126 MADs + 60 bookkeeping instructions = 186 (squaring 158; tools/gen_field29_asm.py, which also
+// product is 131 MADs + 35 bookkeeping instructions = 166 (squaring 138; tools/gen_field29_asm.py, which also
 // checks the generated instruction streams and the limb model of madd29 below against big-integer arithmetic).
 //
 //   value(a) = sum a.v[i] 2^(29 i);  Montgomery radix R' = 2^261 = 128 p-ish, so there are 6 spare bits:
@@ -64,7 +64,7 @@ __device__ __forceinline__ Fe<F> unpack29(const Fe29<F>& a) {
     return r;
 }
 
-#define KH29_CONSTS typedef typename C29<F>::T K; const u32 p1 = K::P1, p2 = K::P2, p3 = K::P3, p4 = K::P4, c22 = 1u << 22, msk = MASK29
+#define KH29_CONSTS typedef typename C29<F>::T K; const u32 p1 = K::P1, p2 = K::P2, p3 = K::P3, p4 = K::P4, c22 = 1u << 22, msk = MASK29, pairk = (1u << 29) + 1u
 
 template <class F>
 __device__ __forceinline__ Fe29<F> mul29(const Fe29<F>& a, const Fe29<F>& b) {
@@ -74,7 +74,23 @@ __device__ __forceinline__ Fe29<F> mul29(const Fe29<F>& a, const Fe29<F>& b) {
         : "=&v"(r.v[0]), "=&v"(r.v[1]), "=&v"(r.v[2]), "=&v"(r.v[3]), "=&v"(r.v[4]), "=&v"(r.v[5]), "=&v"(r.v[6]), "=&v"(r.v[7]), "=&v"(r.v[8])
         : "v"(a.v[0]), "v"(a.v[1]), "v"(a.v[2]), "v"(a.v[3]), "v"(a.v[4]), "v"(a.v[5]), "v"(a.v[6]), "v"(a.v[7]), "v"(a.v[8]),
           "v"(b.v[0]), "v"(b.v[1]), "v"(b.v[2]), "v"(b.v[3]), "v"(b.v[4]), "v"(b.v[5]), "v"(b.v[6]), "v"(b.v[7]), "v"(b.v[8]),
-          "s"(p1), "s"(p2), "s"(p3), "s"(p4), "s"(c22), "s"(msk)
+          "s"(p1), "s"(p2), "s"(p3), "s"(p4), "s"(c22), "s"(msk), "v"(pairk)
+        : "vcc", "v2", "v3");
+    return r;
+}
+// (a b + c d) / R' mod p with ONE reduction: 212 MADs instead of 2 x 131 (and no subtraction afterwards when the caller
+// passes c = K p - c').  Column bound: both products may have one un-normalised operand (limbs < 1.5 * 2^30).
+template <class F>
+__device__ __forceinline__ Fe29<F> muladd29(const Fe29<F>& a, const Fe29<F>& b, const Fe29<F>& c, const Fe29<F>& d) {
+    Fe29<F> r;
+    KH29_CONSTS;
+    asm(KH29_MULADD_ASM
+        : "=&v"(r.v[0]), "=&v"(r.v[1]), "=&v"(r.v[2]), "=&v"(r.v[3]), "=&v"(r.v[4]), "=&v"(r.v[5]), "=&v"(r.v[6]), "=&v"(r.v[7]), "=&v"(r.v[8])
+        : "v"(a.v[0]), "v"(a.v[1]), "v"(a.v[2]), "v"(a.v[3]), "v"(a.v[4]), "v"(a.v[5]), "v"(a.v[6]), "v"(a.v[7]), "v"(a.v[8]),
+          "v"(b.v[0]), "v"(b.v[1]), "v"(b.v[2]), "v"(b.v[3]), "v"(b.v[4]), "v"(b.v[5]), "v"(b.v[6]), "v"(b.v[7]), "v"(b.v[8]),
+          "v"(c.v[0]), "v"(c.v[1]), "v"(c.v[2]), "v"(c.v[3]), "v"(c.v[4]), "v"(c.v[5]), "v"(c.v[6]), "v"(c.v[7]), "v"(c.v[8]),
+          "v"(d.v[0]), "v"(d.v[1]), "v"(d.v[2]), "v"(d.v[3]), "v"(d.v[4]), "v"(d.v[5]), "v"(d.v[6]), "v"(d.v[7]), "v"(d.v[8]),
+          "s"(p1), "s"(p2), "s"(p3), "s"(p4), "s"(c22), "s"(msk), "v"(pairk)
         : "vcc", "v2", "v3");
     return r;
 }
@@ -87,7 +103,7 @@ __device__ __forceinline__ Fe29<F> sqr29(const Fe29<F>& a) {
         : "=&v"(r.v[0]), "=&v"(r.v[1]), "=&v"(r.v[2]), "=&v"(r.v[3]), "=&v"(r.v[4]), "=&v"(r.v[5]), "=&v"(r.v[6]), "=&v"(r.v[7]), "=&v"(r.v[8]),
           "=&v"(d1), "=&v"(d2), "=&v"(d3), "=&v"(d4), "=&v"(d5), "=&v"(d6), "=&v"(d7), "=&v"(d8)
         : "v"(a.v[0]), "v"(a.v[1]), "v"(a.v[2]), "v"(a.v[3]), "v"(a.v[4]), "v"(a.v[5]), "v"(a.v[6]), "v"(a.v[7]), "v"(a.v[8]),
-          "s"(p1), "s"(p2), "s"(p3), "s"(p4), "s"(c22), "s"(msk)
+          "s"(p1), "s"(p2), "s"(p3), "s"(p4), "s"(c22), "s"(msk), "v"(pairk)
         : "vcc", "v2", "v3");
     return r;
 }
@@ -125,7 +141,7 @@ __device__ __forceinline__ Fe<F> from29(const Fe29<F>& a) {        // a < 100 p,
 }
 
 template <class F>
-struct Acc29 {                 // XYZZ accumulator in lazy R'-form: x < 6 p, y < 4 p, zz, zzz < 2 p, all normalised
+struct Acc29 {                 // XYZZ accumulator in lazy R'-form: x < 6 p, y < 4 p (after a madd29: < 1.4 p), zz, zzz < 2 p, all normalised
     Fe29<F> x, y, zz, zzz;
 };
 
@@ -143,17 +159,18 @@ __device__ __forceinline__ bool madd29(Acc29<F>& a, const Fe29<F>& px, const Fe2
     KH29_SUBN(R, S2, a.y, K::s51)
     const Fe29<F> PP = sqr29<F>(P);
     const Fe29<F> PPP = mul29<F>(P, PP), Q = mul29<F>(a.x, PP), RR = sqr29<F>(R);
-    Fe29<F> sub, rx, t, ry;
+    Fe29<F> sub, rx, t, yn;
 #pragma unroll
     for (int i = 0; i < 9; i++) sub.v[i] = PPP.v[i] + 2u * Q.v[i];
     KH29_SUBN(rx, RR, sub, K::s44)
 #pragma unroll
     for (int i = 0; i < 9; i++) t.v[i] = Q.v[i] + K::s61(i) - rx.v[i];          // not normalised: limbs < 2^29 + 2^30
-    const Fe29<F> m1 = mul29<F>(R, t), m2 = mul29<F>(a.y, PPP);
-    KH29_SUBN(ry, m1, m2, K::s21)
+#pragma unroll
+    for (int i = 0; i < 9; i++) yn.v[i] = K::s51(i) - a.y.v[i];                   // 5 p - y, not normalised
+    a.y = muladd29<F>(R, t, yn, PPP);                                           // R (Q - X3) - Y1 PPP, one reduction, < 1.4 p
     a.zz = mul29<F>(a.zz, PP);
     a.zzz = mul29<F>(a.zzz, PPP);
-    a.x = rx; a.y = ry;
+    a.x = rx;
     return true;
 }
 

@@ -312,7 +312,7 @@ k_accumulate(const u32* __restrict__ entries, const u32* __restrict__ off, const
 // group law; it only notices that one cannot be excluded (probability ~2^-25 per addition on random inputs), abandons
 // the task and flags it in handed[]: k_accumulate then redoes exactly those tasks with the exact formulas.  Finished
 // tasks are converted to the canonical wire form, so everything downstream is unchanged and the result stays bit-exact.
-template <class BF>
+template <class BF, bool PREFETCH>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(112)))
 k_accumulate29(const u32* __restrict__ entries, const u32* __restrict__ off, const u32* __restrict__ toff,
                const u32* __restrict__ roff, const u32* __restrict__ order,
@@ -340,6 +340,17 @@ k_accumulate29(const u32* __restrict__ entries, const u32* __restrict__ off, con
 #pragma unroll
     for (int i = 0; i < 9; i++) { acc.zz.v[i] = K29::one(i); acc.zzz.v[i] = K29::one(i); }
     bool ok = true;
+    if (PREFETCH) {                      // the next point's gather is issued before the current addition (16 more VGPRs)
+        Aff<BF> nx = p; u32 ne = 0;
+        if (start + 1 < end) { ne = entries[start + 1]; nx = Aff<BF>::load(pts + (size_t)(ne & 0x7fffffffu) * 64); }
+        for (u32 k = start + 1; k < end; k++) {
+            p = nx; e = ne;
+            if (k + 1 < end) { ne = entries[k + 1]; nx = Aff<BF>::load(pts + (size_t)(ne & 0x7fffffffu) * 64); }
+            if (e >> 31) p.y = neg<BF>(p.y);
+            ok = madd29<BF>(acc, pack29<BF, 5>(p.x), pack29<BF, 5>(p.y));
+            if (!ok) break;
+        }
+    } else
     for (u32 k = start + 1; k < end; k++) {
         e = entries[k];
         p = Aff<BF>::load(pts + (size_t)(e & 0x7fffffffu) * 64);
@@ -739,7 +750,8 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
     // 1.1 "rounds" of resident threads pays a whole extra chain at 10 % occupancy (measured: 1.80 ms
     // instead of 1.72 ms at 2^20).  Size K so that all tasks are resident at once (4 waves/SIMD =
     // 1024 threads per CU) whenever the bucket count allows it.
-    const size_t cap = (size_t)Ctx.num_cus * 1024;
+    static const size_t room_waves = getenv("KH_ROOM_WAVES") ? (size_t)atoi(getenv("KH_ROOM_WAVES")) : 4;     // waves per SIMD the task count is sized for
+    const size_t cap = (size_t)Ctx.num_cus * 256 * room_waves;
     size_t room_sz = cap / 4;                              // many buckets: about one task per bucket anyway
     if (nkeys < cap / 2) room_sz = cap - cap / 16 - nkeys / 2;   // ~ half of the buckets add a remainder task
     const u32 room = (u32)room_sz;                          // K = clamp(ceil(entries / room), 8, MAX_K), on the device
@@ -870,13 +882,15 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
     const uint8_t* handed = acc29 ? C.ws_handed.as<uint8_t>() : nullptr;
     const dim3 agrid((unsigned)((max_tasks + 255) / 256));
     if (acc29) {
+        static const bool prefetch = getenv("KH_ACC_PREFETCH") && atoi(getenv("KH_ACC_PREFETCH")) != 0;
+        auto kern = prefetch ? k_accumulate29<BF, true> : k_accumulate29<BF, false>;
         if (C.timer.enabled && C.timer.created && !gcap.active) {     // the dominant kernel's own start / stop timestamps (bench.py roofline)
-            hipExtLaunchKernelGGL((k_accumulate29<BF>), agrid, dim3(256), 0, s, C.timer.k0, C.timer.k1, 0,
+            hipExtLaunchKernelGGL(kern, agrid, dim3(256), 0, s, C.timer.k0, C.timer.k1, 0,
                                   C.ws_entries.as<u32>(), C.ws_off.as<u32>(), C.ws_toff.as<u32>(), roff, order, nkeys,
                                   (const uint8_t*)basis.pts, C.ws_partial.as<uint8_t>(), C.ws_handed.as<uint8_t>());
             C.timer.kname = "k_accumulate29";
         } else
-        hipLaunchKernelGGL((k_accumulate29<BF>), agrid, dim3(256), 0, s,
+        hipLaunchKernelGGL(kern, agrid, dim3(256), 0, s,
                            C.ws_entries.as<u32>(), C.ws_off.as<u32>(), C.ws_toff.as<u32>(), roff, order, nkeys,
                            (const uint8_t*)basis.pts, C.ws_partial.as<uint8_t>(), C.ws_handed.as<uint8_t>());
         hipLaunchKernelGGL((k_accumulate<BF>), agrid, dim3(256), 0, s,

@@ -37,44 +37,65 @@ def limbs29(x, n=9):
     return [(x >> (29 * i)) & MASK for i in range(n - 1)] + [x >> (29 * (n - 1))]
 
 
-def gen_mul(shift64=False):
+# Operand maps.  Outputs first (inline-asm numbering): %0-%8 r (early clobber; r_k holds m_k until column k+8).
+#   mul    : %9-%17 a, %18-%26 b, %27-%30 P1..P4, %31 2^22, %32 MASK (SGPRs), %33 2^29+1 (VGPR)
+#   sqr    : %9-%16 2*a_1..2*a_8 (scratch outputs), %17-%25 a, %26-%29 P1..P4, %30 2^22, %31 MASK, %32 2^29+1
+#   muladd : r = (a b + c d) / R':  %9-%17 a, %18-%26 b, %27-%35 c, %36-%44 d, %45-%48 P1..P4, %49 2^22, %50 MASK, %51 2^29+1
+def gen_mul(shift64=True):
     r = lambda i: f"%{i}"
     a = lambda i: f"%{9 + i}"
     b = lambda i: f"%{18 + i}"
     P = {1: "%27", 2: "%28", 3: "%29", 4: "%30", 8: "%31"}
-    return _gen(r, lambda i, j: (a(i), b(j)), P, "%32", [(i, k - i) for k in range(17) for i in range(9) if 0 <= k - i < 9], [], shift64)
+    prods = [(i + j, a(i), b(j)) for i in range(9) for j in range(9)]
+    return _gen(r, prods, P, "%32", "%33", [], shift64)
 
 
-def gen_sqr(shift64=False):
+def gen_sqr(shift64=True):
     r = lambda i: f"%{i}"
     d = lambda j: f"%{8 + j}"            # 2 * a_j, j = 1..8 -> %9..%16 (scratch OUTPUT operands)
     a = lambda i: f"%{17 + i}"
     P = {1: "%26", 2: "%27", 3: "%28", 4: "%29", 8: "%30"}
     pre = [f"v_lshlrev_b32 {d(j)}, 1, {a(j)}" for j in range(1, 9)]
-    prods = [(i, k - i) for k in range(17) for i in range(9) if 0 <= k - i < 9 and i <= k - i]
-    return _gen(r, lambda i, j: (a(i), a(j) if i == j else d(j)), P, "%31", prods, pre, shift64)
+    prods = [(i + j, a(i), a(j) if i == j else d(j)) for i in range(9) for j in range(i, 9)]
+    return _gen(r, prods, P, "%31", "%32", pre, shift64)
+
+
+def gen_muladd(shift64=True):
+    r = lambda i: f"%{i}"
+    a = lambda i: f"%{9 + i}"
+    b = lambda i: f"%{18 + i}"
+    c = lambda i: f"%{27 + i}"
+    d = lambda i: f"%{36 + i}"
+    P = {1: "%45", 2: "%46", 3: "%47", 4: "%48", 8: "%49"}
+    prods = [(i + j, a(i), b(j)) for i in range(9) for j in range(9)] + [(i + j, c(i), d(j)) for i in range(9) for j in range(9)]
+    return _gen(r, prods, P, "%50", "%51", [], shift64)
 
 
 ACC, LO, HI = "v[2:3]", "v2", "v3"            # the 64-bit column accumulator: a fixed aligned pair (clobbered)
 
 
-def _gen(r, operand, P, mask, prods, pre, shift64):
+def _gen(r, prods, P, mask, pairk, pre, shift64):
+    """prods: (column, x, y) limb products.  The MASK offsets of two neighbouring reduction columns are added by ONE MAD:
+    column k (even) receives MASK + MASK 2^29 = (2^29 - 1)(2^29 + 1) -- the second term is column k+1's offset, 29 bits
+    up, invisible to m_k and delivered by the shift; column 8 adds its own MASK alone."""
     L = list(pre)
     acc, lo, hi = ACC, LO, HI
     by_col = {}
-    for (i, j) in prods:
-        by_col.setdefault(i + j, []).append((i, j))
+    for (k, x, y) in prods:
+        by_col.setdefault(k, []).append((x, y))
     first = True
     for k in range(17):
-        for (i, j) in by_col.get(k, []):
-            x, y = operand(i, j)
+        for (x, y) in sorted(by_col.get(k, [])):
             L.append(f"v_mad_u64_u32 {acc}, vcc, {x}, {y}, {'0' if first else acc}")
             first = False
         for l in (1, 2, 3, 4, 8):
             if 0 <= k - l <= 8:
                 L.append(f"v_mad_u64_u32 {acc}, vcc, {r(k - l)}, {P[l]}, {acc}")
         if k <= 8:
-            L.append(f"v_mad_u64_u32 {acc}, vcc, {mask}, 1, {acc}")
+            if k == 8:
+                L.append(f"v_mad_u64_u32 {acc}, vcc, {mask}, 1, {acc}")
+            elif k % 2 == 0:
+                L.append(f"v_mad_u64_u32 {acc}, vcc, {mask}, {pairk}, {acc}")
             L.append(f"v_bfi_b32 {r(k)}, {lo}, 0, {mask}")            # m_k = ~lo & MASK
         else:
             L.append(f"v_and_b32 {r(k - 9)}, {mask}, {lo}")
@@ -82,8 +103,8 @@ def _gen(r, operand, P, mask, prods, pre, shift64):
             L.append(f"v_lshrrev_b64 {acc}, 29, {acc}")
         else:
             L.append(f"v_alignbit_b32 {lo}, {hi}, {lo}, 29")
-            L.append(f"v_lshrrev_b32 {hi}, 29, {hi}")
-    L.pop() if not shift64 else None                                  # the last shift's high half is not needed
+            if k < 16:
+                L.append(f"v_lshrrev_b32 {hi}, 29, {hi}")
     L.append(f"v_mov_b32 {r(8)}, {lo}")
     return L
 
@@ -149,7 +170,7 @@ def check(p, name, trials=300):
     assert pl[0] == 1 and pl[5] == pl[6] == pl[7] == 0 and pl[8] == 1 << 22
     Rinv = pow(1 << 261, -1, p)
     for shift64 in (False, True):
-        mul, sqr = gen_mul(shift64), gen_sqr(shift64)
+        mul, sqr, mad = gen_mul(shift64), gen_sqr(shift64), gen_muladd(shift64)
         for t in range(trials):
             # operands as the accumulation kernel produces them: one normalised, one with limbs up to 2^31 - 1 (A + B <= 60)
             kind = t % 4
@@ -165,7 +186,7 @@ def check(p, name, trials=300):
             regs = {f"%{i}": 0 for i in range(9)}
             regs.update({f"%{9 + i}": al[i] for i in range(9)})
             regs.update({f"%{18 + i}": bl[i] for i in range(9)})
-            regs.update({"%27": pl[1], "%28": pl[2], "%29": pl[3], "%30": pl[4], "%31": 1 << 22, "%32": MASK, LO: 0, HI: 0})
+            regs.update({"%27": pl[1], "%28": pl[2], "%29": pl[3], "%30": pl[4], "%31": 1 << 22, "%32": MASK, "%33": (1 << 29) + 1, LO: 0, HI: 0})
             simulate(mul, regs)
             out = [regs[f"%{i}"] for i in range(9)]
             ov = sum(x << (29 * i) for i, x in enumerate(out))
@@ -180,21 +201,38 @@ def check(p, name, trials=300):
             sv = sum(x << (29 * i) for i, x in enumerate(sl))
             regs = {f"%{i}": 0 for i in range(9)}
             regs.update({f"%{17 + i}": sl[i] for i in range(9)})
-            regs.update({"%26": pl[1], "%27": pl[2], "%28": pl[3], "%29": pl[4], "%30": 1 << 22, "%31": MASK, LO: 0, HI: 0})
+            regs.update({"%26": pl[1], "%27": pl[2], "%28": pl[3], "%29": pl[4], "%30": 1 << 22, "%31": MASK, "%32": (1 << 29) + 1, LO: 0, HI: 0})
             regs.update({f"%{8 + j}": 0 for j in range(1, 9)})
             simulate(sqr, regs)
             out = [regs[f"%{i}"] for i in range(9)]
             ov = sum(x << (29 * i) for i, x in enumerate(out))
             assert ov % p == sv * sv * Rinv % p, f"{name} sqr mismatch"
             assert all(x <= MASK for x in out[:8])
-    print(f"{name}: mul {len(gen_mul())} instr ({len(gen_mul(True))} with v_lshrrev_b64), sqr {len(gen_sqr())} ({len(gen_sqr(True))}) -- {trials} x 2 trials OK")
+            # fused a b + c d: one normalised and one un-normalised operand per product (the r.y step of madd29);
+            # worst-case magnitudes in kind 1: limbs 2^29 - 1 against 1.5 * 2^30 and 1.25 * 2^30
+            if kind == 1:
+                cl = [MASK] * 9; dl = [(5 << 28) - 1] * 9; bl2 = [(3 << 29) - 1] * 9; al2 = [MASK] * 9
+            else:
+                al2, bl2 = al, [min(x, (3 << 29) - 1) for x in bl]
+                cl = limbs29(rnd.randrange(0, 2 * p)); dl = [rnd.randrange(0, 5 << 28) for _ in range(9)]
+            regs = {f"%{i}": 0 for i in range(9)}
+            for base, vec in ((9, al2), (18, bl2), (27, cl), (36, dl)):
+                regs.update({f"%{base + i}": vec[i] for i in range(9)})
+            regs.update({"%45": pl[1], "%46": pl[2], "%47": pl[3], "%48": pl[4], "%49": 1 << 22, "%50": MASK, "%51": (1 << 29) + 1, LO: 0, HI: 0})
+            simulate(mad, regs)
+            out = [regs[f"%{i}"] for i in range(9)]
+            ov = sum(x << (29 * i) for i, x in enumerate(out))
+            v4 = [sum(x << (29 * i) for i, x in enumerate(v)) for v in (al2, bl2, cl, dl)]
+            assert ov % p == (v4[0] * v4[1] + v4[2] * v4[3]) * Rinv % p, f"{name} muladd mismatch"
+            assert all(x <= MASK for x in out[:8]) and ov < (v4[0] * v4[1] + v4[2] * v4[3]) // (1 << 261) + p + 1
+    print(f"{name}: mul {len(gen_mul())} instr ({len(gen_mul(False))} with v_alignbit/v_lshrrev_b32 shifts), sqr {len(gen_sqr())}, muladd {len(gen_muladd())} -- {trials} x 2 trials OK")
 
 
 # ------------------------------------------------------------------------------------------- constants + madd model
 # Subtraction a - b + K p on limbs without borrows: add the limbs of K p "spread" so that every limb dominates the
 # subtrahend's: C_0 = d_0 + J 2^29, C_i = d_i + J 2^29 - J (0 < i < 8), C_8 = d_8 - J  (d = limbs of K p; sum C_i 2^(29 i) = K p).
 # Valid when b_i <= J MASK for i < 8 and b_8 <= d_8 - J.
-SPREADS = [(7, 1), (5, 1), (4, 4), (6, 1), (2, 1)]        # (K, J) pairs used by madd29 (field29.cuh)
+SPREADS = [(7, 1), (5, 1), (4, 4), (6, 1)]        # (K, J) pairs used by madd29 (field29.cuh)
 
 
 def spread(p, K, J):
@@ -219,7 +257,7 @@ class Madd29Model:
     exact 32-bit path)."""
 
     def __init__(self, p):
-        self.p = p; self.c = field_consts(p); self.mul_l, self.sqr_l = gen_mul(), gen_sqr()
+        self.p = p; self.c = field_consts(p); self.mul_l, self.sqr_l, self.mad_l = gen_mul(), gen_sqr(), gen_muladd()
         self.pl = limbs29(p)
 
     def mul(self, a, b):
@@ -227,7 +265,7 @@ class Madd29Model:
         regs = {f"%{i}": 0 for i in range(9)}
         regs.update({f"%{9 + i}": a[i] for i in range(9)}); regs.update({f"%{18 + i}": b[i] for i in range(9)})
         pl = self.pl
-        regs.update({"%27": pl[1], "%28": pl[2], "%29": pl[3], "%30": pl[4], "%31": 1 << 22, "%32": MASK, LO: 0, HI: 0})
+        regs.update({"%27": pl[1], "%28": pl[2], "%29": pl[3], "%30": pl[4], "%31": 1 << 22, "%32": MASK, "%33": (1 << 29) + 1, LO: 0, HI: 0})
         simulate(self.mul_l, regs)
         return [regs[f"%{i}"] for i in range(9)]
 
@@ -235,9 +273,18 @@ class Madd29Model:
         regs = {f"%{i}": 0 for i in range(9)}
         regs.update({f"%{17 + i}": a[i] for i in range(9)})
         pl = self.pl
-        regs.update({"%26": pl[1], "%27": pl[2], "%28": pl[3], "%29": pl[4], "%30": 1 << 22, "%31": MASK, LO: 0, HI: 0})
+        regs.update({"%26": pl[1], "%27": pl[2], "%28": pl[3], "%29": pl[4], "%30": 1 << 22, "%31": MASK, "%32": (1 << 29) + 1, LO: 0, HI: 0})
         regs.update({f"%{8 + j}": 0 for j in range(1, 9)})
         simulate(self.sqr_l, regs)
+        return [regs[f"%{i}"] for i in range(9)]
+
+    def muladd(self, a, b, c, d):
+        regs = {f"%{i}": 0 for i in range(9)}
+        for base, vec in ((9, a), (18, b), (27, c), (36, d)):
+            regs.update({f"%{base + i}": vec[i] for i in range(9)})
+        pl = self.pl
+        regs.update({"%45": pl[1], "%46": pl[2], "%47": pl[3], "%48": pl[4], "%49": 1 << 22, "%50": MASK, "%51": (1 << 29) + 1, LO: 0, HI: 0})
+        simulate(self.mad_l, regs)
         return [regs[f"%{i}"] for i in range(9)]
 
     @staticmethod
@@ -269,8 +316,8 @@ class Madd29Model:
         sub = [self.u32(PPP[i] + 2 * Q[i]) for i in range(9)]
         rx = self.subn(RR, sub, c["S44"])
         t = [self.u32(self.u32(Q[i] + c["S61"][i]) - rx[i]) for i in range(9)]          # not normalised: limbs < 2^29 + 2^30
-        m1 = self.mul(R, t); m2 = self.mul(y, PPP)
-        ry = self.subn(m1, m2, c["S21"])
+        yn = [self.u32(c["S51"][i] - y[i]) for i in range(9)]                            # 5p - y, not normalised
+        ry = self.muladd(R, t, yn, PPP)                                                  # R (Q - rx) - y PPP with ONE reduction
         return (rx, ry, self.mul(zz, PP), self.mul(zzz, PPP))
 
 
@@ -355,15 +402,18 @@ INC_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "proof
 
 
 def render():
-    mul, sqr = gen_mul(False), gen_sqr(False)
-    mul64, sqr64 = gen_mul(True), gen_sqr(True)
+    mul, sqr, mad = gen_mul(), gen_sqr(), gen_muladd()
+    mul32 = gen_mul(False)
+    nm = lambda l: sum('v_mad' in x for x in l)
     out = ["// GENERATED by tools/gen_field29_asm.py -- do not edit.  See that file for the schedule and the bounds.",
-           f"// Montgomery product on nine 29-bit limbs (R' = 2^261): {len(mul)} instructions, {sum('v_mad' in x for x in mul)} v_mad_u64_u32.",
+           f"// Montgomery product on nine 29-bit limbs (R' = 2^261): {len(mul)} instructions, {nm(mul)} v_mad_u64_u32.",
            emit("KH29_MUL_ASM", mul),
-           f"// Montgomery squaring: {len(sqr)} instructions, {sum('v_mad' in x for x in sqr)} v_mad_u64_u32.",
+           f"// Montgomery squaring: {len(sqr)} instructions, {nm(sqr)} v_mad_u64_u32.",
            emit("KH29_SQR_ASM", sqr),
-           f"// the same with v_lshrrev_b64 for the column shift ({len(mul64)} / {len(sqr64)} instructions): measured by tools/microbench.hip",
-           emit("KH29_MUL_ASM_B64", mul64), emit("KH29_SQR_ASM_B64", sqr64), emit_consts()]
+           f"// (a b + c d) / R' with one reduction: {len(mad)} instructions, {nm(mad)} v_mad_u64_u32.",
+           emit("KH29_MULADD_ASM", mad),
+           f"// the product with v_alignbit_b32 + v_lshrrev_b32 column shifts ({len(mul32)} instructions): slower (tools/microbench.hip measures both)",
+           emit("KH29_MUL_ASM_B32", mul32), emit_consts()]
     return "\n".join(out)
 
 

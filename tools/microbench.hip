@@ -138,16 +138,16 @@ __global__ void k_prod(u32* out, u32 seed) {
         Fe29<F> x, y;
         for (int i = 0; i < 9; i++) { x.v[i] = (tid * 2654435761u + i * seed) & MASK29; y.v[i] = (tid + 40503u * i + seed) & MASK29; }
         x.v[8] &= 0x3fffffu; y.v[8] &= 0x3fffffu;
-        typedef typename C29<F>::T K; const u32 p1 = K::P1, p2 = K::P2, p3 = K::P3, p4 = K::P4, c22 = 1u << 22, msk = MASK29;
+        typedef typename C29<F>::T K; const u32 p1 = K::P1, p2 = K::P2, p3 = K::P3, p4 = K::P4, c22 = 1u << 22, msk = MASK29, pairk = (1u << 29) + 1u;
         for (int i = 0; i < NPROD; i++) {
             Fe29<F> r;
             if (WHICH == 1) r = mul29<F>(x, y);
             else
-                asm(KH29_MUL_ASM_B64
+                asm(KH29_MUL_ASM_B32
                     : "=&v"(r.v[0]), "=&v"(r.v[1]), "=&v"(r.v[2]), "=&v"(r.v[3]), "=&v"(r.v[4]), "=&v"(r.v[5]), "=&v"(r.v[6]), "=&v"(r.v[7]), "=&v"(r.v[8])
                     : "v"(x.v[0]), "v"(x.v[1]), "v"(x.v[2]), "v"(x.v[3]), "v"(x.v[4]), "v"(x.v[5]), "v"(x.v[6]), "v"(x.v[7]), "v"(x.v[8]),
                       "v"(y.v[0]), "v"(y.v[1]), "v"(y.v[2]), "v"(y.v[3]), "v"(y.v[4]), "v"(y.v[5]), "v"(y.v[6]), "v"(y.v[7]), "v"(y.v[8]),
-                      "s"(p1), "s"(p2), "s"(p3), "s"(p4), "s"(c22), "s"(msk)
+                      "s"(p1), "s"(p2), "s"(p3), "s"(p4), "s"(c22), "s"(msk), "v"(pairk)
                     : "vcc", "v2", "v3");
             x = r;
         }
@@ -184,8 +184,8 @@ int main() {
         sweep_rate<OP_MULLO>() || sweep_rate<OP_MULHI>() || sweep_rate<OP_MAD24>() || sweep_rate<OP_MAD64>() || sweep_rate<OP_MAD64_S>() || sweep_rate<OP_MAD64_ADDC>()) return 1;
     for (int w : {1, 2, 4, 8}) {
         if (run_prod<0>("Montgomery product, 8 x 32-bit limbs (field.cuh)", 254, w)) return 1;
-        if (run_prod<1>("Montgomery product, 9 x 29-bit limbs (field29)", 186, w)) return 1;
-        if (run_prod<2>("  same with v_lshrrev_b64 column shifts", 170, w)) return 1;
+        if (run_prod<1>("Montgomery product, 9 x 29-bit limbs (field29)", 166, w)) return 1;
+        if (run_prod<2>("  same with v_alignbit + v_lshrrev_b32 shifts", 182, w)) return 1;
     }
     return 0;
 }
