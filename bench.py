@@ -38,6 +38,9 @@ sys.path.insert(0, ROOT)
 LOG_N = 20
 ALG_BYTES_PER_PAIR = 96          # 64 B affine point + 32 B scalar, each read once
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec
+PMC_FILE = "r02_msm20_pmc.json"                 # tools/profile_msm.py (rocprofv3 PMC passes), keyed by the hash of csrc/
+MIX_FILE = "r02_k_accumulate29_valu_mix.json"   # tools/valu_mix.py (static opcode histogram of the loop body)
+RATES_FILE = "r02_valu_rates.json"              # per-opcode issue cycles measured by tools/microbench.hip
 
 
 def rand_scalars(rng, n):
@@ -150,30 +153,99 @@ def oplist_replay(khip, g16, srs16, reps=2):
     return best, phases
 
 
+def source_hash():
+    """sha256 over csrc/ -- the PMC / instruction-mix files under profiles/ carry the hash of the sources they were
+    collected on; numbers from a different build are not quoted."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "proof_systems_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".cuh", ".hpp", ".inc", ".cpp")):
+            h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()
+
+
+def load_profile(name):
+    p = os.path.join(ROOT, "profiles", name)
+    try:
+        return json.load(open(p))
+    except (OSError, ValueError):
+        return None
+
+
+def roofline_block(kname, acc_ms, n, log_n):
+    """roofline of the dominant kernel from THIS run's kernel duration; counter-derived fields only from profiles/ files
+    whose source hash equals the hash of the sources that are running."""
+    alg_bytes = ALG_BYTES_PER_PAIR * n
+    block = {"bound": "hbm", "kernel": kname, "achieved": (alg_bytes / (acc_ms * 1e-3) / 1e9) if acc_ms else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+             "frac": (alg_bytes / (acc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if acc_ms else None, "traffic": None, "kernel_ms": acc_ms, "algorithmic_bytes": alg_bytes,
+             "note": "integer-ALU bound (about 10 Montgomery products of 131 v_mad_u64_u32 each per point addition), see DESIGN.md section 3"}
+    here = source_hash()
+    pmc = load_profile(PMC_FILE)
+    mix = load_profile(MIX_FILE)
+    rates = load_profile(RATES_FILE)
+    if log_n != LOG_N or not acc_ms:
+        return block
+    key = kname + "<FqParams>"
+    if not pmc or pmc.get("source_sha256") != here or key not in pmc.get("kernels", {}):
+        block["traffic_note"] = "profiles/%s was not collected on this build (or lacks %s): counter-derived fields withheld" % (PMC_FILE, key)
+        return block
+    k = pmc["kernels"][key]
+    # k_accumulate's reads are 64-byte gathers, not a wide coalesced stream: the raw FETCH_SIZE already exceeds the known
+    # gather + entry bytes, so the guide's 2x under-count correction is not applied to it (DESIGN.md section 3)
+    block["traffic"] = k.get("fetch_raw_bytes", 0.0) + k.get("write_bytes", 0.0)
+    block["traffic_source"] = "profiles/" + PMC_FILE
+    if mix and rates and mix.get("source_sha256") == here and "SQ_INSTS_VALU" in k:
+        hist = mix["valu_histogram"]; tot = float(sum(hist.values()))
+        cyc = {o: rates["cycles"].get(o.replace("_e32", "").replace("_e64", ""), rates["default_cycles"]) for o in hist}
+        per_instr = sum(hist[o] * cyc[o] for o in hist) / tot                  # issue cycles per executed VALU wave-instruction
+        issue_cycles = k["SQ_INSTS_VALU"] * per_instr / 1024.0                  # per SIMD
+        peak_ms = issue_cycles / 2.4e9 * 1e3
+        clk = k.get("sustained_clock_ghz")
+        block["valu_issue"] = {"instructions_per_launch": k["SQ_INSTS_VALU"], "issue_cycles_per_instruction": per_instr,
+                               "issue_bound_ms_at_2.4GHz": peak_ms, "frac": peak_ms / acc_ms,
+                               "sustained_clock_ghz": clk, "frac_at_sustained_clock": (peak_ms * 2.4 / clk / acc_ms) if clk else None,
+                               "unit": "fraction of the issue-bound time for this instruction mix (per-opcode cycles from tools/microbench.hip)"}
+    return block
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--log-n", type=int, default=LOG_N)
+    ap.add_argument("--log-n", type=int, default=LOG_N, help="weak scaling: points PER GPU; with --strong: points in total")
+    ap.add_argument("--strong", action="store_true", help="BASELINE config 4: ONE MSM of 2^log-n points (default 2^22) sharded over the ranks")
     ap.add_argument("--curve", choices=["vesta", "pallas"], default="vesta")
     ap.add_argument("--no-pipeline", action="store_true", help="time synchronous MSMs (one in flight); used for the rocprofv3 kernel-stats profile so kernels do not overlap")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-oplist", action="store_true")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` on its own: become N ranks (one per GPU) under the torch.distributed launcher
+        import socket
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+                                  "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:])
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    n = 1 << args.log_n
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with --nproc-per-node equal to --gpus)" % (args.gpus, world))
+    if args.strong and args.log_n == LOG_N:
+        args.log_n = 22
+    total = (1 << args.log_n) if args.strong else world << args.log_n
 
     import torch
     dist = None
+    coll_dev = "cpu"
+    backend = None
     if world > 1:
         import torch.distributed as dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # KH_BENCH_BACKEND=gloo lets two ranks share ONE GPU (functional check of the N>1 path on a
-        # single-GPU box); the driver's multi-GPU runs use nccl (= RCCL) with one GPU per rank
+        # KH_BENCH_BACKEND=gloo lets several ranks share ONE GPU (functional check of the N>1 path on a single-GPU box);
+        # the driver's multi-GPU runs use nccl (= RCCL over xGMI) with one GPU per rank
         backend = os.environ.get("KH_BENCH_BACKEND", "nccl")
         ndev = max(1, torch.cuda.device_count())
         torch.cuda.set_device(local_rank % ndev)
@@ -182,31 +254,22 @@ def main():
         coll_dev = "cuda" if backend == "nccl" else "cpu"
 
     import proof_systems_amd.khip as khip
-    khip.init(local_rank % max(1, khip.device_count()))
+    from proof_systems_amd import sharded
+    dev = local_rank % max(1, khip.device_count())
     cores = os.cpu_count() or 1
-    gen_threads = max(1, cores // max(1, world))
 
-    # bases: this rank's slice of SRS::<Vesta>::create(world << log_n).g
+    # bases: this rank's point range of SRS::<curve>::create(total).g, generated and table-expanded on its own GPU
     t0 = time.perf_counter()
     CID = khip.VESTA if args.curve == "vesta" else khip.PALLAS
-    srs = khip.Srs.create(CID, n, start=rank * n)      # SRS::create on the device (+ window tables)
+    sm = sharded.RankShardedMsm(CID, total, dist=dist, coll_device=coll_dev, engine=sharded.KhipEngine(dev), rank=rank, world=world)
+    srs, n = sm.shard, sm.count
     t_gen = time.perf_counter() - t0
-    g = None
     sc = rand_scalars(np.random.default_rng(1234 + rank), n)
     d_sc = khip.DevBuf(sc.nbytes).upload(sc)
-    R_FP = [0x34786d38fffffffd, 0x992c350be41914ad, 0xffffffffffffffff, 0x3fffffffffffffff]     # 1 in Montgomery form
-    R_FQ = [0x5b2b3e9cfffffffd, 0x992c350be3420567, 0xffffffffffffffff, 0x3fffffffffffffff]
-    one = np.tile(np.array(R_FP if args.curve == "vesta" else R_FQ, dtype=np.uint64), (world, 1))
 
     def combine(out, inf):
-        if dist is None:
-            return out[0], bool(inf[0])
-        # combine: all-gather the per-rank partial sums (RCCL has no EC-add reduction), fold locally
-        mine = torch.from_numpy(np.concatenate([out[0], inf.astype(np.uint64)]).view(np.int64)).to(coll_dev)
-        allp = [torch.empty_like(mine) for _ in range(world)]
-        dist.all_gather(allp, mine)
-        parts = torch.stack(allp).cpu().numpy().view(np.uint64)
-        return khip.points_sum(CID, parts[:, :8].copy(), inf=parts[:, 8].astype(np.uint8))
+        o, i = sm.combine(out[:1], inf[:1])          # all-gather of the partial sums + local fold (no-op at N = 1)
+        return o[0], bool(i[0])
 
     def fence():
         khip.sync()
@@ -216,21 +279,17 @@ def main():
             torch.cuda.synchronize()
 
     # warm-up doubles as the latency measurement: synchronous steps
-    phase_ms = {}
     sync_ms = []
     for _ in range(max(1, args.warmup)):
         ts = time.perf_counter()
-        out_inf = srs.msm_batch_dev(d_sc.ptr, n, 1)
-        for name, ms in khip.last_timings():          # HIP events on the library's own stream (this rank's MSM)
-            phase_ms.setdefault(name, []).append(ms)
-        result = combine(*out_inf)
+        result = combine(*srs.msm_batch_dev(d_sc.ptr, n, 1))
         sync_ms.append(1e3 * (time.perf_counter() - ts))
-    # timed region: EXACTLY `steps` MSMs, up to three in flight (kh_msm_submit / kh_msm_wait): the sort of
-    # step i+2 and the bucket-reduction tail of step i run underneath the accumulation of step i+1.  Every step is a full MSM
-    # whose affine result is fetched and (N>1) combined across ranks.
+    # timed region: EXACTLY `steps` MSMs, four in flight (kh_msm_submit / kh_msm_wait): the sort of step i+2 and the
+    # bucket-reduction tail of step i run underneath the accumulation of step i+1.  Every step is a full MSM whose affine
+    # result is fetched and (N>1) combined across ranks.
     fence()
     t0 = time.perf_counter()
-    depth = 1 if args.no_pipeline else 4          # jobs in flight (the N>1 combine needs a free slot for its fold)
+    depth = 1 if args.no_pipeline else 4
     pending = []
     for _ in range(args.steps):
         pending.append(srs.msm_submit(d_sc.ptr, n, 1))
@@ -246,72 +305,66 @@ def main():
         elapsed = float(t.item())
 
     ms_per_step = 1e3 * elapsed / args.steps
-    value = (world * n) / (elapsed / args.steps) / 1e6
-    # Per-phase HIP events and the dominant kernel's own start/stop events (hipExtLaunchKernelGGL): taken from
-    # synchronous steps run right AFTER the timed loop, i.e. at the clocks the timed loop ran at (the warm-up steps
-    # start from an idle GPU and read ~7 % slow), one MSM in flight so that kernels do not overlap.  Median of the samples.
-    phase_ms = {}
+    value = total / (elapsed / args.steps) / 1e6
+    # Per-phase HIP events and the dominant kernel's own start/stop events (hipExtLaunchKernelGGL, on the stream the kernel
+    # is launched on): synchronous steps right AFTER the timed loop, i.e. at the clocks the loop ran at, one MSM in flight
+    # so that kernels do not overlap.  Median of the samples.  The same steps give the single-MSM latency.
+    phase_ms, lat_ms = {}, []
     for _ in range(5):
-        srs.msm_batch_dev(d_sc.ptr, n, 1)
+        ts = time.perf_counter()
+        result = combine(*srs.msm_batch_dev(d_sc.ptr, n, 1))
+        lat_ms.append(1e3 * (time.perf_counter() - ts))
         for name, ms in khip.last_timings():
             phase_ms.setdefault(name, []).append(ms)
     phase_avg = {k: float(np.median(v)) for k, v in phase_ms.items()}
     kname = "k_accumulate29" if "k_accumulate29" in phase_avg else "k_accumulate"
     acc = phase_avg.get(kname, phase_avg.get("accumulate"))
-    alg_bytes = ALG_BYTES_PER_PAIR * n
-    traffic = None
-    valu_instr = None
-    pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(pmc_path) and args.log_n == LOG_N:
-        try:
-            pmc = json.load(open(pmc_path))
-            traffic = pmc.get("k_accumulate_hbm_bytes_per_launch")
-            valu_instr = pmc.get("k_accumulate_valu_wave_instructions_per_launch")
-        except Exception:
-            traffic = None
-    roofline = {
-        "bound": "hbm", "kernel": kname,
-        "achieved": (alg_bytes / (acc * 1e-3) / 1e9) if acc else None,
-        "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": (alg_bytes / (acc * 1e-3) / 1e9 / HBM_PEAK_GBS) if acc else None,
-        "traffic": traffic,
-        "kernel_ms": acc, "algorithmic_bytes": alg_bytes,
-        "note": "integer-ALU bound (about 10 Montgomery products per point addition), see DESIGN.md section 3",
-    }
-    if acc and valu_instr:
-        # the roofline that actually binds: VALU issue.  1024 SIMDs x one 32-bit integer wave-instruction per
-        # 4 cycles (tools/microbench.hip) at the 2.4 GHz peak clock; instruction count from the SQ_INSTS_VALU pass.
-        peak = 1024 * 2.4e9 / 4 / 1e9
-        ach = valu_instr / (acc * 1e-3) / 1e9
-        roofline["valu_issue"] = {"achieved": ach, "peak": peak, "unit": "G wave-instr/s", "frac": ach / peak,
-                                  "instructions_per_launch": valu_instr}
+    latency = float(np.median(lat_ms))
 
     line = {
         "metric": "MSM Mscalar/s at 2^%d (%s)" % (args.log_n, args.curve.capitalize()), "value": value, "unit": "Mscalar/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32x8 (255-bit Montgomery integers)",
+        "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "u29x9 / u32x8 (255-bit Montgomery integers)",
         "data": "synthetic",
-        "config": {"workload": "msm_2^%d_%s_srs" % (args.log_n, args.curve), "points_per_gpu": n, "bases": "SRS::<%s>::create" % args.curve.capitalize(),
-                   "scalars": "uniform 254-bit, seed 1234+rank", "parallelism": "point-range x%d" % world},
-        "roofline": roofline,
-        "phases_ms": phase_avg, "ms_per_step_synchronous": float(np.median(sync_ms)), "msm_in_flight": depth,
-        "srs_create_device_s": t_gen,
+        "config": {"workload": ("msm_2^%d_%s_srs" % (args.log_n, args.curve)) + ("_sharded" if args.strong else ""), "points_per_gpu": n, "points_total": total,
+                   "bases": "SRS::<%s>::create" % args.curve.capitalize(),
+                   "scalars": "uniform 254-bit, seed 1234+rank", "parallelism": "point-range x%d" % world, "collective_backend": backend, "world_size_seen": world},
+        "latency_value": total / (latency * 1e-3) / 1e6, "latency_note": "one MSM at a time (submit -> wait -> combine): `value` keeps 4 in flight",
+        "ms_per_step_synchronous": latency, "msm_in_flight": depth,
+        "roofline": roofline_block(kname, acc, n, args.log_n) if not args.strong else roofline_block(kname, acc, n, -1),
+        "phases_ms": phase_avg, "srs_create_device_s": t_gen,
     }
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import cref          # cpu_baseline leg only: the oracle as the timed CPU port + checker
+    # parity at full size, every rank: its partial against the oracle on its own slice; rank 0 then folds the oracle's
+    # partials with the oracle's group law and compares with the combined GPU result
+    if not args.no_cpu_baseline:
+        from oracle import cref          # cpu_baseline / checker leg only
         g = srs.get_g()
+        threads = max(1, cores // world)
         t0 = time.perf_counter()
-        want, winf = cref.msm(CID, g, sc, scalars_mont=True, threads=cores)
+        want, winf = cref.msm(CID, g, sc, scalars_mont=True, threads=threads)
         t_cpu = time.perf_counter() - t0
-        ok = (winf == result[1]) and (winf or bool(np.array_equal(want, result[0])))
-        line["cpu_baseline"] = {"value": n / t_cpu / 1e6, "unit": "Mscalar/s", "cores": cref.last_threads(), "host_cores": cores, "kind": "port",
-                                "sample": "the same 2^%d-point MSM (oracle/pasta_ref.c signed-window Pippenger, threads = windows x point slices)" % args.log_n,
-                                "seconds": t_cpu, "gpu_result_matches": bool(ok)}
-        if not ok:
+        if world == 1:
+            ok = (winf == result[1]) and (winf or bool(np.array_equal(want, result[0])))
+            line["cpu_baseline"] = {"value": n / t_cpu / 1e6, "unit": "Mscalar/s", "cores": cref.last_threads(), "host_cores": cores, "kind": "port",
+                                    "sample": "the same 2^%d-point MSM (oracle/pasta_ref.c signed-window Pippenger, threads = windows x point slices)" % args.log_n,
+                                    "seconds": t_cpu, "gpu_result_matches": bool(ok)}
+        else:
+            mine = torch.from_numpy(np.concatenate([want, np.array([int(winf)], dtype=np.uint64)]).view(np.int64).copy()).to(coll_dev)
+            allp = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(allp, mine)
+            ok = True
+            if rank == 0:
+                parts = torch.stack(allp).cpu().numpy().view(np.uint64)
+                accp, ainf = parts[0, :8].copy(), bool(parts[0, 8])
+                for r in range(1, world):
+                    accp, ainf = cref.point_add(CID, accp, parts[r, :8].copy(), ainf, bool(parts[r, 8]))
+                ok = (ainf == result[1]) and (ainf or bool(np.array_equal(accp, result[0])))
+                line["multi_gpu_parity"] = {"combined_result_matches_oracle": bool(ok), "oracle_seconds_per_rank": t_cpu, "threads_per_rank": threads}
+        if rank == 0 and not ok:
             line["parity_error"] = "GPU result differs from the CPU oracle"
 
-    if rank == 0 and world == 1 and not args.no_oplist and args.curve == "vesta":
+    if rank == 0 and world == 1 and not args.no_oplist and args.curve == "vesta" and not args.strong:
         g16 = srs.get_g(0, 1 << 16)
         srs16 = khip.Srs(khip.VESTA, g16)
         t0 = time.perf_counter()

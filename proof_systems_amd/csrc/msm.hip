@@ -312,7 +312,7 @@ k_accumulate(const u32* __restrict__ entries, const u32* __restrict__ off, const
 // group law; it only notices that one cannot be excluded (probability ~2^-25 per addition on random inputs), abandons
 // the task and flags it in handed[]: k_accumulate then redoes exactly those tasks with the exact formulas.  Finished
 // tasks are converted to the canonical wire form, so everything downstream is unchanged and the result stays bit-exact.
-template <class BF, bool PREFETCH>
+template <class BF>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(112)))
 k_accumulate29(const u32* __restrict__ entries, const u32* __restrict__ off, const u32* __restrict__ toff,
                const u32* __restrict__ roff, const u32* __restrict__ order,
@@ -340,17 +340,8 @@ k_accumulate29(const u32* __restrict__ entries, const u32* __restrict__ off, con
 #pragma unroll
     for (int i = 0; i < 9; i++) { acc.zz.v[i] = K29::one(i); acc.zzz.v[i] = K29::one(i); }
     bool ok = true;
-    if (PREFETCH) {                      // the next point's gather is issued before the current addition (16 more VGPRs)
-        Aff<BF> nx = p; u32 ne = 0;
-        if (start + 1 < end) { ne = entries[start + 1]; nx = Aff<BF>::load(pts + (size_t)(ne & 0x7fffffffu) * 64); }
-        for (u32 k = start + 1; k < end; k++) {
-            p = nx; e = ne;
-            if (k + 1 < end) { ne = entries[k + 1]; nx = Aff<BF>::load(pts + (size_t)(ne & 0x7fffffffu) * 64); }
-            if (e >> 31) p.y = neg<BF>(p.y);
-            ok = madd29<BF>(acc, pack29<BF, 5>(p.x), pack29<BF, 5>(p.y));
-            if (!ok) break;
-        }
-    } else
+    // (issuing the next point's gather before the current addition -- 109 VGPRs -- and sizing the tasks for 5 waves per SIMD
+    //  were both measured: no gain, four waves already hide the gather)
     for (u32 k = start + 1; k < end; k++) {
         e = entries[k];
         p = Aff<BF>::load(pts + (size_t)(e & 0x7fffffffu) * 64);
@@ -882,8 +873,7 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
     const uint8_t* handed = acc29 ? C.ws_handed.as<uint8_t>() : nullptr;
     const dim3 agrid((unsigned)((max_tasks + 255) / 256));
     if (acc29) {
-        static const bool prefetch = getenv("KH_ACC_PREFETCH") && atoi(getenv("KH_ACC_PREFETCH")) != 0;
-        auto kern = prefetch ? k_accumulate29<BF, true> : k_accumulate29<BF, false>;
+        auto kern = k_accumulate29<BF>;
         if (C.timer.enabled && C.timer.created && !gcap.active) {     // the dominant kernel's own start / stop timestamps (bench.py roofline)
             hipExtLaunchKernelGGL(kern, agrid, dim3(256), 0, s, C.timer.k0, C.timer.k1, 0,
                                   C.ws_entries.as<u32>(), C.ws_off.as<u32>(), C.ws_toff.as<u32>(), roff, order, nkeys,

@@ -97,6 +97,48 @@ __global__ void k_rate(u32* out, u32 seed, u32 sval) {
     out[tid] = (u32)s ^ (u32)(s >> 32) ^ (u32)ds ^ (u32)fs;
 }
 
+// further 32-bit ops of the accumulation kernel's instruction mix: one kernel per mnemonic, "op dst, src, dst"
+#define RATE2(NAME, ASM)                                                                                                  \
+    __global__ void k_rate2_##NAME(u32* out, u32 seed) {                                                                  \
+        u32 tid = blockIdx.x * blockDim.x + threadIdx.x;                                                                  \
+        u32 a0 = tid + seed, a1 = tid * 3 + seed, a2 = tid * 5 + 1, a3 = tid * 7 + 2, a4 = tid ^ seed, a5 = tid + 11, a6 = tid + 13, a7 = tid + 17; \
+        u32 x = (tid * 2654435761u + 1) & 15u, y = seed * 40503u + 3;                                                     \
+        for (int i = 0; i < ITERS; i++)                                                                                   \
+            asm volatile(ASM(0) "\n\t" ASM(1) "\n\t" ASM(2) "\n\t" ASM(3) "\n\t" ASM(4) "\n\t" ASM(5) "\n\t" ASM(6) "\n\t" ASM(7)   \
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(x), "v"(y) : "vcc"); \
+        out[tid] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;                                                                 \
+    }
+#define A_SUB(k) "v_sub_u32 %" #k ", %" #k ", %8"
+#define A_LSHR(k) "v_lshrrev_b32 %" #k ", %8, %" #k
+#define A_LSHL(k) "v_lshlrev_b32 %" #k ", %8, %" #k
+#define A_OR(k) "v_or_b32 %" #k ", %" #k ", %8"
+#define A_XOR(k) "v_xor_b32 %" #k ", %" #k ", %8"
+#define A_CNDMASK(k) "v_cndmask_b32 %" #k ", %" #k ", %9, vcc"
+#define A_CMP(k) "v_cmp_le_u32 vcc, %" #k ", %9"
+#define A_LSHLOR(k) "v_lshl_or_b32 %" #k ", %" #k ", 3, %9"
+#define A_ANDOR(k) "v_and_or_b32 %" #k ", %" #k ", %8, %9"
+#define A_LSHLADD(k) "v_lshl_add_u32 %" #k ", %" #k ", 1, %9"
+#define A_SUBCO(k) "v_sub_co_u32 %" #k ", vcc, %" #k ", %8"
+RATE2(sub, A_SUB) RATE2(lshr, A_LSHR) RATE2(lshl, A_LSHL) RATE2(or, A_OR) RATE2(xor, A_XOR) RATE2(cndmask, A_CNDMASK) RATE2(cmp, A_CMP)
+RATE2(lshlor, A_LSHLOR) RATE2(andor, A_ANDOR) RATE2(lshladd, A_LSHLADD) RATE2(subco, A_SUBCO)
+
+static int run_rate2(const char* name, void (*kern)(u32*, u32), int waves_per_simd) {
+    int blocks = 256 * waves_per_simd;
+    u32* out; CHECK(hipMalloc(&out, (size_t)blocks * 256 * 4));
+    hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, 0, out, 1u);
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipEventRecord(e0));
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, 0, out, 2u);
+    CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+    float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+    double wave_instr = (double)blocks * 4 * ITERS * 8;
+    printf("%-30s waves/SIMD=%d  %8.3f ms  %7.2f G wave-instr/s  %5.2f cycles / wave-instr / SIMD (at 2.4 GHz)\n", name, waves_per_simd, ms,
+           wave_instr / (ms * 1e-3) / 1e9, (ms * 1e-3 * 2.4e9) * 1024.0 / wave_instr);
+    CHECK(hipFree(out));
+    return 0;
+}
+
 static const char* OP_NAME[OP_COUNT] = {"v_mov_b32 (control)", "v_add_u32 (control)", "v_and_b32 (control)", "v_add3_u32", "v_addc_co_u32 chain", "v_alignbit_b32",
                                         "v_bfi_b32 (SGPR operand)", "v_lshrrev_b64", "v_lshl_add_u64", "v_mul_lo_u32", "v_mul_hi_u32", "v_mad_u32_u24", "v_mad_u64_u32",
                                         "v_mad_u64_u32 (SGPR operand)", "v_mad_u64_u32 + v_addc pair", "v_fma_f32 (control)", "v_pk_fma_f32 (control)", "v_fma_f64"};
@@ -182,6 +224,10 @@ int main() {
     if (sweep_rate<OP_MOV>() || sweep_rate<OP_ADD>() || sweep_rate<OP_AND>() || sweep_rate<OP_FMA32>() || sweep_rate<OP_PKFMA32>() || sweep_rate<OP_FMA64>() ||
         sweep_rate<OP_ADD3>() || sweep_rate<OP_ADDC>() || sweep_rate<OP_ALIGNBIT>() || sweep_rate<OP_BFI>() || sweep_rate<OP_LSHR64>() || sweep_rate<OP_LSHLADD64>() ||
         sweep_rate<OP_MULLO>() || sweep_rate<OP_MULHI>() || sweep_rate<OP_MAD24>() || sweep_rate<OP_MAD64>() || sweep_rate<OP_MAD64_S>() || sweep_rate<OP_MAD64_ADDC>()) return 1;
+    struct { const char* n; void (*k)(u32*, u32); } more[] = {{"v_sub_u32", k_rate2_sub}, {"v_lshrrev_b32", k_rate2_lshr}, {"v_lshlrev_b32", k_rate2_lshl}, {"v_or_b32", k_rate2_or},
+        {"v_xor_b32", k_rate2_xor}, {"v_cndmask_b32", k_rate2_cndmask}, {"v_cmp_le_u32 (-> vcc)", k_rate2_cmp}, {"v_lshl_or_b32", k_rate2_lshlor}, {"v_and_or_b32", k_rate2_andor},
+        {"v_lshl_add_u32", k_rate2_lshladd}, {"v_sub_co_u32 (-> vcc)", k_rate2_subco}};
+    for (auto& m : more) for (int w : {4, 8}) if (run_rate2(m.n, m.k, w)) return 1;
     for (int w : {1, 2, 4, 8}) {
         if (run_prod<0>("Montgomery product, 8 x 32-bit limbs (field.cuh)", 254, w)) return 1;
         if (run_prod<1>("Montgomery product, 9 x 29-bit limbs (field29)", 166, w)) return 1;
