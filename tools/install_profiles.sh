@@ -1,0 +1,13 @@
+#!/bin/bash
+# After `gpurun -- 'tools/microbench > gpurun_out/r02_microbench.txt; python tools/profile_msm.py gpurun_out/r02_msm20; python bench.py > gpurun_out/r02_bench_n1.json'`
+# copy the evidence bench.py's roofline block quotes into profiles/ (tracked) and derive the two small JSON files from it.
+set -e
+cd "$(dirname "$0")/.."
+R=${1:-r02}
+cp gpurun_out/${R}_microbench.txt profiles/${R}_microbench.txt
+cp gpurun_out/${R}_msm20_pmc.json profiles/${R}_msm20_pmc.json
+cp gpurun_out/${R}_msm20_kernel_stats.csv profiles/${R}_msm20_kernel_stats.csv
+python3 tools/parse_microbench.py profiles/${R}_microbench.txt profiles/${R}_valu_rates.json > /dev/null
+python3 tools/valu_mix.py profiles/${R}_k_accumulate29_valu_mix.json > /dev/null
+[ -f gpurun_out/${R}_bench_n1.json ] && tail -1 gpurun_out/${R}_bench_n1.json > profiles/${R}_bench_line.json
+echo installed profiles/${R}_*
