@@ -369,6 +369,27 @@ int kh_debug_point_op(int curve, int op, const uint64_t *p_xy, const uint8_t *p_
                       const uint64_t *q_xy, const uint8_t *q_inf,
                       uint64_t *out_xy, uint8_t *out_inf, size_t n);
 
+/* ---- Fiat-Shamir sponges (host side) --------------------------------------
+ * The transcript of kimchi's prover / verifier: Kimchi Poseidon (width 3, rate 2, 55 full rounds, x^7) under
+ * DefaultFqSponge (poseidon/src/sponge.rs:228-412) and DefaultFrSponge (kimchi/src/plonk_sponge.rs:36-57).  Host code, no
+ * GPU needed.  kind KH_SPONGE_FQ = the sponge over `curve`'s BASE field that absorbs commitments and squeezes challenges of
+ * the scalar field; KH_SPONGE_FR = the sponge over `curve`'s SCALAR field that absorbs evaluations.  Field elements are
+ * 4 Montgomery limbs as everywhere; a challenge is the raw 128-bit value (2 limbs), to be mapped with
+ * kh_scalar_challenge_to_field where the reference wraps it in a ScalarChallenge. */
+#define KH_SPONGE_FQ 0
+#define KH_SPONGE_FR 1
+typedef struct kh_sponge kh_sponge_t;
+int kh_sponge_new(int kind, int curve, kh_sponge_t **out);
+int kh_sponge_clone(const kh_sponge_t *s, kh_sponge_t **out);           /* fq_sponge.clone() (prover.rs:1193) */
+void kh_sponge_free(kh_sponge_t *s);
+int kh_sponge_absorb_g(kh_sponge_t *s, const uint64_t *xy, const uint8_t *inf /*nullable*/, size_t n);   /* FqSponge::absorb_g */
+int kh_sponge_absorb(kh_sponge_t *s, const uint64_t *x, size_t n);      /* elements of the sponge's own field: absorb_fq / FrSponge::absorb(_multiple) */
+int kh_sponge_absorb_fr(kh_sponge_t *s, const uint64_t *x, size_t n);   /* FqSponge::absorb_fr: scalar-field elements into the base-field sponge */
+int kh_sponge_challenge(kh_sponge_t *s, uint64_t chal[2]);              /* 128-bit challenge, raw */
+int kh_sponge_challenge_field(kh_sponge_t *s, uint64_t out[4]);         /* the same as a scalar-field element (beta, gamma) */
+int kh_sponge_squeeze_field(kh_sponge_t *s, uint64_t out[4]);           /* challenge_fq / digest_fq / FrSponge::digest */
+int kh_sponge_digest(kh_sponge_t *s, uint64_t out[4]);                  /* FqSponge::digest: as a scalar-field element, 0 if it does not fit */
+
 #ifdef __cplusplus
 }
 #endif

@@ -28,6 +28,8 @@ MSM_SLOTS = 4          # KH_MSM_SLOTS: jobs kh_msm_submit accepts before kh_msm_
 
 # every symbol include/kimchi_hip.h declares
 SYMBOLS = [
+    "kh_sponge_new", "kh_sponge_clone", "kh_sponge_free", "kh_sponge_absorb_g", "kh_sponge_absorb", "kh_sponge_absorb_fr", "kh_sponge_challenge",
+    "kh_sponge_challenge_field", "kh_sponge_squeeze_field", "kh_sponge_digest",
     "kh_device_count", "kh_init", "kh_set_device", "kh_get_device", "kh_trim", "kh_srs_device", "kh_last_error", "kh_srs_create", "kh_srs_free", "kh_srs_size",
     "kh_srs_set_lagrange", "kh_srs_compute_lagrange", "kh_srs_get_lagrange", "kh_srs_lagrange_chunks",
     "kh_msm", "kh_msm_batch", "kh_msm_points", "kh_ntt", "kh_lde",
@@ -43,6 +45,17 @@ SYMBOLS = [
 
 _lib.kh_last_error.restype = C.c_char_p
 _lib.kh_set_device.argtypes = [C.c_int]
+_lib.kh_sponge_new.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+_lib.kh_sponge_clone.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+_lib.kh_sponge_free.argtypes = [C.c_void_p]
+_lib.kh_sponge_free.restype = None
+_lib.kh_sponge_absorb_g.argtypes = [C.c_void_p, U64P, U8P, C.c_size_t]
+_lib.kh_sponge_absorb.argtypes = [C.c_void_p, U64P, C.c_size_t]
+_lib.kh_sponge_absorb_fr.argtypes = [C.c_void_p, U64P, C.c_size_t]
+_lib.kh_sponge_challenge.argtypes = [C.c_void_p, U64P]
+_lib.kh_sponge_challenge_field.argtypes = [C.c_void_p, U64P]
+_lib.kh_sponge_squeeze_field.argtypes = [C.c_void_p, U64P]
+_lib.kh_sponge_digest.argtypes = [C.c_void_p, U64P]
 _lib.kh_srs_device.argtypes = [C.c_void_p]
 _lib.kh_srs_size.restype = C.c_size_t
 _lib.kh_srs_size.argtypes = [C.c_void_p]
@@ -639,6 +652,68 @@ def domain_generator(field: int, log2_n: int):
     out = np.zeros(4, dtype=np.uint64)
     _check(_lib.kh_domain_generator(field, log2_n, _p64(out)))
     return out
+
+
+class Sponge:
+    """kh_sponge_*: the host-side Fiat-Shamir sponges (FQ: DefaultFqSponge of `curve`, FR: DefaultFrSponge of `curve`)."""
+    FQ, FR = 0, 1
+
+    def __init__(self, kind: int, curve: int, _h=None):
+        self.kind, self.curve = kind, curve
+        self._h = C.c_void_p()
+        if _h is None:
+            _check(_lib.kh_sponge_new(kind, curve, C.byref(self._h)))
+        else:
+            self._h = _h
+
+    def clone(self):
+        h = C.c_void_p()
+        _check(_lib.kh_sponge_clone(self._h, C.byref(h)))
+        return Sponge(self.kind, self.curve, h)
+
+    def absorb_g(self, xy, inf=None):
+        xy = _c64(xy, (-1, 8))
+        i8 = None if inf is None else np.ascontiguousarray(inf, dtype=np.uint8)
+        _check(_lib.kh_sponge_absorb_g(self._h, _p64(xy), _p8(i8), xy.shape[0]))
+
+    def absorb(self, x):
+        x = _c64(x, (-1, 4))
+        _check(_lib.kh_sponge_absorb(self._h, _p64(x), x.shape[0]))
+
+    def absorb_fr(self, x):
+        x = _c64(x, (-1, 4))
+        _check(_lib.kh_sponge_absorb_fr(self._h, _p64(x), x.shape[0]))
+
+    def challenge(self) -> int:
+        c = np.zeros(2, dtype=np.uint64)
+        _check(_lib.kh_sponge_challenge(self._h, _p64(c)))
+        return int(c[0]) | (int(c[1]) << 64)
+
+    def challenge_field(self):
+        out = np.zeros(4, dtype=np.uint64)
+        _check(_lib.kh_sponge_challenge_field(self._h, _p64(out)))
+        return out
+
+    def squeeze_field(self):
+        out = np.zeros(4, dtype=np.uint64)
+        _check(_lib.kh_sponge_squeeze_field(self._h, _p64(out)))
+        return out
+
+    def digest(self):
+        out = np.zeros(4, dtype=np.uint64)
+        _check(_lib.kh_sponge_digest(self._h, _p64(out)))
+        return out
+
+    def free(self):
+        if self._h:
+            _lib.kh_sponge_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
 
 
 def sync():
