@@ -76,6 +76,9 @@ int kh_srs_device(const kh_srs_t *srs);   /* the device the handle's tables live
  * and the blinding base h (ipa.rs:765-772).  Affine x||y, Montgomery.  threads <= 0: all host cores. */
 int kh_srs_generate(int curve, size_t start, size_t count, uint64_t *out_xy, int threads);
 int kh_srs_h(int curve, uint64_t out_xy[8]);
+/* GroupMap::to_group (groupmap/src/lib.rs:167-189): the U base of SRS::open / verify, u_base = to_group(sponge.challenge_fq())
+ * (ipa.rs:909-913).  t: a base-field element, Montgomery limbs.  Host code. */
+int kh_group_map_to_group(int curve, const uint64_t t[4], uint64_t out_xy[8]);
 
 /* SRS::create(depth) entirely on the device (csrc/srs_gen.hip: Blake2b + group map + Tonelli-Shanks per
  * thread; ~15 ms for 2^20 points), already expanded to the MSM window tables; kh_srs_get_g reads
@@ -329,6 +332,8 @@ int kh_lde(int field, const uint64_t *coeffs, unsigned log2_n, unsigned log2_blo
  * returns; kh_sync() is only needed before the HOST reads a device buffer through its own means. */
 int kh_dev_alloc(void **ptr, size_t bytes);
 int kh_dev_free(void *ptr);
+int kh_dev_copy(void *dst_dev, const void *src_dev, size_t bytes);   /* device-to-device, asynchronous on the library's main stream */
+int kh_dev_memset_zero(void *dst_dev, size_t bytes);
 int kh_dev_upload(void *dst_dev, const void *src_host, size_t bytes);
 int kh_dev_download(void *dst_host, const void *src_dev, size_t bytes);
 int kh_msm_batch_dev(kh_srs_t *srs, int basis, unsigned chunk, size_t offset,

@@ -1,0 +1,215 @@
+"""TEST INFRASTRUCTURE ONLY (see oracle/pasta.py): the parts of kimchi AROUND the hot path that a complete proof needs,
+restated in plain Python integers so that a proof produced by the device pipeline (proof_systems_amd/prover.py) can be
+CHECKED the way the reference's verifier checks it -- for circuits of generic gates (the benchmark circuit of
+kimchi/src/bench.rs:59-96), no lookups, no optional gates, no recursion, one chunk (SRS size = domain size).
+
+  Shifts::new                    kimchi/src/circuits/polynomials/permutation.rs:140-199   (Blake2b-sampled coset shifts)
+  constraint system / index     kimchi/src/circuits/constraints.rs:870-1010 (padding, zk_rows = 3, sid, sigma), gate.rs, wires.rs
+  VerifierIndex::digest          kimchi/src/verifier_index.rs:405-500
+  ProverProof::oracles           kimchi/src/verifier.rs:126-640   (Fiat-Shamir replay, ft_eval0)
+  to_batch                       kimchi/src/verifier.rs:781-1000  (f_comm, ft_comm, the evaluation list)
+  SRS::verify                    oracle/pasta.py ipa_verify_terms (pinned on the reference's opening-proof bytes)
+  generic gate                   kimchi/src/circuits/polynomials/generic.rs:83-120, argument.rs:201-214
+  alpha powers                   kimchi/src/linearization.rs:43-58,167-171: gates 0..20, permutation 21..23
+
+"Parity pinned by definition only" for this file as a whole: the reference's only whole-proof known-answer test
+(kimchi/src/tests/and.rs) needs the Rust prover's RNG stream and lookup gates.  Its building blocks are pinned
+(sponge: poseidon test vectors; SRS::verify / open: opening-proof bytes; MSM / commit: commitment bytes)."""
+import hashlib
+from typing import List, Optional, Sequence
+
+from . import pasta as P
+from . import poseidon as S
+
+COLUMNS, PERMUTS, ZK_ROWS = 15, 7, 3
+ALPHA_PERM0 = 21           # VarbaseMul::CONSTRAINTS = 21 powers are registered for the gates first (linearization.rs:56-58)
+
+
+# ---------------------------------------------------------------------------------------------------- index
+def sample_shifts(F: P.Field, log2_n: int) -> List[int]:
+    """Shifts::new: shift_0 = 1, the others quadratic non-residues outside the domain sampled from Blake2b512(counter)."""
+    n = 1 << log2_n
+    counter = [7]
+
+    def sample():
+        while True:
+            counter[0] += 1
+            d = hashlib.blake2b(counter[0].to_bytes(4, "big"), digest_size=64).digest()
+            s = int.from_bytes(d[:31], "little")                       # F::from_random_bytes(&h[..31])
+            if pow(s, (F.p - 1) // 2, F.p) == F.p - 1 and pow(s, n, F.p) != 1:
+                return s
+    shifts = [1]
+    for _ in range(1, PERMUTS):
+        s = sample()
+        while s in shifts:
+            s = sample()
+        shifts.append(s)
+    return shifts
+
+
+def generic_const_row(F: P.Field, c: int) -> List[int]:
+    """CircuitGate::create_generic_gadget(wires, GenericGateSpec::Const(c), None): coefficients of one row."""
+    co = [0] * COLUMNS
+    co[0] = 1; co[4] = (-c) % F.p
+    return co
+
+
+def build_index(F: P.Field, log2_n: int, gate_coeffs: Sequence[Sequence[int]], wiring=None):
+    """Constraint system of `len(gate_coeffs)` generic gates on a domain of 2^log2_n rows: the remaining rows are Zero
+    gates wired to themselves.  wiring[(col, row)] = (col', row') overrides Wire::for_row (the identity)."""
+    n = 1 << log2_n
+    assert len(gate_coeffs) + ZK_ROWS <= n
+    omega = F.root_of_unity(log2_n)
+    sid = [1] * n
+    for j in range(1, n):
+        sid[j] = sid[j - 1] * omega % F.p
+    shifts = sample_shifts(F, log2_n)
+    coeffs = [[0] * n for _ in range(COLUMNS)]
+    sel = [0] * n
+    for r, co in enumerate(gate_coeffs):
+        sel[r] = 1
+        for c in range(COLUMNS):
+            coeffs[c][r] = co[c] % F.p
+    sigma = [[shifts[c] * sid[r] % F.p for r in range(n)] for c in range(PERMUTS)]
+    if wiring:
+        for (c, r), (c2, r2) in wiring.items():
+            sigma[c][r] = shifts[c2] * sid[r2] % F.p
+    return {"F": F, "log2_n": log2_n, "n": n, "omega": omega, "sid": sid, "shifts": shifts, "coefficients": coeffs, "generic_selector": sel,
+            "sigma": sigma, "zk_rows": ZK_ROWS, "gates": len(gate_coeffs)}
+
+
+def eval_permutation_vanishing_polynomial(ix, x: int) -> int:
+    F = ix["F"]; n = ix["n"]
+    t = pow(ix["omega"], n - ZK_ROWS, F.p)
+    return (x - t) * (x - t * ix["omega"]) % F.p * (x - pow(ix["omega"], n - 1, F.p)) % F.p
+
+
+def absorb_commitment(sponge, chunks):
+    sponge.absorb_g(chunks)
+
+
+def verifier_index_digest(curve: P.Curve, vix) -> int:
+    sp = S.DefaultFqSponge(curve)
+    for c in vix["sigma_comm"]:
+        absorb_commitment(sp, c)
+    for c in vix["coefficients_comm"]:
+        absorb_commitment(sp, c)
+    for k in ("generic_comm", "psm_comm", "complete_add_comm", "mul_comm", "emul_comm", "endomul_scalar_comm"):
+        absorb_commitment(sp, vix[k])
+    return sp.challenge_fq()                               # digest_fq
+
+
+# ---------------------------------------------------------------------------------------------------- verifier
+def generic_constant_term(F: P.Field, ev, alpha: int) -> int:
+    """index(Generic) * (alpha^0 c1 + alpha^1 c2) at zeta from the proof's evaluations (the only non-zero part of
+    linearization.constant_term for a circuit whose other selectors are the zero polynomial)."""
+    w = [e[0] for e in ev["w"]]; co = [e[0] for e in ev["coefficients"]]
+    c1 = (co[0] * w[0] + co[1] * w[1] + co[2] * w[2] + co[3] * w[0] * w[1] + co[4]) % F.p
+    c2 = (co[5] * w[3] + co[6] * w[4] + co[7] * w[5] + co[8] * w[3] * w[4] + co[9]) % F.p
+    return ev["generic_selector"][0] * (c1 + alpha * c2) % F.p
+
+
+def perm_scalars(F: P.Field, ev, beta: int, gamma: int, alpha0: int, zkp_zeta: int) -> int:
+    r = ev["z"][1] * beta % F.p * alpha0 % F.p * zkp_zeta % F.p
+    for w, s in zip(ev["w"], ev["s"]):
+        r = r * ((gamma + beta * s[0] + w[0]) % F.p) % F.p
+    return (-r) % F.p
+
+
+EVAL_ORDER = ["z", "generic_selector", "poseidon_selector", "complete_add_selector", "mul_selector", "emul_selector", "endomul_scalar_selector"]
+
+
+def columns_in_opening_order(ev):
+    """z, the six selectors, w x 15, coefficients x 15, s x 6: FrSponge::absorb_evaluations (plonk_sponge.rs:92-155) and
+    the verifier's evaluation list (verifier.rs:988-1010) use the same order."""
+    out = [ev[k] for k in EVAL_ORDER]
+    out += list(ev["w"]) + list(ev["coefficients"]) + list(ev["s"])
+    return out
+
+
+def fiat_shamir(curve: P.Curve, vix, proof, digest: int):
+    """verifier.rs:160-420: returns the challenges and the Fq-sponge as SRS::verify needs it."""
+    F = curve.scalar
+    _, endo_r = P.endos(curve)
+    fq = S.DefaultFqSponge(curve)
+    fq.absorb_fq([digest])
+    absorb_commitment(fq, [vix["h"]])                                   # public_comm of an empty public input: the blinding commitment
+    for c in proof["w_comm"]:
+        absorb_commitment(fq, c)
+    beta = fq.challenge(); gamma = fq.challenge()
+    absorb_commitment(fq, proof["z_comm"])
+    alpha = P.challenge_to_field(F, fq.challenge(), endo_r)
+    assert len(proof["t_comm"]) <= 7
+    absorb_commitment(fq, proof["t_comm"])
+    zeta = P.challenge_to_field(F, fq.challenge(), endo_r)
+    dg = fq.clone().challenge_fq()
+    dg = dg if dg < F.p else 0                                          # FqSponge::digest
+    fr = S.ArithmeticSponge(F)
+    fr.absorb([dg])
+    fr.absorb([S.ArithmeticSponge(F).squeeze()])                        # prev_challenge_digest of no previous challenges
+    ev = proof["evals"]
+    fr.absorb([proof["ft_eval1"]])
+    fr.absorb([ev["public"][0]]); fr.absorb([ev["public"][1]])
+    for col in columns_in_opening_order(ev):
+        fr.absorb([col[0]]); fr.absorb([col[1]])
+
+    def fr_challenge():                                                 # DefaultFrSponge::challenge: 128 bits of one squeeze (the
+        x = fr.squeeze()                                                # buffer is emptied by every absorb; two limbs per squeeze)
+        return x & ((1 << 128) - 1)
+    # v and u come from consecutive challenge() calls: last_squeezed holds exactly the two limbs of one squeeze
+    v = P.challenge_to_field(F, fr_challenge(), endo_r)
+    u = P.challenge_to_field(F, fr_challenge(), endo_r)
+    return {"beta": beta, "gamma": gamma, "alpha": alpha, "zeta": zeta, "v": v, "u": u, "fq_sponge": fq}
+
+
+def verify(curve: P.Curve, vix, proof, g, h, rng, final_msm=None) -> bool:
+    """kimchi::verifier::verify for the configuration described in the header.  vix: n, log2_n, omega, shifts, h and the
+    index commitments; proof: w_comm, z_comm, t_comm (chunk lists of affine points / None), evals, ft_eval1, opening."""
+    F = curve.scalar
+    n = vix["n"]
+    ch = fiat_shamir(curve, vix, proof, verifier_index_digest(curve, vix))
+    beta, gamma, alpha, zeta, v, u = ch["beta"], ch["gamma"], ch["alpha"], ch["zeta"], ch["v"], ch["u"]
+    ev = proof["evals"]
+    omega = vix["omega"]
+    zetaw = zeta * omega % F.p
+    zeta1 = pow(zeta, n, F.p)
+    alphas = [pow(alpha, ALPHA_PERM0 + i, F.p) for i in range(3)]
+    zkp = eval_permutation_vanishing_polynomial(vix, zeta)
+    # ---- ft_eval0 (verifier.rs:412-490)
+    ft0 = (ev["w"][PERMUTS - 1][0] + gamma) * ev["z"][1] % F.p * alphas[0] % F.p * zkp % F.p
+    for w, s in zip(ev["w"], ev["s"]):
+        ft0 = ft0 * ((beta * s[0] + w[0] + gamma) % F.p) % F.p
+    ft0 = (ft0 - ev["public"][0]) % F.p
+    t = alphas[0] * zkp % F.p * ev["z"][0] % F.p
+    for w, sh in zip(ev["w"], vix["shifts"]):
+        t = t * ((gamma + beta * zeta % F.p * sh + w[0]) % F.p) % F.p
+    ft0 = (ft0 - t) % F.p
+    zeta1m1 = (zeta1 - 1) % F.p
+    w_zk = pow(omega, n - ZK_ROWS, F.p)                                 # index.w()
+    num = (zeta1m1 * alphas[1] % F.p * (zeta - w_zk) + zeta1m1 * alphas[2] % F.p * (zeta - 1)) % F.p * ((1 - ev["z"][0]) % F.p) % F.p
+    den = (zeta - w_zk) * (zeta - 1) % F.p
+    ft0 = (ft0 + num * F.inv(den)) % F.p
+    ft0 = (ft0 - generic_constant_term(F, ev, alpha)) % F.p
+    # ---- commitments: f_comm = perm_scalar * sigma_comm[6]; ft_comm = f_comm - (zeta^n - 1) * sum_i zeta^(n i) t_comm[i]
+    scal = perm_scalars(F, ev, beta, gamma, alphas[0], zkp)
+    sig6 = vix["sigma_comm"][PERMUTS - 1][0]
+    f_comm = curve.mul(sig6, scal) if sig6 is not None else None
+    t_chunk, pw = None, 1
+    for c in proof["t_comm"]:
+        if c is not None:
+            t_chunk = curve.add(t_chunk, curve.mul(c, pw))
+        pw = pw * zeta1 % F.p                                           # zeta^max_poly_size, max_poly_size = n
+    neg = curve.mul(t_chunk, (-zeta1m1) % F.p) if t_chunk is not None else None
+    ft_comm = curve.add(f_comm, neg)
+    # ---- the evaluation list (one chunk each): public, ft, then the columns in opening order
+    evaluations = [([h], [[ev["public"][0]], [ev["public"][1]]]), ([ft_comm], [[ft0], [proof["ft_eval1"]]])]
+    comms = [proof["z_comm"], vix["generic_comm"], vix["psm_comm"], vix["complete_add_comm"], vix["mul_comm"], vix["emul_comm"], vix["endomul_scalar_comm"]]
+    comms += list(proof["w_comm"]) + list(vix["coefficients_comm"]) + list(vix["sigma_comm"][:PERMUTS - 1])
+    for c, e in zip(comms, columns_in_opening_order(ev)):
+        evaluations.append((c, [[e[0]], [e[1]]]))
+    item = {"sponge": ch["fq_sponge"], "evaluation_points": [zeta, zetaw], "polyscale": v, "evalscale": u, "evaluations": evaluations,
+            "opening": proof["opening"], "combined_inner_product": P.combined_inner_product(F, v, u, [e for _, e in evaluations])}
+    if final_msm is None:
+        return P.ipa_verify(curve, g, h, [item], rng)
+    g_terms, pts, sc = P.ipa_verify_terms(curve, n, h, [item], rng)
+    return final_msm(g_terms, pts, sc)

@@ -1120,6 +1120,27 @@ int kh_dev_alloc(void** ptr, size_t bytes) {
     return KH_OK;
 }
 int kh_dev_free(void* ptr) { if (ptr) KH_HIP(hipFree(ptr)); return KH_OK; }
+// device-to-device copy on the main stream (ordered with kh_ntt_dev / kh_lde_dev / the vector steps; asynchronous)
+int kh_dev_copy(void* dst_dev, const void* src_dev, size_t bytes) {
+    int rc = ensure_init(); if (rc) return rc;
+    if (bytes == 0) return KH_OK;
+    KH_REQUIRE(dst_dev && src_dev, "kh_dev_copy: null pointer");
+    Context& C = ctx();
+    std::lock_guard<std::mutex> lk(C.mu);
+    KH_HIP(hipMemcpyAsync(dst_dev, src_dev, bytes, hipMemcpyDeviceToDevice, C.stream));
+    if (hipEventRecord(C.order_ev, C.stream) == hipSuccess) C.main_dirty = true;
+    return KH_OK;
+}
+int kh_dev_memset_zero(void* dst_dev, size_t bytes) {
+    int rc = ensure_init(); if (rc) return rc;
+    if (bytes == 0) return KH_OK;
+    KH_REQUIRE(dst_dev, "kh_dev_memset_zero: null pointer");
+    Context& C = ctx();
+    std::lock_guard<std::mutex> lk(C.mu);
+    KH_HIP(hipMemsetAsync(dst_dev, 0, bytes, C.stream));
+    if (hipEventRecord(C.order_ev, C.stream) == hipSuccess) C.main_dirty = true;
+    return KH_OK;
+}
 // The library's streams are non-blocking (they do not synchronise with the null stream hipMemcpy uses), so both copies
 // first wait for the main stream: an asynchronous kh_ntt_dev / kh_lde_dev on this buffer is complete before it is read
 // or overwritten.

@@ -214,6 +214,16 @@ int kh_srs_generate(int curve, size_t start, size_t count, uint64_t* out_xy, int
     for (auto& t : th) t.join();
     return KH_OK;
 }
+// GroupMap::to_group (groupmap/src/lib.rs:167-189) of a base-field element: the U base of SRS::open / verify
+// (ipa.rs:909-913: u_base = group_map.to_group(sponge.challenge_fq()))
+int kh_group_map_to_group(int curve, const uint64_t t[4], uint64_t out_xy[8]) {
+    KH_REQUIRE(curve == KH_CURVE_VESTA || curve == KH_CURVE_PALLAS, "unknown curve id %d", curve);
+    KH_REQUIRE(t && out_xy, "null argument");
+    fe tt, x, y; memcpy(&tt, t, 32);
+    group_map(curve).to_group(tt, x, y);
+    memcpy(out_xy, &x, 32); memcpy(out_xy + 4, &y, 32);
+    return KH_OK;
+}
 int kh_srs_h(int curve, uint64_t out_xy[8]) {
     KH_REQUIRE(curve == KH_CURVE_VESTA || curve == KH_CURVE_PALLAS, "unknown curve id %d", curve);
     KH_REQUIRE(out_xy, "null output");

@@ -30,6 +30,7 @@ MSM_SLOTS = 4          # KH_MSM_SLOTS: jobs kh_msm_submit accepts before kh_msm_
 SYMBOLS = [
     "kh_sponge_new", "kh_sponge_clone", "kh_sponge_free", "kh_sponge_absorb_g", "kh_sponge_absorb", "kh_sponge_absorb_fr", "kh_sponge_challenge",
     "kh_sponge_challenge_field", "kh_sponge_squeeze_field", "kh_sponge_digest",
+    "kh_group_map_to_group", "kh_dev_copy", "kh_dev_memset_zero",
     "kh_device_count", "kh_init", "kh_set_device", "kh_get_device", "kh_trim", "kh_srs_device", "kh_last_error", "kh_srs_create", "kh_srs_free", "kh_srs_size",
     "kh_srs_set_lagrange", "kh_srs_compute_lagrange", "kh_srs_get_lagrange", "kh_srs_lagrange_chunks",
     "kh_msm", "kh_msm_batch", "kh_msm_points", "kh_ntt", "kh_lde",
@@ -401,6 +402,40 @@ class DevBuf:
         if self.ptr:
             _check(_lib.kh_dev_free(C.c_void_p(self.ptr)))
             self.ptr = None
+
+    def view(self, offset_bytes: int):
+        """A non-owning alias of this allocation starting `offset_bytes` in (anything with a .ptr is accepted as a column)."""
+        return DevView(self.ptr + offset_bytes)
+
+    def upload_at(self, offset_bytes: int, arr):
+        arr = np.ascontiguousarray(arr)
+        assert offset_bytes + arr.nbytes <= self.nbytes
+        _check(_lib.kh_dev_upload(C.c_void_p(self.ptr + offset_bytes), arr.ctypes.data_as(C.c_void_p), arr.nbytes))
+
+    def download_at(self, offset_bytes: int, shape, dtype=np.uint64):
+        out = np.empty(shape, dtype=dtype)
+        assert offset_bytes + out.nbytes <= self.nbytes
+        _check(_lib.kh_dev_download(out.ctypes.data_as(C.c_void_p), C.c_void_p(self.ptr + offset_bytes), out.nbytes))
+        return out
+
+    def zero(self):
+        _check(_lib.kh_dev_memset_zero(C.c_void_p(self.ptr), self.nbytes))
+        return self
+
+
+class DevView:
+    def __init__(self, ptr: int):
+        self.ptr = ptr
+
+
+def dev_copy(dst_ptr: int, src_ptr: int, nbytes: int):
+    _check(_lib.kh_dev_copy(C.c_void_p(dst_ptr), C.c_void_p(src_ptr), nbytes))
+
+
+def group_map_to_group(curve: int, t):
+    out = np.zeros(8, dtype=np.uint64)
+    _check(_lib.kh_group_map_to_group(curve, _p64(_c64(t, (4,))), _p64(out)))
+    return out
 
 
 def ntt_dev(field: int, buf: DevBuf, log2_n: int, inverse: bool, batch: int):

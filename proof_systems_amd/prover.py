@@ -1,0 +1,369 @@
+"""A complete Kimchi proof with every data-parallel step on the device -- the caller of the hot path, restated.
+
+`ProverProof::create` (kimchi/src/prover.rs:187-1515) for circuits of generic gates (the benchmark circuit of
+kimchi/src/bench.rs:59-122: 2^k - 10 `Const(1)` gates, 15 witness columns of ones), no lookups, no optional gates, no
+recursion, one chunk (SRS size = domain size).  The columns never leave HBM between the witness upload and the opening
+proof: witness -> 15 Lagrange-basis commitments -> iNTT -> permutation accumulator z (permutation.rs:447-577) -> commit
+-> 8x extension of w, z (constraints.rs:487-507) -> generic-gate rows on d4 and permutation rows on d8 -> iNTT(4n),
+iNTT(8n) -> division by Z_H with the remainder asserted ZERO -> boundary quotients -> 7-chunk commitment of t -> chunked
+evaluations at zeta, zeta*omega -> ft -> combine_polys / b_init -> the 16 folding rounds of SRS::open.  The transcript runs
+through the library's native sponges (kh_sponge_*), so every challenge is the real Fiat-Shamir value; the host keeps what
+is scalar and sequential (challenge algebra, blinders, the Schnorr tail of the opening), as the reference does.
+
+What is NOT evaluated: the constraints of Poseidon / CompleteAdd / VarBaseMul / EndoMul / EndoMulScalar.  The reference
+evaluates them over d8 on every proof (prover.rs:824-868) although their selectors are the zero polynomial for such a
+circuit; they contribute exactly zero to the quotient, so the proof is the same (their selector columns, commitments and
+evaluations ARE part of the proof and of the transcript here).
+
+The proof this produces is checked by the oracle's restatement of the reference VERIFIER (oracle/kimchi.py: Fiat-Shamir
+replay with the oracle's own sponge, ft_eval0, ft_comm, SRS::verify) in tests/test_gpu_prover.py; bench.py times it.
+This module is product code: it never imports the oracle."""
+from __future__ import annotations
+
+import hashlib
+import time
+
+import numpy as np
+
+from . import khip
+from . import polish as OP
+
+COLUMNS, PERMUTS, ZK_ROWS = 15, 7, 3
+ALPHA_PERM0 = 21                    # the gates register 21 powers of alpha first (linearization.rs:56-58), the permutation the next 3
+MOD = {khip.FP: 0x40000000000000000000000000000000224698fc094cf91b992d30ed00000001,
+       khip.FQ: 0x40000000000000000000000000000000224698fc0994a8dd8c46eb2100000001}
+R256 = 1 << 256
+
+
+class Fld:
+    """Host scalars: Python integers, converted to / from the wire form (4 Montgomery limbs) at the C ABI."""
+
+    def __init__(self, fid: int):
+        self.fid, self.p = fid, MOD[fid]
+        self.rinv = pow(R256, -1, self.p)
+
+    def limbs(self, v: int):
+        m = (v % self.p) * R256 % self.p
+        return np.array([(m >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)], dtype=np.uint64)
+
+    def limbs_many(self, vs):
+        return np.stack([self.limbs(v) for v in vs]) if len(vs) else np.zeros((0, 4), np.uint64)
+
+    def value(self, l) -> int:
+        m = int(l[0]) | (int(l[1]) << 64) | (int(l[2]) << 128) | (int(l[3]) << 192)
+        return m * self.rinv % self.p
+
+    def inv(self, v: int) -> int:
+        return pow(v, -1, self.p)
+
+    def rand(self, rng) -> int:
+        return int.from_bytes(rng.bytes(40), "little") % self.p
+
+
+def sample_shifts(F: Fld, log2_n: int):
+    """Shifts::new (permutation.rs:140-199): shift_0 = 1, then quadratic non-residues outside the domain from Blake2b512(counter)."""
+    n = 1 << log2_n
+    counter = [7]
+
+    def sample():
+        while True:
+            counter[0] += 1
+            d = hashlib.blake2b(counter[0].to_bytes(4, "big"), digest_size=64).digest()
+            s = int.from_bytes(d[:31], "little")
+            if pow(s, (F.p - 1) // 2, F.p) == F.p - 1 and pow(s, n, F.p) != 1:
+                return s
+    shifts = [1]
+    for _ in range(1, PERMUTS):
+        s = sample()
+        while s in shifts:
+            s = sample()
+        shifts.append(s)
+    return shifts
+
+
+def scalar_challenge(curve: int, F: Fld, chal: int) -> int:
+    return F.value(khip.scalar_challenge_to_field(curve, chal))
+
+
+class ProverIndex:
+    """Index of a generic-gate circuit on a domain of 2^log2_n rows, device-resident: coefficient and selector columns,
+    sigma, their coefficient forms and 8x extensions, x and the permutation vanishing polynomial on d8, the SRS with its
+    Lagrange basis, and the verifier-index commitments + digest (verifier_index.rs:175-300, 405-500)."""
+
+    def __init__(self, curve: int, log2_n: int, gate_coeffs, srs=None):
+        """gate_coeffs: (rows, 15, 4) uint64 Montgomery limbs -- coefficient rows of the generic gates (rows <= n - 3)."""
+        self.curve = curve
+        self.fid = khip.FP if curve == khip.VESTA else khip.FQ
+        F = self.F = Fld(self.fid)
+        self.log2_n, self.n = log2_n, 1 << log2_n
+        n, fid = self.n, self.fid
+        gate_coeffs = np.ascontiguousarray(gate_coeffs, dtype=np.uint64).reshape(-1, COLUMNS, 4)
+        self.gates = gate_coeffs.shape[0]
+        assert self.gates + ZK_ROWS <= n
+        self.srs = srs if srs is not None else khip.Srs.create(curve, n)
+        if self.srs.lagrange_chunks(log2_n) == 0:
+            self.srs.compute_lagrange(log2_n)                 # SRS::lagrange_basis on the device (index time)
+        self.h = khip.srs_h(curve)
+        self.omega = F.value(khip.domain_generator(fid, log2_n))
+        self.shifts = sample_shifts(F, log2_n)
+        one = F.limbs(1)
+        # ---- d1 evaluation columns: coefficients (15), generic selector, sid, sigma (7)
+        co = np.zeros((COLUMNS, n, 4), dtype=np.uint64)
+        co[:, :self.gates, :] = np.transpose(gate_coeffs, (1, 0, 2))
+        sel = np.zeros((n, 4), dtype=np.uint64); sel[:self.gates] = one
+        self.d1 = khip.DevBuf((COLUMNS + 1 + 1 + PERMUTS) * n * 32)     # [coef 0..14 | sel | sid | sigma 0..6]
+        self.d1.upload_at(0, co); self.d1.upload_at(COLUMNS * n * 32, sel)
+        xpoly = np.zeros((n, 4), dtype=np.uint64); xpoly[1] = one
+        sid = self.col1(COLUMNS + 1)
+        self.d1.upload_at((COLUMNS + 1) * n * 32, xpoly)
+        khip.ntt_dev(fid, sid, log2_n, False, 1)                                                 # sid[j] = omega^j
+        for i in range(PERMUTS):                                                                 # identity wiring: sigma_i = shift_i * sid
+            khip.expr_evaluations_dev(fid, [OP.cell(0), (OP.TOK_CONST, 0), (OP.TOK_MUL, 0)], [sid], [n], F.limbs_many([self.shifts[i]]), n, self.col1(COLUMNS + 2 + i))
+        self._finish_columns()
+
+    # d1 / coefficient / d8 column views --------------------------------------------------------
+    def col1(self, k):
+        return self.d1.view(k * self.n * 32)
+
+    def colc(self, k):
+        return self.dc.view(k * self.n * 32)
+
+    def col8(self, k):
+        return self.d8.view(k * 8 * self.n * 32)
+
+    def set_sigma(self, sigma_limbs):
+        """Replace the identity wiring by sigma columns (7, n, 4) computed by the caller (copy constraints)."""
+        self.d1.upload_at((COLUMNS + 2) * self.n * 32, np.ascontiguousarray(sigma_limbs, dtype=np.uint64))
+        self._finish_columns()
+
+    def _finish_columns(self):
+        n, fid, F, logn = self.n, self.fid, self.F, self.log2_n
+        ncol = COLUMNS + 1 + 1 + PERMUTS                                # same order as d1
+        if not hasattr(self, "dc"):
+            self.dc = khip.DevBuf((ncol + 2) * n * 32)                  # + [x | zkpm] in coefficient form
+            self.d8 = khip.DevBuf((ncol + 2) * 8 * n * 32)
+            self.zero_poly = khip.DevBuf(n * 32).zero()                 # the five absent selectors: the zero polynomial
+        khip.dev_copy(self.dc.ptr, self.d1.ptr, ncol * n * 32)
+        khip.ntt_dev(fid, self.dc, logn, True, ncol)                    # coefficient forms
+        xpoly = np.zeros((n, 4), dtype=np.uint64); xpoly[1] = F.limbs(1)
+        a = pow(self.omega, n - ZK_ROWS, F.p); b = a * self.omega % F.p; c = pow(self.omega, n - 1, F.p)
+        zk = np.zeros((n, 4), dtype=np.uint64)                          # (x - a)(x - b)(x - c): permutation_vanishing_polynomial
+        zk[:4] = F.limbs_many([(-a * b * c) % F.p, (a * b + a * c + b * c) % F.p, (-(a + b + c)) % F.p, 1])
+        self.zkpm_coeffs = [(-a * b * c) % F.p, (a * b + a * c + b * c) % F.p, (-(a + b + c)) % F.p, 1]
+        self.dc.upload_at(ncol * n * 32, xpoly); self.dc.upload_at((ncol + 1) * n * 32, zk)
+        khip.lde_dev(fid, self.dc, logn, 3, self.d8, ncol + 2)          # everything on d8
+        self.X8, self.ZKPM8 = ncol, ncol + 1
+        # ---- verifier-index commitments (commit_evaluations_non_hiding over the Lagrange basis; selectors masked with 1)
+        com, inf = self.srs.msm_batch_dev(self.d1.ptr, n, COLUMNS + 1, basis=logn)
+        self.coefficients_comm = [(com[i], bool(inf[i])) for i in range(COLUMNS)]
+        g, ginf = self.srs.mask_custom(com[COLUMNS:COLUMNS + 1], inf[COLUMNS:COLUMNS + 1], F.limbs_many([1]))
+        self.generic_comm = (g[0], bool(ginf[0]))
+        com, inf = self.srs.msm_batch_dev(self.col1(COLUMNS + 2).ptr, n, PERMUTS, basis=logn)
+        self.sigma_comm = [(com[i], bool(inf[i])) for i in range(PERMUTS)]
+        self.zero_selector_comm = (self.h.copy(), False)                # identity + 1 * h
+        sp = khip.Sponge(khip.Sponge.FQ, self.curve)
+        for c_, i_ in self.sigma_comm + self.coefficients_comm + [self.generic_comm] + [self.zero_selector_comm] * 5:
+            sp.absorb_g(c_.reshape(1, 8), np.array([1 if i_ else 0], dtype=np.uint8))
+        self.digest = sp.squeeze_field()                                # VerifierIndex::digest -> digest_fq
+        sp.free()
+        khip.sync()
+
+    def free(self):
+        for b in (self.d1, self.dc, self.d8, self.zero_poly):
+            b.free()
+
+
+def bench_circuit_index(curve: int, log2_n: int, srs=None) -> ProverIndex:
+    """BenchmarkCtx::new(log2_n) (kimchi/src/bench.rs:59-96): 2^log2_n - 10 generic gates `Const(1)`, wired to themselves."""
+    fid = khip.FP if curve == khip.VESTA else khip.FQ
+    F = Fld(fid)
+    rows = (1 << log2_n) - 10
+    co = np.zeros((rows, COLUMNS, 4), dtype=np.uint64)
+    co[:, 0, :] = F.limbs(1); co[:, 4, :] = F.limbs(F.p - 1)           # 1 * w0 - 1 = 0
+    return ProverIndex(curve, log2_n, co, srs)
+
+
+def create_proof(ix: ProverIndex, witness, rng, timings=None, check: bool = True, witness_on_device=None):
+    """ProverProof::create.  witness: (15, rows, 4) Montgomery limbs, rows <= n - 3 (padded with zeros, the last 3 rows
+    randomised, prover.rs:254-266) -- or witness_on_device: a DevBuf already holding the padded (15, n, 4) columns.
+    rng: numpy Generator (blinders, zero-knowledge rows).  Returns the proof as a dict of limb arrays / Python ints."""
+    F, fid, n, logn, curve, srs = ix.F, ix.fid, ix.n, ix.log2_n, ix.curve, ix.srs
+    t_start = time.perf_counter()
+    marks = []
+
+    def mark(name):
+        marks.append((name, time.perf_counter()))
+    one = F.limbs(1)
+    NB = n * 32
+    # ---- witness on the device: [w 0..14 | z] in evaluation form, then in coefficient form, then on d8
+    ev = khip.DevBuf(16 * NB)
+    if witness_on_device is None:
+        w = np.zeros((COLUMNS, n, 4), dtype=np.uint64)
+        wit = np.asarray(witness, dtype=np.uint64).reshape(COLUMNS, -1, 4)
+        assert wit.shape[1] + ZK_ROWS <= n, "NoRoomForZkInWitness"
+        w[:, :wit.shape[1]] = wit
+        w[:, n - ZK_ROWS:] = F.limbs_many([F.rand(rng) for _ in range(COLUMNS * ZK_ROWS)]).reshape(COLUMNS, ZK_ROWS, 4)
+        ev.upload_at(0, w)
+    else:
+        khip.dev_copy(ev.ptr, witness_on_device.ptr, COLUMNS * NB)
+    mark("witness_upload")
+    fq = khip.Sponge(khip.Sponge.FQ, curve)
+    fq.absorb(ix.digest)
+    public_comm = (ix.h.copy(), False)                      # zero public polynomial: commit_non_hiding -> [0], masked with 1 -> h
+    fq.absorb_g(public_comm[0].reshape(1, 8))
+    # ---- witness commitments (commit_evaluations_non_hiding x 15 in one batched MSM over the Lagrange basis) + blinders
+    com, inf = srs.msm_batch_dev(ev.ptr, n, COLUMNS, basis=logn)
+    w_blind = [F.rand(rng) for _ in range(COLUMNS)]
+    w_comm, w_inf = srs.mask_custom(com, inf, F.limbs_many(w_blind))
+    fq.absorb_g(w_comm, w_inf)
+    mark("witness_commit")
+    cf = khip.DevBuf(16 * NB)                               # coefficient forms [w | z]
+    khip.dev_copy(cf.ptr, ev.ptr, COLUMNS * NB)
+    khip.ntt_dev(fid, cf, logn, True, COLUMNS)
+    beta = F.value(fq.challenge_field()); gamma = F.value(fq.challenge_field())
+    # ---- permutation accumulator z (perm_aggreg): numerators / denominators, batch inversion, running product
+    d1cols = [ev.view(i * NB) for i in range(PERMUTS)] + [ix.col1(COLUMNS + 2 + i) for i in range(PERMUTS)] + [ix.col1(COLUMNS + 1)]
+    consts = F.limbs_many([gamma, beta] + [beta * s % F.p for s in ix.shifts])
+    num_t, den_t = OP.perm_aggreg_tokens()
+    num = khip.DevBuf(NB); den = khip.DevBuf(NB)
+    num.upload_at(0, one); den.upload_at(0, one)
+    khip.expr_evaluations_dev(fid, num_t, d1cols, [n] * 15, consts, n - 1, num, out_offset=1)
+    khip.expr_evaluations_dev(fid, den_t, d1cols, [n] * 15, consts, n - 1, den, out_offset=1)
+    khip.batch_inversion_dev(fid, den, n - 1, offset=1)
+    zcol = ev.view(COLUMNS * NB)
+    khip.expr_evaluations_dev(fid, [OP.cell(0), OP.cell(1), (OP.TOK_MUL, 0)], [num, den], [n, n], one.reshape(1, 4), n, zcol)
+    khip.field_scan_dev(fid, khip.SCAN_MUL, zcol, n - ZK_ROWS + 1)
+    if check:
+        last = F.value(ev.download_at((COLUMNS * n + n - ZK_ROWS) * 32, (4,)))
+        if last != 1:
+            raise RuntimeError("final value of the permutation accumulator is not 1 (permutation.rs:566-568)")
+    ev.upload_at((COLUMNS * n + n - ZK_ROWS + 1) * 32, F.limbs_many([F.rand(rng), F.rand(rng)]))     # the two random rows
+    khip.dev_copy(cf.ptr + COLUMNS * NB, zcol.ptr, NB)
+    khip.ntt_dev(fid, cf.view(COLUMNS * NB), logn, True, 1)
+    zc = cf.view(COLUMNS * NB)
+    com, inf = srs.msm_batch_dev(zc.ptr, n, 1)
+    z_blind = F.rand(rng)
+    z_comm, z_inf = srs.mask_custom(com, inf, F.limbs_many([z_blind]))
+    fq.absorb_g(z_comm, z_inf)
+    mark("z")
+    alpha = scalar_challenge(curve, F, fq.challenge())
+    alphas = [pow(alpha, ALPHA_PERM0 + i, F.p) for i in range(3)]
+    # ---- 8x extension of w and z, constraint rows, quotient
+    e8 = khip.DevBuf(16 * 8 * NB)
+    khip.lde_dev(fid, cf, logn, 3, e8, 16)
+    N8 = 8 * NB
+    gen_cols = [e8.view(i * N8) for i in range(6)] + [ix.col8(i) for i in range(10)] + [ix.col8(COLUMNS)]
+    t4 = khip.DevBuf(4 * NB); t8 = khip.DevBuf(N8)
+    khip.expr_evaluations_dev(fid, OP.generic_gate_tokens(0, 6, 16, 0, 1), gen_cols, [8 * n] * 17, F.limbs_many([1, alpha]), 4 * n, t4, stride=2, next_shift=8)
+    perm_cols = [e8.view(i * N8) for i in range(PERMUTS)] + [ix.col8(COLUMNS + 2 + i) for i in range(PERMUTS)] + [e8.view(COLUMNS * N8), ix.col8(ix.X8), ix.col8(ix.ZKPM8)]
+    pconsts = F.limbs_many([gamma, beta, alphas[0]] + [beta * s % F.p for s in ix.shifts])
+    khip.expr_evaluations_dev(fid, OP.perm_quot_tokens(w0=0, s0=7, z=14, x=15, zkpm=16, gamma=0, beta=1, bshift0=3, alpha0=2), perm_cols, [8 * n] * 17, pconsts,
+                              8 * n, t8, stride=1, next_shift=8)
+    khip.ntt_dev(fid, t4, logn + 2, True, 1)
+    khip.ntt_dev(fid, t8, logn + 3, True, 1)
+    khip.poly_lincomb_dev(fid, [t8, t4], [8 * n, 4 * n], F.limbs_many([1, 1]), t8, 8 * n)      # f = t4 + t8 (+ the zero public polynomial)
+    quot = khip.DevBuf(7 * NB); rem = khip.DevBuf(NB)
+    khip.divide_by_vanishing_poly_dev(fid, t8, 8 * n, logn, quot, rem)
+    if check and rem.download((n, 4)).any():
+        raise RuntimeError("rest of division by vanishing polynomial (prover.rs:913-917)")
+    zm1 = khip.DevBuf(NB); b1 = khip.DevBuf(NB); b2 = khip.DevBuf(NB)
+    khip.poly_lincomb_dev(fid, [zc], [n], F.limbs_many([1]), zm1, n)
+    z0 = F.value(zm1.download_at(0, (4,)))
+    zm1.upload_at(0, F.limbs((z0 - 1) % F.p))
+    b1.zero(); b2.zero()
+    for a_, dst in ((1, b1), (pow(ix.omega, n - ZK_ROWS, F.p), b2)):
+        r_ = khip.divide_by_linear_dev(fid, zm1, n, F.limbs(a_), dst)
+        if check and r_.any():
+            raise RuntimeError("permutation boundary division rest (permutation.rs:301-321)")
+    khip.poly_lincomb_dev(fid, [quot, b1, b2], [7 * n, n - 1, n - 1], F.limbs_many([1, alphas[1], alphas[2]]), quot, 7 * n)
+    com, inf = srs.msm_batch_dev(quot.ptr, n, 7)
+    t_blind = [F.rand(rng) for _ in range(7)]
+    t_comm, t_inf = srs.mask_custom(com, inf, F.limbs_many(t_blind))
+    fq.absorb_g(t_comm, t_inf)
+    mark("quotient")
+    zeta = scalar_challenge(curve, F, fq.challenge())
+    zetaw = zeta * ix.omega % F.p
+    fq_before = fq.clone()
+    # ---- evaluations at zeta, zeta * omega (coefficient forms; one chunk each)
+    polys = [zc, ix.colc(COLUMNS)] + [ix.zero_poly] * 5 + [cf.view(i * NB) for i in range(COLUMNS)] + [ix.colc(i) for i in range(COLUMNS)] + \
+            [ix.colc(COLUMNS + 2 + i) for i in range(PERMUTS - 1)]
+    pts = F.limbs_many([zeta, zetaw])
+    evl = khip.evaluate_chunks_batch_dev(fid, polys, [n] * len(polys), [1] * len(polys), n, pts)
+    E = [(F.value(e[0, 0]), F.value(e[1, 0])) for e in evl]
+    evals = {"public": (0, 0), "z": E[0], "generic_selector": E[1], "poseidon_selector": E[2], "complete_add_selector": E[3], "mul_selector": E[4],
+             "emul_selector": E[5], "endomul_scalar_selector": E[6], "w": E[7:22], "coefficients": E[22:37], "s": E[37:43]}
+    # ---- ft = perm_scalar * sigma_6 - (zeta^n - 1) * sum_i zeta^(n i) t_i   (Maller; prover.rs:1147-1188)
+    zeta1 = pow(zeta, n, F.p)
+    zkp = (zeta - pow(ix.omega, n - 3, F.p)) * (zeta - pow(ix.omega, n - 2, F.p)) % F.p * (zeta - pow(ix.omega, n - 1, F.p)) % F.p
+    scal = evals["z"][1] * beta % F.p * alphas[0] % F.p * zkp % F.p
+    for w_, s_ in zip(evals["w"], evals["s"]):
+        scal = scal * ((gamma + beta * s_[0] + w_[0]) % F.p) % F.p
+    scal = (-scal) % F.p
+    ft = khip.DevBuf(NB)
+    m1 = (-(zeta1 - 1)) % F.p
+    khip.poly_lincomb_dev(fid, [ix.colc(COLUMNS + 2 + PERMUTS - 1)] + [quot.view(i * NB) for i in range(7)], [n] * 8,
+                          F.limbs_many([scal] + [m1 * pow(zeta1, i, F.p) % F.p for i in range(7)]), ft, n)
+    fte = khip.evaluate_chunks_dev(fid, ft, n, n, 1, pts)
+    ft_eval0, ft_eval1 = F.value(fte[0, 0]), F.value(fte[1, 0])
+    blinding_ft = m1 * sum(b * pow(zeta1, i, F.p) for i, b in enumerate(t_blind)) % F.p
+    # ---- Fr-sponge: v, u
+    fr = khip.Sponge(khip.Sponge.FR, curve)
+    fr.absorb(fq.digest())
+    empty = khip.Sponge(khip.Sponge.FR, curve); fr.absorb(empty.digest()); empty.free()
+    order = [evals["z"], evals["generic_selector"], evals["poseidon_selector"], evals["complete_add_selector"], evals["mul_selector"], evals["emul_selector"],
+             evals["endomul_scalar_selector"]] + list(evals["w"]) + list(evals["coefficients"]) + list(evals["s"])
+    flat = [ft_eval1, 0, 0] + [x for e in order for x in e]
+    fr.absorb(F.limbs_many(flat))
+    v = scalar_challenge(curve, F, fr.challenge())
+    u = scalar_challenge(curve, F, fr.challenge())
+    fr.free()
+    mark("evaluations")
+    # ---- SRS::open on (public, ft, z, 6 selectors, w x 15, coefficients x 15, sigma x 6)
+    open_polys = [ix.zero_poly, ft] + polys
+    open_lens = [0, n] + [n] * len(polys)
+    blinders = [1, blinding_ft, z_blind, 1, 1, 1, 1, 1, 1] + w_blind + [0] * COLUMNS + [0] * (PERMUTS - 1)
+    all_evals = [(0, 0), (ft_eval0, ft_eval1)] + order
+    a_dev = khip.DevBuf(NB); b_dev = khip.DevBuf(NB)
+    khip.combine_polys_dev(fid, open_polys, open_lens, [1] * len(open_polys), F.limbs(v), n, a_dev)
+    khip.b_init_dev(fid, pts, F.limbs(u), n, b_dev)
+    blinding_factor, cip, ps = 0, 0, 1
+    for bl, (e0, e1) in zip(blinders, all_evals):
+        blinding_factor = (blinding_factor + bl * ps) % F.p
+        cip = (cip + ps * ((e0 + u * e1) % F.p)) % F.p                  # combined_inner_product (commitment.rs:622-657) = <p, b_init>
+        ps = ps * v % F.p
+    two_pow = pow(2, F.p.bit_length(), F.p)                             # shift_scalar (commitment.rs:273-288)
+    base_p = MOD[khip.FQ if fid == khip.FP else khip.FP]
+    shifted = (cip - (two_pow + 1)) * F.inv(2) % F.p if F.p < base_p else (cip - two_pow) % F.p
+    sp = fq_before
+    sp.absorb_fr(F.limbs(shifted))
+    u_base = khip.group_map_to_group(curve, sp.squeeze_field())
+    op = khip.IpaOpening(srs, a_dev, b_dev, u_base, a_len=n, b_len=n)
+    lr, rand, chal_u = [], [], []
+    for _ in range(logn):
+        rl, rr = F.rand(rng), F.rand(rng)
+        xy, li = op.round_lr(F.limbs(rl), F.limbs(rr))
+        sp.absorb_g(xy[0:1], li[0:1]); sp.absorb_g(xy[1:2], li[1:2])
+        u_l, _ = op.round_fold(sp.challenge())
+        lr.append((xy.copy(), li.copy())); rand.append((rl, rr)); chal_u.append(F.value(u_l))
+    a0_l, b0_l, sg, sg_inf = op.finish()
+    op.free()
+    a0, b0 = F.value(a0_l), F.value(b0_l)
+    r_prime = blinding_factor
+    for (rl, rr), uu in zip(rand, chal_u):
+        r_prime = (r_prime + rl * F.inv(uu) + rr * uu) % F.p
+    d, r_delta = F.rand(rng), F.rand(rng)
+    delta, dinf = khip.msm_points(curve, np.stack([sg, u_base, ix.h]), F.limbs_many([d, b0 * d % F.p, r_delta]))
+    sp.absorb_g(delta.reshape(1, 8), np.array([1 if dinf else 0], dtype=np.uint8))
+    c = scalar_challenge(curve, F, sp.challenge())
+    opening = {"lr": lr, "delta": (delta, bool(dinf)), "z1": (a0 * c + d) % F.p, "z2": (r_prime * c + r_delta) % F.p, "sg": (sg, bool(sg_inf))}
+    sp.free(); fq.free()
+    mark("opening")
+    for b in (ev, cf, e8, t4, t8, quot, rem, zm1, b1, b2, ft, a_dev, b_dev, num, den):
+        b.free()
+    if timings is not None:
+        prev = t_start
+        for name, t in marks:
+            timings[name] = timings.get(name, 0.0) + (t - prev); prev = t
+        timings["total"] = timings.get("total", 0.0) + (marks[-1][1] - t_start)
+    return {"w_comm": (w_comm, w_inf), "z_comm": (z_comm, z_inf), "t_comm": (t_comm, t_inf), "evals": evals, "ft_eval1": ft_eval1, "opening": opening,
+            "challenges": {"beta": beta, "gamma": gamma, "alpha": alpha, "zeta": zeta, "v": v, "u": u}}

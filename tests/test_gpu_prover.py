@@ -1,0 +1,124 @@
+"""Row a12: a COMPLETE Kimchi proof produced by the device pipeline (proof_systems_amd/prover.py -- witness ->
+commitments -> iNTT -> z -> LDE -> constraint rows -> quotient with zero remainder -> t -> evaluations -> ft -> opening,
+real Fiat-Shamir challenges from the library's native sponges) is ACCEPTED by the oracle's restatement of the reference
+verifier (oracle/kimchi.py: transcript replayed with the oracle's own Poseidon, ft_eval0, ft_comm, SRS::verify); a
+tampered proof is rejected; an unsatisfied circuit cannot be proved."""
+import numpy as np
+import pytest
+
+from oracle import cref
+from oracle import kimchi as K
+from oracle import pasta as P
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def khip():
+    import proof_systems_amd.khip as k
+    k.init(0)
+    return k
+
+
+def _aff(c, xy, inf):
+    if inf:
+        return None
+    return (c.base.from_mont(P.from_limbs(xy[:4])), c.base.from_mont(P.from_limbs(xy[4:])))
+
+
+def _oracle_views(khip, ix, proof):
+    """The device prover's index / proof as the plain-integer structures oracle/kimchi.py verifies."""
+    c = P.CURVES[ix.curve]
+    one = lambda t: [_aff(c, t[0], t[1])]
+    vix = {"F": c.scalar, "n": ix.n, "log2_n": ix.log2_n, "omega": ix.omega, "shifts": ix.shifts, "h": _aff(c, ix.h, False),
+           "sigma_comm": [one(t) for t in ix.sigma_comm], "coefficients_comm": [one(t) for t in ix.coefficients_comm], "generic_comm": one(ix.generic_comm),
+           "psm_comm": one(ix.zero_selector_comm), "complete_add_comm": one(ix.zero_selector_comm), "mul_comm": one(ix.zero_selector_comm),
+           "emul_comm": one(ix.zero_selector_comm), "endomul_scalar_comm": one(ix.zero_selector_comm)}
+    chunks = lambda t: [_aff(c, t[0][j], t[1][j]) for j in range(len(t[1]))]
+    op = proof["opening"]
+    pr = {"w_comm": [[_aff(c, proof["w_comm"][0][i], proof["w_comm"][1][i])] for i in range(15)], "z_comm": chunks(proof["z_comm"]), "t_comm": chunks(proof["t_comm"]),
+          "evals": proof["evals"], "ft_eval1": proof["ft_eval1"],
+          "opening": {"lr": [(_aff(c, xy[0], li[0]), _aff(c, xy[1], li[1])) for xy, li in op["lr"]], "delta": _aff(c, *op["delta"]), "z1": op["z1"], "z2": op["z2"],
+                      "sg": _aff(c, *op["sg"])}}
+    return c, vix, pr
+
+
+def _verify(khip, ix, proof, seed=5):
+    c, vix, pr = _oracle_views(khip, ix, proof)
+    g_l = ix.srs.get_g()
+    h = _aff(c, ix.h, False)
+
+    def final_msm(g_terms, pts, sc):          # the verifier's one MSM with the C oracle (independent of the product)
+        F = c.scalar
+        gs = [0] * ix.n
+        for w, chal in g_terms:
+            for j, s in enumerate(P.b_poly_coefficients(F, chal)):
+                gs[j] = (gs[j] + w * s) % F.p
+        live = [(p, s) for p, s in zip(pts, sc) if p is not None]
+        xy = np.concatenate([g_l, np.stack([cref.ints_to_limbs([c.base.to_mont(p[0]), c.base.to_mont(p[1])]).reshape(8) for p, _ in live])])
+        scal = cref.ints_to_limbs([F.to_mont(s) for s in gs + [s for _, s in live]])
+        _, inf = cref.msm(ix.curve, xy, scal, threads=16)
+        return inf
+    ok = K.verify(c, vix, pr, None, h, P.StdRng(bytes([seed] * 32)), final_msm=final_msm)
+    return ok, (c, vix, pr)
+
+
+@pytest.mark.parametrize("cid,logn", [(0, 7), (1, 7), (0, 12), (0, 16)])
+def test_bench_circuit_proof_is_accepted_by_the_reference_verifier(khip, cid, logn):
+    from proof_systems_amd import prover
+    ix = prover.bench_circuit_index(cid, logn)
+    F = prover.Fld(ix.fid)
+    rows = (1 << logn) - 10
+    wit = np.tile(F.limbs(1), (15, rows, 1))                          # kimchi/src/bench.rs:106
+    t = {}
+    proof = prover.create_proof(ix, wit, np.random.default_rng(11 + logn), timings=t)
+    ok, (c, vix, pr) = _verify(khip, ix, proof)
+    assert ok, "the oracle's verifier rejects the device prover's proof"
+    # the challenges the native sponges produced are the ones the oracle's sponge derives from the same transcript
+    ch = K.fiat_shamir(c, vix, pr, K.verifier_index_digest(c, vix))
+    for k in ("beta", "gamma", "alpha", "zeta", "v", "u"):
+        assert ch[k] == proof["challenges"][k], k
+    if logn <= 12:
+        bad = dict(proof, evals=dict(proof["evals"], z=(proof["evals"]["z"][0], (proof["evals"]["z"][1] + 1) % F.p)))
+        assert not _verify(khip, ix, bad)[0]                          # a tampered evaluation
+        bad = dict(proof, ft_eval1=(proof["ft_eval1"] + 1) % F.p)
+        assert not _verify(khip, ix, bad)[0]
+    ix.free()
+
+
+def test_copy_constraints_and_unsatisfied_witness(khip):
+    """A circuit WITH copy constraints (random wiring between the first rows' cells, witness constant on the cycles): the
+    proof verifies; breaking a gate makes the quotient division fail, breaking a copy constraint makes z end != 1."""
+    from proof_systems_amd import prover
+    cid, logn = 0, 8
+    n = 1 << logn
+    F = prover.Fld(khip.FP)
+    c = P.CURVES[cid]
+    rows = n - 10
+    rnd = np.random.default_rng(3)
+    # gates: w0 + w1 - w2 = 0 (coefficients 1, 1, -1) on every row; witness (a, b, a + b, ...) with wired columns 3..6 equal in pairs
+    co = np.zeros((rows, 15, 4), dtype=np.uint64)
+    co[:, 0] = F.limbs(1); co[:, 1] = F.limbs(1); co[:, 2] = F.limbs(F.p - 1)
+    ix = prover.ProverIndex(cid, logn, co)
+    sid = [pow(ix.omega, j, F.p) for j in range(n)]
+    sigma = [[ix.shifts[i] * sid[j] % F.p for j in range(n)] for i in range(7)]
+    wv = [[0] * rows for _ in range(15)]
+    for j in range(rows):
+        a, b = int(rnd.integers(1, 1 << 60)), int(rnd.integers(1, 1 << 60))
+        wv[0][j], wv[1][j], wv[2][j] = a, b, (a + b) % F.p
+    for j in range(0, rows - 1, 2):                                   # cells (3, j) and (4, j + 1) wired together
+        v = int(rnd.integers(1, 1 << 60))
+        wv[3][j] = v; wv[4][j + 1] = v
+        sigma[3][j] = ix.shifts[4] * sid[j + 1] % F.p
+        sigma[4][j + 1] = ix.shifts[3] * sid[j] % F.p
+    ix.set_sigma(np.stack([F.limbs_many(col) for col in sigma]))
+    wit = np.stack([F.limbs_many(col) for col in wv])
+    proof = prover.create_proof(ix, wit, np.random.default_rng(5))
+    assert _verify(khip, ix, proof)[0]
+    bad = wit.copy(); bad[2, 17] = F.limbs(12345)                     # gate 17 no longer holds
+    with pytest.raises(RuntimeError, match="vanishing"):
+        prover.create_proof(ix, bad, np.random.default_rng(5))
+    bad = wit.copy(); bad[3, 0] = F.limbs(777)                        # copy constraint (3, 0) = (4, 1) broken
+    with pytest.raises(RuntimeError, match="accumulator"):
+        prover.create_proof(ix, bad, np.random.default_rng(5))
+    ix.free()
