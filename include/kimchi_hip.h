@@ -45,6 +45,7 @@ extern "C" {
 #define KH_BASIS_G (-1)      /* the monomial basis g of the SRS */
 
 typedef struct kh_srs kh_srs_t;
+typedef struct kh_sponge kh_sponge_t;      /* host-side Fiat-Shamir sponge, see the end of this file */
 
 /* ---- device ------------------------------------------------------------- */
 int kh_device_count(void);
@@ -269,6 +270,15 @@ int kh_ipa_round_lr(kh_ipa_t *st, const uint64_t rand_l[4], const uint64_t rand_
 int kh_ipa_round_fold(kh_ipa_t *st, const uint64_t chal[2], uint64_t u_out[4], uint64_t u_inv_out[4]);
 int kh_ipa_finish(kh_ipa_t *st, uint64_t a0[4], uint64_t b0[4], uint64_t sg_xy[8], uint8_t *sg_inf);
 void kh_ipa_free(kh_ipa_t *st);
+/* Everything SRS::open does after combine_polys / b_init (ipa.rs:898-1060) in ONE call: absorbs shift_scalar(<a, b>), derives
+ * U = to_group(challenge_fq()), runs the log2(n) rounds (L / R MSMs on the device, absorb, challenge, folds of a, b and of the
+ * challenge tensor), then delta, c, z1, z2.  `sponge`: the prover's Fq-sponge (fq_sponge_before_evaluations, prover.rs:1193),
+ * advanced exactly as the reference advances it.  `blinders`: what the reference draws from its RNG, in its order -- (rand_l,
+ * rand_r) per round, then d, r_delta -- 2 log2(n) + 2 scalar-field elements.  blinding_factor: the combined blinder returned
+ * by combine_polys.  Outputs: lr (log2(n) x 2 points), delta, z1, z2, sg: the OpeningProof (ipa.rs:1175-1191). */
+int kh_ipa_open(kh_srs_t *srs, const uint64_t *a_dev, size_t a_len, const uint64_t *b_dev, size_t b_len, const uint64_t combined_inner_product[4],
+                const uint64_t blinding_factor[4], kh_sponge_t *sponge, const uint64_t *blinders, size_t blinders_len,
+                uint64_t *lr_xy, uint8_t *lr_inf, uint64_t delta_xy[8], uint8_t *delta_inf, uint64_t z1[4], uint64_t z2[4], uint64_t sg_xy[8], uint8_t *sg_inf);
 
 /* PolyComm::multi_scalar_mul (poly-commitment/src/commitment.rs:350-394): m commitments with num_chunks[i] chunks each
  * (chunks_xy / chunks_inf: the chunk lists concatenated, sum(num_chunks) points), m scalars (Montgomery).
@@ -383,7 +393,6 @@ int kh_debug_point_op(int curve, int op, const uint64_t *p_xy, const uint8_t *p_
  * kh_scalar_challenge_to_field where the reference wraps it in a ScalarChallenge. */
 #define KH_SPONGE_FQ 0
 #define KH_SPONGE_FR 1
-typedef struct kh_sponge kh_sponge_t;
 int kh_sponge_new(int kind, int curve, kh_sponge_t **out);
 int kh_sponge_clone(const kh_sponge_t *s, kh_sponge_t **out);           /* fq_sponge.clone() (prover.rs:1193) */
 void kh_sponge_free(kh_sponge_t *s);

@@ -118,6 +118,11 @@ struct kh_srs {
     DevBuf ipa_a[2], ipa_b[2], ipa_coef[2], ipa_sc, ipa_partial;
     hipEvent_t ipa_ev = nullptr;
     uint64_t h[8];
+    // fixed-base table of the blinding base: h_table[i * 255 + (j - 1)] = j * 2^(8 i) * h (XYZZ), built on first use:
+    // SRS::mask_custom is one scalar multiplication by h per chunk (ipa.rs:605-622) -- 32 additions instead of 255
+    // doublings + ~128 additions (a proof masks 23 commitments: 3.5 ms of host time otherwise)
+    std::vector<khost::xyzz> h_table;
+    std::mutex h_mu;
     std::map<unsigned, std::vector<std::unique_ptr<LagrangeChunk>>> lagrange;
     ~kh_srs() { if (ipa_ev) (void)hipEventDestroy(ipa_ev); }      // the DevBufs free themselves
 };
@@ -567,7 +572,9 @@ int kh_commit_evaluations_non_hiding(kh_srs_t* srs, unsigned log2_domain, const 
 
 int kh_srs_set_blinding_base(kh_srs_t* srs, const uint64_t h_xy[8]) {
     KH_REQUIRE(srs && h_xy, "null argument");
+    std::lock_guard<std::mutex> lk(srs->h_mu);
     memcpy(srs->h, h_xy, 64);
+    srs->h_table.clear();
     return KH_OK;
 }
 int kh_srs_get_blinding_base(const kh_srs_t* srs, uint64_t h_xy[8]) {
@@ -581,15 +588,47 @@ int kh_mask_custom(kh_srs_t* srs, const uint64_t* com_xy, const uint8_t* com_inf
     if (com_len != blinders_len) { set_error("BlindersDontMatch(%zu, %zu)", blinders_len, com_len); return KH_E_BLINDERS; }
     khost::Crv crv(srs->curve);
     khost::Fld SF(khost::scalar_field_id(srs->curve));
-    khost::aff h; memcpy(&h, srs->h, 64);
-    khost::xyzz H = crv.from_affine(h);
+    {
+        std::lock_guard<std::mutex> lk(srs->h_mu);
+        if (srs->h_table.empty()) {
+            khost::aff h; memcpy(&h, srs->h, 64);
+            std::vector<khost::xyzz> T(32 * 255);
+            khost::xyzz base = crv.from_affine(h);
+            for (int i = 0; i < 32; i++) {
+                T[i * 255] = base;
+                for (int j = 1; j < 255; j++) T[i * 255 + j] = crv.add(T[i * 255 + j - 1], base);
+                base = crv.add(T[i * 255 + 254], base);            // 256 * base
+            }
+            srs->h_table.swap(T);
+        }
+    }
+    const khost::xyzz* T = srs->h_table.data();
+    std::vector<khost::xyzz> acc(com_len);
     for (size_t j = 0; j < com_len; j++) {
         khost::fe w; memcpy(&w, blinders + 4 * j, 32);
         w = SF.from_mont(w);
-        khost::xyzz acc = crv.mul_plain(H, w);
-        if (!(com_inf && com_inf[j])) { khost::aff c; memcpy(&c, com_xy + 8 * j, 64); acc = crv.add(acc, crv.from_affine(c)); }
-        khost::aff r; bool inf = crv.to_affine(acc, r);
-        memcpy(out_xy + 8 * j, &r, 64); out_inf[j] = inf ? 1 : 0;
+        khost::xyzz s = crv.identity();
+        for (int i = 0; i < 32; i++) {
+            const unsigned byte = (unsigned)((w.l[i >> 3] >> (8 * (i & 7))) & 0xff);
+            if (byte) s = crv.add(s, T[i * 255 + byte - 1]);
+        }
+        if (!(com_inf && com_inf[j])) { khost::aff c; memcpy(&c, com_xy + 8 * j, 64); s = crv.add(s, crv.from_affine(c)); }
+        acc[j] = s;
+    }
+    // XYZZ -> affine for all chunks with ONE field inversion (Montgomery's trick over the ZZZ's)
+    const khost::Fld& F = crv.F;
+    std::vector<khost::fe> pre(com_len + 1);
+    pre[0] = F.f.one;
+    for (size_t j = 0; j < com_len; j++) pre[j + 1] = crv.is_identity(acc[j]) ? pre[j] : F.mul(pre[j], acc[j].zzz);
+    khost::fe inv = F.inv(pre[com_len]);
+    for (size_t j = com_len; j-- > 0;) {
+        if (crv.is_identity(acc[j])) { memset(out_xy + 8 * j, 0, 64); out_inf[j] = 1; continue; }
+        const khost::fe izzz = F.mul(inv, pre[j]);
+        inv = F.mul(inv, acc[j].zzz);
+        const khost::fe izz = F.sqr(F.mul(izzz, acc[j].zz));
+        const khost::fe x = F.mul(acc[j].x, izz), y = F.mul(acc[j].y, izzz);
+        memcpy(out_xy + 8 * j, &x, 32); memcpy(out_xy + 8 * j + 4, &y, 32);
+        out_inf[j] = 0;
     }
     return KH_OK;
 }
@@ -1030,6 +1069,69 @@ void kh_ipa_free(kh_ipa_t* st) {
     (void)hipStreamSynchronize(C.stream);                 // a fold may still be in flight on the library stream
     if (st->srs) st->srs->ipa_live = false;
     delete st;
+}
+
+// The whole tail of SRS::open (ipa.rs:898-1060) in one call, so that a device-resident prover has no per-round host
+// language overhead: absorb the shifted combined inner product, U = to_group(challenge_fq), log2(n) rounds (L / R on the
+// device, absorb, challenge, folds), then delta, c, z1, z2.  `blinders` = the values the reference draws from its RNG, in
+// its order: (rand_l, rand_r) per round, then d, r_delta.  The sponge is advanced exactly as the reference advances it.
+int kh_ipa_open(kh_srs_t* srs, const uint64_t* a_dev, size_t a_len, const uint64_t* b_dev, size_t b_len, const uint64_t combined_inner_product[4],
+                const uint64_t blinding_factor[4], kh_sponge_t* sponge, const uint64_t* blinders, size_t blinders_len,
+                uint64_t* lr_xy, uint8_t* lr_inf, uint64_t delta_xy[8], uint8_t* delta_inf, uint64_t z1[4], uint64_t z2[4], uint64_t sg_xy[8], uint8_t* sg_inf) {
+    KH_REQUIRE(srs && a_dev && b_dev && combined_inner_product && blinding_factor && sponge && blinders && lr_xy && lr_inf && delta_xy && delta_inf && z1 && z2 && sg_xy && sg_inf,
+               "kh_ipa_open: null argument");
+    KH_ON_DEVICE_OF(srs);
+    const size_t n = srs->n;
+    KH_REQUIRE(n > 1 && (n & (n - 1)) == 0, "the opening needs a power-of-two SRS (size %zu)", n);
+    size_t rounds = 0; while (((size_t)1 << rounds) < n) rounds++;
+    KH_REQUIRE(blinders_len == 2 * rounds + 2, "kh_ipa_open: %zu blinders given, 2 * %zu rounds + 2 needed", blinders_len, rounds);
+    const int curve = srs->curve, sfield = khost::scalar_field_id(curve);
+    khost::Fld SF(sfield), BF(khost::base_field_id(curve));
+    khost::Crv crv(curve);
+    auto fe_of = [](const uint64_t* p) { khost::fe v; memcpy(&v, p, 32); return v; };
+    // shift_scalar (commitment.rs:273-288) of the combined inner product, absorbed before U is squeezed (ipa.rs:898-913)
+    {
+        khost::fe two = SF.add(SF.f.one, SF.f.one), acc = SF.f.one;
+        for (int i = 0; i < 255; i++) acc = SF.add(acc, acc);            // 2^255 = 2^(modulus bits) as a field element
+        const khost::fe cip = fe_of(combined_inner_product);
+        khost::fe sh;
+        if (!khost::geq(SF.f.p, BF.f.p)) sh = SF.mul(SF.sub(cip, SF.add(acc, SF.f.one)), SF.inv(two));
+        else sh = SF.sub(cip, acc);
+        int rc = kh_sponge_absorb_fr(sponge, sh.l, 1); if (rc) return rc;
+    }
+    uint64_t t[4], u_base[8];
+    int rc = kh_sponge_squeeze_field(sponge, t); if (rc) return rc;
+    if ((rc = kh_group_map_to_group(curve, t, u_base))) return rc;
+    kh_ipa_t* st = nullptr;
+    if ((rc = kh_ipa_begin_dev(srs, a_dev, a_len, b_dev, b_len, u_base, &st))) return rc;
+    struct Guard { kh_ipa_t* s; ~Guard() { kh_ipa_free(s); } } guard{st};
+    khost::fe r_prime = fe_of(blinding_factor);
+    for (size_t r = 0; r < rounds; r++) {
+        const uint64_t* rl = blinders + 8 * r; const uint64_t* rr = rl + 4;
+        if ((rc = kh_ipa_round_lr(st, rl, rr, lr_xy + 16 * r, lr_inf + 2 * r))) return rc;
+        if ((rc = kh_sponge_absorb_g(sponge, lr_xy + 16 * r, lr_inf + 2 * r, 2))) return rc;
+        uint64_t chal[2], u[4], ui[4];
+        if ((rc = kh_sponge_challenge(sponge, chal))) return rc;
+        if ((rc = kh_ipa_round_fold(st, chal, u, ui))) return rc;
+        r_prime = SF.add(r_prime, SF.add(SF.mul(fe_of(rl), fe_of(ui)), SF.mul(fe_of(rr), fe_of(u))));       // ipa.rs:1021-1027
+    }
+    uint64_t a0[4], b0[4];
+    if ((rc = kh_ipa_finish(st, a0, b0, sg_xy, sg_inf))) return rc;
+    // delta = (g0 + [b0] U) * d + [r_delta] H  (ipa.rs:1036-1041), on the host: three scalar multiplications
+    const khost::fe d = fe_of(blinders + 8 * rounds), r_delta = fe_of(blinders + 8 * rounds + 4);
+    khost::xyzz acc = crv.identity();
+    if (!*sg_inf) { khost::aff g0; memcpy(&g0, sg_xy, 64); acc = crv.mul_plain(crv.from_affine(g0), SF.from_mont(d)); }
+    { khost::aff ub; memcpy(&ub, u_base, 64); acc = crv.add(acc, crv.mul_plain(crv.from_affine(ub), SF.from_mont(SF.mul(fe_of(b0), d)))); }
+    { khost::aff hh; memcpy(&hh, srs->h, 64); acc = crv.add(acc, crv.mul_plain(crv.from_affine(hh), SF.from_mont(r_delta))); }
+    khost::aff da; const bool dinf = crv.to_affine(acc, da);
+    memcpy(delta_xy, &da, 64); *delta_inf = dinf ? 1 : 0;
+    if ((rc = kh_sponge_absorb_g(sponge, delta_xy, delta_inf, 1))) return rc;
+    uint64_t cc[2], c[4];
+    if ((rc = kh_sponge_challenge(sponge, cc))) return rc;
+    scalar_challenge_to_field(sfield, cc, cached_endos(curve).r, c);
+    const khost::fe z1v = SF.add(SF.mul(fe_of(a0), fe_of(c)), d), z2v = SF.add(SF.mul(r_prime, fe_of(c)), r_delta);
+    memcpy(z1, &z1v, 32); memcpy(z2, &z2v, 32);
+    return KH_OK;
 }
 
 // ---------------------------------------------------------------------------------- NTT

@@ -30,7 +30,7 @@ MSM_SLOTS = 4          # KH_MSM_SLOTS: jobs kh_msm_submit accepts before kh_msm_
 SYMBOLS = [
     "kh_sponge_new", "kh_sponge_clone", "kh_sponge_free", "kh_sponge_absorb_g", "kh_sponge_absorb", "kh_sponge_absorb_fr", "kh_sponge_challenge",
     "kh_sponge_challenge_field", "kh_sponge_squeeze_field", "kh_sponge_digest",
-    "kh_group_map_to_group", "kh_dev_copy", "kh_dev_memset_zero",
+    "kh_group_map_to_group", "kh_dev_copy", "kh_dev_memset_zero", "kh_ipa_open",
     "kh_device_count", "kh_init", "kh_set_device", "kh_get_device", "kh_trim", "kh_srs_device", "kh_last_error", "kh_srs_create", "kh_srs_free", "kh_srs_size",
     "kh_srs_set_lagrange", "kh_srs_compute_lagrange", "kh_srs_get_lagrange", "kh_srs_lagrange_chunks",
     "kh_msm", "kh_msm_batch", "kh_msm_points", "kh_ntt", "kh_lde",
@@ -46,6 +46,7 @@ SYMBOLS = [
 
 _lib.kh_last_error.restype = C.c_char_p
 _lib.kh_set_device.argtypes = [C.c_int]
+_lib.kh_ipa_open.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, U64P, U64P, C.c_void_p, U64P, C.c_size_t, U64P, U8P, U64P, U8P, U64P, U64P, U64P, U8P]
 _lib.kh_sponge_new.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_void_p)]
 _lib.kh_sponge_clone.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
 _lib.kh_sponge_free.argtypes = [C.c_void_p]
@@ -674,6 +675,20 @@ class IpaOpening:
             self.free()
         except Exception:
             pass
+
+
+def ipa_open(srs, a_dev, b_dev, n: int, combined_inner_product, blinding_factor, sponge, blinders):
+    """kh_ipa_open: the rounds and the Schnorr tail of SRS::open in one native call.  Returns (lr_xy (k, 2, 8), lr_inf (k, 2),
+    delta_xy, delta_inf, z1, z2, sg_xy, sg_inf)."""
+    bl = _c64(blinders, (-1, 4))
+    k = (bl.shape[0] - 2) // 2
+    lr = np.zeros((k, 2, 8), dtype=np.uint64); lri = np.zeros((k, 2), dtype=np.uint8)
+    delta = np.zeros(8, dtype=np.uint64); dinf = np.zeros(1, dtype=np.uint8)
+    z1 = np.zeros(4, dtype=np.uint64); z2 = np.zeros(4, dtype=np.uint64)
+    sg = np.zeros(8, dtype=np.uint64); sginf = np.zeros(1, dtype=np.uint8)
+    _check(_lib.kh_ipa_open(srs._h, C.c_void_p(a_dev.ptr), n, C.c_void_p(b_dev.ptr), n, _p64(_c64(combined_inner_product, (4,))), _p64(_c64(blinding_factor, (4,))),
+                            sponge._h, _p64(bl), bl.shape[0], _p64(lr), _p8(lri), _p64(delta), _p8(dinf), _p64(z1), _p64(z2), _p64(sg), _p8(sginf)))
+    return lr, lri, delta, bool(dinf[0]), z1, z2, sg, bool(sginf[0])
 
 
 def endos(curve: int):

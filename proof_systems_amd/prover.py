@@ -331,31 +331,10 @@ def create_proof(ix: ProverIndex, witness, rng, timings=None, check: bool = True
         blinding_factor = (blinding_factor + bl * ps) % F.p
         cip = (cip + ps * ((e0 + u * e1) % F.p)) % F.p                  # combined_inner_product (commitment.rs:622-657) = <p, b_init>
         ps = ps * v % F.p
-    two_pow = pow(2, F.p.bit_length(), F.p)                             # shift_scalar (commitment.rs:273-288)
-    base_p = MOD[khip.FQ if fid == khip.FP else khip.FP]
-    shifted = (cip - (two_pow + 1)) * F.inv(2) % F.p if F.p < base_p else (cip - two_pow) % F.p
     sp = fq_before
-    sp.absorb_fr(F.limbs(shifted))
-    u_base = khip.group_map_to_group(curve, sp.squeeze_field())
-    op = khip.IpaOpening(srs, a_dev, b_dev, u_base, a_len=n, b_len=n)
-    lr, rand, chal_u = [], [], []
-    for _ in range(logn):
-        rl, rr = F.rand(rng), F.rand(rng)
-        xy, li = op.round_lr(F.limbs(rl), F.limbs(rr))
-        sp.absorb_g(xy[0:1], li[0:1]); sp.absorb_g(xy[1:2], li[1:2])
-        u_l, _ = op.round_fold(sp.challenge())
-        lr.append((xy.copy(), li.copy())); rand.append((rl, rr)); chal_u.append(F.value(u_l))
-    a0_l, b0_l, sg, sg_inf = op.finish()
-    op.free()
-    a0, b0 = F.value(a0_l), F.value(b0_l)
-    r_prime = blinding_factor
-    for (rl, rr), uu in zip(rand, chal_u):
-        r_prime = (r_prime + rl * F.inv(uu) + rr * uu) % F.p
-    d, r_delta = F.rand(rng), F.rand(rng)
-    delta, dinf = khip.msm_points(curve, np.stack([sg, u_base, ix.h]), F.limbs_many([d, b0 * d % F.p, r_delta]))
-    sp.absorb_g(delta.reshape(1, 8), np.array([1 if dinf else 0], dtype=np.uint8))
-    c = scalar_challenge(curve, F, sp.challenge())
-    opening = {"lr": lr, "delta": (delta, bool(dinf)), "z1": (a0 * c + d) % F.p, "z2": (r_prime * c + r_delta) % F.p, "sg": (sg, bool(sg_inf))}
+    bl = [F.rand(rng) for _ in range(2 * logn + 2)]         # the reference's draw order: (rand_l, rand_r) per round, then d, r_delta
+    lr_xy, lr_inf, delta, dinf, z1_l, z2_l, sg, sg_inf = khip.ipa_open(srs, a_dev, b_dev, n, F.limbs(cip), F.limbs(blinding_factor), sp, F.limbs_many(bl))
+    opening = {"lr": [(lr_xy[r], lr_inf[r]) for r in range(logn)], "delta": (delta, dinf), "z1": F.value(z1_l), "z2": F.value(z2_l), "sg": (sg, sg_inf)}
     sp.free(); fq.free()
     mark("opening")
     for b in (ev, cf, e8, t4, t8, quot, rem, zm1, b1, b2, ft, a_dev, b_dev, num, den):
