@@ -1,5 +1,7 @@
 // api.hip -- the extern "C" boundary declared in include/kimchi_hip.h.
 #include <stdlib.h>
+#include <algorithm>
+#include <chrono>
 #include <map>
 #include <memory>
 
@@ -404,6 +406,29 @@ static int wait_then_finish(std::unique_lock<std::mutex>& lk, Context& C, MsmSlo
     C.cv.notify_all();
     return rc;
 }
+// Coalescing of concurrent synchronous callers.  The reference commits its 15 witness columns from 15 rayon workers at
+// once (prover.rs:329-351), each calling SRS::commit_evaluations_non_hiding -> one MSM over the SAME basis.  Fifteen
+// separate launches queue on four pipeline slots and pay the latency-bound tail kernels fifteen times; one batched launch
+// of k = 15 shares them (0.9 ms against ~0.46 ms EACH).  So: host-buffer, single-MSM calls with the same (handle, basis,
+// chunk, offset, length, scalar form) that arrive while a group is still collecting are merged into ONE msm_enqueue(k = #callers);
+// every caller gets its own result.  A group collects only when calls are arriving in a burst (another call on this
+// context within the last 200 us): a lone sequential caller never waits.
+struct CoalesceMember { const uint64_t* scalars; uint64_t* out_xy; uint8_t* out_inf; };
+struct CoalesceGroup {
+    kh_srs_t* srs; int basis; unsigned chunk; size_t offset, n; int mont;
+    std::vector<CoalesceMember> members;
+    bool closed = false, done = false;
+    int rc = KH_OK;
+    std::string err;
+    std::condition_variable cv;
+};
+static constexpr size_t COALESCE_MAX = 32;
+static std::vector<std::shared_ptr<CoalesceGroup>>& coalesce_groups(Context& C) {      // per device context, guarded by C.mu
+    static std::map<Context*, std::vector<std::shared_ptr<CoalesceGroup>>> G; static std::mutex mu;
+    std::lock_guard<std::mutex> lk(mu);
+    return G[&C];
+}
+
 static int msm_common(kh_srs_t* srs, int basis, unsigned chunk, size_t offset, const uint64_t* scalars, bool scalars_on_device,
                       size_t n, size_t k, int mont, uint64_t* out_xy, uint8_t* out_inf) {
     KH_ON_DEVICE_OF(srs);
@@ -412,9 +437,65 @@ static int msm_common(kh_srs_t* srs, int basis, unsigned chunk, size_t offset, c
     int rc = ensure_init(); if (rc) return rc;
     Context& C = ctx();
     std::unique_lock<std::mutex> lk(C.mu);
-    int si = -1;
-    if ((rc = msm_submit_locked(C, srs, basis, chunk, offset, scalars, scalars_on_device, n, k, mont, &si, &lk))) return rc;
-    return wait_then_finish(lk, C, C.slot[si], out_xy, out_inf);
+    static const bool coalesce_on = !(getenv("KH_NO_COALESCE") && atoi(getenv("KH_NO_COALESCE")) != 0);
+    const auto now = std::chrono::steady_clock::now();
+    const bool burst = C.last_sync_msm_arrival.time_since_epoch().count() != 0 &&
+                       std::chrono::duration_cast<std::chrono::microseconds>(now - C.last_sync_msm_arrival).count() < 200;
+    C.last_sync_msm_arrival = now;
+    bool eligible = coalesce_on && !scalars_on_device && k == 1 && n >= MSM_PRECOMP_MIN_N && srs != nullptr;
+    if (eligible) {                                       // whole-window MSMs only (the ragged tail of a chunked polynomial goes alone)
+        MsmBasis b; if (resolve_basis(srs, basis, chunk, b) != KH_OK || offset > b.n || n > b.n - offset) eligible = false;
+    }
+    if (!eligible) {
+        int si = -1;
+        if ((rc = msm_submit_locked(C, srs, basis, chunk, offset, scalars, scalars_on_device, n, k, mont, &si, &lk))) return rc;
+        return wait_then_finish(lk, C, C.slot[si], out_xy, out_inf);
+    }
+    auto& groups = coalesce_groups(C);
+    for (auto& g : groups)
+        if (!g->closed && g->members.size() < COALESCE_MAX && g->srs == srs && g->basis == basis && g->chunk == chunk && g->offset == offset && g->n == n && g->mont == mont) {
+            std::shared_ptr<CoalesceGroup> grp = g;       // follower: hand the pointers to the leader, sleep until it has the results
+            grp->members.push_back({scalars, out_xy, out_inf});
+            grp->cv.notify_all();
+            grp->cv.wait(lk, [&] { return grp->done; });
+            if (grp->rc) set_error("%s", grp->err.c_str());
+            return grp->rc;
+        }
+    std::shared_ptr<CoalesceGroup> grp(new CoalesceGroup);
+    grp->srs = srs; grp->basis = basis; grp->chunk = chunk; grp->offset = offset; grp->n = n; grp->mont = mont;
+    grp->members.push_back({scalars, out_xy, out_inf});
+    groups.push_back(grp);
+    if (burst) {                                          // leader: collect while callers keep arriving (40 us of silence closes the group)
+        const auto deadline = now + std::chrono::microseconds(400);
+        size_t seen = 1;
+        for (;;) {
+            grp->cv.wait_for(lk, std::chrono::microseconds(40));
+            if (grp->members.size() == seen || grp->members.size() >= COALESCE_MAX || std::chrono::steady_clock::now() >= deadline) break;
+            seen = grp->members.size();
+        }
+    }
+    grp->closed = true;
+    groups.erase(std::find(groups.begin(), groups.end(), grp));
+    const size_t kk = grp->members.size();
+    std::vector<uint64_t> res(8 * kk); std::vector<uint8_t> rinf(kk);
+    auto run = [&]() -> int {
+        MsmBasis b; int r = resolve_basis(srs, basis, chunk, b); if (r) return r;
+        int si = acquire_slot(&lk, C);
+        KH_REQUIRE(si >= 0, "all %d MSM pipeline slots hold an un-waited job (kh_msm_wait first)", MSM_SLOTS);
+        MsmSlot& S = C.slot[si];
+        if ((r = S.ws_scalars.reserve(kk * n * 32))) return r;
+        for (size_t j = 0; j < kk; j++)
+            KH_HIP(hipMemcpyAsync((char*)S.ws_scalars.p + j * n * 32, grp->members[j].scalars, n * 32, hipMemcpyHostToDevice, S.stream));
+        if ((r = msm_enqueue(C, S, srs->curve, b, offset, S.ws_scalars.as<uint64_t>(), n, kk, mont))) return r;
+        return wait_then_finish(lk, C, S, res.data(), rinf.data());
+    };
+    rc = run();
+    if (rc == KH_OK)
+        for (size_t j = 0; j < kk; j++) { memcpy(grp->members[j].out_xy, &res[8 * j], 64); *grp->members[j].out_inf = rinf[j]; }
+    else grp->err = kh_last_error();
+    grp->rc = rc; grp->done = true;
+    grp->cv.notify_all();
+    return rc;
 }
 
 int kh_msm_submit(kh_srs_t* srs, int basis, unsigned chunk, size_t offset, const uint64_t* scalars_dev, size_t n, size_t k,

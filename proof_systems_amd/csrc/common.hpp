@@ -5,6 +5,7 @@
 #include <stdarg.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <chrono>
 #include <condition_variable>
 #include <map>
 #include <mutex>
@@ -124,6 +125,7 @@ struct Context {
     std::vector<std::pair<const char*, float>> last;      // names are string literals (kh_last_timings hands them out)
     MsmSlot slot[MSM_SLOTS];
     uint64_t next_ticket = 1;
+    std::chrono::steady_clock::time_point last_sync_msm_arrival{};     // burst detection of the caller coalescing (api.hip: msm_common)
     // NTT workspace
     DevBuf ws_ntt_a, ws_ntt_b;
     void* pinned = nullptr; size_t pinned_cap = 0;

@@ -55,19 +55,28 @@ struct Fld {
     fe sub(const fe& a, const fe& b) const { fe t; if (sub_n(t, a, b)) add_n(t, t, f.p); return t; }
     fe neg(const fe& a) const { if (is_zero(a)) return a; fe t; sub_n(t, f.p, a); return t; }
     fe dbl(const fe& a) const { return add(a, a); }
+    // Montgomery product, CIOS over 64-bit limbs, using the shape of the Pasta primes p = [p0, p1, 0, 2^62]: the reduction
+    // row needs two multiplications (m p0, m p1) and a shift instead of four.  The transcript's Poseidon permutations
+    // (1155 products each, strictly sequential between a proof's challenges) are what this is tuned for.
     fe mul(const fe& a, const fe& b) const {
-        u64 t[6] = {0, 0, 0, 0, 0, 0};
+        u64 t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
+        const u64 p0 = f.p.l[0], p1 = f.p.l[1];
         for (int i = 0; i < 4; i++) {
-            u128 c = 0;
-            for (int j = 0; j < 4; j++) { c += (u128)a.l[j] * b.l[i] + t[j]; t[j] = (u64)c; c >>= 64; }
-            c += t[4]; t[4] = (u64)c; t[5] = (u64)(c >> 64);
-            u64 m = t[0] * f.inv;
-            c = (u128)m * f.p.l[0] + t[0]; c >>= 64;
-            for (int j = 1; j < 4; j++) { c += (u128)m * f.p.l[j] + t[j]; t[j - 1] = (u64)c; c >>= 64; }
-            c += t[4]; t[3] = (u64)c; t[4] = t[5] + (u64)(c >> 64);
+            const u64 bi = b.l[i];
+            u128 c = (u128)a.l[0] * bi + t0; t0 = (u64)c; c >>= 64;
+            c += (u128)a.l[1] * bi + t1; t1 = (u64)c; c >>= 64;
+            c += (u128)a.l[2] * bi + t2; t2 = (u64)c; c >>= 64;
+            c += (u128)a.l[3] * bi + t3; t3 = (u64)c; c >>= 64;
+            c += t4; t4 = (u64)c; const u64 t5 = (u64)(c >> 64);
+            const u64 m = t0 * f.inv;
+            c = (u128)m * p0 + t0; c >>= 64;
+            c += (u128)m * p1 + t1; t0 = (u64)c; c >>= 64;
+            c += t2; t1 = (u64)c; c >>= 64;                              // p2 = 0
+            c += (u128)(m << 62) + t3; t2 = (u64)c; c >>= 64;            // m * 2^62 = (m >> 2) 2^64 + (m << 62)
+            c += (u128)(m >> 2) + t4; t3 = (u64)c; t4 = t5 + (u64)(c >> 64);
         }
-        fe r = {{t[0], t[1], t[2], t[3]}};
-        if (t[4] || geq(r, f.p)) sub_n(r, r, f.p);
+        fe r = {{t0, t1, t2, t3}};
+        if (t4 || geq(r, f.p)) sub_n(r, r, f.p);
         return r;
     }
     fe sqr(const fe& a) const { return mul(a, a); }

@@ -588,7 +588,8 @@ k_bucket_sum_q(const u32* __restrict__ toff, size_t nkeys, const uint8_t* __rest
         nt = 0;
     }
     // the trip count may differ between the quads of a wave: quad_add's shuffles stay inside the quad, its ballot is only a hint
-    for (u32 k = 0; k < nt; k++) acc = quad_add<BF>(acc, quad_load<BF>(partial + (size_t)(t0 + k) * 128));
+    if (nt) acc = quad_load<BF>(partial + (size_t)t0 * 128);            // (not "identity + first": an addition costs 5 product rounds)
+    for (u32 k = 1; k < nt; k++) acc = quad_add<BF>(acc, quad_load<BF>(partial + (size_t)(t0 + k) * 128));
     if (live) quad_store<BF>(buckets + key * 128, acc);
 }
 
