@@ -1039,6 +1039,17 @@ static int ipa_begin_common(kh_srs_t* srs, const uint64_t* a, size_t a_len, cons
     Context& C = ctx();
     std::lock_guard<std::mutex> lk(C.mu);
     KH_REQUIRE(!srs->ipa_live, "another opening is in progress on this SRS (kh_ipa_free it first)");
+    // A graph of the round MSM is captured and replayed WITHIN one opening only (nothing allocates or frees device memory
+    // between the rounds of an opening); replaying it after the caller has freed and allocated buffers in between faulted
+    // on ROCm 7.2 when another HIP user (PyTorch) shared the process.  Re-capturing costs one extra un-graphed round.
+    static const bool graph_reset = !(getenv("KH_GRAPH_KEEP") && atoi(getenv("KH_GRAPH_KEEP")) != 0);
+    if (graph_reset)
+        for (int i = 0; i < MSM_SLOTS; i++) {
+            MsmSlot& S = C.slot[i];
+            if (S.busy) continue;
+            if (S.gexec) { (void)hipGraphExecDestroy(S.gexec); S.gexec = nullptr; }
+            S.gkey = 0; S.gseen = 0;
+        }
     std::unique_ptr<kh_ipa> st(new kh_ipa);
     st->srs = srs; st->curve = srs->curve; st->field = khost::scalar_field_id(srs->curve); st->n = n; st->cur = n;
     for (int i = 0; i < 2; i++) {
