@@ -98,18 +98,26 @@ def prover_block(khip, srs20, check_with_oracle=True, log_n=16, reps=5):
     cols = [np.ascontiguousarray(padded[i]) for i in range(15)]
     res = [None] * 15
 
-    def one(i):
-        res[i] = srs16.commit_evaluations_non_hiding(log_n, cols[i])
+    bar = threading.Barrier(16)
+    done = threading.Barrier(16)
+
+    def one(i):                                                         # threads are started up front (a rayon pool exists before the proof does)
+        for _ in range(3):
+            bar.wait()
+            res[i] = srs16.commit_evaluations_non_hiding(log_n, cols[i])
+            done.wait()
+    th = [threading.Thread(target=one, args=(i,)) for i in range(15)]
+    for x in th:
+        x.start()
     best_c = None
     for _ in range(3):
-        th = [threading.Thread(target=one, args=(i,)) for i in range(15)]
+        bar.wait()
         t0 = time.perf_counter()
-        for x in th:
-            x.start()
-        for x in th:
-            x.join()
+        done.wait()
         dt = time.perf_counter() - t0
         best_c = dt if best_c is None else min(best_c, dt)
+    for x in th:
+        x.join()
     best_n = None
     for _ in range(3):
         t0 = time.perf_counter()

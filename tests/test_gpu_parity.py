@@ -439,22 +439,28 @@ def test_fifteen_commit_callers_are_coalesced(khip):
     batch = srs.msm_batch(cols, basis=logn)
     t0 = time.perf_counter(); srs.msm_batch(cols, basis=logn); t_batch = time.perf_counter() - t0
     got = [None] * 15
+    bar = threading.Barrier(16); done = threading.Barrier(16)
 
-    def work(j):
-        got[j] = srs.commit_evaluations_non_hiding(logn, cols[j])
+    def work(j):                                                           # a pool that exists before the burst, like rayon's
+        for _ in range(4):
+            bar.wait()
+            got[j] = srs.commit_evaluations_non_hiding(logn, cols[j])
+            done.wait()
 
+    th = [threading.Thread(target=work, args=(j,)) for j in range(15)]
+    for t in th:
+        t.start()
     best = None
     for _ in range(4):
-        th = [threading.Thread(target=work, args=(j,)) for j in range(15)]
+        bar.wait()
         t0 = time.perf_counter()
-        for t in th:
-            t.start()
-        for t in th:
-            t.join()
+        done.wait()
         dt = time.perf_counter() - t0
         best = dt if best is None else min(best, dt)
         for j in range(15):
             assert bool(got[j][1][0]) == bool(batch[1][j]) and np.array_equal(got[j][0][0], batch[0][j]), j
+    for t in th:
+        t.join()
     bxy, binf = srs.get_lagrange(logn)
     for j in (0, 4, 14):
         want, winf = cref.msm(0, bxy, cols[j], inf=binf, threads=16)
