@@ -52,3 +52,249 @@ def perm_aggreg_tokens(permuts: int = 7, w0: int = 0, s0: int = 7, sid: int = 14
         num += [cell(w0 + i), cell(sid), (TOK_CONST, bshift0 + i), (TOK_MUL, 0), (TOK_ADD, 0), (TOK_CONST, gamma), (TOK_ADD, 0)] + ([(TOK_MUL, 0)] if i else [])
         den += [cell(w0 + i), cell(s0 + i), (TOK_CONST, beta), (TOK_MUL, 0), (TOK_ADD, 0), (TOK_CONST, gamma), (TOK_ADD, 0)] + ([(TOK_MUL, 0)] if i else [])
     return num, den
+
+
+# ======================================================================================================================
+# A small expression builder (the role of kimchi's Expr + Expr::to_polish for callers without a Rust toolchain) and the
+# gate library lowered with it: Poseidon, CompleteAdd, VarBaseMul, EndoMul, EndoMulScalar.  Each gate function restates
+# `Argument::constraint_checks` of the reference (file:line in its docstring) on an environment that hands out cells;
+# `combined_constraints` is `Argument::combined_constraints` (argument.rs:201-214): index(gate) * sum_i alpha^(a0 + i) c_i.
+# ======================================================================================================================
+class Node:
+    """A node of an expression DAG.  `cached` nodes are emitted once (Store) and re-read afterwards (Load), like
+    `Cache::cache` / PolishToken::Store / Load in the reference (expr.rs:815-836)."""
+    __slots__ = ("op", "a", "b", "arg", "cached", "slot")
+
+    def __init__(self, op, a=None, b=None, arg=0):
+        self.op, self.a, self.b, self.arg, self.cached, self.slot = op, a, b, arg, False, None
+
+    def _bin(self, op, o):
+        return Node(op, self, o if isinstance(o, Node) else _lit(o))
+
+    def __add__(self, o): return self._bin(TOK_ADD, o)
+    def __sub__(self, o): return self._bin(TOK_SUB, o)
+    def __mul__(self, o): return self._bin(TOK_MUL, o)
+    def __radd__(self, o): return _lit(o)._bin(TOK_ADD, self)
+    def __rsub__(self, o): return _lit(o)._bin(TOK_SUB, self)
+    def __rmul__(self, o): return _lit(o)._bin(TOK_MUL, self)
+    def __pow__(self, e): return Node(TOK_POW, self, None, int(e))
+    def double(self): return Node("dbl", self)          # x Dup Add  (Expr::Double)
+    def square(self): return Node("sqr", self)          # x Dup Mul  (Expr::Square)
+
+    def cache(self):
+        self.cached = True
+        return self
+
+
+class _Lit(Node):
+    pass
+
+
+def _lit(v):
+    n = _Lit("lit"); n.arg = int(v)
+    return n
+
+
+class Env:
+    """Hands out the cells and constants of one gate evaluation.  Column numbering of the token program: witness columns
+    w0 .. w0+14, coefficient columns c0 .. c0+14, then the caller's extra columns (selectors).  Constants (literals, MDS
+    entries, the endo coefficient, alpha powers) are collected in `self.consts` as integers mod p; `table(F_limbs)` turns
+    them into the limb table kh_expr_evaluations_dev takes."""
+
+    def __init__(self, p: int, w0: int = 0, c0: int = 15, mds=None, endo: int = 0):
+        self.p, self.w0, self.c0, self._mds, self._endo = p, w0, c0, mds, endo
+        self.consts, self._index = [], {}
+
+    def const(self, v: int) -> Node:
+        v %= self.p
+        if v not in self._index:
+            self._index[v] = len(self.consts); self.consts.append(v)
+        return Node(TOK_CONST, arg=self._index[v])
+
+    def witness_curr(self, i): return Node(TOK_CELL, arg=2 * (self.w0 + i))
+    def witness_next(self, i): return Node(TOK_CELL, arg=2 * (self.w0 + i) + 1)
+    def coeff(self, i): return Node(TOK_CELL, arg=2 * (self.c0 + i))
+    def column(self, col): return Node(TOK_CELL, arg=2 * col)
+    def mds(self, r, c): return self.const(self._mds[r][c])
+    def endo_coefficient(self): return self.const(self._endo)
+    def one(self): return self.const(1)
+
+
+def compile_tokens(env: Env, expr: Node):
+    """Postfix token list of `expr`; literals met on the way are entered into env.consts."""
+    out, nslots = [], [0]
+
+    def emit(n):
+        if isinstance(n, _Lit):
+            emit(env.const(n.arg)); return
+        if n.cached and n.slot is not None:
+            out.append((TOK_LOAD, n.slot)); return
+        if n.op in (TOK_CONST, TOK_CELL):
+            out.append((n.op, n.arg))
+        elif n.op == TOK_POW:
+            emit(n.a); out.append((TOK_POW, n.arg))
+        elif n.op == "dbl":
+            emit(n.a); out.append((TOK_DUP, 0)); out.append((TOK_ADD, 0))
+        elif n.op == "sqr":
+            emit(n.a); out.append((TOK_DUP, 0)); out.append((TOK_MUL, 0))
+        else:
+            emit(n.a); emit(n.b); out.append((n.op, 0))
+        if n.cached:
+            n.slot = nslots[0]; nslots[0] += 1
+            out.append((TOK_STORE, 0))
+    emit(expr)
+    return out
+
+
+def combined_constraints(env: Env, selector_col, constraints, alpha: int, alpha0: int = 0):
+    """index(gate) * sum_i alpha^(alpha0 + i) * constraint_i (Expr::combine_constraints + the selector, argument.rs:201-214)."""
+    acc = None
+    for i, c in enumerate(constraints):
+        term = env.const(pow(alpha, alpha0 + i, env.p)) * c
+        acc = term if acc is None else acc + term
+    return env.column(selector_col) * acc if selector_col is not None else acc
+
+
+# ---------------------------------------------------------------------------------------------------------------- gates
+ROUND_TO_COLS = [0, 2, 3, 4, 1]           # STATE_ORDER (poseidon.rs:65-73): round r lives in columns 3 * slot .. 3 * slot + 2
+
+
+def poseidon_constraints(env: Env):
+    """Poseidon::constraint_checks (kimchi/src/circuits/polynomials/poseidon.rs:351-436): 5 rounds per row, 15 constraints:
+    state_(r+1)[j] - (rc[3 r + j] + sum_k mds[j][k] * state_r[k]^7); the fifth round's target is the next row's columns 0..2."""
+    res = []
+    for r in range(5):
+        src = [env.witness_curr(3 * ROUND_TO_COLS[r] + k) for k in range(3)]
+        sboxed = [(x ** 7).cache() for x in src]
+        for j in range(3):
+            tgt = env.witness_next(j) if r == 4 else env.witness_curr(3 * ROUND_TO_COLS[r + 1] + j)
+            acc = env.coeff(3 * r + j)
+            for k in range(3):
+                acc = acc + env.mds(j, k) * sboxed[k]
+            res.append(tgt - acc)
+    return res
+
+
+def complete_add_constraints(env: Env):
+    """CompleteAdd::constraint_checks (complete_add.rs:103-226): 7 constraints on (x1, y1, x2, y2, x3, y3, inf, same_x, s, inf_z, x21_inv)."""
+    x1, y1, x2, y2, x3, y3 = (env.witness_curr(i) for i in range(6))
+    inf, same_x, s, inf_z, x21_inv = (env.witness_curr(i) for i in range(6, 11))
+    x21 = (x2 - x1).cache(); y21 = (y2 - y1).cache()
+    res = [x21_inv * x21 - (env.one() - same_x), same_x * x21]                       # zero_check(x21, x21_inv, same_x)
+    x1_sq = (x1 * x1).cache()
+    dbl_case = s.double() * y1 - x1_sq.double() - x1_sq
+    add_case = x21 * s - y21
+    res.append(same_x * dbl_case + (env.one() - same_x) * add_case)
+    res.append(x1 + x2 + x3 - s * s)
+    res.append(s * (x1 - x3) - y1 - y3)
+    res.append(y21 * (same_x - inf))
+    res.append(y21 * inf_z - inf)
+    return res
+
+
+def _single_bit(env: Env, b, base, s1, inp, out):
+    """varbasemul.rs:226-277: one double-and-add step, 4 constraints."""
+    b_sign = b.double() - env.one()
+    s1_sq = (s1 * s1).cache()
+    rx = s1_sq - inp[0] - base[0]
+    t = (inp[0] - rx).cache()
+    u = (inp[1].double() - t * s1).cache()
+    return [b * b - b,
+            (inp[0] - base[0]) * s1 - (inp[1] - b_sign * base[1]),
+            u * u - (t * t) * (out[0] - base[0] + s1_sq),
+            (out[1] + inp[1]) * t - (inp[0] - out[0]) * u]
+
+
+def varbasemul_constraints(env: Env):
+    """VarbaseMul::constraint_checks (varbasemul.rs:419-455; layout :312-331): 21 constraints over two rows.
+    row i:   xT yT x0 y0 n n' . x1 y1 x2 y2 x3 y3 x4 y4      row i+1: x5 y5 b0 b1 b2 b3 b4 s0 s1 s2 s3 s4"""
+    wc, wn = env.witness_curr, env.witness_next
+    accs = [(wc(2), wc(3)), (wc(7), wc(8)), (wc(9), wc(10)), (wc(11), wc(12)), (wc(13), wc(14)), (wn(0), wn(1))]
+    bits = [wn(2 + i) for i in range(5)]
+    ss = [wn(7 + i) for i in range(5)]
+    base = (wc(0), wc(1))
+    acc = wc(4)
+    for b in bits:
+        acc = b + acc.double()
+    res = [wc(5) - acc]
+    for i in range(5):
+        res += _single_bit(env, bits[i], base, ss[i], accs[i], accs[i + 1])
+    return res
+
+
+def endomul_constraints(env: Env):
+    """EndosclMul::constraint_checks (endosclmul.rs:475-558): 12 constraints, 4 scalar bits per row.
+    row i: xT yT inv . xP yP n xR yR s1 s3 b1 b2 b3 b4;  next row: xS = w4', yS = w5', n' = w6'."""
+    wc, wn = env.witness_curr, env.witness_next
+    b1, b2, b3, b4 = wc(11), wc(12), wc(13), wc(14)
+    xt, yt, inv = wc(0), wc(1), wc(2)
+    xs, ys = wn(4), wn(5)
+    xp, yp, xr, yr, s1, s3 = wc(4), wc(5), wc(7), wc(8), wc(9), wc(10)
+    endo_m1 = env.endo_coefficient() - env.one()
+    xq1 = ((env.one() + b1 * endo_m1) * xt).cache()
+    xq2 = ((env.one() + b3 * endo_m1) * xt).cache()
+    yq1 = (b2.double() - env.one()) * yt
+    yq2 = (b4.double() - env.one()) * yt
+    s1_sq = (s1 * s1).cache(); s3_sq = (s3 * s3).cache()
+    n, n_next = wc(6), wn(6)
+    n_constraint = (((n.double() + b1).double() + b2).double() + b3).double() + b4 - n_next
+    xp_xr = (xp - xr).cache(); xr_xs = (xr - xs).cache()
+    ys_yr = (ys + yr).cache(); yr_yp = (yr + yp).cache()
+    return [b1 * b1 - b1, b2 * b2 - b2, b3 * b3 - b3, b4 * b4 - b4,
+            (xq1 - xp) * s1 - (yq1 - yp),
+            ((xp.double() - s1_sq) + xq1) * ((xp_xr * s1) + yr_yp) - (yp.double() * xp_xr),
+            yr_yp.square() - (xp_xr.square() * ((s1_sq - xq1) + xr)),
+            (xq2 - xr) * s3 - (yq2 - yr),
+            ((xr.double() - s3_sq) + xq2) * ((xr_xs * s3) + ys_yr) - (yr.double() * xr_xs),
+            ys_yr.square() - (xr_xs.square() * ((s3_sq - xq2) + xs)),
+            n_constraint,
+            xp_xr * xr_xs * inv - env.one()]
+
+
+def _polynomial(env: Env, coeffs, x):
+    """Horner: sum_i coeffs[i] x^i (endomul_scalar.rs: `polynomial`)."""
+    acc = None
+    for c in reversed(coeffs):
+        acc = env.const(c) if acc is None else acc * x + env.const(c)
+    return acc
+
+
+def endomul_scalar_constraints(env: Env):
+    """EndomulScalar::constraint_checks (endomul_scalar.rs:174-222): 11 constraints, 8 crumbs per row
+    (n0, n8, a0, b0, a8, b8, x0..x7 in columns 0..13)."""
+    p = env.p
+    inv = lambda v: pow(v, -1, p)
+    wc = env.witness_curr
+    n0, n8, a0, b0, a8, b8 = (wc(i) for i in range(6))
+    xs = [wc(6 + i) for i in range(8)]
+    c_coeffs = [0, 11 * inv(6) % p, (-5 * inv(2)) % p, 2 * inv(3) % p]
+    crumb_over_x = [(-6) % p, 11, (-6) % p, 1]
+    d_minus_c = [(-1) % p, 3, (-1) % p]
+    c_funcs = [_polynomial(env, c_coeffs, x).cache() for x in xs]
+    d_funcs = [c_funcs[i] + _polynomial(env, d_minus_c, xs[i]) for i in range(8)]
+    n8_exp = n0
+    for x in xs:
+        n8_exp = n8_exp.double().double() + x
+    a8_exp = a0
+    for c in c_funcs:
+        a8_exp = a8_exp.double() + c
+    b8_exp = b0
+    for d in d_funcs:
+        b8_exp = b8_exp.double() + d
+    return [n8_exp - n8, a8_exp - a8, b8_exp - b8] + [_polynomial(env, crumb_over_x, x) * x for x in xs]
+
+
+GATES = {"Poseidon": (poseidon_constraints, 15), "CompleteAdd": (complete_add_constraints, 7), "VarBaseMul": (varbasemul_constraints, 21),
+         "EndoMul": (endomul_constraints, 12), "EndoMulScalar": (endomul_scalar_constraints, 11)}
+
+
+def gate_program(name: str, p: int, alpha: int, selector_col: int = 30, mds=None, endo: int = 0, w0: int = 0, c0: int = 15):
+    """(tokens, constants as integers) of index(name) * combined constraints, alpha powers from alpha^0 (every gate's
+    constraints start at the first of the 21 gate alphas, linearization.rs:56-58)."""
+    fn, count = GATES[name]
+    env = Env(p, w0=w0, c0=c0, mds=mds, endo=endo)
+    cs = fn(env)
+    assert len(cs) == count, (name, len(cs))
+    expr = combined_constraints(env, selector_col, cs, alpha)
+    toks = compile_tokens(env, expr)
+    return toks, list(env.consts)

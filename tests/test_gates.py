@@ -1,0 +1,130 @@
+"""kimchi's gate library: the token programs of proof_systems_amd/polish.py against the oracle's per-row
+machines (oracle/gates.py) -- CPU part, no GPU needed: the programs are run by the oracle's PolishToken machine.
+
+For each of Poseidon, CompleteAdd, VarBaseMul, EndoMul, EndoMulScalar:
+  * the reference's own witness generator (restated) zeroes every constraint on every gate row, and the gate computes what
+    it claims (the Poseidon output equals the sponge permutation; the EC gates agree with the oracle's group law);
+  * the compiled program evaluates to alpha-combined constraints identical to the straight formulas, row by row, on the
+    satisfied table AND on a perturbed one (non-zero values must agree too);
+  * perturbing any witness cell a constraint reads makes some constraint non-zero."""
+import json
+import os
+import random
+
+import pytest
+
+from oracle import gates as G
+from oracle import pasta as P
+from proof_systems_amd import polish as OP
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+F = P.Fp
+CURVE = P.PALLAS                      # coordinates in Fp: the points a Vesta-side circuit computes on
+
+
+def kimchi_params():
+    d = json.load(open(os.path.join(ROOT, "tests", "golden", "poseidon_kimchi_params.json")))["fp"]
+    return [[int(x) for x in r] for r in d["mds"]], [[int(x) for x in r] for r in d["round_constants"]]
+
+
+def tables(name, rnd):
+    """(witness rows, coefficient rows, number of gate rows, extras) of a satisfied instance."""
+    mds, rc = kimchi_params()
+    endo = P.endos(CURVE)[0]
+    if name == "Poseidon":
+        st = [rnd.randrange(F.p) for _ in range(3)]
+        w, co, out = G.poseidon_witness(F, st, mds, rc, 11)
+        sp = __import__("oracle.poseidon", fromlist=["x"]).ArithmeticSponge(F); sp.state = list(st); sp.permute()
+        assert sp.state == out                                   # 11 gate rows = the 55-round Kimchi permutation
+        return w, co, 11
+    if name == "CompleteAdd":
+        pts = [CURVE.mul(CURVE.gen, rnd.randrange(1, 1 << 60)) for _ in range(6)]
+        cases = [(pts[0], pts[1]), (pts[2], pts[2]), (pts[3], (pts[3][0], (-pts[3][1]) % F.p)), (pts[4], pts[5])]
+        w = []
+        for a, b in cases:
+            row = G.complete_add_witness(F, a, b)
+            want = CURVE.add(a, b)
+            if want is None:
+                assert row[6] == 1
+            else:
+                assert row[6] == 0 and (row[4], row[5]) == want
+            w.append(row)
+        return w + [[0] * 15], [[0] * 15] * 5, 4
+    if name == "VarBaseMul":
+        base = CURVE.mul(CURVE.gen, rnd.randrange(1, 1 << 60))
+        bits = [rnd.randrange(2) for _ in range(20)]
+        acc0 = CURVE.add(base, base)
+        w, acc, n = G.varbasemul_witness(F, base, bits, acc0)
+        k = 2                                                    # acc <- 2 acc + (2b - 1) base per bit, from acc0 = 2 base
+        for b in bits:
+            k = 2 * k + (2 * b - 1)
+        assert acc == CURVE.mul(base, k) and n == int("".join(map(str, bits)), 2)
+        return w + [[0] * 15], [[0] * 15] * (len(w) + 1), len(w)   # gate rows: every even row (the odd ones are read as `next`)
+    if name == "EndoMul":
+        base = CURVE.mul(CURVE.gen, rnd.randrange(1, 1 << 60))
+        phi = (endo * base[0] % F.p, base[1])
+        acc0 = CURVE.add(CURVE.add(base, phi), CURVE.add(base, phi))
+        bits = [rnd.randrange(2) for _ in range(32)]
+        w, acc, n = G.endomul_witness(F, endo, base, bits, acc0)
+        want = acc0
+        for i in range(0, 32, 2):                                # A <- 2A + Q, Q in {+-T, +-phi(T)} chosen by (b_x, b_sign)
+            q = phi if bits[i] else base
+            q = q if bits[i + 1] else (q[0], (-q[1]) % F.p)
+            want = CURVE.add(CURVE.add(want, q), want)
+        assert acc == want and n == int("".join(map(str, bits)), 2)
+        return w, [[0] * 15] * len(w), len(w) - 1
+    scalar = rnd.randrange(1 << 128)
+    w, _ = G.endomul_scalar_witness(F, scalar, endo, 128)
+    return w + [[0] * 15], [[0] * 15] * (len(w) + 1), len(w)
+
+
+def program(name, alpha):
+    mds, _ = kimchi_params()
+    return OP.gate_program(name, F.p, alpha, selector_col=30, mds=mds, endo=P.endos(CURVE)[0])
+
+
+def gate_rows(name, ngate):
+    return list(range(0, ngate, 2)) if name == "VarBaseMul" else list(range(ngate))
+
+
+@pytest.mark.parametrize("name", list(OP.GATES))
+def test_gate_program_matches_row_machine(name):
+    rnd = random.Random(sum(map(ord, name)))
+    mds, _ = kimchi_params()
+    endo = P.endos(CURVE)[0]
+    w, co, ngate = tables(name, rnd)
+    nrows = len(w)
+    alpha = rnd.randrange(F.p)
+    toks, consts = program(name, alpha)
+    sel = [0] * nrows
+    for r in gate_rows(name, ngate):
+        sel[r] = 1
+    for variant in ("satisfied", "perturbed"):
+        wt = [list(r) for r in w]
+        if variant == "perturbed":
+            for r in range(nrows):
+                wt[r][rnd.randrange(15)] = rnd.randrange(F.p)
+        cols = [[wt[r][c] for r in range(nrows)] for c in range(15)] + [[co[r][c] for r in range(nrows)] for c in range(15)] + [sel]
+        got = P.polish_evaluate_rows(F, toks, cols, consts, nrows, 1, 1)
+        nonzero = 0
+        for r in range(nrows):
+            want = sel[r] * G.combined_row(F, name, wt[r], wt[(r + 1) % nrows], co[r], alpha, mds=mds, endo=endo) % F.p
+            assert got[r] == want, (name, variant, r)
+            nonzero += want != 0
+        assert (nonzero == 0) == (variant == "satisfied"), (name, variant)
+
+
+@pytest.mark.parametrize("name", list(OP.GATES))
+def test_every_constrained_cell_matters(name):
+    rnd = random.Random(7)
+    mds, _ = kimchi_params()
+    endo = P.endos(CURVE)[0]
+    w, co, ngate = tables(name, rnd)
+    row = gate_rows(name, ngate)[0]
+    used = {"Poseidon": range(15), "CompleteAdd": range(11), "VarBaseMul": [0, 1, 2, 3, 4, 5, 7, 8, 9, 10, 11, 12, 13, 14], "EndoMul": [0, 1, 2, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14],
+            "EndoMulScalar": range(14)}[name]
+    for c in used:
+        wt = [list(r) for r in w]
+        wt[row][c] = (wt[row][c] + 1 + rnd.randrange(5)) % F.p
+        vals = [G.combined_row(F, name, wt[r], wt[(r + 1) % len(wt)], co[r], 3, mds=mds, endo=endo) for r in gate_rows(name, ngate)]
+        assert any(vals), (name, c)
