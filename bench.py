@@ -308,7 +308,7 @@ def main():
     # result is fetched and (N>1) combined across ranks.
     fence()
     t0 = time.perf_counter()
-    depth = 1 if args.no_pipeline else 4
+    depth = 1 if args.no_pipeline else int(os.environ.get('KH_BENCH_DEPTH', '4'))
     pending = []
     for _ in range(args.steps):
         pending.append(srs.msm_submit(d_sc.ptr, n, 1))

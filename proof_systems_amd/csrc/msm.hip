@@ -40,6 +40,12 @@
 
 namespace kh {
 
+// Every kernel of the pipeline except the accumulation raises its wave priority: VALU issue on a SIMD is arbitrated by priority, then
+// age, so the short sort / tail kernels of the neighbouring jobs -- YOUNGER than the four resident accumulation waves they run
+// underneath -- otherwise get only the leftover issue slots (a 24 us k_digits took 511 us, a 65 us bucket sum 800 us, and the
+// four pipeline slots became latency-bound: tools/timeline.py).  They are a few percent of the work; the accumulation barely notices.
+#define KH_HIGH_PRIO() __builtin_amdgcn_s_setprio(3)
+
 // One persistent helper thread for the host part of msm_finish: on the plain (per-window) path every
 // result needs a ~256-doubling Horner fold (~70 us of CPU); the L and R commitments of an IPA round
 // are finished side by side instead of one after the other.
@@ -74,6 +80,7 @@ static HostHelper& host_helper(int device) {           // one per device context
 static constexpr int SCAN_T = 256, SCAN_I = 8, SCAN_B = SCAN_T * SCAN_I;
 
 __global__ void k_scan_block(const u32* in, u32* out, u32* sums, size_t n) {
+    KH_HIGH_PRIO();
     __shared__ u32 sh[SCAN_T];
     size_t base = (size_t)blockIdx.x * SCAN_B + (size_t)threadIdx.x * SCAN_I;
     u32 v[SCAN_I]; u32 tot = 0;
@@ -93,6 +100,7 @@ __global__ void k_scan_block(const u32* in, u32* out, u32* sums, size_t n) {
     for (int i = 0; i < SCAN_I; i++) { if (base + i < n) out[base + i] = excl; excl += v[i]; }
 }
 __global__ void k_scan_add(u32* out, const u32* sums, size_t n) {
+    KH_HIGH_PRIO();
     size_t i = (size_t)blockIdx.x * SCAN_B + threadIdx.x;
     u32 add = sums[blockIdx.x];
 #pragma unroll
@@ -124,6 +132,7 @@ int exclusive_scan_u32(const u32* in, u32* out, size_t n, DevBuf& tmp, hipStream
 template <class SF>
 __global__ void k_digits(const u64* __restrict__ scalars, const uint8_t* __restrict__ inf, size_t inf_off,
                          size_t inf_batch, size_t n, int mont, int c, int W, int32_t* __restrict__ digits) {
+    KH_HIGH_PRIO();
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     int j = blockIdx.y;
     if (i >= n) return;
@@ -164,6 +173,7 @@ __device__ __forceinline__ void geom_ids(const SortGeom& g, int s, int w, int j,
     else { q = (size_t)j * g.W + w; Sq = g.S; sigma = s; }
 }
 __global__ void k_hist(const int32_t* __restrict__ digits, SortGeom g, u32* __restrict__ H) {
+    KH_HIGH_PRIO();
     extern __shared__ u32 h[];
     int s = blockIdx.x, w = blockIdx.y, j = blockIdx.z;
     for (u32 b = threadIdx.x; b < g.nb; b += blockDim.x) h[b] = 0;
@@ -181,6 +191,7 @@ __global__ void k_hist(const int32_t* __restrict__ digits, SortGeom g, u32* __re
 }
 // per key: turn the per-slice counts into exclusive within-key prefixes, emit the key total
 __global__ void k_key_totals(u32* __restrict__ H, u32 nb, int Sq, size_t nkeys, u32* __restrict__ cnt) {
+    KH_HIGH_PRIO();
     size_t key = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (key >= nkeys) { if (key == nkeys) cnt[key] = 0; return; }
     size_t q = key / nb; u32 b = (u32)(key % nb);
@@ -192,6 +203,7 @@ __global__ void k_key_totals(u32* __restrict__ H, u32 nb, int Sq, size_t nkeys, 
 // ------------------------------------------------------------------------------------ 4 scatter
 __global__ void k_scatter(const int32_t* __restrict__ digits, SortGeom g, const u32* __restrict__ H,
                           const u32* __restrict__ off, u32* __restrict__ entries) {
+    KH_HIGH_PRIO();
     extern __shared__ u32 pos[];
     int s = blockIdx.x, w = blockIdx.y, j = blockIdx.z;
     size_t q; int Sq, sigma; geom_ids(g, s, w, j, q, Sq, sigma);
@@ -220,8 +232,10 @@ __device__ __forceinline__ u32 pick_K(u32 total, u32 room, u32 kmin) {
     u32 K = (total + room - 1) / room;
     return K < kmin ? kmin : (K > MAX_K ? MAX_K : K);
 }
-__global__ void k_ntask(const u32* __restrict__ off, size_t nkeys, u32 room, u32 kmin, u32* __restrict__ nt, u32* __restrict__ len_hist) {
+__global__ void k_ntask(const u32* __restrict__ off, size_t nkeys, u32 room, u32 kmin, u32* __restrict__ nt, u32* __restrict__ len_hist, u32* __restrict__ handed) {
+    KH_HIGH_PRIO();
     __shared__ u32 h[MAX_K + 1];
+    if (handed && blockIdx.x == 0 && threadIdx.x == 0) handed[0] = 0;          // hand-over list of the accumulation that follows
     for (u32 i = threadIdx.x; i <= MAX_K; i += blockDim.x) h[i] = 0;
     __syncthreads();
     const u32 K = pick_K(off[nkeys], room, kmin);
@@ -244,6 +258,7 @@ __global__ void k_ntask(const u32* __restrict__ off, size_t nkeys, u32 room, u32
 // entries per bucket) and the short tasks fill the end of the launch.
 // len_hist -> cursor[L] = first rank of length L (descending order)
 __global__ void k_len_starts(const u32* __restrict__ len_hist, u32* __restrict__ cursor) {
+    KH_HIGH_PRIO();
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         u32 run = 0;
         for (int L = (int)MAX_K; L >= 0; L--) { cursor[L] = run; run += len_hist[L]; }
@@ -252,6 +267,7 @@ __global__ void k_len_starts(const u32* __restrict__ len_hist, u32* __restrict__
 __global__ void __launch_bounds__(256)
 k_len_rank(const u32* __restrict__ off, const u32* __restrict__ nt, size_t nkeys,
            u32* __restrict__ cursor, u32* __restrict__ order, u32* __restrict__ rnt) {
+    KH_HIGH_PRIO();
     // two levels: rank inside the block with LDS atomics, then ONE global cursor increment per
     // (block, length) -- per-wave increments serialise on the few hot lengths (measured 0.6 ms)
     __shared__ u32 cnt[MAX_K + 1], base[MAX_K + 1];
@@ -277,11 +293,16 @@ template <class BF>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(112)))
 k_accumulate(const u32* __restrict__ entries, const u32* __restrict__ off, const u32* __restrict__ toff,
              const u32* __restrict__ roff, const u32* __restrict__ order,
-             size_t nkeys, const uint8_t* __restrict__ pts, uint8_t* __restrict__ partial, const uint8_t* __restrict__ only) {
-    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+             size_t nkeys, const uint8_t* __restrict__ pts, uint8_t* __restrict__ partial, const u32* __restrict__ only) {
+    KH_HIGH_PRIO();
+  // `only` = the hand-over list of k_accumulate29 ([0] = count, then task ids): a small persistent grid walks it (almost always
+  // empty -- a full-size grid of early-exit blocks took 0.6 ms to drain underneath the next job's accumulation)
+  const size_t first = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = only ? (size_t)gridDim.x * blockDim.x : 0;
+  const size_t count = only ? only[0] : 1;
+  for (size_t it = only ? first : 0; it < count; it += stride ? stride : 1) {
+    size_t t = only ? only[1 + it] : first;
     u32 NT = roff[nkeys];
     if (t >= NT) return;
-    if (only && !only[t]) return;        // second pass behind k_accumulate29: just the tasks it handed over
     // binary search over the length-ranked keys: largest rank with roff[rank] <= t
     size_t lo = 0, hi = nkeys;           // invariant roff[lo] <= t < roff[hi]
     while (hi - lo > 1) {
@@ -306,17 +327,22 @@ k_accumulate(const u32* __restrict__ entries, const u32* __restrict__ off, const
         acc = madd<BF>(acc, p, (e >> 31) != 0);
     }
     acc.store(partial + t * 128);
+  }
 }
 // The same task in the lazy 29-bit-limb arithmetic of field29.cuh (186 instead of 254 instructions per product, no
 // carry chains in the subtractions).  Its values are not canonical, so it cannot decide the exceptional cases of the
 // group law; it only notices that one cannot be excluded (probability ~2^-25 per addition on random inputs), abandons
 // the task and flags it in handed[]: k_accumulate then redoes exactly those tasks with the exact formulas.  Finished
 // tasks are converted to the canonical wire form, so everything downstream is unchanged and the result stays bit-exact.
+// Occupancy is CAPPED at 4 waves per SIMD although 92 VGPRs would allow 5: the sort kernels of the next job (k_hist / k_scatter:
+// 1024-thread blocks = 4 waves per SIMD, 128 KB of LDS) must find four free wave slots on every CU to run underneath this kernel;
+// with 5 resident accumulate waves on some CUs they queued instead and an accumulate kernel was running only 73 % of the pipelined
+// steady state (tools/timeline.py).
 template <class BF>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(112)))
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(112), amdgpu_waves_per_eu(4, 4)))
 k_accumulate29(const u32* __restrict__ entries, const u32* __restrict__ off, const u32* __restrict__ toff,
                const u32* __restrict__ roff, const u32* __restrict__ order,
-               size_t nkeys, const uint8_t* __restrict__ pts, uint8_t* __restrict__ partial, uint8_t* __restrict__ handed) {
+               size_t nkeys, const uint8_t* __restrict__ pts, uint8_t* __restrict__ partial, u32* __restrict__ handed) {
     const size_t t0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     u32 NT = roff[nkeys];
     if (t0 >= NT) return;
@@ -349,8 +375,7 @@ k_accumulate29(const u32* __restrict__ entries, const u32* __restrict__ off, con
         ok = madd29<BF>(acc, pack29<BF, 5>(p.x), pack29<BF, 5>(p.y));
         if (!ok) break;
     }
-    handed[t0] = ok ? 0 : 1;             // indexed like the second pass's thread id
-    if (!ok) return;
+    if (!ok) { handed[1 + atomicAdd(&handed[0], 1u)] = (u32)t0; return; }      // the exact kernel redoes this task
     Xyzz<BF> r;
     r.x = from29<BF>(acc.x); r.y = from29<BF>(acc.y); r.zz = from29<BF>(acc.zz); r.zzz = from29<BF>(acc.zzz);
     r.store(partial + t * 128);
@@ -365,6 +390,7 @@ template <class BF>
 __global__ void __launch_bounds__(256)
 k_bucket_sum(const u32* __restrict__ toff, size_t nkeys, const uint8_t* __restrict__ partial,
              uint8_t* __restrict__ buckets, u32* __restrict__ big, size_t cap, u32 SMALL_NT) {
+    KH_HIGH_PRIO();
     size_t key = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (key >= nkeys) return;
     u32 t0 = toff[key], nt = toff[key + 1] - t0;
@@ -398,6 +424,7 @@ template <class BF>
 __global__ void __launch_bounds__(64)
 k_bucket_chunk(const u32* __restrict__ toff, const uint8_t* __restrict__ partial, const u32* __restrict__ big, size_t cap,
                uint8_t* __restrict__ chunk_out) {
+    KH_HIGH_PRIO();
     // one wave = 16 quads per chunk item; every addition is the lane-cooperative one (coop.cuh): 8 sequential + 4 tree levels
     u32 nitems = big[1];
     const u32 quad = threadIdx.x >> 2;
@@ -415,6 +442,7 @@ template <class BF>
 __global__ void __launch_bounds__(256)
 k_bucket_big(const u32* __restrict__ toff, const uint8_t* __restrict__ chunk_out, uint8_t* __restrict__ buckets,
              const u32* __restrict__ big, size_t cap) {
+    KH_HIGH_PRIO();
     // one 256-thread block = 64 quads per hot bucket: a bucket holding 2^20 entries has ~1000 chunk sums
     __shared__ u32 sh[4 * 32];
     u32 nbig = big[0];
@@ -449,6 +477,7 @@ k_bucket_big(const u32* __restrict__ toff, const uint8_t* __restrict__ chunk_out
 template <class BF>
 __global__ void __launch_bounds__(128)
 k_reduce_seg(const uint8_t* __restrict__ buckets, u32 nb, u32 m, size_t ngroups, uint8_t* __restrict__ seg) {
+    KH_HIGH_PRIO();
     u32 nseg = nb / m;
     size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= ngroups * nseg) return;
@@ -500,6 +529,7 @@ __device__ __forceinline__ Xyzz<BF> block_sum(Xyzz<BF> acc, u32* sh) {
 template <class BF>
 __global__ void __launch_bounds__(256)
 k_sum_level(const uint8_t* __restrict__ in, u32 count, u32 out_stride, uint8_t* __restrict__ out) {
+    KH_HIGH_PRIO();
     __shared__ u32 sh[4 * 32];
     size_t q = blockIdx.y;
     const uint8_t* S = in + q * (size_t)count * 128;
@@ -512,6 +542,7 @@ k_sum_level(const uint8_t* __restrict__ in, u32 count, u32 out_stride, uint8_t* 
 template <class BF>
 __global__ void __launch_bounds__(256)
 k_sum_final(const uint8_t* __restrict__ in, u32 count, uint8_t* __restrict__ out) {
+    KH_HIGH_PRIO();
     __shared__ u32 sh[4 * 32];
     size_t q = blockIdx.x;
     const uint8_t* S = in + q * (size_t)count * 128;
@@ -532,6 +563,7 @@ struct MargGeom { u32 nb; u32 sh[3]; u32 wd[3]; };
 template <class BF>
 __global__ void __launch_bounds__(256)
 k_marginals(const uint8_t* __restrict__ buckets, MargGeom g, uint8_t* __restrict__ out) {
+    KH_HIGH_PRIO();
     __shared__ u32 sh[4 * 32];
     const u32 v = blockIdx.x, j = blockIdx.y; const size_t q = blockIdx.z;
     const u32 s = g.sh[j], f = g.wd[j];
@@ -551,6 +583,7 @@ k_marginals(const uint8_t* __restrict__ buckets, MargGeom g, uint8_t* __restrict
 template <class BF>
 __global__ void __launch_bounds__(64)
 k_marginal_fin(const uint8_t* __restrict__ marg, MargGeom g, uint8_t* __restrict__ out) {
+    KH_HIGH_PRIO();
     const u32 j = blockIdx.x; const size_t q = blockIdx.y;
     const u32 v = threadIdx.x, f = g.wd[j];
     Xyzz<BF> r = Xyzz<BF>::identity();
@@ -571,6 +604,7 @@ template <class BF>
 __global__ void __launch_bounds__(256)
 k_bucket_sum_q(const u32* __restrict__ toff, size_t nkeys, const uint8_t* __restrict__ partial,
                uint8_t* __restrict__ buckets, u32* __restrict__ big, size_t cap, u32 SMALL_NT) {
+    KH_HIGH_PRIO();
     size_t key = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
     const bool live = key < nkeys;
     if (!live) key = nkeys - 1;
@@ -598,6 +632,7 @@ k_bucket_sum_q(const u32* __restrict__ toff, size_t nkeys, const uint8_t* __rest
 template <class BF>
 __global__ void __launch_bounds__(1024)
 k_marginals_q(const uint8_t* __restrict__ buckets, MargGeom g, uint8_t* __restrict__ out) {
+    KH_HIGH_PRIO();
     __shared__ u32 sh[16 * 32];
     const u32 v = blockIdx.x, j = blockIdx.y; const size_t q = blockIdx.z;
     const u32 s = g.sh[j], f = g.wd[j];
@@ -632,6 +667,7 @@ k_marginals_q(const uint8_t* __restrict__ buckets, MargGeom g, uint8_t* __restri
 template <class BF>
 __global__ void __launch_bounds__(128)
 k_marginal_fin_q(const uint8_t* __restrict__ marg, MargGeom g, uint8_t* __restrict__ out) {
+    KH_HIGH_PRIO();
     __shared__ u32 sh[32 * 32];
     const u32 j = blockIdx.x; const size_t q = blockIdx.y;
     const u32 v = threadIdx.x >> 2, role = threadIdx.x & 3u, f = g.wd[j];
@@ -760,7 +796,7 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
     if ((rc = C.ws_toff.reserve((nkeys + 2) * sizeof(u32)))) return rc;
     if ((rc = C.ws_entries.reserve((M + 1) * sizeof(u32)))) return rc;
     if ((rc = C.ws_partial.reserve(max_tasks * 128))) return rc;
-    if ((rc = C.ws_handed.reserve(max_tasks + 256))) return rc;
+    if ((rc = C.ws_handed.reserve((max_tasks + 2) * sizeof(u32)))) return rc;
     if ((rc = C.ws_buckets.reserve(nkeys * 128))) return rc;
     const size_t bigcap = nkeys + max_tasks / CHUNK + 2;      // big buckets <= nkeys; chunk items <= tasks/512 + nkeys
     if ((rc = C.ws_biglist.reserve((2 + 4 * bigcap) * sizeof(u32)))) return rc;
@@ -857,7 +893,7 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
     u32* rnt = order + (nkeys + 2);
     u32* roff = rnt + (nkeys + 2);
     KH_HIP(hipMemsetAsync(len_hist, 0, (MAX_K + 1) * sizeof(u32), s));
-    hipLaunchKernelGGL(k_ntask, dim3((unsigned)((nkeys + 1 + 255) / 256)), dim3(256), 0, s, C.ws_off.as<u32>(), nkeys, room, kmin, C.ws_ntask.as<u32>(), len_hist);
+    hipLaunchKernelGGL(k_ntask, dim3((unsigned)((nkeys + 1 + 255) / 256)), dim3(256), 0, s, C.ws_off.as<u32>(), nkeys, room, kmin, C.ws_ntask.as<u32>(), len_hist, C.ws_handed.as<u32>());
     if ((rc = exclusive_scan_u32(C.ws_ntask.as<u32>(), C.ws_toff.as<u32>(), nkeys + 1, C.ws_scan_tmp, s))) return rc;
     static const int rank_min_log = getenv("KH_RANK_MIN_LOG") ? atoi(getenv("KH_RANK_MIN_LOG")) : 22;   // below ~4M entries the three extra launches cost more than the ordering saves
     if (M >= ((size_t)1 << rank_min_log)) {
@@ -871,20 +907,20 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
     C.timer.mark("tasks", s);
     // 5 accumulate: the lazy 29-bit-limb kernel, then the exact kernel over the (almost always zero) tasks it handed over
     static const bool acc29 = !(getenv("KH_ACC29") && atoi(getenv("KH_ACC29")) == 0);
-    const uint8_t* handed = acc29 ? C.ws_handed.as<uint8_t>() : nullptr;
+    const u32* handed = acc29 ? C.ws_handed.as<u32>() : nullptr;
     const dim3 agrid((unsigned)((max_tasks + 255) / 256));
     if (acc29) {
         auto kern = k_accumulate29<BF>;
         if (C.timer.enabled && C.timer.created && !gcap.active) {     // the dominant kernel's own start / stop timestamps (bench.py roofline)
             hipExtLaunchKernelGGL(kern, agrid, dim3(256), 0, s, C.timer.k0, C.timer.k1, 0,
                                   C.ws_entries.as<u32>(), C.ws_off.as<u32>(), C.ws_toff.as<u32>(), roff, order, nkeys,
-                                  (const uint8_t*)basis.pts, C.ws_partial.as<uint8_t>(), C.ws_handed.as<uint8_t>());
+                                  (const uint8_t*)basis.pts, C.ws_partial.as<uint8_t>(), C.ws_handed.as<u32>());
             C.timer.kname = "k_accumulate29";
         } else
         hipLaunchKernelGGL(kern, agrid, dim3(256), 0, s,
                            C.ws_entries.as<u32>(), C.ws_off.as<u32>(), C.ws_toff.as<u32>(), roff, order, nkeys,
-                           (const uint8_t*)basis.pts, C.ws_partial.as<uint8_t>(), C.ws_handed.as<uint8_t>());
-        hipLaunchKernelGGL((k_accumulate<BF>), agrid, dim3(256), 0, s,
+                           (const uint8_t*)basis.pts, C.ws_partial.as<uint8_t>(), C.ws_handed.as<u32>());
+        hipLaunchKernelGGL((k_accumulate<BF>), dim3(128), dim3(256), 0, s,
                            C.ws_entries.as<u32>(), C.ws_off.as<u32>(), C.ws_toff.as<u32>(), roff, order, nkeys,
                            (const uint8_t*)basis.pts, C.ws_partial.as<uint8_t>(), handed);
     } else if (C.timer.enabled && C.timer.created && !gcap.active) {
