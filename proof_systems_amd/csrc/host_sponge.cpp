@@ -24,6 +24,111 @@ namespace kh { void set_error(const char* fmt, ...); }
 namespace {
 #include "poseidon_params.inc"
 
+// Lazy-reduced Poseidon permutation: values stay in [0, 2p) inside x^7 (redc without the conditional subtraction: inputs below 2p
+// give outputs below (2 + tiny) p), the MDS row is ONE reduction of the 512-bit sum of its three products, one conditional subtraction
+// of 2p per state element per round.  Same residues as the plain version, canonical state on exit.
+template <int FID> struct FastPerm {
+    typedef khost::u64 u64; typedef khost::u128 u128; typedef khost::fe fe;
+    static constexpr u64 P0 = FID == 0 ? 0x992d30ed00000001ULL : 0x8c46eb2100000001ULL;
+    static constexpr u64 P1 = FID == 0 ? 0x224698fc094cf91bULL : 0x224698fc0994a8ddULL;
+    static constexpr u64 INV = FID == 0 ? 0x992d30ecffffffffULL : 0x8c46eb20ffffffffULL;
+    static constexpr u64 D0 = P0 << 1, D1 = (P1 << 1) | (P0 >> 63), D2 = P1 >> 63, D3 = 0x8000000000000000ULL;   // 2p
+    static inline void mul_wide(const u64 a[4], const u64 b[4], u64 t[8]) {
+        u128 c = (u128)a[0] * b[0]; t[0] = (u64)c; c >>= 64;
+        c += (u128)a[1] * b[0]; t[1] = (u64)c; c >>= 64;
+        c += (u128)a[2] * b[0]; t[2] = (u64)c; c >>= 64;
+        c += (u128)a[3] * b[0]; t[3] = (u64)c; t[4] = (u64)(c >> 64);
+#pragma GCC unroll 3
+        for (int i = 1; i < 4; i++) {
+            c = (u128)a[0] * b[i] + t[i]; t[i] = (u64)c; c >>= 64;
+            c += (u128)a[1] * b[i] + t[i + 1]; t[i + 1] = (u64)c; c >>= 64;
+            c += (u128)a[2] * b[i] + t[i + 2]; t[i + 2] = (u64)c; c >>= 64;
+            c += (u128)a[3] * b[i] + t[i + 3]; t[i + 3] = (u64)c; t[i + 4] = (u64)(c >> 64);
+        }
+    }
+    static inline void sqr_wide(const u64 a[4], u64 t[8]) {
+        // off-diagonal products
+        u128 c = (u128)a[0] * a[1]; u64 o1 = (u64)c; c >>= 64;
+        c += (u128)a[0] * a[2]; u64 o2 = (u64)c; c >>= 64;
+        c += (u128)a[0] * a[3]; u64 o3 = (u64)c; u64 o4 = (u64)(c >> 64);
+        c = (u128)a[1] * a[2] + o3; o3 = (u64)c; c >>= 64;
+        c += (u128)a[1] * a[3] + o4; o4 = (u64)c; u64 o5 = (u64)(c >> 64);
+        c = (u128)a[2] * a[3] + o5; o5 = (u64)c; u64 o6 = (u64)(c >> 64);
+        // double
+        const u64 o7 = o6 >> 63;
+        o6 = (o6 << 1) | (o5 >> 63); o5 = (o5 << 1) | (o4 >> 63); o4 = (o4 << 1) | (o3 >> 63);
+        o3 = (o3 << 1) | (o2 >> 63); o2 = (o2 << 1) | (o1 >> 63); o1 <<= 1;
+        // diagonals
+        c = (u128)a[0] * a[0]; t[0] = (u64)c; c >>= 64;
+        c += o1; t[1] = (u64)c; c >>= 64;
+        c += (u128)a[1] * a[1] + o2; t[2] = (u64)c; c >>= 64;
+        c += o3; t[3] = (u64)c; c >>= 64;
+        c += (u128)a[2] * a[2] + o4; t[4] = (u64)c; c >>= 64;
+        c += o5; t[5] = (u64)c; c >>= 64;
+        c += (u128)a[3] * a[3] + o6; t[6] = (u64)c; c >>= 64;
+        c += o7; t[7] = (u64)c;
+    }
+    // t / 2^256 mod p, in [0, t / 2^256 + p)
+    static inline void redc(u64 t[8], u64 r[4]) {
+        u64 pc = 0;
+#pragma GCC unroll 4
+        for (int i = 0; i < 4; i++) {
+            const u64 m = t[i] * INV;
+            u128 c = (u128)m * P0 + t[i]; c >>= 64;
+            c += (u128)m * P1 + t[i + 1]; t[i + 1] = (u64)c; c >>= 64;
+            c += t[i + 2]; t[i + 2] = (u64)c; c >>= 64;
+            c += (u128)(m << 62) + t[i + 3]; t[i + 3] = (u64)c; c >>= 64;
+            c += (u128)(m >> 2) + t[i + 4] + pc; t[i + 4] = (u64)c; pc = (u64)(c >> 64);
+        }
+        r[0] = t[4]; r[1] = t[5]; r[2] = t[6]; r[3] = t[7];
+    }
+    static inline void pow7(const u64 x[4], u64 out[4]) {
+        u64 t[8], x2[4], x4[4], x6[4];
+        sqr_wide(x, t); redc(t, x2);
+        sqr_wide(x2, t); redc(t, x4);
+        mul_wide(x4, x2, t); redc(t, x6);
+        mul_wide(x6, x, t); redc(t, out);
+    }
+    static inline void add8(u64 t[8], const u64 o[8]) {
+        u128 c = 0;
+#pragma GCC unroll 8
+        for (int i = 0; i < 8; i++) { c += (u128)t[i] + o[i]; t[i] = (u64)c; c >>= 64; }
+    }
+    static void permute(fe s[3], const fe mds[3][3], const fe rc[55][3]) {
+        u64 x[3][4];
+        for (int i = 0; i < 3; i++) for (int k = 0; k < 4; k++) x[i][k] = s[i].l[k];
+        for (int r = 0; r < 55; r++) {
+            u64 y[3][4];
+            pow7(x[0], y[0]); pow7(x[1], y[1]); pow7(x[2], y[2]);
+            for (int i = 0; i < 3; i++) {
+                u64 t[8], o[8], v[4];
+                mul_wide(mds[i][0].l, y[0], t);
+                mul_wide(mds[i][1].l, y[1], o); add8(t, o);
+                mul_wide(mds[i][2].l, y[2], o); add8(t, o);
+                redc(t, v);                                            // < 2.6 p
+                u128 c = (u128)v[0] + rc[r][i].l[0]; v[0] = (u64)c; c >>= 64;    // < 3.6 p < 2^256
+                c += (u128)v[1] + rc[r][i].l[1]; v[1] = (u64)c; c >>= 64;
+                c += (u128)v[2] + rc[r][i].l[2]; v[2] = (u64)c; c >>= 64;
+                c += (u128)v[3] + rc[r][i].l[3]; v[3] = (u64)c;
+                // conditional subtraction of 2p: below 2p afterwards
+                u128 d = (u128)v[0] - D0; const u64 e0 = (u64)d; u64 br = (u64)(d >> 64) & 1;
+                d = (u128)v[1] - D1 - br; const u64 e1 = (u64)d; br = (u64)(d >> 64) & 1;
+                d = (u128)v[2] - D2 - br; const u64 e2 = (u64)d; br = (u64)(d >> 64) & 1;
+                d = (u128)v[3] - D3 - br; const u64 e3 = (u64)d; br = (u64)(d >> 64) & 1;
+                x[i][0] = br ? v[0] : e0; x[i][1] = br ? v[1] : e1; x[i][2] = br ? v[2] : e2; x[i][3] = br ? v[3] : e3;
+            }
+        }
+        for (int i = 0; i < 3; i++) {                                   // canonical on exit
+            u128 d = (u128)x[i][0] - P0; const u64 e0 = (u64)d; u64 br = (u64)(d >> 64) & 1;
+            d = (u128)x[i][1] - P1 - br; const u64 e1 = (u64)d; br = (u64)(d >> 64) & 1;
+            d = (u128)x[i][2] - br; const u64 e2 = (u64)d; br = (u64)(d >> 64) & 1;
+            d = (u128)x[i][3] - 0x4000000000000000ULL - br; const u64 e3 = (u64)d; br = (u64)(d >> 64) & 1;
+            s[i].l[0] = br ? x[i][0] : e0; s[i].l[1] = br ? x[i][1] : e1; s[i].l[2] = br ? x[i][2] : e2; s[i].l[3] = br ? x[i][3] : e3;
+        }
+    }
+};
+
+
 struct Arith {                       // ArithmeticSponge over field `fid`
     int fid;
     khost::fe s[3];
@@ -31,22 +136,8 @@ struct Arith {                       // ArithmeticSponge over field `fid`
     int n = 0;
     explicit Arith(int f) : fid(f) { memset(s, 0, sizeof(s)); }
     void permute() {
-        khost::Fld F(fid);
-        const khost::fe (*mds)[3] = fid == 0 ? POSEIDON_MDS_FP : POSEIDON_MDS_FQ;
-        const khost::fe (*rc)[3] = fid == 0 ? POSEIDON_RC_FP : POSEIDON_RC_FQ;
-        for (int r = 0; r < 55; r++) {
-            khost::fe t[3];
-            for (int i = 0; i < 3; i++) {                       // x^7
-                const khost::fe x2 = F.sqr(s[i]), x4 = F.sqr(x2);
-                t[i] = F.mul(F.mul(x4, x2), s[i]);
-            }
-            for (int i = 0; i < 3; i++) {
-                khost::fe acc = F.mul(mds[i][0], t[0]);
-                acc = F.add(acc, F.mul(mds[i][1], t[1]));
-                acc = F.add(acc, F.mul(mds[i][2], t[2]));
-                s[i] = F.add(acc, rc[r][i]);
-            }
-        }
+        if (fid == 0) FastPerm<0>::permute(s, POSEIDON_MDS_FP, POSEIDON_RC_FP);
+        else FastPerm<1>::permute(s, POSEIDON_MDS_FQ, POSEIDON_RC_FQ);
     }
     void absorb(const khost::fe& x) {
         khost::Fld F(fid);
