@@ -288,6 +288,215 @@ k_len_rank(const u32* __restrict__ off, const u32* __restrict__ nt, size_t nkeys
     if (active) { u32 rank = base[len] + local; order[rank] = (u32)key; rnt[rank] = n_t; }
     if (key == nkeys) rnt[nkeys] = 0;
 }
+// ------------------------------------------------------------------------------------ fused sort (small jobs over the tables)
+// One to four MSMs of <= ~2^17 scalars over the window tables -- the L / R pair of an opening round, a lone commitment -- are
+// launch-bound in the sort: histogram, key totals, two three-level scans, task counts, scatter and two memsets were 13 dependent
+// launches of a few microseconds of work each (~0.11 ms of the 0.49 ms round).  k_sort_fused runs all of it in ONE launch of
+// <= 32 co-resident blocks separated by three grid barriers (an agent-scope counter in global memory; the blocks of four jobs in
+// flight fill at most half of the CUs, so every block is resident and the spin cannot deadlock).  Block (j, r) owns the r-th
+// contiguous chunk of group j's digit matrix [w][i]; its LDS histogram is one "slice" of the deterministic counting sort, the
+// keys are scanned with one (thread-contiguous keys, block scan, block totals) pass per barrier, and the same block scatters its
+// chunk.  Outputs are exactly those of the multi-launch path (off / toff / entries, empty hand-over and big-bucket lists).
+struct FusedGeom {
+    u32 n, nb, W, k, bpg, split, sub, kpt, nkeys, room, kmin;     // sub = nb / split buckets per block
+    size_t pt_stride, pt_offset, pt_batch;
+};
+static constexpr int FUSED_T = 1024, FUSED_KPT = 2, FUSED_G = 16, FUSED_B = 64;      // chunks per job <= FUSED_G, blocks <= FUSED_B
+static constexpr int FUSED_V = 17, FUSED_C = 16;        // int4's of digits / cursors per thread (registers)
+__device__ __forceinline__ void grid_barrier(u32* ctr, u32 target) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(2);
+    }
+    __syncthreads();
+    // no acquire fence: an agent-scope invalidate of the L2 cost ~7 us per barrier (every wave's first load afterwards waited for
+    // it).  Everything another block wrote is read with coherent (agent-scope, sc1) loads instead: coh_load below.
+}
+__device__ __forceinline__ u32 coh_load(const u32* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// exclusive prefix of v over the block's 1024 threads; *total = the block sum (sh: >= 16 words)
+__device__ __forceinline__ u32 block_scan_1024(u32 v, u32* sh, u32* total) {
+    const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    u32 inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { u32 o = __shfl_up(inc, d, 64); if (lane >= (u32)d) inc += o; }
+    __syncthreads();                                     // sh may still be read from the previous call
+    if (lane == 63) sh[wave] = inc;
+    __syncthreads();
+    u32 base = 0, tot = 0;
+#pragma unroll
+    for (u32 w2 = 0; w2 < FUSED_T / 64; w2++) { const u32 t = sh[w2]; if (w2 < wave) base += t; tot += t; }
+    *total = tot;
+    return base + inc - v;
+}
+// sum of bs[0 .. count) and of bs[0 .. upto) with ONE memory round trip (lane l loads bs[l]; count <= 64)
+__device__ __forceinline__ void lane_sums(const u32* bs, u32 count, u32 upto, u32* below, u32* total) {
+    const u32 lane = threadIdx.x & 63u;
+    u32 v = coh_load(bs + (lane < count ? lane : 0u));
+    if (lane >= count) v = 0u;
+    u32 lo = lane < upto ? v : 0u, all = v;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { lo += __shfl_xor(lo, d, 64); all += __shfl_xor(all, d, 64); }
+    *below = lo; *total = all;
+}
+__global__ void __launch_bounds__(FUSED_T)
+k_sort_fused(const int32_t* __restrict__ digits, FusedGeom g, u32* __restrict__ H, u32* __restrict__ off, u32* __restrict__ toff,
+             u32* __restrict__ entries, u32* __restrict__ handed, u32* __restrict__ big, u32* __restrict__ sync, u32* __restrict__ bsums) {
+    KH_HIGH_PRIO();
+    extern __shared__ u32 lds[];                         // `sub` words: histogram, later the scatter cursors
+    __shared__ u32 sh[FUSED_T / 64 + 1];
+    const u32 G = gridDim.x, blk = blockIdx.x, tid = threadIdx.x;
+    // block = (MSM j of the batch, chunk r of its digit matrix [w][i], bucket sub-range h of that chunk)
+    const u32 h = blk % g.split, r = (blk / g.split) % g.bpg, j = blk / (g.split * g.bpg);
+    const u32 b_lo = h * g.sub;
+    if (blk == 0 && tid == 0) { handed[0] = 0; big[0] = 0; big[1] = 0; }
+#define KH_TS(i) do { if (blk == 0 && tid == 0) ((unsigned long long*)(bsums + 2 * FUSED_B))[i] = wall_clock64(); } while (0)     // KH_FUSED_DEBUG prints them
+    KH_TS(0);
+    // 1 the chunk's digits into registers (every load of this kernel misses the L2 -- the data comes from other XCDs -- so all of
+    //   a phase's loads are issued before anything waits: the phases are memory round trips, not bandwidth), then the histogram
+    const u32 tot4 = (g.W * g.n) / 4;                                   // chunks are whole int4's of the [w][i] matrix
+    const u32 q_lo = (u32)((u64)tot4 * r / g.bpg), q_hi = (u32)((u64)tot4 * (r + 1) / g.bpg);
+    const int4* d4 = (const int4*)(digits + (size_t)j * g.W * g.n);
+    // digits are kept as 16-bit codes, two per register: sign << 15 | (|d| - 1), 0xffff for d = 0 (|d| - 1 = 32767 is never negative)
+    u32 dv[FUSED_V][2];
+#pragma unroll
+    for (int t0 = 0; t0 < FUSED_V; t0 += 6) {                           // six 16-byte loads in flight per thread
+        int4 x[6];
+#pragma unroll
+        for (int u = 0; u < 6; u++) if (t0 + u < FUSED_V) {            // unconditional loads (clamped index): a predicated load is waited for on the spot
+            const u32 q = q_lo + tid + (t0 + u) * FUSED_T;
+            x[u] = d4[q < q_hi ? q : q_hi - 1];
+        }
+#pragma unroll
+        for (int u = 0; u < 6; u++) if (t0 + u < FUSED_V) {
+            const bool in = q_lo + tid + (t0 + u) * FUSED_T < q_hi;
+            const int32_t v[4] = {x[u].x, x[u].y, x[u].z, x[u].w};
+            u32 c[4];
+#pragma unroll
+            for (int l = 0; l < 4; l++) c[l] = (!in || v[l] == 0) ? 0xffffu : ((v[l] < 0 ? 0x8000u : 0u) | ((u32)(v[l] < 0 ? -v[l] : v[l]) - 1u));
+            dv[t0 + u][0] = c[0] | (c[1] << 16); dv[t0 + u][1] = c[2] | (c[3] << 16);
+        }
+    }
+    for (u32 b = tid; b < g.sub; b += FUSED_T) lds[b] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < FUSED_V; t++) {
+#pragma unroll
+        for (int l = 0; l < 4; l++) {
+            const u32 c = (dv[t][l >> 1] >> (16 * (l & 1))) & 0xffffu, b = (c & 0x7fffu) - b_lo;
+            if (c != 0xffffu && b < g.sub) atomicAdd(&lds[b], 1u);
+        }
+    }
+    __syncthreads();
+    u32* hout = H + ((size_t)j * g.bpg + r) * g.nb + b_lo;
+    for (u32 b = tid; b < g.sub; b += FUSED_T) hout[b] = lds[b];
+    KH_TS(1);
+    grid_barrier(sync, G);
+    KH_TS(2);
+    // 2 per key: within-key prefixes over the chunks, the key's count; block-local scan of the counts
+    const u32 key0 = (blk * FUSED_T + tid) * g.kpt;
+    u32 cnt[FUSED_KPT], mine = 0;
+    {
+        u32 hv[FUSED_KPT][FUSED_G];                          // 32-bit indices from the uniform base: one offset register per access
+#pragma unroll
+        for (int i = 0; i < FUSED_KPT; i++) {
+            const u32 key = key0 + i;
+            const bool live = (u32)i < g.kpt && key < g.nkeys;
+            const u32 idx = (key / g.nb) * g.bpg * g.nb + key % g.nb;
+#pragma unroll
+            for (int c = 0; c < FUSED_G; c++) hv[i][c] = coh_load(H + (live ? idx : 0u) + ((u32)c < g.bpg ? (u32)c : 0u) * g.nb);     // unconditional, masked below
+#pragma unroll
+            for (int c = 0; c < FUSED_G; c++) if (!(live && (u32)c < g.bpg)) hv[i][c] = 0u;
+        }
+#pragma unroll
+        for (int i = 0; i < FUSED_KPT; i++) {
+            const u32 key = key0 + i;
+            const bool live = (u32)i < g.kpt && key < g.nkeys;
+            const u32 idx = (key / g.nb) * g.bpg * g.nb + key % g.nb;
+            u32 run = 0;
+#pragma unroll
+            for (int c = 0; c < FUSED_G; c++) { if (live && (u32)c < g.bpg) H[idx + (u32)c * g.nb] = run; run += hv[i][c]; }
+            cnt[i] = run; mine += run;
+        }
+    }
+    u32 btot;
+    const u32 ex1 = block_scan_1024(mine, sh, &btot);
+    if (tid == 0) bsums[blk] = btot;
+    KH_TS(3);
+    grid_barrier(sync, 2 * G);
+    KH_TS(4);
+    // 3 off[]; the task length K from the true entry count; task counts and their block-local scan
+    u32 base, total;
+    lane_sums(bsums, G, blk, &base, &total);
+    KH_TS(9);
+    const u32 K = pick_K(total, g.room, g.kmin);
+    u32 run = base + ex1, ntm = 0, nt[FUSED_KPT];
+#pragma unroll
+    for (int i = 0; i < FUSED_KPT; i++) {
+        const u32 key = key0 + i;
+        nt[i] = (cnt[i] + K - 1) / K;
+        if ((u32)i < g.kpt && key <= g.nkeys) off[key] = run;
+        run += cnt[i]; ntm += nt[i];
+    }
+    KH_TS(10);
+    const u32 ex2 = block_scan_1024(ntm, sh, &btot);
+    KH_TS(11);
+    if (tid == 0) bsums[FUSED_B + blk] = btot;
+    KH_TS(5);
+    grid_barrier(sync, 3 * G);
+    KH_TS(6);
+    // 4 scatter cursors (key offset + the chunk's within-key prefix); toff[]; scatter of the digits held in registers
+    const u32* o = off + (size_t)j * g.nb + b_lo;
+    {
+        u32 a[FUSED_C], hh[FUSED_C];
+#pragma unroll
+        for (int u = 0; u < FUSED_C; u++) { const u32 b = tid + u * FUSED_T, bc = b < g.sub ? b : 0u; a[u] = coh_load(o + bc); hh[u] = coh_load(hout + bc); }
+        u32 total2;
+        lane_sums(bsums + FUSED_B, G, blk, &base, &total2);
+#pragma unroll
+        for (int u = 0; u < FUSED_C; u++) { const u32 b = tid + u * FUSED_T; if (b < g.sub) lds[b] = a[u] + hh[u]; }
+    }
+    run = base + ex2;
+#pragma unroll
+    for (int i = 0; i < FUSED_KPT; i++) {
+        const u32 key = key0 + i;
+        if ((u32)i < g.kpt && key <= g.nkeys) toff[key] = run;
+        run += nt[i];
+    }
+    __syncthreads();
+    KH_TS(7);
+    const u32 pb0 = (u32)(g.pt_offset + (size_t)j * g.pt_batch);
+    const u32 e_first = 4 * (q_lo + tid);
+    u32 w = e_first / g.n, i = e_first - w * g.n;                       // (window, point) of the int4's first digit, advanced incrementally
+#pragma unroll
+    for (int t = 0; t < FUSED_V; t++) asm volatile("" : "+v"(dv[t][0]), "+v"(dv[t][1]));       // (no values of phase 1 kept alive: they spilled)
+#pragma unroll
+    for (int t = 0; t < FUSED_V; t++) {
+#pragma unroll
+        for (int l = 0; l < 4; l++) {
+            const u32 c = (dv[t][l >> 1] >> (16 * (l & 1))) & 0xffffu, b = (c & 0x7fffu) - b_lo;
+            if (c != 0xffffu && b < g.sub) {
+                u32 ii = i + l, ww = w;
+                if (ii >= g.n) { ii -= g.n; ww++; }
+                const u32 slot = atomicAdd(&lds[b], 1u);
+                entries[slot] = (pb0 + (u32)(ww * g.pt_stride) + ii) | ((c & 0x8000u) << 16);
+            }
+        }
+        i += 4 * FUSED_T;
+        while (i >= g.n) { i -= g.n; w++; }
+    }
+    // the last block out re-arms the barrier counter for the next launch
+    __syncthreads();
+    KH_TS(8);
+    if (tid == 0) {
+        const u32 out = __hip_atomic_fetch_add(sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (out == G - 1) {
+            __hip_atomic_store(sync, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(sync + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
 // ------------------------------------------------------------------------------------ 5 accumulate
 template <class BF>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(112)))
@@ -832,6 +1041,28 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
     if (Ctx.once("msm_attr")) {
         KH_HIP(hipFuncSetAttribute((const void*)k_hist, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
         KH_HIP(hipFuncSetAttribute((const void*)k_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+        KH_HIP(hipFuncSetAttribute((const void*)k_sort_fused, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+    }
+    // small jobs over the tables: the whole sort in one launch (k_sort_fused)
+    static const bool fused_off = getenv("KH_NO_FUSED_SORT") != nullptr;
+    static const size_t fused_max = getenv("KH_FUSED_MAX") ? (size_t)atol(getenv("KH_FUSED_MAX")) : ((size_t)1 << 22);
+    FusedGeom fg{};
+    bool fused = precomp && !fused_off && k <= 4 && M < fused_max && nb >= 2048;
+    if (fused) {
+        fg.n = (u32)n; fg.nb = nb; fg.W = (u32)W; fg.k = (u32)k; fg.bpg = (u32)std::min<size_t>(FUSED_G, FUSED_B / (2 * k)); fg.nkeys = (u32)nkeys;
+        fg.split = 2; fg.sub = nb / fg.split;              // 64 blocks of 64 KB LDS: two per CU, so four (even eight) jobs in flight stay co-resident
+        fg.room = room; fg.kmin = kmin; fg.pt_stride = tab_stride; fg.pt_offset = offset; fg.pt_batch = basis.batch_stride;
+        const size_t threads = (size_t)fg.bpg * k * fg.split * FUSED_T;
+        fg.kpt = (u32)((nkeys + 1 + threads - 1) / threads);
+        const size_t tot4 = (size_t)W * n / 4, chunk4 = (tot4 + fg.bpg - 1) / fg.bpg + 1;
+        if (fg.kpt > (u32)FUSED_KPT || n < 4 || ((size_t)W * n) % 4 || chunk4 > (size_t)FUSED_V * FUSED_T || fg.sub > (u32)FUSED_C * FUSED_T) fused = false;
+    }
+    if (fused) {
+        if ((rc = C.ws_hist.reserve((size_t)k * fg.bpg * nb * sizeof(u32)))) return rc;
+        if (!C.ws_sync.p) {
+            if ((rc = C.ws_sync.reserve((2 + 2 * FUSED_B + 32) * sizeof(u32)))) return rc;
+            KH_HIP(hipMemsetAsync(C.ws_sync.p, 0, (2 + 2 * FUSED_B + 32) * sizeof(u32), s));
+        }
     }
     // hipGraph replay / capture (opt-in by the caller; the key covers everything the launches bake in)
     static const bool graphs_off = getenv("KH_NO_GRAPH") != nullptr;
@@ -846,7 +1077,7 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
                                   (uint64_t)(uintptr_t)C.ws_ntask.p, (uint64_t)(uintptr_t)C.ws_toff.p, (uint64_t)(uintptr_t)C.ws_entries.p, (uint64_t)(uintptr_t)C.ws_partial.p,
                                   (uint64_t)(uintptr_t)C.ws_buckets.p, (uint64_t)(uintptr_t)C.ws_seg.p, (uint64_t)(uintptr_t)C.ws_out.p, (uint64_t)(uintptr_t)C.ws_scan_tmp.p,
                                   (uint64_t)(uintptr_t)C.ws_biglist.p, (uint64_t)(uintptr_t)C.ws_order.p, (uint64_t)(uintptr_t)C.ws_chunks.p,
-                                  (uint64_t)(uintptr_t)C.ws_handed.p};
+                                  (uint64_t)(uintptr_t)C.ws_handed.p, (uint64_t)(uintptr_t)C.ws_sync.p, (uint64_t)fused};
         for (uint64_t v : parts) key = fnv(key, v);
         if (C.gexec && C.gkey == key) {                    // replay
             KH_HIP(hipGraphLaunch(C.gexec, s));
@@ -872,39 +1103,48 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
     hipLaunchKernelGGL((k_digits<SF>), dim3((unsigned)((n + 255) / 256), (unsigned)k), dim3(256), 0, s,
                        scalars_dev, basis.inf, offset, basis.batch_stride, n, mont, c, W, C.ws_digits.as<int32_t>());
     C.timer.mark("digits", s);
-    // 2 histogram
-    size_t lds = (size_t)nb * sizeof(u32);
-    dim3 sgrid((unsigned)S, (unsigned)W, (unsigned)k);
-    hipLaunchKernelGGL(k_hist, sgrid, dim3(1024), lds, s, C.ws_digits.as<int32_t>(), g, C.ws_hist.as<u32>());
-    hipLaunchKernelGGL(k_key_totals, dim3((unsigned)((nkeys + 1 + 255) / 256)), dim3(256), 0, s,
-                       C.ws_hist.as<u32>(), nb, Sq, nkeys, C.ws_cnt.as<u32>());
-    C.timer.mark("histogram", s);
-    // 3 scan
-    if ((rc = exclusive_scan_u32(C.ws_cnt.as<u32>(), C.ws_off.as<u32>(), nkeys + 1, C.ws_scan_tmp, s))) return rc;
-    C.timer.mark("scan", s);
-    // 4 scatter
-    hipLaunchKernelGGL(k_scatter, sgrid, dim3(1024), lds, s, C.ws_digits.as<int32_t>(), g, C.ws_hist.as<u32>(),
-                       C.ws_off.as<u32>(), C.ws_entries.as<u32>());
-    C.timer.mark("scatter", s);
-    // tasks
     u32* len_hist = C.ws_order.as<u32>();                       // [MAX_K+1] histogram, [MAX_K+1] cursors, then order / rnt / roff
     u32* cursor = len_hist + (MAX_K + 1);
     u32* order = cursor + (MAX_K + 1);
     u32* rnt = order + (nkeys + 2);
     u32* roff = rnt + (nkeys + 2);
-    KH_HIP(hipMemsetAsync(len_hist, 0, (MAX_K + 1) * sizeof(u32), s));
-    hipLaunchKernelGGL(k_ntask, dim3((unsigned)((nkeys + 1 + 255) / 256)), dim3(256), 0, s, C.ws_off.as<u32>(), nkeys, room, kmin, C.ws_ntask.as<u32>(), len_hist, C.ws_handed.as<u32>());
-    if ((rc = exclusive_scan_u32(C.ws_ntask.as<u32>(), C.ws_toff.as<u32>(), nkeys + 1, C.ws_scan_tmp, s))) return rc;
-    static const int rank_min_log = getenv("KH_RANK_MIN_LOG") ? atoi(getenv("KH_RANK_MIN_LOG")) : 22;   // below ~4M entries the three extra launches cost more than the ordering saves
-    if (M >= ((size_t)1 << rank_min_log)) {
-        hipLaunchKernelGGL(k_len_starts, dim3(1), dim3(64), 0, s, len_hist, cursor);
-        hipLaunchKernelGGL(k_len_rank, dim3((unsigned)((nkeys + 1 + 255) / 256)), dim3(256), 0, s, C.ws_off.as<u32>(), C.ws_ntask.as<u32>(), nkeys, cursor, order, rnt);
-        if ((rc = exclusive_scan_u32(rnt, roff, nkeys + 1, C.ws_scan_tmp, s))) return rc;
-    } else {                     // small problems are launch-latency bound: keep the key order
+    if (fused) {
         order = nullptr; roff = C.ws_toff.as<u32>();
+        u32* sy = C.ws_sync.as<u32>();
+        hipLaunchKernelGGL(k_sort_fused, dim3(fg.bpg * fg.k * fg.split), dim3(FUSED_T), (size_t)fg.sub * sizeof(u32), s, C.ws_digits.as<int32_t>(), fg,
+                           C.ws_hist.as<u32>(), C.ws_off.as<u32>(), C.ws_toff.as<u32>(), C.ws_entries.as<u32>(), C.ws_handed.as<u32>(),
+                           C.ws_biglist.as<u32>(), sy, sy + 2);
+        C.timer.mark("sort", s);
+    } else {
+        // 2 histogram
+        size_t lds = (size_t)nb * sizeof(u32);
+        dim3 sgrid((unsigned)S, (unsigned)W, (unsigned)k);
+        hipLaunchKernelGGL(k_hist, sgrid, dim3(1024), lds, s, C.ws_digits.as<int32_t>(), g, C.ws_hist.as<u32>());
+        hipLaunchKernelGGL(k_key_totals, dim3((unsigned)((nkeys + 1 + 255) / 256)), dim3(256), 0, s,
+                           C.ws_hist.as<u32>(), nb, Sq, nkeys, C.ws_cnt.as<u32>());
+        C.timer.mark("histogram", s);
+        // 3 scan
+        if ((rc = exclusive_scan_u32(C.ws_cnt.as<u32>(), C.ws_off.as<u32>(), nkeys + 1, C.ws_scan_tmp, s))) return rc;
+        C.timer.mark("scan", s);
+        // 4 scatter
+        hipLaunchKernelGGL(k_scatter, sgrid, dim3(1024), lds, s, C.ws_digits.as<int32_t>(), g, C.ws_hist.as<u32>(),
+                           C.ws_off.as<u32>(), C.ws_entries.as<u32>());
+        C.timer.mark("scatter", s);
+        // tasks
+        KH_HIP(hipMemsetAsync(len_hist, 0, (MAX_K + 1) * sizeof(u32), s));
+        hipLaunchKernelGGL(k_ntask, dim3((unsigned)((nkeys + 1 + 255) / 256)), dim3(256), 0, s, C.ws_off.as<u32>(), nkeys, room, kmin, C.ws_ntask.as<u32>(), len_hist, C.ws_handed.as<u32>());
+        if ((rc = exclusive_scan_u32(C.ws_ntask.as<u32>(), C.ws_toff.as<u32>(), nkeys + 1, C.ws_scan_tmp, s))) return rc;
+        static const int rank_min_log = getenv("KH_RANK_MIN_LOG") ? atoi(getenv("KH_RANK_MIN_LOG")) : 22;   // below ~4M entries the three extra launches cost more than the ordering saves
+        if (M >= ((size_t)1 << rank_min_log)) {
+            hipLaunchKernelGGL(k_len_starts, dim3(1), dim3(64), 0, s, len_hist, cursor);
+            hipLaunchKernelGGL(k_len_rank, dim3((unsigned)((nkeys + 1 + 255) / 256)), dim3(256), 0, s, C.ws_off.as<u32>(), C.ws_ntask.as<u32>(), nkeys, cursor, order, rnt);
+            if ((rc = exclusive_scan_u32(rnt, roff, nkeys + 1, C.ws_scan_tmp, s))) return rc;
+        } else {                     // small problems are launch-latency bound: keep the key order
+            order = nullptr; roff = C.ws_toff.as<u32>();
+        }
+        KH_HIP(hipMemsetAsync(C.ws_biglist.p, 0, 2 * sizeof(u32), s));
+        C.timer.mark("tasks", s);
     }
-    KH_HIP(hipMemsetAsync(C.ws_biglist.p, 0, 2 * sizeof(u32), s));
-    C.timer.mark("tasks", s);
     // 5 accumulate: the lazy 29-bit-limb kernel, then the exact kernel over the (almost always zero) tasks it handed over
     static const bool acc29 = !(getenv("KH_ACC29") && atoi(getenv("KH_ACC29")) == 0);
     const u32* handed = acc29 ? C.ws_handed.as<u32>() : nullptr;
@@ -1008,6 +1248,12 @@ int msm_enqueue(Context& C, MsmSlot& S, int curve, const MsmBasis& basis, size_t
 int msm_finish(Context& C, MsmSlot& S, uint64_t* out_xy, uint8_t* out_inf) {
     KH_HIP(hipEventSynchronize(S.done));
     S.busy = false;
+    static const bool fused_dbg = getenv("KH_FUSED_DEBUG") != nullptr;
+    if (fused_dbg && S.ws_sync.p) {                       // phase timestamps of the last k_sort_fused on this slot (block 0)
+        unsigned long long ts[12]; (void)hipMemcpy(ts, S.ws_sync.as<u32>() + 2 + 2 * FUSED_B, sizeof(ts), hipMemcpyDeviceToHost);
+        fprintf(stderr, "k_sort_fused phases (us):"); for (int i = 1; i < 9; i++) fprintf(stderr, " %.1f", (double)(ts[i] - ts[i - 1]) / 100.0);
+        fprintf(stderr, " | p3: %.1f %.1f %.1f %.1f\n", (double)(ts[9] - ts[4]) / 100.0, (double)(ts[10] - ts[9]) / 100.0, (double)(ts[11] - ts[10]) / 100.0, (double)(ts[5] - ts[11]) / 100.0);
+    }
     collect_timings(C, S.timer);
     if (S.ngroups == 0) {
         for (size_t j = 0; j < S.k; j++) { memset(out_xy + 8 * j, 0, 64); out_inf[j] = 1; }
