@@ -397,7 +397,20 @@ static int wait_then_finish(std::unique_lock<std::mutex>& lk, Context& C, MsmSlo
     hipEvent_t ev = S.done;
     C.sync_inflight++;
     lk.unlock();
-    hipError_t e = hipEventSynchronize(ev);
+    // a synchronous caller is latency-bound (an opening round is ~0.4 ms of GPU time, then ~40 us of transcript on this thread):
+    // poll for up to a millisecond before blocking -- the blocking wait's wake-up alone costs 10-20 us
+    static const long spin_us = getenv("KH_SPIN_US") ? atol(getenv("KH_SPIN_US")) : 1000;
+    hipError_t e = hipErrorNotReady;
+    if (spin_us > 0) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (;;) {
+            e = hipEventQuery(ev);
+            if (e != hipErrorNotReady) break;
+            if (std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > spin_us) break;
+            __builtin_ia32_pause();
+        }
+    }
+    if (e == hipErrorNotReady) { (void)hipGetLastError(); e = hipEventSynchronize(ev); }
     lk.lock();
     C.sync_inflight--;
     int rc;
@@ -1025,6 +1038,9 @@ struct kh_ipa {
     int pp = 0;
     hipEvent_t ev = nullptr;              // orders the fold (library stream) before the next round's MSM (slot stream)
     bool lr_done = false;
+    bool pending = false;                 // a recorded, not yet applied fold (kh_ipa_round_fold): the next round's step kernel applies it
+    uint64_t u_p[4] = {0, 0, 0, 0}, ui_p[4] = {0, 0, 0, 0};
+    size_t partial_words = 0;             // u64 words of `partial` before the step kernel's block counter
 };
 
 static int ipa_begin_common(kh_srs_t* srs, const uint64_t* a, size_t a_len, const uint64_t* b, size_t b_len, const uint64_t u_base_xy[8], kh_ipa_t** out,
@@ -1058,9 +1074,11 @@ static int ipa_begin_common(kh_srs_t* srs, const uint64_t* a, size_t a_len, cons
         if ((rc = srs->ipa_coef[i].reserve(n * 32))) return rc;
     }
     if ((rc = srs->ipa_sc.reserve(2 * (n + 2) * 32))) return rc;
-    if ((rc = srs->ipa_partial.reserve(2 * 64 * 32))) return rc;
+    const size_t partial_bytes = 2 * (n / 512 + 1) * 32;               // block sums of the two inner products, then the last-block counter
+    if ((rc = srs->ipa_partial.reserve(partial_bytes + 64))) return rc;
+    KH_HIP(hipMemsetAsync((uint8_t*)srs->ipa_partial.p + partial_bytes, 0, 64, C.stream));
     if (!srs->ipa_ev) KH_HIP(hipEventCreateWithFlags(&srs->ipa_ev, hipEventDisableTiming));
-    st->a = srs->ipa_a; st->b = srs->ipa_b; st->coef = srs->ipa_coef; st->sc = &srs->ipa_sc; st->partial = &srs->ipa_partial; st->ev = srs->ipa_ev;
+    st->a = srs->ipa_a; st->b = srs->ipa_b; st->coef = srs->ipa_coef; st->sc = &srs->ipa_sc; st->partial = &srs->ipa_partial; st->ev = srs->ipa_ev; st->partial_words = partial_bytes / 8;
     // H and U into the two extra slots of every window table
     const int W = srs->g_precomp_c ? (256 + srs->g_precomp_c - 1) / srs->g_precomp_c : 1;
     std::vector<uint64_t> tab((size_t)W * 16), col((size_t)W * 8);
@@ -1103,10 +1121,14 @@ int kh_ipa_round_lr(kh_ipa_t* st, const uint64_t rand_l[4], const uint64_t rand_
     KH_REQUIRE(si >= 0, "all %d MSM pipeline slots hold an un-waited job (kh_msm_wait first)", MSM_SLOTS);
     MsmSlot& S = C.slot[si];
     KH_HIP(hipStreamWaitEvent(S.stream, st->ev, 0));
-    const int p = st->pp;
-    int rc = ipa_round_prepare(S.stream, st->field, st->a[p].as<uint64_t>(), st->b[p].as<uint64_t>(), st->coef[p].as<uint64_t>(),
-                               st->n, st->cur, rand_l, rand_r, st->sc->as<uint64_t>(), st->partial->as<uint64_t>());
+    const int p = st->pp, q = p ^ 1;
+    // one launch: the recorded fold of the previous round (if any), this round's inner products and expanded scalars
+    int rc = ipa_round_step(S.stream, st->field, st->pending ? 1 : 0, st->a[p].as<uint64_t>(), st->b[p].as<uint64_t>(), st->coef[p].as<uint64_t>(),
+                            st->n, st->cur, st->pending ? st->ncoef / 2 : st->ncoef, st->u_p, st->ui_p,
+                            st->a[q].as<uint64_t>(), st->b[q].as<uint64_t>(), st->coef[q].as<uint64_t>(), rand_l, rand_r,
+                            st->sc->as<uint64_t>(), st->partial->as<uint64_t>(), (unsigned*)(st->partial->as<uint64_t>() + st->partial_words));
     if (rc) return rc;
+    if (st->pending) { st->pp = q; st->pending = false; }
     kh_srs_t* srs = st->srs;
     MsmBasis bs; bs.pts = srs->g.p; bs.inf = nullptr; bs.n = srs->g_stride; bs.stride = srs->g_stride; bs.precomp_c = srs->g_precomp_c;
     if ((rc = msm_enqueue(C, S, st->curve, bs, 0, st->sc->as<uint64_t>(), st->n + 2, 2, 1, /*use_graph=*/1))) return rc;
@@ -1122,14 +1144,9 @@ int kh_ipa_round_fold(kh_ipa_t* st, const uint64_t chal[2], uint64_t u_out[4], u
     scalar_challenge_to_field(st->field, chal, cached_endos(st->curve).r, u);
     KH_REQUIRE((u[0] | u[1] | u[2] | u[3]) != 0, "challenge maps to zero (u.inverse().unwrap() in ipa.rs:975)");
     host_field_inverse(st->field, u, ui);
-    Context& C = ctx();
-    std::lock_guard<std::mutex> lk(C.mu);
-    const int p = st->pp, q = p ^ 1;
-    int rc = ipa_round_fold(C.stream, st->field, st->a[p].as<uint64_t>(), st->b[p].as<uint64_t>(), st->coef[p].as<uint64_t>(), st->cur, st->ncoef,
-                            u, ui, st->a[q].as<uint64_t>(), st->b[q].as<uint64_t>(), st->coef[q].as<uint64_t>());
-    if (rc) return rc;
-    KH_HIP(hipEventRecord(st->ev, C.stream));
-    st->pp = q; st->cur /= 2; st->ncoef *= 2; st->lr_done = false;
+    // recorded only: the next round's step kernel (or kh_ipa_finish) applies it -- one launch per round instead of four
+    memcpy(st->u_p, u, 32); memcpy(st->ui_p, ui, 32);
+    st->pending = true; st->cur /= 2; st->ncoef *= 2; st->lr_done = false;
     if (u_out) memcpy(u_out, u, 32);
     if (u_inv_out) memcpy(u_inv_out, ui, 32);
     return KH_OK;
@@ -1144,12 +1161,18 @@ int kh_ipa_finish(kh_ipa_t* st, uint64_t a0[4], uint64_t b0[4], uint64_t sg_xy[8
     KH_REQUIRE(si >= 0, "all %d MSM pipeline slots hold an un-waited job (kh_msm_wait first)", MSM_SLOTS);
     MsmSlot& S = C.slot[si];
     KH_HIP(hipStreamWaitEvent(S.stream, st->ev, 0));
+    int rc;
+    if (st->pending) {                                     // the last round's fold (vectors of length 2 -> 1, the full challenge tensor)
+        const int p0 = st->pp, q0 = p0 ^ 1;
+        if ((rc = ipa_round_fold(S.stream, st->field, st->a[p0].as<uint64_t>(), st->b[p0].as<uint64_t>(), st->coef[p0].as<uint64_t>(), 2 * st->cur, st->ncoef / 2,
+                                 st->u_p, st->ui_p, st->a[q0].as<uint64_t>(), st->b[q0].as<uint64_t>(), st->coef[q0].as<uint64_t>()))) return rc;
+        st->pp = q0; st->pending = false;
+    }
     const int p = st->pp;
     KH_HIP(hipMemcpyAsync(a0, st->a[p].p, 32, hipMemcpyDeviceToHost, S.stream));
     KH_HIP(hipMemcpyAsync(b0, st->b[p].p, 32, hipMemcpyDeviceToHost, S.stream));
     kh_srs_t* srs = st->srs;
     MsmBasis bs; bs.pts = srs->g.p; bs.inf = nullptr; bs.n = srs->n; bs.stride = srs->g_stride; bs.precomp_c = srs->g_precomp_c;
-    int rc;
     if ((rc = msm_enqueue(C, S, st->curve, bs, 0, st->coef[p].as<uint64_t>(), st->n, 1, 1))) return rc;   // sg = <coef, G>
     return wait_then_finish(lk, C, S, sg_xy, sg_inf);
 }

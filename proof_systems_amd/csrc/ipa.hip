@@ -202,6 +202,125 @@ __global__ void k_ipa_fold(const u64* __restrict__ a, const u64* __restrict__ b,
     }
 }
 
+// One launch per round: the PENDING fold of the previous round (a' = a_lo + u^-1 a_hi, b' = b_lo + u b_hi, coef' = coef (x) (1, u);
+// kh_ipa_round_fold only records u), the two inner products of this round over the folded vectors, and the expanded scalars.
+// Thread t expands point t (recomputing the folded a' it needs: a product, not a dependency on another thread's store); threads
+// below m = N'/2 also materialise a', b' at i and i + m and accumulate <a'_hi, b'_lo> / <a'_lo, b'_hi>; the block sums go to
+// `partial`, and the LAST block to finish (agent-scope counter) adds them up and fills the H / U scalar slots of both sides.
+// Replaces k_ipa_fold + k_ipa_ip + k_ipa_ip_fin + k_ipa_expand: four dependent launches (~25 us of an opening round) -> one.
+template <class F>
+__global__ void __launch_bounds__(256)
+k_ipa_step(const u64* __restrict__ a, const u64* __restrict__ b, const u64* __restrict__ coef, size_t n, size_t cur2, unsigned logN2, size_t ncoef,
+           int has_fold, Fe4 u4, Fe4 ui4, u64* __restrict__ a2, u64* __restrict__ b2, u64* __restrict__ coef2,
+           Fe4 rand_l, Fe4 rand_r, u64* __restrict__ sc, u64* __restrict__ partial, unsigned* __restrict__ counter) {
+    __shared__ u32 sh[8 * 8];
+    __shared__ unsigned is_last;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t m = cur2 / 2;
+    const Fe<F> u = Fe<F>::load(u4.l), ui = Fe<F>::load(ui4.l);
+    auto a_at = [&](size_t x) { Fe<F> v = Fe<F>::load(a + 4 * x); if (has_fold) v = add<F>(v, mul<F>(ui, Fe<F>::load(a + 4 * (x + cur2)))); return v; };
+    auto b_at = [&](size_t x) { Fe<F> v = Fe<F>::load(b + 4 * x); if (has_fold) v = add<F>(v, mul<F>(u, Fe<F>::load(b + 4 * (x + cur2)))); return v; };
+    if (t < n) {                                           // expand (ipa.rs:943-961 over the original basis, see above)
+        const size_t r = t & (cur2 - 1), q = t >> logN2;
+        const bool lo = r < m;
+        Fe<F> c = Fe<F>::load(coef + 4 * (has_fold ? q >> 1 : q));
+        if (has_fold && (q & 1)) c = mul<F>(c, u);
+        const Fe<F> v = mul<F>(a_at(lo ? r + m : r - m), c), z = Fe<F>::zero();
+        (lo ? v : z).store(sc + 4 * t);
+        (lo ? z : v).store(sc + 4 * ((n + 2) + t));
+    }
+    if (has_fold && t < 2 * ncoef) {                       // coef' = coef (x) (1, u)
+        Fe<F> c = Fe<F>::load(coef + 4 * (t >> 1));
+        if (t & 1) c = mul<F>(c, u);
+        c.store(coef2 + 4 * t);
+    }
+    Fe<F> accL = Fe<F>::zero(), accR = Fe<F>::zero();
+    const size_t nblk_ip = (m + blockDim.x - 1) / blockDim.x;
+    if (t < m) {
+        const Fe<F> alo = a_at(t), ahi = a_at(t + m), blo = b_at(t), bhi = b_at(t + m);
+        if (has_fold) { alo.store(a2 + 4 * t); ahi.store(a2 + 4 * (t + m)); blo.store(b2 + 4 * t); bhi.store(b2 + 4 * (t + m)); }
+        accL = mul<F>(ahi, blo); accR = mul<F>(alo, bhi);
+    }
+    auto wave_sum = [](Fe<F> v) {                          // sum over the 64 lanes of a wave (valid in lane 0)
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            Fe<F> o;
+#pragma unroll
+            for (int k = 0; k < 8; k++) o.v[k] = __shfl_down(v.v[k], d, 64);
+            v = add<F>(v, o);
+        }
+        return v;
+    };
+    const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (blockIdx.x < nblk_ip) {                            // block sums of the two inner products: wave shuffles, then four values through LDS
+        accL = wave_sum(accL); accR = wave_sum(accR);
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) { sh[(wave * 2) * 8 + k] = accL.v[k]; sh[(wave * 2 + 1) * 8 + k] = accR.v[k]; }
+        }
+        __syncthreads();
+        if (threadIdx.x < 2) {                             // thread = side
+            Fe<F> acc = Fe<F>::zero();
+            for (u32 w = 0; w < 4; w++) {
+                Fe<F> o;
+#pragma unroll
+                for (int k = 0; k < 8; k++) o.v[k] = sh[(w * 2 + threadIdx.x) * 8 + k];
+                acc = add<F>(acc, o);
+            }
+            acc.store(partial + 4 * ((size_t)threadIdx.x * nblk_ip + blockIdx.x));
+        }
+    }
+    // last block out: the final sums and the two extra scalar slots of each side (H: the blinder, U: the inner product)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (blockIdx.x < nblk_ip) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");      // only these blocks publish something the last block reads
+        is_last = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!is_last) return;
+    {
+        const u32 side = threadIdx.x >> 7, x = threadIdx.x & 127u;        // waves 0-1: L, waves 2-3: R
+        Fe<F> acc = Fe<F>::zero();
+        for (size_t k = x; k < nblk_ip; k += 128) {
+            const u64* src = partial + 4 * ((size_t)side * nblk_ip + k);
+            u64 l[4];
+#pragma unroll
+            for (int w = 0; w < 4; w++) l[w] = __hip_atomic_load(src + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // written by other blocks
+            acc = add<F>(acc, Fe<F>::load(l));
+        }
+        acc = wave_sum(acc);
+        __syncthreads();
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) sh[wave * 8 + k] = acc.v[k];
+        }
+        __syncthreads();
+        if (threadIdx.x < 2) {
+            Fe<F> o, r2;
+#pragma unroll
+            for (int k = 0; k < 8; k++) { o.v[k] = sh[(2 * threadIdx.x) * 8 + k]; r2.v[k] = sh[(2 * threadIdx.x + 1) * 8 + k]; }
+            o = add<F>(o, r2);
+            u64* dst = sc + 4 * ((size_t)threadIdx.x * (n + 2) + n);
+            const Fe4& r = threadIdx.x == 0 ? rand_l : rand_r;
+            dst[0] = r.l[0]; dst[1] = r.l[1]; dst[2] = r.l[2]; dst[3] = r.l[3];
+            o.store(dst + 4);
+        }
+    }
+    if (threadIdx.x == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // re-armed for the next round
+}
+// cur2 = the vector length AFTER the pending fold (= cur if none); a2 / b2 / coef2 receive the folded vectors
+int ipa_round_step(hipStream_t s, int field, int has_fold, const uint64_t* a, const uint64_t* b, const uint64_t* coef, size_t n, size_t cur2, size_t ncoef,
+                   const uint64_t u[4], const uint64_t uinv[4], uint64_t* a2, uint64_t* b2, uint64_t* coef2,
+                   const uint64_t rand_l[4], const uint64_t rand_r[4], uint64_t* sc, uint64_t* partial, unsigned* counter) {
+    unsigned logN2 = 0; while (((size_t)1 << logN2) < cur2) logN2++;
+    Fe4 rl, rr, u4, ui4; memcpy(rl.l, rand_l, 32); memcpy(rr.l, rand_r, 32); memcpy(u4.l, u, 32); memcpy(ui4.l, uinv, 32);
+    dim3 g((unsigned)((n + 255) / 256));
+    if (field == KH_FIELD_FP) hipLaunchKernelGGL((k_ipa_step<FpParams>), g, dim3(256), 0, s, a, b, coef, n, cur2, logN2, ncoef, has_fold, u4, ui4, a2, b2, coef2, rl, rr, sc, partial, counter);
+    else hipLaunchKernelGGL((k_ipa_step<FqParams>), g, dim3(256), 0, s, a, b, coef, n, cur2, logN2, ncoef, has_fold, u4, ui4, a2, b2, coef2, rl, rr, sc, partial, counter);
+    KH_HIP(hipGetLastError());
+    return KH_OK;
+}
+
 int ipa_round_prepare(hipStream_t s, int field, const uint64_t* a, const uint64_t* b, const uint64_t* coef, size_t n, size_t Nj,
                       const uint64_t rand_l[4], const uint64_t rand_r[4], uint64_t* sc, uint64_t* partial) {
     const size_t m = Nj / 2;

@@ -1190,6 +1190,7 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
                        C.ws_toff.as<u32>(), C.ws_chunks.as<uint8_t>(), C.ws_buckets.as<uint8_t>(), C.ws_biglist.as<u32>(), bigcap);
     C.timer.mark("bucket_sum", s);
     // 7 reduce
+    bool direct_out = false;                              // latency path: the last kernel writes the (768-byte) result to host memory itself -- no copy node
     if (planes) {
         // few groups: 256 threads per marginal (4 sequential additions + the tree: shortest chain); batches: one wave
         // per marginal (16 + 6 additions deep, but 2.2x less issue work -- batches are throughput-bound)
@@ -1197,7 +1198,8 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
         static const size_t quad_maxg = getenv("KH_QUAD_MAXG") ? (size_t)atol(getenv("KH_QUAD_MAXG")) : 4;
         if (ngroups <= quad_maxg && quad_threads > 0) {    // latency path: lane-cooperative additions (coop.cuh)
             hipLaunchKernelGGL((k_marginals_q<BF>), dim3(32, 3, (unsigned)ngroups), dim3(quad_threads), 0, s, C.ws_buckets.as<uint8_t>(), mg, C.ws_seg.as<uint8_t>());
-            hipLaunchKernelGGL((k_marginal_fin_q<BF>), dim3(3, (unsigned)ngroups), dim3(128), 0, s, C.ws_seg.as<uint8_t>(), mg, C.ws_out.as<uint8_t>());
+            hipLaunchKernelGGL((k_marginal_fin_q<BF>), dim3(3, (unsigned)ngroups), dim3(128), 0, s, C.ws_seg.as<uint8_t>(), mg, (uint8_t*)C.pinned);   // straight into the pinned host staging
+            direct_out = true;
         } else {
         hipLaunchKernelGGL((k_marginals<BF>), dim3(32, 3, (unsigned)ngroups), dim3(ngroups <= 4 ? 256 : 64), 0, s, C.ws_buckets.as<uint8_t>(), mg, C.ws_seg.as<uint8_t>());
         hipLaunchKernelGGL((k_marginal_fin<BF>), dim3(3, (unsigned)ngroups), dim3(64), 0, s, C.ws_seg.as<uint8_t>(), mg, C.ws_out.as<uint8_t>());
@@ -1214,7 +1216,7 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
     C.timer.mark("reduce", s);
     KH_HIP(hipGetLastError());
     // group sums -> pinned host staging
-    KH_HIP(hipMemcpyAsync(C.pinned, C.ws_out.p, nout * 128, hipMemcpyDeviceToHost, s));
+    if (!direct_out) KH_HIP(hipMemcpyAsync(C.pinned, C.ws_out.p, nout * 128, hipMemcpyDeviceToHost, s));
     if (gcap.active) {
         hipGraph_t g = nullptr;
         gcap.active = false;
@@ -1282,7 +1284,7 @@ int msm_finish(Context& C, MsmSlot& S, uint64_t* out_xy, uint8_t* out_inf) {
             }
         }
     };
-    if ((!S.precomp || S.planes) && S.k >= 2) {                     // split the Horner folds with the helper thread
+    if ((!S.precomp && S.k >= 2) || (S.planes && S.k >= 16)) {      // split the Horner folds with the helper thread (a hand-over costs ~10 us: not for a few doublings)
         const size_t half = S.k / 2, kk = S.k;
         HostHelper& hh = host_helper(C.device);
         hh.run([finish_one, half, kk] { for (size_t j = half; j < kk; j++) finish_one(j); });

@@ -35,6 +35,9 @@ void ntt_trim(Context& C);
 int ipa_fold_scalars(Context& C, int field, const uint64_t* lo, const uint64_t* hi, const uint64_t u[4], size_t n, uint64_t* out);
 int ipa_inner_product(Context& C, int field, const uint64_t* a, const uint64_t* b, size_t n, uint64_t out[4]);
 int ipa_fold_points_endo(Context& C, int curve, const uint64_t* g_lo, const uint64_t* g_hi, const uint64_t chal[2], size_t n, uint64_t* out_xy, uint8_t* out_inf);
+int ipa_round_step(hipStream_t s, int field, int has_fold, const uint64_t* a, const uint64_t* b, const uint64_t* coef, size_t n, size_t cur2, size_t ncoef,
+                   const uint64_t u[4], const uint64_t uinv[4], uint64_t* a2, uint64_t* b2, uint64_t* coef2,
+                   const uint64_t rand_l[4], const uint64_t rand_r[4], uint64_t* sc, uint64_t* partial, unsigned* counter);
 int ipa_round_prepare(hipStream_t s, int field, const uint64_t* a, const uint64_t* b, const uint64_t* coef, size_t n, size_t Nj,
                       const uint64_t rand_l[4], const uint64_t rand_r[4], uint64_t* sc, uint64_t* partial);
 int ipa_round_fold(hipStream_t s, int field, const uint64_t* a, const uint64_t* b, const uint64_t* coef, size_t Nj, size_t ncoef,

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Kernel timeline of ONE opening round from a rocprofv3 --kernel-trace database: finds the last k_ipa_expand launch but 3
+"""Kernel timeline of ONE opening round from a rocprofv3 --kernel-trace database: finds the last k_ipa_step launch but 3
 and prints every kernel until the next one (start offset, duration, gap to the previous kernel's end).
 Usage: tools/trace_round.py results.db"""
 import sqlite3, sys
@@ -7,7 +7,7 @@ db = sqlite3.connect(sys.argv[1])
 cols = [r[1] for r in db.execute("pragma table_info(kernels)")]
 namecol = "name" if "name" in cols else [c for c in cols if "name" in c][0]
 rows = db.execute(f"select {namecol}, start, end from kernels order by start").fetchall()
-marks = [i for i, r in enumerate(rows) if "k_ipa_expand" in r[0]]
+marks = [i for i, r in enumerate(rows) if "k_ipa_step" in r[0]]
 if len(marks) < 5:
     print("no opening rounds in the trace"); sys.exit(0)
 a, b = marks[-4], marks[-3]
