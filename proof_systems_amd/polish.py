@@ -115,6 +115,7 @@ class Env:
     def witness_next(self, i): return Node(TOK_CELL, arg=2 * (self.w0 + i) + 1)
     def coeff(self, i): return Node(TOK_CELL, arg=2 * (self.c0 + i))
     def column(self, col): return Node(TOK_CELL, arg=2 * col)
+    def column_next(self, col): return Node(TOK_CELL, arg=2 * col + 1)
     def mds(self, r, c): return self.const(self._mds[r][c])
     def endo_coefficient(self): return self.const(self._endo)
     def one(self): return self.const(1)
@@ -298,3 +299,122 @@ def gate_program(name: str, p: int, alpha: int, selector_col: int = 30, mds=None
     expr = combined_constraints(env, selector_col, cs, alpha)
     toks = compile_tokens(env, expr)
     return toks, list(env.consts)
+
+
+# ---------------------------------------------------------------------------------------------------------------- lookups
+# The lookup argument's constraints (kimchi/src/circuits/lookup/constraints.rs:378-673, generate_feature_flags = false) as a
+# token program.  The pattern data (which cells of a row are looked up, into which table) is the reference's
+# LookupPattern::lookups (lookups.rs:417-487); it is protocol data, restated here so that the product does not import oracle/.
+LOOKUP_XOR_TABLE_ID, LOOKUP_RANGE_CHECK_TABLE_ID = 0, 1
+LOOKUP_PATTERNS = {                      # name -> list of (table id: int | ("wit", column), [witness columns of the entry])
+    "Xor": [(LOOKUP_XOR_TABLE_ID, [3 + i, 7 + i, 11 + i]) for i in range(4)],
+    "Lookup": [(("wit", 0), [2 * i + 1, 2 * i + 2]) for i in range(3)],
+    "RangeCheck": [(LOOKUP_RANGE_CHECK_TABLE_ID, [c]) for c in range(3, 7)],
+    "ForeignFieldMul": [(LOOKUP_RANGE_CHECK_TABLE_ID, [c]) for c in range(7, 11)],
+}
+LOOKUP_PATTERN_ORDER = ["Xor", "Lookup", "RangeCheck", "ForeignFieldMul"]
+
+
+def lookup_max_per_row(patterns):
+    return max(len(LOOKUP_PATTERNS[q]) for q in patterns)
+
+
+def lookup_max_joint_size(patterns):
+    return max(len(e) for q in patterns for _, e in LOOKUP_PATTERNS[q])
+
+
+def _joint_value(env: Env, joint_combiner: Node, table_id_combiner: Node, cells, table_id):
+    """combine_table_entry (tables/mod.rs:147-162): Horner in the joint combiner from the last column + table_id_combiner * id."""
+    acc = None
+    for c in reversed(cells):
+        acc = c if acc is None else joint_combiner * acc + c
+    tid = env.witness_curr(table_id[1]) if isinstance(table_id, tuple) else env.const(table_id)
+    return acc + table_id_combiner * tid if acc is not None else table_id_combiner * tid
+
+
+def lookup_constraints(env: Env, patterns, cols, joint_combiner: int, table_id_combiner: int, beta: int, gamma: int, dummy_value: int = 0):
+    """The 3 + max_per_row (+ zero padding to 7) lookup constraints in the reference's order.  `cols`: column numbers of
+    'sorted' (list of max_per_row + 1), 'aggreg', 'table', 'selector' (dict pattern -> column), and of the three row-set
+    atoms 'vanish' (VanishesOnZeroKnowledgeAndPreviousRows), 'l0' (UnnormalizedLagrangeBasis(0)), 'lfinal'
+    (UnnormalizedLagrangeBasis(-zk_rows - 1)), which the caller provides as evaluation columns."""
+    patterns = [q for q in LOOKUP_PATTERN_ORDER if q in patterns]
+    mpr = lookup_max_per_row(patterns)
+    p = env.p
+    jc, tic = env.const(joint_combiner), env.const(table_id_combiner)
+    g, b = env.const(gamma), env.const(beta)
+    gb1 = env.const(gamma * (1 + beta) % p)
+    b1m = pow(1 + beta, mpr, p)
+
+    def f_term(spec):                    # (1 + beta)^max_per_row * (gamma + dummy)^padding * prod (gamma + joint value)
+        acc = env.const(pow((gamma + dummy_value) % p, mpr - len(spec), p) * b1m % p)
+        for tid, entry in spec:
+            acc = acc * (g + _joint_value(env, jc, tic, [env.witness_curr(c) for c in entry], tid))
+        return acc
+
+    indicator = None
+    for q in patterns:
+        sel = env.column(cols["selector"][q])
+        indicator = sel if indicator is None else indicator + sel
+    f_chunk = (env.one() - indicator) * f_term([])
+    for q in patterns:
+        f_chunk = f_chunk + env.column(cols["selector"][q]) * f_term(LOOKUP_PATTERNS[q])
+    t_chunk = gb1 + env.column(cols["table"]) + b * env.column_next(cols["table"])
+    numerator = f_chunk * t_chunk
+    denominator = None
+    for i in range(mpr + 1):
+        c, nx = env.column(cols["sorted"][i]), env.column_next(cols["sorted"][i])
+        term = (gb1 + c + b * nx) if i % 2 == 0 else (gb1 + nx + b * c)
+        denominator = term if denominator is None else denominator * term
+    aggreg_eq = env.column_next(cols["aggreg"]) * denominator - env.column(cols["aggreg"]) * numerator
+    res = [env.column(cols["vanish"]) * aggreg_eq,
+           env.column(cols["l0"]) * (env.column(cols["aggreg"]) - env.one()),
+           env.column(cols["lfinal"]) * (env.column(cols["aggreg"]) - env.one())]
+    for i in range(mpr):
+        basis = env.column(cols["lfinal"] if i % 2 == 0 else cols["l0"])
+        res.append(basis * (env.column(cols["sorted"][i]) - env.column(cols["sorted"][i + 1])))
+    return res
+
+
+def lookup_program(p: int, patterns, cols, joint_combiner: int, table_id_combiner: int, beta: int, gamma: int, alpha: int, alpha0: int = 0,
+                   dummy_value: int = 0, w0: int = 0):
+    """(tokens, constants) of sum_i alpha^(alpha0 + i) * lookup constraint_i (prover.rs:874-903)."""
+    env = Env(p, w0=w0)
+    cs = lookup_constraints(env, patterns, cols, joint_combiner, table_id_combiner, beta, gamma, dummy_value)
+    return compile_tokens(env, combined_constraints(env, None, cs, alpha, alpha0)), list(env.consts)
+
+
+def lookup_aggregation_programs(p: int, patterns, cols, joint_combiner: int, table_id_combiner: int, beta: int, gamma: int, dummy_value: int = 0, w0: int = 0):
+    """Two token programs for the rows of the aggregation (constraints.rs:233-338): the numerator f_chunk * t_chunk and the
+    denominator s_chunk of row i (cells of rows i and i + 1); aggreg[i + 1] = aggreg[i] * numerator_i / denominator_i."""
+    patterns = [q for q in LOOKUP_PATTERN_ORDER if q in patterns]
+    mpr = lookup_max_per_row(patterns)
+    out = []
+    for which in ("num", "den"):
+        env = Env(p, w0=w0)
+        jc, tic = env.const(joint_combiner), env.const(table_id_combiner)
+        g, b = env.const(gamma), env.const(beta)
+        gb1 = env.const(gamma * (1 + beta) % p)
+        if which == "num":
+            b1m = pow(1 + beta, mpr, p)
+
+            def f_term(spec):
+                acc = env.const(pow((gamma + dummy_value) % p, mpr - len(spec), p) * b1m % p)
+                for tid, entry in spec:
+                    acc = acc * (g + _joint_value(env, jc, tic, [env.witness_curr(c) for c in entry], tid))
+                return acc
+            indicator = None
+            for q in patterns:
+                sel = env.column(cols["selector"][q])
+                indicator = sel if indicator is None else indicator + sel
+            expr = (env.one() - indicator) * f_term([])
+            for q in patterns:
+                expr = expr + env.column(cols["selector"][q]) * f_term(LOOKUP_PATTERNS[q])
+            expr = expr * (gb1 + env.column(cols["table"]) + b * env.column_next(cols["table"]))
+        else:
+            expr = None
+            for i in range(mpr + 1):
+                c, nx = env.column(cols["sorted"][i]), env.column_next(cols["sorted"][i])
+                term = (gb1 + c + b * nx) if i % 2 == 0 else (gb1 + nx + b * c)
+                expr = term if expr is None else expr * term
+        out.append((compile_tokens(env, expr), list(env.consts)))
+    return out
