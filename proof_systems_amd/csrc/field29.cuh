@@ -145,17 +145,36 @@ struct Acc29 {                 // XYZZ accumulator in lazy R'-form: x < 6 p, y <
     Fe29<F> x, y, zz, zzz;
 };
 
+// x (limbs 0..7 normalised) == k p as integers?  Runs only behind the one-limb filters below (p = 1 mod 2^29: k p has low limb k),
+// i.e. about once per 2^25 additions: without it every such coincidence abandoned the task, and the exact kernel then spent ~0.25 ms of
+// one thread's time on it -- in every other 2^20-point MSM (16.7 M additions).
+template <class F>
+__device__ __forceinline__ bool is_kp29(const Fe29<F>& x, u32 k) {
+    typedef typename C29<F>::T K;
+    const u32 pl[9] = {1u, K::P1, K::P2, K::P3, K::P4, 0u, 0u, 0u, 1u << 22};
+    u64 carry = 0;
+    bool same = true;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        const u64 t = (u64)k * pl[i] + carry;
+        const u32 limb = i < 8 ? (u32)(t & MASK29) : (u32)t;
+        carry = t >> 29;
+        same = same && (limb == x.v[i]);
+    }
+    return same;
+}
+
 // acc += (px, py) with px = 32 X, py = 32 Y (pack29<F, 5> of the canonical affine coordinates; the sign already applied).
 // Returns false -- acc untouched -- when an exceptional case of the group law cannot be excluded (acc possibly the
 // identity, the points possibly equal or opposite); see the header.  Bounds: tools/gen_field29_asm.py (Madd29Model).
 template <class F>
 __device__ __forceinline__ bool madd29(Acc29<F>& a, const Fe29<F>& px, const Fe29<F>& py) {
     typedef typename C29<F>::T K;
-    if (a.zz.v[0] <= 1u) return false;                     // zz in {0, p}: the identity
+    if (__builtin_expect(a.zz.v[0] <= 1u, 0) && is_kp29<F>(a.zz, a.zz.v[0])) return false;        // zz in {0, p}: the identity
     const Fe29<F> U2 = mul29<F>(px, a.zz), S2 = mul29<F>(py, a.zzz);
     Fe29<F> P, R;
     KH29_SUBN(P, U2, a.x, K::s71)
-    if (P.v[0] <= 8u) return false;                        // P = k p, k <= 8: same x
+    if (__builtin_expect(P.v[0] <= 8u, 0) && is_kp29<F>(P, P.v[0])) return false;                  // P = k p, k <= 8: same x
     KH29_SUBN(R, S2, a.y, K::s51)
     const Fe29<F> PP = sqr29<F>(P);
     const Fe29<F> PPP = mul29<F>(P, PP), Q = mul29<F>(a.x, PP), RR = sqr29<F>(R);

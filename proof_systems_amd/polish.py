@@ -304,7 +304,7 @@ def gate_program(name: str, p: int, alpha: int, selector_col: int = 30, mds=None
 # ---------------------------------------------------------------------------------------------------------------- lookups
 # The lookup argument's constraints (kimchi/src/circuits/lookup/constraints.rs:378-673, generate_feature_flags = false) as a
 # token program.  The pattern data (which cells of a row are looked up, into which table) is the reference's
-# LookupPattern::lookups (lookups.rs:417-487); it is protocol data, restated here so that the product does not import oracle/.
+# LookupPattern::lookups (lookups.rs:417-487); it is protocol data, restated here (the product carries its own copy of the protocol data).
 LOOKUP_XOR_TABLE_ID, LOOKUP_RANGE_CHECK_TABLE_ID = 0, 1
 LOOKUP_PATTERNS = {                      # name -> list of (table id: int | ("wit", column), [witness columns of the entry])
     "Xor": [(LOOKUP_XOR_TABLE_ID, [3 + i, 7 + i, 11 + i]) for i in range(4)],
