@@ -188,7 +188,7 @@ int kh_trim(void) {
         MsmSlot& S = C.slot[i];
         if (S.gexec) { (void)hipGraphExecDestroy(S.gexec); S.gexec = nullptr; S.gkey = 0; S.gseen = 0; }
         for (DevBuf* b : {&S.ws_scalars, &S.ws_digits, &S.ws_hist, &S.ws_cnt, &S.ws_off, &S.ws_ntask, &S.ws_toff, &S.ws_entries, &S.ws_partial, &S.ws_buckets,
-                          &S.ws_seg, &S.ws_out, &S.ws_scan_tmp, &S.ws_biglist, &S.ws_points, &S.ws_order, &S.ws_chunks, &S.ws_handed}) b->release();
+                          &S.ws_seg, &S.ws_out, &S.ws_scan_tmp, &S.ws_biglist, &S.ws_points, &S.ws_order, &S.ws_chunks, &S.ws_handed, &S.ws_sync, &S.ws_mid}) b->release();
     }
     C.ws_ntt_a.release(); C.ws_ntt_b.release();
     C.trim_scratch();

@@ -92,7 +92,7 @@ struct MsmSlot {
     hipStream_t stream = nullptr;
     PhaseTimer timer;
     DevBuf ws_scalars, ws_digits, ws_hist, ws_cnt, ws_off, ws_ntask, ws_toff, ws_entries, ws_partial,
-        ws_buckets, ws_seg, ws_out, ws_scan_tmp, ws_biglist, ws_points, ws_order, ws_chunks, ws_handed, ws_sync;
+        ws_buckets, ws_seg, ws_out, ws_scan_tmp, ws_biglist, ws_points, ws_order, ws_chunks, ws_handed, ws_sync, ws_mid;
     void* pinned = nullptr; size_t pinned_cap = 0;      // host staging of the group sums (XYZZ)
     hipEvent_t done = nullptr;
     // pending job (set by enqueue, consumed by finish)

@@ -223,6 +223,106 @@ __global__ void k_scatter(const int32_t* __restrict__ digits, SortGeom g, const 
         }
     }
 }
+// ------------------------------------------------------------------------------------ partitioned sort (large jobs over the tables)
+// k_scatter writes each 4-byte entry to a random place in a 67 MB array: every store is its own partial cache line (PMC: 538 MB of
+// write traffic for 67 MB of payload at 2^20 points, and the slowest kernel of the sort).  For the 2^15 buckets of the window
+// tables the sort runs in two passes instead, each with few enough open output streams per block that a line is completed in
+// the L2 before it is evicted:
+//   pass A  by the top 8 bits of the bucket (256 partitions): k_part_hist counts per (partition, block), one scan gives every
+//           block its output run inside every partition, k_part_scatter writes 32-bit records
+//           (7 low bucket bits | sign | window | point) through 256 LDS cursors -- 256 sequential streams per block;
+//   pass B  one block per partition (~64 K records, read twice from the L2): histogram of its 128 buckets, off[], then the
+//           final entries through 128 LDS cursors into a 256 KB window.
+// No per-slice histogram matrix, no key-total pass, no global scan over the keys.  Needs n <= 2^20 and W <= 16 for the record.
+static constexpr int PART_T = 1024, PART_P = 256, PART_LOW = 7;
+__global__ void __launch_bounds__(PART_T)
+k_part_hist(const int32_t* __restrict__ digits, u32 tot_e, u32 nblk, u32* __restrict__ PH) {
+    KH_HIGH_PRIO();
+    __shared__ u32 cnt[PART_P];
+    const u32 blk = blockIdx.x, j = blockIdx.y, tid = threadIdx.x;
+    if (tid < PART_P) cnt[tid] = 0;
+    __syncthreads();
+    const u32 e_lo = (u32)((u64)tot_e * blk / nblk), e_hi = (u32)((u64)tot_e * (blk + 1) / nblk);
+    const int32_t* d = digits + (size_t)j * tot_e;
+    for (u32 e0 = e_lo + tid; e0 < e_hi; e0 += 8 * PART_T) {
+        int32_t v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const u32 e = e0 + u * PART_T; v[u] = d[e < e_hi ? e : e_hi - 1]; if (e >= e_hi) v[u] = 0; }
+#pragma unroll
+        for (int u = 0; u < 8; u++) if (v[u]) atomicAdd(&cnt[((u32)(v[u] < 0 ? -v[u] : v[u]) - 1u) >> PART_LOW], 1u);
+    }
+    __syncthreads();
+    if (tid < PART_P) PH[((size_t)j * PART_P + tid) * nblk + blk] = cnt[tid];
+    if (blk == 0 && j == 0 && tid == 0) PH[(size_t)gridDim.y * PART_P * nblk] = 0;      // the scan runs one element further: the total
+}
+__global__ void __launch_bounds__(PART_T)
+k_part_scatter(const int32_t* __restrict__ digits, u32 tot_e, u32 n, u32 nblk, const u32* __restrict__ PO, u32* __restrict__ mid) {
+    KH_HIGH_PRIO();
+    __shared__ u32 cur[PART_P];
+    const u32 blk = blockIdx.x, j = blockIdx.y, tid = threadIdx.x;
+    if (tid < PART_P) cur[tid] = PO[((size_t)j * PART_P + tid) * nblk + blk];
+    __syncthreads();
+    const u32 e_lo = (u32)((u64)tot_e * blk / nblk), e_hi = (u32)((u64)tot_e * (blk + 1) / nblk);
+    const int32_t* d = digits + (size_t)j * tot_e;
+    u32 w = (e_lo + tid) / n, i = (e_lo + tid) - w * n;
+    for (u32 e0 = e_lo + tid; e0 < e_hi; e0 += 8 * PART_T) {
+        int32_t v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const u32 e = e0 + u * PART_T; v[u] = d[e < e_hi ? e : e_hi - 1]; if (e >= e_hi) v[u] = 0; }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            if (v[u]) {
+                const u32 b = (u32)(v[u] < 0 ? -v[u] : v[u]) - 1u;
+                const u32 pos = atomicAdd(&cur[b >> PART_LOW], 1u);
+                mid[pos] = ((b & ((1u << PART_LOW) - 1u)) << 25) | (v[u] < 0 ? 1u << 24 : 0u) | (w << 20) | i;
+            }
+            i += PART_T;
+            while (i >= n) { i -= n; w++; }
+        }
+    }
+}
+__global__ void __launch_bounds__(PART_T)
+k_part_sort(const u32* __restrict__ mid, const u32* __restrict__ PO, u32 nblk, u32 nb, size_t pt_stride, size_t pt_offset, size_t pt_batch,
+            u32 last_group, u32* __restrict__ off, u32* __restrict__ entries) {
+    KH_HIGH_PRIO();
+    __shared__ u32 hist[1u << PART_LOW], cur[1u << PART_LOW];
+    const u32 pidx = blockIdx.x, j = blockIdx.y, tid = threadIdx.x;
+    const size_t q = (size_t)j * PART_P + pidx;
+    const u32 base = PO[q * nblk], end = PO[(q + 1) * nblk];          // (the scan has one element more than the matrix: the total)
+    if (tid < (1u << PART_LOW)) hist[tid] = 0;
+    __syncthreads();
+    for (u32 x0 = base + tid; x0 < end; x0 += 8 * PART_T) {
+        u32 m[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const u32 x = x0 + u * PART_T; m[u] = mid[x < end ? x : end - 1]; }
+#pragma unroll
+        for (int u = 0; u < 8; u++) if (x0 + u * PART_T < end) atomicAdd(&hist[m[u] >> 25], 1u);
+    }
+    __syncthreads();
+    if (tid < 64) {                                      // exclusive scan of the 128 counts: two per lane of one wave
+        const u32 a = hist[2 * tid], b = hist[2 * tid + 1];
+        u32 inc = a + b;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const u32 o = __shfl_up(inc, d, 64); if (tid >= (u32)d) inc += o; }
+        const u32 ex = base + inc - (a + b);
+        u32* o = off + (size_t)j * nb + (size_t)pidx * (1u << PART_LOW);
+        o[2 * tid] = ex; o[2 * tid + 1] = ex + a;
+        cur[2 * tid] = ex; cur[2 * tid + 1] = ex + a;
+        if (tid == 63 && pidx == PART_P - 1 && j == last_group) off[(size_t)(j + 1) * nb] = end;       // off[nkeys] = number of entries
+    }
+    __syncthreads();
+    const u32 pb0 = (u32)(pt_offset + (size_t)j * pt_batch);
+    for (u32 x0 = base + tid; x0 < end; x0 += 8 * PART_T) {
+        u32 m[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const u32 x = x0 + u * PART_T; m[u] = mid[x < end ? x : end - 1]; }
+#pragma unroll
+        for (int u = 0; u < 8; u++) if (x0 + u * PART_T < end) {
+            const u32 pos = atomicAdd(&cur[m[u] >> 25], 1u);
+            entries[pos] = (pb0 + (u32)(((m[u] >> 20) & 15u) * pt_stride) + (m[u] & 0xfffffu)) | ((m[u] & (1u << 24)) << 7);
+        }
+    }
+}
 // ------------------------------------------------------------------------------------ tasks
 static constexpr u32 MAX_K = 256;           // upper bound of the task length (length bins of the task ordering)
 // K (entries per task) is chosen HERE from the actual number of entries off[nkeys]: zero digits
@@ -1057,6 +1157,16 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
         const size_t tot4 = (size_t)W * n / 4, chunk4 = (tot4 + fg.bpg - 1) / fg.bpg + 1;
         if (fg.kpt > (u32)FUSED_KPT || n < 4 || ((size_t)W * n) % 4 || chunk4 > (size_t)FUSED_V * FUSED_T || fg.sub > (u32)FUSED_C * FUSED_T) fused = false;
     }
+    // large jobs over the tables: the two-pass partitioned sort (k_part_*)
+    static const bool part_off = getenv("KH_NO_PART_SORT") != nullptr;
+    const bool part = precomp && !fused && !part_off && nb == ((u32)PART_P << PART_LOW) && n <= ((size_t)1 << 20) && W <= 16 && M >= ((size_t)1 << 21);
+    const u32 part_nblk = part ? (u32)std::max<size_t>(1, std::min<size_t>(256, 512 / k)) : 0;
+    const size_t part_size = (size_t)k * PART_P * part_nblk;
+    if (part) {
+        if ((rc = C.ws_hist.reserve((part_size + 1) * sizeof(u32)))) return rc;
+        if ((rc = C.ws_cnt.reserve((part_size + 1) * sizeof(u32)))) return rc;
+        if ((rc = C.ws_mid.reserve(M * sizeof(u32)))) return rc;
+    }
     if (fused) {
         if ((rc = C.ws_hist.reserve((size_t)k * fg.bpg * nb * sizeof(u32)))) return rc;
         if (!C.ws_sync.p) {
@@ -1077,7 +1187,7 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
                                   (uint64_t)(uintptr_t)C.ws_ntask.p, (uint64_t)(uintptr_t)C.ws_toff.p, (uint64_t)(uintptr_t)C.ws_entries.p, (uint64_t)(uintptr_t)C.ws_partial.p,
                                   (uint64_t)(uintptr_t)C.ws_buckets.p, (uint64_t)(uintptr_t)C.ws_seg.p, (uint64_t)(uintptr_t)C.ws_out.p, (uint64_t)(uintptr_t)C.ws_scan_tmp.p,
                                   (uint64_t)(uintptr_t)C.ws_biglist.p, (uint64_t)(uintptr_t)C.ws_order.p, (uint64_t)(uintptr_t)C.ws_chunks.p,
-                                  (uint64_t)(uintptr_t)C.ws_handed.p, (uint64_t)(uintptr_t)C.ws_sync.p, (uint64_t)fused};
+                                  (uint64_t)(uintptr_t)C.ws_handed.p, (uint64_t)(uintptr_t)C.ws_sync.p, (uint64_t)fused, (uint64_t)(uintptr_t)C.ws_mid.p, (uint64_t)part};
         for (uint64_t v : parts) key = fnv(key, v);
         if (C.gexec && C.gkey == key) {                    // replay
             KH_HIP(hipGraphLaunch(C.gexec, s));
@@ -1115,6 +1225,17 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
                            C.ws_hist.as<u32>(), C.ws_off.as<u32>(), C.ws_toff.as<u32>(), C.ws_entries.as<u32>(), C.ws_handed.as<u32>(),
                            C.ws_biglist.as<u32>(), sy, sy + 2);
         C.timer.mark("sort", s);
+    } else if (part) {
+        const u32 tot_e = (u32)((size_t)W * n);
+        const dim3 pgrid(part_nblk, (unsigned)k);
+        hipLaunchKernelGGL(k_part_hist, pgrid, dim3(PART_T), 0, s, C.ws_digits.as<int32_t>(), tot_e, part_nblk, C.ws_hist.as<u32>());
+        C.timer.mark("histogram", s);
+        if ((rc = exclusive_scan_u32(C.ws_hist.as<u32>(), C.ws_cnt.as<u32>(), part_size + 1, C.ws_scan_tmp, s))) return rc;
+        C.timer.mark("scan", s);
+        hipLaunchKernelGGL(k_part_scatter, pgrid, dim3(PART_T), 0, s, C.ws_digits.as<int32_t>(), tot_e, (u32)n, part_nblk, C.ws_cnt.as<u32>(), C.ws_mid.as<u32>());
+        hipLaunchKernelGGL(k_part_sort, dim3(PART_P, (unsigned)k), dim3(PART_T), 0, s, C.ws_mid.as<u32>(), C.ws_cnt.as<u32>(), part_nblk, nb,
+                           tab_stride, offset, basis.batch_stride, (u32)(k - 1), C.ws_off.as<u32>(), C.ws_entries.as<u32>());
+        C.timer.mark("scatter", s);
     } else {
         // 2 histogram
         size_t lds = (size_t)nb * sizeof(u32);
@@ -1130,6 +1251,8 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
         hipLaunchKernelGGL(k_scatter, sgrid, dim3(1024), lds, s, C.ws_digits.as<int32_t>(), g, C.ws_hist.as<u32>(),
                            C.ws_off.as<u32>(), C.ws_entries.as<u32>());
         C.timer.mark("scatter", s);
+    }
+    if (!fused) {
         // tasks
         KH_HIP(hipMemsetAsync(len_hist, 0, (MAX_K + 1) * sizeof(u32), s));
         hipLaunchKernelGGL(k_ntask, dim3((unsigned)((nkeys + 1 + 255) / 256)), dim3(256), 0, s, C.ws_off.as<u32>(), nkeys, room, kmin, C.ws_ntask.as<u32>(), len_hist, C.ws_handed.as<u32>());
