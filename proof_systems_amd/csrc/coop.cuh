@@ -22,39 +22,42 @@
 
 namespace kh {
 
-// value of `v` in the lane of this quad whose role is `role` (all 64 lanes execute)
-template <class F>
-__device__ __forceinline__ Fe<F> quad_get(const Fe<F>& v, int role) {
-    const int src = ((int)(threadIdx.x & 63u) & ~3) | role;
+// Intra-quad moves are DPP quad permutes (one VALU instruction per word, no LDS round trip -- __shfl compiles to ds_bpermute_b32,
+// ~100 cycles of latency in a chain that is nothing but latency).  CTRL = quad_perm control: lane i of every quad reads lane
+// ((CTRL >> 2 i) & 3) of the same quad.
+static constexpr int QP_BCAST0 = 0x00, QP_BCAST1 = 0x55, QP_BCAST2 = 0xaa, QP_BCAST3 = 0xff, QP_XOR2 = 0x4e;     // [r,r,r,r]; [2,3,0,1]
+template <int CTRL>
+__device__ __forceinline__ u32 quad_perm(u32 v) { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false); }
+// value of `v` in the lane of this quad selected by CTRL (all 64 lanes execute)
+template <class F, int CTRL>
+__device__ __forceinline__ Fe<F> quad_get(const Fe<F>& v) {
     Fe<F> r;
 #pragma unroll
-    for (int k = 0; k < 8; k++) r.v[k] = (u32)__shfl((int)v.v[k], src, 64);
+    for (int k = 0; k < 8; k++) r.v[k] = quad_perm<CTRL>(v.v[k]);
     return r;
 }
-__device__ __forceinline__ bool quad_flag(bool f, int role) {
-    const int src = ((int)(threadIdx.x & 63u) & ~3) | role;
-    return __shfl((int)f, src, 64) != 0;
-}
+template <int CTRL>
+__device__ __forceinline__ bool quad_flag(bool f) { return quad_perm<CTRL>(f ? 1u : 0u) != 0u; }
 
 // this lane's coordinate of A + B, given its coordinate of A (a) and of B (b)
 template <class F>
 __device__ __forceinline__ Fe<F> quad_add(const Fe<F>& a, const Fe<F>& b) {
     const int role = (int)(threadIdx.x & 3u);
-    const bool a_id = quad_flag(a.is_zero(), 2), b_id = quad_flag(b.is_zero(), 2);
+    const bool a_id = quad_flag<QP_BCAST2>(a.is_zero()), b_id = quad_flag<QP_BCAST2>(b.is_zero());
     // round 1
-    const Fe<F> t1 = mul<F>(a, quad_get<F>(b, role ^ 2));
+    const Fe<F> t1 = mul<F>(a, quad_get<F, QP_XOR2>(b));
     // round 2
-    const Fe<F> d = sub<F>(quad_get<F>(t1, role ^ 2), t1);              // role0: P, role1: R (roles 2,3: unused)
+    const Fe<F> d = sub<F>(quad_get<F, QP_XOR2>(t1), t1);              // role0: P, role1: R (roles 2,3: unused)
     const bool lo = role < 2;
     const Fe<F> m2 = mul<F>(lo ? d : a, lo ? d : b);                    // PP | RR | ZZ1 ZZ2 | ZZZ1 ZZZ2
-    const bool p0 = quad_flag(d.is_zero(), 0), r0 = quad_flag(d.is_zero(), 1);
+    const bool p0 = quad_flag<QP_BCAST0>(d.is_zero()), r0 = quad_flag<QP_BCAST1>(d.is_zero());
     // round 3
-    const Fe<F> PPb = quad_get<F>(m2, 0), Pb = quad_get<F>(d, 0), U1b = quad_get<F>(t1, 0);
+    const Fe<F> PPb = quad_get<F, QP_BCAST0>(m2), Pb = quad_get<F, QP_BCAST0>(d), U1b = quad_get<F, QP_BCAST0>(t1);
     Fe<F> x3 = role == 0 ? d : (role == 1 ? U1b : (role == 2 ? m2 : Pb));
     Fe<F> y3 = role == 0 ? m2 : PPb;
     const Fe<F> m3 = mul<F>(x3, y3);                                     // PPP | Q | ZZ3 | PPP
     // round 4
-    const Fe<F> PPPb = quad_get<F>(m3, 0), RRb = quad_get<F>(m2, 1), Qb = quad_get<F>(m3, 1);
+    const Fe<F> PPPb = quad_get<F, QP_BCAST0>(m3), RRb = quad_get<F, QP_BCAST1>(m2), Qb = quad_get<F, QP_BCAST1>(m3);
     const Fe<F> m4 = mul<F>(role == 1 ? t1 : m2, role == 1 ? PPPb : m3);   // role1: S1 PPP, role3: ZZZ3 (roles 0,2: unused)
     const Fe<F> X3 = sub<F>(sub<F>(sub<F>(RRb, PPPb), Qb), Qb);            // meaningful in every lane (all inputs broadcast)
     // round 5
@@ -64,7 +67,7 @@ __device__ __forceinline__ Fe<F> quad_add(const Fe<F>& a, const Fe<F>& b) {
     const bool need_dbl = p0 && r0 && !a_id && !b_id;
     if (__ballot(need_dbl) != 0ull) {
         Xyzz<F> A;
-        A.x = quad_get<F>(a, 0); A.y = quad_get<F>(a, 1); A.zz = quad_get<F>(a, 2); A.zzz = quad_get<F>(a, 3);
+        A.x = quad_get<F, QP_BCAST0>(a); A.y = quad_get<F, QP_BCAST1>(a); A.zz = quad_get<F, QP_BCAST2>(a); A.zzz = quad_get<F, QP_BCAST3>(a);
         if (need_dbl) {
             const Xyzz<F> D = dbl<F>(A);
             res = role == 0 ? D.x : (role == 1 ? D.y : (role == 2 ? D.zz : D.zzz));

@@ -198,12 +198,16 @@ def create_proof(ix: ProverIndex, witness, rng, timings=None, check: bool = True
     # ---- witness on the device: [w 0..14 | z] in evaluation form, then in coefficient form, then on d8
     ev = khip.DevBuf(16 * NB)
     if witness_on_device is None:
-        w = np.zeros((COLUMNS, n, 4), dtype=np.uint64)
+        # straight from the caller's columns (no padded host copy: that staging was 1.7 of this phase's 2.4 ms): zero the device
+        # buffer, upload each column's rows, then the three zero-knowledge rows per column (prover.rs:254-286)
         wit = np.asarray(witness, dtype=np.uint64).reshape(COLUMNS, -1, 4)
         assert wit.shape[1] + ZK_ROWS <= n, "NoRoomForZkInWitness"
-        w[:, :wit.shape[1]] = wit
-        w[:, n - ZK_ROWS:] = F.limbs_many([F.rand(rng) for _ in range(COLUMNS * ZK_ROWS)]).reshape(COLUMNS, ZK_ROWS, 4)
-        ev.upload_at(0, w)
+        if wit.shape[1] + ZK_ROWS < n:
+            ev.zero()
+        zk = F.limbs_many([F.rand(rng) for _ in range(COLUMNS * ZK_ROWS)]).reshape(COLUMNS, ZK_ROWS, 4)
+        for c in range(COLUMNS):
+            ev.upload_at(c * NB, wit[c])
+            ev.upload_at(c * NB + (n - ZK_ROWS) * 32, zk[c])
     else:
         khip.dev_copy(ev.ptr, witness_on_device.ptr, COLUMNS * NB)
     mark("witness_upload")
