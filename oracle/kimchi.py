@@ -100,6 +100,31 @@ def verifier_index_digest(curve: P.Curve, vix) -> int:
 
 
 # ---------------------------------------------------------------------------------------------------- verifier
+def public_commitment(curve: P.Curve, h, lagrange_commitments, public: Sequence[int]):
+    """verifier.rs:834-858: the commitment to the (negated) public-input polynomial over the Lagrange basis, masked with the
+    blinder 1; `lagrange_commitments[i]` = the commitment to L_i (one chunk).  Empty public input: the blinding commitment."""
+    if not public:
+        return [h]
+    F = curve.scalar
+    acc = None
+    for L, x in zip(lagrange_commitments, public):
+        acc = curve.add(acc, curve.mul(L, (-x) % F.p))
+    return [curve.add(acc, h)]
+
+
+def public_evaluations(F: P.Field, n: int, omega: int, public: Sequence[int], zeta: int):
+    """verifier.rs:336-386: (p(zeta), p(zeta omega)) of the negated public-input polynomial -sum_i pub_i L_i, from the inputs."""
+    out = []
+    for x in (zeta, zeta * omega % F.p):
+        zh = (pow(x, n, F.p) - 1) % F.p
+        acc = 0
+        for i, v in enumerate(public):
+            wi = pow(omega, i, F.p)
+            acc = (acc - v * wi % F.p * F.inv((x - wi) % F.p)) % F.p
+        out.append(acc * zh % F.p * F.inv(n % F.p) % F.p)
+    return tuple(out)
+
+
 def generic_constant_term(F: P.Field, ev, alpha: int) -> int:
     """index(Generic) * (alpha^0 c1 + alpha^1 c2) at zeta from the proof's evaluations (the only non-zero part of
     linearization.constant_term for a circuit whose other selectors are the zero polynomial)."""
@@ -107,6 +132,28 @@ def generic_constant_term(F: P.Field, ev, alpha: int) -> int:
     c1 = (co[0] * w[0] + co[1] * w[1] + co[2] * w[2] + co[3] * w[0] * w[1] + co[4]) % F.p
     c2 = (co[5] * w[3] + co[6] * w[4] + co[7] * w[5] + co[8] * w[3] * w[4] + co[9]) % F.p
     return ev["generic_selector"][0] * (c1 + alpha * c2) % F.p
+
+
+GATE_SELECTORS = (("Poseidon", "poseidon_selector"), ("CompleteAdd", "complete_add_selector"), ("VarBaseMul", "mul_selector"),
+                  ("EndoMul", "emul_selector"), ("EndoMulScalar", "endomul_scalar_selector"))
+
+
+def gate_library_constant_term(curve: P.Curve, ev, alpha: int) -> int:
+    """sum over the five always-present gate types of selector(zeta) * (sum_i alpha^i constraint_i) on the proof's evaluations:
+    curr = w(zeta), next = w(zeta omega), coefficients(zeta) -- the rest of linearization.constant_term (linearization.rs:43-100;
+    every gate's constraints start at alpha^0).  The row machines are oracle/gates.py's."""
+    from . import gates as G
+    F = curve.scalar
+    total = 0
+    live = [(name, ev[key][0]) for name, key in GATE_SELECTORS if ev[key][0] % F.p]
+    if not live:
+        return 0
+    curr = [e[0] for e in ev["w"]]; nxt = [e[1] for e in ev["w"]]; co = [e[0] for e in ev["coefficients"]]
+    mds = S.params("fp" if F is P.Fp else "fq")["mds"]
+    endo = P.endos(P.PALLAS if curve is P.VESTA else P.VESTA)[0]        # VerifierIndex::endo = endos::<G::OtherCurve>().0 (an element of G's scalar field)
+    for name, sel in live:
+        total = (total + sel * G.combined_row(F, name, curr, nxt, co, alpha, mds=mds, endo=endo)) % F.p
+    return total
 
 
 def perm_scalars(F: P.Field, ev, beta: int, gamma: int, alpha0: int, zkp_zeta: int) -> int:
@@ -133,7 +180,7 @@ def fiat_shamir(curve: P.Curve, vix, proof, digest: int):
     _, endo_r = P.endos(curve)
     fq = S.DefaultFqSponge(curve)
     fq.absorb_fq([digest])
-    absorb_commitment(fq, [vix["h"]])                                   # public_comm of an empty public input: the blinding commitment
+    absorb_commitment(fq, vix.get("public_comm") or [vix["h"]])         # public_comm; for an empty public input: the blinding commitment
     for c in proof["w_comm"]:
         absorb_commitment(fq, c)
     beta = fq.challenge(); gamma = fq.challenge()
@@ -173,6 +220,8 @@ def verify(curve: P.Curve, vix, proof, g, h, rng, final_msm=None) -> bool:
     omega = vix["omega"]
     zetaw = zeta * omega % F.p
     zeta1 = pow(zeta, n, F.p)
+    srs_len = vix.get("max_poly_size", n)                               # chunk length = SRS size (verifier.rs:795, zeta_to_srs_len)
+    zeta_srs = pow(zeta, srs_len, F.p)
     alphas = [pow(alpha, ALPHA_PERM0 + i, F.p) for i in range(3)]
     zkp = eval_permutation_vanishing_polynomial(vix, zeta)
     # ---- ft_eval0 (verifier.rs:412-490)
@@ -190,6 +239,7 @@ def verify(curve: P.Curve, vix, proof, g, h, rng, final_msm=None) -> bool:
     den = (zeta - w_zk) * (zeta - 1) % F.p
     ft0 = (ft0 + num * F.inv(den)) % F.p
     ft0 = (ft0 - generic_constant_term(F, ev, alpha)) % F.p
+    ft0 = (ft0 - gate_library_constant_term(curve, ev, alpha)) % F.p
     # ---- commitments: f_comm = perm_scalar * sigma_comm[6]; ft_comm = f_comm - (zeta^n - 1) * sum_i zeta^(n i) t_comm[i]
     scal = perm_scalars(F, ev, beta, gamma, alphas[0], zkp)
     sig6 = vix["sigma_comm"][PERMUTS - 1][0]
@@ -198,11 +248,11 @@ def verify(curve: P.Curve, vix, proof, g, h, rng, final_msm=None) -> bool:
     for c in proof["t_comm"]:
         if c is not None:
             t_chunk = curve.add(t_chunk, curve.mul(c, pw))
-        pw = pw * zeta1 % F.p                                           # zeta^max_poly_size, max_poly_size = n
+        pw = pw * zeta_srs % F.p                                        # zeta^max_poly_size
     neg = curve.mul(t_chunk, (-zeta1m1) % F.p) if t_chunk is not None else None
     ft_comm = curve.add(f_comm, neg)
     # ---- the evaluation list (one chunk each): public, ft, then the columns in opening order
-    evaluations = [([h], [[ev["public"][0]], [ev["public"][1]]]), ([ft_comm], [[ft0], [proof["ft_eval1"]]])]
+    evaluations = [(vix.get("public_comm") or [h], [[ev["public"][0]], [ev["public"][1]]]), ([ft_comm], [[ft0], [proof["ft_eval1"]]])]
     comms = [proof["z_comm"], vix["generic_comm"], vix["psm_comm"], vix["complete_add_comm"], vix["mul_comm"], vix["emul_comm"], vix["endomul_scalar_comm"]]
     comms += list(proof["w_comm"]) + list(vix["coefficients_comm"]) + list(vix["sigma_comm"][:PERMUTS - 1])
     for c, e in zip(comms, columns_in_opening_order(ev)):
@@ -211,5 +261,5 @@ def verify(curve: P.Curve, vix, proof, g, h, rng, final_msm=None) -> bool:
             "opening": proof["opening"], "combined_inner_product": P.combined_inner_product(F, v, u, [e for _, e in evaluations])}
     if final_msm is None:
         return P.ipa_verify(curve, g, h, [item], rng)
-    g_terms, pts, sc = P.ipa_verify_terms(curve, n, h, [item], rng)
+    g_terms, pts, sc = P.ipa_verify_terms(curve, srs_len, h, [item], rng)
     return final_msm(g_terms, pts, sc)
