@@ -12,9 +12,10 @@ kimchi/src/bench.rs:59-96), no lookups, no optional gates, no recursion, one chu
   generic gate                   kimchi/src/circuits/polynomials/generic.rs:83-120, argument.rs:201-214
   alpha powers                   kimchi/src/linearization.rs:43-58,167-171: gates 0..20, permutation 21..23
 
-"Parity pinned by definition only" for this file as a whole: the reference's only whole-proof known-answer test
-(kimchi/src/tests/and.rs) needs the Rust prover's RNG stream and lookup gates.  Its building blocks are pinned
-(sponge: poseidon test vectors; SRS::verify / open: opening-proof bytes; MSM / commit: commitment bytes)."""
+PINNED on the reference's stored proofs (kimchi/src/tests/fixtures/*.bin, copies in tests/golden/ref_fixtures/): `verify` accepts
+eight proofs the reference's own prover produced (generic gates with / without public inputs, Poseidon, CompleteAdd, VarBaseMul,
+EndoMul, EndoMulScalar) and rejects tampered ones, and `build_index` + commitments reproduce the reference's serialised verifier
+index byte for byte (tests/test_reference_fixtures.py).  Byte parity of a whole PROOF is not claimed (Rust RNG stream)."""
 import hashlib
 from typing import List, Optional, Sequence
 

@@ -1,0 +1,97 @@
+"""The device path against bytes the REFERENCE produced (tests/golden/ref_fixtures/, see tests/test_reference_fixtures.py):
+for the circuit of kimchi's `test_generic_gate` (polynomials/generic.rs:380-470) the device-built prover index has the reference's
+verifier-index commitments and digest; the device iNTT (+ commitment over the monomial basis), the 8x extension (+ strided
+commitment over the Lagrange basis) and the chunk evaluator reproduce the reference's commitments and the evaluations its proof
+states at its own zeta / zeta omega; and a proof made by the device prover for this circuit is accepted by the oracle verifier
+under the index commitments taken from the reference's bytes.  Rows a7 / a8 / a12: pinned on reference-generated data."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import cref
+from oracle import fixtures as FX
+from oracle import kimchi as K
+from oracle import pasta as P
+
+from test_gpu_prover import _aff, _verify
+from test_reference_fixtures import C, F, HERE, generic_test_circuit
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def khip():
+    import proof_systems_amd.khip as k
+    k.init(0)
+    return k
+
+
+def _limbs(vals):
+    return cref.ints_to_limbs([F.to_mont(v) for v in vals])
+
+
+def _ints(limbs):
+    return [F.from_mont(v) for v in cref.limbs_to_ints(np.asarray(limbs).reshape(-1, 4))]
+
+
+def test_device_index_transforms_and_prover_against_the_reference_bytes(khip):
+    from proof_systems_amd import prover
+    fx = FX.load(os.path.join(HERE, "test_generic_gate.bin"), C)
+    v = fx["vindex"]
+    rows, wit = generic_test_circuit()
+    co = np.stack([_limbs(r) for r in rows])                              # (20, 15, 4)
+    ix = prover.ProverIndex(khip.VESTA, 5, co)
+    one = lambda t: [_aff(C, t[0], t[1])]
+    # ---- the index commitments and the digest
+    assert [one(t) for t in ix.sigma_comm] == v["sigma_comm"]
+    assert [one(t) for t in ix.coefficients_comm] == v["coefficients_comm"]
+    assert one(ix.generic_comm) == v["generic_comm"] and one(ix.zero_selector_comm) == v["psm_comm"]
+    h = C.srs_h()
+    vix_ref = dict(v); vix_ref["h"] = h
+    assert C.base.from_mont(P.from_limbs(ix.digest)) == K.verifier_index_digest(C, vix_ref)
+    assert ix.shifts == v["shifts"] and ix.omega == v["omega"]
+    # ---- the transforms on the reference's columns: sigma_3 and coefficient column 8 (rebuilt by the oracle, whose commitments
+    #      were checked against the same bytes on the CPU)
+    oix = K.build_index(F, 5, rows)
+    srs = ix.srs
+    fid = khip.FP
+    vixv, proofv = FX.oracle_views(fx, h)
+    ch = K.fiat_shamir(C, vixv, proofv, K.verifier_index_digest(C, vixv))
+    zeta = ch["zeta"]; zetaw = zeta * v["omega"] % F.p
+    ev = proofv["evals"]
+    cases = [(oix["sigma"][3], v["sigma_comm"][3], ev["s"][3]), (oix["coefficients"][8], v["coefficients_comm"][8], ev["coefficients"][8]),
+             (oix["coefficients"][0], v["coefficients_comm"][0], ev["coefficients"][0])]
+    for col, want_comm, want_eval in cases:
+        e = _limbs(col)
+        coeffs = khip.ntt(fid, e[None], 5, inverse=True)[0]                # Evaluations::interpolate
+        com, inf = srs.commit_non_hiding(coeffs, 1)
+        assert [_aff(C, com[0], inf[0])] == want_comm
+        d8 = khip.lde(fid, coeffs[None], 5, 3)[0]                          # evaluate_over_domain_by_ref(d8)
+        com, inf = srs.commit_evaluations_non_hiding(5, d8)
+        assert [_aff(C, com[0], inf[0])] == want_comm
+        assert np.array_equal(khip.ntt(fid, d8[None].copy(), 8, inverse=True)[0][:32], coeffs) and not khip.ntt(fid, d8[None].copy(), 8, inverse=True)[0][32:].any()
+        buf = khip.DevBuf(32 * 32).upload(coeffs)
+        got = khip.evaluate_chunks_dev(fid, buf, 32, 32, 1, _limbs([zeta, zetaw]))
+        assert tuple(_ints(got)) == tuple(want_eval)                       # the evaluations the reference's proof states
+        buf.free()
+    # ---- the device prover on the reference's circuit and witness; verifier index commitments from the reference's bytes
+    w = np.stack([_limbs(c) for c in wit])                                 # (15, 20, 4)
+    proof = prover.create_proof(ix, w, np.random.default_rng(4))
+    ok, (c, vix, pr) = _verify(khip, ix, proof)
+    assert ok
+    for k in ("sigma_comm", "coefficients_comm", "generic_comm", "psm_comm", "complete_add_comm", "mul_comm", "emul_comm", "endomul_scalar_comm"):
+        vix[k] = v[k]                                                       # (equal anyway: asserted above)
+    g_l = ix.srs.get_g()
+
+    def final_msm(g_terms, pts, sc):
+        gs = [0] * ix.n
+        for wt, chal in g_terms:
+            for j, s in enumerate(P.b_poly_coefficients(F, chal)):
+                gs[j] = (gs[j] + wt * s) % F.p
+        live = [(p, s) for p, s in zip(pts, sc) if p is not None]
+        xy = np.concatenate([g_l, np.stack([cref.ints_to_limbs([C.base.to_mont(p[0]), C.base.to_mont(p[1])]).reshape(8) for p, _ in live])])
+        scal = cref.ints_to_limbs([F.to_mont(s) for s in gs + [s for _, s in live]])
+        _, inf = cref.msm(0, xy, scal, threads=8)
+        return inf
+    assert K.verify(C, vix, pr, None, h, P.StdRng(bytes([7] * 32)), final_msm=final_msm)
