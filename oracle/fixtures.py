@@ -56,9 +56,19 @@ def load(path: str, curve: P.Curve) -> Dict[str, Any]:
         "generic_comm": comm(vi[7]), "psm_comm": comm(vi[8]), "complete_add_comm": comm(vi[9]), "mul_comm": comm(vi[10]),
         "emul_comm": comm(vi[11]), "endomul_scalar_comm": comm(vi[12]),
         "optional_comms": [_opt(c, comm) for c in vi[13:19]],
-        "shifts": [_fe(bytes(s)) for s in vi[19]], "lookup_index": vi[20],
+        "shifts": [_fe(bytes(s)) for s in vi[19]], "lookup_index": None,
         "F": F,
     }
+    if vi[20] is not None:                                   # LookupVerifierIndex (verifier_index.rs:35-56), LookupInfo / LookupFeatures / LookupPatterns (lookups.rs)
+        li = vi[20]
+        info = li[4]
+        vindex["lookup_index"] = {
+            "joint_lookup_used": bool(li[0]), "lookup_table": [comm(c) for c in li[1]],
+            "lookup_selectors": dict(zip(("Xor", "Lookup", "RangeCheck", "ForeignFieldMul"), [_opt(c, comm) for c in li[2]])),
+            "table_ids": _opt(li[3], comm), "max_per_row": info[0], "max_joint_size": info[1],
+            "patterns": [q for q, on in zip(("Xor", "Lookup", "RangeCheck", "ForeignFieldMul"), info[2][0]) if on],
+            "uses_runtime_tables": bool(info[2][2]), "runtime_tables_selector": _opt(li[5], comm),
+        }
     # ---- proof
     cm, op, ev = pr[0], pr[1], pr[2]
     pe = lambda e: ([_fe(bytes(x)) for x in e[0]], [_fe(bytes(x)) for x in e[1]])      # PointEvaluations { zeta, zeta_omega }
@@ -67,10 +77,14 @@ def load(path: str, curve: P.Curve) -> Dict[str, Any]:
         "coefficients": [pe(e) for e in ev[4]],
         "generic_selector": pe(ev[5]), "poseidon_selector": pe(ev[6]), "complete_add_selector": pe(ev[7]), "mul_selector": pe(ev[8]),
         "emul_selector": pe(ev[9]), "endomul_scalar_selector": pe(ev[10]),
-        "optional_raw": list(ev[11:]),                       # optional gate selectors, lookup evaluations (None for the circuits read here)
+        "optional_gate_selectors": [_opt(e, pe) for e in ev[11:17]],           # range_check0/1, foreign_field_add/mul, xor, rot
+        "lookup_aggregation": _opt(ev[17], pe), "lookup_table": _opt(ev[18], pe), "lookup_sorted": [_opt(e, pe) for e in ev[19]],
+        "runtime_lookup_table": _opt(ev[20], pe), "runtime_lookup_table_selector": _opt(ev[21], pe),
+        "lookup_selectors": dict(zip(("Xor", "Lookup", "RangeCheck", "ForeignFieldMul"), [_opt(e, pe) for e in ev[22:26]])),
     }
     proof = {
-        "w_comm": [comm(c) for c in cm[0]], "z_comm": comm(cm[1]), "t_comm": comm(cm[2]), "lookup": cm[3],
+        "w_comm": [comm(c) for c in cm[0]], "z_comm": comm(cm[1]), "t_comm": comm(cm[2]),
+        "lookup": _opt(cm[3], lambda l: {"sorted": [comm(c) for c in l[0]], "aggreg": comm(l[1]), "runtime": _opt(l[2], comm)}),
         "opening": {"lr": [(curve.decompress(bytes(l)), curve.decompress(bytes(r))) for l, r in op[0]], "delta": curve.decompress(bytes(op[1])),
                     "z1": _fe(bytes(op[2])), "z2": _fe(bytes(op[3])), "sg": curve.decompress(bytes(op[4]))},
         "evals": evals, "ft_eval1": _fe(bytes(pr[3])), "prev_challenges": pr[4],
@@ -89,5 +103,9 @@ def oracle_views(fx, h):
     pe = {k: one(ev[k]) for k in K.EVAL_ORDER}
     pe.update({"public": one(ev["public"]) if ev["public"] is not None else None, "w": [one(e) for e in ev["w"]], "s": [one(e) for e in ev["s"]],
                "coefficients": [one(e) for e in ev["coefficients"]]})
+    for k in ("lookup_aggregation", "lookup_table"):
+        pe[k] = one(ev[k]) if ev[k] is not None else None
+    pe["lookup_sorted"] = [one(e) for e in ev["lookup_sorted"] if e is not None]
+    pe["lookup_selectors"] = {q: one(e) for q, e in ev["lookup_selectors"].items() if e is not None}
     proof = dict(fx["proof"]); proof["evals"] = pe
     return vix, proof

@@ -97,6 +97,15 @@ def verifier_index_digest(curve: P.Curve, vix) -> int:
         absorb_commitment(sp, c)
     for k in ("generic_comm", "psm_comm", "complete_add_comm", "mul_comm", "emul_comm", "endomul_scalar_comm"):
         absorb_commitment(sp, vix[k])
+    li = vix.get("lookup_index")
+    if li:                                                 # verifier_index.rs:482-525: table columns, table ids, (runtime selector), pattern selectors
+        for c in li["lookup_table"]:
+            absorb_commitment(sp, c)
+        if li["table_ids"] is not None:
+            absorb_commitment(sp, li["table_ids"])
+        for q in LOOKUP_PATTERN_ORDER:
+            if li["lookup_selectors"].get(q) is not None:
+                absorb_commitment(sp, li["lookup_selectors"][q])
     return sp.challenge_fq()                               # digest_fq
 
 
@@ -175,6 +184,64 @@ def columns_in_opening_order(ev):
     return out
 
 
+LOOKUP_PATTERN_ORDER = ("Xor", "Lookup", "RangeCheck", "ForeignFieldMul")
+ALPHA_LOOKUP0 = ALPHA_PERM0 + 3        # linearization.rs:170-186: the lookup constraints are registered after the permutation's three powers
+
+
+def lookup_evaluations_in_sponge_order(ev, li):
+    """FrSponge::absorb_evaluations (plonk_sponge.rs:127-155): aggregation, table, sorted..., the pattern selectors."""
+    if not li:
+        return []
+    return [ev["lookup_aggregation"], ev["lookup_table"]] + list(ev["lookup_sorted"]) + [ev["lookup_selectors"][q] for q in LOOKUP_PATTERN_ORDER if q in ev["lookup_selectors"]]
+
+
+def lookup_constant_term(F: P.Field, vix, ev, ch, zeta: int) -> int:
+    """sum_k alpha^(24 + k) * lookup constraint_k on the proof's evaluations: the lookup part of linearization.constant_term.
+    The constraints are oracle/lookup.py's (constraints.rs:378-673); the table-id combiner is joint_combiner^max_joint_size
+    unconditionally there (constraints.rs:424-440), cells of row Curr / Next are the evaluations at zeta / zeta omega."""
+    from . import lookup as L
+    li = vix["lookup_index"]
+    n, omega, zk = vix["n"], vix["omega"], vix["zk_rows"]
+    jc = ch["joint_combiner"]
+
+    class Shim:                                                         # what constraint_values reads from a LookupCS
+        p = F.p
+
+        class info:
+            patterns = [q for q in LOOKUP_PATTERN_ORDER if q in li["patterns"]]
+            max_per_row = li["max_per_row"]
+
+        @staticmethod
+        def constraint_combiners(j):
+            return j % F.p, pow(j, li["max_joint_size"], F.p)
+
+        @staticmethod
+        def dummy_value(j):
+            return 0
+    cols = {"w": ev["w"], "sorted": ev["lookup_sorted"], "aggreg": [ev["lookup_aggregation"]], "table": [ev["lookup_table"]]}
+
+    def cell(kind, idx, row):
+        if kind == "selector":
+            return ev["lookup_selectors"][idx][0]
+        return cols[kind][idx][row]
+    atoms = {"vanish": L.vanishes_on_last_n_rows(F.p, omega, n, zk + 1, zeta),
+             "l0": L.unnormalized_lagrange_basis(F.p, omega, n, 0, zeta),
+             "lfinal": L.unnormalized_lagrange_basis(F.p, omega, n, -(zk + 1), zeta)}
+    vals = L.constraint_values(Shim, jc, ch["beta"], ch["gamma"], cell, atoms)
+    return sum(pow(ch["alpha"], ALPHA_LOOKUP0 + k, F.p) * v for k, v in enumerate(vals)) % F.p
+
+
+def lookup_table_commitment(curve: P.Curve, li, jc: int):
+    """combine_table (lookup/tables/mod.rs:164-199): sum_i jc^i * column_i + jc^max_joint_size * table_ids (one chunk)."""
+    F = curve.scalar
+    acc, j = None, 1
+    for c in li["lookup_table"]:
+        acc = curve.add(acc, curve.mul(c[0], j)); j = j * jc % F.p
+    if li["table_ids"] is not None:
+        acc = curve.add(acc, curve.mul(li["table_ids"][0], pow(jc, li["max_joint_size"], F.p)))
+    return [acc]
+
+
 def fiat_shamir(curve: P.Curve, vix, proof, digest: int):
     """verifier.rs:160-420: returns the challenges and the Fq-sponge as SRS::verify needs it."""
     F = curve.scalar
@@ -184,7 +251,15 @@ def fiat_shamir(curve: P.Curve, vix, proof, digest: int):
     absorb_commitment(fq, vix.get("public_comm") or [vix["h"]])         # public_comm; for an empty public input: the blinding commitment
     for c in proof["w_comm"]:
         absorb_commitment(fq, c)
+    li = vix.get("lookup_index")
+    joint_combiner = None
+    if li:                                                              # verifier.rs:179-230 (no runtime tables)
+        joint_combiner = P.challenge_to_field(F, fq.challenge() if li["joint_lookup_used"] else 0, endo_r)
+        for c in proof["lookup"]["sorted"]:
+            absorb_commitment(fq, c)
     beta = fq.challenge(); gamma = fq.challenge()
+    if li:
+        absorb_commitment(fq, proof["lookup"]["aggreg"])
     absorb_commitment(fq, proof["z_comm"])
     alpha = P.challenge_to_field(F, fq.challenge(), endo_r)
     assert len(proof["t_comm"]) <= 7
@@ -198,7 +273,7 @@ def fiat_shamir(curve: P.Curve, vix, proof, digest: int):
     ev = proof["evals"]
     fr.absorb([proof["ft_eval1"]])
     fr.absorb([ev["public"][0]]); fr.absorb([ev["public"][1]])
-    for col in columns_in_opening_order(ev):
+    for col in columns_in_opening_order(ev) + lookup_evaluations_in_sponge_order(ev, li):
         fr.absorb([col[0]]); fr.absorb([col[1]])
 
     def fr_challenge():                                                 # DefaultFrSponge::challenge: 128 bits of one squeeze (the
@@ -207,7 +282,7 @@ def fiat_shamir(curve: P.Curve, vix, proof, digest: int):
     # v and u come from consecutive challenge() calls: last_squeezed holds exactly the two limbs of one squeeze
     v = P.challenge_to_field(F, fr_challenge(), endo_r)
     u = P.challenge_to_field(F, fr_challenge(), endo_r)
-    return {"beta": beta, "gamma": gamma, "alpha": alpha, "zeta": zeta, "v": v, "u": u, "fq_sponge": fq}
+    return {"beta": beta, "gamma": gamma, "alpha": alpha, "zeta": zeta, "v": v, "u": u, "fq_sponge": fq, "joint_combiner": joint_combiner}
 
 
 def verify(curve: P.Curve, vix, proof, g, h, rng, final_msm=None) -> bool:
@@ -241,6 +316,9 @@ def verify(curve: P.Curve, vix, proof, g, h, rng, final_msm=None) -> bool:
     ft0 = (ft0 + num * F.inv(den)) % F.p
     ft0 = (ft0 - generic_constant_term(F, ev, alpha)) % F.p
     ft0 = (ft0 - gate_library_constant_term(curve, ev, alpha)) % F.p
+    li = vix.get("lookup_index")
+    if li:
+        ft0 = (ft0 - lookup_constant_term(F, vix, ev, ch, zeta)) % F.p
     # ---- commitments: f_comm = perm_scalar * sigma_comm[6]; ft_comm = f_comm - (zeta^n - 1) * sum_i zeta^(n i) t_comm[i]
     scal = perm_scalars(F, ev, beta, gamma, alphas[0], zkp)
     sig6 = vix["sigma_comm"][PERMUTS - 1][0]
@@ -258,6 +336,12 @@ def verify(curve: P.Curve, vix, proof, g, h, rng, final_msm=None) -> bool:
     comms += list(proof["w_comm"]) + list(vix["coefficients_comm"]) + list(vix["sigma_comm"][:PERMUTS - 1])
     for c, e in zip(comms, columns_in_opening_order(ev)):
         evaluations.append((c, [[e[0]], [e[1]]]))
+    if li:                                                              # verifier.rs:1034-1175: sorted..., aggregation, the combined table, the pattern selectors
+        lk = [(c, e) for c, e in zip(proof["lookup"]["sorted"], ev["lookup_sorted"])] + [(proof["lookup"]["aggreg"], ev["lookup_aggregation"])]
+        lk.append((lookup_table_commitment(curve, li, ch["joint_combiner"]), ev["lookup_table"]))
+        lk += [(li["lookup_selectors"][q], ev["lookup_selectors"][q]) for q in LOOKUP_PATTERN_ORDER if li["lookup_selectors"].get(q) is not None]
+        for c, e in lk:
+            evaluations.append((c, [[e[0]], [e[1]]]))
     item = {"sponge": ch["fq_sponge"], "evaluation_points": [zeta, zetaw], "polyscale": v, "evalscale": u, "evaluations": evaluations,
             "opening": proof["opening"], "combined_inner_product": P.combined_inner_product(F, v, u, [e for _, e in evaluations])}
     if final_msm is None:

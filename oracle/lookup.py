@@ -171,6 +171,11 @@ class LookupCS:
         tic = pow(joint_combiner, self.info.max_joint_size, self.p) if self.table_ids is not None else 0
         return joint_combiner % self.p, tic
 
+    def constraint_combiners(self, joint_combiner: int):
+        """The constraint EXPRESSIONS use joint_combiner^max_joint_size for the table id whether or not the index has a table-id
+        column (constraints.rs:424-440); on the domain both agree (all table ids are 0 then), at zeta they do not."""
+        return joint_combiner % self.p, pow(joint_combiner, self.info.max_joint_size, self.p)
+
     def joint_table(self, joint_combiner: int) -> List[int]:
         """The combined table on d1 (prover.rs:500-572, the stride-8 sub-grid of joint_lookup_table_d8)."""
         jc, tic = self.combiners(joint_combiner)
@@ -282,7 +287,7 @@ def constraint_values(cs: LookupCS, joint_combiner: int, beta: int, gamma: int, 
     'lfinal': UnnormalizedLagrangeBasis(-zk_rows - 1)} at that point."""
     p = cs.p
     info = cs.info
-    jc, tic = cs.combiners(joint_combiner)
+    jc, tic = cs.constraint_combiners(joint_combiner)
     mpr = info.max_per_row
     beta1 = (1 + beta) % p
     gb1 = gamma * beta1 % p

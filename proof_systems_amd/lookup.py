@@ -102,6 +102,11 @@ class LookupIndex:
         p = self.F.p
         return joint_combiner % p, (pow(joint_combiner, self.max_joint_size, p) if self.table_ids is not None else 0)
 
+    def constraint_combiners(self, joint_combiner: int):
+        """For the constraint token program: the expressions use joint_combiner^max_joint_size for the table id whether or not the
+        index has a table-id column (constraints.rs:424-440) -- equal on the domain, different at zeta, and the verifier's."""
+        return joint_combiner % self.F.p, pow(joint_combiner, self.max_joint_size, self.F.p)
+
     # ---- the combined table (prover.rs:500-572) on the device: Horner over the table columns + table_id_combiner * ids
     def joint_table_dev(self, joint_combiner: int) -> "khip.DevBuf":
         jc, tic = self.combiners(joint_combiner)

@@ -64,7 +64,7 @@ def test_lookup_argument_on_device(env):
     assert agg == want_agg and agg[N - ZK - 1] == 1
     # ---- constraint rows on d1: token program vs the oracle's row machine
     cols = LK.column_layout(ix)
-    _, tic = ix.combiners(jc)
+    _, tic = ix.constraint_combiners(jc)
     toks, consts = OP.lookup_program(p, ix.patterns, cols, jc, tic, beta, gamma, alpha)
     atoms1 = LK.atom_columns(ix, 0)
     omega = F.root_of_unity(LOGN)

@@ -7,6 +7,9 @@ What they pin, none of it "by definition":
     generic gates with and without public inputs, and one circuit per gate type of the library (Poseidon, CompleteAdd,
     VarBaseMul, EndoMul, EndoMulScalar), whose constraint rows (oracle/gates.py) enter ft_eval0 as the linearization's
     constant term: the row machines the device token programs are tested against are the reference's constraints;
+  * the lookup argument: two proofs of circuits of 500 Lookup gates (one table / five tables with ids) are accepted with
+    oracle/lookup.py's constraint values as the lookup part of the constant term, the combined table commitment of combine_table
+    and the transcript / evaluation order of verifier.rs:179-246, 1034-1175;
   * the index side: domain generator, Shifts::new, sigma, the coefficient layout of create_generic_gadget, and -- through the
     Lagrange-basis commitments of the index columns -- the inverse-DFT conventions of the oracle's NTT (rows a7 / a8 of
     SURVEY 8): the rebuilt commitments equal the reference's bytes.
@@ -29,6 +32,7 @@ SRS_LEN = 65536                                   # every fixture was made over 
 GATE_FIXTURES = {"test_poseidon": "poseidon_selector", "ec_test": "complete_add_selector", "varbase_mul_test": "mul_selector",
                  "endomul_test": "emul_selector", "endomul_scalar_test": "endomul_scalar_selector"}
 GENERIC_FIXTURES = ["test_generic_gate", "test_generic_gate_pub", "test_generic_gate_pub_empty"]
+LOOKUP_FIXTURES = ["lookup_gate_proving_works", "lookup_gate_proving_works_multiple_tables"]     # tests/lookup.rs:38-170: 500 Lookup gates
 
 
 def generic_test_circuit():
@@ -85,11 +89,16 @@ def verify(fx, srs, mutate=None):
     return K.verify(C, vix, proof, None, h, P.StdRng(bytes([5] * 32)), final_msm=final_msm)
 
 
-@pytest.mark.parametrize("name", GENERIC_FIXTURES + list(GATE_FIXTURES))
+@pytest.mark.parametrize("name", GENERIC_FIXTURES + list(GATE_FIXTURES) + LOOKUP_FIXTURES)
 def test_oracle_verifier_accepts_the_reference_proof(name, srs):
     fx = FX.load(os.path.join(HERE, name + ".bin"), C)
     v = fx["vindex"]
-    assert v["max_poly_size"] == SRS_LEN and v["zk_rows"] == 3 and v["lookup_index"] is None and fx["proof"]["lookup"] is None
+    assert v["max_poly_size"] == SRS_LEN and v["zk_rows"] == 3
+    assert (v["lookup_index"] is not None) == (name in LOOKUP_FIXTURES) == (fx["proof"]["lookup"] is not None)
+    if name in LOOKUP_FIXTURES:
+        li = v["lookup_index"]
+        assert li["patterns"] == ["Lookup"] and (li["max_per_row"], li["max_joint_size"], li["joint_lookup_used"]) == (3, 2, True)
+        assert (li["table_ids"] is not None) == name.endswith("multiple_tables") and len(fx["proof"]["lookup"]["sorted"]) == 4
     assert v["omega"] == F.root_of_unity(v["log2_n"]) and v["shifts"] == K.sample_shifts(F, v["log2_n"])        # domains.rs, Shifts::new
     if name in GATE_FIXTURES:                      # the gate type under test is live in this proof: its selector does not evaluate to 0
         assert fx["proof"]["evals"][GATE_FIXTURES[name]][0][0] != 0
@@ -114,6 +123,18 @@ def test_oracle_verifier_rejects_tampering(srs):
         w = list(proof["evals"]["w"]); w[4] = ((w[4][0] + 1) % F.p, w[4][1]); proof["evals"]["w"] = w
     for m in (bump_eval, bump_ft, swap_sigma, bump_witness_eval):
         assert not verify(fx, srs, m), m.__name__
+    fxl = FX.load(os.path.join(HERE, "lookup_gate_proving_works_multiple_tables.bin"), C)
+
+    def bump_sorted(vix, proof):                  # breaks the lookup constant term only
+        srt = list(proof["evals"]["lookup_sorted"]); srt[2] = ((srt[2][0] + 1) % F.p, srt[2][1]); proof["evals"]["lookup_sorted"] = srt
+
+    def bump_aggreg(vix, proof):
+        a = proof["evals"]["lookup_aggregation"]; proof["evals"]["lookup_aggregation"] = (a[0], (a[1] + 1) % F.p)
+
+    def drop_table_ids(vix, proof):               # the combined table commitment loses its table-id term
+        vix["lookup_index"] = dict(vix["lookup_index"]); vix["lookup_index"]["table_ids"] = None
+    for m in (bump_sorted, bump_aggreg, drop_table_ids):
+        assert not verify(fxl, srs, m), m.__name__
     fxp = FX.load(os.path.join(HERE, "test_generic_gate_pub.bin"), C)
     fxp["public"][2] = 4                            # a different public input
     assert not verify(fxp, srs)
