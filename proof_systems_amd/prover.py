@@ -168,6 +168,39 @@ class ProverIndex:
         sp.free()
         khip.sync()
 
+    def attach_lookup(self, LI):
+        """Adds a lookup constraint system (proof_systems_amd.lookup.LookupIndex over the same domain): coefficient forms and
+        8x extensions of the pattern selectors, the row-set atoms on d8, and the verifier-index side -- table columns and the
+        table-id column committed and masked with 1, selectors committed non-hiding (verifier_index.rs:189-216) -- folded into
+        the digest (verifier_index.rs:482-530)."""
+        from . import lookup as LK
+        assert LI.n == self.n and LI.fid == self.fid
+        n, fid, F, logn = self.n, self.fid, self.F, self.log2_n
+        self.lookup = LI
+        LI.sel_c = {}; LI.sel8 = {}
+        for q in LI.patterns:
+            c = khip.DevBuf(n * 32); khip.dev_copy(c.ptr, LI.d_selectors[q].ptr, n * 32); khip.ntt_dev(fid, c, logn, True, 1)
+            e = khip.DevBuf(8 * n * 32); khip.lde_dev(fid, c, logn, 3, e, 1)
+            LI.sel_c[q], LI.sel8[q] = c, e
+        LI.atoms8 = LK.atom_columns(LI, 3)
+        one = F.limbs_many([1])
+
+        def commit(vals, masked):
+            com, inf = self.srs.commit_evaluations_non_hiding(logn, F.limbs_many(vals))
+            if masked:
+                com, inf = self.srs.mask_custom(com, inf, one)
+            return (com[0], bool(inf[0]))
+        LI.table_comm = [commit(c, True) for c in LI.table_cols]
+        LI.table_ids_comm = commit(LI.table_ids, True) if LI.table_ids is not None else None
+        LI.selector_comm = {q: commit(LI.selectors[q], False) for q in LI.patterns}
+        sp = khip.Sponge(khip.Sponge.FQ, self.curve)
+        extra = LI.table_comm + ([LI.table_ids_comm] if LI.table_ids_comm else []) + [LI.selector_comm[q] for q in LI.patterns]
+        for c_, i_ in self.sigma_comm + self.coefficients_comm + [self.generic_comm] + [self.zero_selector_comm] * 5 + extra:
+            sp.absorb_g(c_.reshape(1, 8), np.array([1 if i_ else 0], dtype=np.uint8))
+        self.digest = sp.squeeze_field()
+        sp.free()
+        khip.sync()
+
     def free(self):
         for b in (self.d1, self.dc, self.d8, self.zero_poly):
             b.free()
@@ -220,11 +253,40 @@ def create_proof(ix: ProverIndex, witness, rng, timings=None, check: bool = True
     w_blind = [F.rand(rng) for _ in range(COLUMNS)]
     w_comm, w_inf = srs.mask_custom(com, inf, F.limbs_many(w_blind))
     fq.absorb_g(w_comm, w_inf)
+    LI = getattr(ix, "lookup", None)
+    lkp = None
+    if LI is not None:                                      # prover.rs:383-633: joint combiner, combined table, sorted columns
+        from . import lookup as LK
+        jc = scalar_challenge(curve, F, fq.challenge() if LI.joint_lookup_used else 0)
+        d_table = LI.joint_table_dev(jc)
+        table_ints = [F.value(l) for l in d_table.download((n, 4))]
+        wcols = ev.download((COLUMNS, n, 4))
+        used = sorted({c for q in LI.patterns for tid, entry in OP.LOOKUP_PATTERNS[q] for c in (list(entry) + ([tid[1]] if isinstance(tid, tuple) else []))})
+        wit_ints = [[F.value(l) for l in wcols[c]] if c in used else None for c in range(COLUMNS)]
+        srt = [LK.zk_patch(F, c, n, ZK_ROWS, rng) for c in LK.sorted_columns(LI, wit_ints, table_ints, jc)]    # ValueError(row): value not in the table
+        d_sorted = [khip.DevBuf(NB).upload(F.limbs_many(c)) for c in srt]
+        s_blind, s_comm = [], []
+        for b in d_sorted:
+            com, inf = srs.msm_batch_dev(b.ptr, n, 1, basis=logn)
+            bl_ = F.rand(rng)
+            com, inf = srs.mask_custom(com, inf, F.limbs_many([bl_]))
+            fq.absorb_g(com, inf)
+            s_blind.append(bl_); s_comm.append((com[0], bool(inf[0])))
+        lkp = {"jc": jc, "d_table": d_table, "d_sorted": d_sorted, "s_blind": s_blind, "s_comm": s_comm}
     mark("witness_commit")
     cf = khip.DevBuf(16 * NB)                               # coefficient forms [w | z]
     khip.dev_copy(cf.ptr, ev.ptr, COLUMNS * NB)
     khip.ntt_dev(fid, cf, logn, True, COLUMNS)
     beta = F.value(fq.challenge_field()); gamma = F.value(fq.challenge_field())
+    if lkp is not None:                                     # prover.rs:635-673: the lookup aggregation, committed before z
+        d_agg = LK.aggregation_dev(LI, [ev.view(i * NB) for i in range(COLUMNS)], lkp["d_sorted"], lkp["d_table"], lkp["jc"], beta, gamma, rng)
+        if check and F.value(d_agg.download_at((n - ZK_ROWS - 1) * 32, (4,))) != 1:
+            raise RuntimeError("final value of the lookup aggregation is not 1 (lookup/constraints.rs:325-331)")
+        com, inf = srs.msm_batch_dev(d_agg.ptr, n, 1, basis=logn)
+        a_blind = F.rand(rng)
+        com, inf = srs.mask_custom(com, inf, F.limbs_many([a_blind]))
+        fq.absorb_g(com, inf)
+        lkp.update({"d_agg": d_agg, "a_blind": a_blind, "a_comm": (com[0], bool(inf[0]))})
     # ---- permutation accumulator z (perm_aggreg): numerators / denominators, batch inversion, running product
     d1cols = [ev.view(i * NB) for i in range(PERMUTS)] + [ix.col1(COLUMNS + 2 + i) for i in range(PERMUTS)] + [ix.col1(COLUMNS + 1)]
     consts = F.limbs_many([gamma, beta] + [beta * s % F.p for s in ix.shifts])
@@ -263,6 +325,20 @@ def create_proof(ix: ProverIndex, witness, rng, timings=None, check: bool = True
     pconsts = F.limbs_many([gamma, beta, alphas[0]] + [beta * s % F.p for s in ix.shifts])
     khip.expr_evaluations_dev(fid, OP.perm_quot_tokens(w0=0, s0=7, z=14, x=15, zkpm=16, gamma=0, beta=1, bshift0=3, alpha0=2), perm_cols, [8 * n] * 17, pconsts,
                               8 * n, t8, stride=1, next_shift=8)
+    if lkp is not None:                                     # the lookup constraints on d8 (prover.rs:874-903), powers alpha^24 ...
+        nl = len(lkp["d_sorted"]) + 2
+        lkc = khip.DevBuf(nl * NB); lk8 = khip.DevBuf(nl * N8)   # coefficient forms / d8: [sorted ... | aggregation | combined table]
+        for k_, b in enumerate(lkp["d_sorted"] + [lkp["d_agg"], lkp["d_table"]]):
+            khip.dev_copy(lkc.ptr + k_ * NB, b.ptr, NB)
+        khip.ntt_dev(fid, lkc, logn, True, nl)
+        khip.lde_dev(fid, lkc, logn, 3, lk8, nl)
+        cols = LK.column_layout(LI)
+        _, tic_expr = LI.constraint_combiners(lkp["jc"])
+        ltoks, lconsts = OP.lookup_program(F.p, LI.patterns, cols, lkp["jc"], tic_expr, beta, gamma, alpha, alpha0=ALPHA_PERM0 + 3)
+        lbufs = [e8.view(i * N8) for i in range(COLUMNS)] + [lk8.view(k_ * N8) for k_ in range(nl)] + [LI.sel8[q] for q in LI.patterns] + list(LI.atoms8)
+        assert len(lbufs) == cols["count"]
+        khip.expr_evaluations_dev(fid, ltoks, lbufs, [8 * n] * len(lbufs), F.limbs_many(lconsts), 8 * n, t8, stride=1, next_shift=8, accumulate=True)
+        lkp.update({"lkc": lkc, "lk8": lk8, "nl": nl})
     khip.ntt_dev(fid, t4, logn + 2, True, 1)
     khip.ntt_dev(fid, t8, logn + 3, True, 1)
     khip.poly_lincomb_dev(fid, [t8, t4], [8 * n, 4 * n], F.limbs_many([1, 1]), t8, 8 * n)      # f = t4 + t8 (+ the zero public polynomial)
@@ -291,11 +367,21 @@ def create_proof(ix: ProverIndex, witness, rng, timings=None, check: bool = True
     # ---- evaluations at zeta, zeta * omega (coefficient forms; one chunk each)
     polys = [zc, ix.colc(COLUMNS)] + [ix.zero_poly] * 5 + [cf.view(i * NB) for i in range(COLUMNS)] + [ix.colc(i) for i in range(COLUMNS)] + \
             [ix.colc(COLUMNS + 2 + i) for i in range(PERMUTS - 1)]
+    lk_polys = []
+    if lkp is not None:                                     # opening order (prover.rs:1368-1420): sorted ..., aggregation, combined table, pattern selectors
+        lk_polys = [lkp["lkc"].view(k_ * NB) for k_ in range(lkp["nl"])] + [LI.sel_c[q] for q in LI.patterns]
     pts = F.limbs_many([zeta, zetaw])
-    evl = khip.evaluate_chunks_batch_dev(fid, polys, [n] * len(polys), [1] * len(polys), n, pts)
+    evl = khip.evaluate_chunks_batch_dev(fid, polys + lk_polys, [n] * (len(polys) + len(lk_polys)), [1] * (len(polys) + len(lk_polys)), n, pts)
     E = [(F.value(e[0, 0]), F.value(e[1, 0])) for e in evl]
     evals = {"public": (0, 0), "z": E[0], "generic_selector": E[1], "poseidon_selector": E[2], "complete_add_selector": E[3], "mul_selector": E[4],
              "emul_selector": E[5], "endomul_scalar_selector": E[6], "w": E[7:22], "coefficients": E[22:37], "s": E[37:43]}
+    lk_evals_open, lk_evals_sponge = [], []
+    if lkp is not None:
+        ns = len(lkp["d_sorted"])
+        evals["lookup_sorted"] = E[43:43 + ns]; evals["lookup_aggregation"] = E[43 + ns]; evals["lookup_table"] = E[44 + ns]
+        evals["lookup_selectors"] = {q: E[45 + ns + k_] for k_, q in enumerate(LI.patterns)}
+        lk_evals_open = E[43:]
+        lk_evals_sponge = [evals["lookup_aggregation"], evals["lookup_table"]] + list(evals["lookup_sorted"]) + [evals["lookup_selectors"][q] for q in LI.patterns]
     # ---- ft = perm_scalar * sigma_6 - (zeta^n - 1) * sum_i zeta^(n i) t_i   (Maller; prover.rs:1147-1188)
     zeta1 = pow(zeta, n, F.p)
     zkp = (zeta - pow(ix.omega, n - 3, F.p)) * (zeta - pow(ix.omega, n - 2, F.p)) % F.p * (zeta - pow(ix.omega, n - 1, F.p)) % F.p
@@ -316,17 +402,21 @@ def create_proof(ix: ProverIndex, witness, rng, timings=None, check: bool = True
     empty = khip.Sponge(khip.Sponge.FR, curve); fr.absorb(empty.digest()); empty.free()
     order = [evals["z"], evals["generic_selector"], evals["poseidon_selector"], evals["complete_add_selector"], evals["mul_selector"], evals["emul_selector"],
              evals["endomul_scalar_selector"]] + list(evals["w"]) + list(evals["coefficients"]) + list(evals["s"])
-    flat = [ft_eval1, 0, 0] + [x for e in order for x in e]
+    flat = [ft_eval1, 0, 0] + [x for e in order + lk_evals_sponge for x in e]       # plonk_sponge.rs:92-155
     fr.absorb(F.limbs_many(flat))
     v = scalar_challenge(curve, F, fr.challenge())
     u = scalar_challenge(curve, F, fr.challenge())
     fr.free()
     mark("evaluations")
     # ---- SRS::open on (public, ft, z, 6 selectors, w x 15, coefficients x 15, sigma x 6)
-    open_polys = [ix.zero_poly, ft] + polys
-    open_lens = [0, n] + [n] * len(polys)
+    open_polys = [ix.zero_poly, ft] + polys + lk_polys
+    open_lens = [0, n] + [n] * (len(polys) + len(lk_polys))
     blinders = [1, blinding_ft, z_blind, 1, 1, 1, 1, 1, 1] + w_blind + [0] * COLUMNS + [0] * (PERMUTS - 1)
-    all_evals = [(0, 0), (ft_eval0, ft_eval1)] + order
+    if lkp is not None:                                     # the combined table's blinder: sum_i jc^i over its masked columns + the table-id combiner (prover.rs:1384-1400)
+        jc_, tic_ = LI.combiners(lkp["jc"])
+        tb = sum(pow(jc_, i, F.p) for i in range(len(LI.table_cols))) + tic_
+        blinders += lkp["s_blind"] + [lkp["a_blind"], tb % F.p] + [0] * len(LI.patterns)
+    all_evals = [(0, 0), (ft_eval0, ft_eval1)] + order + lk_evals_open
     a_dev = khip.DevBuf(NB); b_dev = khip.DevBuf(NB)
     khip.combine_polys_dev(fid, open_polys, open_lens, [1] * len(open_polys), F.limbs(v), n, a_dev)
     khip.b_init_dev(fid, pts, F.limbs(u), n, b_dev)
@@ -343,10 +433,15 @@ def create_proof(ix: ProverIndex, witness, rng, timings=None, check: bool = True
     mark("opening")
     for b in (ev, cf, e8, t4, t8, quot, rem, zm1, b1, b2, ft, a_dev, b_dev, num, den):
         b.free()
+    lk_out = {}
+    if lkp is not None:
+        lk_out = {"lookup": {"sorted": lkp["s_comm"], "aggreg": lkp["a_comm"]}}
+        for b in lkp["d_sorted"] + [lkp["d_agg"], lkp["d_table"], lkp["lkc"], lkp["lk8"]]:
+            b.free()
     if timings is not None:
         prev = t_start
         for name, t in marks:
             timings[name] = timings.get(name, 0.0) + (t - prev); prev = t
         timings["total"] = timings.get("total", 0.0) + (marks[-1][1] - t_start)
     return {"w_comm": (w_comm, w_inf), "z_comm": (z_comm, z_inf), "t_comm": (t_comm, t_inf), "evals": evals, "ft_eval1": ft_eval1, "opening": opening,
-            "challenges": {"beta": beta, "gamma": gamma, "alpha": alpha, "zeta": zeta, "v": v, "u": u}}
+            "challenges": {"beta": beta, "gamma": gamma, "alpha": alpha, "zeta": zeta, "v": v, "u": u}, **lk_out}

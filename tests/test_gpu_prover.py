@@ -40,6 +40,14 @@ def _oracle_views(khip, ix, proof):
           "evals": proof["evals"], "ft_eval1": proof["ft_eval1"],
           "opening": {"lr": [(_aff(c, xy[0], li[0]), _aff(c, xy[1], li[1])) for xy, li in op["lr"]], "delta": _aff(c, *op["delta"]), "z1": op["z1"], "z2": op["z2"],
                       "sg": _aff(c, *op["sg"])}}
+    LI = getattr(ix, "lookup", None)
+    if LI is not None:
+        vix["lookup_index"] = {"joint_lookup_used": LI.joint_lookup_used, "lookup_table": [one(t) for t in LI.table_comm],
+                               "lookup_selectors": {q: one(LI.selector_comm[q]) for q in LI.patterns},
+                               "table_ids": one(LI.table_ids_comm) if LI.table_ids_comm else None, "max_per_row": LI.max_per_row,
+                               "max_joint_size": LI.max_joint_size, "patterns": list(LI.patterns), "uses_runtime_tables": False, "runtime_tables_selector": None}
+        vix["zk_rows"] = 3
+        pr["lookup"] = {"sorted": [one(t) for t in proof["lookup"]["sorted"]], "aggreg": one(proof["lookup"]["aggreg"])}
     return c, vix, pr
 
 
@@ -122,3 +130,45 @@ def test_copy_constraints_and_unsatisfied_witness(khip):
     with pytest.raises(RuntimeError, match="accumulator"):
         prover.create_proof(ix, bad, np.random.default_rng(5))
     ix.free()
+
+
+def test_proof_with_lookups_is_accepted_by_the_reference_pinned_verifier(khip):
+    """A circuit in the shape of the reference's lookup tests (kimchi/src/tests/lookup.rs:38-170: Lookup gates into user tables with
+    ids, here next to generic gates): the device prover commits the sorted columns and the aggregation, evaluates the lookup
+    constraints on d8 with the powers alpha^24.., opens the extra polynomials -- and the oracle verifier, which accepts the reference's
+    own stored Lookup-gate proofs (tests/test_reference_fixtures.py), accepts the proof; tampering and a value outside the table fail."""
+    import random
+    from proof_systems_amd import lookup as LK, prover
+    logn = 9; n = 1 << logn
+    rnd = random.Random(21)
+    F = prover.Fld(khip.FP)
+    tables = [{"id": 0, "data": [list(range(40)), [0] + [rnd.randrange(F.p) for _ in range(39)]]},
+              {"id": 3, "data": [list(range(25)), [rnd.randrange(F.p) for _ in range(25)]]}]
+    ngen, nlook = 30, 200
+    co = np.zeros((ngen, 15, 4), dtype=np.uint64)
+    co[:, 0, :] = F.limbs(1); co[:, 4, :] = F.limbs(F.p - 7)          # generic rows: w0 - 7 = 0
+    gates = ["Generic"] * ngen + ["Lookup"] * nlook + ["Zero"] * (n - 3 - ngen - nlook)
+    rows = ngen + nlook
+    wit = [[0] * rows for _ in range(15)]
+    for r in range(ngen):
+        wit[0][r] = 7
+    for r in range(ngen, rows):
+        t = tables[rnd.randrange(2)]
+        wit[0][r] = t["id"]
+        for i in range(3):
+            e = rnd.randrange(len(t["data"][0]))
+            wit[2 * i + 1][r], wit[2 * i + 2][r] = t["data"][0][e], t["data"][1][e]
+    ix = prover.ProverIndex(khip.VESTA, logn, co)
+    ix.attach_lookup(LK.LookupIndex(khip.FP, gates, tables, logn))
+    w = np.stack([F.limbs_many(c) for c in wit])
+    proof = prover.create_proof(ix, w, np.random.default_rng(8))
+    ok, (c, vix, pr) = _verify(khip, ix, proof)
+    assert ok
+    assert len(pr["lookup"]["sorted"]) == 4 and vix["lookup_index"]["table_ids"] is not None
+    bad = dict(proof); be = dict(proof["evals"]); be["lookup_aggregation"] = (be["lookup_aggregation"][0], (be["lookup_aggregation"][1] + 1) % F.p); bad["evals"] = be
+    assert not _verify(khip, ix, bad)[0]
+    bad = dict(proof); be = dict(proof["evals"]); srt = list(be["lookup_sorted"]); srt[1] = ((srt[1][0] + 1) % F.p, srt[1][1]); be["lookup_sorted"] = srt; bad["evals"] = be
+    assert not _verify(khip, ix, bad)[0]
+    wit[2][ngen + 5] = (wit[2][ngen + 5] + 1) % F.p                     # a looked-up value that is not in its table
+    with pytest.raises(ValueError):
+        prover.create_proof(ix, np.stack([F.limbs_many(c) for c in wit]), np.random.default_rng(8))
