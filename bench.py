@@ -151,7 +151,7 @@ def oracle_verifies(khip, ix, proof):
     vix = {"F": c.scalar, "n": ix.n, "log2_n": ix.log2_n, "omega": ix.omega, "shifts": ix.shifts, "h": aff(ix.h, False),
            "sigma_comm": [one(t) for t in ix.sigma_comm], "coefficients_comm": [one(t) for t in ix.coefficients_comm], "generic_comm": one(ix.generic_comm)}
     for k in ("psm_comm", "complete_add_comm", "mul_comm", "emul_comm", "endomul_scalar_comm"):
-        vix[k] = one(ix.zero_selector_comm)
+        vix[k] = one(ix.selector_comms[("psm_comm", "complete_add_comm", "mul_comm", "emul_comm", "endomul_scalar_comm").index(k)])
     chunks = lambda t: [aff(t[0][j], t[1][j]) for j in range(len(t[1]))]
     op = proof["opening"]
     pr = {"w_comm": [[aff(proof["w_comm"][0][i], proof["w_comm"][1][i])] for i in range(15)], "z_comm": chunks(proof["z_comm"]), "t_comm": chunks(proof["t_comm"]),

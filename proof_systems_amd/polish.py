@@ -289,6 +289,14 @@ GATES = {"Poseidon": (poseidon_constraints, 15), "CompleteAdd": (complete_add_co
          "EndoMul": (endomul_constraints, 12), "EndoMulScalar": (endomul_scalar_constraints, 11)}
 
 
+# Kimchi Poseidon MDS matrices (poseidon/src/pasta/fp_kimchi.rs, fq_kimchi.rs: `mds`), by field id 0 = Fp, 1 = Fq -- the constants of
+# Constant::Mds in the Poseidon gate's expression (the round constants are circuit data: the gate's coefficient columns).
+POSEIDON_MDS = {
+    0: [[12035446894107573964500871153637039653510326950134440362813193268448863222019, 25461374787957152039031444204194007219326765802730624564074257060397341542093, 27667907157110496066452777015908813333407980290333709698851344970789663080149], [4491931056866994439025447213644536587424785196363427220456343191847333476930, 14743631939509747387607291926699970421064627808101543132147270746750887019919, 9448400033389617131295304336481030167723486090288313334230651810071857784477], [10525578725509990281643336361904863911009900817790387635342941550657754064843, 27437632000253211280915908546961303399777448677029255413769125486614773776695, 27566319851776897085443681456689352477426926500749993803132851225169606086988]],
+    1: [[28115781186772277486790024060542467295096710153315236019619365740021995624782, 22098002279041163367053200604969603243328318626084412751290336872362628294144, 10518156075882958317589806716220047551309200159506906232124952575033472931386], [8515206633865386306014865142947895502833797732365705727001733785057042819852, 19310731234716792175834594131802557577955166208124819468043130037927500684373, 361439796332338311597104753147071943681730695313819021679602959964518909239], [2193808570710678216879007026210418088296432071066284289131688133644970611483, 1201496953174589855481629688627002262719699487577300614284420648015658009380, 11619800255560837597192574795389782851917036920101027584480912719351481334717]],
+}
+
+
 def gate_program(name: str, p: int, alpha: int, selector_col: int = 30, mds=None, endo: int = 0, w0: int = 0, c0: int = 15):
     """(tokens, constants as integers) of index(name) * combined constraints, alpha powers from alpha^0 (every gate's
     constraints start at the first of the 21 gate alphas, linearization.rs:56-58)."""

@@ -90,8 +90,11 @@ class ProverIndex:
     sigma, their coefficient forms and 8x extensions, x and the permutation vanishing polynomial on d8, the SRS with its
     Lagrange basis, and the verifier-index commitments + digest (verifier_index.rs:175-300, 405-500)."""
 
-    def __init__(self, curve: int, log2_n: int, gate_coeffs, srs=None):
-        """gate_coeffs: (rows, 15, 4) uint64 Montgomery limbs -- coefficient rows of the generic gates (rows <= n - 3)."""
+    GATE_TYPES = ("Poseidon", "CompleteAdd", "VarBaseMul", "EndoMul", "EndoMulScalar")     # the always-present selectors after Generic
+
+    def __init__(self, curve: int, log2_n: int, gate_coeffs, srs=None, gate_types=None):
+        """gate_coeffs: (rows, 15, 4) uint64 Montgomery limbs -- coefficient rows of the gates (rows <= n - 3).  gate_types: one name
+        per row ("Generic", one of GATE_TYPES, or anything else -- "Zero", "Lookup" -- for a row without gate constraints); default: all Generic."""
         self.curve = curve
         self.fid = khip.FP if curve == khip.VESTA else khip.FQ
         F = self.F = Fld(self.fid)
@@ -110,9 +113,18 @@ class ProverIndex:
         # ---- d1 evaluation columns: coefficients (15), generic selector, sid, sigma (7)
         co = np.zeros((COLUMNS, n, 4), dtype=np.uint64)
         co[:, :self.gates, :] = np.transpose(gate_coeffs, (1, 0, 2))
-        sel = np.zeros((n, 4), dtype=np.uint64); sel[:self.gates] = one
-        self.d1 = khip.DevBuf((COLUMNS + 1 + 1 + PERMUTS) * n * 32)     # [coef 0..14 | sel | sid | sigma 0..6]
+        self.gate_types = list(gate_types) if gate_types is not None else ["Generic"] * self.gates
+        assert len(self.gate_types) == self.gates
+        self.live_gate_types = set(self.gate_types)
+        sel = np.zeros((n, 4), dtype=np.uint64)
+        sel[[r for r, g in enumerate(self.gate_types) if g == "Generic"]] = one
+        self.SEL0 = COLUMNS + 2 + PERMUTS                               # first of the five further selector columns
+        self.d1 = khip.DevBuf((COLUMNS + 1 + 1 + PERMUTS + 5) * n * 32)  # [coef 0..14 | generic sel | sid | sigma 0..6 | psm add mul emul emulscalar]
         self.d1.upload_at(0, co); self.d1.upload_at(COLUMNS * n * 32, sel)
+        for k, name in enumerate(self.GATE_TYPES):
+            sk = np.zeros((n, 4), dtype=np.uint64)
+            sk[[r for r, g in enumerate(self.gate_types) if g == name]] = one
+            self.d1.upload_at((self.SEL0 + k) * n * 32, sk)
         xpoly = np.zeros((n, 4), dtype=np.uint64); xpoly[1] = one
         sid = self.col1(COLUMNS + 1)
         self.d1.upload_at((COLUMNS + 1) * n * 32, xpoly)
@@ -138,7 +150,7 @@ class ProverIndex:
 
     def _finish_columns(self):
         n, fid, F, logn = self.n, self.fid, self.F, self.log2_n
-        ncol = COLUMNS + 1 + 1 + PERMUTS                                # same order as d1
+        ncol = COLUMNS + 1 + 1 + PERMUTS + 5                            # same order as d1
         if not hasattr(self, "dc"):
             self.dc = khip.DevBuf((ncol + 2) * n * 32)                  # + [x | zkpm] in coefficient form
             self.d8 = khip.DevBuf((ncol + 2) * 8 * n * 32)
@@ -161,8 +173,11 @@ class ProverIndex:
         com, inf = self.srs.msm_batch_dev(self.col1(COLUMNS + 2).ptr, n, PERMUTS, basis=logn)
         self.sigma_comm = [(com[i], bool(inf[i])) for i in range(PERMUTS)]
         self.zero_selector_comm = (self.h.copy(), False)                # identity + 1 * h
+        com, inf = self.srs.msm_batch_dev(self.col1(self.SEL0).ptr, n, 5, basis=logn)
+        com, inf = self.srs.mask_custom(com, inf, F.limbs_many([1] * 5))
+        self.selector_comms = [(com[i], bool(inf[i])) for i in range(5)]  # psm, complete_add, mul, emul, endomul_scalar (= h for an absent gate type)
         sp = khip.Sponge(khip.Sponge.FQ, self.curve)
-        for c_, i_ in self.sigma_comm + self.coefficients_comm + [self.generic_comm] + [self.zero_selector_comm] * 5:
+        for c_, i_ in self.sigma_comm + self.coefficients_comm + [self.generic_comm] + self.selector_comms:
             sp.absorb_g(c_.reshape(1, 8), np.array([1 if i_ else 0], dtype=np.uint8))
         self.digest = sp.squeeze_field()                                # VerifierIndex::digest -> digest_fq
         sp.free()
@@ -195,7 +210,7 @@ class ProverIndex:
         LI.selector_comm = {q: commit(LI.selectors[q], False) for q in LI.patterns}
         sp = khip.Sponge(khip.Sponge.FQ, self.curve)
         extra = LI.table_comm + ([LI.table_ids_comm] if LI.table_ids_comm else []) + [LI.selector_comm[q] for q in LI.patterns]
-        for c_, i_ in self.sigma_comm + self.coefficients_comm + [self.generic_comm] + [self.zero_selector_comm] * 5 + extra:
+        for c_, i_ in self.sigma_comm + self.coefficients_comm + [self.generic_comm] + self.selector_comms + extra:
             sp.absorb_g(c_.reshape(1, 8), np.array([1 if i_ else 0], dtype=np.uint8))
         self.digest = sp.squeeze_field()
         sp.free()
@@ -325,6 +340,13 @@ def create_proof(ix: ProverIndex, witness, rng, timings=None, check: bool = True
     pconsts = F.limbs_many([gamma, beta, alphas[0]] + [beta * s % F.p for s in ix.shifts])
     khip.expr_evaluations_dev(fid, OP.perm_quot_tokens(w0=0, s0=7, z=14, x=15, zkpm=16, gamma=0, beta=1, bshift0=3, alpha0=2), perm_cols, [8 * n] * 17, pconsts,
                               8 * n, t8, stride=1, next_shift=8)
+    live_gates = [(k_, name) for k_, name in enumerate(ix.GATE_TYPES) if name in ix.live_gate_types]
+    if live_gates:                                          # the gate library on d8 (prover.rs:824-868): index(gate) * sum_i alpha^i constraint_i
+        endo_q = F.value(khip.endos(1 - curve)[0])          # VerifierIndex::endo = endos::<OtherCurve>().0, an element of this scalar field
+        gcols = [e8.view(i * N8) for i in range(COLUMNS)] + [ix.col8(i) for i in range(COLUMNS)]
+        for k_, name in live_gates:
+            gtoks, gconsts = OP.gate_program(name, F.p, alpha, selector_col=30, mds=OP.POSEIDON_MDS[fid], endo=endo_q)
+            khip.expr_evaluations_dev(fid, gtoks, gcols + [ix.col8(ix.SEL0 + k_)], [8 * n] * 31, F.limbs_many(gconsts), 8 * n, t8, stride=1, next_shift=8, accumulate=True)
     if lkp is not None:                                     # the lookup constraints on d8 (prover.rs:874-903), powers alpha^24 ...
         nl = len(lkp["d_sorted"]) + 2
         lkc = khip.DevBuf(nl * NB); lk8 = khip.DevBuf(nl * N8)   # coefficient forms / d8: [sorted ... | aggregation | combined table]
@@ -365,7 +387,7 @@ def create_proof(ix: ProverIndex, witness, rng, timings=None, check: bool = True
     zetaw = zeta * ix.omega % F.p
     fq_before = fq.clone()
     # ---- evaluations at zeta, zeta * omega (coefficient forms; one chunk each)
-    polys = [zc, ix.colc(COLUMNS)] + [ix.zero_poly] * 5 + [cf.view(i * NB) for i in range(COLUMNS)] + [ix.colc(i) for i in range(COLUMNS)] + \
+    polys = [zc, ix.colc(COLUMNS)] + [ix.colc(ix.SEL0 + k_) for k_ in range(5)] + [cf.view(i * NB) for i in range(COLUMNS)] + [ix.colc(i) for i in range(COLUMNS)] + \
             [ix.colc(COLUMNS + 2 + i) for i in range(PERMUTS - 1)]
     lk_polys = []
     if lkp is not None:                                     # opening order (prover.rs:1368-1420): sorted ..., aggregation, combined table, pattern selectors

@@ -32,8 +32,8 @@ def _oracle_views(khip, ix, proof):
     one = lambda t: [_aff(c, t[0], t[1])]
     vix = {"F": c.scalar, "n": ix.n, "log2_n": ix.log2_n, "omega": ix.omega, "shifts": ix.shifts, "h": _aff(c, ix.h, False),
            "sigma_comm": [one(t) for t in ix.sigma_comm], "coefficients_comm": [one(t) for t in ix.coefficients_comm], "generic_comm": one(ix.generic_comm),
-           "psm_comm": one(ix.zero_selector_comm), "complete_add_comm": one(ix.zero_selector_comm), "mul_comm": one(ix.zero_selector_comm),
-           "emul_comm": one(ix.zero_selector_comm), "endomul_scalar_comm": one(ix.zero_selector_comm)}
+           "psm_comm": one(ix.selector_comms[0]), "complete_add_comm": one(ix.selector_comms[1]), "mul_comm": one(ix.selector_comms[2]),
+           "emul_comm": one(ix.selector_comms[3]), "endomul_scalar_comm": one(ix.selector_comms[4])}
     chunks = lambda t: [_aff(c, t[0][j], t[1][j]) for j in range(len(t[1]))]
     op = proof["opening"]
     pr = {"w_comm": [[_aff(c, proof["w_comm"][0][i], proof["w_comm"][1][i])] for i in range(15)], "z_comm": chunks(proof["z_comm"]), "t_comm": chunks(proof["t_comm"]),
@@ -172,3 +172,42 @@ def test_proof_with_lookups_is_accepted_by_the_reference_pinned_verifier(khip):
     wit[2][ngen + 5] = (wit[2][ngen + 5] + 1) % F.p                     # a looked-up value that is not in its table
     with pytest.raises(ValueError):
         prover.create_proof(ix, np.stack([F.limbs_many(c) for c in wit]), np.random.default_rng(8))
+
+
+def test_proof_over_the_gate_library_is_accepted(khip):
+    """One circuit with every always-present gate type -- generic rows, a Poseidon permutation (11 rows), complete additions incl. the
+    doubling and inverse cases, a variable-base scalar multiplication, an endo scalar multiplication and an endo-scalar decomposition
+    (witnesses by the reference's generators restated in oracle/gates.py): the device prover evaluates each gate's token program
+    (proof_systems_amd/polish.py) on d8 next to the permutation rows, and the oracle verifier -- which accepts the reference's own
+    stored proofs for each of these gate types -- accepts the proof; a broken gate row makes the prover fail at the zero-remainder check."""
+    import random
+    from proof_systems_amd import prover
+    from test_gates import gate_rows, tables
+    rnd = random.Random(77)
+    F = prover.Fld(khip.FP)
+    wrows, crows, types = [], [], []
+    for r in range(6):
+        wrows.append([5] + [0] * 14); crows.append([1, 0, 0, 0, F.p - 5] + [0] * 10); types.append("Generic")
+    for name in ("Poseidon", "CompleteAdd", "VarBaseMul", "EndoMul", "EndoMulScalar"):
+        w, co, ngate = tables(name, rnd)
+        live = set(gate_rows(name, ngate))
+        for r, (wr, cr) in enumerate(zip(w, co)):
+            wrows.append(list(wr)); crows.append(list(cr)); types.append(name if r in live else "Zero")
+    rows = len(wrows)
+    logn = 7
+    assert rows + 3 <= 1 << logn
+    co = np.stack([F.limbs_many(r) for r in crows])
+    ix = prover.ProverIndex(khip.VESTA, logn, co, gate_types=types)
+    wit = np.stack([F.limbs_many([wrows[r][c] for r in range(rows)]) for c in range(15)])
+    proof = prover.create_proof(ix, wit, np.random.default_rng(12))
+    ok, (c, vix, pr) = _verify(khip, ix, proof)
+    assert ok
+    for key in ("poseidon_selector", "complete_add_selector", "mul_selector", "emul_selector", "endomul_scalar_selector"):
+        assert proof["evals"][key][0] != 0                              # every gate type is live in this proof
+    bad = dict(proof); be = dict(proof["evals"]); w_ = list(be["w"]); w_[2] = ((w_[2][0] + 1) % F.p, w_[2][1]); be["w"] = w_; bad["evals"] = be
+    assert not _verify(khip, ix, bad)[0]
+    r0 = types.index("Poseidon") + 3
+    wrows[r0][7] = (wrows[r0][7] + 1) % F.p
+    wit = np.stack([F.limbs_many([wrows[r][c] for r in range(rows)]) for c in range(15)])
+    with pytest.raises(RuntimeError):
+        prover.create_proof(ix, wit, np.random.default_rng(12))
