@@ -92,10 +92,11 @@ class ProverIndex:
 
     GATE_TYPES = ("Poseidon", "CompleteAdd", "VarBaseMul", "EndoMul", "EndoMulScalar")     # the always-present selectors after Generic
 
-    def __init__(self, curve: int, log2_n: int, gate_coeffs, srs=None, gate_types=None):
+    def __init__(self, curve: int, log2_n: int, gate_coeffs, srs=None, gate_types=None, public: int = 0):
         """gate_coeffs: (rows, 15, 4) uint64 Montgomery limbs -- coefficient rows of the gates (rows <= n - 3).  gate_types: one name
         per row ("Generic", one of GATE_TYPES, or anything else -- "Zero", "Lookup" -- for a row without gate constraints); default: all Generic."""
         self.curve = curve
+        self.public = public                                 # number of public inputs: witness[0][0..public] (constraints.rs:870-890)
         self.fid = khip.FP if curve == khip.VESTA else khip.FQ
         F = self.F = Fld(self.fid)
         self.log2_n, self.n = log2_n, 1 << log2_n
@@ -261,8 +262,18 @@ def create_proof(ix: ProverIndex, witness, rng, timings=None, check: bool = True
     mark("witness_upload")
     fq = khip.Sponge(khip.Sponge.FQ, curve)
     fq.absorb(ix.digest)
-    public_comm = (ix.h.copy(), False)                      # zero public polynomial: commit_non_hiding -> [0], masked with 1 -> h
-    fq.absorb_g(public_comm[0].reshape(1, 8))
+    pub_c = None
+    if ix.public:                                           # the negated public-input polynomial (prover.rs:281-309): -p_i on the first rows
+        pe_ = np.zeros((n, 4), dtype=np.uint64)
+        pub_vals = [F.value(l) for l in ev.download_at(0, (ix.public, 4))]
+        pe_[:ix.public] = F.limbs_many([(-x) % F.p for x in pub_vals])
+        pub_c = khip.DevBuf(NB).upload(pe_)
+        com, inf = srs.msm_batch_dev(pub_c.ptr, n, 1, basis=logn)
+        com, inf = srs.mask_custom(com, inf, F.limbs_many([1]))
+        fq.absorb_g(com, inf)
+        khip.ntt_dev(fid, pub_c, logn, True, 1)
+    else:
+        fq.absorb_g(ix.h.copy().reshape(1, 8))              # zero public polynomial: commit_non_hiding -> [0], masked with 1 -> h
     # ---- witness commitments (commit_evaluations_non_hiding x 15 in one batched MSM over the Lagrange basis) + blinders
     com, inf = srs.msm_batch_dev(ev.ptr, n, COLUMNS, basis=logn)
     w_blind = [F.rand(rng) for _ in range(COLUMNS)]
@@ -363,7 +374,10 @@ def create_proof(ix: ProverIndex, witness, rng, timings=None, check: bool = True
         lkp.update({"lkc": lkc, "lk8": lk8, "nl": nl})
     khip.ntt_dev(fid, t4, logn + 2, True, 1)
     khip.ntt_dev(fid, t8, logn + 3, True, 1)
-    khip.poly_lincomb_dev(fid, [t8, t4], [8 * n, 4 * n], F.limbs_many([1, 1]), t8, 8 * n)      # f = t4 + t8 (+ the zero public polynomial)
+    if pub_c is not None:
+        khip.poly_lincomb_dev(fid, [t8, t4, pub_c], [8 * n, 4 * n, n], F.limbs_many([1, 1, 1]), t8, 8 * n)    # f = t4 + t8 + public (prover.rs:906-908)
+    else:
+        khip.poly_lincomb_dev(fid, [t8, t4], [8 * n, 4 * n], F.limbs_many([1, 1]), t8, 8 * n)
     quot = khip.DevBuf(7 * NB); rem = khip.DevBuf(NB)
     khip.divide_by_vanishing_poly_dev(fid, t8, 8 * n, logn, quot, rem)
     if check and rem.download((n, 4)).any():
@@ -395,7 +409,11 @@ def create_proof(ix: ProverIndex, witness, rng, timings=None, check: bool = True
     pts = F.limbs_many([zeta, zetaw])
     evl = khip.evaluate_chunks_batch_dev(fid, polys + lk_polys, [n] * (len(polys) + len(lk_polys)), [1] * (len(polys) + len(lk_polys)), n, pts)
     E = [(F.value(e[0, 0]), F.value(e[1, 0])) for e in evl]
-    evals = {"public": (0, 0), "z": E[0], "generic_selector": E[1], "poseidon_selector": E[2], "complete_add_selector": E[3], "mul_selector": E[4],
+    pub_eval = (0, 0)
+    if pub_c is not None:
+        pe2 = khip.evaluate_chunks_dev(fid, pub_c, n, n, 1, pts)
+        pub_eval = (F.value(pe2[0, 0]), F.value(pe2[1, 0]))
+    evals = {"public": pub_eval, "z": E[0], "generic_selector": E[1], "poseidon_selector": E[2], "complete_add_selector": E[3], "mul_selector": E[4],
              "emul_selector": E[5], "endomul_scalar_selector": E[6], "w": E[7:22], "coefficients": E[22:37], "s": E[37:43]}
     lk_evals_open, lk_evals_sponge = [], []
     if lkp is not None:
@@ -424,21 +442,21 @@ def create_proof(ix: ProverIndex, witness, rng, timings=None, check: bool = True
     empty = khip.Sponge(khip.Sponge.FR, curve); fr.absorb(empty.digest()); empty.free()
     order = [evals["z"], evals["generic_selector"], evals["poseidon_selector"], evals["complete_add_selector"], evals["mul_selector"], evals["emul_selector"],
              evals["endomul_scalar_selector"]] + list(evals["w"]) + list(evals["coefficients"]) + list(evals["s"])
-    flat = [ft_eval1, 0, 0] + [x for e in order + lk_evals_sponge for x in e]       # plonk_sponge.rs:92-155
+    flat = [ft_eval1, pub_eval[0], pub_eval[1]] + [x for e in order + lk_evals_sponge for x in e]       # plonk_sponge.rs:92-155
     fr.absorb(F.limbs_many(flat))
     v = scalar_challenge(curve, F, fr.challenge())
     u = scalar_challenge(curve, F, fr.challenge())
     fr.free()
     mark("evaluations")
     # ---- SRS::open on (public, ft, z, 6 selectors, w x 15, coefficients x 15, sigma x 6)
-    open_polys = [ix.zero_poly, ft] + polys + lk_polys
-    open_lens = [0, n] + [n] * (len(polys) + len(lk_polys))
+    open_polys = [pub_c if pub_c is not None else ix.zero_poly, ft] + polys + lk_polys
+    open_lens = [n if pub_c is not None else 0, n] + [n] * (len(polys) + len(lk_polys))
     blinders = [1, blinding_ft, z_blind, 1, 1, 1, 1, 1, 1] + w_blind + [0] * COLUMNS + [0] * (PERMUTS - 1)
     if lkp is not None:                                     # the combined table's blinder: sum_i jc^i over its masked columns + the table-id combiner (prover.rs:1384-1400)
         jc_, tic_ = LI.combiners(lkp["jc"])
         tb = sum(pow(jc_, i, F.p) for i in range(len(LI.table_cols))) + tic_
         blinders += lkp["s_blind"] + [lkp["a_blind"], tb % F.p] + [0] * len(LI.patterns)
-    all_evals = [(0, 0), (ft_eval0, ft_eval1)] + order + lk_evals_open
+    all_evals = [pub_eval, (ft_eval0, ft_eval1)] + order + lk_evals_open
     a_dev = khip.DevBuf(NB); b_dev = khip.DevBuf(NB)
     khip.combine_polys_dev(fid, open_polys, open_lens, [1] * len(open_polys), F.limbs(v), n, a_dev)
     khip.b_init_dev(fid, pts, F.limbs(u), n, b_dev)
@@ -455,6 +473,8 @@ def create_proof(ix: ProverIndex, witness, rng, timings=None, check: bool = True
     mark("opening")
     for b in (ev, cf, e8, t4, t8, quot, rem, zm1, b1, b2, ft, a_dev, b_dev, num, den):
         b.free()
+    if pub_c is not None:
+        pub_c.free()
     lk_out = {}
     if lkp is not None:
         lk_out = {"lookup": {"sorted": lkp["s_comm"], "aggreg": lkp["a_comm"]}}
