@@ -421,6 +421,46 @@ def test_concurrent_callers(khip):
     srs.close()
 
 
+@pytest.mark.timeout(300)
+def test_four_streams_of_small_msms_share_the_chip(khip):
+    """The one-launch sort of small jobs (k_sort_fused) keeps 64 blocks spinning on grid barriers; four host threads -- one per
+    pipeline slot -- run 40 single and paired commitments each over a 2^14-point basis at the same time, with a few 2^16-sized
+    jobs (the large path) mixed in: nobody deadlocks, and every result is the single-threaded one."""
+    import threading
+    rng = np.random.default_rng(4242)
+    logn = 14; n = 1 << logn
+    srs = khip.Srs.create(khip.VESTA, 1 << 16)
+    cols = [rand_fe_fast(rng, n) for _ in range(6)]
+    pair = np.stack(cols[:2])
+    big = rand_fe_fast(rng, 1 << 16)
+    want = [srs.msm(c) for c in cols]
+    want_pair = srs.msm_batch(pair)
+    want_big = srs.msm(big)
+    errors = []
+
+    def work(t):
+        try:
+            for it in range(40):
+                j = (t + it) % 6
+                xy, inf = srs.msm(cols[j])
+                assert inf == want[j][1] and np.array_equal(xy, want[j][0])
+                if it % 5 == t % 5:
+                    bxy, binf = srs.msm_batch(pair)
+                    assert np.array_equal(bxy, want_pair[0]) and np.array_equal(binf, want_pair[1])
+                if it % 13 == 0:
+                    xy, inf = srs.msm(big)
+                    assert inf == want_big[1] and np.array_equal(xy, want_big[0])
+        except Exception as e:                                               # noqa: BLE001 -- reported below, from the main thread
+            errors.append((t, repr(e)))
+    th = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors
+    srs.close()
+
+
 def test_fifteen_commit_callers_are_coalesced(khip):
     """The reference's witness commitments: 15 threads, each SRS::commit_evaluations_non_hiding on ITS OWN host column over
     the same Lagrange basis, at 2^16.  The library merges callers that arrive in a burst into batched launches; every

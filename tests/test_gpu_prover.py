@@ -132,7 +132,8 @@ def test_copy_constraints_and_unsatisfied_witness(khip):
     ix.free()
 
 
-def test_proof_with_lookups_is_accepted_by_the_reference_pinned_verifier(khip):
+@pytest.mark.parametrize("cid", [0, 1])
+def test_proof_with_lookups_is_accepted_by_the_reference_pinned_verifier(khip, cid):
     """A circuit in the shape of the reference's lookup tests (kimchi/src/tests/lookup.rs:38-170: Lookup gates into user tables with
     ids, here next to generic gates): the device prover commits the sorted columns and the aggregation, evaluates the lookup
     constraints on d8 with the powers alpha^24.., opens the extra polynomials -- and the oracle verifier, which accepts the reference's
@@ -141,7 +142,8 @@ def test_proof_with_lookups_is_accepted_by_the_reference_pinned_verifier(khip):
     from proof_systems_amd import lookup as LK, prover
     logn = 9; n = 1 << logn
     rnd = random.Random(21)
-    F = prover.Fld(khip.FP)
+    fid = khip.FP if cid == 0 else khip.FQ
+    F = prover.Fld(fid)
     tables = [{"id": 0, "data": [list(range(40)), [0] + [rnd.randrange(F.p) for _ in range(39)]]},
               {"id": 3, "data": [list(range(25)), [rnd.randrange(F.p) for _ in range(25)]]}]
     ngen, nlook = 30, 200
@@ -158,8 +160,8 @@ def test_proof_with_lookups_is_accepted_by_the_reference_pinned_verifier(khip):
         for i in range(3):
             e = rnd.randrange(len(t["data"][0]))
             wit[2 * i + 1][r], wit[2 * i + 2][r] = t["data"][0][e], t["data"][1][e]
-    ix = prover.ProverIndex(khip.VESTA, logn, co)
-    ix.attach_lookup(LK.LookupIndex(khip.FP, gates, tables, logn))
+    ix = prover.ProverIndex(cid, logn, co)
+    ix.attach_lookup(LK.LookupIndex(fid, gates, tables, logn))
     w = np.stack([F.limbs_many(c) for c in wit])
     proof = prover.create_proof(ix, w, np.random.default_rng(8))
     ok, (c, vix, pr) = _verify(khip, ix, proof)
