@@ -1147,7 +1147,8 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
     static const bool fused_off = getenv("KH_NO_FUSED_SORT") != nullptr;
     static const size_t fused_max = getenv("KH_FUSED_MAX") ? (size_t)atol(getenv("KH_FUSED_MAX")) : ((size_t)1 << 22);
     FusedGeom fg{};
-    bool fused = precomp && !fused_off && k <= 4 && M < fused_max && nb >= 2048;
+    // (co-residency of the spinning blocks is what makes the grid barriers safe: 64 blocks x 4 jobs in flight need 128 CUs -- not in a partitioned mode)
+    bool fused = precomp && !fused_off && k <= 4 && M < fused_max && nb >= 2048 && Ctx.num_cus >= 128;
     if (fused) {
         fg.n = (u32)n; fg.nb = nb; fg.W = (u32)W; fg.k = (u32)k; fg.bpg = (u32)std::min<size_t>(FUSED_G, FUSED_B / (2 * k)); fg.nkeys = (u32)nkeys;
         fg.split = 2; fg.sub = nb / fg.split;              // 64 blocks of 64 KB LDS: two per CU, so four (even eight) jobs in flight stay co-resident
