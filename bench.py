@@ -28,6 +28,7 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -134,7 +135,29 @@ def prover_block(khip, srs20, check_with_oracle=True, log_n=16, reps=5):
                      "note": "what a Rust prover gets by only swapping in GpuSrs / the ark-poly patch; PCIe-bound (pageable host memory)"}
     if check_with_oracle:
         out["proof_accepted_by_oracle_verifier"] = bool(oracle_verifies(khip, ix, proof))
-    ix.free()
+    # several provers in flight (one host thread and one SRS handle each): a single proof is mostly latency chains, independent proofs overlap
+    T, per = 4, 5
+    ixs = [ix] + [prover.bench_circuit_index(khip.VESTA, log_n) for _ in range(T - 1)]
+    for j in ixs[1:]:
+        prover.create_proof(j, wit, np.random.default_rng(2), check=False)
+    bar = threading.Barrier(T + 1)
+
+    def run(t):
+        r_ = np.random.default_rng(50 + t)
+        bar.wait()
+        for _ in range(per):
+            prover.create_proof(ixs[t], wit, r_, check=False)
+        bar.wait()
+    th = [threading.Thread(target=run, args=(t,)) for t in range(T)]
+    for t_ in th:
+        t_.start()
+    bar.wait(); t0 = time.perf_counter(); bar.wait(); dt = time.perf_counter() - t0
+    for t_ in th:
+        t_.join()
+    out["concurrent"] = {"provers_in_flight": T, "proofs_per_s": T * per / dt, "constraints_per_s": T * per * (1 << log_n) / dt,
+                         "note": "throughput of independent proofs on one GPU; `seconds` above is the latency of one"}
+    for j in ixs:
+        j.free()
     return out
 
 

@@ -154,6 +154,37 @@ static int resolve_basis(kh_srs_t* srs, int basis, unsigned chunk, MsmBasis& out
     return KH_OK;
 }
 
+// one non-blocking copy stream per (host thread, device), created on first use
+static hipStream_t thread_copy_stream() {
+    static thread_local hipStream_t tl[KH_MAX_DEVICES] = {nullptr};
+    const int d = kh::ctx().device >= 0 && kh::ctx().device < KH_MAX_DEVICES ? kh::ctx().device : 0;
+    if (!tl[d] && hipStreamCreateWithFlags(&tl[d], hipStreamNonBlocking) != hipSuccess) { kh::set_error("hipStreamCreate for a copy stream failed"); return nullptr; }
+    return tl[d];
+}
+
+// kh_dev_alloc / kh_dev_free go through a small caching pool: hipFree synchronises the device and takes ~0.25 ms, and a prover frees
+// ~15 column buffers per proof (3.8 ms of a 16 ms proof, measured with cProfile on proof_systems_amd/prover.py).  Freed blocks are
+// kept per device, keyed by their (4 KiB-rounded) size, and handed out again to a request of nearly that size; reuse is safe because
+// every consumer of such buffers is either synchronous or ordered on the context's main stream.  kh_trim empties the pool;
+// KH_POOL_MAX_MB (default 8192) bounds what it may hold, KH_POOL_MAX_MB=0 disables it.
+namespace {
+struct DevPool {
+    std::mutex mu;
+    std::multimap<size_t, void*> free_blocks[KH_MAX_DEVICES];
+    std::map<void*, std::pair<int, size_t>> live;          // pointer -> (device, rounded size)
+    size_t cached[KH_MAX_DEVICES] = {0};
+};
+DevPool& dev_pool() { static DevPool p; return p; }
+size_t pool_limit() { static const size_t lim = (getenv("KH_POOL_MAX_MB") ? (size_t)atol(getenv("KH_POOL_MAX_MB")) : 8192) << 20; return lim; }
+}  // namespace
+static void dev_pool_trim(int device) {
+    DevPool& P = dev_pool();
+    std::lock_guard<std::mutex> lk(P.mu);
+    const int d = device >= 0 && device < KH_MAX_DEVICES ? device : 0;
+    for (auto& kv : P.free_blocks[d]) (void)hipFree(kv.second);
+    P.free_blocks[d].clear(); P.cached[d] = 0;
+}
+
 extern "C" {
 
 int kh_device_count(void) {
@@ -191,6 +222,7 @@ int kh_trim(void) {
                           &S.ws_seg, &S.ws_out, &S.ws_scan_tmp, &S.ws_biglist, &S.ws_points, &S.ws_order, &S.ws_chunks, &S.ws_handed, &S.ws_sync, &S.ws_mid}) b->release();
     }
     C.ws_ntt_a.release(); C.ws_ntt_b.release();
+    dev_pool_trim(C.device);
     C.trim_scratch();
     ntt_trim(C);
     return KH_OK;
@@ -356,9 +388,13 @@ static int free_slot(Context& C) {
 }
 // a synchronous entry point may wait for a slot that another thread is blocked on (it will be released); slots held by
 // un-waited kh_msm_submit tickets never free up by themselves, so with only those busy the answer is still -1
-static int acquire_slot(std::unique_lock<std::mutex>* lk, Context& C) {
+// side_first: take a slot other than the main stream's when one is free -- a job that may CAPTURE its launch sequence into a hipGraph
+// must not do so on the stream other host threads synchronise and launch on (a capture is invalidated by, and invalidates, such calls)
+static int acquire_slot(std::unique_lock<std::mutex>* lk, Context& C, bool side_first = false) {
     for (;;) {
-        int si = free_slot(C);
+        int si = -1;
+        if (side_first) for (int i = MSM_SLOTS - 1; i >= 1; i--) if (!C.slot[i].busy) { si = i; break; }
+        if (si < 0) si = free_slot(C);
         if (si >= 0 || !lk || C.sync_inflight == 0) return si;
         C.cv.wait(*lk);
     }
@@ -1117,7 +1153,7 @@ int kh_ipa_round_lr(kh_ipa_t* st, const uint64_t rand_l[4], const uint64_t rand_
     KH_REQUIRE(!st->lr_done, "kh_ipa_round_fold must follow kh_ipa_round_lr");
     Context& C = ctx();
     std::unique_lock<std::mutex> lk(C.mu);
-    int si = acquire_slot(&lk, C);
+    int si = acquire_slot(&lk, C, /*side_first=*/true);
     KH_REQUIRE(si >= 0, "all %d MSM pipeline slots hold an un-waited job (kh_msm_wait first)", MSM_SLOTS);
     MsmSlot& S = C.slot[si];
     KH_HIP(hipStreamWaitEvent(S.stream, st->ev, 0));
@@ -1333,10 +1369,43 @@ int kh_lde(int field, const uint64_t* coeffs, unsigned log2_n, unsigned log2_blo
 int kh_dev_alloc(void** ptr, size_t bytes) {
     KH_REQUIRE(ptr, "null ptr");
     int rc = ensure_init(); if (rc) return rc;
-    KH_HIP(hipMalloc(ptr, bytes ? bytes : 1));
+    const size_t want = ((bytes ? bytes : 1) + 4095) & ~(size_t)4095;
+    const int d = ctx().device >= 0 && ctx().device < KH_MAX_DEVICES ? ctx().device : 0;
+    DevPool& P = dev_pool();
+    {
+        std::lock_guard<std::mutex> lk(P.mu);
+        auto it = P.free_blocks[d].lower_bound(want);
+        if (it != P.free_blocks[d].end() && it->first <= want + want / 4) {
+            *ptr = it->second; P.live[*ptr] = {d, it->first}; P.cached[d] -= it->first;
+            P.free_blocks[d].erase(it);
+            return KH_OK;
+        }
+    }
+    hipError_t e = hipMalloc(ptr, want);
+    if (e != hipSuccess) {                                  // give the cached blocks back and retry once
+        (void)hipGetLastError();
+        dev_pool_trim(d);
+        KH_HIP(hipMalloc(ptr, want));
+    }
+    std::lock_guard<std::mutex> lk(P.mu);
+    P.live[*ptr] = {d, want};
     return KH_OK;
 }
-int kh_dev_free(void* ptr) { if (ptr) KH_HIP(hipFree(ptr)); return KH_OK; }
+int kh_dev_free(void* ptr) {
+    if (!ptr) return KH_OK;
+    DevPool& P = dev_pool();
+    {
+        std::lock_guard<std::mutex> lk(P.mu);
+        auto it = P.live.find(ptr);
+        if (it != P.live.end()) {
+            const int d = it->second.first; const size_t sz = it->second.second;
+            P.live.erase(it);
+            if (P.cached[d] + sz <= pool_limit()) { P.free_blocks[d].emplace(sz, ptr); P.cached[d] += sz; return KH_OK; }
+        }
+    }
+    KH_HIP(hipFree(ptr));
+    return KH_OK;
+}
 // device-to-device copy on the main stream (ordered with kh_ntt_dev / kh_lde_dev / the vector steps; asynchronous)
 int kh_dev_copy(void* dst_dev, const void* src_dev, size_t bytes) {
     int rc = ensure_init(); if (rc) return rc;
@@ -1361,16 +1430,24 @@ int kh_dev_memset_zero(void* dst_dev, size_t bytes) {
 // The library's streams are non-blocking (they do not synchronise with the null stream hipMemcpy uses), so both copies
 // first wait for the main stream: an asynchronous kh_ntt_dev / kh_lde_dev on this buffer is complete before it is read
 // or overwritten.
+// The copies themselves run on a per-thread non-blocking stream, not on the legacy stream: a legacy-stream operation is refused ("would
+// make the legacy stream depend on a capturing ... stream") while ANOTHER host thread captures an opening round's MSM into a hipGraph.
 int kh_dev_upload(void* dst_dev, const void* src_host, size_t bytes) {
     int rc = ensure_init(); if (rc) return rc;
+    if (bytes == 0) return KH_OK;
+    hipStream_t cs = thread_copy_stream(); if (!cs) return KH_E_DEVICE;
     KH_HIP(hipStreamSynchronize(ctx().stream));
-    KH_HIP(hipMemcpy(dst_dev, src_host, bytes, hipMemcpyHostToDevice));
+    KH_HIP(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, cs));
+    KH_HIP(hipStreamSynchronize(cs));
     return KH_OK;
 }
 int kh_dev_download(void* dst_host, const void* src_dev, size_t bytes) {
     int rc = ensure_init(); if (rc) return rc;
+    if (bytes == 0) return KH_OK;
+    hipStream_t cs = thread_copy_stream(); if (!cs) return KH_E_DEVICE;
     KH_HIP(hipStreamSynchronize(ctx().stream));
-    KH_HIP(hipMemcpy(dst_host, src_dev, bytes, hipMemcpyDeviceToHost));
+    KH_HIP(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, cs));
+    KH_HIP(hipStreamSynchronize(cs));
     return KH_OK;
 }
 int kh_sync(void) {

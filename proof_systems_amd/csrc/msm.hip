@@ -1180,7 +1180,7 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
     uint64_t key = 0;
     CaptureGuard gcap{s};
     const bool timers_were = C.timer.enabled;
-    if (use_graph && !graphs_off) {
+    if (use_graph && !graphs_off && s != Ctx.stream) {       // never capture on the main stream: other host threads synchronise and launch on it
         key = 0xcbf29ce484222325ull;
         const uint64_t parts[] = {(uint64_t)(uintptr_t)basis.pts, (uint64_t)(uintptr_t)basis.inf, basis.n, basis.stride, basis.batch_stride, (uint64_t)basis.precomp_c,
                                   offset, (uint64_t)(uintptr_t)scalars_dev, n, k, (uint64_t)mont, (uint64_t)curve, (uint64_t)(uintptr_t)C.pinned,
