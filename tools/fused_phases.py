@@ -1,3 +1,5 @@
+"""Phase times of k_sort_fused (block 0's wall-clock stamps between its grid barriers) for a k = 2 batch of 2^16-point MSMs.
+Usage: KH_FUSED_DEBUG=1 python tools/fused_phases.py"""
 import os, sys, time, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import proof_systems_amd.khip as khip
