@@ -140,3 +140,52 @@ def test_device_prover_on_the_reference_public_input_circuit(khip):
         if want:
             ch = K.fiat_shamir(C, vix, pr, K.verifier_index_digest(C, vix))
             assert K.public_evaluations(F, ix.n, ix.omega, public, ch["zeta"]) == tuple(proof["evals"]["public"])
+
+
+@pytest.mark.parametrize("name", ["test_poseidon", "ec_test", "varbase_mul_test", "endomul_test", "endomul_scalar_test",
+                                  "lookup_gate_proving_works", "lookup_gate_proving_works_multiple_tables"])
+def test_device_token_programs_on_the_reference_proof_evaluations(khip, name):
+    """The token programs of proof_systems_amd/polish.py, run by kh_expr_evaluations_dev on two-row columns made of the evaluations a
+    REFERENCE proof states (row 0: at zeta, row 1: at zeta omega), give the constant term with which the oracle verifier accepts that
+    proof (tests/test_reference_fixtures.py): gate library and lookup constraints, device side, on reference-generated data."""
+    from proof_systems_amd import polish as OP
+    from oracle import lookup as L
+    fx = FX.load(os.path.join(HERE, name + ".bin"), C)
+    h = C.srs_h()
+    vix, proof = FX.oracle_views(fx, h)
+    ch = K.fiat_shamir(C, vix, proof, K.verifier_index_digest(C, vix))
+    ev = proof["evals"]
+    alpha, zeta = ch["alpha"], ch["zeta"]
+    fid = khip.FP
+    col = lambda e: khip.DevBuf(64).upload(_limbs([e[0], e[1]]))
+    wcols = [col(e) for e in ev["w"]]
+    out = khip.DevBuf(32)
+    if vix["lookup_index"] is None:
+        ccols = [col(e) for e in ev["coefficients"]]
+        total = 0
+        endo = P.endos(P.PALLAS)[0]
+        for gname, key in K.GATE_SELECTORS:
+            toks, consts = OP.gate_program(gname, F.p, alpha, selector_col=30, mds=OP.POSEIDON_MDS[0], endo=endo)
+            khip.expr_evaluations_dev(fid, toks, wcols + ccols + [col(ev[key])], [2] * 31, _limbs(consts), 1, out, stride=1, next_shift=1)
+            total = (total + _ints(out.download((1, 4)))[0]) % F.p
+        assert total == K.gate_library_constant_term(C, ev, alpha) and total != 0
+    else:
+        li = vix["lookup_index"]
+        n, omega, zk = vix["n"], vix["omega"], vix["zk_rows"]
+        jc = ch["joint_combiner"]
+        one = lambda x: khip.DevBuf(32).upload(_limbs([x]))
+        c = 15
+        cols = {"sorted": list(range(c, c + li["max_per_row"] + 1))}
+        c += li["max_per_row"] + 1
+        cols["aggreg"], cols["table"] = c, c + 1
+        cols["selector"] = {q: c + 2 + k for k, q in enumerate(li["patterns"])}
+        c += 2 + len(li["patterns"])
+        cols["vanish"], cols["l0"], cols["lfinal"] = c, c + 1, c + 2
+        bufs = wcols + [col(e) for e in ev["lookup_sorted"]] + [col(ev["lookup_aggregation"]), col(ev["lookup_table"])]
+        bufs += [col(ev["lookup_selectors"][q]) for q in li["patterns"]]
+        bufs += [one(L.vanishes_on_last_n_rows(F.p, omega, n, zk + 1, zeta)), one(L.unnormalized_lagrange_basis(F.p, omega, n, 0, zeta)),
+                 one(L.unnormalized_lagrange_basis(F.p, omega, n, -(zk + 1), zeta))]
+        toks, consts = OP.lookup_program(F.p, li["patterns"], cols, jc, pow(jc, li["max_joint_size"], F.p), ch["beta"], ch["gamma"], alpha, alpha0=K.ALPHA_LOOKUP0)
+        lens = [2] * (len(bufs) - 3) + [1] * 3
+        khip.expr_evaluations_dev(fid, toks, bufs, lens, _limbs(consts), 1, out, stride=1, next_shift=1)
+        assert _ints(out.download((1, 4)))[0] == K.lookup_constant_term(F, vix, ev, ch, zeta)
