@@ -29,10 +29,12 @@ C = P.VESTA
 F = C.scalar
 SRS_LEN = 65536                                   # every fixture was made over the reference's 2^16 test SRS
 
-GATE_FIXTURES = {"test_poseidon": "poseidon_selector", "ec_test": "complete_add_selector", "varbase_mul_test": "mul_selector",
+GATE_FIXTURES = {"test_poseidon": "poseidon_selector", "test_poseidon_in_circuit_extra_zero_block": "poseidon_selector", "ec_test": "complete_add_selector", "varbase_mul_test": "mul_selector",
                  "endomul_test": "emul_selector", "endomul_scalar_test": "endomul_scalar_selector"}
-GENERIC_FIXTURES = ["test_generic_gate", "test_generic_gate_pub", "test_generic_gate_pub_empty"]
-LOOKUP_FIXTURES = ["lookup_gate_proving_works", "lookup_gate_proving_works_multiple_tables"]     # tests/lookup.rs:38-170: 500 Lookup gates
+GENERIC_FIXTURES = ["test_generic_gate", "test_generic_gate_pub", "test_generic_gate_pub_empty", "test_generic_gate_pub_all_zeros",
+                    "test_prove_and_verify_five_not_gnrc"]                   # (the Not gadget built from generic gates, tests/not.rs)
+LOOKUP_FIXTURES = ["lookup_gate_proving_works", "lookup_gate_proving_works_multiple_tables",     # tests/lookup.rs:38-170: 500 Lookup gates
+                   "test_dummy_value_is_added_in_an_arbitraly_created_table_when_no_table_with_id_0"]   # the dummy entry's table is synthesised (lookup/index.rs)
 
 
 def generic_test_circuit():
@@ -98,7 +100,7 @@ def test_oracle_verifier_accepts_the_reference_proof(name, srs):
     if name in LOOKUP_FIXTURES:
         li = v["lookup_index"]
         assert li["patterns"] == ["Lookup"] and (li["max_per_row"], li["max_joint_size"], li["joint_lookup_used"]) == (3, 2, True)
-        assert (li["table_ids"] is not None) == name.endswith("multiple_tables") and len(fx["proof"]["lookup"]["sorted"]) == 4
+        assert (li["table_ids"] is not None) == (not name.endswith("proving_works")) and len(fx["proof"]["lookup"]["sorted"]) == 4
     assert v["omega"] == F.root_of_unity(v["log2_n"]) and v["shifts"] == K.sample_shifts(F, v["log2_n"])        # domains.rs, Shifts::new
     if name in GATE_FIXTURES:                      # the gate type under test is live in this proof: its selector does not evaluate to 0
         assert fx["proof"]["evals"][GATE_FIXTURES[name]][0][0] != 0
