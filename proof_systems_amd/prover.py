@@ -342,8 +342,13 @@ def create_proof(ix: ProverIndex, witness, rng, timings=None, check: bool = True
     alphas = [pow(alpha, ALPHA_PERM0 + i, F.p) for i in range(3)]
     # ---- 8x extension of w and z, constraint rows, quotient
     e8 = khip.DevBuf(16 * 8 * NB)
-    khip.lde_dev(fid, cf, logn, 3, e8, 16)
     N8 = 8 * NB
+    if lkp is None and not (ix.live_gate_types & set(ix.GATE_TYPES)):
+        # generic gates + permutation read only w0..w6 and z on d8 (generic.rs:83-120, permutation.rs:216-331): half of the reference's 16 extensions
+        khip.lde_dev(fid, cf, logn, 3, e8, PERMUTS)
+        khip.lde_dev(fid, cf.view(COLUMNS * NB), logn, 3, e8.view(COLUMNS * N8), 1)
+    else:
+        khip.lde_dev(fid, cf, logn, 3, e8, 16)
     gen_cols = [e8.view(i * N8) for i in range(6)] + [ix.col8(i) for i in range(10)] + [ix.col8(COLUMNS)]
     t4 = khip.DevBuf(4 * NB); t8 = khip.DevBuf(N8)
     khip.expr_evaluations_dev(fid, OP.generic_gate_tokens(0, 6, 16, 0, 1), gen_cols, [8 * n] * 17, F.limbs_many([1, alpha]), 4 * n, t4, stride=2, next_shift=8)
