@@ -346,6 +346,9 @@ int kh_dev_copy(void *dst_dev, const void *src_dev, size_t bytes);   /* device-t
 int kh_dev_memset_zero(void *dst_dev, size_t bytes);
 int kh_dev_upload(void *dst_dev, const void *src_host, size_t bytes);
 int kh_dev_download(void *dst_host, const void *src_dev, size_t bytes);
+/* `rows` runs of `width` bytes, `src_pitch` / `dst_pitch` bytes apart: the witness columns of a prover ([Vec<F>; 15], each shorter than
+ * the domain: kimchi/src/prover.rs:254-266) go into their padded device columns in one transfer. */
+int kh_dev_upload_2d(void *dst_dev, size_t dst_pitch, const void *src_host, size_t src_pitch, size_t width, size_t rows);
 int kh_msm_batch_dev(kh_srs_t *srs, int basis, unsigned chunk, size_t offset,
                      const uint64_t *scalars_dev, size_t n, size_t k, int scalars_are_montgomery,
                      uint64_t *out_xy /* host, k x 8 */, uint8_t *out_is_inf /* host, k */);

@@ -1250,6 +1250,8 @@ int kh_ipa_open(kh_srs_t* srs, const uint64_t* a_dev, size_t a_len, const uint64
         else sh = SF.sub(cip, acc);
         int rc = kh_sponge_absorb_fr(sponge, sh.l, 1); if (rc) return rc;
     }
+    static const bool ipa_timing = getenv("KH_IPA_TIMING") != nullptr;      // phase split of one opening on stderr
+    const auto tp0 = std::chrono::steady_clock::now();
     uint64_t t[4], u_base[8];
     int rc = kh_sponge_squeeze_field(sponge, t); if (rc) return rc;
     if ((rc = kh_group_map_to_group(curve, t, u_base))) return rc;
@@ -1257,6 +1259,7 @@ int kh_ipa_open(kh_srs_t* srs, const uint64_t* a_dev, size_t a_len, const uint64
     if ((rc = kh_ipa_begin_dev(srs, a_dev, a_len, b_dev, b_len, u_base, &st))) return rc;
     struct Guard { kh_ipa_t* s; ~Guard() { kh_ipa_free(s); } } guard{st};
     khost::fe r_prime = fe_of(blinding_factor);
+    const auto tp1 = std::chrono::steady_clock::now();
     for (size_t r = 0; r < rounds; r++) {
         const uint64_t* rl = blinders + 8 * r; const uint64_t* rr = rl + 4;
         if ((rc = kh_ipa_round_lr(st, rl, rr, lr_xy + 16 * r, lr_inf + 2 * r))) return rc;
@@ -1266,8 +1269,10 @@ int kh_ipa_open(kh_srs_t* srs, const uint64_t* a_dev, size_t a_len, const uint64
         if ((rc = kh_ipa_round_fold(st, chal, u, ui))) return rc;
         r_prime = SF.add(r_prime, SF.add(SF.mul(fe_of(rl), fe_of(ui)), SF.mul(fe_of(rr), fe_of(u))));       // ipa.rs:1021-1027
     }
+    const auto tp2 = std::chrono::steady_clock::now();
     uint64_t a0[4], b0[4];
     if ((rc = kh_ipa_finish(st, a0, b0, sg_xy, sg_inf))) return rc;
+    const auto tp3 = std::chrono::steady_clock::now();
     // delta = (g0 + [b0] U) * d + [r_delta] H  (ipa.rs:1036-1041), on the host: three scalar multiplications
     const khost::fe d = fe_of(blinders + 8 * rounds), r_delta = fe_of(blinders + 8 * rounds + 4);
     khost::xyzz acc = crv.identity();
@@ -1282,6 +1287,11 @@ int kh_ipa_open(kh_srs_t* srs, const uint64_t* a_dev, size_t a_len, const uint64
     scalar_challenge_to_field(sfield, cc, cached_endos(curve).r, c);
     const khost::fe z1v = SF.add(SF.mul(fe_of(a0), fe_of(c)), d), z2v = SF.add(SF.mul(r_prime, fe_of(c)), r_delta);
     memcpy(z1, &z1v, 32); memcpy(z2, &z2v, 32);
+    if (ipa_timing) {
+        auto us = [](std::chrono::steady_clock::time_point x, std::chrono::steady_clock::time_point y) { return std::chrono::duration<double, std::micro>(y - x).count(); };
+        fprintf(stderr, "kh_ipa_open: begin %.0f us, %zu rounds %.0f us, sg %.0f us, delta / z1 / z2 %.0f us\n", us(tp0, tp1), rounds, us(tp1, tp2), us(tp2, tp3),
+                us(tp3, std::chrono::steady_clock::now()));
+    }
     return KH_OK;
 }
 
@@ -1438,6 +1448,16 @@ int kh_dev_upload(void* dst_dev, const void* src_host, size_t bytes) {
     hipStream_t cs = thread_copy_stream(); if (!cs) return KH_E_DEVICE;
     KH_HIP(hipStreamSynchronize(ctx().stream));
     KH_HIP(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, cs));
+    KH_HIP(hipStreamSynchronize(cs));
+    return KH_OK;
+}
+int kh_dev_upload_2d(void* dst_dev, size_t dst_pitch, const void* src_host, size_t src_pitch, size_t width, size_t rows) {
+    int rc = ensure_init(); if (rc) return rc;
+    if (width == 0 || rows == 0) return KH_OK;
+    KH_REQUIRE(dst_dev && src_host && dst_pitch >= width && src_pitch >= width, "kh_dev_upload_2d: bad argument");
+    hipStream_t cs = thread_copy_stream(); if (!cs) return KH_E_DEVICE;
+    KH_HIP(hipStreamSynchronize(ctx().stream));
+    KH_HIP(hipMemcpy2DAsync(dst_dev, dst_pitch, src_host, src_pitch, width, rows, hipMemcpyHostToDevice, cs));
     KH_HIP(hipStreamSynchronize(cs));
     return KH_OK;
 }

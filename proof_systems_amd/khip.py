@@ -34,7 +34,7 @@ SYMBOLS = [
     "kh_device_count", "kh_init", "kh_set_device", "kh_get_device", "kh_trim", "kh_srs_device", "kh_last_error", "kh_srs_create", "kh_srs_free", "kh_srs_size",
     "kh_srs_set_lagrange", "kh_srs_compute_lagrange", "kh_srs_get_lagrange", "kh_srs_lagrange_chunks",
     "kh_msm", "kh_msm_batch", "kh_msm_points", "kh_ntt", "kh_lde",
-    "kh_dev_alloc", "kh_dev_free", "kh_dev_upload", "kh_dev_download",
+    "kh_dev_alloc", "kh_dev_free", "kh_dev_upload", "kh_dev_download", "kh_dev_upload_2d",
     "kh_msm_batch_dev", "kh_ntt_dev", "kh_lde_dev", "kh_coset_ntt_dev", "kh_sync", "kh_last_timings",
     "kh_debug_field_op", "kh_debug_point_op", "kh_srs_generate", "kh_srs_h",
     "kh_commit_non_hiding", "kh_commit_evaluations_non_hiding", "kh_srs_set_blinding_base",
@@ -120,6 +120,7 @@ _lib.kh_dev_alloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
 _lib.kh_dev_free.argtypes = [C.c_void_p]
 _lib.kh_dev_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
 _lib.kh_dev_download.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+_lib.kh_dev_upload_2d.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t]
 _lib.kh_last_timings.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int]
 _lib.kh_debug_field_op.argtypes = [C.c_int, C.c_int, U64P, U64P, U64P, C.c_size_t]
 _lib.kh_debug_point_op.argtypes = [C.c_int, C.c_int, U64P, U8P, U64P, U8P, U64P, U8P, C.c_size_t]
@@ -412,6 +413,13 @@ class DevBuf:
         arr = np.ascontiguousarray(arr)
         assert offset_bytes + arr.nbytes <= self.nbytes
         _check(_lib.kh_dev_upload(C.c_void_p(self.ptr + offset_bytes), arr.ctypes.data_as(C.c_void_p), arr.nbytes))
+
+    def upload_2d(self, offset_bytes: int, dst_pitch: int, arr2d):
+        """arr2d: (rows, ...) C-contiguous; row r goes to offset_bytes + r * dst_pitch."""
+        a = np.ascontiguousarray(arr2d)
+        rows = a.shape[0]; width = a.nbytes // rows
+        assert offset_bytes + (rows - 1) * dst_pitch + width <= self.nbytes
+        _check(_lib.kh_dev_upload_2d(C.c_void_p(self.ptr + offset_bytes), dst_pitch, a.ctypes.data_as(C.c_void_p), width, width, rows))
 
     def download_at(self, offset_bytes: int, shape, dtype=np.uint64):
         out = np.empty(shape, dtype=dtype)

@@ -254,9 +254,8 @@ def create_proof(ix: ProverIndex, witness, rng, timings=None, check: bool = True
         if wit.shape[1] + ZK_ROWS < n:
             ev.zero()
         zk = F.limbs_many([F.rand(rng) for _ in range(COLUMNS * ZK_ROWS)]).reshape(COLUMNS, ZK_ROWS, 4)
-        for c in range(COLUMNS):
-            ev.upload_at(c * NB, wit[c])
-            ev.upload_at(c * NB + (n - ZK_ROWS) * 32, zk[c])
+        ev.upload_2d(0, NB, wit)                             # 15 columns, each into its padded device column, one transfer
+        ev.upload_2d((n - ZK_ROWS) * 32, NB, zk)
     else:
         khip.dev_copy(ev.ptr, witness_on_device.ptr, COLUMNS * NB)
     mark("witness_upload")
