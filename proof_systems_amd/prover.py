@@ -274,7 +274,11 @@ def create_proof(ix: ProverIndex, witness, rng, timings=None, check: bool = True
     else:
         fq.absorb_g(ix.h.copy().reshape(1, 8))              # zero public polynomial: commit_non_hiding -> [0], masked with 1 -> h
     # ---- witness commitments (commit_evaluations_non_hiding x 15 in one batched MSM over the Lagrange basis) + blinders
-    com, inf = srs.msm_batch_dev(ev.ptr, n, COLUMNS, basis=logn)
+    tk = srs.msm_submit(ev.ptr, n, COLUMNS, basis=logn)       # ... while the columns are interpolated on the main stream (both only read `ev`)
+    cf = khip.DevBuf(16 * NB)                               # coefficient forms [w | z]
+    khip.dev_copy(cf.ptr, ev.ptr, COLUMNS * NB)
+    khip.ntt_dev(fid, cf, logn, True, COLUMNS)
+    com, inf = srs.msm_wait(tk)
     w_blind = [F.rand(rng) for _ in range(COLUMNS)]
     w_comm, w_inf = srs.mask_custom(com, inf, F.limbs_many(w_blind))
     fq.absorb_g(w_comm, w_inf)
@@ -299,9 +303,6 @@ def create_proof(ix: ProverIndex, witness, rng, timings=None, check: bool = True
             s_blind.append(bl_); s_comm.append((com[0], bool(inf[0])))
         lkp = {"jc": jc, "d_table": d_table, "d_sorted": d_sorted, "s_blind": s_blind, "s_comm": s_comm}
     mark("witness_commit")
-    cf = khip.DevBuf(16 * NB)                               # coefficient forms [w | z]
-    khip.dev_copy(cf.ptr, ev.ptr, COLUMNS * NB)
-    khip.ntt_dev(fid, cf, logn, True, COLUMNS)
     beta = F.value(fq.challenge_field()); gamma = F.value(fq.challenge_field())
     if lkp is not None:                                     # prover.rs:635-673: the lookup aggregation, committed before z
         d_agg = LK.aggregation_dev(LI, [ev.view(i * NB) for i in range(COLUMNS)], lkp["d_sorted"], lkp["d_table"], lkp["jc"], beta, gamma, rng)
@@ -332,14 +333,7 @@ def create_proof(ix: ProverIndex, witness, rng, timings=None, check: bool = True
     khip.dev_copy(cf.ptr + COLUMNS * NB, zcol.ptr, NB)
     khip.ntt_dev(fid, cf.view(COLUMNS * NB), logn, True, 1)
     zc = cf.view(COLUMNS * NB)
-    com, inf = srs.msm_batch_dev(zc.ptr, n, 1)
-    z_blind = F.rand(rng)
-    z_comm, z_inf = srs.mask_custom(com, inf, F.limbs_many([z_blind]))
-    fq.absorb_g(z_comm, z_inf)
-    mark("z")
-    alpha = scalar_challenge(curve, F, fq.challenge())
-    alphas = [pow(alpha, ALPHA_PERM0 + i, F.p) for i in range(3)]
-    # ---- 8x extension of w and z, constraint rows, quotient
+    tk = srs.msm_submit(zc.ptr, n, 1)                       # the commitment to z runs while w and z are extended to d8 (no challenge needed for that)
     e8 = khip.DevBuf(16 * 8 * NB)
     N8 = 8 * NB
     if lkp is None and not (ix.live_gate_types & set(ix.GATE_TYPES)):
@@ -348,6 +342,14 @@ def create_proof(ix: ProverIndex, witness, rng, timings=None, check: bool = True
         khip.lde_dev(fid, cf.view(COLUMNS * NB), logn, 3, e8.view(COLUMNS * N8), 1)
     else:
         khip.lde_dev(fid, cf, logn, 3, e8, 16)
+    com, inf = srs.msm_wait(tk)
+    z_blind = F.rand(rng)
+    z_comm, z_inf = srs.mask_custom(com, inf, F.limbs_many([z_blind]))
+    fq.absorb_g(z_comm, z_inf)
+    mark("z")
+    alpha = scalar_challenge(curve, F, fq.challenge())
+    alphas = [pow(alpha, ALPHA_PERM0 + i, F.p) for i in range(3)]
+    # ---- 8x extension of w and z, constraint rows, quotient
     gen_cols = [e8.view(i * N8) for i in range(6)] + [ix.col8(i) for i in range(10)] + [ix.col8(COLUMNS)]
     t4 = khip.DevBuf(4 * NB); t8 = khip.DevBuf(N8)
     khip.expr_evaluations_dev(fid, OP.generic_gate_tokens(0, 6, 16, 0, 1), gen_cols, [8 * n] * 17, F.limbs_many([1, alpha]), 4 * n, t4, stride=2, next_shift=8)
