@@ -50,6 +50,9 @@ DeviceScope::DeviceScope(int device) : prev(tl_dev) {
 DeviceScope::~DeviceScope() { tl_dev = prev; }
 
 static int do_init(int device_id) {
+    if (!(__builtin_cpu_supports("bmi2") && __builtin_cpu_supports("adx"))) {      // the host code is built with -mbmi2 -madx (__graft_entry__.py)
+        set_error("this build needs a host CPU with BMI2 and ADX"); return KH_E_DEVICE;
+    }
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
     if (e != hipSuccess || count <= 0) {

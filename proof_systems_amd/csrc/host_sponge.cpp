@@ -33,7 +33,7 @@ template <int FID> struct FastPerm {
     static constexpr u64 P1 = FID == 0 ? 0x224698fc094cf91bULL : 0x224698fc0994a8ddULL;
     static constexpr u64 INV = FID == 0 ? 0x992d30ecffffffffULL : 0x8c46eb20ffffffffULL;
     static constexpr u64 D0 = P0 << 1, D1 = (P1 << 1) | (P0 >> 63), D2 = P1 >> 63, D3 = 0x8000000000000000ULL;   // 2p
-    static inline void mul_wide(const u64 a[4], const u64 b[4], u64 t[8]) {
+    static inline __attribute__((always_inline)) void mul_wide(const u64 a[4], const u64 b[4], u64 t[8]) {
         u128 c = (u128)a[0] * b[0]; t[0] = (u64)c; c >>= 64;
         c += (u128)a[1] * b[0]; t[1] = (u64)c; c >>= 64;
         c += (u128)a[2] * b[0]; t[2] = (u64)c; c >>= 64;
@@ -46,7 +46,7 @@ template <int FID> struct FastPerm {
             c += (u128)a[3] * b[i] + t[i + 3]; t[i + 3] = (u64)c; t[i + 4] = (u64)(c >> 64);
         }
     }
-    static inline void sqr_wide(const u64 a[4], u64 t[8]) {
+    static inline __attribute__((always_inline)) void sqr_wide(const u64 a[4], u64 t[8]) {
         // off-diagonal products
         u128 c = (u128)a[0] * a[1]; u64 o1 = (u64)c; c >>= 64;
         c += (u128)a[0] * a[2]; u64 o2 = (u64)c; c >>= 64;
@@ -69,7 +69,7 @@ template <int FID> struct FastPerm {
         c += o7; t[7] = (u64)c;
     }
     // t / 2^256 mod p, in [0, t / 2^256 + p)
-    static inline void redc(u64 t[8], u64 r[4]) {
+    static inline __attribute__((always_inline)) void redc(u64 t[8], u64 r[4]) {
         u64 pc = 0;
 #pragma GCC unroll 4
         for (int i = 0; i < 4; i++) {
@@ -82,19 +82,26 @@ template <int FID> struct FastPerm {
         }
         r[0] = t[4]; r[1] = t[5]; r[2] = t[6]; r[3] = t[7];
     }
-    static inline void pow7(const u64 x[4], u64 out[4]) {
+    static inline __attribute__((always_inline)) void pow7(const u64 x[4], u64 out[4]) {
         u64 t[8], x2[4], x4[4], x6[4];
         sqr_wide(x, t); redc(t, x2);
         sqr_wide(x2, t); redc(t, x4);
         mul_wide(x4, x2, t); redc(t, x6);
         mul_wide(x6, x, t); redc(t, out);
     }
-    static inline void add8(u64 t[8], const u64 o[8]) {
+    static inline __attribute__((always_inline)) void add8(u64 t[8], const u64 o[8]) {
         u128 c = 0;
 #pragma GCC unroll 8
         for (int i = 0; i < 8; i++) { c += (u128)t[i] + o[i]; t[i] = (u64)c; c >>= 64; }
     }
+    // Two builds of the same body: with BMI2 / ADX (mulx keeps the flags out of the multiply chains: 20 against 26 us per permutation
+    // on the build host, same source) when the CPU has them -- checked at run time, so the library still loads anywhere.
+    __attribute__((target("bmi2,adx"))) static void permute_mulx(fe s[3], const fe mds[3][3], const fe rc[55][3]) { permute_body(s, mds, rc); }
     static void permute(fe s[3], const fe mds[3][3], const fe rc[55][3]) {
+        static const bool mulx = __builtin_cpu_supports("bmi2") && __builtin_cpu_supports("adx");
+        if (mulx) permute_mulx(s, mds, rc); else permute_body(s, mds, rc);
+    }
+    static inline __attribute__((always_inline)) void permute_body(fe s[3], const fe mds[3][3], const fe rc[55][3]) {
         u64 x[3][4];
         for (int i = 0; i < 3; i++) for (int k = 0; k < 4; k++) x[i][k] = s[i].l[k];
         for (int r = 0; r < 55; r++) {
