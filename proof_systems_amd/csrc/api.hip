@@ -1263,13 +1263,22 @@ int kh_ipa_open(kh_srs_t* srs, const uint64_t* a_dev, size_t a_len, const uint64
     struct Guard { kh_ipa_t* s; ~Guard() { kh_ipa_free(s); } } guard{st};
     khost::fe r_prime = fe_of(blinding_factor);
     const auto tp1 = std::chrono::steady_clock::now();
+    double t_lr = 0, t_sponge = 0, t_fold = 0;
     for (size_t r = 0; r < rounds; r++) {
         const uint64_t* rl = blinders + 8 * r; const uint64_t* rr = rl + 4;
+        const auto q0 = std::chrono::steady_clock::now();
         if ((rc = kh_ipa_round_lr(st, rl, rr, lr_xy + 16 * r, lr_inf + 2 * r))) return rc;
+        const auto q1 = std::chrono::steady_clock::now();
         if ((rc = kh_sponge_absorb_g(sponge, lr_xy + 16 * r, lr_inf + 2 * r, 2))) return rc;
         uint64_t chal[2], u[4], ui[4];
         if ((rc = kh_sponge_challenge(sponge, chal))) return rc;
+        const auto q2 = std::chrono::steady_clock::now();
         if ((rc = kh_ipa_round_fold(st, chal, u, ui))) return rc;
+        if (ipa_timing) {
+            const auto q3 = std::chrono::steady_clock::now();
+            t_lr += std::chrono::duration<double, std::micro>(q1 - q0).count(); t_sponge += std::chrono::duration<double, std::micro>(q2 - q1).count();
+            t_fold += std::chrono::duration<double, std::micro>(q3 - q2).count();
+        }
         r_prime = SF.add(r_prime, SF.add(SF.mul(fe_of(rl), fe_of(ui)), SF.mul(fe_of(rr), fe_of(u))));       // ipa.rs:1021-1027
     }
     const auto tp2 = std::chrono::steady_clock::now();
@@ -1292,8 +1301,8 @@ int kh_ipa_open(kh_srs_t* srs, const uint64_t* a_dev, size_t a_len, const uint64
     memcpy(z1, &z1v, 32); memcpy(z2, &z2v, 32);
     if (ipa_timing) {
         auto us = [](std::chrono::steady_clock::time_point x, std::chrono::steady_clock::time_point y) { return std::chrono::duration<double, std::micro>(y - x).count(); };
-        fprintf(stderr, "kh_ipa_open: begin %.0f us, %zu rounds %.0f us, sg %.0f us, delta / z1 / z2 %.0f us\n", us(tp0, tp1), rounds, us(tp1, tp2), us(tp2, tp3),
-                us(tp3, std::chrono::steady_clock::now()));
+        fprintf(stderr, "kh_ipa_open: begin %.0f us, %zu rounds %.0f us (per round: launch + wait + finish %.0f, sponge %.0f, to_field + inverse %.0f), sg %.0f us, delta / z1 / z2 %.0f us\n",
+                us(tp0, tp1), rounds, us(tp1, tp2), t_lr / rounds, t_sponge / rounds, t_fold / rounds, us(tp2, tp3), us(tp3, std::chrono::steady_clock::now()));
     }
     return KH_OK;
 }
