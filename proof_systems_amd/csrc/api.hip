@@ -127,6 +127,7 @@ struct kh_srs {
     // SRS::mask_custom is one scalar multiplication by h per chunk (ipa.rs:605-622) -- 32 additions instead of 255
     // doublings + ~128 additions (a proof masks 23 commitments: 3.5 ms of host time otherwise)
     std::vector<khost::xyzz> h_table;
+    std::vector<uint64_t> h_multiples;     // 2^(c w) * h for the W windows (affine, 8 words each): slots of the opening's MSMs
     std::mutex h_mu;
     std::map<unsigned, std::vector<std::unique_ptr<LagrangeChunk>>> lagrange;
     ~kh_srs() { if (ipa_ev) (void)hipEventDestroy(ipa_ev); }      // the DevBufs free themselves
@@ -707,7 +708,7 @@ int kh_srs_set_blinding_base(kh_srs_t* srs, const uint64_t h_xy[8]) {
     KH_REQUIRE(srs && h_xy, "null argument");
     std::lock_guard<std::mutex> lk(srs->h_mu);
     memcpy(srs->h, h_xy, 64);
-    srs->h_table.clear();
+    srs->h_table.clear(); srs->h_multiples.clear();
     return KH_OK;
 }
 int kh_srs_get_blinding_base(const kh_srs_t* srs, uint64_t h_xy[8]) {
@@ -1080,6 +1081,7 @@ struct kh_ipa {
     bool pending = false;                 // a recorded, not yet applied fold (kh_ipa_round_fold): the next round's step kernel applies it
     uint64_t u_p[4] = {0, 0, 0, 0}, ui_p[4] = {0, 0, 0, 0};
     size_t partial_words = 0;             // u64 words of `partial` before the step kernel's block counter
+    std::vector<uint64_t> tab;            // H / U window multiples staged for the asynchronous upload of kh_ipa_begin
 };
 
 static int ipa_begin_common(kh_srs_t* srs, const uint64_t* a, size_t a_len, const uint64_t* b, size_t b_len, const uint64_t u_base_xy[8], kh_ipa_t** out,
@@ -1120,19 +1122,24 @@ static int ipa_begin_common(kh_srs_t* srs, const uint64_t* a, size_t a_len, cons
     st->a = srs->ipa_a; st->b = srs->ipa_b; st->coef = srs->ipa_coef; st->sc = &srs->ipa_sc; st->partial = &srs->ipa_partial; st->ev = srs->ipa_ev; st->partial_words = partial_bytes / 8;
     // H and U into the two extra slots of every window table
     const int W = srs->g_precomp_c ? (256 + srs->g_precomp_c - 1) / srs->g_precomp_c : 1;
-    std::vector<uint64_t> tab((size_t)W * 16), col((size_t)W * 8);
-    host_window_multiples(srs->curve, srs->h, W, srs->g_precomp_c, col.data());
-    for (int w = 0; w < W; w++) memcpy(&tab[16 * w], &col[8 * w], 64);
+    std::vector<uint64_t>& tab = st->tab;                  // lives as long as the opening: no synchronisation before returning
+    std::vector<uint64_t> col((size_t)W * 8);
+    tab.resize((size_t)W * 16);
+    if (srs->h_multiples.size() != (size_t)W * 8) {        // H is the SRS's: its window multiples are computed once
+        srs->h_multiples.resize((size_t)W * 8);
+        host_window_multiples(srs->curve, srs->h, W, srs->g_precomp_c, srs->h_multiples.data());
+    }
+    for (int w = 0; w < W; w++) memcpy(&tab[16 * w], &srs->h_multiples[8 * w], 64);
     host_window_multiples(srs->curve, u_base_xy, W, srs->g_precomp_c, col.data());
     for (int w = 0; w < W; w++) memcpy(&tab[16 * w + 8], &col[8 * w], 64);
     hipStream_t s = C.stream;
     KH_HIP(hipMemcpy2DAsync((char*)srs->g.p + n * 64, srs->g_stride * 64, tab.data(), 128, 128, W, hipMemcpyHostToDevice, s));
-    KH_HIP(hipMemsetAsync(st->a[0].p, 0, n * 32, s));
+    if (a_len < n) KH_HIP(hipMemsetAsync((char*)st->a[0].p + a_len * 32, 0, (n - a_len) * 32, s));
     KH_HIP(hipMemcpyAsync(st->a[0].p, a, a_len * 32, kind, s));
     KH_HIP(hipMemcpyAsync(st->b[0].p, b, n * 32, kind, s));
-    const khost::fe one = khost::field(st->field).one;
-    KH_HIP(hipMemcpyAsync(st->coef[0].p, &one, 32, hipMemcpyHostToDevice, s));
-    KH_HIP(hipStreamSynchronize(s));                       // the staging vectors above are locals
+    static const khost::fe ones[2] = {khost::field(0).one, khost::field(1).one};
+    KH_HIP(hipMemcpyAsync(st->coef[0].p, &ones[st->field & 1], 32, hipMemcpyHostToDevice, s));
+    if (kind != hipMemcpyDeviceToDevice) KH_HIP(hipStreamSynchronize(s));      // host inputs may be the caller's temporaries
     KH_HIP(hipEventRecord(st->ev, s));
     srs->ipa_live = true;
     *out = st.release();
@@ -1259,6 +1266,7 @@ int kh_ipa_open(kh_srs_t* srs, const uint64_t* a_dev, size_t a_len, const uint64
     int rc = kh_sponge_squeeze_field(sponge, t); if (rc) return rc;
     if ((rc = kh_group_map_to_group(curve, t, u_base))) return rc;
     kh_ipa_t* st = nullptr;
+    const auto tp_map = std::chrono::steady_clock::now();
     if ((rc = kh_ipa_begin_dev(srs, a_dev, a_len, b_dev, b_len, u_base, &st))) return rc;
     struct Guard { kh_ipa_t* s; ~Guard() { kh_ipa_free(s); } } guard{st};
     khost::fe r_prime = fe_of(blinding_factor);
@@ -1287,12 +1295,24 @@ int kh_ipa_open(kh_srs_t* srs, const uint64_t* a_dev, size_t a_len, const uint64
     const auto tp3 = std::chrono::steady_clock::now();
     // delta = (g0 + [b0] U) * d + [r_delta] H  (ipa.rs:1036-1041), on the host: three scalar multiplications
     const khost::fe d = fe_of(blinders + 8 * rounds), r_delta = fe_of(blinders + 8 * rounds + 4);
-    khost::xyzz acc = crv.identity();
-    if (!*sg_inf) { khost::aff g0; memcpy(&g0, sg_xy, 64); acc = crv.mul_plain(crv.from_affine(g0), SF.from_mont(d)); }
-    { khost::aff ub; memcpy(&ub, u_base, 64); acc = crv.add(acc, crv.mul_plain(crv.from_affine(ub), SF.from_mont(SF.mul(fe_of(b0), d)))); }
-    { khost::aff hh; memcpy(&hh, srs->h, 64); acc = crv.add(acc, crv.mul_plain(crv.from_affine(hh), SF.from_mont(r_delta))); }
-    khost::aff da; const bool dinf = crv.to_affine(acc, da);
-    memcpy(delta_xy, &da, 64); *delta_inf = dinf ? 1 : 0;
+    // [d] g0 + [b0 d] U by one joint double-and-add (Shamir's trick: 256 doublings shared), then + [r_delta] H through the fixed-base
+    // table of kh_mask_custom (32 additions): 0.19 -> 0.09 ms against three separate 255-bit ladders
+    {
+        const khost::fe k1 = SF.from_mont(d), k2 = SF.from_mont(SF.mul(fe_of(b0), d));
+        khost::aff ub; memcpy(&ub, u_base, 64);
+        const khost::xyzz P2 = crv.from_affine(ub);
+        khost::xyzz P1 = crv.identity(), P12 = P2;
+        if (!*sg_inf) { khost::aff g0; memcpy(&g0, sg_xy, 64); P1 = crv.from_affine(g0); P12 = crv.add(P1, P2); }
+        khost::xyzz acc = crv.identity();
+        for (int i = 255; i >= 0; i--) {
+            acc = crv.dbl(acc);
+            const int b1 = (int)((k1.l[i >> 6] >> (i & 63)) & 1) & (*sg_inf ? 0 : 1), b2 = (int)((k2.l[i >> 6] >> (i & 63)) & 1);
+            if (b1 && b2) acc = crv.add(acc, P12); else if (b1) acc = crv.add(acc, P1); else if (b2) acc = crv.add(acc, P2);
+        }
+        khost::aff pa; const bool pinf = crv.to_affine(acc, pa);
+        uint64_t pxy[8]; uint8_t pi = pinf ? 1 : 0; memset(pxy, 0, 64); if (!pinf) memcpy(pxy, &pa, 64);
+        if ((rc = kh_mask_custom(srs, pxy, &pi, 1, r_delta.l, 1, delta_xy, delta_inf))) return rc;
+    }
     if ((rc = kh_sponge_absorb_g(sponge, delta_xy, delta_inf, 1))) return rc;
     uint64_t cc[2], c[4];
     if ((rc = kh_sponge_challenge(sponge, cc))) return rc;
@@ -1301,8 +1321,8 @@ int kh_ipa_open(kh_srs_t* srs, const uint64_t* a_dev, size_t a_len, const uint64
     memcpy(z1, &z1v, 32); memcpy(z2, &z2v, 32);
     if (ipa_timing) {
         auto us = [](std::chrono::steady_clock::time_point x, std::chrono::steady_clock::time_point y) { return std::chrono::duration<double, std::micro>(y - x).count(); };
-        fprintf(stderr, "kh_ipa_open: begin %.0f us, %zu rounds %.0f us (per round: launch + wait + finish %.0f, sponge %.0f, to_field + inverse %.0f), sg %.0f us, delta / z1 / z2 %.0f us\n",
-                us(tp0, tp1), rounds, us(tp1, tp2), t_lr / rounds, t_sponge / rounds, t_fold / rounds, us(tp2, tp3), us(tp3, std::chrono::steady_clock::now()));
+        fprintf(stderr, "kh_ipa_open: begin %.0f us (of which shift + squeeze + to_group %.0f), %zu rounds %.0f us (per round: launch + wait + finish %.0f, sponge %.0f, to_field + inverse %.0f), sg %.0f us, delta / z1 / z2 %.0f us\n",
+                us(tp0, tp1), us(tp0, tp_map), rounds, us(tp1, tp2), t_lr / rounds, t_sponge / rounds, t_fold / rounds, us(tp2, tp3), us(tp3, std::chrono::steady_clock::now()));
     }
     return KH_OK;
 }
