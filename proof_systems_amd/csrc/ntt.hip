@@ -9,12 +9,16 @@
 // is a multi-pass decimation-in-frequency decomposition built for the MI355X:
 //
 //   N = R_1 * R_2 * ... * R_P  (each R <= 256).  Pass p runs R_p-point sub-transforms on
-//   tiles of T columns staged in LDS (R*T = 2048 elements = 64 KiB, limb-plane SoA so every
-//   LDS access is a conflict-free ds_read/write_b64), radix-2 butterflies with stage twiddles
-//   read from LDS, then multiplies by the inter-pass twiddle w_L^(b*k) on the way out.
+//   tiles of T columns (R*T = 1024 elements, four per thread).  A thread keeps its four elements
+//   in registers and does two radix-2 stages per step; between steps the tile goes through LDS
+//   (32 KiB, limb-plane SoA so every access is a conflict-free ds_read/write_b64); the first
+//   step loads straight from global memory and the last stores straight to it, multiplying by
+//   the inter-pass twiddle w_L^(b*k) on the way out.  Stage twiddles are read from LDS.
 //   Global accesses are T*32-byte contiguous runs.  Positions after the passes are
 //   digit-reversed; the LAST pass undoes that while writing (its tiles take T rows with
 //   consecutive top digit so the natural-order stores are T*32-byte runs too).
+//   An inverse transform of two or more passes carries its 1/N in the first pass's inter-pass
+//   twiddles (a second, scaled table), so the scaling costs no product of its own.
 //   The low-degree extension n -> n*2^b is the same machinery with a virtual first digit
 //   (the coset index r): the first pass reads the n coefficients and multiplies by
 //   w_(n 2^b)^(i*r) while loading, so the zero-padded 7/8 of the input never exists in HBM.
@@ -28,16 +32,19 @@
 
 namespace kh {
 
-static constexpr int NTT_THREADS = 512;
-static constexpr int NTT_LOG_TILE = 11;                 // R*T = 2048 elements per workgroup
+// 2^10 elements (32 KiB of LDS) and 256 threads per workgroup: four workgroups per CU.  The butterflies are VALU-bound, so a pass
+// lasts as long as the busiest CU's share, ceil(tiles / CUs) tiles; against 2^11-element tiles the finer grain wins where the tile
+// count is a small multiple of the CU count (19 columns of 2^16: 0.131 -> 0.116 ms) and ties elsewhere (2^22: 0.512 vs 0.509 ms).
+static constexpr int NTT_THREADS = 256;
+static constexpr int NTT_LOG_TILE = 10;                 // R*T elements per workgroup = 4 per thread
 static constexpr int NTT_MAX_LOGR = 8;
 
 struct PassArgs {
-    const u64* src; u64* dst; const u64* tw;
+    const u64* src; u64* dst; const u64* tw; const u64* tw_out;
     u32 log_ntot, log_n, log_blow, log_L, log_R, log_T;
-    u32 first, last, src_is_coeffs, scale;
+    u32 first, last, src_is_coeffs, scale, scale_out;
     u32 nd; u32 dig[6];          // last pass: log-sizes of the row-index digits, most significant first
-    u32 inv_n[8];                // N^-1 (Montgomery), used when scale != 0
+    u32 inv_n[8];                // N^-1 (Montgomery), used when scale or scale_out is set
     u64 batch;
 };
 
@@ -65,8 +72,12 @@ __device__ __forceinline__ Fe<F> tw_get(const u64* tw, u32 log_ntot, u64 e) {
 }
 __device__ __forceinline__ u32 bitrev(u32 x, u32 bits) { return bits ? (__brev(x) >> (32 - bits)) : 0u; }
 
-template <class F>
-__global__ void __launch_bounds__(NTT_THREADS)
+// One workgroup transforms a tile of T columns x R points.  Every thread owns FOUR elements per step and keeps them in
+// registers: a step is two radix-2 stages (a radix-4 butterfly on the quad {lo, lo+q, lo+2q, lo+3q}), or a single stage on two
+// pairs when the stage count is odd (taken first).  The first step reads its quad straight from global memory and the last one
+// stores straight to it, so a pass of 8 stages makes 3 trips through LDS and 3 barriers instead of 9 and 9.
+template <class F, int THREADS>
+__global__ void __launch_bounds__(THREADS)
 k_ntt_pass(PassArgs A) {
     extern __shared__ u64 lds[];
     const u32 R = 1u << A.log_R, T = 1u << A.log_T, RT = R * T;
@@ -80,8 +91,8 @@ k_ntt_pass(PassArgs A) {
     // ---- decode the tile
     u64 tile = blockIdx.x;
     u64 batch_idx = 0, k0 = 0, sa = 0, bt = 0, rest = 0, dt = 0, Mrows = 1;
-    bool row_mode = A.last != 0;
-    bool flat_rows = row_mode && A.nd == 0;          // single pass, no virtual digit: tiles run across the batch
+    const bool row_mode = A.last != 0;
+    const bool flat_rows = row_mode && A.nd == 0;          // single pass, no virtual digit: tiles run across the batch
     if (!row_mode) {
         u64 tiles_per_item = ntot >> (A.log_R + A.log_T);
         batch_idx = tile / tiles_per_item; u64 r = tile % tiles_per_item;
@@ -99,81 +110,189 @@ k_ntt_pass(PassArgs A) {
     const u64 total_rows_flat = A.batch;             // flat mode: one row per batch item
 
     // ---- stage twiddles w_R^i = w_Ntot^(i * Ntot/R), i < R/2
-    for (u32 i = tid; i < R / 2; i += NTT_THREADS) {
+    for (u32 i = tid; i < R / 2; i += THREADS) {
         Fe<F> w = Fe<F>::load(A.tw + 4 * ((u64)i << (A.log_ntot - A.log_R)));
         lds_put<F>(twl, R / 2, i, w);
     }
-    // ---- load the tile: LDS index n1*T + t
-    for (u32 idx = tid; idx < RT; idx += NTT_THREADS) {
-        u32 n1 = idx >> A.log_T, t = idx & (T - 1);
-        Fe<F> x;
-        if (!row_mode) {
-            u64 inner = sa * ((u64)1 << A.log_L) + (u64)n1 * B + bt * T + t;     // position inside the inner NTT
-            u64 spos = A.src_is_coeffs ? (batch_idx * n + inner) : (batch_idx * ntot + k0 * n + inner);
-            x = Fe<F>::load(A.src + 4 * spos);
-            if (A.first && A.log_blow && k0) x = mul<F>(x, tw_get<F>(A.tw, A.log_ntot, inner * k0));
-        } else if (flat_rows) {
-            u64 g = tile * T + t;
-            if (g < total_rows_flat) x = Fe<F>::load(A.src + 4 * (g * R + n1)); else x = Fe<F>::zero();
-        } else {
-            u64 a = (dt * T + t) * Mrows + rest;                                   // row index, top digit = dt*T+t
-            u64 kk0 = A.log_blow ? (a >> (A.log_n - A.log_R)) : 0;                 // virtual digit of this row
-            u64 inner = (A.log_blow ? (a & ((n >> A.log_R) - 1)) : a) * R + n1;    // position inside the inner NTT
-            u64 spos = A.src_is_coeffs ? (batch_idx * n + inner) : (batch_idx * ntot + a * R + n1);
-            x = Fe<F>::load(A.src + 4 * spos);
-            if (A.first && A.log_blow && kk0) x = mul<F>(x, tw_get<F>(A.tw, A.log_ntot, inner * kk0));
-        }
-        lds_put<F>(data, RT, idx, x);
-    }
-    __syncthreads();
-    // ---- radix-2 DIF stages inside LDS
-    for (u32 lh = A.log_R; lh-- > 0;) {
+
+    // ---- the four elements of this thread (LDS index n1*T + t) for the first step
+    const u32 nq = RT >= 4 ? RT / 4 : 1;
+    const bool active = tid < nq;
+    int lh = (int)A.log_R - 1;                       // upper stage of the coming step
+    const bool odd = (A.log_R & 1) != 0;
+    u32 li[4];
+    bool ok01 = active, ok23 = active;
+    if (odd) {                                       // two pairs of stage lh: (lo, lo+h)
         const u32 h = 1u << lh;
-        for (u32 pi = tid; pi < RT / 2; pi += NTT_THREADS) {
-            u32 t = pi & (T - 1), pr = pi >> A.log_T;          // pair index within the column
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+            u32 pi = tid + p * nq;
+            u32 t = pi & (T - 1), pr = pi >> A.log_T;
             u32 i = pr & (h - 1), grp = pr >> lh;
             u32 lo = (grp << (lh + 1)) + i;
-            u32 ia = lo * T + t, ib = (lo + h) * T + t;
-            Fe<F> u = lds_get<F>(data, RT, ia), v = lds_get<F>(data, RT, ib);
-            Fe<F> s = add<F>(u, v), d = sub<F>(u, v);
-            if (i) d = mul<F>(d, lds_get<F>(twl, R / 2, i << (A.log_R - 1 - lh)));
-            lds_put<F>(data, RT, ia, s);
-            lds_put<F>(data, RT, ib, d);
+            li[2 * p] = lo * T + t; li[2 * p + 1] = (lo + h) * T + t;
         }
-        __syncthreads();
-    }
-    // ---- write out (LDS position bitrev(k) holds output k)
-    Fe<F> invn;
+        ok01 = active && tid < RT / 2;
+        ok23 = active && tid + nq < RT / 2;
+    } else {
+        const u32 q = 1u << (lh - 1);
+        u32 t = tid & (T - 1), pr = tid >> A.log_T;
+        u32 i = pr & (q - 1), grp = pr >> (lh - 1);
+        u32 lo = (grp << (lh + 1)) + i;
 #pragma unroll
-    for (int i = 0; i < 8; i++) invn.v[i] = A.inv_n[i];
-    for (u32 idx = tid; idx < RT; idx += NTT_THREADS) {
-        u32 k1 = idx >> A.log_T, t = idx & (T - 1);
-        Fe<F> x = lds_get<F>(data, RT, bitrev(k1, A.log_R) * T + t);
-        if (!row_mode) {
+        for (int j = 0; j < 4; j++) li[j] = (lo + j * q) * T + t;
+    }
+
+    // ---- load them (all four loads issued before anything waits on one)
+    Fe<F> x[4];
+    u64 ex[4];                                        // exponent of the extension's coset twiddle (0 = none)
+    {
+        u64 spos[4]; bool have[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const u32 n1 = li[j] >> A.log_T, t = li[j] & (T - 1);
+            have[j] = j < 2 ? ok01 : ok23; ex[j] = 0;
+            if (!row_mode) {
+                u64 inner = sa * ((u64)1 << A.log_L) + (u64)n1 * B + bt * T + t;     // position inside the inner NTT
+                spos[j] = A.src_is_coeffs ? (batch_idx * n + inner) : (batch_idx * ntot + k0 * n + inner);
+                ex[j] = inner * k0;
+            } else if (flat_rows) {
+                u64 g = tile * T + t;
+                have[j] = have[j] && g < total_rows_flat;
+                spos[j] = g * R + n1;
+            } else {
+                u64 a = (dt * T + t) * Mrows + rest;                                   // row index, top digit = dt*T+t
+                u64 kk0 = A.log_blow ? (a >> (A.log_n - A.log_R)) : 0;                 // virtual digit of this row
+                u64 inner = (A.log_blow ? (a & ((n >> A.log_R) - 1)) : a) * R + n1;    // position inside the inner NTT
+                spos[j] = A.src_is_coeffs ? (batch_idx * n + inner) : (batch_idx * ntot + a * R + n1);
+                ex[j] = inner * kk0;
+            }
+            if (!have[j]) spos[j] = 0;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) x[j] = Fe<F>::load(A.src + 4 * spos[j]);
+#pragma unroll
+        for (int j = 0; j < 4; j++) if (!have[j]) x[j] = Fe<F>::zero();
+    }
+    if (A.first && A.log_blow) {
+        Fe<F> w[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) w[j] = tw_get<F>(A.tw, A.log_ntot, ex[j]);
+#pragma unroll
+        for (int j = 0; j < 4; j++) if (ex[j]) x[j] = mul<F>(x[j], w[j]);
+    }
+    __syncthreads();                                 // stage twiddles are in LDS
+
+    // ---- the stages (decimation in frequency)
+    if (odd) {
+        if (active) {
+            const u32 h = 1u << lh, sh = A.log_R - 1 - lh;
+#pragma unroll
+            for (int p = 0; p < 2; p++) {
+                u32 i = (li[2 * p] >> A.log_T) & (h - 1);
+                Fe<F> s = add<F>(x[2 * p], x[2 * p + 1]), d = sub<F>(x[2 * p], x[2 * p + 1]);
+                if (i) d = mul<F>(d, lds_get<F>(twl, R / 2, i << sh));
+                x[2 * p] = s; x[2 * p + 1] = d;
+            }
+        }
+        lh -= 1;
+    }
+    bool fresh = !odd;                               // registers already hold the quad of the coming step
+    while (lh >= 1) {
+        const u32 q = 1u << (lh - 1);
+        if (!fresh) {                                // through LDS to the quads of this step
+            if (active) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) if (j < 2 ? ok01 : ok23) lds_put<F>(data, RT, li[j], x[j]);
+            }
+            __syncthreads();
+            if (active) {
+                u32 t = tid & (T - 1), pr = tid >> A.log_T;
+                u32 i = pr & (q - 1), grp = pr >> (lh - 1);
+                u32 lo = (grp << (lh + 1)) + i;
+#pragma unroll
+                for (int j = 0; j < 4; j++) { li[j] = (lo + j * q) * T + t; x[j] = lds_get<F>(data, RT, li[j]); }
+            }
+            ok01 = ok23 = active;
+        }
+        fresh = false;
+        if (active) {
+            const u32 i = (li[0] >> A.log_T) & (q - 1), sa_ = A.log_R - 1 - lh;
+            // stage lh: pairs (0,2) with twiddle index i and (1,3) with i + q
+            Fe<F> s0 = add<F>(x[0], x[2]), d0 = sub<F>(x[0], x[2]);
+            Fe<F> s1 = add<F>(x[1], x[3]), d1 = sub<F>(x[1], x[3]);
+            d1 = mul<F>(d1, lds_get<F>(twl, R / 2, (i + q) << sa_));
+            if (i) d0 = mul<F>(d0, lds_get<F>(twl, R / 2, i << sa_));
+            // stage lh-1: pairs (0,1) and (2,3), both with twiddle index i
+            x[0] = add<F>(s0, s1); x[1] = sub<F>(s0, s1);
+            x[2] = add<F>(d0, d1); x[3] = sub<F>(d0, d1);
+            if (i) {
+                Fe<F> wb = lds_get<F>(twl, R / 2, i << (sa_ + 1));
+                x[1] = mul<F>(x[1], wb); x[3] = mul<F>(x[3], wb);
+            }
+        }
+        lh -= 2;
+    }
+
+    // ---- write out (position n1 holds output bitrev(n1)); entry 0 of the scaled table is 1/N itself
+    u64 dpos[4]; bool st[4];
+    if (!row_mode) {
+        u64 eo[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const u32 n1 = li[j] >> A.log_T, t = li[j] & (T - 1);
+            const u32 k1 = bitrev(n1, A.log_R);
             u64 b = bt * T + t;
-            if (k1 && b) x = mul<F>(x, tw_get<F>(A.tw, A.log_ntot, ((u64)k1 * b) << (A.log_ntot - A.log_L)));
-            u64 dpos = batch_idx * ntot + k0 * n + sa * ((u64)1 << A.log_L) + (u64)k1 * B + b;
-            x.store(A.dst + 4 * dpos);
-        } else {
-            if (A.scale) x = mul<F>(x, invn);
+            eo[j] = (k1 && b) ? ((u64)k1 * b) << (A.log_ntot - A.log_L) : 0;
+            dpos[j] = batch_idx * ntot + k0 * n + sa * ((u64)1 << A.log_L) + (u64)k1 * B + b;
+            st[j] = j < 2 ? ok01 : ok23;
+        }
+        Fe<F> w[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) w[j] = tw_get<F>(A.tw_out, A.log_ntot, eo[j]);
+#pragma unroll
+        for (int j = 0; j < 4; j++) if (eo[j] || A.scale_out) x[j] = mul<F>(x[j], w[j]);
+    } else {
+        Fe<F> invn;
+#pragma unroll
+        for (int i = 0; i < 8; i++) invn.v[i] = A.inv_n[i];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const u32 n1 = li[j] >> A.log_T, t = li[j] & (T - 1);
+            const u32 k1 = bitrev(n1, A.log_R);
+            st[j] = j < 2 ? ok01 : ok23;
             if (flat_rows) {
                 u64 g = tile * T + t;
-                if (g < total_rows_flat) x.store(A.dst + 4 * (g * R + k1));
+                st[j] = st[j] && g < total_rows_flat;
+                dpos[j] = g * R + k1;
             } else {
                 u64 a = (dt * T + t) * Mrows + rest;
                 // digit-reverse the row index (digits most-significant first in A.dig)
-                u64 rev = 0, wgt = 1, rem = a;
+                u64 rev = 0, wgt = 1;
                 u32 shift = A.log_ntot - A.log_R;
                 for (u32 d = 0; d < A.nd; d++) {
                     shift -= A.dig[d];
-                    u64 digit = (rem >> shift) & (((u64)1 << A.dig[d]) - 1);
+                    u64 digit = (a >> shift) & (((u64)1 << A.dig[d]) - 1);
                     rev += digit * wgt; wgt <<= A.dig[d];
                 }
-                u64 nat = rev + ((u64)k1 << (A.log_ntot - A.log_R));
-                x.store(A.dst + 4 * (batch_idx * ntot + nat));
+                dpos[j] = batch_idx * ntot + rev + ((u64)k1 << (A.log_ntot - A.log_R));
             }
+            if (A.scale) x[j] = mul<F>(x[j], invn);
         }
     }
+#pragma unroll
+    for (int j = 0; j < 4; j++) if (st[j]) x[j].store(A.dst + 4 * dpos[j]);
+}
+
+// tab[e] *= c  (the inverse transform's inter-pass twiddles carry the 1/N)
+template <class F>
+__global__ void k_scale_table(u64* dst, const u64* src, const u32* c8, u64 count) {
+    u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= count) return;
+    Fe<F> c;
+#pragma unroll
+    for (int i = 0; i < 8; i++) c.v[i] = c8[i];
+    mul<F>(Fe<F>::load(src + 4 * e), c).store(dst + 4 * e);
 }
 
 // ---- twiddle table w^e, e < N/2, built on the device from the 2^i-th powers
@@ -188,7 +307,7 @@ __global__ void k_build_twiddles(u64* tw, const u64* pow2 /* w^(2^i), i < 32 */,
 }
 
 struct TwKey { int device; int field; unsigned logn; int inverse; bool operator<(const TwKey& o) const { return std::tie(device, field, logn, inverse) < std::tie(o.device, o.field, o.logn, o.inverse); } };
-struct TwEntry { DevBuf tab; khost::fe inv_n; };
+struct TwEntry { DevBuf tab; DevBuf tab_scaled /* tab * 1/N, built on first use by an inverse transform of two or more passes */; khost::fe inv_n; };
 static std::map<TwKey, TwEntry> g_tw;          // twiddle tables per (device, field, size, direction); guarded by the device context's mutex
 static std::mutex g_tw_mu;                      // ... and this one for the map itself (contexts of different devices share it)
 void ntt_trim(Context& C) {                     // kh_trim: drop this device's tables (rebuilt on demand, ~20 us per table)
@@ -256,9 +375,23 @@ static std::vector<unsigned> split_passes(unsigned log_n) {
 template <class F>
 static int launch_pass(Context& C, const PassArgs& A, u64 tiles) {
     size_t lds = ((size_t)4 << (A.log_R + A.log_T)) * 8 + ((size_t)4 << (A.log_R ? A.log_R - 1 : 0)) * 8;
-    if (C.once(__PRETTY_FUNCTION__)) KH_HIP(hipFuncSetAttribute((const void*)k_ntt_pass<F>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304));
-    hipLaunchKernelGGL((k_ntt_pass<F>), dim3((unsigned)tiles), dim3(NTT_THREADS), lds, C.stream, A);
+    hipLaunchKernelGGL((k_ntt_pass<F, NTT_THREADS>), dim3((unsigned)tiles), dim3(NTT_THREADS), lds, C.stream, A);
     KH_HIP(hipGetLastError());
+    return KH_OK;
+}
+
+static int get_scaled_table(Context& C, int field, unsigned log_ntot, TwEntry* E, const u64** out) {
+    u64 count = log_ntot ? ((u64)1 << (log_ntot - 1)) : 1;
+    if (!E->tab_scaled.p) {
+        int rc = E->tab_scaled.reserve(count * 32 + 32); if (rc) return rc;
+        u32* c8 = (u32*)(E->tab_scaled.as<u64>() + count * 4);
+        KH_HIP(hipMemcpyAsync(c8, &E->inv_n, 32, hipMemcpyHostToDevice, C.stream));      // inv_n lives in the table entry
+        dim3 grid((unsigned)((count + 255) / 256));
+        if (field == KH_FIELD_FP) hipLaunchKernelGGL((k_scale_table<FpParams>), grid, dim3(256), 0, C.stream, E->tab_scaled.as<u64>(), E->tab.as<u64>(), c8, count);
+        else hipLaunchKernelGGL((k_scale_table<FqParams>), grid, dim3(256), 0, C.stream, E->tab_scaled.as<u64>(), E->tab.as<u64>(), c8, count);
+        KH_HIP(hipGetLastError());
+    }
+    *out = E->tab_scaled.as<u64>();
     return KH_OK;
 }
 
@@ -273,13 +406,17 @@ static int transform(Context& C, int field, const u64* src, u64* dst, u64* tmp, 
     std::vector<unsigned> passes = split_passes(log_n);
     const size_t P = passes.size();
     PassArgs A; memset(&A, 0, sizeof(A));
-    A.tw = E->tab.as<u64>(); A.log_ntot = log_ntot; A.log_n = log_n; A.log_blow = log_blow; A.batch = batch;
+    A.tw = E->tab.as<u64>(); A.tw_out = A.tw; A.log_ntot = log_ntot; A.log_n = log_n; A.log_blow = log_blow; A.batch = batch;
     memcpy(A.inv_n, &E->inv_n, 32);
     if (P == 0) {
         // n == 1: each output of the extension equals the single coefficient; plain NTT of size 1 is the identity
         if (log_blow == 0) { if (src != dst) KH_HIP(hipMemcpyAsync(dst, src, batch * 32, hipMemcpyDeviceToDevice, C.stream)); return KH_OK; }
         set_error("kh_lde with n == 1 is not supported"); return KH_E_INVALID;
     }
+    // An inverse transform of two or more passes folds the 1/N into the first pass's inter-pass twiddles (one product per
+    // element less); a single pass scales on the way out.
+    const u64* scaled = nullptr;
+    if (inverse && P >= 2 && (rc = get_scaled_table(C, field, log_ntot, E, &scaled))) return rc;
     // buffer plan: pass 1 reads src; middle passes run in place on tmp; the last pass writes dst.
     unsigned log_L = log_n;
     for (size_t p = 0; p < P; p++) {
@@ -287,7 +424,9 @@ static int transform(Context& C, int field, const u64* src, u64* dst, u64* tmp, 
         A.log_R = passes[p]; A.log_L = log_L;
         A.first = first; A.last = last;
         A.src_is_coeffs = (first && log_blow) ? 1 : 0;
-        A.scale = (last && inverse) ? 1 : 0;
+        A.scale = (last && inverse && !scaled) ? 1 : 0;
+        A.scale_out = (first && scaled) ? 1 : 0;
+        A.tw_out = (first && scaled) ? scaled : A.tw;
         A.src = first ? src : tmp;
         A.dst = last ? dst : tmp;
         unsigned log_T = NTT_LOG_TILE - A.log_R;

@@ -41,44 +41,51 @@ __global__ void k_b_init(const u64* __restrict__ elm, const u64* __restrict__ sc
     for (size_t i = 0; i < k; i++) acc = add<F>(acc, mul<F>(Fe<F>::load(scales + 4 * i), pow_u64<F>(Fe<F>::load(elm + 4 * i), j)));
     acc.store(out + 4 * j);
 }
-// one block per (chunk, point): sum_{j < len} c[j] x^j with thread t running Horner over j = t, t+T, ... in y = x^T
-// (T = 1024: 64 steps for a 2^16-coefficient chunk), then x^t and a block tree.  The chunk table (pointer, length,
-// output slot) lets one launch cover every polynomial of a proof.
-struct ChunkDesc { const u64* ptr; u64 len; u64 out; u64 pstride; };   // result slot = out + point * pstride
+// ---------------------------------------------------------------- chunked evaluation
+// kh_evaluate_chunks(_batch)_dev: the prover's zeta / zeta*omega evaluations (prover.rs:939-1010, PolyComm-chunked).  A chunk is cut
+// into segments; one 256-thread workgroup per (segment, point): thread t runs Horner in y = x^256 down its residue class of the
+// segment, multiplies by x^(segment start + t) -- the product of the host-supplied powers x^(2^k) over the set bits -- and a block
+// tree adds the 256 values.  The host adds the segment values.  A proof's 50 chunks x 2 points used to be 100 workgroups of 1024
+// threads on 100 CUs, each SIMD issuing four 94-product chains (171 us); 800 smaller workgroups spread the same products over the
+// whole chip, and the lone ft polynomial (one chunk, one point: the same 171 us on ONE CU) becomes 32 short segments.
+struct ChunkDesc { const u64* ptr; u64 len; u64 out; u64 start; };   // a segment: `len` coefficients from ptr, value slot `out`, x^start factor
+static constexpr int EVAL_T = 256, EVAL_PW = 40;                     // powers x^(2^k), k < EVAL_PW, per point
 template <class F>
-__global__ void __launch_bounds__(1024)
-k_eval_chunks(const ChunkDesc* __restrict__ tab, const u64* __restrict__ points, u64* __restrict__ out) {
-    __shared__ u32 sh[1024 * 8];
+__global__ void __launch_bounds__(EVAL_T)
+k_eval_chunks(const ChunkDesc* __restrict__ tab, const u64* __restrict__ pw, size_t nseg, u64* __restrict__ out) {
+    __shared__ u32 sh[EVAL_T * 8];
     const ChunkDesc d = tab[blockIdx.x];
     const size_t p = blockIdx.y;
     const size_t len = d.len;
-    const Fe<F> x = Fe<F>::load(points + 4 * p);
-    const u32 T = blockDim.x, t = threadIdx.x;
+    const u64* xp = pw + 4 * EVAL_PW * p;
+    const u32 t = threadIdx.x;
     Fe<F> acc = Fe<F>::zero();
     if (t < len) {
-        const Fe<F> y = pow_u64<F>(x, T);
-        size_t last = t + ((len - 1 - t) / T) * T;           // highest index of this thread's residue class
-        for (size_t j = last;; j -= T) {
+        const Fe<F> y = Fe<F>::load(xp + 4 * 8);             // x^256
+        size_t last = t + ((len - 1 - t) / EVAL_T) * EVAL_T; // highest index of this thread's residue class
+        for (size_t j = last;; j -= EVAL_T) {
             acc = add<F>(mul<F>(acc, y), Fe<F>::load(d.ptr + 4 * j));
-            if (j < T) break;
+            if (j < EVAL_T) break;
         }
-        acc = mul<F>(acc, pow_u64<F>(x, t));
+        u64 e = d.start + t;
+        for (int k = 0; e; k++, e >>= 1)
+            if (e & 1) acc = mul<F>(acc, Fe<F>::load(xp + 4 * k));
     }
 #pragma unroll
-    for (int k = 0; k < 8; k++) sh[k * 1024 + t] = acc.v[k];
+    for (int k = 0; k < 8; k++) sh[k * EVAL_T + t] = acc.v[k];
     __syncthreads();
-    for (int s = 512; s >= 1; s >>= 1) {
+    for (int s = EVAL_T / 2; s >= 1; s >>= 1) {
         if ((int)t < s) {
             Fe<F> o;
 #pragma unroll
-            for (int k = 0; k < 8; k++) o.v[k] = sh[k * 1024 + t + s];
+            for (int k = 0; k < 8; k++) o.v[k] = sh[k * EVAL_T + t + s];
             acc = add<F>(acc, o);
 #pragma unroll
-            for (int k = 0; k < 8; k++) sh[k * 1024 + t] = acc.v[k];
+            for (int k = 0; k < 8; k++) sh[k * EVAL_T + t] = acc.v[k];
         }
         __syncthreads();
     }
-    if (t == 0) acc.store(out + 4 * (d.out + p * d.pstride));
+    if (t == 0) acc.store(out + 4 * (d.out + p * nseg));
 }
 // f = q (x^n - 1) + r:  q[i] = sum_{k >= 1} f[i + k n],  r[i] = sum_{k >= 0} f[i + k n] (i < n).
 // Thread per residue i: suffix sums down the class.
@@ -273,27 +280,54 @@ int poly_b_init(Context& C, int field, const uint64_t* elm, const uint64_t* scal
 // polynomial in order, npts x num_chunks[j] values: out_j[p][c] = chunk_c(points[p])
 int poly_eval_chunks(Context& C, int field, const uint64_t* const* polys_dev, const size_t* lens, const size_t* num_chunks, size_t m, size_t chunk,
                      const uint64_t* points, size_t npts, uint64_t* out) {
-    std::vector<ChunkDesc> tab;
-    size_t base = 0;
-    for (size_t j = 0; j < m; j++) {
+    size_t nchunks = 0;
+    for (size_t j = 0; j < m; j++) nchunks += num_chunks[j];
+    if (nchunks == 0 || npts == 0) return KH_OK;
+    // segment length: long enough to amortise the x^(start + t) product, short enough to fill the chip
+    const size_t seg = nchunks * npts >= 32 ? 8192 : 2048;
+    struct Slot { size_t first, count; };          // segments of one (polynomial, chunk)
+    std::vector<ChunkDesc> tab; std::vector<Slot> slots;
+    for (size_t j = 0; j < m; j++)
         for (size_t c = 0; c < num_chunks[j]; c++) {
             const size_t off = c * chunk;
             const size_t len = off >= lens[j] ? 0 : std::min(chunk, lens[j] - off);
-            tab.push_back(ChunkDesc{polys_dev[j] + 4 * off, (u64)len, (u64)(base + c), (u64)num_chunks[j]});
+            slots.push_back(Slot{tab.size(), 0});
+            for (size_t b = 0; b < len; b += seg) {
+                tab.push_back(ChunkDesc{polys_dev[j] + 4 * (off + b), (u64)std::min(seg, len - b), (u64)tab.size(), (u64)b});
+                slots.back().count++;
+            }
         }
-        base += npts * num_chunks[j];
+    const size_t nseg = tab.size(), base = nchunks * npts;
+    khost::Fld F(field);
+    if (nseg == 0) { memset(out, 0, base * 32); return KH_OK; }
+    std::vector<khost::fe> pw(npts * EVAL_PW);
+    for (size_t p = 0; p < npts; p++) {
+        memcpy(&pw[p * EVAL_PW], points + 4 * p, 32);
+        for (int k = 1; k < EVAL_PW; k++) pw[p * EVAL_PW + k] = F.sqr(pw[p * EVAL_PW + k - 1]);
     }
-    if (tab.empty() || npts == 0) return KH_OK;
     int rc;
-    const size_t tab_bytes = tab.size() * sizeof(ChunkDesc);
-    if ((rc = g_poly_tab.reserve(tab_bytes + npts * 32 + base * 32 + 64))) return rc;
+    const size_t tab_bytes = nseg * sizeof(ChunkDesc), pw_bytes = pw.size() * 32, res_bytes = nseg * npts * 32;
+    if ((rc = g_poly_tab.reserve(tab_bytes + pw_bytes + res_bytes + 64))) return rc;
     hipStream_t s = C.stream;
-    char* d_tab = g_poly_tab.as<char>(); u64* pts = (u64*)(d_tab + tab_bytes); u64* res = pts + 4 * npts;
+    char* d_tab = g_poly_tab.as<char>(); u64* d_pw = (u64*)(d_tab + tab_bytes); u64* res = d_pw + pw_bytes / 8;
+    std::vector<khost::fe> part(nseg * npts);
     KH_HIP(hipMemcpyAsync(d_tab, tab.data(), tab_bytes, hipMemcpyHostToDevice, s));
-    KH_HIP(hipMemcpyAsync(pts, points, npts * 32, hipMemcpyHostToDevice, s));
-    KH_FIELD_DISPATCH(k_eval_chunks, dim3((unsigned)tab.size(), (unsigned)npts), dim3(1024), s, (const ChunkDesc*)d_tab, (const u64*)pts, res);
-    KH_HIP(hipMemcpyAsync(out, res, base * 32, hipMemcpyDeviceToHost, s));
+    KH_HIP(hipMemcpyAsync(d_pw, pw.data(), pw_bytes, hipMemcpyHostToDevice, s));
+    KH_FIELD_DISPATCH(k_eval_chunks, dim3((unsigned)nseg, (unsigned)npts), dim3(EVAL_T), s, (const ChunkDesc*)d_tab, (const u64*)d_pw, nseg, res);
+    KH_HIP(hipMemcpyAsync(part.data(), res, res_bytes, hipMemcpyDeviceToHost, s));
     KH_HIP(hipStreamSynchronize(s));
+    // out_j[p][c] for polynomial j in order: npts x num_chunks[j]
+    size_t o = 0, sl = 0;
+    for (size_t j = 0; j < m; j++) {
+        for (size_t p = 0; p < npts; p++)
+            for (size_t c = 0; c < num_chunks[j]; c++) {
+                const Slot& S = slots[sl + c];
+                khost::fe v; memset(&v, 0, 32);
+                for (size_t q = 0; q < S.count; q++) v = F.add(v, part[p * nseg + S.first + q]);
+                memcpy(out + 4 * (o + p * num_chunks[j] + c), &v, 32);
+            }
+        o += npts * num_chunks[j]; sl += num_chunks[j];
+    }
     return KH_OK;
 }
 int poly_div_vanishing(Context& C, int field, const uint64_t* f_dev, size_t len, size_t n, uint64_t* q_dev, uint64_t* r_dev) {

@@ -278,11 +278,18 @@ def create_proof(ix: ProverIndex, witness, rng, timings=None, check: bool = True
     cf = khip.DevBuf(16 * NB)                               # coefficient forms [w | z]
     khip.dev_copy(cf.ptr, ev.ptr, COLUMNS * NB)
     khip.ntt_dev(fid, cf, logn, True, COLUMNS)
+    # The 8x extension of the witness needs no challenge either: queued here, it runs while the host blinds and absorbs the commitments
+    # (~0.4 ms in which the main stream had nothing to do).  Generic gates + permutation read only w0..w6 (and z) on d8
+    # (generic.rs:83-120, permutation.rs:216-331): half of the reference's 16 extensions.
+    LI = getattr(ix, "lookup", None)
+    e8 = khip.DevBuf(16 * 8 * NB)
+    N8 = 8 * NB
+    w8 = PERMUTS if LI is None and not (ix.live_gate_types & set(ix.GATE_TYPES)) else COLUMNS
+    khip.lde_dev(fid, cf, logn, 3, e8, w8)
     com, inf = srs.msm_wait(tk)
     w_blind = [F.rand(rng) for _ in range(COLUMNS)]
     w_comm, w_inf = srs.mask_custom(com, inf, F.limbs_many(w_blind))
     fq.absorb_g(w_comm, w_inf)
-    LI = getattr(ix, "lookup", None)
     lkp = None
     if LI is not None:                                      # prover.rs:383-633: joint combiner, combined table, sorted columns
         from . import lookup as LK
@@ -333,15 +340,8 @@ def create_proof(ix: ProverIndex, witness, rng, timings=None, check: bool = True
     khip.dev_copy(cf.ptr + COLUMNS * NB, zcol.ptr, NB)
     khip.ntt_dev(fid, cf.view(COLUMNS * NB), logn, True, 1)
     zc = cf.view(COLUMNS * NB)
-    tk = srs.msm_submit(zc.ptr, n, 1)                       # the commitment to z runs while w and z are extended to d8 (no challenge needed for that)
-    e8 = khip.DevBuf(16 * 8 * NB)
-    N8 = 8 * NB
-    if lkp is None and not (ix.live_gate_types & set(ix.GATE_TYPES)):
-        # generic gates + permutation read only w0..w6 and z on d8 (generic.rs:83-120, permutation.rs:216-331): half of the reference's 16 extensions
-        khip.lde_dev(fid, cf, logn, 3, e8, PERMUTS)
-        khip.lde_dev(fid, cf.view(COLUMNS * NB), logn, 3, e8.view(COLUMNS * N8), 1)
-    else:
-        khip.lde_dev(fid, cf, logn, 3, e8, 16)
+    tk = srs.msm_submit(zc.ptr, n, 1)                       # the commitment to z runs while z is extended to d8
+    khip.lde_dev(fid, zc, logn, 3, e8.view(COLUMNS * N8), 1)
     com, inf = srs.msm_wait(tk)
     z_blind = F.rand(rng)
     z_comm, z_inf = srs.mask_custom(com, inf, F.limbs_many([z_blind]))
@@ -349,7 +349,7 @@ def create_proof(ix: ProverIndex, witness, rng, timings=None, check: bool = True
     mark("z")
     alpha = scalar_challenge(curve, F, fq.challenge())
     alphas = [pow(alpha, ALPHA_PERM0 + i, F.p) for i in range(3)]
-    # ---- 8x extension of w and z, constraint rows, quotient
+    # ---- constraint rows on d8, quotient
     gen_cols = [e8.view(i * N8) for i in range(6)] + [ix.col8(i) for i in range(10)] + [ix.col8(COLUMNS)]
     t4 = khip.DevBuf(4 * NB); t8 = khip.DevBuf(N8)
     khip.expr_evaluations_dev(fid, OP.generic_gate_tokens(0, 6, 16, 0, 1), gen_cols, [8 * n] * 17, F.limbs_many([1, alpha]), 4 * n, t4, stride=2, next_shift=8)
