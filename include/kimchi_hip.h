@@ -335,7 +335,10 @@ int kh_lde(int field, const uint64_t *coeffs, unsigned log2_n, unsigned log2_blo
  * Same operations on buffers that already live in HBM (hipMalloc'd by the caller or by
  * kh_dev_alloc).  These are what the benchmark times ("inputs already resident in HBM")
  * and what a prover that keeps witness columns on the device would call.
- * Ordering: kh_ntt_dev / kh_lde_dev return as soon as their kernels are queued on the library's main stream; every
+ * Ordering: kh_ntt_dev / kh_lde_dev / kh_coset_ntt_dev / kh_dev_copy and the vector steps whose result stays on the device
+ * (kh_expr_evaluations_dev, kh_poly_lincomb_dev, kh_combine_polys_dev, kh_b_init_dev, kh_field_scan_dev, kh_batch_inversion_dev,
+ * kh_divide_by_vanishing_poly_dev) return as soon as their kernels are queued on the library's main stream; their host
+ * arguments (token programs, pointer tables, constants) are copied before the call returns.  Every
  * other entry point that consumes a device buffer either runs on that same stream or waits for it on the device
  * (MSMs on another pipeline slot's stream wait for an event recorded on the main stream), so a producer followed by a
  * consumer needs no kh_sync in between.  Host-visible results (points, evaluations) are complete when the call

@@ -40,6 +40,30 @@ static Context& ctx_of(int dev) {
 }
 Context& ctx() { return ctx_of(current_device()); }
 
+int Context::stage_upload(void* dst_dev, std::initializer_list<std::pair<const void*, size_t>> parts) {
+    size_t total = 0;
+    for (const auto& pr : parts) total += pr.second;
+    if (total == 0) return KH_OK;
+    const size_t need = (total + 63) & ~(size_t)63;
+    if (need > stage_cap / 4) {                       // a large table, or no ring yet: make room for many calls per turn
+        const size_t cap = std::max<size_t>((size_t)1 << 20, 8 * need);
+        if (cap > stage_cap) {
+            KH_HIP(hipStreamSynchronize(stream));     // nothing in flight reads the old ring any more
+            if (stage) (void)hipHostFree(stage);
+            stage = nullptr; stage_cap = 0; stage_cur = 0;
+            KH_HIP(hipHostMalloc((void**)&stage, cap, hipHostMallocDefault));
+            stage_cap = cap;
+        }
+    }
+    if (stage_cur + need > stage_cap) { KH_HIP(hipStreamSynchronize(stream)); stage_cur = 0; }
+    char* h = stage + stage_cur;
+    size_t o = 0;
+    for (const auto& pr : parts) { if (pr.second) memcpy(h + o, pr.first, pr.second); o += pr.second; }
+    stage_cur += need;
+    KH_HIP(hipMemcpyAsync(dst_dev, h, total, hipMemcpyHostToDevice, stream));
+    return KH_OK;
+}
+
 static int bind_thread(int dev) {
     if (tl_hip_dev != dev) { KH_HIP(hipSetDevice(dev)); tl_hip_dev = dev; }
     return KH_OK;
@@ -860,6 +884,7 @@ int kh_combine_polys_dev(int field, const uint64_t* const* polys_dev, const size
     Context& C = ctx();
     std::lock_guard<std::mutex> lk(C.mu);
     if ((rc = poly_lincomb(C, field, segs.data(), slen.data(), (const uint64_t*)scales.data(), segs.size(), out_dev, srs_length))) return rc;
+    C.mark_async();
     if (out_len) *out_len = longest;
     return KH_OK;
 }
@@ -871,7 +896,9 @@ int kh_poly_lincomb_dev(int field, const uint64_t* const* polys_dev, const size_
     int rc = ensure_init(); if (rc) return rc;
     Context& C = ctx();
     std::lock_guard<std::mutex> lk(C.mu);
-    return poly_lincomb(C, field, polys_dev, lens, scalars, m, out_dev, out_len);
+    rc = poly_lincomb(C, field, polys_dev, lens, scalars, m, out_dev, out_len);
+    if (rc == KH_OK) C.mark_async();
+    return rc;
 }
 int kh_b_init_dev(int field, const uint64_t* elm, size_t k, const uint64_t evalscale[4], size_t padded_len, uint64_t* out_dev) {
     KH_REQUIRE(field == KH_FIELD_FP || field == KH_FIELD_FQ, "unknown field id %d", field);
@@ -884,7 +911,9 @@ int kh_b_init_dev(int field, const uint64_t* elm, size_t k, const uint64_t evals
     for (size_t i = 0; i < k; i++) { scales[i] = sc; sc = F.mul(sc, es); }
     Context& C = ctx();
     std::lock_guard<std::mutex> lk(C.mu);
-    return poly_b_init(C, field, elm, (const uint64_t*)scales.data(), k, padded_len, out_dev);
+    rc = poly_b_init(C, field, elm, (const uint64_t*)scales.data(), k, padded_len, out_dev);
+    if (rc == KH_OK) C.mark_async();
+    return rc;
 }
 int kh_evaluate_chunks_batch_dev(int field, const uint64_t* const* polys_dev, const size_t* lens, const size_t* num_chunks, size_t m,
                                  size_t chunk_size, const uint64_t* points, size_t npts, uint64_t* out) {
@@ -914,7 +943,9 @@ int kh_divide_by_vanishing_poly_dev(int field, const uint64_t* f_dev, size_t len
     int rc = ensure_init(); if (rc) return rc;
     Context& C = ctx();
     std::lock_guard<std::mutex> lk(C.mu);
-    return poly_div_vanishing(C, field, f_dev, len, n, q_dev, r_dev);
+    rc = poly_div_vanishing(C, field, f_dev, len, n, q_dev, r_dev);
+    if (rc == KH_OK) C.mark_async();
+    return rc;
 }
 
 int kh_field_scan_dev(int field, int op, int reverse, uint64_t* data_dev, size_t n) {
@@ -923,7 +954,9 @@ int kh_field_scan_dev(int field, int op, int reverse, uint64_t* data_dev, size_t
     int rc = ensure_init(); if (rc) return rc;
     Context& C = ctx();
     std::lock_guard<std::mutex> lk(C.mu);
-    return poly_scan(C, field, op, reverse ? 1 : 0, data_dev, n);
+    rc = poly_scan(C, field, op, reverse ? 1 : 0, data_dev, n);
+    if (rc == KH_OK) C.mark_async();
+    return rc;
 }
 int kh_batch_inversion_dev(int field, uint64_t* v_dev, size_t n) {
     KH_REQUIRE(field == KH_FIELD_FP || field == KH_FIELD_FQ, "unknown field id %d", field);
@@ -931,7 +964,9 @@ int kh_batch_inversion_dev(int field, uint64_t* v_dev, size_t n) {
     int rc = ensure_init(); if (rc) return rc;
     Context& C = ctx();
     std::lock_guard<std::mutex> lk(C.mu);
-    return poly_batch_inversion(C, field, v_dev, n);
+    rc = poly_batch_inversion(C, field, v_dev, n);
+    if (rc == KH_OK) C.mark_async();
+    return rc;
 }
 int kh_divide_by_linear_dev(int field, const uint64_t* f_dev, size_t len, const uint64_t a[4], uint64_t* q_dev, uint64_t rem[4]) {
     KH_REQUIRE(field == KH_FIELD_FP || field == KH_FIELD_FQ, "unknown field id %d", field);
@@ -950,7 +985,9 @@ int kh_expr_evaluations_dev(int field, const uint32_t* tokens, size_t ntok, cons
     int rc = ensure_init(); if (rc) return rc;
     Context& C = ctx();
     std::lock_guard<std::mutex> lk(C.mu);
-    return expr_run(C, field, tokens, ntok, cols_dev, col_len, ncols, constants, nconsts, rows, stride, next_shift, accumulate, out_dev);
+    rc = expr_run(C, field, tokens, ntok, cols_dev, col_len, ncols, constants, nconsts, rows, stride, next_shift, accumulate, out_dev);
+    if (rc == KH_OK) C.mark_async();
+    return rc;
 }
 
 // ---------------------------------------------------------------------------------- challenge polynomials (verifier side)

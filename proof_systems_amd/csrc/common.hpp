@@ -7,6 +7,7 @@
 #include <stdio.h>
 #include <chrono>
 #include <condition_variable>
+#include <initializer_list>
 #include <map>
 #include <mutex>
 #include <set>
@@ -129,6 +130,15 @@ struct Context {
     // NTT workspace
     DevBuf ws_ntt_a, ws_ntt_b;
     void* pinned = nullptr; size_t pinned_cap = 0;
+    // Pinned staging ring for the small argument tables of the vector steps (token programs, pointer tables, constants): a copy
+    // from pageable memory drains the stream first, one from pinned memory is just another stream operation -- so kh_expr_* /
+    // kh_poly_* can be queued back to back like kh_ntt_dev.  A slice is reused only after a full turn of the ring, which waits
+    // for the main stream.  Guarded by `mu`.
+    char* stage = nullptr; size_t stage_cap = 0, stage_cur = 0;
+    // copies the parts back to back into the ring and queues ONE host-to-device copy of them to dst_dev on the main stream
+    int stage_upload(void* dst_dev, std::initializer_list<std::pair<const void*, size_t>> parts);
+    // asynchronous work was queued on the main stream: a later MSM on another slot's stream waits for this point
+    void mark_async() { if (hipEventRecord(order_ev, stream) == hipSuccess) main_dirty = true; }
     // named scratch buffers / one-time flags of the other translation units (what used to be function-local statics:
     // a static is process-wide, these belong to ONE device).  References stay valid (std::map nodes do not move).
     std::mutex scratch_mu;

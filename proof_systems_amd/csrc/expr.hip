@@ -122,12 +122,7 @@ int expr_run(Context& C, int field, const uint32_t* prog, size_t ntok, const uin
     char* d_cols = base; char* d_len = d_cols + ncols * 8; char* d_consts = d_len + ncols * 8; char* d_prog = d_consts + nconsts * 32;
     std::vector<u64> len64(col_len, col_len + ncols);
     hipStream_t s = C.stream;
-    if (ncols) {
-        KH_HIP(hipMemcpyAsync(d_cols, cols_dev, ncols * 8, hipMemcpyHostToDevice, s));
-        KH_HIP(hipMemcpyAsync(d_len, len64.data(), ncols * 8, hipMemcpyHostToDevice, s));
-    }
-    if (nconsts) KH_HIP(hipMemcpyAsync(d_consts, consts, nconsts * 32, hipMemcpyHostToDevice, s));
-    KH_HIP(hipMemcpyAsync(d_prog, prog, ntok * 8, hipMemcpyHostToDevice, s));
+    if ((rc = C.stage_upload(base, {{cols_dev, ncols * 8}, {len64.data(), ncols * 8}, {consts, nconsts * 32}, {prog, ntok * 8}}))) return rc;
     if (C.once("expr_attr")) {
         KH_HIP(hipFuncSetAttribute((const void*)k_expr<FpParams>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         KH_HIP(hipFuncSetAttribute((const void*)k_expr<FqParams>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -142,8 +137,7 @@ int expr_run(Context& C, int field, const uint32_t* prog, size_t ntok, const uin
                            (const u64*)d_consts, rows, (u32)stride, (u32)next_shift, slots, accumulate, out_dev);
     KH_HIP(hipGetLastError());
     C.timer.mark("expr", s);
-    KH_HIP(hipStreamSynchronize(s));
-    return KH_OK;
+    return KH_OK;                 // asynchronous on the main stream, like kh_ntt_dev
 }
 
 }  // namespace kh

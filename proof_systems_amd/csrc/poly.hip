@@ -252,14 +252,9 @@ int poly_lincomb(Context& C, int field, const uint64_t* const* segs_dev, const s
     char* tab = g_poly_tab.as<char>();
     std::vector<u64> lens64(lens, lens + m);
     hipStream_t s = C.stream;
-    if (m) {
-        KH_HIP(hipMemcpyAsync(tab, segs_dev, m * 8, hipMemcpyHostToDevice, s));
-        KH_HIP(hipMemcpyAsync(tab + m * 8, lens64.data(), m * 8, hipMemcpyHostToDevice, s));
-        KH_HIP(hipMemcpyAsync(tab + m * 16, scales, m * 32, hipMemcpyHostToDevice, s));
-    }
+    if (m && (rc = C.stage_upload(tab, {{segs_dev, m * 8}, {lens64.data(), m * 8}, {scales, m * 32}}))) return rc;
     KH_FIELD_DISPATCH(k_lincomb, dim3((unsigned)((out_len + 255) / 256)), dim3(256), s,
                       (const u64* const*)tab, (const u64*)(tab + m * 8), (const u64*)(tab + m * 16), m, out_len, out_dev);
-    KH_HIP(hipStreamSynchronize(s));
     return KH_OK;
 }
 int poly_b_init(Context& C, int field, const uint64_t* elm, const uint64_t* scales, size_t k, size_t n, uint64_t* out_dev) {
@@ -267,13 +262,9 @@ int poly_b_init(Context& C, int field, const uint64_t* elm, const uint64_t* scal
     int rc;
     if ((rc = g_poly_tab.reserve(k * 64 + 64))) return rc;
     hipStream_t s = C.stream;
-    if (k) {
-        KH_HIP(hipMemcpyAsync(g_poly_tab.p, elm, k * 32, hipMemcpyHostToDevice, s));
-        KH_HIP(hipMemcpyAsync(g_poly_tab.as<char>() + k * 32, scales, k * 32, hipMemcpyHostToDevice, s));
-    }
+    if (k && (rc = C.stage_upload(g_poly_tab.p, {{elm, k * 32}, {scales, k * 32}}))) return rc;
     KH_FIELD_DISPATCH(k_b_init, dim3((unsigned)((n + 255) / 256)), dim3(256), s,
                       g_poly_tab.as<u64>(), g_poly_tab.as<u64>() + 4 * k, k, n, out_dev);
-    KH_HIP(hipStreamSynchronize(s));
     return KH_OK;
 }
 // polynomial j (polys_dev[j], lens[j] coefficients) is cut into num_chunks[j] chunks of `chunk`; out (host) receives, per
@@ -311,8 +302,7 @@ int poly_eval_chunks(Context& C, int field, const uint64_t* const* polys_dev, co
     hipStream_t s = C.stream;
     char* d_tab = g_poly_tab.as<char>(); u64* d_pw = (u64*)(d_tab + tab_bytes); u64* res = d_pw + pw_bytes / 8;
     std::vector<khost::fe> part(nseg * npts);
-    KH_HIP(hipMemcpyAsync(d_tab, tab.data(), tab_bytes, hipMemcpyHostToDevice, s));
-    KH_HIP(hipMemcpyAsync(d_pw, pw.data(), pw_bytes, hipMemcpyHostToDevice, s));
+    if ((rc = C.stage_upload(d_tab, {{tab.data(), tab_bytes}, {pw.data(), pw_bytes}}))) return rc;
     KH_FIELD_DISPATCH(k_eval_chunks, dim3((unsigned)nseg, (unsigned)npts), dim3(EVAL_T), s, (const ChunkDesc*)d_tab, (const u64*)d_pw, nseg, res);
     KH_HIP(hipMemcpyAsync(part.data(), res, res_bytes, hipMemcpyDeviceToHost, s));
     KH_HIP(hipStreamSynchronize(s));
@@ -333,7 +323,6 @@ int poly_eval_chunks(Context& C, int field, const uint64_t* const* polys_dev, co
 int poly_div_vanishing(Context& C, int field, const uint64_t* f_dev, size_t len, size_t n, uint64_t* q_dev, uint64_t* r_dev) {
     hipStream_t s = C.stream;
     KH_FIELD_DISPATCH(k_div_vanishing, dim3((unsigned)((n + 255) / 256)), dim3(256), s, f_dev, len, n, q_dev, r_dev);
-    KH_HIP(hipStreamSynchronize(s));
     return KH_OK;
 }
 
@@ -374,9 +363,7 @@ int poly_coset_ntt(Context& C, int field, const uint64_t* coeffs_dev, unsigned l
     return ntt_run(C, field, out_dev, log2_n, 0, batch);
 }
 int poly_scan(Context& C, int field, int op, int rev, uint64_t* data_dev, size_t n) {
-    int rc = scan_enqueue(C.stream, field, op, rev, data_dev, n); if (rc) return rc;
-    KH_HIP(hipStreamSynchronize(C.stream));
-    return KH_OK;
+    return scan_enqueue(C.stream, field, op, rev, data_dev, n);
 }
 // ark_ff::batch_inversion: every non-zero element replaced by its inverse, zeros untouched
 int poly_batch_inversion(Context& C, int field, uint64_t* v_dev, size_t n) {
@@ -395,7 +382,6 @@ int poly_batch_inversion(Context& C, int field, uint64_t* v_dev, size_t n) {
     KH_HIP(hipStreamSynchronize(s));
     Fe4p inv; host_field_inverse(field, total.l, inv.l);   // one inversion, on the host (20 us against ~0.2 ms for a lone GPU thread)
     KH_FIELD_DISPATCH(k_batch_inv_finish, g, dim3(256), s, v_dev, (const u64*)g_scan_a.as<u64>(), (const u64*)g_scan_b.as<u64>(), inv, n);
-    KH_HIP(hipStreamSynchronize(s));
     return KH_OK;
 }
 // f = q (x - a) + rem, rem = f(a): q_i = a^-(i+1) sum_{k > i} c_k a^k

@@ -43,15 +43,21 @@ class Fld:
         self.rinv = pow(R256, -1, self.p)
 
     def limbs(self, v: int):
-        m = (v % self.p) * R256 % self.p
-        return np.array([(m >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)], dtype=np.uint64)
+        return np.frombuffer(((v % self.p) * R256 % self.p).to_bytes(32, "little"), dtype=np.uint64).copy()
 
     def limbs_many(self, vs):
-        return np.stack([self.limbs(v) for v in vs]) if len(vs) else np.zeros((0, 4), np.uint64)
+        if not len(vs):
+            return np.zeros((0, 4), np.uint64)
+        p = self.p
+        return np.frombuffer(b"".join(((v % p) * R256 % p).to_bytes(32, "little") for v in vs), dtype=np.uint64).reshape(-1, 4).copy()
 
     def value(self, l) -> int:
-        m = int(l[0]) | (int(l[1]) << 64) | (int(l[2]) << 128) | (int(l[3]) << 192)
-        return m * self.rinv % self.p
+        return int.from_bytes(np.ascontiguousarray(l, dtype=np.uint64).tobytes(), "little") * self.rinv % self.p
+
+    def values(self, arr):
+        """every element of an (..., 4) limb array, flattened, as integers"""
+        b = np.ascontiguousarray(arr, dtype=np.uint64).tobytes()
+        return [int.from_bytes(b[i:i + 32], "little") * self.rinv % self.p for i in range(0, len(b), 32)]
 
     def inv(self, v: int) -> int:
         return pow(v, -1, self.p)
@@ -264,7 +270,7 @@ def create_proof(ix: ProverIndex, witness, rng, timings=None, check: bool = True
     pub_c = None
     if ix.public:                                           # the negated public-input polynomial (prover.rs:281-309): -p_i on the first rows
         pe_ = np.zeros((n, 4), dtype=np.uint64)
-        pub_vals = [F.value(l) for l in ev.download_at(0, (ix.public, 4))]
+        pub_vals = F.values(ev.download_at(0, (ix.public, 4)))
         pe_[:ix.public] = F.limbs_many([(-x) % F.p for x in pub_vals])
         pub_c = khip.DevBuf(NB).upload(pe_)
         com, inf = srs.msm_batch_dev(pub_c.ptr, n, 1, basis=logn)
@@ -295,10 +301,10 @@ def create_proof(ix: ProverIndex, witness, rng, timings=None, check: bool = True
         from . import lookup as LK
         jc = scalar_challenge(curve, F, fq.challenge() if LI.joint_lookup_used else 0)
         d_table = LI.joint_table_dev(jc)
-        table_ints = [F.value(l) for l in d_table.download((n, 4))]
+        table_ints = F.values(d_table.download((n, 4)))
         wcols = ev.download((COLUMNS, n, 4))
         used = sorted({c for q in LI.patterns for tid, entry in OP.LOOKUP_PATTERNS[q] for c in (list(entry) + ([tid[1]] if isinstance(tid, tuple) else []))})
-        wit_ints = [[F.value(l) for l in wcols[c]] if c in used else None for c in range(COLUMNS)]
+        wit_ints = [F.values(wcols[c]) if c in used else None for c in range(COLUMNS)]
         srt = [LK.zk_patch(F, c, n, ZK_ROWS, rng) for c in LK.sorted_columns(LI, wit_ints, table_ints, jc)]    # ValueError(row): value not in the table
         d_sorted = [khip.DevBuf(NB).upload(F.limbs_many(c)) for c in srt]
         s_blind, s_comm = [], []
@@ -414,7 +420,7 @@ def create_proof(ix: ProverIndex, witness, rng, timings=None, check: bool = True
         lk_polys = [lkp["lkc"].view(k_ * NB) for k_ in range(lkp["nl"])] + [LI.sel_c[q] for q in LI.patterns]
     pts = F.limbs_many([zeta, zetaw])
     evl = khip.evaluate_chunks_batch_dev(fid, polys + lk_polys, [n] * (len(polys) + len(lk_polys)), [1] * (len(polys) + len(lk_polys)), n, pts)
-    E = [(F.value(e[0, 0]), F.value(e[1, 0])) for e in evl]
+    E = [tuple(F.values(e)) for e in evl]                 # one chunk per polynomial: (value at zeta, value at zeta * omega)
     pub_eval = (0, 0)
     if pub_c is not None:
         pe2 = khip.evaluate_chunks_dev(fid, pub_c, n, n, 1, pts)
