@@ -144,7 +144,7 @@ struct kh_srs {
     int g_precomp_c = 0;
     bool ipa_live = false;    // the U slot belongs to one opening at a time
     // workspace of the opening rounds, kept across openings (hipMalloc / hipFree cost ~0.1 ms each: 1 ms per proof)
-    DevBuf ipa_a[2], ipa_b[2], ipa_coef[2], ipa_sc, ipa_partial;
+    DevBuf ipa_a[2], ipa_b[2], ipa_coef[2], ipa_sc, ipa_partial, ipa_sg;
     hipEvent_t ipa_ev = nullptr;
     uint64_t h[8];
     // fixed-base table of the blinding base: h_table[i * 255 + (j - 1)] = j * 2^(8 i) * h (XYZZ), built on first use:
@@ -1119,6 +1119,8 @@ struct kh_ipa {
     uint64_t u_p[4] = {0, 0, 0, 0}, ui_p[4] = {0, 0, 0, 0};
     size_t partial_words = 0;             // u64 words of `partial` before the step kernel's block counter
     std::vector<uint64_t> tab;            // H / U window multiples staged for the asynchronous upload of kh_ipa_begin
+    int sg_slot = -1;                     // pipeline slot holding the two half-sums of sg launched during the last round (kh_ipa_open), -1: none
+    bool sg_want = false;                 // kh_ipa_open asks the last kh_ipa_round_lr to launch them
 };
 
 static int ipa_begin_common(kh_srs_t* srs, const uint64_t* a, size_t a_len, const uint64_t* b, size_t b_len, const uint64_t u_base_xy[8], kh_ipa_t** out,
@@ -1152,6 +1154,7 @@ static int ipa_begin_common(kh_srs_t* srs, const uint64_t* a, size_t a_len, cons
         if ((rc = srs->ipa_coef[i].reserve(n * 32))) return rc;
     }
     if ((rc = srs->ipa_sc.reserve(2 * (n + 2) * 32))) return rc;
+    if ((rc = srs->ipa_sg.reserve(2 * n * 32))) return rc;             // scalars of the two halves of sg (kh_ipa_open)
     const size_t partial_bytes = 2 * (n / 512 + 1) * 32;               // block sums of the two inner products, then the last-block counter
     if ((rc = srs->ipa_partial.reserve(partial_bytes + 64))) return rc;
     KH_HIP(hipMemsetAsync((uint8_t*)srs->ipa_partial.p + partial_bytes, 0, 64, C.stream));
@@ -1193,6 +1196,23 @@ int kh_ipa_rounds_left(const kh_ipa_t* st) {
     int r = 0; for (size_t c = st->cur; c > 1; c >>= 1) r++;
     return r;
 }
+// During the LAST round of an opening: the two halves of sg (ipa.hip: k_sg_split) as one batch of two MSMs on a side slot.  They need only the
+// challenges of the earlier rounds, so they run underneath the last round instead of after it (0.39 ms of every opening); queued right
+// behind the round's own launches, so that their ~15 un-graphed launches overlap its execution.  `p` / `had_fold`: the challenge tensor as it
+// was BEFORE the round's step kernel (which only reads it).  Quietly does nothing when no other slot is free: kh_ipa_open then computes
+// sg the plain way.  Called with the library lock held.
+static void ipa_sg_prelaunch_locked(kh_ipa_t* st, Context& C, int p, bool had_fold) {
+    int si = -1;
+    for (int i = MSM_SLOTS - 1; i >= 1; i--) if (!C.slot[i].busy) { si = i; break; }
+    if (si < 0) return;
+    MsmSlot& S = C.slot[si];
+    kh_srs_t* srs = st->srs;
+    if (hipStreamWaitEvent(S.stream, st->ev, 0) != hipSuccess) return;
+    if (ipa_sg_split(S.stream, st->field, st->coef[p].as<uint64_t>(), st->n, had_fold ? 1 : 0, st->u_p, srs->ipa_sg.as<uint64_t>())) return;
+    MsmBasis bs; bs.pts = srs->g.p; bs.inf = nullptr; bs.n = srs->n; bs.stride = srs->g_stride; bs.precomp_c = srs->g_precomp_c;
+    if (msm_enqueue(C, S, st->curve, bs, 0, srs->ipa_sg.as<uint64_t>(), st->n, 2, 1)) return;
+    st->sg_slot = si;
+}
 int kh_ipa_round_lr(kh_ipa_t* st, const uint64_t rand_l[4], const uint64_t rand_r[4], uint64_t lr_xy[16], uint8_t lr_inf[2]) {
     kh::DeviceScope dev_scope_((st && st->srs) ? st->srs->device : -1);
     KH_REQUIRE(st && rand_l && rand_r && lr_xy && lr_inf, "kh_ipa_round_lr: null argument");
@@ -1205,6 +1225,7 @@ int kh_ipa_round_lr(kh_ipa_t* st, const uint64_t rand_l[4], const uint64_t rand_
     MsmSlot& S = C.slot[si];
     KH_HIP(hipStreamWaitEvent(S.stream, st->ev, 0));
     const int p = st->pp, q = p ^ 1;
+    const bool had_fold = st->pending;
     // one launch: the recorded fold of the previous round (if any), this round's inner products and expanded scalars
     int rc = ipa_round_step(S.stream, st->field, st->pending ? 1 : 0, st->a[p].as<uint64_t>(), st->b[p].as<uint64_t>(), st->coef[p].as<uint64_t>(),
                             st->n, st->cur, st->pending ? st->ncoef / 2 : st->ncoef, st->u_p, st->ui_p,
@@ -1215,6 +1236,7 @@ int kh_ipa_round_lr(kh_ipa_t* st, const uint64_t rand_l[4], const uint64_t rand_
     kh_srs_t* srs = st->srs;
     MsmBasis bs; bs.pts = srs->g.p; bs.inf = nullptr; bs.n = srs->g_stride; bs.stride = srs->g_stride; bs.precomp_c = srs->g_precomp_c;
     if ((rc = msm_enqueue(C, S, st->curve, bs, 0, st->sc->as<uint64_t>(), st->n + 2, 2, 1, /*use_graph=*/1))) return rc;
+    if (st->sg_want && st->cur == 2) { st->sg_want = false; ipa_sg_prelaunch_locked(st, C, p, had_fold); }
     if ((rc = wait_then_finish(lk, C, S, lr_xy, lr_inf))) return rc;
     st->lr_done = true;
     return KH_OK;
@@ -1234,9 +1256,9 @@ int kh_ipa_round_fold(kh_ipa_t* st, const uint64_t chal[2], uint64_t u_out[4], u
     if (u_inv_out) memcpy(u_inv_out, ui, 32);
     return KH_OK;
 }
-int kh_ipa_finish(kh_ipa_t* st, uint64_t a0[4], uint64_t b0[4], uint64_t sg_xy[8], uint8_t* sg_inf) {
+// sg_xy == nullptr: only the last fold and a0, b0 (the caller has the halves of sg in flight on st->sg_slot)
+static int ipa_finish_impl(kh_ipa_t* st, uint64_t a0[4], uint64_t b0[4], uint64_t* sg_xy, uint8_t* sg_inf) {
     kh::DeviceScope dev_scope_((st && st->srs) ? st->srs->device : -1);
-    KH_REQUIRE(st && a0 && b0 && sg_xy && sg_inf, "kh_ipa_finish: null argument");
     KH_REQUIRE(st->cur == 1, "%d rounds still to run", kh_ipa_rounds_left(st));
     Context& C = ctx();
     std::unique_lock<std::mutex> lk(C.mu);
@@ -1256,13 +1278,82 @@ int kh_ipa_finish(kh_ipa_t* st, uint64_t a0[4], uint64_t b0[4], uint64_t sg_xy[8
     KH_HIP(hipMemcpyAsync(b0, st->b[p].p, 32, hipMemcpyDeviceToHost, S.stream));
     kh_srs_t* srs = st->srs;
     MsmBasis bs; bs.pts = srs->g.p; bs.inf = nullptr; bs.n = srs->n; bs.stride = srs->g_stride; bs.precomp_c = srs->g_precomp_c;
+    if (!sg_xy) { KH_HIP(hipStreamSynchronize(S.stream)); return KH_OK; }
     if ((rc = msm_enqueue(C, S, st->curve, bs, 0, st->coef[p].as<uint64_t>(), st->n, 1, 1))) return rc;   // sg = <coef, G>
     return wait_then_finish(lk, C, S, sg_xy, sg_inf);
+}
+int kh_ipa_finish(kh_ipa_t* st, uint64_t a0[4], uint64_t b0[4], uint64_t sg_xy[8], uint8_t* sg_inf) {
+    KH_REQUIRE(st && a0 && b0 && sg_xy && sg_inf, "kh_ipa_finish: null argument");
+    return ipa_finish_impl(st, a0, b0, sg_xy, sg_inf);
+}
+// [u] B for u = scalar_challenge_to_field(chal) = a * endo_r + b with a, b < 2^67 (poseidon/src/sponge.rs:190-226): [a] phi(B) + [b] B,
+// phi(x, y) = (endo_q x, y), as one joint double-and-add of 67 steps instead of a 255-bit ladder (0.10 -> 0.03 ms on the host).
+// That [endo_r] P = phi(P) for the pair kh_endos returns is checked once per curve on the first point; if it ever failed the plain ladder runs.
+static khost::xyzz endo_challenge_mul(const khost::Crv& crv, int curve, const khost::aff& B, const uint64_t chal[2], const uint64_t u[4]) {
+    khost::Fld SF(khost::scalar_field_id(curve));
+    const EndoPair& e = cached_endos(curve);
+    khost::fe eq; memcpy(&eq, e.q, 32);
+    khost::aff PB = B; PB.x = crv.F.mul(B.x, eq);
+    const khost::xyzz P1 = crv.from_affine(B), P2 = crv.from_affine(PB);
+    static int endo_ok[2] = {-1, -1};
+    static std::mutex once_mu;
+    {
+        std::lock_guard<std::mutex> lk(once_mu);
+        if (endo_ok[curve & 1] < 0) {
+            khost::fe er; memcpy(&er, e.r, 32);
+            khost::aff lhs; const bool inf = crv.to_affine(crv.mul_plain(P1, SF.from_mont(er)), lhs);
+            endo_ok[curve & 1] = (!inf && memcmp(&lhs, &PB, 64) == 0) ? 1 : 0;
+        }
+    }
+    if (endo_ok[curve & 1] != 1) { khost::fe uu; memcpy(&uu, u, 32); return crv.mul_plain(P1, SF.from_mont(uu)); }
+    unsigned __int128 a = 2, b = 2;
+    for (int i = 63; i >= 0; i--) {
+        a <<= 1; b <<= 1;
+        const uint64_t w = chal[i >> 5]; const int sh = 2 * (i & 31);
+        const bool plus = (w >> sh) & 1;
+        if ((w >> (sh + 1)) & 1) { if (plus) a += 1; else a -= 1; } else { if (plus) b += 1; else b -= 1; }
+    }
+    const khost::xyzz P12 = crv.add(P1, P2);
+    khost::xyzz acc = crv.identity();
+    for (int i = 67; i >= 0; i--) {
+        acc = crv.dbl(acc);
+        const int ba = (int)((a >> i) & 1), bb = (int)((b >> i) & 1);
+        if (ba && bb) acc = crv.add(acc, P12); else if (ba) acc = crv.add(acc, P2); else if (bb) acc = crv.add(acc, P1);
+    }
+    return acc;
+}
+// A + [u] B from the two halves (affine, st->sg_slot) -> sg
+static int ipa_sg_collect(kh_ipa_t* st, const uint64_t chal_last[2], const uint64_t u_last[4], uint64_t sg_xy[8], uint8_t* sg_inf) {
+    kh::DeviceScope dev_scope_(st->srs->device);
+    uint64_t ab[16]; uint8_t abi[2];
+    {
+        Context& C = ctx();
+        std::unique_lock<std::mutex> lk(C.mu);
+        const int si = st->sg_slot; st->sg_slot = -1;
+        int rc = wait_then_finish(lk, C, C.slot[si], ab, abi); if (rc) return rc;
+    }
+    khost::Crv crv(st->curve);
+    khost::xyzz acc = crv.identity();
+    if (!abi[1]) {
+        khost::aff B; memcpy(&B, ab + 8, 64);
+        acc = endo_challenge_mul(crv, st->curve, B, chal_last, u_last);
+    }
+    if (!abi[0]) { khost::aff A; memcpy(&A, ab, 64); acc = crv.add(acc, crv.from_affine(A)); }
+    khost::aff out; const bool inf = crv.to_affine(acc, out);
+    memset(sg_xy, 0, 64); if (!inf) memcpy(sg_xy, &out, 64);
+    *sg_inf = inf ? 1 : 0;
+    return KH_OK;
 }
 void kh_ipa_free(kh_ipa_t* st) {
     if (!st) return;
     kh::DeviceScope dev_scope_(st->srs ? st->srs->device : -1);
     Context& C = ctx();
+    if (st->sg_slot >= 0) {                                // an opening that failed after launching the halves of sg: release their slot
+        uint64_t ab[16]; uint8_t abi[2];
+        std::unique_lock<std::mutex> ul(C.mu);
+        const int si = st->sg_slot; st->sg_slot = -1;
+        (void)wait_then_finish(ul, C, C.slot[si], ab, abi);
+    }
     std::lock_guard<std::mutex> lk(C.mu);
     (void)hipStreamSynchronize(C.stream);                 // a fold may still be in flight on the library stream
     if (st->srs) st->srs->ipa_live = false;
@@ -1309,9 +1400,12 @@ int kh_ipa_open(kh_srs_t* srs, const uint64_t* a_dev, size_t a_len, const uint64
     khost::fe r_prime = fe_of(blinding_factor);
     const auto tp1 = std::chrono::steady_clock::now();
     double t_lr = 0, t_sponge = 0, t_fold = 0;
+    static const bool sg_split = getenv("KH_NO_SG_SPLIT") == nullptr;
+    uint64_t u_last[4] = {0, 0, 0, 0}, chal_last[2] = {0, 0};
     for (size_t r = 0; r < rounds; r++) {
         const uint64_t* rl = blinders + 8 * r; const uint64_t* rr = rl + 4;
         const auto q0 = std::chrono::steady_clock::now();
+        if (r + 1 == rounds && sg_split) st->sg_want = true;
         if ((rc = kh_ipa_round_lr(st, rl, rr, lr_xy + 16 * r, lr_inf + 2 * r))) return rc;
         const auto q1 = std::chrono::steady_clock::now();
         if ((rc = kh_sponge_absorb_g(sponge, lr_xy + 16 * r, lr_inf + 2 * r, 2))) return rc;
@@ -1319,6 +1413,7 @@ int kh_ipa_open(kh_srs_t* srs, const uint64_t* a_dev, size_t a_len, const uint64
         if ((rc = kh_sponge_challenge(sponge, chal))) return rc;
         const auto q2 = std::chrono::steady_clock::now();
         if ((rc = kh_ipa_round_fold(st, chal, u, ui))) return rc;
+        memcpy(u_last, u, 32); chal_last[0] = chal[0]; chal_last[1] = chal[1];
         if (ipa_timing) {
             const auto q3 = std::chrono::steady_clock::now();
             t_lr += std::chrono::duration<double, std::micro>(q1 - q0).count(); t_sponge += std::chrono::duration<double, std::micro>(q2 - q1).count();
@@ -1328,7 +1423,10 @@ int kh_ipa_open(kh_srs_t* srs, const uint64_t* a_dev, size_t a_len, const uint64
     }
     const auto tp2 = std::chrono::steady_clock::now();
     uint64_t a0[4], b0[4];
-    if ((rc = kh_ipa_finish(st, a0, b0, sg_xy, sg_inf))) return rc;
+    if (st->sg_slot >= 0) {
+        if ((rc = ipa_finish_impl(st, a0, b0, nullptr, nullptr))) return rc;
+        if ((rc = ipa_sg_collect(st, chal_last, u_last, sg_xy, sg_inf))) return rc;
+    } else if ((rc = kh_ipa_finish(st, a0, b0, sg_xy, sg_inf))) return rc;
     const auto tp3 = std::chrono::steady_clock::now();
     // delta = (g0 + [b0] U) * d + [r_delta] H  (ipa.rs:1036-1041), on the host: three scalar multiplications
     const khost::fe d = fe_of(blinders + 8 * rounds), r_delta = fe_of(blinders + 8 * rounds + 4);

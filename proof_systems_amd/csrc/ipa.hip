@@ -351,6 +351,30 @@ int ipa_round_fold(hipStream_t s, int field, const uint64_t* a, const uint64_t* 
     return KH_OK;
 }
 
+// sg = <coef_R, G> split on the LAST challenge: coef_R[2s + b] = coef_{R-1}[s] u_R^b, so sg = A + u_R B with A = sum_s coef_{R-1}[s] G_{2s} and
+// B = sum_s coef_{R-1}[s] G_{2s+1} -- two MSMs that need only the first R-1 challenges and therefore run on a side slot DURING the last round
+// (kh_ipa_open); the host finishes with one scalar multiplication.  out = [A scalars | B scalars], n each; coef holds coef_{R-2} when the
+// fold of round R-1 is still pending (has_fold: u = its challenge), else coef_{R-1}.
+template <class F>
+__global__ void k_sg_split(const u64* __restrict__ coef, size_t n, int has_fold, Fe4 u4, u64* __restrict__ out) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const size_t s = t >> 1;
+    Fe<F> c = Fe<F>::load(coef + 4 * (has_fold ? s >> 1 : s));
+    if (has_fold && (s & 1)) c = mul<F>(c, Fe<F>::load(u4.l));
+    const Fe<F> z = Fe<F>::zero();
+    ((t & 1) ? z : c).store(out + 4 * t);
+    ((t & 1) ? c : z).store(out + 4 * (n + t));
+}
+int ipa_sg_split(hipStream_t s, int field, const uint64_t* coef, size_t n, int has_fold, const uint64_t u[4], uint64_t* out) {
+    Fe4 u4; memcpy(u4.l, u, 32);
+    dim3 g((unsigned)((n + 255) / 256));
+    if (field == KH_FIELD_FP) hipLaunchKernelGGL((k_sg_split<FpParams>), g, dim3(256), 0, s, coef, n, has_fold, u4, out);
+    else hipLaunchKernelGGL((k_sg_split<FqParams>), g, dim3(256), 0, s, coef, n, has_fold, u4, out);
+    KH_HIP(hipGetLastError());
+    return KH_OK;
+}
+
 // ---------------------------------------------------------------- challenge polynomial coefficients
 // b_poly_coefficients (commitment.rs:464-476): s[i] = prod_{j : bit j of i} chals[rounds - 1 - j].  One thread per
 // coefficient, <= rounds products.  With `rs`: out[i] = sum_j rs[j] * s_j[i] over the k challenge sets, the

@@ -42,6 +42,7 @@ int ipa_round_prepare(hipStream_t s, int field, const uint64_t* a, const uint64_
                       const uint64_t rand_l[4], const uint64_t rand_r[4], uint64_t* sc, uint64_t* partial);
 int ipa_round_fold(hipStream_t s, int field, const uint64_t* a, const uint64_t* b, const uint64_t* coef, size_t Nj, size_t ncoef,
                    const uint64_t u[4], const uint64_t uinv[4], uint64_t* a2, uint64_t* b2, uint64_t* coef2);
+int ipa_sg_split(hipStream_t s, int field, const uint64_t* coef, size_t n, int has_fold, const uint64_t u[4], uint64_t* out);
 int bpoly_run(hipStream_t s, int field, const uint64_t* chals_dev, unsigned rounds, size_t k, const uint64_t* rs_dev, uint64_t* out_dev);
 // poly.hip
 int poly_lincomb(Context& C, int field, const uint64_t* const* segs_dev, const size_t* lens, const uint64_t* scales, size_t m, uint64_t* out_dev, size_t out_len);
