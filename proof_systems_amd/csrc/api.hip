@@ -1121,6 +1121,7 @@ struct kh_ipa {
     std::vector<uint64_t> tab;            // H / U window multiples staged for the asynchronous upload of kh_ipa_begin
     int sg_slot = -1;                     // pipeline slot holding the two half-sums of sg launched during the last round (kh_ipa_open), -1: none
     bool sg_want = false;                 // kh_ipa_open asks the last kh_ipa_round_lr to launch them
+    std::vector<hipGraphExec_t> retired;  // the previous opening's executable graphs: destroyed underneath the first round's GPU time
 };
 
 static int ipa_begin_common(kh_srs_t* srs, const uint64_t* a, size_t a_len, const uint64_t* b, size_t b_len, const uint64_t u_base_xy[8], kh_ipa_t** out,
@@ -1139,13 +1140,17 @@ static int ipa_begin_common(kh_srs_t* srs, const uint64_t* a, size_t a_len, cons
     // between the rounds of an opening); replaying it after the caller has freed and allocated buffers in between faulted
     // on ROCm 7.2 when another HIP user (PyTorch) shared the process.  Re-capturing costs one extra un-graphed round.
     static const bool graph_reset = !(getenv("KH_GRAPH_KEEP") && atoi(getenv("KH_GRAPH_KEEP")) != 0);
+    static const bool begin_timing = getenv("KH_IPA_TIMING") != nullptr;
+    std::vector<hipGraphExec_t> retired;
+    const auto b0_ = std::chrono::steady_clock::now();
     if (graph_reset)
         for (int i = 0; i < MSM_SLOTS; i++) {
             MsmSlot& S = C.slot[i];
             if (S.busy) continue;
-            if (S.gexec) { (void)hipGraphExecDestroy(S.gexec); S.gexec = nullptr; }
+            if (S.gexec) { retired.push_back(S.gexec); S.gexec = nullptr; }      // destroyed while the first round runs (~0.2 ms of host time each)
             S.gkey = 0; S.gseen = 0;
         }
+    const auto b1_ = std::chrono::steady_clock::now();
     std::unique_ptr<kh_ipa> st(new kh_ipa);
     st->srs = srs; st->curve = srs->curve; st->field = khost::scalar_field_id(srs->curve); st->n = n; st->cur = n;
     for (int i = 0; i < 2; i++) {
@@ -1170,7 +1175,9 @@ static int ipa_begin_common(kh_srs_t* srs, const uint64_t* a, size_t a_len, cons
         host_window_multiples(srs->curve, srs->h, W, srs->g_precomp_c, srs->h_multiples.data());
     }
     for (int w = 0; w < W; w++) memcpy(&tab[16 * w], &srs->h_multiples[8 * w], 64);
+    const auto b2_ = std::chrono::steady_clock::now();
     host_window_multiples(srs->curve, u_base_xy, W, srs->g_precomp_c, col.data());
+    const auto b3_ = std::chrono::steady_clock::now();
     for (int w = 0; w < W; w++) memcpy(&tab[16 * w + 8], &col[8 * w], 64);
     hipStream_t s = C.stream;
     KH_HIP(hipMemcpy2DAsync((char*)srs->g.p + n * 64, srs->g_stride * 64, tab.data(), 128, 128, W, hipMemcpyHostToDevice, s));
@@ -1181,7 +1188,12 @@ static int ipa_begin_common(kh_srs_t* srs, const uint64_t* a, size_t a_len, cons
     KH_HIP(hipMemcpyAsync(st->coef[0].p, &ones[st->field & 1], 32, hipMemcpyHostToDevice, s));
     if (kind != hipMemcpyDeviceToDevice) KH_HIP(hipStreamSynchronize(s));      // host inputs may be the caller's temporaries
     KH_HIP(hipEventRecord(st->ev, s));
+    if (begin_timing) {
+        auto us = [](std::chrono::steady_clock::time_point x, std::chrono::steady_clock::time_point y) { return std::chrono::duration<double, std::micro>(y - x).count(); };
+        fprintf(stderr, "kh_ipa_begin: graph reset %.0f us, workspace %.0f, U multiples %.0f, uploads + copies %.0f\n", us(b0_, b1_), us(b1_, b2_), us(b2_, b3_), us(b3_, std::chrono::steady_clock::now()));
+    }
     srs->ipa_live = true;
+    st->retired = std::move(retired);
     *out = st.release();
     return KH_OK;
 }
@@ -1237,6 +1249,8 @@ int kh_ipa_round_lr(kh_ipa_t* st, const uint64_t rand_l[4], const uint64_t rand_
     MsmBasis bs; bs.pts = srs->g.p; bs.inf = nullptr; bs.n = srs->g_stride; bs.stride = srs->g_stride; bs.precomp_c = srs->g_precomp_c;
     if ((rc = msm_enqueue(C, S, st->curve, bs, 0, st->sc->as<uint64_t>(), st->n + 2, 2, 1, /*use_graph=*/1))) return rc;
     if (st->sg_want && st->cur == 2) { st->sg_want = false; ipa_sg_prelaunch_locked(st, C, p, had_fold); }
+    for (hipGraphExec_t g : st->retired) (void)hipGraphExecDestroy(g);      // the GPU is busy with this round for the next ~0.3 ms
+    st->retired.clear();
     if ((rc = wait_then_finish(lk, C, S, lr_xy, lr_inf))) return rc;
     st->lr_done = true;
     return KH_OK;
@@ -1348,6 +1362,8 @@ void kh_ipa_free(kh_ipa_t* st) {
     if (!st) return;
     kh::DeviceScope dev_scope_(st->srs ? st->srs->device : -1);
     Context& C = ctx();
+    for (hipGraphExec_t g : st->retired) (void)hipGraphExecDestroy(g);
+    st->retired.clear();
     if (st->sg_slot >= 0) {                                // an opening that failed after launching the halves of sg: release their slot
         uint64_t ab[16]; uint8_t abi[2];
         std::unique_lock<std::mutex> ul(C.mu);
