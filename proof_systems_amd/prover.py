@@ -65,6 +65,11 @@ class Fld:
     def rand(self, rng) -> int:
         return int.from_bytes(rng.bytes(40), "little") % self.p
 
+    def rand_many(self, rng, k: int):
+        """k uniform field elements from ONE draw of the generator (the per-call overhead of numpy's Generator.bytes dominates `rand`)"""
+        b = rng.bytes(40 * k)
+        return [int.from_bytes(b[40 * i:40 * i + 40], "little") % self.p for i in range(k)]
+
 
 def sample_shifts(F: Fld, log2_n: int):
     """Shifts::new (permutation.rs:140-199): shift_0 = 1, then quadratic non-residues outside the domain from Blake2b512(counter)."""
@@ -259,7 +264,7 @@ def create_proof(ix: ProverIndex, witness, rng, timings=None, check: bool = True
         assert wit.shape[1] + ZK_ROWS <= n, "NoRoomForZkInWitness"
         if wit.shape[1] + ZK_ROWS < n:
             ev.zero()
-        zk = F.limbs_many([F.rand(rng) for _ in range(COLUMNS * ZK_ROWS)]).reshape(COLUMNS, ZK_ROWS, 4)
+        zk = F.limbs_many(F.rand_many(rng, COLUMNS * ZK_ROWS)).reshape(COLUMNS, ZK_ROWS, 4)
         ev.upload_2d(0, NB, wit)                             # 15 columns, each into its padded device column, one transfer
         ev.upload_2d((n - ZK_ROWS) * 32, NB, zk)
     else:
@@ -293,7 +298,7 @@ def create_proof(ix: ProverIndex, witness, rng, timings=None, check: bool = True
     w8 = PERMUTS if LI is None and not (ix.live_gate_types & set(ix.GATE_TYPES)) else COLUMNS
     khip.lde_dev(fid, cf, logn, 3, e8, w8)
     com, inf = srs.msm_wait(tk)
-    w_blind = [F.rand(rng) for _ in range(COLUMNS)]
+    w_blind = F.rand_many(rng, COLUMNS)
     w_comm, w_inf = srs.mask_custom(com, inf, F.limbs_many(w_blind))
     fq.absorb_g(w_comm, w_inf)
     lkp = None
@@ -342,7 +347,7 @@ def create_proof(ix: ProverIndex, witness, rng, timings=None, check: bool = True
         last = F.value(ev.download_at((COLUMNS * n + n - ZK_ROWS) * 32, (4,)))
         if last != 1:
             raise RuntimeError("final value of the permutation accumulator is not 1 (permutation.rs:566-568)")
-    ev.upload_at((COLUMNS * n + n - ZK_ROWS + 1) * 32, F.limbs_many([F.rand(rng), F.rand(rng)]))     # the two random rows
+    ev.upload_at((COLUMNS * n + n - ZK_ROWS + 1) * 32, F.limbs_many(F.rand_many(rng, 2)))     # the two random rows
     khip.dev_copy(cf.ptr + COLUMNS * NB, zcol.ptr, NB)
     khip.ntt_dev(fid, cf.view(COLUMNS * NB), logn, True, 1)
     zc = cf.view(COLUMNS * NB)
@@ -405,7 +410,7 @@ def create_proof(ix: ProverIndex, witness, rng, timings=None, check: bool = True
             raise RuntimeError("permutation boundary division rest (permutation.rs:301-321)")
     khip.poly_lincomb_dev(fid, [quot, b1, b2], [7 * n, n - 1, n - 1], F.limbs_many([1, alphas[1], alphas[2]]), quot, 7 * n)
     com, inf = srs.msm_batch_dev(quot.ptr, n, 7)
-    t_blind = [F.rand(rng) for _ in range(7)]
+    t_blind = F.rand_many(rng, 7)
     t_comm, t_inf = srs.mask_custom(com, inf, F.limbs_many(t_blind))
     fq.absorb_g(t_comm, t_inf)
     mark("quotient")
@@ -478,7 +483,7 @@ def create_proof(ix: ProverIndex, witness, rng, timings=None, check: bool = True
         cip = (cip + ps * ((e0 + u * e1) % F.p)) % F.p                  # combined_inner_product (commitment.rs:622-657) = <p, b_init>
         ps = ps * v % F.p
     sp = fq_before
-    bl = [F.rand(rng) for _ in range(2 * logn + 2)]         # the reference's draw order: (rand_l, rand_r) per round, then d, r_delta
+    bl = F.rand_many(rng, 2 * logn + 2)         # the reference's draw order: (rand_l, rand_r) per round, then d, r_delta
     lr_xy, lr_inf, delta, dinf, z1_l, z2_l, sg, sg_inf = khip.ipa_open(srs, a_dev, b_dev, n, F.limbs(cip), F.limbs(blinding_factor), sp, F.limbs_many(bl))
     opening = {"lr": [(lr_xy[r], lr_inf[r]) for r in range(logn)], "delta": (delta, dinf), "z1": F.value(z1_l), "z2": F.value(z2_l), "sg": (sg, sg_inf)}
     sp.free(); fq.free()

@@ -14,4 +14,4 @@ for _ in range(3): prover.create_proof(ix, wit, rng, check=False)
 pr = cProfile.Profile(); pr.enable()
 for _ in range(5): prover.create_proof(ix, wit, rng, check=False)
 pr.disable()
-st = pstats.Stats(pr); st.sort_stats("tottime").print_stats(22)
+st = pstats.Stats(pr); st.sort_stats("tottime").print_stats(45)
