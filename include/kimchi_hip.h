@@ -359,7 +359,8 @@ int kh_msm_batch_dev(kh_srs_t *srs, int basis, unsigned chunk, size_t offset,
  * library's four MSM pipeline slots and returns at once; kh_msm_wait blocks for that job and
  * finishes it (XYZZ -> affine on the host).  With jobs in flight the sort of one MSM and the
  * latency-bound tail (bucket reduction) of another run underneath the bucket accumulation of a third.
- * At most KH_MSM_SLOTS (4) un-waited tickets; a further submit returns KH_E_INVALID. */
+ * At most KH_MSM_SLOTS (4) un-waited tickets: a further submit by the thread that holds them all returns KH_E_INVALID at once; when
+ * some of them are OTHER threads' (more provers than slots) it waits -- two seconds at most -- for one of those to be waited for. */
 #define KH_MSM_SLOTS 4
 int kh_msm_submit(kh_srs_t *srs, int basis, unsigned chunk, size_t offset,
                   const uint64_t *scalars_dev, size_t n, size_t k, int scalars_are_montgomery,

@@ -414,17 +414,24 @@ static int free_slot(Context& C) {
     for (int i = 0; i < MSM_SLOTS; i++) if (!C.slot[i].busy) return i;
     return -1;
 }
-// a synchronous entry point may wait for a slot that another thread is blocked on (it will be released); slots held by
-// un-waited kh_msm_submit tickets never free up by themselves, so with only those busy the answer is still -1
+// a caller may wait for a slot that another thread is blocked on (it will be released) or that holds ANOTHER thread's un-waited
+// kh_msm_submit ticket (more provers than slots: that thread is on its way to kh_msm_wait) -- the latter for two seconds at most, in case
+// the tickets' owners are themselves waiting here; with only the caller's own un-waited tickets busy the answer is -1 at once
 // side_first: take a slot other than the main stream's when one is free -- a job that may CAPTURE its launch sequence into a hipGraph
 // must not do so on the stream other host threads synchronise and launch on (a capture is invalidated by, and invalidates, such calls)
 static int acquire_slot(std::unique_lock<std::mutex>* lk, Context& C, bool side_first = false) {
+    const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(2);
     for (;;) {
         int si = -1;
         if (side_first) for (int i = MSM_SLOTS - 1; i >= 1; i--) if (!C.slot[i].busy) { si = i; break; }
         if (si < 0) si = free_slot(C);
-        if (si >= 0 || !lk || C.sync_inflight == 0) return si;
-        C.cv.wait(*lk);
+        if (si >= 0 || !lk) return si;
+        if (C.sync_inflight == 0) {
+            bool others = false;
+            for (int i = 0; i < MSM_SLOTS; i++) if (C.slot[i].busy && C.slot[i].owner != std::this_thread::get_id()) others = true;
+            if (!others || std::chrono::steady_clock::now() > deadline) return -1;
+            C.cv.wait_for(*lk, std::chrono::milliseconds(50));
+        } else C.cv.wait(*lk);
     }
 }
 // enqueue on a free slot; returns the slot index through *slot_out
@@ -582,9 +589,9 @@ int kh_msm_submit(kh_srs_t* srs, int basis, unsigned chunk, size_t offset, const
     KH_REQUIRE(scalars_dev || n == 0 || k == 0, "null scalars");
     int rc = ensure_init(); if (rc) return rc;
     Context& C = ctx();
-    std::lock_guard<std::mutex> lk(C.mu);
+    std::unique_lock<std::mutex> lk(C.mu);
     int si = -1;
-    if ((rc = msm_submit_locked(C, srs, basis, chunk, offset, scalars_dev, true, n, k, scalars_are_montgomery, &si))) return rc;
+    if ((rc = msm_submit_locked(C, srs, basis, chunk, offset, scalars_dev, true, n, k, scalars_are_montgomery, &si, &lk))) return rc;
     *ticket = C.slot[si].ticket | ((uint64_t)C.device << 56);      // the device rides in the top byte: kh_msm_wait may run on any thread
     return KH_OK;
 }

@@ -12,6 +12,7 @@
 #include <mutex>
 #include <set>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/kimchi_hip.h"
@@ -98,6 +99,7 @@ struct MsmSlot {
     hipEvent_t done = nullptr;
     // pending job (set by enqueue, consumed by finish)
     bool busy = false;
+    std::thread::id owner;             // the host thread that queued the pending job (acquire_slot: another thread's ticket will be waited for)
     uint64_t ticket = 0;
     int curve = 0, W = 0, c = 0, precomp = 0, planes = 0, plane_shift[2] = {0, 0};
     size_t k = 0, ngroups = 0;

@@ -1193,7 +1193,7 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
         if (C.gexec && C.gkey == key) {                    // replay
             KH_HIP(hipGraphLaunch(C.gexec, s));
             KH_HIP(hipEventRecord(C.done, s));
-            C.busy = true; C.ticket = Ctx.next_ticket++;
+            C.busy = true; C.owner = std::this_thread::get_id(); C.ticket = Ctx.next_ticket++;
             C.curve = curve; C.W = C.g_W; C.c = C.g_c; C.precomp = C.g_precomp; C.k = k; C.ngroups = C.g_ngroups; C.planes = C.g_planes;
             C.plane_shift[0] = C.g_shift[0]; C.plane_shift[1] = C.g_shift[1];
             C.timer.n = 0;                                 // no per-phase events inside a graph
@@ -1354,7 +1354,7 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
         KH_HIP(hipGraphLaunch(C.gexec, s));
     }
     KH_HIP(hipEventRecord(C.done, s));
-    C.busy = true; C.ticket = Ctx.next_ticket++;
+    C.busy = true; C.owner = std::this_thread::get_id(); C.ticket = Ctx.next_ticket++;
     C.curve = curve; C.W = W; C.c = c; C.precomp = precomp; C.k = k; C.ngroups = ngroups; C.planes = (int)planes; C.plane_shift[0] = (int)mg.wd[0]; C.plane_shift[1] = (int)mg.wd[1];
     return KH_OK;
 }
@@ -1362,7 +1362,7 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
 int msm_enqueue(Context& C, MsmSlot& S, int curve, const MsmBasis& basis, size_t offset, const uint64_t* scalars_dev, size_t n, size_t k, int mont,
                 int use_graph) {
     if (n == 0 || k == 0) {          // nothing to launch: finish() emits k identities
-        S.busy = true; S.ticket = C.next_ticket++; S.curve = curve; S.k = k; S.ngroups = 0; S.W = 0; S.c = 0; S.precomp = 1; S.planes = 0;
+        S.busy = true; S.owner = std::this_thread::get_id(); S.ticket = C.next_ticket++; S.curve = curve; S.k = k; S.ngroups = 0; S.W = 0; S.c = 0; S.precomp = 1; S.planes = 0;
         KH_HIP(hipEventRecord(S.done, S.stream));
         return KH_OK;
     }

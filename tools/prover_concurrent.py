@@ -22,11 +22,15 @@ for T in counts:
 
     def work(t):
         rng = np.random.default_rng(100 + t)
-        bar.wait()
-        for _ in range(PROOFS):
-            prover.create_proof(ixs[t], wit, rng, check=False)
-        bar.wait()
-    th = [threading.Thread(target=work, args=(t,)) for t in range(T)]
+        try:
+            bar.wait()
+            for _ in range(PROOFS):
+                prover.create_proof(ixs[t], wit, rng, check=False)
+            bar.wait()
+        except BaseException:
+            bar.abort()                  # a failing prover must not leave the others (and the GPU box) waiting at the barrier
+            raise
+    th = [threading.Thread(target=work, args=(t,), daemon=True) for t in range(T)]
     for t in th:
         t.start()
     bar.wait(); t0 = time.perf_counter(); bar.wait(); dt = time.perf_counter() - t0
