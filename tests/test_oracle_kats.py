@@ -386,3 +386,55 @@ def test_verifier_accepts_reference_proof(golden):
     assert P.ipa_verify(c, g, h, [dict(vi, sponge=vi["sponge"].clone())], rng)
     bad = dict(vi, sponge=vi["sponge"].clone(), opening=dict(proof, z2=(proof["z2"] + 1) % c.scalar.p))
     assert not P.ipa_verify(c, g, h, [bad], rng)
+
+
+# ---- the identities kh_ipa_open's split of sg relies on (csrc/api.hip: ipa_sg_collect, csrc/ipa.hip: k_sg_split), against the literal definitions
+
+def test_sg_splits_on_the_last_challenge():
+    """sg = <b_poly_coefficients(chals), G> (ipa.rs:452-470) = A + [u_last] B with A / B the sums over the even / odd points weighted by the
+    coefficient vector of the EARLIER challenges: what lets the device compute A and B underneath the last round."""
+    curve = P.VESTA
+    F = curve.scalar
+    rng = random.Random(11)
+    rounds = 4
+    g = [curve.mul(curve.gen, rng.randrange(1, F.p)) for _ in range(1 << rounds)]
+    chals = [rng.randrange(1, F.p) for _ in range(rounds)]          # chals[j] = the challenge of round j + 1
+    sg = curve.msm(g, P.b_poly_coefficients(F, chals))
+    # the folded basis of the literal loop (g <- g_lo + u g_hi, ipa.rs:1006) ends at the same point
+    gg = list(g)
+    for u in chals:
+        m = len(gg) // 2
+        gg = [curve.add(gg[i], curve.mul(gg[i + m], u)) for i in range(m)]
+    assert gg[0] == sg
+    # device convention (k_ipa_fold): coef' [2i] = coef[i], coef'[2i+1] = coef[i] u, so the last challenge sits on the lowest index bit
+    coef = [1]
+    for u in chals[:-1]:
+        coef = [c * f % F.p for c in coef for f in (1, u)]
+    A = curve.msm(g[0::2], coef)
+    B = curve.msm(g[1::2], coef)
+    assert curve.add(A, curve.mul(B, chals[-1])) == sg
+
+
+def test_endo_challenge_decomposition():
+    """u = challenge_to_field(c) = a endo_r + b with a, b < 2^67 (sponge.rs:190-226), hence [u] B = [a] phi(B) + [b] B with
+    phi(x, y) = (endo_q x, y): the 67-step joint ladder the host uses instead of a 255-bit one."""
+    curve = P.VESTA
+    F = curve.scalar
+    eq, er = P.endos(curve)
+    rng = random.Random(12)
+    Bp = curve.mul(curve.gen, rng.randrange(1, F.p))
+    for _ in range(4):
+        c = rng.getrandbits(128)
+        a = b = 2
+        for i in reversed(range(64)):
+            a, b = 2 * a, 2 * b
+            s = 1 if (c >> (2 * i)) & 1 else -1
+            if (c >> (2 * i + 1)) & 1:
+                a += s
+            else:
+                b += s
+        assert 0 < a < 1 << 67 and 0 < b < 1 << 67
+        u = P.challenge_to_field(F, c, er)
+        assert (a * er + b) % F.p == u
+        phi = (Bp[0] * eq % curve.base.p, Bp[1])
+        assert curve.add(curve.mul(phi, a), curve.mul(Bp, b)) == curve.mul(Bp, u)
