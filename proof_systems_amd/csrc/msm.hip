@@ -861,7 +861,7 @@ k_sum_final(const uint8_t* __restrict__ in, u32 count, uint8_t* __restrict__ out
     if (threadIdx.x == 0) acc.store(out + q * 128);
 }
 
-// Latency path of the weighted reduction for one to four MSMs over the tables (the per-round L / R of an opening,
+// Latency path of the weighted reduction for one to eight MSMs over the tables (the per-round L / R of an opening, the seven chunks of t,
 // a lone commitment).  Bucket t has weight t + 1; with t = (a, b, c) split into three digit fields,
 //   sum_t (t+1) B_t = 2^(f0+f1) sum_a a A_a + 2^f0 sum_b b B_b + sum_c (c+1) C_c ,
 // A_a / B_b / C_c = the marginal sums of the buckets over the other two digits.  The marginals are plain tree
@@ -936,7 +936,7 @@ k_bucket_sum_q(const u32* __restrict__ toff, size_t nkeys, const uint8_t* __rest
     if (live) quad_store<BF>(buckets + key * 128, acc);
 }
 
-// Quad versions of the two reduction kernels for the latency path (<= 4 MSMs): the same marginal sums with the
+// Quad versions of the two reduction kernels for the latency path (<= 8 MSMs): the same marginal sums with the
 // lane-cooperative addition of coop.cuh -- every addition of the chain costs 5 product rounds instead of 14 products.
 template <class BF>
 __global__ void __launch_bounds__(1024)
@@ -1299,7 +1299,7 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
     C.timer.mark("accumulate", s);
     // 6 bucket sums
     static const bool bsum_quad = !getenv("KH_NO_BSUM_QUAD");
-    static const size_t bsum_maxg = getenv("KH_QUAD_MAXG") ? (size_t)atol(getenv("KH_QUAD_MAXG")) : 4;
+    static const size_t bsum_maxg = getenv("KH_QUAD_MAXG") ? (size_t)atol(getenv("KH_QUAD_MAXG")) : 8;     // 5 / 7 / 8 MSMs of 2^16: 0.94 / 1.09 / 1.14 -> 0.85 / 1.05 / 1.09 ms against 4
     if (precomp && ngroups <= bsum_maxg && bsum_quad)
         hipLaunchKernelGGL((k_bucket_sum_q<BF>), dim3((unsigned)((4 * nkeys + 255) / 256)), dim3(256), 0, s,
                            C.ws_toff.as<u32>(), nkeys, C.ws_partial.as<uint8_t>(), C.ws_buckets.as<uint8_t>(), C.ws_biglist.as<u32>(),
@@ -1319,7 +1319,7 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
         // few groups: 256 threads per marginal (4 sequential additions + the tree: shortest chain); batches: one wave
         // per marginal (16 + 6 additions deep, but 2.2x less issue work -- batches are throughput-bound)
         static const int quad_threads = getenv("KH_QUAD") ? atoi(getenv("KH_QUAD")) : 256;   // 0: scalar additions
-        static const size_t quad_maxg = getenv("KH_QUAD_MAXG") ? (size_t)atol(getenv("KH_QUAD_MAXG")) : 4;
+        static const size_t quad_maxg = getenv("KH_QUAD_MAXG") ? (size_t)atol(getenv("KH_QUAD_MAXG")) : 8;
         if (ngroups <= quad_maxg && quad_threads > 0) {    // latency path: lane-cooperative additions (coop.cuh)
             hipLaunchKernelGGL((k_marginals_q<BF>), dim3(32, 3, (unsigned)ngroups), dim3(quad_threads), 0, s, C.ws_buckets.as<uint8_t>(), mg, C.ws_seg.as<uint8_t>());
             hipLaunchKernelGGL((k_marginal_fin_q<BF>), dim3(3, (unsigned)ngroups), dim3(128), 0, s, C.ws_seg.as<uint8_t>(), mg, (uint8_t*)C.pinned);   // straight into the pinned host staging

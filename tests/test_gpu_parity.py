@@ -576,6 +576,25 @@ def test_msm_randomized_differential(khip):
         assert ginf == winf and (winf or np.array_equal(got, want)), case
 
 
+@pytest.mark.parametrize("k", [5, 8])
+def test_batches_of_five_to_eight_over_the_tables(khip, k):
+    """The seven chunks of t (prover.rs:923-926) are one batch over the monomial basis: batches of up to eight take the lane-cooperative
+    reduction kernels of the latency path; uniform scalars, and a skewed batch (most scalars equal) for the hot-bucket kernels."""
+    rng = np.random.default_rng(4242 + k)
+    n = 1 << 12
+    g = cref.srs_generate(0, 3, n, threads=8)
+    srs = khip.Srs(0, g)
+    for skew in (False, True):
+        cols = np.stack([rand_fe_fast(rng, n) for _ in range(k)])
+        if skew:
+            cols[:, : n - 37] = cols[0, 0]
+        got, ginf = srs.msm_batch(cols)
+        for j in range(k):
+            w, wi = cref.msm(0, g, cols[j], threads=8)
+            assert bool(ginf[j]) == wi and (wi or np.array_equal(got[j], w)), (k, skew, j)
+    srs.close()
+
+
 def test_ntt_randomized_differential(khip):
     rng = np.random.default_rng(777)
     for case in range(24):
