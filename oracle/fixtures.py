@@ -105,6 +105,7 @@ def oracle_views(fx, h):
                "coefficients": [one(e) for e in ev["coefficients"]]})
     for k in ("lookup_aggregation", "lookup_table"):
         pe[k] = one(ev[k]) if ev[k] is not None else None
+    pe["optional_gate_selectors"] = [one(e) if e is not None else None for e in ev["optional_gate_selectors"]]
     pe["lookup_sorted"] = [one(e) for e in ev["lookup_sorted"] if e is not None]
     pe["lookup_selectors"] = {q: one(e) for q, e in ev["lookup_selectors"].items() if e is not None}
     proof = dict(fx["proof"]); proof["evals"] = pe

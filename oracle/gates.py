@@ -247,7 +247,37 @@ def endomul_scalar_witness(F: P.Field, scalar: int, endo_scalar: int, num_bits: 
     return rows, (a * endo_scalar + b) % p
 
 
-ROW_MACHINES = {"Poseidon": 15, "CompleteAdd": 7, "VarBaseMul": 21, "EndoMul": 12, "EndoMulScalar": 11}
+# ------------------------------------------------------------------------------------------------------------ Xor16
+def xor16_row(F: P.Field, curr, nxt) -> List[int]:
+    """xor.rs:152-174: for in1, in2, out (columns 0, 1, 2): four 4-bit nybbles + 2^16 * the next row's value - the value."""
+    p = F.p
+    return [(curr[3 + 4 * i] + curr[4 + 4 * i] * 16 + curr[5 + 4 * i] * 256 + curr[6 + 4 * i] * 4096 + 65536 * nxt[i] - curr[i]) % p for i in range(3)]
+
+
+def xor_witness(F: P.Field, in1: int, in2: int, bits: int) -> List[List[int]]:
+    """create_xor_witness (xor.rs:262-296, layout :177-232): num_xors(bits) Xor16 rows + the zero row, as rows of 15 cells."""
+    assert in1 < (1 << bits) and in2 < (1 << bits)
+    out = in1 ^ in2
+    rows = []
+    for i in range(-(-bits // 16)):
+        vals = [in1 >> (16 * i), in2 >> (16 * i), out >> (16 * i)]
+        row = list(vals)
+        for v in vals:
+            row += [(v >> (4 * k)) & 15 for k in range(4)]
+        rows.append(row)
+    rows.append([0] * COLUMNS)
+    return rows
+
+
+def and_witness(F: P.Field, in1: int, in2: int, nbytes: int) -> List[List[int]]:
+    """create_and_witness (and.rs:174-204): the xor gadget's rows + the double generic row (in1, in2, sum, sum, xor, and)."""
+    rows = xor_witness(F, in1, in2, 8 * nbytes)
+    s = (in1 + in2) % F.p
+    rows.append([in1, in2, s, s, in1 ^ in2, in1 & in2] + [0] * 9)
+    return rows
+
+
+ROW_MACHINES = {"Poseidon": 15, "CompleteAdd": 7, "VarBaseMul": 21, "EndoMul": 12, "EndoMulScalar": 11, "Xor16": 3}
 
 
 def combined_row(F: P.Field, name: str, curr, nxt, coeffs, alpha: int, mds=None, endo: int = 0) -> int:
@@ -260,8 +290,12 @@ def combined_row(F: P.Field, name: str, curr, nxt, coeffs, alpha: int, mds=None,
         cs = varbasemul_row(F, curr, nxt)
     elif name == "EndoMul":
         cs = endomul_row(F, curr, nxt, endo)
-    else:
+    elif name == "Xor16":
+        cs = xor16_row(F, curr, nxt)
+    elif name == "EndoMulScalar":
         cs = endomul_scalar_row(F, curr)
+    else:
+        raise NotImplementedError(name)
     assert len(cs) == ROW_MACHINES[name]
     acc, a = 0, 1
     for c in cs:

@@ -81,7 +81,7 @@ def build_index(F: P.Field, log2_n: int, gate_coeffs: Sequence[Sequence[int]], w
 
 def eval_permutation_vanishing_polynomial(ix, x: int) -> int:
     F = ix["F"]; n = ix["n"]
-    t = pow(ix["omega"], n - ZK_ROWS, F.p)
+    t = pow(ix["omega"], n - ix.get("zk_rows", ZK_ROWS), F.p)
     return (x - t) * (x - t * ix["omega"]) % F.p * (x - pow(ix["omega"], n - 1, F.p)) % F.p
 
 
@@ -97,6 +97,10 @@ def verifier_index_digest(curve: P.Curve, vix) -> int:
         absorb_commitment(sp, c)
     for k in ("generic_comm", "psm_comm", "complete_add_comm", "mul_comm", "emul_comm", "endomul_scalar_comm"):
         absorb_commitment(sp, vix[k])
+    opt = vix.get("optional_comms") or [None] * 6           # struct order: range_check0, range_check1, foreign_field_add, foreign_field_mul, xor, rot
+    for k in (0, 1, 3, 2, 4, 5):                            # the digest absorbs foreign_field_mul BEFORE foreign_field_add (verifier_index.rs:466-480)
+        if opt[k] is not None:
+            absorb_commitment(sp, opt[k])
     li = vix.get("lookup_index")
     if li:                                                 # verifier_index.rs:482-525: table columns, table ids, (runtime selector), pattern selectors
         for c in li["lookup_table"]:
@@ -146,6 +150,13 @@ def generic_constant_term(F: P.Field, ev, alpha: int) -> int:
 
 GATE_SELECTORS = (("Poseidon", "poseidon_selector"), ("CompleteAdd", "complete_add_selector"), ("VarBaseMul", "mul_selector"),
                   ("EndoMul", "emul_selector"), ("EndoMulScalar", "endomul_scalar_selector"))
+# the optional gates, in the order of ProofEvaluations / the Fr-sponge / the opening (proof.rs:95-106, plonk_sponge.rs:103-122,
+# verifier.rs:1003-1038); evals["optional_gate_selectors"][k] is None for a gate type the circuit does not use
+OPTIONAL_GATES = ("RangeCheck0", "RangeCheck1", "ForeignFieldAdd", "ForeignFieldMul", "Xor16", "Rot64")
+
+
+def optional_selectors(ev):
+    return list(ev.get("optional_gate_selectors") or [None] * 6)
 
 
 def gate_library_constant_term(curve: P.Curve, ev, alpha: int) -> int:
@@ -156,6 +167,7 @@ def gate_library_constant_term(curve: P.Curve, ev, alpha: int) -> int:
     F = curve.scalar
     total = 0
     live = [(name, ev[key][0]) for name, key in GATE_SELECTORS if ev[key][0] % F.p]
+    live += [(name, e[0]) for name, e in zip(OPTIONAL_GATES, optional_selectors(ev)) if e is not None]
     if not live:
         return 0
     curr = [e[0] for e in ev["w"]]; nxt = [e[1] for e in ev["w"]]; co = [e[0] for e in ev["coefficients"]]
@@ -181,6 +193,7 @@ def columns_in_opening_order(ev):
     the verifier's evaluation list (verifier.rs:988-1010) use the same order."""
     out = [ev[k] for k in EVAL_ORDER]
     out += list(ev["w"]) + list(ev["coefficients"]) + list(ev["s"])
+    out += [e for e in optional_selectors(ev) if e is not None]
     return out
 
 
@@ -231,15 +244,84 @@ def lookup_constant_term(F: P.Field, vix, ev, ch, zeta: int) -> int:
     return sum(pow(ch["alpha"], ALPHA_LOOKUP0 + k, F.p) * v for k, v in enumerate(vals)) % F.p
 
 
-def lookup_table_commitment(curve: P.Curve, li, jc: int):
-    """combine_table (lookup/tables/mod.rs:164-199): sum_i jc^i * column_i + jc^max_joint_size * table_ids (one chunk)."""
+def lookup_table_commitment(curve: P.Curve, li, jc: int, runtime=None):
+    """combine_table (lookup/tables/mod.rs:164-199): sum_i jc^i * column_i + jc^max_joint_size * table_ids (+ jc * runtime), per chunk."""
     F = curve.scalar
-    acc, j = None, 1
-    for c in li["lookup_table"]:
-        acc = curve.add(acc, curve.mul(c[0], j)); j = j * jc % F.p
-    if li["table_ids"] is not None:
-        acc = curve.add(acc, curve.mul(li["table_ids"][0], pow(jc, li["max_joint_size"], F.p)))
-    return [acc]
+    nch = len(li["lookup_table"][0])
+    out = []
+    for k in range(nch):
+        acc, j = None, 1
+        for c in li["lookup_table"]:
+            if c[k] is not None:
+                acc = curve.add(acc, curve.mul(c[k], j))
+            j = j * jc % F.p
+        if li["table_ids"] is not None and li["table_ids"][k] is not None:
+            acc = curve.add(acc, curve.mul(li["table_ids"][k], pow(jc, li["max_joint_size"], F.p)))
+        if runtime is not None and runtime[k] is not None:
+            acc = curve.add(acc, curve.mul(runtime[k], jc))
+        out.append(acc)
+    return out
+
+
+def _chunks(e):
+    """an evaluation as (chunks at zeta, chunks at zeta omega): plain pairs of integers are one-chunk evaluations"""
+    if e is None:
+        return None
+    a, b = e
+    return (list(a) if isinstance(a, (list, tuple)) else [a], list(b) if isinstance(b, (list, tuple)) else [b])
+
+
+def normalize_evals(ev):
+    """ProofEvaluations<PointEvaluations<Vec<F>>>: every entry as chunk lists."""
+    out = dict(ev)
+    for k in EVAL_ORDER + ["public", "lookup_aggregation", "lookup_table", "runtime_lookup_table", "runtime_lookup_table_selector"]:
+        if k in ev:
+            out[k] = _chunks(ev[k])
+    for k in ("w", "coefficients", "s", "lookup_sorted"):
+        out[k] = [_chunks(e) for e in ev.get(k, [])]
+    out["optional_gate_selectors"] = [_chunks(e) for e in optional_selectors(ev)]
+    out["lookup_selectors"] = {q: _chunks(e) for q, e in (ev.get("lookup_selectors") or {}).items()}
+    return out
+
+
+def combine_evals(F: P.Field, evn, zeta_srs: int, zetaw_srs: int):
+    """ProofEvaluations::combine (proof.rs:430-470): sum_c chunk_c * (zeta^max_poly_size)^c -- the value of the whole polynomial."""
+    def hz(e):
+        if e is None:
+            return None
+        a = b = 0
+        for c in reversed(e[0]):
+            a = (a * zeta_srs + c) % F.p
+        for c in reversed(e[1]):
+            b = (b * zetaw_srs + c) % F.p
+        return (a, b)
+    out = dict(evn)
+    for k, v in evn.items():
+        if k == "lookup_selectors":
+            out[k] = {q: hz(e) for q, e in v.items()}
+        elif isinstance(v, list):
+            out[k] = [hz(e) for e in v]
+        else:
+            out[k] = hz(v)
+    return out
+
+
+def prev_challenge_evals(F: P.Field, chals, max_poly_size: int, points, powers):
+    """RecursionChallenge::evals (proof.rs:455-494): b_poly at both points, split into two chunks when 2^len(chals) > max_poly_size."""
+    b_len = 1 << len(chals)
+    out = []
+    coeffs = None
+    for x, pw in zip(points, powers):
+        full = P.b_poly(F, chals, x)
+        if max_poly_size == b_len:
+            out.append([full]); continue
+        coeffs = coeffs or P.b_poly_coefficients(F, chals)
+        diff, acc = 0, 1
+        for j in range(max_poly_size, b_len):
+            diff = (diff + acc * coeffs[j]) % F.p
+            acc = acc * x % F.p
+        out.append([(full - diff * pw) % F.p, diff])
+    return out
 
 
 def fiat_shamir(curve: P.Curve, vix, proof, digest: int):
@@ -248,12 +330,17 @@ def fiat_shamir(curve: P.Curve, vix, proof, digest: int):
     _, endo_r = P.endos(curve)
     fq = S.DefaultFqSponge(curve)
     fq.absorb_fq([digest])
+    prev = proof.get("prev_challenges") or []
+    for _chals, comm in prev:
+        absorb_commitment(fq, comm)
     absorb_commitment(fq, vix.get("public_comm") or [vix["h"]])         # public_comm; for an empty public input: the blinding commitment
     for c in proof["w_comm"]:
         absorb_commitment(fq, c)
     li = vix.get("lookup_index")
     joint_combiner = None
-    if li:                                                              # verifier.rs:179-230 (no runtime tables)
+    if li:                                                              # verifier.rs:179-230
+        if li.get("runtime_tables_selector") is not None:
+            absorb_commitment(fq, proof["lookup"]["runtime"])
         joint_combiner = P.challenge_to_field(F, fq.challenge() if li["joint_lookup_used"] else 0, endo_r)
         for c in proof["lookup"]["sorted"]:
             absorb_commitment(fq, c)
@@ -262,19 +349,24 @@ def fiat_shamir(curve: P.Curve, vix, proof, digest: int):
         absorb_commitment(fq, proof["lookup"]["aggreg"])
     absorb_commitment(fq, proof["z_comm"])
     alpha = P.challenge_to_field(F, fq.challenge(), endo_r)
-    assert len(proof["t_comm"]) <= 7
+    n = vix["n"]
+    size = vix.get("max_poly_size", n)
+    assert len(proof["t_comm"]) <= 7 * max(1, n // size)
     absorb_commitment(fq, proof["t_comm"])
     zeta = P.challenge_to_field(F, fq.challenge(), endo_r)
     dg = fq.clone().challenge_fq()
     dg = dg if dg < F.p else 0                                          # FqSponge::digest
     fr = S.ArithmeticSponge(F)
     fr.absorb([dg])
-    fr.absorb([S.ArithmeticSponge(F).squeeze()])                        # prev_challenge_digest of no previous challenges
-    ev = proof["evals"]
+    pd = S.ArithmeticSponge(F)
+    for chals, _comm in prev:
+        pd.absorb(list(chals))
+    fr.absorb([pd.squeeze()])                                           # prev_challenge_digest
+    ev = normalize_evals(proof["evals"])
     fr.absorb([proof["ft_eval1"]])
-    fr.absorb([ev["public"][0]]); fr.absorb([ev["public"][1]])
+    fr.absorb(ev["public"][0]); fr.absorb(ev["public"][1])
     for col in columns_in_opening_order(ev) + lookup_evaluations_in_sponge_order(ev, li):
-        fr.absorb([col[0]]); fr.absorb([col[1]])
+        fr.absorb(col[0]); fr.absorb(col[1])
 
     def fr_challenge():                                                 # DefaultFrSponge::challenge: 128 bits of one squeeze (the
         x = fr.squeeze()                                                # buffer is emptied by every absorb; two limbs per squeeze)
@@ -286,18 +378,21 @@ def fiat_shamir(curve: P.Curve, vix, proof, digest: int):
 
 
 def verify(curve: P.Curve, vix, proof, g, h, rng, final_msm=None) -> bool:
-    """kimchi::verifier::verify for the configuration described in the header.  vix: n, log2_n, omega, shifts, h and the
-    index commitments; proof: w_comm, z_comm, t_comm (chunk lists of affine points / None), evals, ft_eval1, opening."""
+    """kimchi::verifier::verify (verifier.rs:781-1200 + SRS::verify).  vix: n, log2_n, omega, shifts, h, max_poly_size, zk_rows and the
+    index commitments; proof: w_comm, z_comm, t_comm (chunk lists of affine points / None), evals (pairs of integers or of chunk
+    lists), ft_eval1, opening, optionally lookup and prev_challenges [(chals, comm chunks)]."""
     F = curve.scalar
     n = vix["n"]
     ch = fiat_shamir(curve, vix, proof, verifier_index_digest(curve, vix))
     beta, gamma, alpha, zeta, v, u = ch["beta"], ch["gamma"], ch["alpha"], ch["zeta"], ch["v"], ch["u"]
-    ev = proof["evals"]
     omega = vix["omega"]
     zetaw = zeta * omega % F.p
     zeta1 = pow(zeta, n, F.p)
     srs_len = vix.get("max_poly_size", n)                               # chunk length = SRS size (verifier.rs:795, zeta_to_srs_len)
-    zeta_srs = pow(zeta, srs_len, F.p)
+    zeta_srs = pow(zeta, srs_len, F.p); zetaw_srs = pow(zetaw, srs_len, F.p)
+    evc = normalize_evals(proof["evals"])                               # chunked, as absorbed and opened
+    ev = combine_evals(F, evc, zeta_srs, zetaw_srs)                     # combined, as the constraints see them
+    zk_rows = vix.get("zk_rows", ZK_ROWS)
     alphas = [pow(alpha, ALPHA_PERM0 + i, F.p) for i in range(3)]
     zkp = eval_permutation_vanishing_polynomial(vix, zeta)
     # ---- ft_eval0 (verifier.rs:412-490)
@@ -310,7 +405,7 @@ def verify(curve: P.Curve, vix, proof, g, h, rng, final_msm=None) -> bool:
         t = t * ((gamma + beta * zeta % F.p * sh + w[0]) % F.p) % F.p
     ft0 = (ft0 - t) % F.p
     zeta1m1 = (zeta1 - 1) % F.p
-    w_zk = pow(omega, n - ZK_ROWS, F.p)                                 # index.w()
+    w_zk = pow(omega, n - zk_rows, F.p)                                 # index.w()
     num = (zeta1m1 * alphas[1] % F.p * (zeta - w_zk) + zeta1m1 * alphas[2] % F.p * (zeta - 1)) % F.p * ((1 - ev["z"][0]) % F.p) % F.p
     den = (zeta - w_zk) * (zeta - 1) % F.p
     ft0 = (ft0 + num * F.inv(den)) % F.p
@@ -319,29 +414,40 @@ def verify(curve: P.Curve, vix, proof, g, h, rng, final_msm=None) -> bool:
     li = vix.get("lookup_index")
     if li:
         ft0 = (ft0 - lookup_constant_term(F, vix, ev, ch, zeta)) % F.p
-    # ---- commitments: f_comm = perm_scalar * sigma_comm[6]; ft_comm = f_comm - (zeta^n - 1) * sum_i zeta^(n i) t_comm[i]
+    # ---- commitments: f_comm = perm_scalar * sigma_comm[6] chunk-combined; ft_comm = f_comm - (zeta^n - 1) * sum_i zeta^(srs_len i) t_comm[i]
     scal = perm_scalars(F, ev, beta, gamma, alphas[0], zkp)
-    sig6 = vix["sigma_comm"][PERMUTS - 1][0]
-    f_comm = curve.mul(sig6, scal) if sig6 is not None else None
-    t_chunk, pw = None, 1
-    for c in proof["t_comm"]:
-        if c is not None:
-            t_chunk = curve.add(t_chunk, curve.mul(c, pw))
-        pw = pw * zeta_srs % F.p                                        # zeta^max_poly_size
+
+    def chunk_commitment(chunks, pw0):                                  # PolyComm::chunk_commitment (commitment.rs:188-205)
+        acc, pw = None, 1
+        for c in chunks:
+            if c is not None:
+                acc = curve.add(acc, curve.mul(c, pw))
+            pw = pw * pw0 % F.p
+        return acc
+    f_comm = chunk_commitment([curve.mul(c, scal) if c is not None else None for c in vix["sigma_comm"][PERMUTS - 1]], zeta_srs)
+    t_chunk = chunk_commitment(proof["t_comm"], zeta_srs)
     neg = curve.mul(t_chunk, (-zeta1m1) % F.p) if t_chunk is not None else None
     ft_comm = curve.add(f_comm, neg)
-    # ---- the evaluation list (one chunk each): public, ft, then the columns in opening order
-    evaluations = [(vix.get("public_comm") or [h], [[ev["public"][0]], [ev["public"][1]]]), ([ft_comm], [[ft0], [proof["ft_eval1"]]])]
+    # ---- the evaluation list: previous challenges, public, ft, then the columns in opening order
+    evaluations = []
+    for chals, comm in (proof.get("prev_challenges") or []):
+        evaluations.append((list(comm), prev_challenge_evals(F, chals, srs_len, [zeta, zetaw], [zeta_srs, zetaw_srs])))
+    evaluations += [(vix.get("public_comm") or [h], [evc["public"][0], evc["public"][1]]), ([ft_comm], [[ft0], [proof["ft_eval1"]]])]
     comms = [proof["z_comm"], vix["generic_comm"], vix["psm_comm"], vix["complete_add_comm"], vix["mul_comm"], vix["emul_comm"], vix["endomul_scalar_comm"]]
     comms += list(proof["w_comm"]) + list(vix["coefficients_comm"]) + list(vix["sigma_comm"][:PERMUTS - 1])
-    for c, e in zip(comms, columns_in_opening_order(ev)):
-        evaluations.append((c, [[e[0]], [e[1]]]))
+    comms += [c for c in (vix.get("optional_comms") or []) if c is not None]
+    assert len(comms) == len(columns_in_opening_order(evc)), "optional gate commitments / evaluations mismatch"
+    for c, e in zip(comms, columns_in_opening_order(evc)):
+        evaluations.append((c, [e[0], e[1]]))
     if li:                                                              # verifier.rs:1034-1175: sorted..., aggregation, the combined table, the pattern selectors
-        lk = [(c, e) for c, e in zip(proof["lookup"]["sorted"], ev["lookup_sorted"])] + [(proof["lookup"]["aggreg"], ev["lookup_aggregation"])]
-        lk.append((lookup_table_commitment(curve, li, ch["joint_combiner"]), ev["lookup_table"]))
-        lk += [(li["lookup_selectors"][q], ev["lookup_selectors"][q]) for q in LOOKUP_PATTERN_ORDER if li["lookup_selectors"].get(q) is not None]
+        lk = [(c, e) for c, e in zip(proof["lookup"]["sorted"], evc["lookup_sorted"])] + [(proof["lookup"]["aggreg"], evc["lookup_aggregation"])]
+        lk.append((lookup_table_commitment(curve, li, ch["joint_combiner"], proof["lookup"].get("runtime")), evc["lookup_table"]))
+        if li.get("runtime_tables_selector") is not None:
+            lk.append((proof["lookup"]["runtime"], evc["runtime_lookup_table"]))
+            lk.append((li["runtime_tables_selector"], evc["runtime_lookup_table_selector"]))
+        lk += [(li["lookup_selectors"][q], evc["lookup_selectors"][q]) for q in LOOKUP_PATTERN_ORDER if li["lookup_selectors"].get(q) is not None]
         for c, e in lk:
-            evaluations.append((c, [[e[0]], [e[1]]]))
+            evaluations.append((c, [e[0], e[1]]))
     item = {"sponge": ch["fq_sponge"], "evaluation_points": [zeta, zetaw], "polyscale": v, "evalscale": u, "evaluations": evaluations,
             "opening": proof["opening"], "combined_inner_product": P.combined_inner_product(F, v, u, [e for _, e in evaluations])}
     if final_msm is None:

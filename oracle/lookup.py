@@ -233,8 +233,9 @@ def sorted_columns(cs: LookupCS, gates: Sequence[str], witness, joint_combiner: 
 
 
 def aggregation(cs: LookupCS, gates: Sequence[str], witness, joint_combiner: int, beta: int, gamma: int,
-                sorted_cols: Sequence[Sequence[int]], zk_values: Sequence[int]) -> List[int]:
-    """constraints.rs:233-338; `sorted_cols` are the zk-patched columns (length n)."""
+                sorted_cols: Sequence[Sequence[int]], zk_values: Optional[Sequence[int]], draw=None) -> List[int]:
+    """constraints.rs:233-338; `sorted_cols` are the zk-patched columns (length n).  The random tail is `zk_values`, or drawn
+    with `draw()` AFTER the running product, as the reference's zk_patch call does (constraints.rs:327)."""
     p, n = cs.p, cs.n
     jc, tic = cs.combiners(joint_combiner)
     table = cs.joint_table(joint_combiner)
@@ -261,6 +262,8 @@ def aggregation(cs: LookupCS, gates: Sequence[str], witness, joint_combiner: int
             f = f * ((gamma + spec_value(p, jl, jc, tic, witness, row)) % p) % p
         t = (gb1 + table[row] + beta * table[row + 1]) % p
         agg.append(agg[-1] * f % p * t % p * pow(den, p - 2, p) % p)
+    if zk_values is None:
+        zk_values = [draw() for _ in range(cs.zk_rows)]
     return zk_patch(agg, n, cs.zk_rows, zk_values)
 
 

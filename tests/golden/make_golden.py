@@ -128,6 +128,23 @@ def main():
     with open(os.path.join(OUT, "reference_kats.json"), "w") as f:
         json.dump(golden, f, indent=1)
     print("wrote", os.path.join(OUT, "reference_kats.json"))
+    whole_proof_kat()
+
+
+def whole_proof_kat():
+    """kimchi/src/tests/and.rs:126-160, 404-731: the serialised ProverProof of the 8-byte AND gadget proved with
+    make_test_rng(Some(RNG_SEED)) -- the reference's only byte-exact whole-proof regression.  Seed and bytes are parsed from
+    the test's source; written as and_serialization_regression.json (seed, bytes as hex)."""
+    src = read("kimchi/src/tests/and.rs")
+    body = src[src.index("fn prove_and_check_serialization_regression"):]
+    seed = [int(x) for x in re.findall(r"\d+", re.search(r"const RNG_SEED: \[u8; 32\] = \[(.*?)\];", body, re.S).group(1))]
+    reg = src[src.index("fn test_serialization_regression"):]
+    buf = bytes(int(x) for x in re.findall(r"\d+", re.search(r"let buf_expected = vec!\[(.*?)\];", reg, re.S).group(1)))
+    assert len(seed) == 32 and len(buf) == 6160
+    with open(os.path.join(OUT, "and_serialization_regression.json"), "w") as f:
+        json.dump({"source": "kimchi/src/tests/and.rs:126-160,404-731", "curve": "vesta", "bytes_of_and": 8, "seed": seed,
+                   "sha256": hashlib.sha256(buf).hexdigest(), "proof_hex": buf.hex()}, f, indent=1)
+    print("wrote and_serialization_regression.json")
 
 
 if __name__ == "__main__":

@@ -33,6 +33,7 @@ GATE_FIXTURES = {"test_poseidon": "poseidon_selector", "test_poseidon_in_circuit
                  "endomul_test": "emul_selector", "endomul_scalar_test": "endomul_scalar_selector"}
 GENERIC_FIXTURES = ["test_generic_gate", "test_generic_gate_pub", "test_generic_gate_pub_empty", "test_generic_gate_pub_all_zeros",
                     "test_prove_and_verify_five_not_gnrc"]                   # (the Not gadget built from generic gates, tests/not.rs)
+XOR_FIXTURES = ["and_prove_and_verify_vesta", "test_prove_and_verify_xor", "test_xor_finalization", "test_prove_and_verify_not_xor"]   # Xor16 + its lookups
 LOOKUP_FIXTURES = ["lookup_gate_proving_works", "lookup_gate_proving_works_multiple_tables",     # tests/lookup.rs:38-170: 500 Lookup gates
                    "test_dummy_value_is_added_in_an_arbitraly_created_table_when_no_table_with_id_0"]   # the dummy entry's table is synthesised (lookup/index.rs)
 
@@ -69,6 +70,24 @@ def lagrange_commitments(g_l, log2_n, count):
     return out
 
 
+def final_msm_for(g_l, n_srs, curve=C):
+    """the verifier's one MSM (ipa.rs:452-502), in the C oracle"""
+    Fs = curve.scalar
+    cid = 0 if curve is P.VESTA else 1
+
+    def final_msm(g_terms, pts, sc):
+        gs = [0] * n_srs
+        for w, chal in g_terms:
+            for j, s in enumerate(P.b_poly_coefficients(Fs, chal)):
+                gs[j] = (gs[j] + w * s) % Fs.p
+        live = [(p, s) for p, s in zip(pts, sc) if p is not None]
+        xy = np.concatenate([g_l[:n_srs], np.stack([cref.ints_to_limbs([curve.base.to_mont(p[0]), curve.base.to_mont(p[1])]).reshape(8) for p, _ in live])])
+        scal = cref.ints_to_limbs([Fs.to_mont(s) for s in gs + [s for _, s in live]])
+        _, inf = cref.msm(cid, xy, scal, threads=8)
+        return inf
+    return final_msm
+
+
 def verify(fx, srs, mutate=None):
     g_l, h = srs
     vix, proof = FX.oracle_views(fx, h)
@@ -77,26 +96,17 @@ def verify(fx, srs, mutate=None):
         vix["public_comm"] = K.public_commitment(C, h, lagrange_commitments(g_l, vix["log2_n"], len(fx["public"])), fx["public"])
     if mutate:
         mutate(vix, proof)
-
-    def final_msm(g_terms, pts, sc):              # the verifier's one MSM, in the C oracle
-        gs = [0] * n_srs
-        for w, chal in g_terms:
-            for j, s in enumerate(P.b_poly_coefficients(F, chal)):
-                gs[j] = (gs[j] + w * s) % F.p
-        live = [(p, s) for p, s in zip(pts, sc) if p is not None]
-        xy = np.concatenate([g_l[:n_srs], np.stack([cref.ints_to_limbs([C.base.to_mont(p[0]), C.base.to_mont(p[1])]).reshape(8) for p, _ in live])])
-        scal = cref.ints_to_limbs([F.to_mont(s) for s in gs + [s for _, s in live]])
-        _, inf = cref.msm(0, xy, scal, threads=8)
-        return inf
-    return K.verify(C, vix, proof, None, h, P.StdRng(bytes([5] * 32)), final_msm=final_msm)
+    return K.verify(C, vix, proof, None, h, P.StdRng(bytes([5] * 32)), final_msm=final_msm_for(g_l, n_srs))
 
 
-@pytest.mark.parametrize("name", GENERIC_FIXTURES + list(GATE_FIXTURES) + LOOKUP_FIXTURES)
+@pytest.mark.parametrize("name", GENERIC_FIXTURES + list(GATE_FIXTURES) + LOOKUP_FIXTURES + XOR_FIXTURES)
 def test_oracle_verifier_accepts_the_reference_proof(name, srs):
     fx = FX.load(os.path.join(HERE, name + ".bin"), C)
     v = fx["vindex"]
     assert v["max_poly_size"] == SRS_LEN and v["zk_rows"] == 3
-    assert (v["lookup_index"] is not None) == (name in LOOKUP_FIXTURES) == (fx["proof"]["lookup"] is not None)
+    assert (v["lookup_index"] is not None) == (name in LOOKUP_FIXTURES + XOR_FIXTURES) == (fx["proof"]["lookup"] is not None)
+    if name in XOR_FIXTURES:
+        assert v["lookup_index"]["patterns"] == ["Xor"] and fx["proof"]["evals"]["optional_gate_selectors"][4] is not None
     if name in LOOKUP_FIXTURES:
         li = v["lookup_index"]
         assert li["patterns"] == ["Lookup"] and (li["max_per_row"], li["max_joint_size"], li["joint_lookup_used"]) == (3, 2, True)
