@@ -163,36 +163,11 @@ def prover_block(khip, srs20, check_with_oracle=True, log_n=16, reps=5):
 
 def oracle_verifies(khip, ix, proof):
     """Checker leg (never timed): oracle/kimchi.py restates the reference verifier; the final MSM runs in the C oracle."""
-    from oracle import cref
     from oracle import kimchi as K
     from oracle import pasta as P
-    c = P.CURVES[ix.curve]
-
-    def aff(xy, inf):
-        return None if inf else (c.base.from_mont(P.from_limbs(xy[:4])), c.base.from_mont(P.from_limbs(xy[4:])))
-    one = lambda t: [aff(t[0], t[1])]
-    vix = {"F": c.scalar, "n": ix.n, "log2_n": ix.log2_n, "omega": ix.omega, "shifts": ix.shifts, "h": aff(ix.h, False),
-           "sigma_comm": [one(t) for t in ix.sigma_comm], "coefficients_comm": [one(t) for t in ix.coefficients_comm], "generic_comm": one(ix.generic_comm)}
-    for k in ("psm_comm", "complete_add_comm", "mul_comm", "emul_comm", "endomul_scalar_comm"):
-        vix[k] = one(ix.selector_comms[("psm_comm", "complete_add_comm", "mul_comm", "emul_comm", "endomul_scalar_comm").index(k)])
-    chunks = lambda t: [aff(t[0][j], t[1][j]) for j in range(len(t[1]))]
-    op = proof["opening"]
-    pr = {"w_comm": [[aff(proof["w_comm"][0][i], proof["w_comm"][1][i])] for i in range(15)], "z_comm": chunks(proof["z_comm"]), "t_comm": chunks(proof["t_comm"]),
-          "evals": proof["evals"], "ft_eval1": proof["ft_eval1"],
-          "opening": {"lr": [(aff(xy[0], li[0]), aff(xy[1], li[1])) for xy, li in op["lr"]], "delta": aff(*op["delta"]), "z1": op["z1"], "z2": op["z2"], "sg": aff(*op["sg"])}}
-    g_l = ix.srs.get_g()
-
-    def final_msm(g_terms, pts, sc):
-        F = c.scalar
-        gs = [0] * ix.n
-        for w, chal in g_terms:
-            for j, s in enumerate(P.b_poly_coefficients(F, chal)):
-                gs[j] = (gs[j] + w * s) % F.p
-        live = [(p, s) for p, s in zip(pts, sc) if p is not None]
-        xy = np.concatenate([g_l, np.stack([cref.ints_to_limbs([c.base.to_mont(p[0]), c.base.to_mont(p[1])]).reshape(8) for p, _ in live])])
-        scal = cref.ints_to_limbs([F.to_mont(s) for s in gs + [s for _, s in live]])
-        return cref.msm(ix.curve, xy, scal, threads=16)[1]
-    return K.verify(c, vix, pr, None, aff(ix.h, False), P.StdRng(bytes([9] * 32)), final_msm=final_msm)
+    from oracle import views as V
+    c, vix, pr = V.device_views(ix, proof)
+    return K.verify(c, vix, pr, None, vix["h"], P.StdRng(bytes([9] * 32)), final_msm=V.final_msm_c(c, ix.srs.get_g(), ix.size))
 
 
 def source_hash():

@@ -87,7 +87,8 @@ def load(path: str, curve: P.Curve) -> Dict[str, Any]:
         "lookup": _opt(cm[3], lambda l: {"sorted": [comm(c) for c in l[0]], "aggreg": comm(l[1]), "runtime": _opt(l[2], comm)}),
         "opening": {"lr": [(curve.decompress(bytes(l)), curve.decompress(bytes(r))) for l, r in op[0]], "delta": curve.decompress(bytes(op[1])),
                     "z1": _fe(bytes(op[2])), "z2": _fe(bytes(op[3])), "sg": curve.decompress(bytes(op[4]))},
-        "evals": evals, "ft_eval1": _fe(bytes(pr[3])), "prev_challenges": pr[4],
+        "evals": evals, "ft_eval1": _fe(bytes(pr[3])),
+        "prev_challenges": [([_fe(bytes(x)) for x in rc[0]], comm(rc[1])) for rc in pr[4]],      # RecursionChallenge { chals, comm } (proof.rs:117-131)
     }
     # public inputs: ark compressed field elements, back to back
     pub = [int.from_bytes(bytes(pub_b)[32 * i: 32 * i + 32], "little") for i in range(npub)]

@@ -496,12 +496,13 @@ def serialize_proof(curve: P.Curve, proof) -> bytes:
     pe = lambda e: None if e is None else [[fe(x) for x in e[0]], [fe(x) for x in e[1]]]
     ev = proof["evals"]
     lk = proof.get("lookup")
-    srt = list(ev["lookup_sorted"]) + [None] * (5 - len(ev["lookup_sorted"]))
+    srt = list(ev.get("lookup_sorted") or [])
+    srt += [None] * (5 - len(srt))
     evals = [pe(ev["public"]), [pe(e) for e in ev["w"]], pe(ev["z"]), [pe(e) for e in ev["s"]], [pe(e) for e in ev["coefficients"]],
              pe(ev["generic_selector"]), pe(ev["poseidon_selector"]), pe(ev["complete_add_selector"]), pe(ev["mul_selector"]), pe(ev["emul_selector"]),
              pe(ev["endomul_scalar_selector"])] + [pe(e) for e in ev["optional_gate_selectors"]] + \
-            [pe(ev["lookup_aggregation"]), pe(ev["lookup_table"]), [pe(e) for e in srt], pe(ev.get("runtime_lookup_table")),
-             pe(ev.get("runtime_lookup_table_selector"))] + [pe(ev["lookup_selectors"].get(q)) for q in K.LOOKUP_PATTERN_ORDER]
+            [pe(ev.get("lookup_aggregation")), pe(ev.get("lookup_table")), [pe(e) for e in srt], pe(ev.get("runtime_lookup_table")),
+             pe(ev.get("runtime_lookup_table_selector"))] + [pe((ev.get("lookup_selectors") or {}).get(q)) for q in K.LOOKUP_PATTERN_ORDER]
     op = proof["opening"]
     commitments = [[comm(c) for c in proof["w_comm"]], comm(proof["z_comm"]), comm(proof["t_comm"]),
                    None if lk is None else [[comm(c) for c in lk["sorted"]], comm(lk["aggreg"]), None if lk.get("runtime") is None else comm(lk["runtime"])]]

@@ -375,6 +375,13 @@ int kh_srs_compute_lagrange(kh_srs_t* srs, unsigned log2_domain) {
     const size_t n = (size_t)1 << log2_domain;
     const unsigned num_chunks = (unsigned)((n + srs->n - 1) / srs->n);            // ipa.rs:1143-1144
     auto& vec = srs->lagrange[log2_domain];
+    // idempotent: the reference's get_lagrange_basis is a cache lookup (ipa.rs:780-795) that 15 rayon workers hit at once on the first
+    // proof; a second computation would free the tables behind an MSM that has already resolved them
+    if (vec.size() == num_chunks) {
+        bool all = true;
+        for (auto& c : vec) if (!c) all = false;
+        if (all) return KH_OK;
+    }
     vec.clear(); vec.resize(num_chunks);
     const bool pre = n >= MSM_PRECOMP_MIN_N && !getenv("KH_NO_PRECOMP");
     const int W = (256 + MSM_PRECOMP_C - 1) / MSM_PRECOMP_C;
@@ -419,19 +426,25 @@ static int free_slot(Context& C) {
 // the tickets' owners are themselves waiting here; with only the caller's own un-waited tickets busy the answer is -1 at once
 // side_first: take a slot other than the main stream's when one is free -- a job that may CAPTURE its launch sequence into a hipGraph
 // must not do so on the stream other host threads synchronise and launch on (a capture is invalidated by, and invalidates, such calls)
+// Back-pressure, not a time-out: the caller blocks until a slot is released (an oversubscribed rayon pool must see a slow call, not
+// a spurious error).  The one case that can never resolve is refused at once: every busy slot holds an un-waited ticket whose owner
+// is itself blocked in here (or is the caller) -- nobody is left to call kh_msm_wait.
 static int acquire_slot(std::unique_lock<std::mutex>* lk, Context& C, bool side_first = false) {
-    const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(2);
+    const auto me = std::this_thread::get_id();
     for (;;) {
         int si = -1;
         if (side_first) for (int i = MSM_SLOTS - 1; i >= 1; i--) if (!C.slot[i].busy) { si = i; break; }
         if (si < 0) si = free_slot(C);
         if (si >= 0 || !lk) return si;
         if (C.sync_inflight == 0) {
-            bool others = false;
-            for (int i = 0; i < MSM_SLOTS; i++) if (C.slot[i].busy && C.slot[i].owner != std::this_thread::get_id()) others = true;
-            if (!others || std::chrono::steady_clock::now() > deadline) return -1;
-            C.cv.wait_for(*lk, std::chrono::milliseconds(50));
-        } else C.cv.wait(*lk);
+            bool progress = false;                          // some ticket owner is still free to reach kh_msm_wait
+            for (int i = 0; i < MSM_SLOTS; i++)
+                if (C.slot[i].busy && C.slot[i].owner != me && !C.blocked_owners.count(C.slot[i].owner)) progress = true;
+            if (!progress) return -1;
+        }
+        C.blocked_owners.insert(me);
+        C.cv.wait_for(*lk, std::chrono::milliseconds(50));  // (the time-out only re-evaluates the deadlock test; it never gives up)
+        C.blocked_owners.erase(C.blocked_owners.find(me));
     }
 }
 // enqueue on a free slot; returns the slot index through *slot_out
@@ -442,6 +455,7 @@ static int msm_submit_locked(Context& C, kh_srs_t* srs, int basis, unsigned chun
     size_t use = n < b.n - offset ? n : b.n - offset;      // msm_bigint semantics: min(len) pairs
     int si = acquire_slot(lk, C);
     KH_REQUIRE(si >= 0, "all %d MSM pipeline slots hold an un-waited job (kh_msm_wait first)", MSM_SLOTS);
+    if (lk && (rc = resolve_basis(srs, basis, chunk, b))) return rc;     // acquire_slot may have dropped the lock: the basis map can have changed
     MsmSlot& S = C.slot[si];
     const uint64_t* sdev = scalars;
     if (!scalars_on_device && use > 0 && k > 0) {
@@ -563,9 +577,10 @@ static int msm_common(kh_srs_t* srs, int basis, unsigned chunk, size_t offset, c
     const size_t kk = grp->members.size();
     std::vector<uint64_t> res(8 * kk); std::vector<uint8_t> rinf(kk);
     auto run = [&]() -> int {
-        MsmBasis b; int r = resolve_basis(srs, basis, chunk, b); if (r) return r;
+        MsmBasis b; int r;
         int si = acquire_slot(&lk, C);
         KH_REQUIRE(si >= 0, "all %d MSM pipeline slots hold an un-waited job (kh_msm_wait first)", MSM_SLOTS);
+        if ((r = resolve_basis(srs, basis, chunk, b))) return r;         // after the wait: the lock was dropped meanwhile
         MsmSlot& S = C.slot[si];
         if ((r = S.ws_scalars.reserve(kk * n * 32))) return r;
         for (size_t j = 0; j < kk; j++)

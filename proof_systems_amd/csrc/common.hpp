@@ -117,6 +117,7 @@ struct Context {
     std::mutex mu;            // serialises the host side of the C ABI (GPU waits happen outside it)
     std::condition_variable cv;        // a synchronous caller that finds every slot busy waits here for one to finish
     int sync_inflight = 0;             // slots some thread is currently blocked on (they WILL free up)
+    std::multiset<std::thread::id> blocked_owners;   // threads waiting in acquire_slot (deadlock test: see there)
     int device = -1;
     bool ready = false;
     hipStream_t stream = nullptr;      // = slot[0].stream: the library's main stream (NTT / LDE / vector steps / opening folds)

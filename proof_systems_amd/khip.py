@@ -436,6 +436,9 @@ class DevView:
     def __init__(self, ptr: int):
         self.ptr = ptr
 
+    def view(self, offset_bytes: int):
+        return DevView(self.ptr + offset_bytes)
+
 
 def dev_copy(dst_ptr: int, src_ptr: int, nbytes: int):
     _check(_lib.kh_dev_copy(C.c_void_p(dst_ptr), C.c_void_p(src_ptr), nbytes))

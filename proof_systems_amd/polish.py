@@ -285,8 +285,19 @@ def endomul_scalar_constraints(env: Env):
     return [n8_exp - n8, a8_exp - a8, b8_exp - b8] + [_polynomial(env, crumb_over_x, x) * x for x in xs]
 
 
+def xor16_constraints(env: Env):
+    """Xor16::constraint_checks (xor.rs:152-174): in1, in2, out (columns 0, 1, 2) each equal their four 4-bit nybbles
+    (columns 3 + 4i .. 6 + 4i) + 2^16 * the next row's value; the XOR itself is the row's four lookups."""
+    wc, wn = env.witness_curr, env.witness_next
+    out = []
+    for i in range(3):
+        acc = wc(3 + 4 * i) + wc(4 + 4 * i) * env.const(1 << 4) + wc(5 + 4 * i) * env.const(1 << 8) + wc(6 + 4 * i) * env.const(1 << 12)
+        out.append(acc + env.const(1 << 16) * wn(i) - wc(i))
+    return out
+
+
 GATES = {"Poseidon": (poseidon_constraints, 15), "CompleteAdd": (complete_add_constraints, 7), "VarBaseMul": (varbasemul_constraints, 21),
-         "EndoMul": (endomul_constraints, 12), "EndoMulScalar": (endomul_scalar_constraints, 11)}
+         "EndoMul": (endomul_constraints, 12), "EndoMulScalar": (endomul_scalar_constraints, 11), "Xor16": (xor16_constraints, 3)}
 
 
 # Kimchi Poseidon MDS matrices (poseidon/src/pasta/fp_kimchi.rs, fq_kimchi.rs: `mds`), by field id 0 = Fp, 1 = Fq -- the constants of

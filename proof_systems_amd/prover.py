@@ -1,8 +1,10 @@
 """A complete Kimchi proof with every data-parallel step on the device -- the caller of the hot path, restated.
 
-`ProverProof::create` (kimchi/src/prover.rs:187-1515) for circuits of generic gates (the benchmark circuit of
-kimchi/src/bench.rs:59-122: 2^k - 10 `Const(1)` gates, 15 witness columns of ones), no lookups, no optional gates, no
-recursion, one chunk (SRS size = domain size).  The columns never leave HBM between the witness upload and the opening
+`ProverProof::create_recursive` (kimchi/src/prover.rs:187-1515): generic gates (the benchmark circuit of kimchi/src/bench.rs:59-122),
+the five library gates, Xor16, lookups into fixed tables, public inputs, previous challenges (recursion), an SRS longer than the
+domain (one chunk, the opening padded to the SRS size) or SHORTER than it (chunked commitments / evaluations, tests/chunked.rs),
+and the reference's RNG draw order -- with the same random stream the proof is BYTE-IDENTICAL to the reference's (the seeded
+regression of kimchi/src/tests/and.rs:404-731, tests/test_gpu_prover_parity.py).  The columns never leave HBM between the witness upload and the opening
 proof: witness -> 15 Lagrange-basis commitments -> iNTT -> permutation accumulator z (permutation.rs:447-577) -> commit
 -> 8x extension of w, z (constraints.rs:487-507) -> generic-gate rows on d4 and permutation rows on d8 -> iNTT(4n),
 iNTT(8n) -> division by Z_H with the remainder asserted ZERO -> boundary quotients -> 7-chunk commitment of t -> chunked
@@ -10,10 +12,9 @@ evaluations at zeta, zeta*omega -> ft -> combine_polys / b_init -> the 16 foldin
 through the library's native sponges (kh_sponge_*), so every challenge is the real Fiat-Shamir value; the host keeps what
 is scalar and sequential (challenge algebra, blinders, the Schnorr tail of the opening), as the reference does.
 
-What is NOT evaluated: the constraints of Poseidon / CompleteAdd / VarBaseMul / EndoMul / EndoMulScalar.  The reference
-evaluates them over d8 on every proof (prover.rs:824-868) although their selectors are the zero polynomial for such a
-circuit; they contribute exactly zero to the quotient, so the proof is the same (their selector columns, commitments and
-evaluations ARE part of the proof and of the transcript here).
+Gate types that do not occur in the circuit: by default their constraints are not evaluated (their selectors are the zero
+polynomial and contribute exactly zero to the quotient; selector columns, commitments and evaluations ARE part of the proof);
+`create_proof(..., all_gates=True)` evaluates every always-present gate type over d8 as the reference does (prover.rs:824-868).
 
 The proof this produces is checked by the oracle's restatement of the reference VERIFIER (oracle/kimchi.py: Fiat-Shamir
 replay with the oracle's own sponge, ft_eval0, ft_comm, SRS::verify) in tests/test_gpu_prover.py; bench.py times it.
@@ -29,6 +30,7 @@ from . import khip
 from . import polish as OP
 
 COLUMNS, PERMUTS, ZK_ROWS = 15, 7, 3
+OPTIONAL_GATES = ("RangeCheck0", "RangeCheck1", "ForeignFieldAdd", "ForeignFieldMul", "Xor16", "Rot64")   # proof.rs:95-106 order
 ALPHA_PERM0 = 21                    # the gates register 21 powers of alpha first (linearization.rs:56-58), the permutation the next 3
 MOD = {khip.FP: 0x40000000000000000000000000000000224698fc094cf91b992d30ed00000001,
        khip.FQ: 0x40000000000000000000000000000000224698fc0994a8dd8c46eb2100000001}
@@ -63,10 +65,14 @@ class Fld:
         return pow(v, -1, self.p)
 
     def rand(self, rng) -> int:
-        return int.from_bytes(rng.bytes(40), "little") % self.p
+        return self.rand_many(rng, 1)[0]
 
     def rand_many(self, rng, k: int):
-        """k uniform field elements from ONE draw of the generator (the per-call overhead of numpy's Generator.bytes dominates `rand`)"""
+        """k uniform field elements, in draw order.  `rng` is the CALLER's generator (the reference takes `rng: &mut RNG`): an object
+        with field_elements(field_id, k) -> integers (e.g. a StdRng whose stream must equal the Rust one), or a numpy Generator
+        (one bulk read: the per-call overhead of Generator.bytes dominates)."""
+        if hasattr(rng, "field_elements"):
+            return [int(x) % self.p for x in rng.field_elements(self.fid, k)]
         b = rng.bytes(40 * k)
         return [int.from_bytes(b[40 * i:40 * i + 40], "little") % self.p for i in range(k)]
 
@@ -97,43 +103,53 @@ def scalar_challenge(curve: int, F: Fld, chal: int) -> int:
 
 
 class ProverIndex:
-    """Index of a generic-gate circuit on a domain of 2^log2_n rows, device-resident: coefficient and selector columns,
-    sigma, their coefficient forms and 8x extensions, x and the permutation vanishing polynomial on d8, the SRS with its
-    Lagrange basis, and the verifier-index commitments + digest (verifier_index.rs:175-300, 405-500)."""
+    """Index of a circuit on a domain of 2^log2_n rows, device-resident: coefficient and selector columns, sigma, their coefficient
+    forms and 8x extensions, x and the permutation vanishing polynomial on d8, the SRS with its Lagrange basis, and the
+    verifier-index commitments + digest (verifier_index.rs:175-300, 405-540).  The SRS may be longer than the domain (one chunk;
+    the opening runs over the whole SRS) or shorter (num_chunks = n / srs size chunks per polynomial, prover.rs:208-212)."""
 
     GATE_TYPES = ("Poseidon", "CompleteAdd", "VarBaseMul", "EndoMul", "EndoMulScalar")     # the always-present selectors after Generic
 
-    def __init__(self, curve: int, log2_n: int, gate_coeffs, srs=None, gate_types=None, public: int = 0):
-        """gate_coeffs: (rows, 15, 4) uint64 Montgomery limbs -- coefficient rows of the gates (rows <= n - 3).  gate_types: one name
-        per row ("Generic", one of GATE_TYPES, or anything else -- "Zero", "Lookup" -- for a row without gate constraints); default: all Generic."""
+    def __init__(self, curve: int, log2_n: int, gate_coeffs, srs=None, gate_types=None, public: int = 0, zk_rows: int = None, prev_challenges: int = 0):
+        """gate_coeffs: (rows, 15, 4) uint64 Montgomery limbs -- coefficient rows of the gates (rows <= n - zk_rows).  gate_types: one name
+        per row ("Generic", one of GATE_TYPES / OPTIONAL_GATES, or anything else -- "Zero", "Lookup" -- for a row without gate constraints);
+        default: all Generic.  zk_rows: default (16 num_chunks + 5) / 7 (constraints.rs:946-999)."""
         self.curve = curve
         self.public = public                                 # number of public inputs: witness[0][0..public] (constraints.rs:870-890)
+        self.prev_challenges = prev_challenges
         self.fid = khip.FP if curve == khip.VESTA else khip.FQ
         F = self.F = Fld(self.fid)
         self.log2_n, self.n = log2_n, 1 << log2_n
         n, fid = self.n, self.fid
         gate_coeffs = np.ascontiguousarray(gate_coeffs, dtype=np.uint64).reshape(-1, COLUMNS, 4)
         self.gates = gate_coeffs.shape[0]
-        assert self.gates + ZK_ROWS <= n
         self.srs = srs if srs is not None else khip.Srs.create(curve, n)
+        self.size = self.srs.n                               # max_poly_size
+        self.num_chunks = 1 if n < self.size else n // self.size
+        self.zk_rows = zk_rows if zk_rows is not None else (16 * self.num_chunks + 5) // 7
+        assert self.zk_rows > (2 * (PERMUTS + 1) * self.num_chunks - 2) // PERMUTS, "NotZeroKnowledge"
+        assert self.gates + self.zk_rows <= n
         if self.srs.lagrange_chunks(log2_n) == 0:
             self.srs.compute_lagrange(log2_n)                 # SRS::lagrange_basis on the device (index time)
         self.h = khip.srs_h(curve)
         self.omega = F.value(khip.domain_generator(fid, log2_n))
         self.shifts = sample_shifts(F, log2_n)
         one = F.limbs(1)
-        # ---- d1 evaluation columns: coefficients (15), generic selector, sid, sigma (7)
+        # ---- d1 evaluation columns: coefficients (15), generic selector, sid, sigma (7), the five library selectors, the optional ones
         co = np.zeros((COLUMNS, n, 4), dtype=np.uint64)
         co[:, :self.gates, :] = np.transpose(gate_coeffs, (1, 0, 2))
         self.gate_types = list(gate_types) if gate_types is not None else ["Generic"] * self.gates
         assert len(self.gate_types) == self.gates
         self.live_gate_types = set(self.gate_types)
+        self.optional = [t for t in OPTIONAL_GATES if t in self.live_gate_types]
         sel = np.zeros((n, 4), dtype=np.uint64)
         sel[[r for r, g in enumerate(self.gate_types) if g == "Generic"]] = one
         self.SEL0 = COLUMNS + 2 + PERMUTS                               # first of the five further selector columns
-        self.d1 = khip.DevBuf((COLUMNS + 1 + 1 + PERMUTS + 5) * n * 32)  # [coef 0..14 | generic sel | sid | sigma 0..6 | psm add mul emul emulscalar]
+        self.OPT0 = self.SEL0 + 5                                       # first optional-gate selector column
+        self.ncol = self.OPT0 + len(self.optional)
+        self.d1 = khip.DevBuf(self.ncol * n * 32)  # [coef 0..14 | generic sel | sid | sigma 0..6 | psm add mul emul emulscalar | optional ...]
         self.d1.upload_at(0, co); self.d1.upload_at(COLUMNS * n * 32, sel)
-        for k, name in enumerate(self.GATE_TYPES):
+        for k, name in enumerate(self.GATE_TYPES + tuple(self.optional)):
             sk = np.zeros((n, 4), dtype=np.uint64)
             sk[[r for r, g in enumerate(self.gate_types) if g == name]] = one
             self.d1.upload_at((self.SEL0 + k) * n * 32, sk)
@@ -160,40 +176,92 @@ class ProverIndex:
         self.d1.upload_at((COLUMNS + 2) * self.n * 32, np.ascontiguousarray(sigma_limbs, dtype=np.uint64))
         self._finish_columns()
 
+    def set_wiring(self, wires):
+        """wires[row][col] = (row', col') for the first len(wires) rows (CircuitGate::wires, gate.rs:150-170): sigma_col[row] = shift[col'] * omega^row'."""
+        F, n = self.F, self.n
+        sid = [1] * n
+        for j in range(1, n):
+            sid[j] = sid[j - 1] * self.omega % F.p
+        sg = [[self.shifts[c] * sid[r] % F.p for r in range(n)] for c in range(PERMUTS)]
+        for r, w in enumerate(wires):
+            for c in range(PERMUTS):
+                r2, c2 = w[c]
+                sg[c][r] = self.shifts[c2] * sid[r2] % F.p
+        self.set_sigma(np.stack([F.limbs_many(col) for col in sg]))
+
+    # commitments: (xy (chunks, 8), inf (chunks,)) ------------------------------------------------
+    def commit_evals(self, ptr: int, k: int):
+        """SRS::commit_evaluations_non_hiding of k columns of n evaluations starting at device address `ptr`: per chunk of the Lagrange
+        basis one batched MSM over ALL n evaluations (ipa.rs:706-728, commitment.rs:359-368).  Returns k commitments."""
+        per = [self.srs.msm_batch_dev(ptr, self.n, k, basis=self.log2_n, chunk=c) for c in range(self.num_chunks)]
+        return [(np.stack([per[c][0][i] for c in range(self.num_chunks)]), np.array([per[c][1][i] for c in range(self.num_chunks)], dtype=np.uint8)) for i in range(k)]
+
+    def commit_coeffs(self, ptr: int, length: int, num_chunks: int):
+        """SRS::commit_non_hiding (ipa.rs:638-683): `length` coefficients at `ptr` in chunks of the SRS size, padded with the point
+        at infinity to num_chunks.  The full chunks are one batched MSM."""
+        size = self.size
+        cnt = max(num_chunks, -(-length // size), 1)
+        xy = np.zeros((cnt, 8), dtype=np.uint64); inf = np.ones(cnt, dtype=np.uint8)
+        full = length // size
+        if full:
+            o, i = self.srs.msm_batch_dev(ptr, size, full)
+            xy[:full] = o; inf[:full] = i
+        rem = length - full * size
+        if rem:
+            o, i = self.srs.msm_batch_dev(ptr + full * size * 32, rem, 1)
+            xy[full] = o[0]; inf[full] = i[0]
+        return xy, inf
+
+    def mask(self, comms, blinders):
+        """SRS::mask_custom over a list of commitments; blinders: one integer per chunk, flat, commitment by commitment."""
+        xy = np.concatenate([c[0].reshape(-1, 8) for c in comms]); inf = np.concatenate([np.asarray(c[1], dtype=np.uint8).reshape(-1) for c in comms])
+        oxy, oinf = self.srs.mask_custom(xy, inf, self.F.limbs_many(blinders))
+        out, pos = [], 0
+        for c in comms:
+            k = c[0].reshape(-1, 8).shape[0]
+            out.append((oxy[pos:pos + k], oinf[pos:pos + k])); pos += k
+        return out
+
     def _finish_columns(self):
-        n, fid, F, logn = self.n, self.fid, self.F, self.log2_n
-        ncol = COLUMNS + 1 + 1 + PERMUTS + 5                            # same order as d1
+        n, fid, F, logn, ncol, nch = self.n, self.fid, self.F, self.log2_n, self.ncol, self.num_chunks
+        zk = self.zk_rows
         if not hasattr(self, "dc"):
             self.dc = khip.DevBuf((ncol + 2) * n * 32)                  # + [x | zkpm] in coefficient form
             self.d8 = khip.DevBuf((ncol + 2) * 8 * n * 32)
-            self.zero_poly = khip.DevBuf(n * 32).zero()                 # the five absent selectors: the zero polynomial
+            self.zero_poly = khip.DevBuf(n * 32).zero()                 # the zero public polynomial
         khip.dev_copy(self.dc.ptr, self.d1.ptr, ncol * n * 32)
         khip.ntt_dev(fid, self.dc, logn, True, ncol)                    # coefficient forms
         xpoly = np.zeros((n, 4), dtype=np.uint64); xpoly[1] = F.limbs(1)
-        a = pow(self.omega, n - ZK_ROWS, F.p); b = a * self.omega % F.p; c = pow(self.omega, n - 1, F.p)
-        zk = np.zeros((n, 4), dtype=np.uint64)                          # (x - a)(x - b)(x - c): permutation_vanishing_polynomial
-        zk[:4] = F.limbs_many([(-a * b * c) % F.p, (a * b + a * c + b * c) % F.p, (-(a + b + c)) % F.p, 1])
+        a = pow(self.omega, n - zk, F.p); b = a * self.omega % F.p; c = pow(self.omega, n - 1, F.p)
+        zkc = np.zeros((n, 4), dtype=np.uint64)                         # (x - a)(x - b)(x - c): permutation_vanishing_polynomial (permutation.rs:107-118)
         self.zkpm_coeffs = [(-a * b * c) % F.p, (a * b + a * c + b * c) % F.p, (-(a + b + c)) % F.p, 1]
-        self.dc.upload_at(ncol * n * 32, xpoly); self.dc.upload_at((ncol + 1) * n * 32, zk)
+        zkc[:4] = F.limbs_many(self.zkpm_coeffs)
+        self.dc.upload_at(ncol * n * 32, xpoly); self.dc.upload_at((ncol + 1) * n * 32, zkc)
         khip.lde_dev(fid, self.dc, logn, 3, self.d8, ncol + 2)          # everything on d8
         self.X8, self.ZKPM8 = ncol, ncol + 1
-        # ---- verifier-index commitments (commit_evaluations_non_hiding over the Lagrange basis; selectors masked with 1)
-        com, inf = self.srs.msm_batch_dev(self.d1.ptr, n, COLUMNS + 1, basis=logn)
-        self.coefficients_comm = [(com[i], bool(inf[i])) for i in range(COLUMNS)]
-        g, ginf = self.srs.mask_custom(com[COLUMNS:COLUMNS + 1], inf[COLUMNS:COLUMNS + 1], F.limbs_many([1]))
-        self.generic_comm = (g[0], bool(ginf[0]))
-        com, inf = self.srs.msm_batch_dev(self.col1(COLUMNS + 2).ptr, n, PERMUTS, basis=logn)
-        self.sigma_comm = [(com[i], bool(inf[i])) for i in range(PERMUTS)]
-        self.zero_selector_comm = (self.h.copy(), False)                # identity + 1 * h
-        com, inf = self.srs.msm_batch_dev(self.col1(self.SEL0).ptr, n, 5, basis=logn)
-        com, inf = self.srs.mask_custom(com, inf, F.limbs_many([1] * 5))
-        self.selector_comms = [(com[i], bool(inf[i])) for i in range(5)]  # psm, complete_add, mul, emul, endomul_scalar (= h for an absent gate type)
+        # ---- verifier-index commitments (commit_evaluations_non_hiding over the Lagrange basis; the six main selectors masked with 1,
+        #      the optional gates' selectors non-hiding: verifier_index.rs:255-300)
+        ones = [1] * nch
+        com = self.commit_evals(self.d1.ptr, COLUMNS + 1)
+        self.coefficients_comm = com[:COLUMNS]
+        self.generic_comm = self.mask(com[COLUMNS:], ones)[0]
+        self.sigma_comm = self.commit_evals(self.col1(COLUMNS + 2).ptr, PERMUTS)
+        com = self.commit_evals(self.col1(self.SEL0).ptr, 5 + len(self.optional))
+        self.selector_comms = self.mask(com[:5], ones * 5)              # psm, complete_add, mul, emul, endomul_scalar (= h for an absent gate type)
+        self.zero_selector_comm = self.mask([(np.zeros((nch, 8), dtype=np.uint64), np.ones(nch, dtype=np.uint8))], ones)[0]
+        self.optional_comms = {t: com[5 + k] for k, t in enumerate(self.optional)}
+        self._digest()
+        khip.sync()
+
+    def _digest(self, extra=()):
+        """VerifierIndex::digest (verifier_index.rs:405-540): sigma, coefficients, the six selectors, the optional gates (range_check0,
+        range_check1, foreign_field_MUL, foreign_field_ADD, xor, rot -- in that order), then the lookup index."""
         sp = khip.Sponge(khip.Sponge.FQ, self.curve)
-        for c_, i_ in self.sigma_comm + self.coefficients_comm + [self.generic_comm] + self.selector_comms:
-            sp.absorb_g(c_.reshape(1, 8), np.array([1 if i_ else 0], dtype=np.uint8))
+        opt = [self.optional_comms[t] for t in ("RangeCheck0", "RangeCheck1", "ForeignFieldMul", "ForeignFieldAdd", "Xor16", "Rot64") if t in self.optional_comms]
+        for c_, i_ in self.sigma_comm + self.coefficients_comm + [self.generic_comm] + self.selector_comms + opt + list(extra):
+            sp.absorb_g(np.ascontiguousarray(c_).reshape(-1, 8), np.ascontiguousarray(i_, dtype=np.uint8).reshape(-1))
         self.digest = sp.squeeze_field()                                # VerifierIndex::digest -> digest_fq
         sp.free()
-        khip.sync()
 
     def attach_lookup(self, LI):
         """Adds a lookup constraint system (proof_systems_amd.lookup.LookupIndex over the same domain): coefficient forms and
@@ -201,7 +269,7 @@ class ProverIndex:
         table-id column committed and masked with 1, selectors committed non-hiding (verifier_index.rs:189-216) -- folded into
         the digest (verifier_index.rs:482-530)."""
         from . import lookup as LK
-        assert LI.n == self.n and LI.fid == self.fid
+        assert LI.n == self.n and LI.fid == self.fid and LI.zk_rows == self.zk_rows
         n, fid, F, logn = self.n, self.fid, self.F, self.log2_n
         self.lookup = LI
         LI.sel_c = {}; LI.sel8 = {}
@@ -210,22 +278,11 @@ class ProverIndex:
             e = khip.DevBuf(8 * n * 32); khip.lde_dev(fid, c, logn, 3, e, 1)
             LI.sel_c[q], LI.sel8[q] = c, e
         LI.atoms8 = LK.atom_columns(LI, 3)
-        one = F.limbs_many([1])
-
-        def commit(vals, masked):
-            com, inf = self.srs.commit_evaluations_non_hiding(logn, F.limbs_many(vals))
-            if masked:
-                com, inf = self.srs.mask_custom(com, inf, one)
-            return (com[0], bool(inf[0]))
-        LI.table_comm = [commit(c, True) for c in LI.table_cols]
-        LI.table_ids_comm = commit(LI.table_ids, True) if LI.table_ids is not None else None
-        LI.selector_comm = {q: commit(LI.selectors[q], False) for q in LI.patterns}
-        sp = khip.Sponge(khip.Sponge.FQ, self.curve)
-        extra = LI.table_comm + ([LI.table_ids_comm] if LI.table_ids_comm else []) + [LI.selector_comm[q] for q in LI.patterns]
-        for c_, i_ in self.sigma_comm + self.coefficients_comm + [self.generic_comm] + self.selector_comms + extra:
-            sp.absorb_g(c_.reshape(1, 8), np.array([1 if i_ else 0], dtype=np.uint8))
-        self.digest = sp.squeeze_field()
-        sp.free()
+        ones = [1] * self.num_chunks
+        LI.table_comm = [self.mask(self.commit_evals(b.ptr, 1), ones)[0] for b in LI.d_table_cols]
+        LI.table_ids_comm = self.mask(self.commit_evals(LI.d_table_ids.ptr, 1), ones)[0] if LI.d_table_ids is not None else None
+        LI.selector_comm = {q: self.commit_evals(LI.d_selectors[q].ptr, 1)[0] for q in LI.patterns}
+        self._digest(LI.table_comm + ([LI.table_ids_comm] if LI.table_ids_comm else []) + [LI.selector_comm[q] for q in LI.patterns])
         khip.sync()
 
     def free(self):
@@ -243,11 +300,21 @@ def bench_circuit_index(curve: int, log2_n: int, srs=None) -> ProverIndex:
     return ProverIndex(curve, log2_n, co, srs)
 
 
-def create_proof(ix: ProverIndex, witness, rng, timings=None, check: bool = True, witness_on_device=None):
-    """ProverProof::create.  witness: (15, rows, 4) Montgomery limbs, rows <= n - 3 (padded with zeros, the last 3 rows
-    randomised, prover.rs:254-266) -- or witness_on_device: a DevBuf already holding the padded (15, n, 4) columns.
-    rng: numpy Generator (blinders, zero-knowledge rows).  Returns the proof as a dict of limb arrays / Python ints."""
+def _horner(p: int, coeffs, x: int) -> int:
+    acc = 0
+    for c in reversed(coeffs):
+        acc = (acc * x + c) % p
+    return acc
+
+
+def create_proof(ix: ProverIndex, witness, rng, timings=None, check: bool = True, witness_on_device=None, prev_challenges=(), all_gates: bool = False):
+    """ProverProof::create_recursive.  witness: (15, rows, 4) Montgomery limbs, rows <= n - zk_rows (padded with zeros, the last zk_rows
+    rows randomised, prover.rs:254-266) -- or witness_on_device: a DevBuf already holding the padded (15, n, 4) columns.
+    rng: the caller's generator (Fld.rand_many: blinders, zero-knowledge rows, in the reference's draw order).
+    prev_challenges: [(chals as integers, (xy (chunks, 8), inf (chunks,)))] (RecursionChallenge, proof.rs:117-131).
+    Returns the proof as a dict of limb arrays / Python ints; evaluations are pairs of chunk lists (at zeta, at zeta omega)."""
     F, fid, n, logn, curve, srs = ix.F, ix.fid, ix.n, ix.log2_n, ix.curve, ix.srs
+    size, nch, zk = ix.size, ix.num_chunks, ix.zk_rows
     t_start = time.perf_counter()
     marks = []
 
@@ -255,37 +322,40 @@ def create_proof(ix: ProverIndex, witness, rng, timings=None, check: bool = True
         marks.append((name, time.perf_counter()))
     one = F.limbs(1)
     NB = n * 32
+    ones_c, zeros_c = [1] * nch, [0] * nch
     # ---- witness on the device: [w 0..14 | z] in evaluation form, then in coefficient form, then on d8
     ev = khip.DevBuf(16 * NB)
     if witness_on_device is None:
         # straight from the caller's columns (no padded host copy: that staging was 1.7 of this phase's 2.4 ms): zero the device
-        # buffer, upload each column's rows, then the three zero-knowledge rows per column (prover.rs:254-286)
+        # buffer, upload each column's rows, then the zero-knowledge rows -- drawn per column from the LAST row backwards (prover.rs:254-286)
         wit = np.asarray(witness, dtype=np.uint64).reshape(COLUMNS, -1, 4)
-        assert wit.shape[1] + ZK_ROWS <= n, "NoRoomForZkInWitness"
-        if wit.shape[1] + ZK_ROWS < n:
+        assert wit.shape[1] + zk <= n, "NoRoomForZkInWitness"
+        if wit.shape[1] + zk < n:
             ev.zero()
-        zk = F.limbs_many(F.rand_many(rng, COLUMNS * ZK_ROWS)).reshape(COLUMNS, ZK_ROWS, 4)
+        zkr = F.limbs_many(F.rand_many(rng, COLUMNS * zk)).reshape(COLUMNS, zk, 4)[:, ::-1, :]
         ev.upload_2d(0, NB, wit)                             # 15 columns, each into its padded device column, one transfer
-        ev.upload_2d((n - ZK_ROWS) * 32, NB, zk)
+        ev.upload_2d((n - zk) * 32, NB, np.ascontiguousarray(zkr))
     else:
         khip.dev_copy(ev.ptr, witness_on_device.ptr, COLUMNS * NB)
     mark("witness_upload")
     fq = khip.Sponge(khip.Sponge.FQ, curve)
     fq.absorb(ix.digest)
+    for _chals, (cxy, cinf) in prev_challenges:             # prover.rs:276-279
+        fq.absorb_g(np.ascontiguousarray(cxy).reshape(-1, 8), np.ascontiguousarray(cinf, dtype=np.uint8).reshape(-1))
     pub_c = None
     if ix.public:                                           # the negated public-input polynomial (prover.rs:281-309): -p_i on the first rows
         pe_ = np.zeros((n, 4), dtype=np.uint64)
         pub_vals = F.values(ev.download_at(0, (ix.public, 4)))
         pe_[:ix.public] = F.limbs_many([(-x) % F.p for x in pub_vals])
         pub_c = khip.DevBuf(NB).upload(pe_)
-        com, inf = srs.msm_batch_dev(pub_c.ptr, n, 1, basis=logn)
-        com, inf = srs.mask_custom(com, inf, F.limbs_many([1]))
-        fq.absorb_g(com, inf)
+        pcom = ix.commit_evals(pub_c.ptr, 1)                  # = commit_non_hiding of the interpolant, chunk for chunk
+        public_comm = ix.mask(pcom, ones_c)[0]
         khip.ntt_dev(fid, pub_c, logn, True, 1)
-    else:
-        fq.absorb_g(ix.h.copy().reshape(1, 8))              # zero public polynomial: commit_non_hiding -> [0], masked with 1 -> h
-    # ---- witness commitments (commit_evaluations_non_hiding x 15 in one batched MSM over the Lagrange basis) + blinders
-    tk = srs.msm_submit(ev.ptr, n, COLUMNS, basis=logn)       # ... while the columns are interpolated on the main stream (both only read `ev`)
+    else:                                                   # zero polynomial: commit_non_hiding -> infinity per chunk, masked with 1 -> h
+        public_comm = ix.zero_selector_comm
+    fq.absorb_g(public_comm[0], public_comm[1])
+    # ---- witness commitments (commit_evaluations_non_hiding x 15, one batched MSM per chunk of the Lagrange basis) + blinders
+    tk = srs.msm_submit(ev.ptr, n, COLUMNS, basis=logn) if nch == 1 else None     # ... while the columns are interpolated on the main stream
     cf = khip.DevBuf(16 * NB)                               # coefficient forms [w | z]
     khip.dev_copy(cf.ptr, ev.ptr, COLUMNS * NB)
     khip.ntt_dev(fid, cf, logn, True, COLUMNS)
@@ -295,12 +365,18 @@ def create_proof(ix: ProverIndex, witness, rng, timings=None, check: bool = True
     LI = getattr(ix, "lookup", None)
     e8 = khip.DevBuf(16 * 8 * NB)
     N8 = 8 * NB
-    w8 = PERMUTS if LI is None and not (ix.live_gate_types & set(ix.GATE_TYPES)) else COLUMNS
+    live_lib = ix.live_gate_types & (set(ix.GATE_TYPES) | set(OPTIONAL_GATES))
+    w8 = PERMUTS if LI is None and not live_lib and not all_gates else COLUMNS
     khip.lde_dev(fid, cf, logn, 3, e8, w8)
-    com, inf = srs.msm_wait(tk)
-    w_blind = F.rand_many(rng, COLUMNS)
-    w_comm, w_inf = srs.mask_custom(com, inf, F.limbs_many(w_blind))
-    fq.absorb_g(w_comm, w_inf)
+    if tk is not None:
+        com, inf = srs.msm_wait(tk)
+        wcom = [(com[i:i + 1], inf[i:i + 1]) for i in range(COLUMNS)]
+    else:
+        wcom = ix.commit_evals(ev.ptr, COLUMNS)
+    w_blind = F.rand_many(rng, COLUMNS * nch)               # blinder(num_chunks) per column, column by column (prover.rs:316-327)
+    w_comm = ix.mask(wcom, w_blind)
+    for c_, i_ in w_comm:
+        fq.absorb_g(c_, i_)
     lkp = None
     if LI is not None:                                      # prover.rs:383-633: joint combiner, combined table, sorted columns
         from . import lookup as LK
@@ -310,27 +386,26 @@ def create_proof(ix: ProverIndex, witness, rng, timings=None, check: bool = True
         wcols = ev.download((COLUMNS, n, 4))
         used = sorted({c for q in LI.patterns for tid, entry in OP.LOOKUP_PATTERNS[q] for c in (list(entry) + ([tid[1]] if isinstance(tid, tuple) else []))})
         wit_ints = [F.values(wcols[c]) if c in used else None for c in range(COLUMNS)]
-        srt = [LK.zk_patch(F, c, n, ZK_ROWS, rng) for c in LK.sorted_columns(LI, wit_ints, table_ints, jc)]    # ValueError(row): value not in the table
+        srt = [LK.zk_patch(F, c, n, zk, rng) for c in LK.sorted_columns(LI, wit_ints, table_ints, jc)]    # ValueError(row): value not in the table
         d_sorted = [khip.DevBuf(NB).upload(F.limbs_many(c)) for c in srt]
         s_blind, s_comm = [], []
-        for b in d_sorted:
-            com, inf = srs.msm_batch_dev(b.ptr, n, 1, basis=logn)
-            bl_ = F.rand(rng)
-            com, inf = srs.mask_custom(com, inf, F.limbs_many([bl_]))
-            fq.absorb_g(com, inf)
-            s_blind.append(bl_); s_comm.append((com[0], bool(inf[0])))
+        for b in d_sorted:                                  # commit_evaluations(d1, v, rng): non-hiding, then one blinder per chunk
+            bl_ = F.rand_many(rng, nch)
+            cm = ix.mask(ix.commit_evals(b.ptr, 1), bl_)[0]
+            s_blind.append(bl_); s_comm.append(cm)
+        for c_, i_ in s_comm:
+            fq.absorb_g(c_, i_)
         lkp = {"jc": jc, "d_table": d_table, "d_sorted": d_sorted, "s_blind": s_blind, "s_comm": s_comm}
     mark("witness_commit")
     beta = F.value(fq.challenge_field()); gamma = F.value(fq.challenge_field())
     if lkp is not None:                                     # prover.rs:635-673: the lookup aggregation, committed before z
         d_agg = LK.aggregation_dev(LI, [ev.view(i * NB) for i in range(COLUMNS)], lkp["d_sorted"], lkp["d_table"], lkp["jc"], beta, gamma, rng)
-        if check and F.value(d_agg.download_at((n - ZK_ROWS - 1) * 32, (4,))) != 1:
+        if check and F.value(d_agg.download_at((n - zk - 1) * 32, (4,))) != 1:
             raise RuntimeError("final value of the lookup aggregation is not 1 (lookup/constraints.rs:325-331)")
-        com, inf = srs.msm_batch_dev(d_agg.ptr, n, 1, basis=logn)
-        a_blind = F.rand(rng)
-        com, inf = srs.mask_custom(com, inf, F.limbs_many([a_blind]))
-        fq.absorb_g(com, inf)
-        lkp.update({"d_agg": d_agg, "a_blind": a_blind, "a_comm": (com[0], bool(inf[0]))})
+        a_blind = F.rand_many(rng, nch)
+        a_comm = ix.mask(ix.commit_evals(d_agg.ptr, 1), a_blind)[0]
+        fq.absorb_g(a_comm[0], a_comm[1])
+        lkp.update({"d_agg": d_agg, "a_blind": a_blind, "a_comm": a_comm})
     # ---- permutation accumulator z (perm_aggreg): numerators / denominators, batch inversion, running product
     d1cols = [ev.view(i * NB) for i in range(PERMUTS)] + [ix.col1(COLUMNS + 2 + i) for i in range(PERMUTS)] + [ix.col1(COLUMNS + 1)]
     consts = F.limbs_many([gamma, beta] + [beta * s % F.p for s in ix.shifts])
@@ -342,21 +417,24 @@ def create_proof(ix: ProverIndex, witness, rng, timings=None, check: bool = True
     khip.batch_inversion_dev(fid, den, n - 1, offset=1)
     zcol = ev.view(COLUMNS * NB)
     khip.expr_evaluations_dev(fid, [OP.cell(0), OP.cell(1), (OP.TOK_MUL, 0)], [num, den], [n, n], one.reshape(1, 4), n, zcol)
-    khip.field_scan_dev(fid, khip.SCAN_MUL, zcol, n - ZK_ROWS + 1)
+    khip.field_scan_dev(fid, khip.SCAN_MUL, zcol, n - zk + 1)
     if check:
-        last = F.value(ev.download_at((COLUMNS * n + n - ZK_ROWS) * 32, (4,)))
+        last = F.value(ev.download_at((COLUMNS * n + n - zk) * 32, (4,)))
         if last != 1:
             raise RuntimeError("final value of the permutation accumulator is not 1 (permutation.rs:566-568)")
-    ev.upload_at((COLUMNS * n + n - ZK_ROWS + 1) * 32, F.limbs_many(F.rand_many(rng, 2)))     # the two random rows
+    # z[n - zk + 1], z[n - zk + 2] are random (drawn in that order); the rows behind them continue the running product from there
+    ev.upload_at((COLUMNS * n + n - zk + 1) * 32, F.limbs_many(F.rand_many(rng, 2)))
+    if zk > 3:
+        khip.field_scan_dev(fid, khip.SCAN_MUL, zcol, zk - 2, offset=n - zk + 2)
     khip.dev_copy(cf.ptr + COLUMNS * NB, zcol.ptr, NB)
     khip.ntt_dev(fid, cf.view(COLUMNS * NB), logn, True, 1)
     zc = cf.view(COLUMNS * NB)
-    tk = srs.msm_submit(zc.ptr, n, 1)                       # the commitment to z runs while z is extended to d8
+    tk = srs.msm_submit(zc.ptr, n, 1) if nch == 1 and size == n else None    # the commitment to z runs while z is extended to d8
     khip.lde_dev(fid, zc, logn, 3, e8.view(COLUMNS * N8), 1)
-    com, inf = srs.msm_wait(tk)
-    z_blind = F.rand(rng)
-    z_comm, z_inf = srs.mask_custom(com, inf, F.limbs_many([z_blind]))
-    fq.absorb_g(z_comm, z_inf)
+    zcom = srs.msm_wait(tk) if tk is not None else ix.commit_coeffs(zc.ptr, n, nch)
+    z_blind = F.rand_many(rng, len(zcom[1]))
+    z_comm = ix.mask([zcom], z_blind)[0]
+    fq.absorb_g(z_comm[0], z_comm[1])
     mark("z")
     alpha = scalar_challenge(curve, F, fq.challenge())
     alphas = [pow(alpha, ALPHA_PERM0 + i, F.p) for i in range(3)]
@@ -368,7 +446,7 @@ def create_proof(ix: ProverIndex, witness, rng, timings=None, check: bool = True
     pconsts = F.limbs_many([gamma, beta, alphas[0]] + [beta * s % F.p for s in ix.shifts])
     khip.expr_evaluations_dev(fid, OP.perm_quot_tokens(w0=0, s0=7, z=14, x=15, zkpm=16, gamma=0, beta=1, bshift0=3, alpha0=2), perm_cols, [8 * n] * 17, pconsts,
                               8 * n, t8, stride=1, next_shift=8)
-    live_gates = [(k_, name) for k_, name in enumerate(ix.GATE_TYPES) if name in ix.live_gate_types]
+    live_gates = [(k_, name) for k_, name in enumerate(ix.GATE_TYPES + tuple(ix.optional)) if all_gates or name in ix.live_gate_types]
     if live_gates:                                          # the gate library on d8 (prover.rs:824-868): index(gate) * sum_i alpha^i constraint_i
         endo_q = F.value(khip.endos(1 - curve)[0])          # VerifierIndex::endo = endos::<OtherCurve>().0, an element of this scalar field
         gcols = [e8.view(i * N8) for i in range(COLUMNS)] + [ix.col8(i) for i in range(COLUMNS)]
@@ -404,91 +482,129 @@ def create_proof(ix: ProverIndex, witness, rng, timings=None, check: bool = True
     z0 = F.value(zm1.download_at(0, (4,)))
     zm1.upload_at(0, F.limbs((z0 - 1) % F.p))
     b1.zero(); b2.zero()
-    for a_, dst in ((1, b1), (pow(ix.omega, n - ZK_ROWS, F.p), b2)):
+    for a_, dst in ((1, b1), (pow(ix.omega, n - zk, F.p), b2)):
         r_ = khip.divide_by_linear_dev(fid, zm1, n, F.limbs(a_), dst)
         if check and r_.any():
             raise RuntimeError("permutation boundary division rest (permutation.rs:301-321)")
     khip.poly_lincomb_dev(fid, [quot, b1, b2], [7 * n, n - 1, n - 1], F.limbs_many([1, alphas[1], alphas[2]]), quot, 7 * n)
-    com, inf = srs.msm_batch_dev(quot.ptr, n, 7)
-    t_blind = F.rand_many(rng, 7)
-    t_comm, t_inf = srs.mask_custom(com, inf, F.limbs_many(t_blind))
-    fq.absorb_g(t_comm, t_inf)
+    tcom = ix.commit_coeffs(quot.ptr, 7 * n, 7 * nch)       # (the quotient's trailing coefficients are zero: an all-zero chunk commits to infinity either way)
+    t_blind = F.rand_many(rng, len(tcom[1]))
+    t_comm = ix.mask([tcom], t_blind)[0]
+    fq.absorb_g(t_comm[0], t_comm[1])
     mark("quotient")
     zeta = scalar_challenge(curve, F, fq.challenge())
     zetaw = zeta * ix.omega % F.p
     fq_before = fq.clone()
-    # ---- evaluations at zeta, zeta * omega (coefficient forms; one chunk each)
+    # ---- chunked evaluations at zeta, zeta * omega (coefficient forms; num_chunks chunks of the SRS size each)
     polys = [zc, ix.colc(COLUMNS)] + [ix.colc(ix.SEL0 + k_) for k_ in range(5)] + [cf.view(i * NB) for i in range(COLUMNS)] + [ix.colc(i) for i in range(COLUMNS)] + \
-            [ix.colc(COLUMNS + 2 + i) for i in range(PERMUTS - 1)]
+            [ix.colc(COLUMNS + 2 + i) for i in range(PERMUTS - 1)] + [ix.colc(ix.OPT0 + k_) for k_ in range(len(ix.optional))]
     lk_polys = []
     if lkp is not None:                                     # opening order (prover.rs:1368-1420): sorted ..., aggregation, combined table, pattern selectors
         lk_polys = [lkp["lkc"].view(k_ * NB) for k_ in range(lkp["nl"])] + [LI.sel_c[q] for q in LI.patterns]
     pts = F.limbs_many([zeta, zetaw])
-    evl = khip.evaluate_chunks_batch_dev(fid, polys + lk_polys, [n] * (len(polys) + len(lk_polys)), [1] * (len(polys) + len(lk_polys)), n, pts)
-    E = [tuple(F.values(e)) for e in evl]                 # one chunk per polynomial: (value at zeta, value at zeta * omega)
-    pub_eval = (0, 0)
+    npoly = len(polys) + len(lk_polys)
+    evl = khip.evaluate_chunks_batch_dev(fid, polys + lk_polys, [n] * npoly, [nch] * npoly, size, pts)
+    E = [(F.values(e[0]), F.values(e[1])) for e in evl]   # per polynomial: (chunks at zeta, chunks at zeta * omega)
+    pub_eval = ([0] * nch, [0] * nch)
     if pub_c is not None:
-        pe2 = khip.evaluate_chunks_dev(fid, pub_c, n, n, 1, pts)
-        pub_eval = (F.value(pe2[0, 0]), F.value(pe2[1, 0]))
+        pe2 = khip.evaluate_chunks_dev(fid, pub_c, n, size, nch, pts)
+        pub_eval = (F.values(pe2[0]), F.values(pe2[1]))
+    no = len(ix.optional)
     evals = {"public": pub_eval, "z": E[0], "generic_selector": E[1], "poseidon_selector": E[2], "complete_add_selector": E[3], "mul_selector": E[4],
-             "emul_selector": E[5], "endomul_scalar_selector": E[6], "w": E[7:22], "coefficients": E[22:37], "s": E[37:43]}
+             "emul_selector": E[5], "endomul_scalar_selector": E[6], "w": E[7:22], "coefficients": E[22:37], "s": E[37:43],
+             "optional_gate_selectors": [E[43 + ix.optional.index(t)] if t in ix.optional else None for t in OPTIONAL_GATES]}
     lk_evals_open, lk_evals_sponge = [], []
+    L0 = 43 + no
     if lkp is not None:
         ns = len(lkp["d_sorted"])
-        evals["lookup_sorted"] = E[43:43 + ns]; evals["lookup_aggregation"] = E[43 + ns]; evals["lookup_table"] = E[44 + ns]
-        evals["lookup_selectors"] = {q: E[45 + ns + k_] for k_, q in enumerate(LI.patterns)}
-        lk_evals_open = E[43:]
+        evals["lookup_sorted"] = E[L0:L0 + ns]; evals["lookup_aggregation"] = E[L0 + ns]; evals["lookup_table"] = E[L0 + ns + 1]
+        evals["lookup_selectors"] = {q: E[L0 + ns + 2 + k_] for k_, q in enumerate(LI.patterns)}
+        lk_evals_open = E[L0:]
         lk_evals_sponge = [evals["lookup_aggregation"], evals["lookup_table"]] + list(evals["lookup_sorted"]) + [evals["lookup_selectors"][q] for q in LI.patterns]
-    # ---- ft = perm_scalar * sigma_6 - (zeta^n - 1) * sum_i zeta^(n i) t_i   (Maller; prover.rs:1147-1188)
+    # ---- ft = perm_scalar * sigma_6 - (zeta^n - 1) * t, both chunk-linearised with zeta^max_poly_size (Maller; prover.rs:1147-1200)
     zeta1 = pow(zeta, n, F.p)
-    zkp = (zeta - pow(ix.omega, n - 3, F.p)) * (zeta - pow(ix.omega, n - 2, F.p)) % F.p * (zeta - pow(ix.omega, n - 1, F.p)) % F.p
-    scal = evals["z"][1] * beta % F.p * alphas[0] % F.p * zkp % F.p
+    zeta_srs = pow(zeta, size, F.p); zetaw_srs = pow(zetaw, size, F.p)
+    comb = lambda e: (_horner(F.p, e[0], zeta_srs), _horner(F.p, e[1], zetaw_srs))        # ProofEvaluations::combine
+    zkp = (zeta - pow(ix.omega, n - zk, F.p)) * (zeta - pow(ix.omega, n - zk + 1, F.p)) % F.p * (zeta - pow(ix.omega, n - 1, F.p)) % F.p
+    scal = comb(evals["z"])[1] * beta % F.p * alphas[0] % F.p * zkp % F.p
     for w_, s_ in zip(evals["w"], evals["s"]):
-        scal = scal * ((gamma + beta * s_[0] + w_[0]) % F.p) % F.p
+        scal = scal * ((gamma + beta * comb(s_)[0] + comb(w_)[0]) % F.p) % F.p
     scal = (-scal) % F.p
-    ft = khip.DevBuf(NB)
     m1 = (-(zeta1 - 1)) % F.p
-    khip.poly_lincomb_dev(fid, [ix.colc(COLUMNS + 2 + PERMUTS - 1)] + [quot.view(i * NB) for i in range(7)], [n] * 8,
-                          F.limbs_many([scal] + [m1 * pow(zeta1, i, F.p) % F.p for i in range(7)]), ft, n)
-    fte = khip.evaluate_chunks_dev(fid, ft, n, n, 1, pts)
+    ft_len = min(size, 7 * n)
+    ft = khip.DevBuf(ft_len * 32)
+    sig6 = ix.colc(COLUMNS + 2 + PERMUTS - 1)
+    segs, lens_, scs = [], [], []
+    for c in range(nch):                                    # f_chunked.linearize(zeta^srs_len)
+        ln = min(size, n - c * size)
+        if ln > 0:
+            segs.append(sig6.view(c * size * 32) if c else sig6); lens_.append(ln); scs.append(scal * pow(zeta_srs, c, F.p) % F.p)
+    for c in range(7 * nch):                                # t_chunked.linearize(zeta^srs_len) * -(zeta^n - 1)
+        ln = min(size, 7 * n - c * size)
+        if ln > 0:
+            segs.append(quot.view(c * size * 32)); lens_.append(ln); scs.append(m1 * pow(zeta_srs, c, F.p) % F.p)
+    khip.poly_lincomb_dev(fid, segs, lens_, F.limbs_many(scs), ft, ft_len)
+    fte = khip.evaluate_chunks_dev(fid, ft, ft_len, ft_len, 1, pts)
     ft_eval0, ft_eval1 = F.value(fte[0, 0]), F.value(fte[1, 0])
-    blinding_ft = m1 * sum(b * pow(zeta1, i, F.p) for i, b in enumerate(t_blind)) % F.p
-    # ---- Fr-sponge: v, u
+    blinding_ft = m1 * _horner(F.p, t_blind, zeta_srs) % F.p
+    # ---- Fr-sponge: v, u (prover.rs:1206-1250)
     fr = khip.Sponge(khip.Sponge.FR, curve)
     fr.absorb(fq.digest())
-    empty = khip.Sponge(khip.Sponge.FR, curve); fr.absorb(empty.digest()); empty.free()
+    pd = khip.Sponge(khip.Sponge.FR, curve)
+    for chals, _c in prev_challenges:
+        pd.absorb(F.limbs_many(list(chals)))
+    fr.absorb(pd.digest()); pd.free()
     order = [evals["z"], evals["generic_selector"], evals["poseidon_selector"], evals["complete_add_selector"], evals["mul_selector"], evals["emul_selector"],
-             evals["endomul_scalar_selector"]] + list(evals["w"]) + list(evals["coefficients"]) + list(evals["s"])
-    flat = [ft_eval1, pub_eval[0], pub_eval[1]] + [x for e in order + lk_evals_sponge for x in e]       # plonk_sponge.rs:92-155
+             evals["endomul_scalar_selector"]] + list(evals["w"]) + list(evals["coefficients"]) + list(evals["s"]) + [e for e in evals["optional_gate_selectors"] if e is not None]
+    flat = [ft_eval1] + list(pub_eval[0]) + list(pub_eval[1]) + [x for e in order + lk_evals_sponge for half in e for x in half]       # plonk_sponge.rs:92-155
     fr.absorb(F.limbs_many(flat))
     v = scalar_challenge(curve, F, fr.challenge())
     u = scalar_challenge(curve, F, fr.challenge())
     fr.free()
     mark("evaluations")
-    # ---- SRS::open on (public, ft, z, 6 selectors, w x 15, coefficients x 15, sigma x 6)
-    open_polys = [pub_c if pub_c is not None else ix.zero_poly, ft] + polys + lk_polys
-    open_lens = [n if pub_c is not None else 0, n] + [n] * (len(polys) + len(lk_polys))
-    blinders = [1, blinding_ft, z_blind, 1, 1, 1, 1, 1, 1] + w_blind + [0] * COLUMNS + [0] * (PERMUTS - 1)
+    # ---- SRS::open on (previous challenges, public, ft, z, 6 selectors, w x 15, coefficients x 15, sigma x 6, optional selectors, lookup)
+    prev_bufs, prev_evals = [], []
+    for chals, (cxy, cinf) in prev_challenges:              # b_poly_coefficients(chals), non-hiding, comm.len() chunks (prover.rs:1227-1262)
+        bc = khip.b_poly_coefficients(fid, F.limbs_many(list(chals)), len(chals))[0]
+        prev_bufs.append((khip.DevBuf(bc.shape[0] * 32).upload(bc), bc.shape[0], np.ascontiguousarray(cinf).reshape(-1).shape[0]))
+    open_polys = [b for b, _l, _k in prev_bufs] + [pub_c if pub_c is not None else ix.zero_poly, ft] + polys + lk_polys
+    open_lens = [l_ for _b, l_, _k in prev_bufs] + [n if pub_c is not None else 0, ft_len] + [n] * npoly
+    open_chunks = [k_ for _b, _l, k_ in prev_bufs] + [nch, 1] + [nch] * npoly
+    blinders = [0] * sum(k_ for _b, _l, k_ in prev_bufs) + ones_c + [blinding_ft] + z_blind + ones_c * 6 + w_blind + zeros_c * COLUMNS + zeros_c * (PERMUTS - 1) + zeros_c * no
     if lkp is not None:                                     # the combined table's blinder: sum_i jc^i over its masked columns + the table-id combiner (prover.rs:1384-1400)
         jc_, tic_ = LI.combiners(lkp["jc"])
         tb = sum(pow(jc_, i, F.p) for i in range(len(LI.table_cols))) + tic_
-        blinders += lkp["s_blind"] + [lkp["a_blind"], tb % F.p] + [0] * len(LI.patterns)
-    all_evals = [pub_eval, (ft_eval0, ft_eval1)] + order + lk_evals_open
-    a_dev = khip.DevBuf(NB); b_dev = khip.DevBuf(NB)
-    khip.combine_polys_dev(fid, open_polys, open_lens, [1] * len(open_polys), F.limbs(v), n, a_dev)
-    khip.b_init_dev(fid, pts, F.limbs(u), n, b_dev)
+        blinders += [x for bl_ in lkp["s_blind"] for x in bl_] + lkp["a_blind"] + [tb % F.p] * nch + zeros_c * len(LI.patterns)
+    for chals, _c in prev_challenges:
+        ln = 1 << len(chals)
+        ch_l = list(chals)
+        full = [_b_poly(F.p, ch_l, x) for x in (zeta, zetaw)]
+        if ln == size:
+            prev_evals.append(([full[0]], [full[1]]))
+        else:                                               # RecursionChallenge::evals (proof.rs:455-494): two chunks
+            bc_ = F.values(khip.b_poly_coefficients(fid, F.limbs_many(ch_l), len(ch_l))[0][size:])
+            d0, d1_ = _horner(F.p, bc_, zeta), _horner(F.p, bc_, zetaw)
+            prev_evals.append(([(full[0] - d0 * zeta_srs) % F.p, d0], [(full[1] - d1_ * zetaw_srs) % F.p, d1_]))
+    all_evals = prev_evals + [pub_eval, ([ft_eval0], [ft_eval1])] + order + lk_evals_open
+    a_dev = khip.DevBuf(size * 32); b_dev = khip.DevBuf(size * 32)
+    khip.combine_polys_dev(fid, open_polys, open_lens, open_chunks, F.limbs(v), size, a_dev)
+    khip.b_init_dev(fid, pts, F.limbs(u), size, b_dev)
     blinding_factor, cip, ps = 0, 0, 1
-    for bl, (e0, e1) in zip(blinders, all_evals):
-        blinding_factor = (blinding_factor + bl * ps) % F.p
-        cip = (cip + ps * ((e0 + u * e1) % F.p)) % F.p                  # combined_inner_product (commitment.rs:622-657) = <p, b_init>
-        ps = ps * v % F.p
+    bi = iter(blinders)
+    for e0, e1 in all_evals:                                # per chunk: combined_inner_product (commitment.rs:622-657) = <p, b_init>, and the combined blinder
+        for c0_, c1_ in zip(e0, e1):
+            blinding_factor = (blinding_factor + next(bi) * ps) % F.p
+            cip = (cip + ps * ((c0_ + u * c1_) % F.p)) % F.p
+            ps = ps * v % F.p
+    assert next(bi, None) is None, "blinders / evaluation chunks mismatch"
     sp = fq_before
-    bl = F.rand_many(rng, 2 * logn + 2)         # the reference's draw order: (rand_l, rand_r) per round, then d, r_delta
-    lr_xy, lr_inf, delta, dinf, z1_l, z2_l, sg, sg_inf = khip.ipa_open(srs, a_dev, b_dev, n, F.limbs(cip), F.limbs(blinding_factor), sp, F.limbs_many(bl))
-    opening = {"lr": [(lr_xy[r], lr_inf[r]) for r in range(logn)], "delta": (delta, dinf), "z1": F.value(z1_l), "z2": F.value(z2_l), "sg": (sg, sg_inf)}
+    logs = size.bit_length() - 1
+    bl = F.rand_many(rng, 2 * logs + 2)         # the reference's draw order: (rand_l, rand_r) per round, then d, r_delta
+    lr_xy, lr_inf, delta, dinf, z1_l, z2_l, sg, sg_inf = khip.ipa_open(srs, a_dev, b_dev, size, F.limbs(cip), F.limbs(blinding_factor), sp, F.limbs_many(bl))
+    opening = {"lr": [(lr_xy[r], lr_inf[r]) for r in range(logs)], "delta": (delta, dinf), "z1": F.value(z1_l), "z2": F.value(z2_l), "sg": (sg, sg_inf)}
     sp.free(); fq.free()
     mark("opening")
-    for b in (ev, cf, e8, t4, t8, quot, rem, zm1, b1, b2, ft, a_dev, b_dev, num, den):
+    for b in [ev, cf, e8, t4, t8, quot, rem, zm1, b1, b2, ft, a_dev, b_dev, num, den] + [b for b, _l, _k in prev_bufs]:
         b.free()
     if pub_c is not None:
         pub_c.free()
@@ -502,5 +618,18 @@ def create_proof(ix: ProverIndex, witness, rng, timings=None, check: bool = True
         for name, t in marks:
             timings[name] = timings.get(name, 0.0) + (t - prev); prev = t
         timings["total"] = timings.get("total", 0.0) + (marks[-1][1] - t_start)
-    return {"w_comm": (w_comm, w_inf), "z_comm": (z_comm, z_inf), "t_comm": (t_comm, t_inf), "evals": evals, "ft_eval1": ft_eval1, "opening": opening,
-            "challenges": {"beta": beta, "gamma": gamma, "alpha": alpha, "zeta": zeta, "v": v, "u": u}, **lk_out}
+    return {"w_comm": w_comm, "z_comm": z_comm, "t_comm": t_comm, "public_comm": public_comm, "evals": evals, "ft_eval1": ft_eval1, "opening": opening,
+            "prev_challenges": [(list(c), m) for c, m in prev_challenges],
+            "challenges": {"beta": beta, "gamma": gamma, "alpha": alpha, "zeta": zeta, "v": v, "u": u, "joint_combiner": lkp["jc"] if lkp else None}, **lk_out}
+
+
+def _b_poly(p: int, chals, x: int) -> int:
+    """b_poly (commitment.rs:426-436): prod_i (1 + chals[i] * x^(2^(k - 1 - i)))."""
+    k = len(chals)
+    pw = [x % p]
+    for _ in range(1, k):
+        pw.append(pw[-1] * pw[-1] % p)
+    r = 1
+    for i in range(k):
+        r = r * (1 + chals[i] * pw[k - 1 - i]) % p
+    return r

@@ -73,6 +73,11 @@ def tables(name, rnd):
             want = CURVE.add(CURVE.add(want, q), want)
         assert acc == want and n == int("".join(map(str, bits)), 2)
         return w, [[0] * 15] * len(w), len(w) - 1
+    if name == "Xor16":
+        a, b = rnd.randrange(1 << 64), rnd.randrange(1 << 64)
+        w = G.xor_witness(F, a, b, 64)                           # 4 Xor16 rows + the zero row
+        assert w[0][2] == a ^ b
+        return w, [[0] * 15] * len(w), len(w) - 1
     scalar = rnd.randrange(1 << 128)
     w, _ = G.endomul_scalar_witness(F, scalar, endo, 128)
     return w + [[0] * 15], [[0] * 15] * (len(w) + 1), len(w)
@@ -122,7 +127,7 @@ def test_every_constrained_cell_matters(name):
     w, co, ngate = tables(name, rnd)
     row = gate_rows(name, ngate)[0]
     used = {"Poseidon": range(15), "CompleteAdd": range(11), "VarBaseMul": [0, 1, 2, 3, 4, 5, 7, 8, 9, 10, 11, 12, 13, 14], "EndoMul": [0, 1, 2, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14],
-            "EndoMulScalar": range(14)}[name]
+            "EndoMulScalar": range(14), "Xor16": range(15)}[name]
     for c in used:
         wt = [list(r) for r in w]
         wt[row][c] = (wt[row][c] + 1 + rnd.randrange(5)) % F.p

@@ -9,6 +9,7 @@ import pytest
 from oracle import cref
 from oracle import kimchi as K
 from oracle import pasta as P
+from oracle import views as V
 
 pytestmark = pytest.mark.gpu
 
@@ -21,53 +22,29 @@ def khip():
 
 
 def _aff(c, xy, inf):
-    if inf:
-        return None
-    return (c.base.from_mont(P.from_limbs(xy[:4])), c.base.from_mont(P.from_limbs(xy[4:])))
+    return V.aff(c, xy, inf)
 
 
 def _oracle_views(khip, ix, proof):
     """The device prover's index / proof as the plain-integer structures oracle/kimchi.py verifies."""
-    c = P.CURVES[ix.curve]
-    one = lambda t: [_aff(c, t[0], t[1])]
-    vix = {"F": c.scalar, "n": ix.n, "log2_n": ix.log2_n, "omega": ix.omega, "shifts": ix.shifts, "h": _aff(c, ix.h, False),
-           "sigma_comm": [one(t) for t in ix.sigma_comm], "coefficients_comm": [one(t) for t in ix.coefficients_comm], "generic_comm": one(ix.generic_comm),
-           "psm_comm": one(ix.selector_comms[0]), "complete_add_comm": one(ix.selector_comms[1]), "mul_comm": one(ix.selector_comms[2]),
-           "emul_comm": one(ix.selector_comms[3]), "endomul_scalar_comm": one(ix.selector_comms[4])}
-    chunks = lambda t: [_aff(c, t[0][j], t[1][j]) for j in range(len(t[1]))]
-    op = proof["opening"]
-    pr = {"w_comm": [[_aff(c, proof["w_comm"][0][i], proof["w_comm"][1][i])] for i in range(15)], "z_comm": chunks(proof["z_comm"]), "t_comm": chunks(proof["t_comm"]),
-          "evals": proof["evals"], "ft_eval1": proof["ft_eval1"],
-          "opening": {"lr": [(_aff(c, xy[0], li[0]), _aff(c, xy[1], li[1])) for xy, li in op["lr"]], "delta": _aff(c, *op["delta"]), "z1": op["z1"], "z2": op["z2"],
-                      "sg": _aff(c, *op["sg"])}}
-    LI = getattr(ix, "lookup", None)
-    if LI is not None:
-        vix["lookup_index"] = {"joint_lookup_used": LI.joint_lookup_used, "lookup_table": [one(t) for t in LI.table_comm],
-                               "lookup_selectors": {q: one(LI.selector_comm[q]) for q in LI.patterns},
-                               "table_ids": one(LI.table_ids_comm) if LI.table_ids_comm else None, "max_per_row": LI.max_per_row,
-                               "max_joint_size": LI.max_joint_size, "patterns": list(LI.patterns), "uses_runtime_tables": False, "runtime_tables_selector": None}
-        vix["zk_rows"] = 3
-        pr["lookup"] = {"sorted": [one(t) for t in proof["lookup"]["sorted"]], "aggreg": one(proof["lookup"]["aggreg"])}
-    return c, vix, pr
+    return V.device_views(ix, proof)
+
+
+def _bump(e, half, p):
+    """an evaluation (chunks at zeta, chunks at zeta omega) with the first chunk of one half incremented"""
+    a, b = list(e[0]), list(e[1])
+    if half == 0:
+        a[0] = (a[0] + 1) % p
+    else:
+        b[0] = (b[0] + 1) % p
+    return (a, b)
 
 
 def _verify(khip, ix, proof, seed=5):
     c, vix, pr = _oracle_views(khip, ix, proof)
     g_l = ix.srs.get_g()
     h = _aff(c, ix.h, False)
-
-    def final_msm(g_terms, pts, sc):          # the verifier's one MSM with the C oracle (independent of the product)
-        F = c.scalar
-        gs = [0] * ix.n
-        for w, chal in g_terms:
-            for j, s in enumerate(P.b_poly_coefficients(F, chal)):
-                gs[j] = (gs[j] + w * s) % F.p
-        live = [(p, s) for p, s in zip(pts, sc) if p is not None]
-        xy = np.concatenate([g_l, np.stack([cref.ints_to_limbs([c.base.to_mont(p[0]), c.base.to_mont(p[1])]).reshape(8) for p, _ in live])])
-        scal = cref.ints_to_limbs([F.to_mont(s) for s in gs + [s for _, s in live]])
-        _, inf = cref.msm(ix.curve, xy, scal, threads=16)
-        return inf
-    ok = K.verify(c, vix, pr, None, h, P.StdRng(bytes([seed] * 32)), final_msm=final_msm)
+    ok = K.verify(c, vix, pr, None, h, P.StdRng(bytes([seed] * 32)), final_msm=V.final_msm_c(c, g_l, ix.size))
     return ok, (c, vix, pr)
 
 
@@ -87,7 +64,7 @@ def test_bench_circuit_proof_is_accepted_by_the_reference_verifier(khip, cid, lo
     for k in ("beta", "gamma", "alpha", "zeta", "v", "u"):
         assert ch[k] == proof["challenges"][k], k
     if logn <= 12:
-        bad = dict(proof, evals=dict(proof["evals"], z=(proof["evals"]["z"][0], (proof["evals"]["z"][1] + 1) % F.p)))
+        bad = dict(proof, evals=dict(proof["evals"], z=_bump(proof["evals"]["z"], 1, F.p)))
         assert not _verify(khip, ix, bad)[0]                          # a tampered evaluation
         bad = dict(proof, ft_eval1=(proof["ft_eval1"] + 1) % F.p)
         assert not _verify(khip, ix, bad)[0]
@@ -167,9 +144,9 @@ def test_proof_with_lookups_is_accepted_by_the_reference_pinned_verifier(khip, c
     ok, (c, vix, pr) = _verify(khip, ix, proof)
     assert ok
     assert len(pr["lookup"]["sorted"]) == 4 and vix["lookup_index"]["table_ids"] is not None
-    bad = dict(proof); be = dict(proof["evals"]); be["lookup_aggregation"] = (be["lookup_aggregation"][0], (be["lookup_aggregation"][1] + 1) % F.p); bad["evals"] = be
+    bad = dict(proof); be = dict(proof["evals"]); be["lookup_aggregation"] = _bump(be["lookup_aggregation"], 1, F.p); bad["evals"] = be
     assert not _verify(khip, ix, bad)[0]
-    bad = dict(proof); be = dict(proof["evals"]); srt = list(be["lookup_sorted"]); srt[1] = ((srt[1][0] + 1) % F.p, srt[1][1]); be["lookup_sorted"] = srt; bad["evals"] = be
+    bad = dict(proof); be = dict(proof["evals"]); srt = list(be["lookup_sorted"]); srt[1] = _bump(srt[1], 0, F.p); be["lookup_sorted"] = srt; bad["evals"] = be
     assert not _verify(khip, ix, bad)[0]
     wit[2][ngen + 5] = (wit[2][ngen + 5] + 1) % F.p                     # a looked-up value that is not in its table
     with pytest.raises(ValueError):
@@ -205,8 +182,8 @@ def test_proof_over_the_gate_library_is_accepted(khip):
     ok, (c, vix, pr) = _verify(khip, ix, proof)
     assert ok
     for key in ("poseidon_selector", "complete_add_selector", "mul_selector", "emul_selector", "endomul_scalar_selector"):
-        assert proof["evals"][key][0] != 0                              # every gate type is live in this proof
-    bad = dict(proof); be = dict(proof["evals"]); w_ = list(be["w"]); w_[2] = ((w_[2][0] + 1) % F.p, w_[2][1]); be["w"] = w_; bad["evals"] = be
+        assert proof["evals"][key][0][0] != 0                              # every gate type is live in this proof
+    bad = dict(proof); be = dict(proof["evals"]); w_ = list(be["w"]); w_[2] = _bump(w_[2], 0, F.p); be["w"] = w_; bad["evals"] = be
     assert not _verify(khip, ix, bad)[0]
     r0 = types.index("Poseidon") + 3
     wrows[r0][7] = (wrows[r0][7] + 1) % F.p

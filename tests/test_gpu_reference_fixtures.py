@@ -13,6 +13,7 @@ from oracle import cref
 from oracle import fixtures as FX
 from oracle import kimchi as K
 from oracle import pasta as P
+from oracle import views as V
 
 from test_gpu_prover import _aff, _verify
 from test_reference_fixtures import C, F, HERE, generic_test_circuit
@@ -42,7 +43,7 @@ def test_device_index_transforms_and_prover_against_the_reference_bytes(khip):
     rows, wit = generic_test_circuit()
     co = np.stack([_limbs(r) for r in rows])                              # (20, 15, 4)
     ix = prover.ProverIndex(khip.VESTA, 5, co)
-    one = lambda t: [_aff(C, t[0], t[1])]
+    one = lambda t: V.chunks(C, t)
     # ---- the index commitments and the digest
     assert [one(t) for t in ix.sigma_comm] == v["sigma_comm"]
     assert [one(t) for t in ix.coefficients_comm] == v["coefficients_comm"]
@@ -83,17 +84,7 @@ def test_device_index_transforms_and_prover_against_the_reference_bytes(khip):
     for k in ("sigma_comm", "coefficients_comm", "generic_comm", "psm_comm", "complete_add_comm", "mul_comm", "emul_comm", "endomul_scalar_comm"):
         vix[k] = v[k]                                                       # (equal anyway: asserted above)
     g_l = ix.srs.get_g()
-
-    def final_msm(g_terms, pts, sc):
-        gs = [0] * ix.n
-        for wt, chal in g_terms:
-            for j, s in enumerate(P.b_poly_coefficients(F, chal)):
-                gs[j] = (gs[j] + wt * s) % F.p
-        live = [(p, s) for p, s in zip(pts, sc) if p is not None]
-        xy = np.concatenate([g_l, np.stack([cref.ints_to_limbs([C.base.to_mont(p[0]), C.base.to_mont(p[1])]).reshape(8) for p, _ in live])])
-        scal = cref.ints_to_limbs([F.to_mont(s) for s in gs + [s for _, s in live]])
-        _, inf = cref.msm(0, xy, scal, threads=8)
-        return inf
+    final_msm = V.final_msm_c(C, g_l, ix.size, threads=8)
     assert K.verify(C, vix, pr, None, h, P.StdRng(bytes([7] * 32)), final_msm=final_msm)
 
 
@@ -109,29 +100,20 @@ def test_device_prover_on_the_reference_public_input_circuit(khip):
     pub_rows = [[1] + [0] * 14 for _ in range(5)]                          # GenericGateSpec::Pub: coefficient 1 on the left wire
     co = np.stack([_limbs(r) for r in pub_rows + rows])
     ix = prover.ProverIndex(khip.VESTA, 5, co, public=5)
-    one = lambda t: [_aff(C, t[0], t[1])]
+    one = lambda t: V.chunks(C, t)
     assert [one(t) for t in ix.sigma_comm] == v["sigma_comm"] and [one(t) for t in ix.coefficients_comm] == v["coefficients_comm"]
     assert one(ix.generic_comm) == v["generic_comm"] and v["public"] == 5
     w = [[3] * 5 + col for col in wit]
     for c in range(1, 15):
         w[c][:5] = [0] * 5
     proof = prover.create_proof(ix, np.stack([_limbs(c) for c in w]), np.random.default_rng(6))
-    assert proof["evals"]["public"] != (0, 0)
+    assert proof["evals"]["public"] != ([0], [0])
     h = C.srs_h()
     g_l = ix.srs.get_g()
     lag = lagrange_commitments(g_l, 5, 5)
     from test_gpu_prover import _oracle_views
 
-    def final_msm(g_terms, pts, sc):
-        gs = [0] * ix.n
-        for wt, chal in g_terms:
-            for j, s_ in enumerate(P.b_poly_coefficients(F, chal)):
-                gs[j] = (gs[j] + wt * s_) % F.p
-        live = [(p, s_) for p, s_ in zip(pts, sc) if p is not None]
-        xy = np.concatenate([g_l, np.stack([cref.ints_to_limbs([C.base.to_mont(p[0]), C.base.to_mont(p[1])]).reshape(8) for p, _ in live])])
-        scal = cref.ints_to_limbs([F.to_mont(s_) for s_ in gs + [s_ for _, s_ in live]])
-        _, inf = cref.msm(0, xy, scal, threads=8)
-        return inf
+    final_msm = V.final_msm_c(C, g_l, ix.size, threads=8)
     for public, want in (([3] * 5, True), ([3, 3, 4, 3, 3], False)):
         c, vix, pr = _oracle_views(khip, ix, proof)
         vix["public_comm"] = K.public_commitment(C, h, lag, public)
@@ -139,7 +121,7 @@ def test_device_prover_on_the_reference_public_input_circuit(khip):
         # the evaluations of the public polynomial the proof carries are the ones the verifier would compute from the inputs
         if want:
             ch = K.fiat_shamir(C, vix, pr, K.verifier_index_digest(C, vix))
-            assert K.public_evaluations(F, ix.n, ix.omega, public, ch["zeta"]) == tuple(proof["evals"]["public"])
+            assert K.public_evaluations(F, ix.n, ix.omega, public, ch["zeta"]) == tuple(x[0] for x in proof["evals"]["public"])
 
 
 @pytest.mark.parametrize("name", ["test_poseidon", "ec_test", "varbase_mul_test", "endomul_test", "endomul_scalar_test",
