@@ -143,6 +143,7 @@ struct kh_srs {
     size_t g_stride = 0;      // (the two extra bases of the opening rounds, written by kh_ipa_begin)
     int g_precomp_c = 0;
     bool ipa_live = false;    // the U slot belongs to one opening at a time
+    std::thread::id ipa_owner;   // ... begun by this thread (a second opening from ANOTHER thread waits for it: SRS::open is re-entrant on &self)
     // workspace of the opening rounds, kept across openings (hipMalloc / hipFree cost ~0.1 ms each: 1 ms per proof)
     DevBuf ipa_a[2], ipa_b[2], ipa_coef[2], ipa_sc, ipa_partial, ipa_sg;
     hipEvent_t ipa_ev = nullptr;
@@ -1156,8 +1157,11 @@ static int ipa_begin_common(kh_srs_t* srs, const uint64_t* a, size_t a_len, cons
     KH_REQUIRE(b_len == n, "b must hold padded_length = %zu evaluation-point powers (got %zu)", n, b_len);
     int rc = ensure_init(); if (rc) return rc;
     Context& C = ctx();
-    std::lock_guard<std::mutex> lk(C.mu);
-    KH_REQUIRE(!srs->ipa_live, "another opening is in progress on this SRS (kh_ipa_free it first)");
+    std::unique_lock<std::mutex> lk(C.mu);
+    // the reference's SRS::open takes &self and is called from several threads on clones of one SRS (GpuSrs is Clone + Sync): a second
+    // opening on the same handle waits for the first to be freed; only the SAME thread beginning twice is a programming error
+    KH_REQUIRE(!(srs->ipa_live && srs->ipa_owner == std::this_thread::get_id()), "another opening is in progress on this SRS in this thread (kh_ipa_free it first)");
+    C.cv.wait(lk, [&] { return !srs->ipa_live; });
     // A graph of the round MSM is captured and replayed WITHIN one opening only (nothing allocates or frees device memory
     // between the rounds of an opening); replaying it after the caller has freed and allocated buffers in between faulted
     // on ROCm 7.2 when another HIP user (PyTorch) shared the process.  Re-capturing costs one extra un-graphed round.
@@ -1214,7 +1218,7 @@ static int ipa_begin_common(kh_srs_t* srs, const uint64_t* a, size_t a_len, cons
         auto us = [](std::chrono::steady_clock::time_point x, std::chrono::steady_clock::time_point y) { return std::chrono::duration<double, std::micro>(y - x).count(); };
         fprintf(stderr, "kh_ipa_begin: graph reset %.0f us, workspace %.0f, U multiples %.0f, uploads + copies %.0f\n", us(b0_, b1_), us(b1_, b2_), us(b2_, b3_), us(b3_, std::chrono::steady_clock::now()));
     }
-    srs->ipa_live = true;
+    srs->ipa_live = true; srs->ipa_owner = std::this_thread::get_id();
     st->retired = std::move(retired);
     *out = st.release();
     return KH_OK;
@@ -1396,6 +1400,7 @@ void kh_ipa_free(kh_ipa_t* st) {
     (void)hipStreamSynchronize(C.stream);                 // a fold may still be in flight on the library stream
     if (st->srs) st->srs->ipa_live = false;
     delete st;
+    C.cv.notify_all();                                    // an opening another thread wants to begin on this handle can start
 }
 
 // The whole tail of SRS::open (ipa.rs:898-1060) in one call, so that a device-resident prover has no per-round host

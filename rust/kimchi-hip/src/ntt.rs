@@ -4,8 +4,9 @@
 //! kimchi/src/prover.rs:289,377,907,1163, circuits/constraints.rs:490-495), so there is no trait to implement; the seam is
 //! the crate itself.  `rust/ark-poly-patch/` holds the two functions to splice into a fork of ark-poly 0.5
 //! (`Radix2EvaluationDomain::{fft_in_place, ifft_in_place}`), wired in with `[patch.crates-io]` like the arkworks patches
-//! the workspace already carries (proof-systems/Cargo.toml:151-152).  These helpers are what that patch calls, and what a
-//! prover restructured around device-resident columns calls directly.
+//! the workspace already carries (proof-systems/Cargo.toml:151-152).  That fork binds `kimchi-hip-sys` DIRECTLY (this crate
+//! depends on poly-commitment -> ark-poly: calling it from the fork would be a dependency cycle); the helpers below are the
+//! same calls for a prover restructured around batches of columns.
 use ark_ff::PrimeField;
 use kimchi_hip_sys as sys;
 

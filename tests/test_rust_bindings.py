@@ -104,3 +104,41 @@ def test_safe_crate_calls_exist_with_the_right_arity():
                    "commit_evaluations", "commit_evaluations_custom", "create", "get_lagrange_basis", "get_lagrange_basis_from_domain_size", "size"):
         assert re.search(r"fn %s\b" % method, src), method
     assert "impl<G: HipCurve, const FULL_ROUNDS: usize> OpenProof<G, FULL_ROUNDS> for GpuOpeningProof<G, FULL_ROUNDS>" in src
+
+
+def _path_deps(cargo_toml: str):
+    """names of the `path = ...` / plain dependencies a Cargo.toml (or a patch adding lines to one) declares"""
+    return set(re.findall(r"^\+?\s*([a-z][a-z0-9_-]*)\s*=\s*(?:\{[^}]*\}|\"[^\"]*\")", cargo_toml, flags=re.M))
+
+
+def test_no_dependency_cycle():
+    """kimchi-hip-sys <- ark-poly fork <- poly-commitment <- kimchi-hip: the fork must bind the -sys crate only.  Builds the crate graph
+    from rust/*/Cargo.toml, the Cargo.toml hunk + `use` lines of the ark-poly patch and the reference's known edge
+    poly-commitment -> ark-poly (poly-commitment/Cargo.toml), and fails on any cycle."""
+    g = {}
+    for crate in ("kimchi-hip-sys", "kimchi-hip"):
+        toml = open(os.path.join(ROOT, "rust", crate, "Cargo.toml")).read()
+        deps = toml[toml.index("[dependencies]"):] if "[dependencies]" in toml else ""
+        deps = re.sub(r"^#.*$", "", deps, flags=re.M)
+        g[crate] = _path_deps(deps) - {"version", "edition", "path"}
+    patch = open(os.path.join(ROOT, "rust", "ark-poly-patch", "radix2_fft_in_place.patch")).read()
+    hunk = patch[patch.index("+++ b/poly/Cargo.toml"):patch.index("--- a/poly/src")]
+    added = _path_deps("\n".join(l for l in hunk.splitlines() if l.startswith("+") and not l.startswith("+#") and not l.startswith("+++")))
+    used = set(re.findall(r"^\+use ([a-z_]+)", patch, flags=re.M)) | set(re.findall(r"\b(kimchi_hip(?:_sys)?)::", patch))
+    assert {u.replace("_", "-") for u in used if u.startswith("kimchi")} <= added, (used, added)       # every kimchi crate the patch uses is declared
+    g["ark-poly"] = added
+    g["poly-commitment"] = {"ark-poly"}                                     # /root/reference/poly-commitment/Cargo.toml: ark-poly.workspace = true
+    assert g["kimchi-hip-sys"] == set(), g["kimchi-hip-sys"]
+    assert "kimchi-hip" not in g["ark-poly"] and g["ark-poly"] == {"kimchi-hip-sys"}
+
+    def reach(a, seen=()):
+        for b in g.get(a, ()):
+            assert b not in seen + (a,), f"dependency cycle through {a} -> {b}"
+            reach(b, seen + (a,))
+    for c in g:
+        reach(c)
+    # the forward transform must not zero-extend on the host before the call (the padding would cross PCIe): no resize to self.size() in fft_in_place
+    fwd = re.sub(r"//.*", "", patch[patch.index("fn fft_in_place"):patch.index("fn ifft_in_place")])
+    assert "resize" not in fwd and "kimchi_hip_dispatch::forward" in fwd
+    assert "TypeId" not in patch.replace("`TypeId::of::<T>()`", "")        # DomainCoeff has no 'static bound
+    assert "sys::kh_lde(" in patch and "sys::kh_ntt(" in patch
