@@ -20,9 +20,14 @@ Extra objects on the JSON line:
   cpu_baseline  the oracle's C Pippenger (oracle/pasta_ref.c, "port") on this box's host cores,
                 same bases and scalars, on rank 0 at N=1; its result also cross-checks the
                 GPU result bit-for-bit at full size
+  ntt_kernels   (N=1) the transform half of the metric: iNTT 2^16 x 19 and LDE 2^16 -> 2^19 x 16 (the shapes of one proof), device
+                resident, HIP-event timed: ms, algorithmic GB/s (64 B per element in place, 288 n per LDE column),
+                fraction of the HBM peak, and the VALU-issue fraction from the PMC profile of the same build
   prover        (N=1) BASELINE config 3: ProverProof::create at 2^16 gates on Vesta -- a complete, verified proof by the
-                device-resident pipeline (proof_systems_amd/prover.py) -> constraints/s; plus the reference's own call
-                pattern against the library (15 threads on host buffers: `dropin`)
+                device-resident pipeline (proof_systems_amd/prover.py) -> constraints/s; `seconds_all_gates` with every
+                always-present gate type evaluated over d8 as the reference does; `cpu_baseline` = config 3's operation list
+                on the host cores with the C port; the reference's own call pattern against the library (`dropin`: 15 threads
+                on host buffers, 15 interpolations, 16 extensions); `pair` = BASELINE config 5 (Pallas + Vesta, 2^16 each)
 """
 import argparse
 import json
@@ -39,15 +44,105 @@ sys.path.insert(0, ROOT)
 LOG_N = 20
 ALG_BYTES_PER_PAIR = 96          # 64 B affine point + 32 B scalar, each read once
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec
-PMC_FILE = "r02_msm20_pmc.json"                 # tools/profile_msm.py (rocprofv3 PMC passes), keyed by the hash of csrc/
-MIX_FILE = "r02_k_accumulate29_valu_mix.json"   # tools/valu_mix.py (static opcode histogram of the loop body)
-RATES_FILE = "r02_valu_rates.json"              # per-opcode issue cycles measured by tools/microbench.hip
+PMC_FILE = "r03_msm20_pmc.json"                 # tools/profile_msm.py (rocprofv3 PMC passes), keyed by the hash of csrc/
+MIX_FILE = "r03_k_accumulate29_valu_mix.json"   # tools/valu_mix.py (static opcode histogram of the loop body)
+RATES_FILE = "r03_valu_rates.json"              # per-opcode issue cycles measured by tools/microbench.hip
+NTT_PMC_FILE = "r03_ntt_pmc.json"               # tools/profile_msm.py --workload ntt (tools/bench_ntt.py --bench-shapes)
+NTT_MIX_FILE = "r03_k_ntt_pass_valu_mix.json"   # tools/valu_mix.py --kernel ntt
 
 
 def rand_scalars(rng, n):
     s = rng.integers(0, 1 << 64, size=(n, 4), dtype=np.uint64)
     s[:, 3] &= np.uint64((1 << 62) - 1)          # < 2^254 < p: valid Montgomery limbs
     return s
+
+
+def ntt_block(khip):
+    """The transform shapes of one 2^16 proof, device resident (kh_ntt_dev / kh_lde_dev), timed with the library's own HIP events
+    on its stream (khip.last_timings).  Algorithmic bytes: SURVEY 8d."""
+    rng = np.random.default_rng(7)
+
+    def timed(fn, reps=10):
+        fn(); khip.sync()
+        ts = []
+        for _ in range(reps):
+            fn(); khip.sync()
+            ts.append(sum(ms for _, ms in khip.last_timings()))
+        return float(np.median(ts))
+    n = 1 << 16
+    out = {}
+    buf = khip.DevBuf(19 * n * 32).upload(rand_scalars(rng, 19 * n))
+    ms = timed(lambda: khip.ntt_dev(khip.FP, buf, 16, True, 19))
+    gb = 64.0 * n * 19 / (ms * 1e-3) / 1e9
+    out["intt_2^16_x19"] = {"ms": ms, "algorithmic_GBps": gb, "hbm_frac": gb / HBM_PEAK_GBS, "algorithmic_bytes": 64 * n * 19}
+    buf.free()
+    src = khip.DevBuf(16 * n * 32).upload(rand_scalars(rng, 16 * n)); dst = khip.DevBuf(16 * 8 * n * 32)
+    ms = timed(lambda: khip.lde_dev(khip.FP, src, 16, 3, dst, 16))
+    gb = 288.0 * n * 16 / (ms * 1e-3) / 1e9
+    out["lde_2^16_to_2^19_x16"] = {"ms": ms, "algorithmic_GBps": gb, "hbm_frac": gb / HBM_PEAK_GBS, "algorithmic_bytes": 288 * n * 16}
+    src.free(); dst.free()
+    out["bound"] = "integer ALU (VALU issue): 0.41 log2 N + 1 Montgomery products per element; DESIGN.md section 4"
+    here = source_hash()
+    pmc = load_profile(NTT_PMC_FILE); mix = load_profile(NTT_MIX_FILE); rates = load_profile(RATES_FILE)
+    key = next((k for k in (pmc or {}).get("kernels", {}) if k.startswith("k_ntt_pass<FpParams")), None)
+    if not pmc or pmc.get("source_sha256") != here or key is None:
+        out["valu_issue_note"] = "profiles/%s was not collected on this build: counter-derived fields withheld" % NTT_PMC_FILE
+        return out
+    k = pmc["kernels"][key]
+    per_instr = None
+    if mix and rates and mix.get("source_sha256") == here:
+        hist = mix["valu_histogram"]; tot = float(sum(hist.values()))
+        per_instr = sum(c * rates["cycles"].get(o.replace("_e32", "").replace("_e64", ""), rates["default_cycles"]) for o, c in hist.items()) / tot
+    if per_instr and k.get("sustained_clock_ghz"):
+        issue_ms = k["SQ_INSTS_VALU"] * per_instr / 1024.0 / (k["sustained_clock_ghz"] * 1e9) * 1e3
+        out["valu_issue"] = {"kernel": key, "instructions_per_launch": k["SQ_INSTS_VALU"], "issue_cycles_per_instruction": per_instr, "avg_launch_ms": k["avg_ns"] * 1e-6,
+                             "sustained_clock_ghz": k["sustained_clock_ghz"], "frac_at_sustained_clock": issue_ms / (k["avg_ns"] * 1e-6),
+                             "traffic_bytes_per_launch": k.get("fetch_raw_bytes", 0.0) + k.get("write_bytes", 0.0), "source": "profiles/" + NTT_PMC_FILE,
+                             "workload": pmc.get("command")}
+    return out
+
+
+def prover_cpu_baseline(khip, ix, wit_padded, log_n=16):
+    """BASELINE config 3's operation list (15 Lagrange-basis MSMs of the benchmark witness + 1 + 7 monomial MSMs + the 32
+    round MSMs of the opening, 19 iNTT(2^16) + 16 LDE(-> 2^19) + iNTT(2^18) + iNTT(2^19)) on THIS box's host cores with the C port
+    (oracle/pasta_ref.c: signed-window Pippenger and radix-2 NTT over std threads) -- `kind: "port"`: the Rust reference cannot be
+    built here.  It is the data-parallel part of ProverProof::create only (no gate evaluation, no transcript), i.e. a LOWER bound on
+    what a CPU prover of this family needs on this host.  Never the target; checker-side code, outside every timed region."""
+    from oracle import cref
+    n = 1 << log_n
+    cores = os.cpu_count() or 1
+    thr = min(cores, 64)
+    rng = np.random.default_rng(5)
+    g = ix.srs.get_g()
+    lag, linf = ix.srs.get_lagrange(log_n)
+    uni = rand_scalars(rng, n)
+    t0 = time.perf_counter()
+    for i in range(15):                                                       # witness commitments (mostly ones: the bench circuit)
+        cref.msm(0, lag, wit_padded[i], inf=linf, threads=thr)
+    for _ in range(8):                                                        # z + the seven chunks of t (uniform coefficients)
+        cref.msm(0, g, uni, threads=thr)
+    m = n // 2
+    while m >= 1:                                                             # the opening: L and R over half of the current basis
+        for _ in range(2):
+            cref.msm(0, g[:m], uni[:m], threads=thr)
+        m //= 2
+    t_msm = time.perf_counter() - t0
+    cols = rand_scalars(rng, 19 * n).reshape(19, n, 4)
+    t0 = time.perf_counter()
+    cref.ntt(0, cols.copy(), log_n, True, threads=thr)
+    cref.lde(0, cols[:16].copy(), log_n, 3, threads=thr)
+    cref.ntt(0, rand_scalars(rng, 4 * n).reshape(1, 4 * n, 4), log_n + 2, True, threads=thr)
+    cref.ntt(0, rand_scalars(rng, 8 * n).reshape(1, 8 * n, 4), log_n + 3, True, threads=thr)
+    t_ntt = time.perf_counter() - t0
+    model = ""
+    try:
+        model = next(l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name"))
+    except (OSError, StopIteration):
+        pass
+    return {"seconds": t_msm + t_ntt, "msm_seconds": t_msm, "ntt_seconds": t_ntt, "constraints_per_s": n / (t_msm + t_ntt), "cores": thr, "host_cores": cores,
+            "cpu_model": model, "kind": "port",
+            "sample": "the whole operation list of one 2^16 proof once: 23 commitment MSMs + 32 opening-round MSMs, 19 iNTT(2^16), 16 LDE(2^16 -> 2^19), iNTT(2^18), iNTT(2^19)",
+            "note": "data-parallel part only (no constraint evaluation, no sponge): a lower bound for a CPU prover of this algorithmic family on this host; not the reference binary"}
 
 
 def prover_block(khip, srs20, check_with_oracle=True, log_n=16, reps=5):
@@ -88,9 +183,20 @@ def prover_block(khip, srs20, check_with_oracle=True, log_n=16, reps=5):
         if best_res is None or t["total"] < best_res["total"]:
             best_res = t
     d_w.free()
+    prover.create_proof(ix, wit, rng, all_gates=True)
+    best_all = None
+    for _ in range(3):
+        t = {}
+        khip.sync()
+        prover.create_proof(ix, wit, rng, timings=t, all_gates=True)
+        if best_all is None or t["total"] < best_all["total"]:
+            best_all = t
     out = {"workload": "ProverProof::create, benchmark circuit (2^%d - 10 generic gates), Vesta, SRS 2^%d, one chunk" % (log_n, log_n),
            "seconds": best["total"], "constraints_per_s": n / best["total"], "phases_s": {k: v for k, v in best.items() if k != "total"},
            "seconds_resident": best_res["total"], "constraints_per_s_resident": n / best_res["total"],
+           "seconds_all_gates": best_all["total"], "constraints_per_s_all_gates": n / best_all["total"],
+           "all_gates_note": "Poseidon, CompleteAdd, VarBaseMul, EndoMul, EndoMulScalar constraints evaluated over d8 although their selectors are zero for this circuit, "
+                             "and all 15 witness columns extended -- the work the reference does on every proof (prover.rs:824-868); same proof",
            "index_time_s": t_index,
            "reference_readme_seconds": 6.3, "reference_note": "o1-labs README figure for 2^16 gates, hardware unspecified; not measured here (no Rust toolchain)",
            "note": "complete proof: 15 + 1 + 7 commitments, 16 + 2 iNTT, 16 LDE, generic + permutation rows, division by Z_H (zero remainder asserted), 43 x 2 evaluations, ft, "
@@ -126,15 +232,27 @@ def prover_block(khip, srs20, check_with_oracle=True, log_n=16, reps=5):
             khip.ntt(khip.FP, cols[i], log_n, inverse=True)
         dt = time.perf_counter() - t0
         best_n = dt if best_n is None else min(best_n, dt)
+    coeffs16 = np.ascontiguousarray(padded[:, :, :].copy()); coeffs16 = np.concatenate([coeffs16, coeffs16[:1]])     # 16 columns of n coefficients (15 w + z)
+    best_l = None
+    for _ in range(3):
+        t0 = time.perf_counter()
+        for i in range(16):
+            khip.lde(khip.FP, coeffs16[i:i + 1], log_n, 3)                   # evaluate_over_domain_by_ref(d8) of one column: n up, 8n down
+        dt = time.perf_counter() - t0
+        best_l = dt if best_l is None else min(best_l, dt)
     t0 = time.perf_counter()
     batch = srs16.msm_batch(padded, basis=log_n)
     t_batch = time.perf_counter() - t0
     same = all(np.array_equal(res[i][0][0], batch[0][i]) for i in range(15))
     out["dropin"] = {"commit_15_threads_host_buffers_s": best_c, "commit_one_batched_call_host_buffers_s": t_batch, "threads_match_batch": bool(same),
                      "interpolate_15_columns_one_call_each_host_buffers_s": best_n,
-                     "note": "what a Rust prover gets by only swapping in GpuSrs / the ark-poly patch; PCIe-bound (pageable host memory)"}
+                     "extend_16_columns_2^16_to_2^19_one_call_each_host_buffers_s": best_l,
+                     "swap_crates_only_total_s": best_c + best_n + best_l,
+                     "note": "what a Rust prover gets by only swapping in GpuSrs / the ark-poly patch (rust/ark-poly-patch: interpolate -> kh_ntt, evaluate_over_domain_by_ref -> kh_lde, "
+                             "the zero padding never crosses PCIe); witness commitments + interpolations + 8x extensions of one proof; PCIe-bound (pageable host memory)"}
     if check_with_oracle:
         out["proof_accepted_by_oracle_verifier"] = bool(oracle_verifies(khip, ix, proof))
+        out["cpu_baseline"] = prover_cpu_baseline(khip, ix, padded, log_n)
     # several provers in flight (one host thread and one SRS handle each): a single proof is mostly latency chains, independent proofs overlap
     T, per = 4, 5
     ixs = [ix] + [prover.bench_circuit_index(khip.VESTA, log_n) for _ in range(T - 1)]
@@ -159,6 +277,63 @@ def prover_block(khip, srs20, check_with_oracle=True, log_n=16, reps=5):
     for j in ixs:
         j.free()
     return out
+
+
+def pair_block(khip, log_n=16, per=4, check_with_oracle=True):
+    """BASELINE config 5: the Pallas + Vesta recursion pair, 2^16 gates each, both SRS (with their window tables and Lagrange bases)
+    and all four kernel instantiations (MSM over Fq / Fp coordinates, NTT over Fp / Fq) resident in one process.  One host thread
+    per curve; the handles live on devices 0 and 1 when two GPUs are visible, else both on device 0.  No inter-GPU traffic (SURVEY 8e:
+    replicas only).  Reports each curve's proof latency alone and the pair's throughput with both in flight."""
+    from proof_systems_amd import prover
+    ndev = max(1, khip.device_count())
+    devs = [0, 1 % ndev]
+    n = 1 << log_n
+    state = [None, None]
+    res = {}
+    bar = threading.Barrier(3)
+
+    def run(k):
+        cid = (khip.VESTA, khip.PALLAS)[k]
+        khip.set_device(devs[k])                                         # HIP's current device is per-thread state
+        ix = prover.bench_circuit_index(cid, log_n)
+        F = prover.Fld(ix.fid)
+        wit = np.tile(F.limbs(1), (15, n - 10, 1))
+        rng = np.random.default_rng(90 + k)
+        proof = prover.create_proof(ix, wit, rng)
+        state[k] = (ix, proof)
+        bar.wait()                                                       # 1: both warm
+        if k == 0:                                                       # latencies alone, one curve after the other
+            pass
+        for phase in (0, 1):
+            bar.wait()
+            if phase == k:
+                best = None
+                for _ in range(3):
+                    t = {}
+                    prover.create_proof(ix, wit, rng, timings=t, check=False)
+                    best = t["total"] if best is None else min(best, t["total"])
+                res["seconds_alone_" + ("vesta", "pallas")[k]] = best
+            bar.wait()
+        bar.wait()                                                       # both in flight
+        for _ in range(per):
+            prover.create_proof(ix, wit, rng, check=False)
+        bar.wait()
+    th = [threading.Thread(target=run, args=(k,)) for k in range(2)]
+    for t_ in th:
+        t_.start()
+    bar.wait()
+    for _ in (0, 1):
+        bar.wait(); bar.wait()
+    bar.wait(); t0 = time.perf_counter(); bar.wait(); dt = time.perf_counter() - t0
+    for t_ in th:
+        t_.join()
+    res.update({"workload": "Pallas + Vesta pair, benchmark circuit 2^%d gates each, both curves resident in one process" % log_n, "devices": devs,
+                "devices_visible": ndev, "pairs_per_s": per / dt, "constraints_per_s": 2 * per * n / dt, "seconds_per_pair_both_in_flight": dt / per})
+    if check_with_oracle:
+        res["pallas_proof_accepted_by_oracle_verifier"] = bool(oracle_verifies(khip, *state[1]))
+    for ix, _ in state:
+        ix.free()
+    return res
 
 
 def oracle_verifies(khip, ix, proof):
@@ -237,6 +412,8 @@ def main():
     ap.add_argument("--no-pipeline", action="store_true", help="time synchronous MSMs (one in flight); used for the rocprofv3 kernel-stats profile so kernels do not overlap")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-oplist", "--no-prover", dest="no_oplist", action="store_true", help="skip the ProverProof::create block")
+    ap.add_argument("--no-pair", action="store_true", help="skip BASELINE config 5 (Pallas + Vesta pair) inside the prover block")
+    ap.add_argument("--pair", action="store_true", help="BASELINE config 5 only: the Pallas + Vesta pair at 2^16 gates, then exit")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -272,6 +449,10 @@ def main():
 
     import proof_systems_amd.khip as khip
     from proof_systems_amd import sharded
+    if args.pair:
+        khip.init(0)
+        print(json.dumps({"metric": "Pallas + Vesta pair, ProverProof::create at 2^16 gates each", "unit": "constraints/s", **pair_block(khip, check_with_oracle=not args.no_cpu_baseline)}))
+        return
     dev = local_rank % max(1, khip.device_count())
     cores = os.cpu_count() or 1
 
@@ -382,7 +563,10 @@ def main():
             line["parity_error"] = "GPU result differs from the CPU oracle"
 
     if rank == 0 and world == 1 and not args.no_oplist and args.curve == "vesta" and not args.strong:
+        line["ntt_kernels"] = ntt_block(khip)
         line["prover"] = prover_block(khip, srs, check_with_oracle=not args.no_cpu_baseline)
+        if not args.no_pair:
+            line["prover"]["pair"] = pair_block(khip, check_with_oracle=not args.no_cpu_baseline)
 
     if rank == 0:
         print(json.dumps(line))

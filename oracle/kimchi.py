@@ -324,6 +324,12 @@ def prev_challenge_evals(F: P.Field, chals, max_poly_size: int, points, powers):
     return out
 
 
+def default_public_comm(vix):
+    """verifier.rs:844-846: an empty public input commits to the blinding commitment, once per chunk."""
+    n, size = vix["n"], vix.get("max_poly_size", vix["n"])
+    return [vix["h"]] * (1 if n < size else n // size)
+
+
 def fiat_shamir(curve: P.Curve, vix, proof, digest: int):
     """verifier.rs:160-420: returns the challenges and the Fq-sponge as SRS::verify needs it."""
     F = curve.scalar
@@ -333,7 +339,7 @@ def fiat_shamir(curve: P.Curve, vix, proof, digest: int):
     prev = proof.get("prev_challenges") or []
     for _chals, comm in prev:
         absorb_commitment(fq, comm)
-    absorb_commitment(fq, vix.get("public_comm") or [vix["h"]])         # public_comm; for an empty public input: the blinding commitment
+    absorb_commitment(fq, vix.get("public_comm") or default_public_comm(vix))
     for c in proof["w_comm"]:
         absorb_commitment(fq, c)
     li = vix.get("lookup_index")
@@ -432,7 +438,7 @@ def verify(curve: P.Curve, vix, proof, g, h, rng, final_msm=None) -> bool:
     evaluations = []
     for chals, comm in (proof.get("prev_challenges") or []):
         evaluations.append((list(comm), prev_challenge_evals(F, chals, srs_len, [zeta, zetaw], [zeta_srs, zetaw_srs])))
-    evaluations += [(vix.get("public_comm") or [h], [evc["public"][0], evc["public"][1]]), ([ft_comm], [[ft0], [proof["ft_eval1"]]])]
+    evaluations += [(vix.get("public_comm") or default_public_comm(vix), [evc["public"][0], evc["public"][1]]), ([ft_comm], [[ft0], [proof["ft_eval1"]]])]
     comms = [proof["z_comm"], vix["generic_comm"], vix["psm_comm"], vix["complete_add_comm"], vix["mul_comm"], vix["emul_comm"], vix["endomul_scalar_comm"]]
     comms += list(proof["w_comm"]) + list(vix["coefficients_comm"]) + list(vix["sigma_comm"][:PERMUTS - 1])
     comms += [c for c in (vix.get("optional_comms") or []) if c is not None]

@@ -152,3 +152,64 @@ def test_degenerate_bases_stress(khip, cid, logn):
                     w, winf = cref.msm(cid, g, scs[j * n:(j + 1) * n], scalars_mont=False, threads=8)
                     assert bool(ginf[j]) == bool(winf) and (winf or np.array_equal(got[j], w)), (variant, bits, k, j)
         srs.close()
+
+
+# ---------------------------------------------------------------------------------------------- configs 3 / 5 and chunked proofs at size
+def _accepted(khip, ix, proof, seed=9):
+    from oracle import kimchi as K
+    from oracle import views as V
+    c, vix, pr = V.device_views(ix, proof)
+    return K.verify(c, vix, pr, None, vix["h"], P.StdRng(bytes([seed] * 32)), final_msm=V.final_msm_c(c, ix.srs.get_g(), ix.size, threads=THREADS))
+
+
+def test_config5_pallas_and_vesta_proofs_at_2_16_from_one_process(khip):
+    """BASELINE config 5: the recursion pair -- a Vesta proof and a Pallas proof at 2^16 gates, both SRS (window tables, Lagrange
+    bases) and all four kernel instantiations resident in ONE process, proved concurrently from two host threads; on devices 0 / 1
+    when two GPUs are visible, else both on device 0.  Each proof is accepted by the oracle's restatement of the reference verifier
+    (which runs the Fq-side multi-pass NTT kernels at 2^16 / 2^18 / 2^19 inside a Pallas proof for the first time in pytest)."""
+    import threading
+    from proof_systems_amd import prover
+    ndev = max(1, khip.device_count())
+    out, err = [None, None], []
+
+    def run(k):
+        try:
+            khip.set_device(k % ndev)
+            cid = (khip.VESTA, khip.PALLAS)[k]
+            ix = prover.bench_circuit_index(cid, 16)
+            F = prover.Fld(ix.fid)
+            wit = np.tile(F.limbs(1), (15, (1 << 16) - 10, 1))
+            proofs = [prover.create_proof(ix, wit, np.random.default_rng(40 + k + 2 * j)) for j in range(2)]
+            out[k] = (ix, proofs)
+        except Exception as e:                                  # noqa: BLE001 -- reported below
+            err.append((k, repr(e)))
+    th = [threading.Thread(target=run, args=(k,)) for k in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not err, err
+    khip.set_device(0)
+    for k in range(2):
+        ix, proofs = out[k]
+        assert ix.curve == (khip.VESTA, khip.PALLAS)[k] and ix.n == 1 << 16
+        assert _accepted(khip, ix, proofs[1]), ("vesta", "pallas")[k]
+        ix.free()
+
+
+def test_chunked_proof_2_17_rows_over_the_2_16_srs(khip):
+    """kimchi/src/tests/chunked.rs:91: a 2^17-row circuit proved over the 2^16 SRS -- num_chunks = 2, zk_rows = 5, every polynomial
+    committed and evaluated in two chunks, 14 chunks of t, ft linearised with zeta^(2^16) (prover.rs:208-212, 989-1004, 1147-1188);
+    accepted by the oracle's verifier (chunk-aware: verifier.rs:795-880)."""
+    from proof_systems_amd import prover
+    srs = khip.Srs.create(khip.VESTA, 1 << 16)
+    ix = prover.bench_circuit_index(khip.VESTA, 17, srs=srs)
+    assert (ix.num_chunks, ix.zk_rows, ix.size) == (2, 5, 1 << 16)
+    F = prover.Fld(ix.fid)
+    wit = np.tile(F.limbs(1), (15, (1 << 17) - 10, 1))
+    proof = prover.create_proof(ix, wit, np.random.default_rng(17))
+    assert len(proof["t_comm"][1]) == 14 and all(len(c[1]) == 2 for c in proof["w_comm"]) and len(proof["evals"]["z"][0]) == 2
+    assert _accepted(khip, ix, proof)
+    bad = dict(proof, evals=dict(proof["evals"], z=([proof["evals"]["z"][0][0], (proof["evals"]["z"][0][1] + 1) % F.p], proof["evals"]["z"][1])))
+    assert not _accepted(khip, ix, bad)                          # the SECOND chunk's evaluation matters
+    ix.free()

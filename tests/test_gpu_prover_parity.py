@@ -98,7 +98,7 @@ def test_device_prover_reproduces_the_reference_whole_proof_bytes(khip):
     assert len(got) == 6160
 
 
-@pytest.mark.parametrize("cid,logn,log_srs", [(0, 7, 7), (1, 7, 7), (0, 10, 10), (0, 8, 10), (0, 9, 7), (1, 8, 7)])
+@pytest.mark.parametrize("cid,logn,log_srs", [(0, 7, 7), (1, 7, 7), (0, 10, 10), (0, 8, 10), (0, 9, 7), (1, 8, 7), (0, 12, 11)])
 def test_device_proof_equals_the_oracle_provers_proof(khip, cid, logn, log_srs):
     """generic-gate circuits with copy constraints and public inputs; log_srs > logn: SRS longer than the domain; log_srs < logn:
     chunked (2^(logn - log_srs) chunks, more zero-knowledge rows)."""

@@ -24,7 +24,8 @@ def timed(fn, reps=10):
 
 
 print(f"{'op':28s} {'ms':>9s} {'alg GB/s':>10s} {'%HBM':>7s} {'Gmul/s':>8s}")
-for logn, batch in [(12, 64), (16, 1), (16, 19), (18, 1), (19, 1), (20, 1), (22, 1)]:
+BENCH_SHAPES = "--bench-shapes" in sys.argv       # only the two shapes bench.py's ntt_kernels block quotes (the PMC profile of that block)
+for logn, batch in ([(16, 19)] if BENCH_SHAPES else [(12, 64), (16, 1), (16, 19), (18, 1), (19, 1), (20, 1), (22, 1)]):
     n = 1 << logn
     buf = khip.DevBuf(batch * n * 32).upload(rs(batch * n))
     for inv in (True,):
@@ -33,7 +34,7 @@ for logn, batch in [(12, 64), (16, 1), (16, 19), (18, 1), (19, 1), (20, 1), (22,
         muls = (0.5 * logn + 1.0) * n * batch / (ms * 1e-3) / 1e9
         print(f"{'intt 2^%d x%d' % (logn, batch):28s} {ms:9.4f} {gbs:10.1f} {100 * gbs / 8000:7.2f} {muls:8.1f}")
     buf.free()
-for logn, logb, batch in [(16, 3, 16), (16, 3, 1), (12, 3, 16)]:
+for logn, logb, batch in ([(16, 3, 16)] if BENCH_SHAPES else [(16, 3, 16), (16, 3, 1), (12, 3, 16)]):
     n = 1 << logn
     src = khip.DevBuf(batch * n * 32).upload(rs(batch * n))
     dst = khip.DevBuf(batch * (n << logb) * 32)

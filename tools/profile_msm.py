@@ -78,7 +78,7 @@ def main():
     if workload == "msm":
         cmd = [sys.executable, "bench.py", "--no-pipeline", "--no-cpu-baseline", "--no-oplist", "--steps", "10", "--warmup", "2"]
     else:
-        cmd = [sys.executable, "tools/bench_ntt.py"]
+        cmd = [sys.executable, "tools/bench_ntt.py", "--bench-shapes"]      # iNTT 2^16 x 19 + LDE 2^16 -> 2^19 x 16: what bench.py's ntt_kernels quotes
     res = {"source_sha256": source_hash(), "command": " ".join(cmd[1:]), "kernels": {}}
     db = run_pass("trace", ["--kernel-trace"], cmd, outdir)
     if db:

@@ -23,15 +23,27 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 from profile_msm import source_hash  # noqa: E402
 
 KERNEL = "_ZN2kh14k_accumulate29INS_8FqParamsE"
+NTT_KERNEL = "_ZN2kh10k_ntt_passINS_8FpParamsELi256E"       # tools/valu_mix.py OUT --kernel ntt: the whole kernel (straight-line radix-4 steps)
 
 
 def main():
     out = sys.argv[1]
+    ntt = "--kernel" in sys.argv and sys.argv[sys.argv.index("--kernel") + 1] == "ntt"
     with tempfile.TemporaryDirectory() as td:
-        asm = os.path.join(td, "msm.s")
+        asm = os.path.join(td, "k.s")
         subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-o", asm,
-                               os.path.join(ROOT, "proof_systems_amd", "csrc", "msm.hip")], stderr=subprocess.DEVNULL)
+                               os.path.join(ROOT, "proof_systems_amd", "csrc", "ntt.hip" if ntt else "msm.hip")], stderr=subprocess.DEVNULL)
         lines = open(asm).read().split("\n")
+    if ntt:
+        start = next(i for i, l in enumerate(lines) if l.startswith(NTT_KERNEL) and l.split(";")[0].strip().endswith(":"))
+        end = next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end"))
+        ops = [l.split(";")[0].strip().split()[0] for l in lines[start + 1:end] if l.split(";")[0].strip() and not l.split(";")[0].strip().startswith(".") and not l.split(";")[0].strip().endswith(":")]
+        hist = Counter(op for op in ops if op.startswith("v_"))
+        res = {"source_sha256": source_hash(), "kernel": "k_ntt_pass<FpParams, 256>", "block": "whole kernel (static)", "block_instructions": len(ops),
+               "block_valu_instructions": sum(hist.values()), "valu_histogram": dict(sorted(hist.items(), key=lambda kv: -kv[1]))}
+        json.dump(res, open(out, "w"), indent=1)
+        print(json.dumps(res, indent=1)[:600])
+        return
     start = next(i for i, l in enumerate(lines) if l.startswith(KERNEL) and l.split(";")[0].strip().endswith(":"))
     end = next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end"))
     blocks, cur = {"entry": []}, "entry"
