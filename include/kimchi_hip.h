@@ -140,6 +140,20 @@ int kh_msm_points_batch(int curve, const uint64_t *xy, const uint8_t *inf, const
  * sums of a point-range-sharded MSM after the all-gather, or `(r1 + r2).into_affine()` of ipa.rs:661. */
 int kh_points_sum(int curve, const uint64_t *xy, const uint8_t *inf, size_t n, uint64_t out_xy[8], uint8_t *out_is_inf);
 
+/* One MSM over a basis sharded by POINT RANGE over R handles (BASELINE config 4): shard r holds g[o_r, o_r + n_r), o_r =
+ * n_0 + ... + n_(r-1), n_r = kh_srs_size(shards[r]), on whatever device it was created on (kh_srs_create_device_range after
+ * kh_set_device: one shard per GPU, or several per GPU).  Each shard reduces its slice of the scalars with the full single-GPU
+ * pipeline on its own device, concurrently; the R partial sums are folded on the host (kh_points_sum: RCCL has no group-addition
+ * reduction, and R x 64 bytes do not need one).  `scalars`: host, N x 4 limbs, N = sum n_r (fewer: the tail shards get the rest / nothing).
+ * This is the whole of config 4 for a one-process caller (the Rust shim); one-process-per-GPU deployments all-gather the partials
+ * instead (proof_systems_amd/sharded.py over torch.distributed / RCCL). */
+int kh_msm_sharded(kh_srs_t *const *shards, size_t R, const uint64_t *scalars, size_t n, int scalars_are_montgomery,
+                   uint64_t out_xy[8], uint8_t *out_is_inf);
+/* The same with the scalars already resident: scalars_dev[r] = shard r's slice (counts[r] <= n_r elements) on shard r's device.
+ * All R jobs are submitted before the first is waited for. */
+int kh_msm_sharded_dev(kh_srs_t *const *shards, size_t R, const uint64_t *const *scalars_dev, const size_t *counts,
+                       int scalars_are_montgomery, uint64_t out_xy[8], uint8_t *out_is_inf);
+
 /* ---- IPA round vector operations (poly-commitment/src/ipa.rs:980-1006) -----
  * out[i] = lo[i] + u * hi[i]      (a' = a_lo + u^-1 a_hi with u := u^-1; b' = b_lo + u b_hi)          */
 int kh_ipa_fold_scalars(int field, const uint64_t *lo, const uint64_t *hi, const uint64_t u[4], size_t n, uint64_t *out);
@@ -360,7 +374,8 @@ int kh_msm_batch_dev(kh_srs_t *srs, int basis, unsigned chunk, size_t offset,
  * finishes it (XYZZ -> affine on the host).  With jobs in flight the sort of one MSM and the
  * latency-bound tail (bucket reduction) of another run underneath the bucket accumulation of a third.
  * At most KH_MSM_SLOTS (4) un-waited tickets: a further submit by the thread that holds them all returns KH_E_INVALID at once; when
- * some of them are OTHER threads' (more provers than slots) it waits -- two seconds at most -- for one of those to be waited for. */
+ * some of them are OTHER threads' (more provers than slots) it BLOCKS until one of those is waited for (back-pressure, no time-out);
+ * only when every busy slot's owner is itself blocked in a submit -- nobody left to call kh_msm_wait -- it returns KH_E_INVALID. */
 #define KH_MSM_SLOTS 4
 int kh_msm_submit(kh_srs_t *srs, int basis, unsigned chunk, size_t offset,
                   const uint64_t *scalars_dev, size_t n, size_t k, int scalars_are_montgomery,

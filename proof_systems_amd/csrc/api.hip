@@ -624,6 +624,64 @@ int kh_msm_wait(uint64_t ticket, uint64_t* out_xy, uint8_t* out_is_inf) {
     return KH_E_INVALID;
 }
 
+// ---- point-range sharding over several handles / devices (BASELINE config 4 inside the library)
+int kh_msm_sharded_dev(kh_srs_t* const* shards, size_t R, const uint64_t* const* scalars_dev, const size_t* counts, int scalars_are_montgomery,
+                       uint64_t out_xy[8], uint8_t* out_is_inf) {
+    KH_REQUIRE(shards && scalars_dev && counts && out_xy && out_is_inf && R > 0, "kh_msm_sharded_dev: null argument");
+    KH_REQUIRE(R <= 64, "at most 64 shards (got %zu)", R);
+    for (size_t r = 0; r < R; r++) {
+        KH_REQUIRE(shards[r], "shard %zu is null", r);
+        KH_REQUIRE(shards[r]->curve == shards[0]->curve, "shard %zu is on another curve", r);
+        KH_REQUIRE(counts[r] <= shards[r]->n, "shard %zu: %zu scalars for %zu points", r, counts[r], shards[r]->n);
+    }
+    std::vector<uint64_t> tickets(R, 0), part(8 * R, 0);
+    std::vector<uint8_t> pinf(R, 1);
+    std::vector<size_t> pending;                                // submitted, not yet waited for (oldest first)
+    int rc = KH_OK;
+    auto wait_oldest = [&]() {
+        const size_t r = pending.front(); pending.erase(pending.begin());
+        int w = kh_msm_wait(tickets[r], &part[8 * r], &pinf[r]);
+        if (rc == KH_OK) rc = w;
+    };
+    for (size_t r = 0; r < R && rc == KH_OK; r++) {            // as much as the pipeline slots allow is in flight before the first wait
+        if (counts[r] == 0) continue;
+        for (;;) {
+            int s_ = kh_msm_submit(shards[r], KH_BASIS_G, 0, 0, scalars_dev[r], counts[r], 1, scalars_are_montgomery, &tickets[r]);
+            if (s_ == KH_OK) { pending.push_back(r); break; }
+            if (s_ == KH_E_INVALID && !pending.empty()) { wait_oldest(); if (rc) break; continue; }   // several shards on one device: its four slots are ours
+            rc = s_; break;
+        }
+    }
+    while (!pending.empty()) wait_oldest();                     // (also after an error: no ticket may be left un-waited)
+    if (rc) return rc;
+    return kh_points_sum(shards[0]->curve, part.data(), pinf.data(), R, out_xy, out_is_inf);
+}
+int kh_msm_sharded(kh_srs_t* const* shards, size_t R, const uint64_t* scalars, size_t n, int scalars_are_montgomery, uint64_t out_xy[8], uint8_t* out_is_inf) {
+    KH_REQUIRE(shards && out_xy && out_is_inf && R > 0 && (scalars || n == 0), "kh_msm_sharded: null argument");
+    KH_REQUIRE(R <= 64, "at most 64 shards (got %zu)", R);
+    size_t total = 0;
+    for (size_t r = 0; r < R; r++) { KH_REQUIRE(shards[r], "shard %zu is null", r); total += shards[r]->n; }
+    KH_REQUIRE(n <= total, "%zu scalars for %zu points", n, total);
+    // the slices go up from R host threads at once, each bound to its shard's device (kh_msm: upload + MSM + affine result)
+    std::vector<uint64_t> part(8 * R, 0);
+    std::vector<uint8_t> pinf(R, 1);
+    std::vector<int> rcs(R, KH_OK);
+    std::vector<std::string> errs(R);
+    std::vector<std::thread> th;
+    size_t off = 0;
+    for (size_t r = 0; r < R; r++) {
+        const size_t cnt = off >= n ? 0 : std::min(shards[r]->n, n - off);
+        if (cnt) th.emplace_back([&, r, off, cnt] {
+            rcs[r] = kh_msm(shards[r], KH_BASIS_G, 0, 0, scalars + 4 * off, cnt, scalars_are_montgomery, &part[8 * r], &pinf[r]);
+            if (rcs[r]) errs[r] = kh_last_error();               // (the message is thread-local)
+        });
+        off += shards[r]->n;
+    }
+    for (auto& t : th) t.join();
+    for (size_t r = 0; r < R; r++) if (rcs[r]) { set_error("shard %zu: %s", r, errs[r].c_str()); return rcs[r]; }
+    return kh_points_sum(shards[0]->curve, part.data(), pinf.data(), R, out_xy, out_is_inf);
+}
+
 int kh_msm(kh_srs_t* srs, int basis, unsigned chunk, size_t offset, const uint64_t* scalars, size_t n,
            int scalars_are_montgomery, uint64_t out_xy[8], uint8_t* out_is_inf) {
     return msm_common(srs, basis, chunk, offset, scalars, false, n, 1, scalars_are_montgomery, out_xy, out_is_inf);

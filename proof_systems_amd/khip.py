@@ -37,6 +37,7 @@ SYMBOLS = [
     "kh_dev_alloc", "kh_dev_free", "kh_dev_upload", "kh_dev_download", "kh_dev_upload_2d",
     "kh_msm_batch_dev", "kh_ntt_dev", "kh_lde_dev", "kh_coset_ntt_dev", "kh_sync", "kh_last_timings",
     "kh_debug_field_op", "kh_debug_point_op", "kh_srs_generate", "kh_srs_h",
+    "kh_msm_sharded", "kh_msm_sharded_dev",
     "kh_commit_non_hiding", "kh_commit_evaluations_non_hiding", "kh_srs_set_blinding_base",
     "kh_srs_get_blinding_base", "kh_mask_custom", "kh_domain_generator", "kh_msm_points_batch", "kh_msm_submit", "kh_msm_wait",
     "kh_ipa_fold_scalars", "kh_inner_product", "kh_ipa_fold_points", "kh_ipa_fold_points_endo", "kh_endos", "kh_scalar_challenge_to_field",
@@ -326,6 +327,26 @@ class Srs:
         inf = np.zeros(k, dtype=np.uint8)
         _check(_lib.kh_msm_batch_dev(self._h, basis, chunk, offset, C.c_void_p(scalars_dev), n, k, int(mont), _p64(out), _p8(inf)))
         return out, inf
+
+
+def msm_sharded(shards, scalars, mont: bool = True):
+    """kh_msm_sharded: ONE MSM over a basis sharded by point range over the Srs handles `shards` (each on its own device): the slices
+    of the host scalars go to their shards' devices concurrently, the partial sums are folded on the host."""
+    sc = _c64(scalars, (-1, 4))
+    hs = (C.c_void_p * len(shards))(*[s._h for s in shards])
+    out = np.zeros(8, dtype=np.uint64); inf = np.zeros(1, dtype=np.uint8)
+    _check(_lib.kh_msm_sharded(hs, len(shards), _p64(sc), sc.shape[0], int(mont), _p64(out), _p8(inf)))
+    return out, bool(inf[0])
+
+
+def msm_sharded_dev(shards, bufs, counts, mont: bool = True):
+    """kh_msm_sharded_dev: bufs[r] = DevBuf on shard r's device holding its counts[r] scalars."""
+    hs = (C.c_void_p * len(shards))(*[s._h for s in shards])
+    ps = (C.c_void_p * len(shards))(*[C.c_void_p(b.ptr) for b in bufs])
+    cs = (C.c_size_t * len(shards))(*counts)
+    out = np.zeros(8, dtype=np.uint64); inf = np.zeros(1, dtype=np.uint8)
+    _check(_lib.kh_msm_sharded_dev(hs, len(shards), ps, cs, int(mont), _p64(out), _p8(inf)))
+    return out, bool(inf[0])
 
 
 def srs_generate(curve: int, start: int, count: int, threads: int = 0):

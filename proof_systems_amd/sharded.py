@@ -9,9 +9,10 @@ collective.  There is no other data-path communication.
 Two deployments share this file:
   * `RankShardedMsm`  -- one process per GPU under torch.distributed (backend "nccl" = RCCL over xGMI; "gloo" lets
                          several ranks share one GPU for tests).  What `bench.py --gpus N` times.
-  * `LocalShardedMsm` -- ONE process, one SRS handle per device (`kh_set_device` + `kh_srs_create_device_range`), one host
-                         thread per shard: what a single Rust prover process does with the per-device contexts of
-                         the library (BASELINE config 4 without torchrun; also config 5: one curve per device).
+  * `LocalShardedMsm` -- ONE process, one SRS handle per device (`kh_set_device` + `kh_srs_create_device_range`): with the
+                         product engine the whole MSM is ONE library call, `kh_msm_sharded` (native thread per shard, fold in
+                         the library) -- what a single Rust prover process calls (`GpuShardedMsm` in rust/kimchi-hip);
+                         BASELINE config 4 without torchrun (config 5 = one curve per device: bench.py --pair).
 
 The compute engine is a parameter so that the CPU-only tests can run the very same sharding / collective / fold code
 with the oracle standing in for the GPU (tests/test_multirank_gloo.py); the product never does that: the default
@@ -130,6 +131,12 @@ class LocalShardedMsm:
 
     def msm(self, scalars, mont: bool = True):
         R = len(self.shards)
+        if all(isinstance(e, KhipEngine) for e in self.engines):
+            # the product: ONE library call (kh_msm_sharded: the slices go to their devices from native threads, the fold is the
+            # library's) -- what the Rust shim's GpuShardedMsm calls; no Python thread or GIL in the path
+            sc = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
+            assert [self.ranges[r][0] for r in range(R)] == [sum(c for _, c in self.ranges[:r]) for r in range(R)]
+            return self.engines[0].khip.msm_sharded(self.shards, sc, mont=mont)
         parts = [None] * R
         errs = []
 

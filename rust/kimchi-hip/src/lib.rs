@@ -166,6 +166,47 @@ where
     }
 }
 
+/// ONE large MSM over several GPUs (BASELINE config 4): the basis is split by point range, shard r lives on device r
+/// (`kh_set_device` + `kh_srs_create`), every shard reduces its slice with the full single-GPU pipeline and the partial
+/// sums are folded on the host.  No collective, no torch: `kh_msm_sharded` does the whole thing.
+pub struct GpuShardedMsm<G: HipCurve> {
+    shards: Vec<DevHandle>,
+    _g: core::marker::PhantomData<G>,
+}
+
+impl<G: HipCurve> GpuShardedMsm<G>
+where
+    G::BaseField: PrimeField,
+{
+    /// `devices[r]` gets `g[r * len / R .. (r + 1) * len / R)`.
+    pub fn new(g: &[G], devices: &[i32]) -> Self {
+        let r_ = devices.len();
+        let mut shards = Vec::with_capacity(r_);
+        let prev = unsafe { sys::kh_get_device() };
+        for (r, dev) in devices.iter().enumerate() {
+            let (lo, hi) = (r * g.len() / r_, (r + 1) * g.len() / r_);
+            ok(unsafe { sys::kh_set_device(*dev) });
+            let (xy, _) = pack(&g[lo..hi]);
+            let mut h = core::ptr::null_mut();
+            ok(unsafe { sys::kh_srs_create(G::CURVE_ID, xy.as_ptr(), hi - lo, &mut h) });
+            shards.push(DevHandle(h));
+        }
+        if prev >= 0 {
+            ok(unsafe { sys::kh_set_device(prev) });
+        }
+        Self { shards, _g: core::marker::PhantomData }
+    }
+
+    /// `VariableBaseMSM::msm(g, scalars)` over all the shards.
+    pub fn msm(&self, scalars: &[G::ScalarField]) -> G {
+        let hs: Vec<*mut sys::kh_srs_t> = self.shards.iter().map(|d| d.0).collect();
+        let mut xy = vec![0u64; 8];
+        let mut inf = vec![0u8; 1];
+        ok(unsafe { sys::kh_msm_sharded(hs.as_ptr(), hs.len(), limbs(scalars), scalars.len(), 1, xy.as_mut_ptr(), inf.as_mut_ptr()) });
+        unpack::<G>(&xy, &inf)[0]
+    }
+}
+
 impl<G: HipCurve> SRS<G> for GpuSrs<G>
 where
     G::BaseField: PrimeField,

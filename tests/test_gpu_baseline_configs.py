@@ -213,3 +213,39 @@ def test_chunked_proof_2_17_rows_over_the_2_16_srs(khip):
     bad = dict(proof, evals=dict(proof["evals"], z=([proof["evals"]["z"][0][0], (proof["evals"]["z"][0][1] + 1) % F.p], proof["evals"]["z"][1])))
     assert not _accepted(khip, ix, bad)                          # the SECOND chunk's evaluation matters
     ix.free()
+
+
+def test_config4_through_kh_msm_sharded(khip, vesta20):
+    """BASELINE config 4 inside the LIBRARY (no torch, no Python threads): kh_msm_sharded over R handles created with
+    kh_srs_create_device_range -- one per visible device round-robin (all on device 0 on a one-GPU box) -- equals ONE oracle MSM
+    over the whole range; the device-resident form (kh_msm_sharded_dev: all jobs submitted before the first wait) gives the same
+    point; fewer scalars than points and an empty tail shard are handled."""
+    _, g = vesta20
+    ndev = max(1, khip.device_count())
+    for R, total in ((3, 3 << 16), (8, 1 << 20)):
+        per = total // R
+        shards = []
+        for r in range(R):
+            khip.set_device(r % ndev)
+            shards.append(khip.Srs.create(khip.VESTA, per, start=r * per))
+        khip.set_device(0)
+        rng = np.random.default_rng(R)
+        sc = _rand_fe(rng, R * per)
+        want, winf = cref.msm(0, g[:R * per], sc, threads=THREADS)
+        out, inf = khip.msm_sharded(shards, sc)
+        assert inf == bool(winf) and np.array_equal(out, want), R
+        bufs = []
+        for r in range(R):
+            khip.set_device(r % ndev)
+            bufs.append(khip.DevBuf(per * 32).upload(sc[r * per:(r + 1) * per]))
+        khip.set_device(0)
+        out, inf = khip.msm_sharded_dev(shards, bufs, [per] * R)
+        assert np.array_equal(out, want), R
+        short = R * per - per - 5                               # the last shard gets nothing, the one before 5 scalars less
+        want2, _ = cref.msm(0, g[:short], sc[:short], threads=THREADS)
+        out, inf = khip.msm_sharded(shards, sc[:short])
+        assert np.array_equal(out, want2)
+        for b in bufs:
+            b.free()
+        for s in shards:
+            s.close()
