@@ -153,6 +153,10 @@ struct kh_srs {
     // doublings + ~128 additions (a proof masks 23 commitments: 3.5 ms of host time otherwise)
     std::vector<khost::xyzz> h_table;
     std::vector<uint64_t> h_multiples;     // 2^(c w) * h for the W windows (affine, 8 words each): slots of the opening's MSMs
+    // second table set for the opening ROUNDS (KH_IPA_C, window width c2 < 16): a round's two MSMs are latency-bound in the bucket
+    // reduction (2^15 buckets for 2^20 entries), so narrower windows -- more accumulation work, 8-16x fewer buckets -- shorten the round
+    DevBuf g2; int g2_c = 0;
+    std::vector<uint64_t> h_multiples2;
     std::mutex h_mu;
     std::map<unsigned, std::vector<std::unique_ptr<LagrangeChunk>>> lagrange;
     ~kh_srs() { if (ipa_ev) (void)hipEventDestroy(ipa_ev); }      // the DevBufs free themselves
@@ -1203,6 +1207,7 @@ struct kh_ipa {
     int sg_slot = -1;                     // pipeline slot holding the two half-sums of sg launched during the last round (kh_ipa_open), -1: none
     bool sg_want = false;                 // kh_ipa_open asks the last kh_ipa_round_lr to launch them
     std::vector<hipGraphExec_t> retired;  // the previous opening's executable graphs: destroyed underneath the first round's GPU time
+    void* round_tab = nullptr; int round_c = 0;   // table set the round MSMs run over (the SRS's own, or its narrower-window second set)
 };
 
 static int ipa_begin_common(kh_srs_t* srs, const uint64_t* a, size_t a_len, const uint64_t* b, size_t b_len, const uint64_t u_base_xy[8], kh_ipa_t** out,
@@ -1231,8 +1236,9 @@ static int ipa_begin_common(kh_srs_t* srs, const uint64_t* a, size_t a_len, cons
         for (int i = 0; i < MSM_SLOTS; i++) {
             MsmSlot& S = C.slot[i];
             if (S.busy) continue;
+            if (S.gexec && S.gscalars != srs->ipa_sc.p) continue;                // another handle's opening, between two of its rounds: not ours to retire
             if (S.gexec) { retired.push_back(S.gexec); S.gexec = nullptr; }      // destroyed while the first round runs (~0.2 ms of host time each)
-            S.gkey = 0; S.gseen = 0;
+            S.gkey = 0; S.gseen = 0; S.gscalars = nullptr;
         }
     const auto b1_ = std::chrono::steady_clock::now();
     std::unique_ptr<kh_ipa> st(new kh_ipa);
@@ -1250,21 +1256,35 @@ static int ipa_begin_common(kh_srs_t* srs, const uint64_t* a, size_t a_len, cons
     if (!srs->ipa_ev) KH_HIP(hipEventCreateWithFlags(&srs->ipa_ev, hipEventDisableTiming));
     st->a = srs->ipa_a; st->b = srs->ipa_b; st->coef = srs->ipa_coef; st->sc = &srs->ipa_sc; st->partial = &srs->ipa_partial; st->ev = srs->ipa_ev; st->partial_words = partial_bytes / 8;
     // H and U into the two extra slots of every window table
-    const int W = srs->g_precomp_c ? (256 + srs->g_precomp_c - 1) / srs->g_precomp_c : 1;
+    // the rounds' table set: the SRS's own (c = 16) or, with KH_IPA_C = c2, a second set with narrower windows built on first use
+    static const int ipa_c = getenv("KH_IPA_C") ? atoi(getenv("KH_IPA_C")) : IPA_ROUND_C;
+    const bool second = srs->g_precomp_c && ipa_c >= 12 && ipa_c < srs->g_precomp_c && n >= 4096;
+    if (second && srs->g2_c != ipa_c) {
+        const int W2 = (256 + ipa_c - 1) / ipa_c;
+        if ((rc = srs->g2.reserve(srs->g_stride * 64 * W2))) return rc;
+        KH_HIP(hipMemcpyAsync(srs->g2.p, srs->g.p, srs->g_stride * 64, hipMemcpyDeviceToDevice, C.stream));
+        if ((rc = msm_precompute(C, srs->curve, srs->g2.p, nullptr, srs->g_stride, ipa_c))) return rc;
+        srs->g2_c = ipa_c; srs->h_multiples2.clear();
+    }
+    const int rc_c = second ? srs->g2_c : srs->g_precomp_c;                        // window width of the rounds' tables
+    void* const round_tab = second ? srs->g2.p : srs->g.p;
+    std::vector<uint64_t>& hm = second ? srs->h_multiples2 : srs->h_multiples;
+    st->round_tab = round_tab; st->round_c = rc_c;
+    const int W = rc_c ? (256 + rc_c - 1) / rc_c : 1;
     std::vector<uint64_t>& tab = st->tab;                  // lives as long as the opening: no synchronisation before returning
     std::vector<uint64_t> col((size_t)W * 8);
     tab.resize((size_t)W * 16);
-    if (srs->h_multiples.size() != (size_t)W * 8) {        // H is the SRS's: its window multiples are computed once
-        srs->h_multiples.resize((size_t)W * 8);
-        host_window_multiples(srs->curve, srs->h, W, srs->g_precomp_c, srs->h_multiples.data());
+    if (hm.size() != (size_t)W * 8) {                      // H is the SRS's: its window multiples are computed once
+        hm.resize((size_t)W * 8);
+        host_window_multiples(srs->curve, srs->h, W, rc_c, hm.data());
     }
-    for (int w = 0; w < W; w++) memcpy(&tab[16 * w], &srs->h_multiples[8 * w], 64);
+    for (int w = 0; w < W; w++) memcpy(&tab[16 * w], &hm[8 * w], 64);
     const auto b2_ = std::chrono::steady_clock::now();
-    host_window_multiples(srs->curve, u_base_xy, W, srs->g_precomp_c, col.data());
+    host_window_multiples(srs->curve, u_base_xy, W, rc_c, col.data());
     const auto b3_ = std::chrono::steady_clock::now();
     for (int w = 0; w < W; w++) memcpy(&tab[16 * w + 8], &col[8 * w], 64);
     hipStream_t s = C.stream;
-    KH_HIP(hipMemcpy2DAsync((char*)srs->g.p + n * 64, srs->g_stride * 64, tab.data(), 128, 128, W, hipMemcpyHostToDevice, s));
+    KH_HIP(hipMemcpy2DAsync((char*)round_tab + n * 64, srs->g_stride * 64, tab.data(), 128, 128, W, hipMemcpyHostToDevice, s));
     if (a_len < n) KH_HIP(hipMemsetAsync((char*)st->a[0].p + a_len * 32, 0, (n - a_len) * 32, s));
     KH_HIP(hipMemcpyAsync(st->a[0].p, a, a_len * 32, kind, s));
     KH_HIP(hipMemcpyAsync(st->b[0].p, b, n * 32, kind, s));
@@ -1330,11 +1350,15 @@ int kh_ipa_round_lr(kh_ipa_t* st, const uint64_t rand_l[4], const uint64_t rand_
     if (rc) return rc;
     if (st->pending) { st->pp = q; st->pending = false; }
     kh_srs_t* srs = st->srs;
-    MsmBasis bs; bs.pts = srs->g.p; bs.inf = nullptr; bs.n = srs->g_stride; bs.stride = srs->g_stride; bs.precomp_c = srs->g_precomp_c;
+    MsmBasis bs; bs.pts = st->round_tab; bs.inf = nullptr; bs.n = srs->g_stride; bs.stride = srs->g_stride; bs.precomp_c = st->round_c;
     if ((rc = msm_enqueue(C, S, st->curve, bs, 0, st->sc->as<uint64_t>(), st->n + 2, 2, 1, /*use_graph=*/1))) return rc;
     if (st->sg_want && st->cur == 2) { st->sg_want = false; ipa_sg_prelaunch_locked(st, C, p, had_fold); }
-    for (hipGraphExec_t g : st->retired) (void)hipGraphExecDestroy(g);      // the GPU is busy with this round for the next ~0.3 ms
-    st->retired.clear();
+    if (!st->retired.empty()) {                           // the GPU is busy with this round for the next ~0.3 ms; other callers are not held up:
+        std::vector<hipGraphExec_t> gone; gone.swap(st->retired);
+        lk.unlock();                                      // the slot stays busy (ours), so nothing of this opening can be touched meanwhile
+        for (hipGraphExec_t g : gone) (void)hipGraphExecDestroy(g);
+        lk.lock();
+    }
     if ((rc = wait_then_finish(lk, C, S, lr_xy, lr_inf))) return rc;
     st->lr_done = true;
     return KH_OK;

@@ -5,6 +5,7 @@
 #include <stdarg.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <initializer_list>
@@ -49,8 +50,13 @@ struct DevBuf {
     DevBuf(DevBuf&& o) noexcept : p(o.p), cap(o.cap) { o.p = nullptr; o.cap = 0; }
     DevBuf& operator=(DevBuf&& o) noexcept { if (this != &o) { release(); p = o.p; cap = o.cap; o.p = nullptr; o.cap = 0; } return *this; }
     ~DevBuf() { release(); }
+    // bumped by every (re)allocation / release of any workspace buffer: part of the hipGraph key, so that a captured launch sequence can
+    // never be replayed across a reallocation -- not even one that hands the same address back (defence in depth: every pointer the
+    // launches bake in is in the key as well)
+    static std::atomic<uint64_t>& generation() { static std::atomic<uint64_t> g{1}; return g; }
     int reserve(size_t bytes) {
         if (bytes <= cap) return KH_OK;
+        generation()++;
         if (p) { hipError_t e = hipFree(p); (void)e; p = nullptr; cap = 0; }
         size_t want = bytes + bytes / 8;
         hipError_t e = hipMalloc(&p, want);
@@ -58,7 +64,7 @@ struct DevBuf {
         cap = want;
         return KH_OK;
     }
-    void release() { if (p) { hipError_t e = hipFree(p); (void)e; } p = nullptr; cap = 0; }
+    void release() { if (p) { hipError_t e = hipFree(p); (void)e; generation()++; } p = nullptr; cap = 0; }
     template <class T> T* as() const { return (T*)p; }
 };
 
@@ -107,9 +113,16 @@ struct MsmSlot {
     // 16 times: ~22 launches per round replayed as one graph).  Keyed by every pointer and size the launches bake in.
     hipGraphExec_t gexec = nullptr;
     uint64_t gkey = 0, gseen = 0;
+    const void* gscalars = nullptr;   // the scalar buffer the captured launch sequence reads (an opening's: its SRS handle's ipa_sc)
     size_t gnout = 0;
     int g_W = 0, g_c = 0, g_precomp = 0, g_planes = 0, g_shift[2] = {0, 0};
     size_t g_ngroups = 0;
+    // the one-launch sort (k_sort_fused) spins on grid barriers and needs all its blocks resident at once; if another PROCESS shares the
+    // GPU they may never be -- its barriers then give up after a bounded spin, set this host-visible word, and msm_finish re-runs the job
+    // with the multi-launch sort (the arguments of the pending job are kept for that) and disables the fused path for the process
+    volatile uint32_t* host_abort = nullptr;          // pinned host memory, written by the kernel
+    bool fused_used = false, g_fused = false;
+    struct { const void* pts; const uint8_t* inf; size_t bn, stride, batch_stride; int precomp_c; size_t offset; const uint64_t* scalars; size_t n, k; int mont, curve; } retry{};
 };
 static constexpr int MSM_SLOTS = 4;
 
@@ -124,6 +137,7 @@ struct Context {
     bool main_dirty = false;           // asynchronous work was queued on the main stream since the last kh_sync
     hipEvent_t order_ev = nullptr;     // orders device-resident producers on the main stream before an MSM on another slot's stream
     int num_cus = 256;
+    bool fused_disabled = false;       // a k_sort_fused launch could not get all its blocks resident (shared GPU): multi-launch sort from then on
     PhaseTimer timer;                  // NTT / LDE phases (MSM phases are per slot)
     // last timings (filled after a sync)
     std::vector<std::pair<const char*, float>> last;      // names are string literals (kh_last_timings hands them out)

@@ -235,6 +235,24 @@ __global__ void k_scatter(const int32_t* __restrict__ digits, SortGeom g, const 
 //           final entries through 128 LDS cursors into a 256 KB window.
 // No per-slice histogram matrix, no key-total pass, no global scan over the keys.  Needs n <= 2^20 and W <= 16 for the record.
 static constexpr int PART_T = 1024, PART_P = 256, PART_LOW = 7;
+// LDS counter increment with wave aggregation for the skewed case: when every active lane of the wave targets the SAME counter (the
+// reference's benchmark witness puts n - 10 of n scalars into one bucket: 65,526 same-address LDS atomics serialise, 228 us in
+// k_part_sort for 15 such columns) ONE lane adds the lane count and the others take consecutive positions; a mixed wave pays one
+// ballot + one shuffle more than the plain per-lane atomics it then issues.  Must be called by all non-exited lanes of the wave together.
+__device__ __forceinline__ u32 lds_inc_agg(u32* ctr, u32 key, bool active) {
+    const u64 act = __ballot(active);
+    if (!act) return 0;
+    const int leader = __ffsll((long long)act) - 1;
+    const u32 k0 = __shfl(key, leader, 64);
+    if (__ballot(active && key == k0) == act) {
+        const int lane = (int)(threadIdx.x & 63u);
+        u32 b = 0;
+        if (lane == leader) b = atomicAdd(&ctr[k0], (u32)__popcll(act));
+        b = __shfl(b, leader, 64);
+        return b + (u32)__popcll(act & ((1ull << lane) - 1ull));
+    }
+    return active ? atomicAdd(&ctr[key], 1u) : 0u;
+}
 __global__ void __launch_bounds__(PART_T)
 k_part_hist(const int32_t* __restrict__ digits, u32 tot_e, u32 nblk, u32* __restrict__ PH) {
     KH_HIGH_PRIO();
@@ -249,7 +267,7 @@ k_part_hist(const int32_t* __restrict__ digits, u32 tot_e, u32 nblk, u32* __rest
 #pragma unroll
         for (int u = 0; u < 8; u++) { const u32 e = e0 + u * PART_T; v[u] = d[e < e_hi ? e : e_hi - 1]; if (e >= e_hi) v[u] = 0; }
 #pragma unroll
-        for (int u = 0; u < 8; u++) if (v[u]) atomicAdd(&cnt[((u32)(v[u] < 0 ? -v[u] : v[u]) - 1u) >> PART_LOW], 1u);
+        for (int u = 0; u < 8; u++) (void)lds_inc_agg(cnt, ((u32)(v[u] < 0 ? -v[u] : v[u]) - 1u) >> PART_LOW, v[u] != 0);
     }
     __syncthreads();
     if (tid < PART_P) PH[((size_t)j * PART_P + tid) * nblk + blk] = cnt[tid];
@@ -271,11 +289,9 @@ k_part_scatter(const int32_t* __restrict__ digits, u32 tot_e, u32 n, u32 nblk, c
         for (int u = 0; u < 8; u++) { const u32 e = e0 + u * PART_T; v[u] = d[e < e_hi ? e : e_hi - 1]; if (e >= e_hi) v[u] = 0; }
 #pragma unroll
         for (int u = 0; u < 8; u++) {
-            if (v[u]) {
-                const u32 b = (u32)(v[u] < 0 ? -v[u] : v[u]) - 1u;
-                const u32 pos = atomicAdd(&cur[b >> PART_LOW], 1u);
-                mid[pos] = ((b & ((1u << PART_LOW) - 1u)) << 25) | (v[u] < 0 ? 1u << 24 : 0u) | (w << 20) | i;
-            }
+            const u32 b = (u32)(v[u] < 0 ? -v[u] : v[u]) - 1u;
+            const u32 pos = lds_inc_agg(cur, b >> PART_LOW, v[u] != 0);
+            if (v[u]) mid[pos] = ((b & ((1u << PART_LOW) - 1u)) << 25) | (v[u] < 0 ? 1u << 24 : 0u) | (w << 20) | i;
             i += PART_T;
             while (i >= n) { i -= n; w++; }
         }
@@ -296,7 +312,7 @@ k_part_sort(const u32* __restrict__ mid, const u32* __restrict__ PO, u32 nblk, u
 #pragma unroll
         for (int u = 0; u < 8; u++) { const u32 x = x0 + u * PART_T; m[u] = mid[x < end ? x : end - 1]; }
 #pragma unroll
-        for (int u = 0; u < 8; u++) if (x0 + u * PART_T < end) atomicAdd(&hist[m[u] >> 25], 1u);
+        for (int u = 0; u < 8; u++) (void)lds_inc_agg(hist, m[u] >> 25, x0 + u * PART_T < end);
     }
     __syncthreads();
     if (tid < 64) {                                      // exclusive scan of the 128 counts: two per lane of one wave
@@ -317,9 +333,10 @@ k_part_sort(const u32* __restrict__ mid, const u32* __restrict__ PO, u32 nblk, u
 #pragma unroll
         for (int u = 0; u < 8; u++) { const u32 x = x0 + u * PART_T; m[u] = mid[x < end ? x : end - 1]; }
 #pragma unroll
-        for (int u = 0; u < 8; u++) if (x0 + u * PART_T < end) {
-            const u32 pos = atomicAdd(&cur[m[u] >> 25], 1u);
-            entries[pos] = (pb0 + (u32)(((m[u] >> 20) & 15u) * pt_stride) + (m[u] & 0xfffffu)) | ((m[u] & (1u << 24)) << 7);
+        for (int u = 0; u < 8; u++) {
+            const bool live = x0 + u * PART_T < end;
+            const u32 pos = lds_inc_agg(cur, m[u] >> 25, live);
+            if (live) entries[pos] = (pb0 + (u32)(((m[u] >> 20) & 15u) * pt_stride) + (m[u] & 0xfffffu)) | ((m[u] & (1u << 24)) << 7);
         }
     }
 }
@@ -403,14 +420,32 @@ struct FusedGeom {
 };
 static constexpr int FUSED_T = 1024, FUSED_KPT = 2, FUSED_G = 16, FUSED_B = 64;      // chunks per job <= FUSED_G, blocks <= FUSED_B
 static constexpr int FUSED_V = 17, FUSED_C = 16;        // int4's of digits / cursors per thread (registers)
-__device__ __forceinline__ void grid_barrier(u32* ctr, u32 target) {
+// Bounded: the barrier assumes every block of the launch is resident.  Inside one process that holds (64 blocks of 64 KB LDS, two per
+// CU, even with all four pipeline slots in flight); with several PROCESSES on one GPU it need not, and resident blocks would spin on
+// peers that cannot be scheduled.  After `limit` ticks of the 100 MHz wall clock (or when another block has given up) the barrier
+// returns false, the whole launch drains, and the host re-runs the job with the multi-launch sort (msm_finish).
+__device__ __forceinline__ bool grid_barrier(u32* ctr, u32 target, u32* abort_dev, volatile uint32_t* abort_host, unsigned long long limit) {
+    __shared__ int ok_;
     __syncthreads();
     if (threadIdx.x == 0) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(2);
+        int ok = 1;
+        const unsigned long long t0 = wall_clock64();
+        u32 spins = 0;
+        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(2);
+            if ((spins++ & 127u) == 0 && (__hip_atomic_load(abort_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 || wall_clock64() - t0 > limit)) {
+                __hip_atomic_store(abort_dev, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                *abort_host = 1u;
+                ok = 0;
+                break;
+            }
+        }
+        ok_ = ok;
     }
     __syncthreads();
+    return ok_ != 0;
     // no acquire fence: an agent-scope invalidate of the L2 cost ~7 us per barrier (every wave's first load afterwards waited for
     // it).  Everything another block wrote is read with coherent (agent-scope, sc1) loads instead: coh_load below.
 }
@@ -442,7 +477,8 @@ __device__ __forceinline__ void lane_sums(const u32* bs, u32 count, u32 upto, u3
 }
 __global__ void __launch_bounds__(FUSED_T)
 k_sort_fused(const int32_t* __restrict__ digits, FusedGeom g, u32* __restrict__ H, u32* __restrict__ off, u32* __restrict__ toff,
-             u32* __restrict__ entries, u32* __restrict__ handed, u32* __restrict__ big, u32* __restrict__ sync, u32* __restrict__ bsums) {
+             u32* __restrict__ entries, u32* __restrict__ handed, u32* __restrict__ big, u32* __restrict__ sync, u32* __restrict__ bsums,
+             volatile uint32_t* abort_host, unsigned long long spin_limit) {
     KH_HIGH_PRIO();
     extern __shared__ u32 lds[];                         // `sub` words: histogram, later the scatter cursors
     __shared__ u32 sh[FUSED_T / 64 + 1];
@@ -492,7 +528,8 @@ k_sort_fused(const int32_t* __restrict__ digits, FusedGeom g, u32* __restrict__ 
     u32* hout = H + ((size_t)j * g.bpg + r) * g.nb + b_lo;
     for (u32 b = tid; b < g.sub; b += FUSED_T) hout[b] = lds[b];
     KH_TS(1);
-    grid_barrier(sync, G);
+    u32* const abort_dev = bsums + 2 * FUSED_B + 32;
+    if (!grid_barrier(sync, G, abort_dev, abort_host, spin_limit)) return;
     KH_TS(2);
     // 2 per key: within-key prefixes over the chunks, the key's count; block-local scan of the counts
     const u32 key0 = (blk * FUSED_T + tid) * g.kpt;
@@ -524,7 +561,7 @@ k_sort_fused(const int32_t* __restrict__ digits, FusedGeom g, u32* __restrict__ 
     const u32 ex1 = block_scan_1024(mine, sh, &btot);
     if (tid == 0) bsums[blk] = btot;
     KH_TS(3);
-    grid_barrier(sync, 2 * G);
+    if (!grid_barrier(sync, 2 * G, abort_dev, abort_host, spin_limit)) return;
     KH_TS(4);
     // 3 off[]; the task length K from the true entry count; task counts and their block-local scan
     u32 base, total;
@@ -544,7 +581,7 @@ k_sort_fused(const int32_t* __restrict__ digits, FusedGeom g, u32* __restrict__ 
     KH_TS(11);
     if (tid == 0) bsums[FUSED_B + blk] = btot;
     KH_TS(5);
-    grid_barrier(sync, 3 * G);
+    if (!grid_barrier(sync, 3 * G, abort_dev, abort_host, spin_limit)) return;
     KH_TS(6);
     // 4 scatter cursors (key offset + the chunk's within-key prefix); toff[]; scatter of the digits held in registers
     const u32* o = off + (size_t)j * g.nb + b_lo;
@@ -1146,9 +1183,11 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
     // small jobs over the tables: the whole sort in one launch (k_sort_fused)
     static const bool fused_off = getenv("KH_NO_FUSED_SORT") != nullptr;
     static const size_t fused_max = getenv("KH_FUSED_MAX") ? (size_t)atol(getenv("KH_FUSED_MAX")) : ((size_t)1 << 22);
+    // bounded spin of its grid barriers: 20 ms of the 100 MHz wall clock by default (a barrier normally waits < 50 us)
+    static const unsigned long long fused_spin_ticks = 100ull * (getenv("KH_FUSED_SPIN_US") ? (unsigned long long)atoll(getenv("KH_FUSED_SPIN_US")) : 20000ull);
     FusedGeom fg{};
     // (co-residency of the spinning blocks is what makes the grid barriers safe: 64 blocks x 4 jobs in flight need 128 CUs -- not in a partitioned mode)
-    bool fused = precomp && !fused_off && k <= 4 && M < fused_max && nb >= 2048 && Ctx.num_cus >= 128;
+    bool fused = precomp && !fused_off && !Ctx.fused_disabled && k <= 4 && M < fused_max && nb >= 2048 && Ctx.num_cus >= 128;
     if (fused) {
         fg.n = (u32)n; fg.nb = nb; fg.W = (u32)W; fg.k = (u32)k; fg.bpg = (u32)std::min<size_t>(FUSED_G, FUSED_B / (2 * k)); fg.nkeys = (u32)nkeys;
         fg.split = 2; fg.sub = nb / fg.split;              // 64 blocks of 64 KB LDS: two per CU, so four (even eight) jobs in flight stay co-resident
@@ -1171,8 +1210,13 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
     if (fused) {
         if ((rc = C.ws_hist.reserve((size_t)k * fg.bpg * nb * sizeof(u32)))) return rc;
         if (!C.ws_sync.p) {
-            if ((rc = C.ws_sync.reserve((2 + 2 * FUSED_B + 32) * sizeof(u32)))) return rc;
-            KH_HIP(hipMemsetAsync(C.ws_sync.p, 0, (2 + 2 * FUSED_B + 32) * sizeof(u32), s));
+            if ((rc = C.ws_sync.reserve((2 + 2 * FUSED_B + 32 + 2) * sizeof(u32)))) return rc;
+            KH_HIP(hipMemsetAsync(C.ws_sync.p, 0, (2 + 2 * FUSED_B + 32 + 2) * sizeof(u32), s));
+        }
+        if (!C.host_abort) {
+            void* hp = nullptr;
+            KH_HIP(hipHostMalloc(&hp, 64, hipHostMallocDefault));
+            C.host_abort = (volatile uint32_t*)hp; *C.host_abort = 0;
         }
     }
     // hipGraph replay / capture (opt-in by the caller; the key covers everything the launches bake in)
@@ -1188,9 +1232,12 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
                                   (uint64_t)(uintptr_t)C.ws_ntask.p, (uint64_t)(uintptr_t)C.ws_toff.p, (uint64_t)(uintptr_t)C.ws_entries.p, (uint64_t)(uintptr_t)C.ws_partial.p,
                                   (uint64_t)(uintptr_t)C.ws_buckets.p, (uint64_t)(uintptr_t)C.ws_seg.p, (uint64_t)(uintptr_t)C.ws_out.p, (uint64_t)(uintptr_t)C.ws_scan_tmp.p,
                                   (uint64_t)(uintptr_t)C.ws_biglist.p, (uint64_t)(uintptr_t)C.ws_order.p, (uint64_t)(uintptr_t)C.ws_chunks.p,
-                                  (uint64_t)(uintptr_t)C.ws_handed.p, (uint64_t)(uintptr_t)C.ws_sync.p, (uint64_t)fused, (uint64_t)(uintptr_t)C.ws_mid.p, (uint64_t)part};
+                                  (uint64_t)(uintptr_t)C.ws_handed.p, (uint64_t)(uintptr_t)C.ws_sync.p, (uint64_t)fused, (uint64_t)(uintptr_t)C.ws_mid.p, (uint64_t)part,
+                                  DevBuf::generation().load()};
         for (uint64_t v : parts) key = fnv(key, v);
         if (C.gexec && C.gkey == key) {                    // replay
+            C.fused_used = C.g_fused;
+            C.retry = {basis.pts, basis.inf, basis.n, basis.stride, basis.batch_stride, basis.precomp_c, offset, scalars_dev, n, k, mont, curve};
             KH_HIP(hipGraphLaunch(C.gexec, s));
             KH_HIP(hipEventRecord(C.done, s));
             C.busy = true; C.owner = std::this_thread::get_id(); C.ticket = Ctx.next_ticket++;
@@ -1224,7 +1271,7 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
         u32* sy = C.ws_sync.as<u32>();
         hipLaunchKernelGGL(k_sort_fused, dim3(fg.bpg * fg.k * fg.split), dim3(FUSED_T), (size_t)fg.sub * sizeof(u32), s, C.ws_digits.as<int32_t>(), fg,
                            C.ws_hist.as<u32>(), C.ws_off.as<u32>(), C.ws_toff.as<u32>(), C.ws_entries.as<u32>(), C.ws_handed.as<u32>(),
-                           C.ws_biglist.as<u32>(), sy, sy + 2);
+                           C.ws_biglist.as<u32>(), sy, sy + 2, C.host_abort, fused_spin_ticks);
         C.timer.mark("sort", s);
     } else if (part) {
         const u32 tot_e = (u32)((size_t)W * n);
@@ -1326,6 +1373,11 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
             direct_out = true;
         } else {
         hipLaunchKernelGGL((k_marginals<BF>), dim3(32, 3, (unsigned)ngroups), dim3(ngroups <= 4 ? 256 : 64), 0, s, C.ws_buckets.as<uint8_t>(), mg, C.ws_seg.as<uint8_t>());
+        // the weighted tail is 3 x ngroups blocks however many MSMs there are: a pure latency chain (10 additions deep), so it takes the
+        // lane-cooperative kernel for batches too (15 witness columns: 96 -> 35 us); the records have the same 128-byte layout
+        static const bool fin_quad = !getenv("KH_NO_FIN_QUAD");
+        if (fin_quad) { hipLaunchKernelGGL((k_marginal_fin_q<BF>), dim3(3, (unsigned)ngroups), dim3(128), 0, s, C.ws_seg.as<uint8_t>(), mg, (uint8_t*)C.pinned); direct_out = true; }
+        else
         hipLaunchKernelGGL((k_marginal_fin<BF>), dim3(3, (unsigned)ngroups), dim3(64), 0, s, C.ws_seg.as<uint8_t>(), mg, C.ws_out.as<uint8_t>());
         }
     } else {
@@ -1349,13 +1401,15 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
         if (e == hipSuccess && g) e = hipGraphInstantiate(&C.gexec, g, nullptr, nullptr, 0);
         if (g) (void)hipGraphDestroy(g);
         if (e != hipSuccess) { C.gexec = nullptr; set_error("hipGraph capture of the MSM launch sequence failed: %s", hipGetErrorString(e)); return KH_E_DEVICE; }
-        C.gkey = key; C.gnout = nout;
+        C.gkey = key; C.gnout = nout; C.gscalars = scalars_dev; C.g_fused = fused;
         C.g_W = W; C.g_c = c; C.g_precomp = precomp; C.g_planes = (int)planes; C.g_shift[0] = (int)mg.wd[0]; C.g_shift[1] = (int)mg.wd[1]; C.g_ngroups = ngroups;
         KH_HIP(hipGraphLaunch(C.gexec, s));
     }
     KH_HIP(hipEventRecord(C.done, s));
     C.busy = true; C.owner = std::this_thread::get_id(); C.ticket = Ctx.next_ticket++;
     C.curve = curve; C.W = W; C.c = c; C.precomp = precomp; C.k = k; C.ngroups = ngroups; C.planes = (int)planes; C.plane_shift[0] = (int)mg.wd[0]; C.plane_shift[1] = (int)mg.wd[1];
+    C.fused_used = fused;
+    C.retry = {basis.pts, basis.inf, basis.n, basis.stride, basis.batch_stride, basis.precomp_c, offset, scalars_dev, n, k, mont, curve};
     return KH_OK;
 }
 
@@ -1373,6 +1427,20 @@ int msm_enqueue(Context& C, MsmSlot& S, int curve, const MsmBasis& basis, size_t
 // 8 finish on the host: wait for the slot, Horner over the window sums (plain path), XYZZ -> affine
 int msm_finish(Context& C, MsmSlot& S, uint64_t* out_xy, uint8_t* out_inf) {
     KH_HIP(hipEventSynchronize(S.done));
+    if (S.fused_used && S.host_abort && *S.host_abort) {
+        // the one-launch sort gave up at a grid barrier (its blocks were not all resident: the GPU is shared with another process):
+        // everything behind it ran on garbage.  Re-run this job with the multi-launch sort and stay on it.
+        *S.host_abort = 0;
+        if (!C.fused_disabled) fprintf(stderr, "libkimchi_hip: k_sort_fused could not get its blocks co-resident (shared GPU?): using the multi-launch sort from now on\n");
+        C.fused_disabled = true;
+        KH_HIP(hipMemsetAsync(S.ws_sync.p, 0, (2 + 2 * FUSED_B + 32 + 2) * sizeof(u32), S.stream));
+        const uint64_t ticket = S.ticket; const auto owner = S.owner;
+        MsmBasis b; b.pts = S.retry.pts; b.inf = S.retry.inf; b.n = S.retry.bn; b.stride = S.retry.stride; b.batch_stride = S.retry.batch_stride; b.precomp_c = S.retry.precomp_c;
+        int rc = msm_enqueue(C, S, S.retry.curve, b, S.retry.offset, S.retry.scalars, S.retry.n, S.retry.k, S.retry.mont, 0);
+        S.ticket = ticket; S.owner = owner; C.next_ticket--;
+        if (rc) { S.busy = false; return rc; }
+        KH_HIP(hipEventSynchronize(S.done));
+    }
     S.busy = false;
     static const bool fused_dbg = getenv("KH_FUSED_DEBUG") != nullptr;
     if (fused_dbg && S.ws_sync.p) {                       // phase timestamps of the last k_sort_fused on this slot (block 0)

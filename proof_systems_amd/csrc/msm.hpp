@@ -19,6 +19,7 @@ int msm_pick_window(size_t n);
 int msm_precompute(Context& C, int curve, void* tables, const uint8_t* inf, size_t n, int c);
 static constexpr int MSM_PRECOMP_C = 16;          // window width of the precomputed tables
 static constexpr size_t MSM_PRECOMP_MIN_N = 1024; // smaller bases keep the plain per-window path
+static constexpr int IPA_ROUND_C = 16;            // window width of the opening rounds' table set (KH_IPA_C overrides; < 16: a second, narrower set)
 // enqueue all device work of k MSMs on slot S (returns immediately); msm_finish waits for it and does the host part
 // use_graph: the caller repeats this exact MSM (same buffers and sizes): from the second call on the launch sequence is
 // captured once into a hipGraph and replayed
