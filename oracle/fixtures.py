@@ -104,7 +104,7 @@ def oracle_views(fx, h):
     pe = {k: one(ev[k]) for k in K.EVAL_ORDER}
     pe.update({"public": one(ev["public"]) if ev["public"] is not None else None, "w": [one(e) for e in ev["w"]], "s": [one(e) for e in ev["s"]],
                "coefficients": [one(e) for e in ev["coefficients"]]})
-    for k in ("lookup_aggregation", "lookup_table"):
+    for k in ("lookup_aggregation", "lookup_table", "runtime_lookup_table", "runtime_lookup_table_selector"):
         pe[k] = one(ev[k]) if ev[k] is not None else None
     pe["optional_gate_selectors"] = [one(e) if e is not None else None for e in ev["optional_gate_selectors"]]
     pe["lookup_sorted"] = [one(e) for e in ev["lookup_sorted"] if e is not None]

@@ -277,7 +277,108 @@ def and_witness(F: P.Field, in1: int, in2: int, nbytes: int) -> List[List[int]]:
     return rows
 
 
-ROW_MACHINES = {"Poseidon": 15, "CompleteAdd": 7, "VarBaseMul": 21, "EndoMul": 12, "EndoMulScalar": 11, "Xor16": 3}
+# ------------------------------------------------------------------------------------------------------------ range checks, rot, foreign field
+LIMB_BITS = 88                        # KimchiForeignElement: three 88-bit limbs (foreign_field.rs)
+
+
+def _crumb(p, x):
+    return x * (x - 1) % p * (x - 2) % p * (x - 3) % p
+
+
+def range_check0_row(F: P.Field, curr, nxt, coeffs) -> List[int]:
+    """range_check/circuitgates.rs:117-163: eight crumbs (columns 7..14), the 88-bit decomposition of column 0 into six 12-bit limbs
+    (columns 1..6) and the crumbs, and -- when coefficient 0 is set -- the compact form next[1] = curr[0] + 2^88 next[0]."""
+    p = F.p
+    out = [_crumb(p, curr[i]) for i in range(7, COLUMNS)]
+    pw, acc = 1, 0
+    for i in range(COLUMNS - 1, 6, -1):
+        acc = (acc + pw * curr[i]) % p; pw = pw * 4 % p
+    for i in range(6, 0, -1):
+        acc = (acc + pw * curr[i]) % p; pw = pw * 4096 % p
+    out.append((acc - curr[0]) % p)
+    out.append(coeffs[0] * (nxt[1] - (curr[0] + (1 << LIMB_BITS) * nxt[0])) % p)
+    return out
+
+
+def range_check1_row(F: P.Field, curr, nxt) -> List[int]:
+    """range_check/circuitgates.rs:279-345: 20 crumbs over the two rows and the decomposition of column 0."""
+    p = F.p
+    out = [_crumb(p, curr[2])] + [_crumb(p, curr[i]) for i in range(7, COLUMNS)] + [_crumb(p, nxt[i]) for i in range(3)] + [_crumb(p, nxt[i]) for i in range(7, COLUMNS)]
+    pw, acc = 1, 0
+    for i in range(COLUMNS - 1, 6, -1):
+        acc = (acc + pw * nxt[i]) % p; pw = pw * 4 % p
+    for i in range(2, -1, -1):
+        acc = (acc + pw * nxt[i]) % p; pw = pw * 4 % p
+    for i in range(COLUMNS - 1, 6, -1):
+        acc = (acc + pw * curr[i]) % p; pw = pw * 4 % p
+    for i in range(6, 2, -1):
+        acc = (acc + pw * curr[i]) % p; pw = pw * 4096 % p
+    acc = (acc + pw * curr[2]) % p
+    out.append((acc - curr[0]) % p)
+    return out
+
+
+def rot64_row(F: P.Field, curr, nxt, coeffs) -> List[int]:
+    """rot.rs:190-237: word * 2^rot = excess * 2^64 + shifted, rotated = shifted + excess, and the bound excess - 2^rot + 2^64 decomposed."""
+    p = F.p
+    out = [_crumb(p, curr[i]) for i in range(7, COLUMNS)]
+    word, rotated, excess, shifted, two_rot = curr[0], curr[1], curr[2], nxt[0], coeffs[0]
+    out.append((word * two_rot - (excess * (1 << 64) + shifted)) % p)
+    out.append((rotated - (shifted + excess)) % p)
+    pw, acc = 1, 0
+    for i in range(COLUMNS - 1, 6, -1):
+        acc = (acc + pw * curr[i]) % p; pw = pw * 4 % p
+    for i in range(6, 2, -1):
+        acc = (acc + pw * curr[i]) % p; pw = pw * 4096 % p
+    out.append((acc - (excess - two_rot + (1 << 64))) % p)
+    return out
+
+
+def foreign_field_add_row(F: P.Field, curr, nxt, coeffs) -> List[int]:
+    """foreign_field_add/circuitgates.rs:133-186: coefficients = the foreign modulus' three limbs and the sign."""
+    p = F.p
+    L = 1 << LIMB_BITS
+    fm, sign = coeffs[:3], coeffs[3]
+    llo, lmi, lhi, rlo, rmi, rhi, ovf, carry = curr[:8]
+    compact = lambda lo, mi: (lo + mi * L) % p
+    out = [ovf * (ovf - sign) % p, carry * (carry - 1) % p * (carry + 1) % p]
+    bot = (compact(llo, lmi) + sign * compact(rlo, rmi) - ovf * compact(fm[0], fm[1]) - carry * (L * L)) % p
+    top = (lhi + sign * rhi - ovf * fm[2] + carry) % p
+    out.append((bot - compact(nxt[0], nxt[1])) % p)
+    out.append((top - nxt[2]) % p)
+    return out
+
+
+def foreign_field_mul_row(F: P.Field, curr, nxt, coeffs) -> List[int]:
+    """foreign_field_mul/circuitgates.rs:196-372: coefficients = the top limb of the foreign modulus, then the three limbs of its negation."""
+    p = F.p
+    L = 1 << LIMB_BITS
+    a, b = curr[0:3], curr[3:6]
+    c1 = [curr[7], curr[8], curr[9], curr[10], nxt[8], nxt[9], nxt[10], curr[11], curr[12], curr[13], curr[14]]
+    carry1 = (sum(c1[i] << (12 * i) for i in range(8)) + (c1[8] << 86) + (c1[9] << 88) + (c1[10] << 90)) % p
+    carry0 = nxt[11]
+    q = nxt[2:5]
+    q_hi_bound = nxt[5]
+    rem = nxt[0:2]
+    p1_lo, p1_hi0, p1_hi1 = curr[6], nxt[6], nxt[7]
+    hi_f, nf = coeffs[0], coeffs[1:4]
+    prod = [(a[0] * b[0] + q[0] * nf[0]) % p,
+            (a[0] * b[1] + a[1] * b[0] + q[0] * nf[1] + q[1] * nf[0]) % p,
+            (a[0] * b[2] + a[2] * b[0] + a[1] * b[1] + q[0] * nf[2] + q[2] * nf[0] + q[1] * nf[1]) % p]
+    nat = lambda v: (L * L * v[2] + L * v[1] + v[0]) % p
+    a_n, b_n, q_n, nf_n = nat(a), nat(b), nat(q), nat(nf)
+    r_n = (L * L * rem[1] + rem[0]) % p
+    bound = (q[2] + L - hi_f - 1) % p
+    p1_hi = (L * p1_hi1 + p1_hi0) % p
+    return [_crumb(p, p1_hi1), _crumb(p, carry0), (prod[1] - (L * p1_hi + p1_lo)) % p,
+            (L * L * carry0 - (prod[0] + L * p1_lo - rem[0])) % p,
+            (a_n * b_n + q_n * nf_n - r_n - q_n * (L * L * L)) % p,
+            _crumb(p, curr[11]), _crumb(p, curr[12]), _crumb(p, curr[13]), (curr[14] * curr[14] - curr[14]) % p,
+            (L * carry1 - (prod[2] + p1_hi + carry0 - rem[1])) % p, (q_hi_bound - bound) % p]
+
+
+ROW_MACHINES = {"Poseidon": 15, "CompleteAdd": 7, "VarBaseMul": 21, "EndoMul": 12, "EndoMulScalar": 11, "Xor16": 3,
+                "RangeCheck0": 10, "RangeCheck1": 21, "Rot64": 11, "ForeignFieldAdd": 4, "ForeignFieldMul": 11}
 
 
 def combined_row(F: P.Field, name: str, curr, nxt, coeffs, alpha: int, mds=None, endo: int = 0) -> int:
@@ -294,6 +395,16 @@ def combined_row(F: P.Field, name: str, curr, nxt, coeffs, alpha: int, mds=None,
         cs = xor16_row(F, curr, nxt)
     elif name == "EndoMulScalar":
         cs = endomul_scalar_row(F, curr)
+    elif name == "RangeCheck0":
+        cs = range_check0_row(F, curr, nxt, coeffs)
+    elif name == "RangeCheck1":
+        cs = range_check1_row(F, curr, nxt)
+    elif name == "Rot64":
+        cs = rot64_row(F, curr, nxt, coeffs)
+    elif name == "ForeignFieldAdd":
+        cs = foreign_field_add_row(F, curr, nxt, coeffs)
+    elif name == "ForeignFieldMul":
+        cs = foreign_field_mul_row(F, curr, nxt, coeffs)
     else:
         raise NotImplementedError(name)
     assert len(cs) == ROW_MACHINES[name]

@@ -107,6 +107,8 @@ def verifier_index_digest(curve: P.Curve, vix) -> int:
             absorb_commitment(sp, c)
         if li["table_ids"] is not None:
             absorb_commitment(sp, li["table_ids"])
+        if li.get("runtime_tables_selector") is not None:
+            absorb_commitment(sp, li["runtime_tables_selector"])
         for q in LOOKUP_PATTERN_ORDER:
             if li["lookup_selectors"].get(q) is not None:
                 absorb_commitment(sp, li["lookup_selectors"][q])
@@ -205,7 +207,8 @@ def lookup_evaluations_in_sponge_order(ev, li):
     """FrSponge::absorb_evaluations (plonk_sponge.rs:127-155): aggregation, table, sorted..., the pattern selectors."""
     if not li:
         return []
-    return [ev["lookup_aggregation"], ev["lookup_table"]] + list(ev["lookup_sorted"]) + [ev["lookup_selectors"][q] for q in LOOKUP_PATTERN_ORDER if q in ev["lookup_selectors"]]
+    rt = [ev[k] for k in ("runtime_lookup_table", "runtime_lookup_table_selector") if ev.get(k) is not None]
+    return [ev["lookup_aggregation"], ev["lookup_table"]] + list(ev["lookup_sorted"]) + rt + [ev["lookup_selectors"][q] for q in LOOKUP_PATTERN_ORDER if q in ev["lookup_selectors"]]
 
 
 def lookup_constant_term(F: P.Field, vix, ev, ch, zeta: int) -> int:
@@ -241,6 +244,8 @@ def lookup_constant_term(F: P.Field, vix, ev, ch, zeta: int) -> int:
              "l0": L.unnormalized_lagrange_basis(F.p, omega, n, 0, zeta),
              "lfinal": L.unnormalized_lagrange_basis(F.p, omega, n, -(zk + 1), zeta)}
     vals = L.constraint_values(Shim, jc, ch["beta"], ch["gamma"], cell, atoms)
+    if li.get("uses_runtime_tables"):                                   # runtime_tables::constraints (runtime_tables.rs:59-66), after the padding to four
+        vals.append(ev["runtime_lookup_table"][0] * ev["runtime_lookup_table_selector"][0] % F.p)
     return sum(pow(ch["alpha"], ALPHA_LOOKUP0 + k, F.p) * v for k, v in enumerate(vals)) % F.p
 
 

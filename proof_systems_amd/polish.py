@@ -296,8 +296,102 @@ def xor16_constraints(env: Env):
     return out
 
 
+LIMB_BITS = 88                               # KimchiForeignElement: three 88-bit limbs
+
+
+def _crumb(env: Env, x):
+    """constraints::crumb (expr.rs:3406-3412): x (x - 1)(x - 2)(x - 3)"""
+    return x * (x - 1) * (x - 2) * (x - 3)
+
+
+def _weighted_sum(env: Env, cells_and_bits):
+    """sum of cells times increasing powers of two: [(cell, bits of the cell), ...] from the least significant one"""
+    acc, shift = None, 0
+    for c, bits in cells_and_bits:
+        term = c if shift == 0 else env.const(1 << shift) * c
+        acc = term if acc is None else acc + term
+        shift += bits
+    return acc
+
+
+def range_check0_constraints(env: Env):
+    """RangeCheck0::constraint_checks (range_check/circuitgates.rs:117-163): 8 crumbs, the 88-bit decomposition of column 0 (six 12-bit
+    limbs in columns 1..6 -- range-checked by the row's lookups -- and the crumbs), and coeff 0 * (next[1] - (curr[0] + 2^88 next[0]))."""
+    wc, wn = env.witness_curr, env.witness_next
+    out = [_crumb(env, wc(i)) for i in range(7, 15)]
+    limbs = [(wc(i), 2) for i in range(14, 6, -1)] + [(wc(i), 12) for i in range(6, 0, -1)]
+    out.append(_weighted_sum(env, limbs) - wc(0))
+    out.append(env.coeff(0) * (wn(1) - (wc(0) + env.const(1 << LIMB_BITS) * wn(0))))
+    return out
+
+
+def range_check1_constraints(env: Env):
+    """RangeCheck1::constraint_checks (range_check/circuitgates.rs:279-345): 20 crumbs over the two rows + the decomposition."""
+    wc, wn = env.witness_curr, env.witness_next
+    out = [_crumb(env, wc(2))] + [_crumb(env, wc(i)) for i in range(7, 15)] + [_crumb(env, wn(i)) for i in range(3)] + [_crumb(env, wn(i)) for i in range(7, 15)]
+    limbs = [(wn(i), 2) for i in range(14, 6, -1)] + [(wn(i), 2) for i in range(2, -1, -1)] + [(wc(i), 2) for i in range(14, 6, -1)] + \
+            [(wc(i), 12) for i in range(6, 2, -1)] + [(wc(2), 2)]
+    out.append(_weighted_sum(env, limbs) - wc(0))
+    return out
+
+
+def rot64_constraints(env: Env):
+    """Rot64::constraint_checks (rot.rs:190-237); coefficient 0 = 2^rot."""
+    wc, wn = env.witness_curr, env.witness_next
+    out = [_crumb(env, wc(i)) for i in range(7, 15)]
+    word, rotated, excess, shifted, two_rot = wc(0), wc(1), wc(2), wn(0), env.coeff(0)
+    t64 = env.const(1 << 64)
+    out.append(word * two_rot - (excess * t64 + shifted))
+    out.append(rotated - (shifted + excess))
+    limbs = [(wc(i), 2) for i in range(14, 6, -1)] + [(wc(i), 12) for i in range(6, 2, -1)]
+    out.append(_weighted_sum(env, limbs) - (excess - two_rot + t64))
+    return out
+
+
+def foreign_field_add_constraints(env: Env):
+    """ForeignFieldAdd::constraint_checks (foreign_field_add/circuitgates.rs:133-186); coefficients 0..2 = the foreign modulus' limbs, 3 = the sign."""
+    wc, wn = env.witness_curr, env.witness_next
+    L = env.const(1 << LIMB_BITS)
+    fm, sign = [env.coeff(i) for i in range(3)], env.coeff(3)
+    ovf, carry = wc(6), wc(7)
+    compact = lambda lo, mi: lo + mi * L
+    bot = compact(wc(0), wc(1)) + sign * compact(wc(3), wc(4)) - ovf * compact(fm[0], fm[1]) - carry * env.const(1 << (2 * LIMB_BITS))
+    top = wc(2) + sign * wc(5) - ovf * fm[2] + carry
+    return [ovf * (ovf - sign), carry * (carry - 1) * (carry + 1), bot - compact(wn(0), wn(1)), top - wn(2)]
+
+
+def foreign_field_mul_constraints(env: Env):
+    """ForeignFieldMul::constraint_checks (foreign_field_mul/circuitgates.rs:196-372); coefficient 0 = the top limb of the foreign modulus,
+    1..3 = the limbs of its negation (2^264 - f)."""
+    wc, wn = env.witness_curr, env.witness_next
+    L, L2, L3 = env.const(1 << LIMB_BITS), env.const(1 << (2 * LIMB_BITS)), env.const(1 << (3 * LIMB_BITS))
+    a, b = [wc(i) for i in range(3)], [wc(3 + i) for i in range(3)]
+    c1 = [(wc(7), 12), (wc(8), 12), (wc(9), 12), (wc(10), 12), (wn(8), 12), (wn(9), 12), (wn(10), 12), (wc(11), 2), (wc(12), 2), (wc(13), 2), (wc(14), 1)]
+    carry1 = _weighted_sum(env, c1)                           # 2^84 | 2^86 | 2^88 | 2^90 for the crumbs and the bit
+    carry0 = wn(11)
+    q = [wn(2), wn(3), wn(4)]
+    rem = [wn(0), wn(1)]
+    p1_lo, p1_hi0, p1_hi1 = wc(6), wn(6), wn(7)
+    hi_f, nf = env.coeff(0), [env.coeff(1 + i) for i in range(3)]
+    prod = [a[0] * b[0] + q[0] * nf[0],
+            a[0] * b[1] + a[1] * b[0] + q[0] * nf[1] + q[1] * nf[0],
+            a[0] * b[2] + a[2] * b[0] + a[1] * b[1] + q[0] * nf[2] + q[2] * nf[0] + q[1] * nf[1]]
+    nat = lambda v: L2 * v[2] + L * v[1] + v[0]
+    q_n = nat(q).cache()
+    r_n = L2 * rem[1] + rem[0]
+    bound = q[2] + L - hi_f - 1
+    p1_hi = (L * p1_hi1 + p1_hi0).cache()
+    return [_crumb(env, p1_hi1), _crumb(env, carry0), prod[1] - (L * p1_hi + p1_lo),
+            L2 * carry0 - (prod[0] + L * p1_lo - rem[0]),
+            nat(a) * nat(b) + q_n * nat(nf) - r_n - q_n * L3,
+            _crumb(env, wc(11)), _crumb(env, wc(12)), _crumb(env, wc(13)), wc(14).square() - wc(14),
+            L * carry1 - (prod[2] + p1_hi + carry0 - rem[1]), wn(5) - bound]
+
+
 GATES = {"Poseidon": (poseidon_constraints, 15), "CompleteAdd": (complete_add_constraints, 7), "VarBaseMul": (varbasemul_constraints, 21),
-         "EndoMul": (endomul_constraints, 12), "EndoMulScalar": (endomul_scalar_constraints, 11), "Xor16": (xor16_constraints, 3)}
+         "EndoMul": (endomul_constraints, 12), "EndoMulScalar": (endomul_scalar_constraints, 11), "Xor16": (xor16_constraints, 3),
+         "RangeCheck0": (range_check0_constraints, 10), "RangeCheck1": (range_check1_constraints, 21), "Rot64": (rot64_constraints, 11),
+         "ForeignFieldAdd": (foreign_field_add_constraints, 4), "ForeignFieldMul": (foreign_field_mul_constraints, 11)}
 
 
 # Kimchi Poseidon MDS matrices (poseidon/src/pasta/fp_kimchi.rs, fq_kimchi.rs: `mds`), by field id 0 = Fp, 1 = Fq -- the constants of
@@ -391,6 +485,9 @@ def lookup_constraints(env: Env, patterns, cols, joint_combiner: int, table_id_c
     for i in range(mpr):
         basis = env.column(cols["lfinal"] if i % 2 == 0 else cols["l0"])
         res.append(basis * (env.column(cols["sorted"][i]) - env.column(cols["sorted"][i + 1])))
+    if cols.get("runtime") is not None:                     # runtime tables: the constraints are padded to 3 + 4, then RT(x) * selector_RT(x) (constraints.rs:658-680, runtime_tables.rs:59-66)
+        res += [env.const(0)] * (4 - mpr)
+        res.append(env.column(cols["runtime"]) * env.column(cols["runtime_selector"]))
     return res
 
 

@@ -62,6 +62,11 @@ def test_gate_on_device(khip, name):
         got = _ints(out.download((n, 4)))
         want = [sel[r] * G.combined_row(F, name, wt[r], wt[(r + 1) % n], ct[r], alpha, mds=mds, endo=endo) % F.p for r in range(n)]
         assert got == want, (name, variant)
+        if name == "ForeignFieldMul":                              # random rows (tests/test_gates.py): the program equals the row machine; nothing to divide
+            assert any(want)
+            for b in bufs + [out]:
+                b.free()
+            continue
         assert any(want) == (variant == "violated")
         # the quotient step: coefficient forms -> d8 -> constraint rows on d8 -> iNTT(8n) -> / Z_H
         coeffs = khip.ntt(fid, d1, logn, inverse=True)

@@ -124,12 +124,18 @@ def test_device_prover_on_the_reference_public_input_circuit(khip):
             assert K.public_evaluations(F, ix.n, ix.omega, public, ch["zeta"]) == tuple(x[0] for x in proof["evals"]["public"])
 
 
-@pytest.mark.parametrize("name", ["test_poseidon", "ec_test", "varbase_mul_test", "endomul_test", "endomul_scalar_test",
-                                  "lookup_gate_proving_works", "lookup_gate_proving_works_multiple_tables"])
+FIXTURES_WITH_GATE_TERMS = ["test_poseidon", "ec_test", "varbase_mul_test", "endomul_test", "endomul_scalar_test", "test_prove_and_verify_xor", "and_prove_and_verify_vesta",
+                            "verify_range_check_valid_proof1", "rot_prove_and_verify_vesta", "test_ffadd_finalization", "test_max_foreign_multiplicands", "test_carry_plookups"]
+FIXTURES_WITH_LOOKUPS = ["lookup_gate_proving_works", "lookup_gate_proving_works_multiple_tables", "test_prove_and_verify_xor", "verify_range_check_valid_proof1",
+                         "test_max_foreign_multiplicands", "test_runtime_table"]
+
+
+@pytest.mark.parametrize("name", sorted(set(FIXTURES_WITH_GATE_TERMS + FIXTURES_WITH_LOOKUPS)))
 def test_device_token_programs_on_the_reference_proof_evaluations(khip, name):
     """The token programs of proof_systems_amd/polish.py, run by kh_expr_evaluations_dev on two-row columns made of the evaluations a
     REFERENCE proof states (row 0: at zeta, row 1: at zeta omega), give the constant term with which the oracle verifier accepts that
-    proof (tests/test_reference_fixtures.py): gate library and lookup constraints, device side, on reference-generated data."""
+    proof (tests/test_reference_fixtures.py): the gate library, the optional gates (Xor16, RangeCheck0/1, Rot64, ForeignFieldAdd/Mul)
+    and the lookup constraints incl. runtime tables, device side, on reference-generated data."""
     from proof_systems_amd import polish as OP
     from oracle import lookup as L
     fx = FX.load(os.path.join(HERE, name + ".bin"), C)
@@ -142,16 +148,17 @@ def test_device_token_programs_on_the_reference_proof_evaluations(khip, name):
     col = lambda e: khip.DevBuf(64).upload(_limbs([e[0], e[1]]))
     wcols = [col(e) for e in ev["w"]]
     out = khip.DevBuf(32)
-    if vix["lookup_index"] is None:
+    if name in FIXTURES_WITH_GATE_TERMS:
         ccols = [col(e) for e in ev["coefficients"]]
         total = 0
         endo = P.endos(P.PALLAS)[0]
-        for gname, key in K.GATE_SELECTORS:
+        sels = [(g, ev[key]) for g, key in K.GATE_SELECTORS] + [(g, e) for g, e in zip(K.OPTIONAL_GATES, ev["optional_gate_selectors"]) if e is not None]
+        for gname, sel in sels:
             toks, consts = OP.gate_program(gname, F.p, alpha, selector_col=30, mds=OP.POSEIDON_MDS[0], endo=endo)
-            khip.expr_evaluations_dev(fid, toks, wcols + ccols + [col(ev[key])], [2] * 31, _limbs(consts), 1, out, stride=1, next_shift=1)
+            khip.expr_evaluations_dev(fid, toks, wcols + ccols + [col(sel)], [2] * 31, _limbs(consts), 1, out, stride=1, next_shift=1)
             total = (total + _ints(out.download((1, 4)))[0]) % F.p
         assert total == K.gate_library_constant_term(C, ev, alpha) and total != 0
-    else:
+    if name in FIXTURES_WITH_LOOKUPS:
         li = vix["lookup_index"]
         n, omega, zk = vix["n"], vix["omega"], vix["zk_rows"]
         jc = ch["joint_combiner"]
@@ -167,7 +174,11 @@ def test_device_token_programs_on_the_reference_proof_evaluations(khip, name):
         bufs += [col(ev["lookup_selectors"][q]) for q in li["patterns"]]
         bufs += [one(L.vanishes_on_last_n_rows(F.p, omega, n, zk + 1, zeta)), one(L.unnormalized_lagrange_basis(F.p, omega, n, 0, zeta)),
                  one(L.unnormalized_lagrange_basis(F.p, omega, n, -(zk + 1), zeta))]
-        toks, consts = OP.lookup_program(F.p, li["patterns"], cols, jc, pow(jc, li["max_joint_size"], F.p), ch["beta"], ch["gamma"], alpha, alpha0=K.ALPHA_LOOKUP0)
         lens = [2] * (len(bufs) - 3) + [1] * 3
+        if li["uses_runtime_tables"]:
+            cols["runtime"], cols["runtime_selector"] = c + 3, c + 4
+            bufs += [col(ev["runtime_lookup_table"]), col(ev["runtime_lookup_table_selector"])]
+            lens += [2, 2]
+        toks, consts = OP.lookup_program(F.p, li["patterns"], cols, jc, pow(jc, li["max_joint_size"], F.p), ch["beta"], ch["gamma"], alpha, alpha0=K.ALPHA_LOOKUP0)
         khip.expr_evaluations_dev(fid, toks, bufs, lens, _limbs(consts), 1, out, stride=1, next_shift=1)
         assert _ints(out.download((1, 4)))[0] == K.lookup_constant_term(F, vix, ev, ch, zeta)

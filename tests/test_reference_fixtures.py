@@ -1,6 +1,8 @@
 """The reference's OWN stored proofs (kimchi/src/tests/fixtures/*.bin: proof + verifier index serialised by the reference's
-prover, verified by its prover-less test mode, tests/generic.rs:56-103) as golden vectors.  Copies of eight of them live in
-tests/golden/ref_fixtures/ (binary test data, read with oracle/fixtures.py); nothing here touches /root/reference.
+prover, verified by its prover-less test mode, tests/generic.rs:56-103) as golden vectors.  Copies of ALL FORTY live in
+tests/golden/ref_fixtures/ (binary test data, read with oracle/fixtures.py); nothing here touches /root/reference.  Every one of
+them is accepted by the oracle's verifier: generic gates, the gate library, lookups, Xor16, range checks, Rot64, foreign-field
+addition and multiplication, runtime tables, recursion, and the two Pallas proofs.
 
 What they pin, none of it "by definition":
   * the oracle's VERIFIER (oracle/kimchi.py) accepts every one of these reference-generated proofs and rejects tampered ones --
@@ -34,6 +36,16 @@ GATE_FIXTURES = {"test_poseidon": "poseidon_selector", "test_poseidon_in_circuit
 GENERIC_FIXTURES = ["test_generic_gate", "test_generic_gate_pub", "test_generic_gate_pub_empty", "test_generic_gate_pub_all_zeros",
                     "test_prove_and_verify_five_not_gnrc"]                   # (the Not gadget built from generic gates, tests/not.rs)
 XOR_FIXTURES = ["and_prove_and_verify_vesta", "test_prove_and_verify_xor", "test_xor_finalization", "test_prove_and_verify_not_xor"]   # Xor16 + its lookups
+# the optional gates (range_check/, rot.rs, foreign_field_add/, foreign_field_mul/): their row machines (oracle/gates.py) are the constant
+# term with which these proofs verify; runtime tables (lookup/runtime_tables.rs); previous challenges (tests/recursion.rs); Pallas
+OPTIONAL_GATE_FIXTURES = {"verify_range_check_valid_proof1": (0, 1), "verify_compact_multi_range_check_proof": (0, 1), "rot_prove_and_verify_vesta": (0, 5), "test_rot_finalization": (0, 5),
+                          "test_ffadd_finalization": (0, 1, 2), "prove_and_verify_1": (2,), "prove_and_verify_50": (2,),
+                          "test_zero_mul": (0, 1, 3), "test_one_mul": (0, 1, 3), "test_max_native_square": (0, 1, 3), "test_max_foreign_square": (0, 1, 3),
+                          "test_max_native_multiplicands": (0, 1, 3), "test_max_foreign_multiplicands": (0, 1, 3),
+                          "test_carry_plookups": (3,), "test_invalid_carry1_bit": (3,), "test_invalid_wraparound_carry1_hi": (3,)}    # indices into OPTIONAL_GATES
+RUNTIME_FIXTURES = ["test_runtime_table", "test_runtime_table_only_one_table_with_id_zero_with_non_zero_entries_fixed_values",
+                    "test_runtime_table_only_one_table_with_id_zero_with_non_zero_entries_random_values"]
+PALLAS_FIXTURES = ["and_prove_and_verify_pallas", "rot_prove_and_verify_pallas"]
 LOOKUP_FIXTURES = ["lookup_gate_proving_works", "lookup_gate_proving_works_multiple_tables",     # tests/lookup.rs:38-170: 500 Lookup gates
                    "test_dummy_value_is_added_in_an_arbitraly_created_table_when_no_table_with_id_0"]   # the dummy entry's table is synthesised (lookup/index.rs)
 
@@ -88,15 +100,50 @@ def final_msm_for(g_l, n_srs, curve=C):
     return final_msm
 
 
-def verify(fx, srs, mutate=None):
+def verify(fx, srs, mutate=None, curve=C):
     g_l, h = srs
     vix, proof = FX.oracle_views(fx, h)
     n_srs = vix["max_poly_size"]
     if fx["public"]:
+        assert curve is C
         vix["public_comm"] = K.public_commitment(C, h, lagrange_commitments(g_l, vix["log2_n"], len(fx["public"])), fx["public"])
     if mutate:
         mutate(vix, proof)
-    return K.verify(C, vix, proof, None, h, P.StdRng(bytes([5] * 32)), final_msm=final_msm_for(g_l, n_srs))
+    return K.verify(curve, vix, proof, None, h, P.StdRng(bytes([5] * 32)), final_msm=final_msm_for(g_l, n_srs, curve))
+
+
+def test_every_stored_fixture_of_the_reference_is_covered():
+    names = sorted(f[:-4] for f in os.listdir(HERE) if f.endswith(".bin"))
+    covered = GENERIC_FIXTURES + list(GATE_FIXTURES) + LOOKUP_FIXTURES + XOR_FIXTURES + list(OPTIONAL_GATE_FIXTURES) + RUNTIME_FIXTURES + PALLAS_FIXTURES + ["test_recursion"]
+    assert names == sorted(covered) and len(names) == 40
+
+
+@pytest.mark.parametrize("name", list(OPTIONAL_GATE_FIXTURES) + RUNTIME_FIXTURES + ["test_recursion"])
+def test_oracle_verifier_accepts_optional_gate_runtime_table_and_recursive_proofs(name, srs):
+    fx = FX.load(os.path.join(HERE, name + ".bin"), C)
+    v, ev = fx["vindex"], fx["proof"]["evals"]
+    if name in OPTIONAL_GATE_FIXTURES:
+        on = [k for k, e in enumerate(ev["optional_gate_selectors"]) if e is not None]
+        assert tuple(on) == OPTIONAL_GATE_FIXTURES[name] == tuple(k for k, c in enumerate(v["optional_comms"]) if c is not None)
+    if name in RUNTIME_FIXTURES:
+        assert v["lookup_index"]["uses_runtime_tables"] and fx["proof"]["lookup"]["runtime"] is not None and ev["runtime_lookup_table"] is not None
+    if name == "test_recursion":
+        assert len(fx["proof"]["prev_challenges"]) == 1 and len(fx["proof"]["prev_challenges"][0][0]) == 16
+    assert verify(fx, srs)
+
+    def bump_w(vix, proof):                          # every gate type of these circuits reads witness column 1 (and the permutation does)
+        w = list(proof["evals"]["w"]); w[1] = ((w[1][0] + 1) % F.p, w[1][1]); proof["evals"]["w"] = w
+    assert not verify(fx, srs, bump_w)
+
+
+@pytest.mark.parametrize("name", PALLAS_FIXTURES)
+def test_oracle_verifier_accepts_the_pallas_proofs(name):
+    """the same circuits proved over Pallas (scalar field Fq, sponge parameters of the other curve): and.rs / rot.rs `test_prove_and_verify`"""
+    CP = P.PALLAS
+    fx = FX.load(os.path.join(HERE, name + ".bin"), CP)
+    srs_p = (cref.srs_generate(1, 0, SRS_LEN, threads=8), CP.srs_h())
+    assert fx["endo"] is None or fx["endo"] == P.endos(P.VESTA)[0]
+    assert verify(fx, srs_p, curve=CP)
 
 
 @pytest.mark.parametrize("name", GENERIC_FIXTURES + list(GATE_FIXTURES) + LOOKUP_FIXTURES + XOR_FIXTURES)
