@@ -176,5 +176,8 @@ def verify_witness(cs, witness) -> None:
             pub = w[0][r] if r < cs["public"] else 0
             assert (co[0] * curr[0] + co[1] * curr[1] + co[2] * curr[2] + co[3] * curr[0] * curr[1] + co[4] - pub) % p == 0, ("generic", r)
             assert (co[5] * curr[3] + co[6] * curr[4] + co[7] * curr[5] + co[8] * curr[3] * curr[4] + co[9]) % p == 0, ("generic", r)
-        elif g["typ"] == "Xor16":
-            assert not any(G.xor16_row(F, curr, nxt)), ("Xor16", r)
+        elif g["typ"] in G.ROW_MACHINES:
+            from . import poseidon as S
+            co = [cs["coefficients"][c][r] for c in range(COLUMNS)]
+            mds = S.params("fp" if F is P.Fp else "fq")["mds"]
+            assert G.combined_row(F, g["typ"], curr, nxt, co, 7, mds=mds, endo=P.endos(P.PALLAS if F is P.Fp else P.VESTA)[0]) == 0, (g["typ"], r)

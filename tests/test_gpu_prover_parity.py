@@ -193,3 +193,48 @@ def test_recursive_proof_equals_the_oracle_provers_proof(khip, cid, logn, log_sr
     assert compare(C, oproof, pr) is None, compare(C, oproof, pr)
     assert OPR.serialize_proof(C, pr) == OPR.serialize_proof(C, oproof)
     ix.free()
+
+
+def test_optional_gate_circuit_proof_equals_the_oracle_provers_proof(khip):
+    """A circuit of RangeCheck0 rows (12-bit lookups into the range-check table, the compact form on one of them), a Rot64 row with its
+    two range-check rows, and a ForeignFieldAdd row: optional-gate selectors committed non-hiding and evaluated, the RangeCheck lookup
+    pattern with its 2^12-entry table on a 2^13 domain -- device proof = oracle proof, byte for byte."""
+    from proof_systems_amd import prover
+    import random
+    from test_gates import tables
+    C = P.VESTA; F = C.scalar; p = F.p
+    rnd = random.Random(77)
+    gates, rows = [], []
+
+    def put(name, coeff_rows, wit_rows, ngate):
+        base = len(gates)
+        for k, wr in enumerate(wit_rows):
+            typ = name if k < ngate else "Zero"
+            gates.append(CC.gate(typ, base + k, [c % p for c in coeff_rows[k]] if typ != "Zero" else []))
+            rows.append(list(wr))
+    for name in ("RangeCheck0", "Rot64", "ForeignFieldAdd", "RangeCheck0"):
+        w, co, ngate = tables(name, rnd)
+        if name == "Rot64":                                     # the rot row reads `shifted` in the next row, which is itself a RangeCheck0 row: decompose it
+            sh = w[1][0]
+            w[1] = [sh] + [(sh >> (76 - 12 * k)) & 4095 for k in range(6)] + [(sh >> (14 - 2 * k)) & 3 for k in range(8)]
+            put("Rot64", co, w[:1], 1); put("RangeCheck0", [[0] * 15], [w[1]], 1)
+        else:
+            put(name, co, w, ngate)
+    cs = CC.build(F, gates)
+    assert cs["log2_n"] == 13 and cs["optional"] == ["RangeCheck0", "ForeignFieldAdd", "Rot64"] and cs["lookup"].info.patterns == ["RangeCheck"]
+    wit = [[r[c] for r in rows] for c in range(15)]
+    CC.verify_witness(cs, wit)
+    seed = bytes([44] * 32)
+    osrs = OPR.Srs(C, 1 << 13)
+    oix = OPR.Index(C, cs, osrs)
+    oproof = OPR.create_proof(oix, wit, P.StdRng(seed))
+    assert K.verify(C, dict(oix.vindex), oproof, None, osrs.h, P.StdRng(bytes([5] * 32)), final_msm=V.final_msm_c(C, osrs.g, osrs.size))
+    srs = khip.Srs.create(khip.VESTA, 1 << 13)
+    ix = device_index(khip, cs, khip.VESTA, srs)
+    c, vix, _ = V.device_views(ix, None)
+    assert vix["optional_comms"] == oix.vindex["optional_comms"] and K.verifier_index_digest(C, vix | {"lookup_index": None}) is not None
+    dproof = prover.create_proof(ix, np.stack([_limbs(F, col) for col in wit]), V.RefRng(P.StdRng(seed)))
+    c, vix, pr = V.device_views(ix, dproof)
+    assert compare(C, oproof, pr) is None, compare(C, oproof, pr)
+    assert OPR.serialize_proof(C, pr) == OPR.serialize_proof(C, oproof)
+    ix.free()
