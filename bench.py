@@ -96,7 +96,9 @@ def ntt_block(khip):
     if per_instr and k.get("sustained_clock_ghz"):
         issue_ms = k["SQ_INSTS_VALU"] * per_instr / 1024.0 / (k["sustained_clock_ghz"] * 1e9) * 1e3
         out["valu_issue"] = {"kernel": key, "instructions_per_launch": k["SQ_INSTS_VALU"], "issue_cycles_per_instruction": per_instr, "avg_launch_ms": k["avg_ns"] * 1e-6,
+                             "frac": issue_ms * k["sustained_clock_ghz"] / 2.4 / (k["avg_ns"] * 1e-6),
                              "sustained_clock_ghz": k["sustained_clock_ghz"], "frac_at_sustained_clock": issue_ms / (k["avg_ns"] * 1e-6),
+                             "mix": "static opcode histogram of the whole kernel (profiles/%s), per-opcode cycles from profiles/%s" % (NTT_MIX_FILE, RATES_FILE),
                              "traffic_bytes_per_launch": k.get("fetch_raw_bytes", 0.0) + k.get("write_bytes", 0.0), "source": "profiles/" + NTT_PMC_FILE,
                              "workload": pmc.get("command")}
     return out

@@ -188,18 +188,28 @@ static int resolve_basis(kh_srs_t* srs, int basis, unsigned chunk, MsmBasis& out
 }
 
 // one non-blocking copy stream per (host thread, device), created on first use
+// (destroyed with the thread: a pool of short-lived worker threads must not leak a stream each)
+struct ThreadCopyStreams {
+    hipStream_t s[KH_MAX_DEVICES] = {nullptr};
+    ~ThreadCopyStreams() {
+        for (int d = 0; d < KH_MAX_DEVICES; d++)
+            if (s[d]) { int cur = -1; if (hipGetDevice(&cur) == hipSuccess) { (void)hipSetDevice(d); (void)hipStreamDestroy(s[d]); (void)hipSetDevice(cur); } }
+    }
+};
 static hipStream_t thread_copy_stream() {
-    static thread_local hipStream_t tl[KH_MAX_DEVICES] = {nullptr};
+    static thread_local ThreadCopyStreams tl;
     const int d = kh::ctx().device >= 0 && kh::ctx().device < KH_MAX_DEVICES ? kh::ctx().device : 0;
-    if (!tl[d] && hipStreamCreateWithFlags(&tl[d], hipStreamNonBlocking) != hipSuccess) { kh::set_error("hipStreamCreate for a copy stream failed"); return nullptr; }
-    return tl[d];
+    if (!tl.s[d] && hipStreamCreateWithFlags(&tl.s[d], hipStreamNonBlocking) != hipSuccess) { kh::set_error("hipStreamCreate for a copy stream failed"); return nullptr; }
+    return tl.s[d];
 }
 
 // kh_dev_alloc / kh_dev_free go through a small caching pool: hipFree synchronises the device and takes ~0.25 ms, and a prover frees
 // ~15 column buffers per proof (3.8 ms of a 16 ms proof, measured with cProfile on proof_systems_amd/prover.py).  Freed blocks are
 // kept per device, keyed by their (4 KiB-rounded) size, and handed out again to a request of nearly that size; reuse is safe because
 // every consumer of such buffers is either synchronous or ordered on the context's main stream.  kh_trim empties the pool;
-// KH_POOL_MAX_MB (default 8192) bounds what it may hold, KH_POOL_MAX_MB=0 disables it.
+// KH_POOL_MAX_MB (default 2048: a 2^16 proof cycles ~0.6 GiB of column buffers) bounds what it may hold, KH_POOL_MAX_MB=0 disables it.
+// A co-tenant of the process (PyTorch's allocator) that runs short of memory can ask for the cached blocks back with kh_trim(); the
+// library itself trims before reporting an allocation failure.
 namespace {
 struct DevPool {
     std::mutex mu;
@@ -208,7 +218,7 @@ struct DevPool {
     size_t cached[KH_MAX_DEVICES] = {0};
 };
 DevPool& dev_pool() { static DevPool p; return p; }
-size_t pool_limit() { static const size_t lim = (getenv("KH_POOL_MAX_MB") ? (size_t)atol(getenv("KH_POOL_MAX_MB")) : 8192) << 20; return lim; }
+size_t pool_limit() { static const size_t lim = (getenv("KH_POOL_MAX_MB") ? (size_t)atol(getenv("KH_POOL_MAX_MB")) : 2048) << 20; return lim; }
 }  // namespace
 static void dev_pool_trim(int device) {
     DevPool& P = dev_pool();
