@@ -103,7 +103,7 @@ def zk_rows_strict_lower_bound(num_chunks: int) -> int:
 GATE_TABLE = {"Xor": ("Xor", 256), "RangeCheck": ("RangeCheck", 4096), "ForeignFieldMul": ("RangeCheck", 4096), "Lookup": (None, 0)}
 
 
-def build(F: P.Field, gates, public: int = 0, lookup_tables=(), max_poly_size: Optional[int] = None, prev_challenges: int = 0):
+def build(F: P.Field, gates, public: int = 0, lookup_tables=(), max_poly_size: Optional[int] = None, prev_challenges: int = 0, runtime_tables=None):
     """ConstraintSystem::build + the column evaluations of the index on d1 (prover_index.rs / constraints.rs:596-731):
     returns a dict with n, zk_rows, omega, shifts, sid, coefficients[15], sigma[7], selectors {gate type -> column},
     optional (the enabled optional gate types), lookup (oracle.lookup.LookupCS or None), gate_types (per row)."""
@@ -111,8 +111,10 @@ def build(F: P.Field, gates, public: int = 0, lookup_tables=(), max_poly_size: O
     gates = [dict(g, wires=list(g["wires"]), coeffs=list(g["coeffs"])) for g in gates]
     assert len(gates) > 1
     types = [g["typ"] for g in gates]
-    info = L.LookupInfo(types)
+    info = L.LookupInfo(types, uses_runtime_tables=runtime_tables is not None)
     lookup_domain_size = sum(len(t["data"][0]) if t["data"] else 0 for t in lookup_tables)
+    if runtime_tables is not None:
+        lookup_domain_size += sum(len(rt["first_column"]) for rt in runtime_tables)
     tabs = {GATE_TABLE[q][0]: GATE_TABLE[q][1] for q in info.patterns if GATE_TABLE[q][0]}
     lookup_domain_size += sum(tabs.values())
     if not any(t["id"] == 0 for t in lookup_tables):
@@ -152,7 +154,7 @@ def build(F: P.Field, gates, public: int = 0, lookup_tables=(), max_poly_size: O
         selectors[t] = sel((t,))
     lcs = None
     if info.patterns:
-        lcs = L.LookupCS(p, types, list(lookup_tables), n, zk_rows)
+        lcs = L.LookupCS(p, types, list(lookup_tables), n, zk_rows, runtime_tables=runtime_tables)
     return {"F": F, "log2_n": log2_n, "n": n, "zk_rows": zk_rows, "omega": omega, "sid": sid, "shifts": shifts, "coefficients": coeffs, "sigma": sigma,
             "selectors": selectors, "optional": optional, "lookup": lcs, "gate_types": types, "gates": gates, "public": public,
             "prev_challenges": prev_challenges, "generic_selector": selectors["Generic"]}

@@ -129,9 +129,11 @@ class LookupCS:
     """LookupConstraintSystem::create without runtime tables (index.rs:188-430): selector columns, the concatenated
     fixed + gate tables padded with zeros to n - zk_rows - 1 rows, the table-id column (None if every id is 0)."""
 
-    def __init__(self, p: int, gates: Sequence[str], fixed_tables, n: int, zk_rows: int):
+    def __init__(self, p: int, gates: Sequence[str], fixed_tables, n: int, zk_rows: int, runtime_tables=None):
+        """runtime_tables: None or [{"id", "first_column"}] (RuntimeTableCfg, runtime_tables.rs:20-50): their first columns are fixed, the
+        second column is supplied per proof (index.rs:241-311)."""
         self.p, self.n, self.zk_rows = p, n, zk_rows
-        self.info = LookupInfo(gates)
+        self.info = LookupInfo(gates, uses_runtime_tables=runtime_tables is not None)
         assert self.info.patterns, "no lookup pattern in the circuit"
         max_entries = n - zk_rows - 1
         # selectors (lookups.rs:222-264)
@@ -146,6 +148,17 @@ class LookupCS:
                         gate_tables.add(PATTERNS[pat]["table"])
         order = sorted(gate_tables, key=lambda t: 0 if t == "RangeCheck" else 1)       # Ord for GateLookupTable (mod.rs:26-37)
         tables = list(fixed_tables) + [range_check_table(p) if t == "RangeCheck" else xor_table(p) for t in order]
+        self.runtime_tables = None if runtime_tables is None else [(rt["id"], len(rt["first_column"])) for rt in runtime_tables]
+        self.runtime_offset, self.runtime_selector = None, None
+        if runtime_tables is not None:
+            assert len({rt["id"] for rt in runtime_tables}) == len(runtime_tables), "runtime table duplicates"
+            self.runtime_offset = sum(len(t["data"][0]) for t in tables)
+            rlen = sum(len(rt["first_column"]) for rt in runtime_tables)
+            sel = [1] * self.runtime_offset + [0] * rlen + [1] * (n - self.runtime_offset - rlen)
+            for r in range(n - zk_rows, n):
+                sel[r] = 0
+            self.runtime_selector = sel
+            tables += [{"id": rt["id"], "data": [list(rt["first_column"]), [0] * len(rt["first_column"])]} for rt in runtime_tables]
         ids = [t["id"] for t in tables]
         assert len(set(ids)) == len(ids), "lookup table id collision"
         width = max([len(t["data"]) for t in tables] + [self.info.max_joint_size])
@@ -176,10 +189,14 @@ class LookupCS:
         column (constraints.rs:424-440); on the domain both agree (all table ids are 0 then), at zeta they do not."""
         return joint_combiner % self.p, pow(joint_combiner, self.info.max_joint_size, self.p)
 
-    def joint_table(self, joint_combiner: int) -> List[int]:
-        """The combined table on d1 (prover.rs:500-572, the stride-8 sub-grid of joint_lookup_table_d8)."""
+    def joint_table(self, joint_combiner: int, runtime_second_column=None) -> List[int]:
+        """The combined table on d1 (prover.rs:500-572, the stride-8 sub-grid of joint_lookup_table_d8); with runtime tables the second
+        column is the fixed one + the proof's runtime contribution (prover.rs:455-464)."""
         jc, tic = self.combiners(joint_combiner)
-        return [combine_table_entry(self.p, jc, tic, [c[r] for c in self.table_cols], self.table_ids[r] if self.table_ids else 0)
+        cols = self.table_cols
+        if runtime_second_column is not None:
+            cols = [c if k != 1 else [(a + b) % self.p for a, b in zip(c, runtime_second_column)] for k, c in enumerate(cols)]
+        return [combine_table_entry(self.p, jc, tic, [c[r] for c in cols], self.table_ids[r] if self.table_ids else 0)
                 for r in range(self.n)]
 
     def dummy_value(self, joint_combiner: int) -> int:
@@ -194,13 +211,13 @@ def zk_patch(vals: List[int], n: int, zk_rows: int, zk_values: Sequence[int]) ->
     return list(vals) + [0] * (last - len(vals)) + list(zk_values)
 
 
-def sorted_columns(cs: LookupCS, gates: Sequence[str], witness, joint_combiner: int) -> List[List[int]]:
+def sorted_columns(cs: LookupCS, gates: Sequence[str], witness, joint_combiner: int, table=None) -> List[List[int]]:
     """constraints.rs:90-194: the multiset table ++ lookups, sorted by the table and laid out as a snake over
     max_per_row + 1 columns of n - zk_rows values each (before zk_patch).  Raises ValueError(row) on a value
     that is not in the table (ProverError::ValueNotInTable)."""
     p, n = cs.p, cs.n
     jc, tic = cs.combiners(joint_combiner)
-    table = cs.joint_table(joint_combiner)
+    table = table if table is not None else cs.joint_table(joint_combiner)
     dummy = cs.dummy_value(joint_combiner)
     lookup_rows = n - cs.zk_rows - 1
     mpr = cs.info.max_per_row
@@ -233,12 +250,12 @@ def sorted_columns(cs: LookupCS, gates: Sequence[str], witness, joint_combiner: 
 
 
 def aggregation(cs: LookupCS, gates: Sequence[str], witness, joint_combiner: int, beta: int, gamma: int,
-                sorted_cols: Sequence[Sequence[int]], zk_values: Optional[Sequence[int]], draw=None) -> List[int]:
+                sorted_cols: Sequence[Sequence[int]], zk_values: Optional[Sequence[int]], draw=None, table=None) -> List[int]:
     """constraints.rs:233-338; `sorted_cols` are the zk-patched columns (length n).  The random tail is `zk_values`, or drawn
     with `draw()` AFTER the running product, as the reference's zk_patch call does (constraints.rs:327)."""
     p, n = cs.p, cs.n
     jc, tic = cs.combiners(joint_combiner)
-    table = cs.joint_table(joint_combiner)
+    table = table if table is not None else cs.joint_table(joint_combiner)
     dummy = cs.dummy_value(joint_combiner)
     lookup_rows = n - cs.zk_rows - 1
     mpr = cs.info.max_per_row

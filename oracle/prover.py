@@ -110,7 +110,8 @@ class Index:
                 "lookup_selectors": {q: (ce(lcs.selectors[q]) if q in lcs.info.patterns else None) for q in K.LOOKUP_PATTERN_ORDER},
                 "table_ids": srs.mask(ce(lcs.table_ids), one) if lcs.table_ids is not None else None,
                 "max_per_row": lcs.info.max_per_row, "max_joint_size": lcs.info.max_joint_size, "patterns": list(lcs.info.patterns),
-                "uses_runtime_tables": False, "runtime_tables_selector": None}
+                "uses_runtime_tables": lcs.runtime_selector is not None,
+                "runtime_tables_selector": ce(lcs.runtime_selector) if lcs.runtime_selector is not None else None}
         self.vindex = v
         self.digest = K.verifier_index_digest(curve, v)
 
@@ -212,9 +213,9 @@ def unnormalized_lagrange_poly(p: int, omega: int, n: int, i: int) -> List[int]:
 
 
 # ---------------------------------------------------------------------------------------------------- the prover
-def create_proof(ix: Index, witness: Sequence[Sequence[int]], rng: P.StdRng, prev_challenges=(), trace: Optional[dict] = None):
-    """ProverProof::create_recursive (prover.rs:187-1515) without runtime tables.  witness: 15 columns of equal length <= n - zk_rows;
-    prev_challenges: [(chals, comm chunks)].  Returns the proof as plain integers / affine points (None = infinity):
+def create_proof(ix: Index, witness: Sequence[Sequence[int]], rng: P.StdRng, prev_challenges=(), trace: Optional[dict] = None, runtime_tables=()):
+    """ProverProof::create_recursive (prover.rs:187-1515).  witness: 15 columns of equal length <= n - zk_rows;
+    prev_challenges: [(chals, comm chunks)]; runtime_tables: [(id, data)] in the configured order (RuntimeTable, runtime_tables.rs:52-58).  Returns the proof as plain integers / affine points (None = infinity):
     w_comm, z_comm, t_comm, lookup, opening, evals (each a pair of chunk lists), ft_eval1, prev_challenges."""
     curve, cs, srs = ix.curve, ix.cs, ix.srs
     F = curve.scalar; p = F.p
@@ -256,10 +257,26 @@ def create_proof(ix: Index, witness: Sequence[Sequence[int]], rng: P.StdRng, pre
     lk = None
     types = cs["gate_types"]
     if lcs is not None:
+        rt = None
+        if lcs.runtime_selector is not None:                   # prover.rs:397-470
+            assert [(i, len(d)) for i, d in runtime_tables] == lcs.runtime_tables, "RuntimeTablesInconsistent"
+            rte = [0] * n
+            off = lcs.runtime_offset
+            for _id, data in runtime_tables:
+                rte[off:off + len(data)] = [v % p for v in data]
+                off += len(data)
+            for r in range(n - 1, n - 1 - zk, -1):             # zero-knowledge rows, from the last row backwards
+                rte[r] = rand()
+            rt_poly = P.ntt(F, rte, logn, inverse=True)
+            com = srs.commit_non_hiding(rt_poly, nch)
+            rt_blind = [rand() for _ in com]
+            rt_comm = srs.mask(com, rt_blind)
+            fq.absorb_g(rt_comm)
+            rt = {"evals": rte, "poly": rt_poly, "blind": rt_blind, "comm": rt_comm, "sel_poly": P.ntt(F, lcs.runtime_selector, logn, inverse=True)}
         jc = P.challenge_to_field(F, fq.challenge() if lcs.info.joint_lookup_used else 0, endo_r)
-        table = lcs.joint_table(jc)
+        table = lcs.joint_table(jc, rt["evals"] if rt else None)
         table_poly = P.ntt(F, table, logn, inverse=True)
-        srt = L.sorted_columns(lcs, types, w, jc)
+        srt = L.sorted_columns(lcs, types, w, jc, table=table)
         srt = [L.zk_patch(c, n, zk, [rand() for _ in range(zk)]) for c in srt]
         s_blind, s_comm = [], []
         for c in srt:                                          # commit_evaluations(d1, v, rng): non-hiding, then one blinder per chunk
@@ -268,11 +285,11 @@ def create_proof(ix: Index, witness: Sequence[Sequence[int]], rng: P.StdRng, pre
             s_blind.append(bl); s_comm.append(srs.mask(com, bl))
         for c in s_comm:
             fq.absorb_g(c)
-        lk = {"jc": jc, "table": table, "table_poly": table_poly, "sorted": srt, "s_blind": s_blind, "s_comm": s_comm,
+        lk = {"jc": jc, "table": table, "table_poly": table_poly, "sorted": srt, "s_blind": s_blind, "s_comm": s_comm, "rt": rt,
               "sorted_poly": [P.ntt(F, c, logn, inverse=True) for c in srt]}
     beta = fq.challenge(); gamma = fq.challenge()
     if lk is not None:                                         # prover.rs:635-673
-        agg = L.aggregation(lcs, types, w, lk["jc"], beta, gamma, lk["sorted"], None, draw=rand)
+        agg = L.aggregation(lcs, types, w, lk["jc"], beta, gamma, lk["sorted"], None, draw=rand, table=lk["table"])
         assert agg[n - zk - 1] == 1, "aggregation incorrect"
         com = srs.commit_evaluations_non_hiding(logn, agg)
         a_blind = [rand() for _ in com]
@@ -317,6 +334,8 @@ def create_proof(ix: Index, witness: Sequence[Sequence[int]], rng: P.StdRng, pre
         ev["lookup_sorted"] = [ec(q) for q in lk["sorted_poly"]]
         lk_sel_poly = {q: interp(lcs.selectors[q]) for q in lcs.info.patterns}
         ev["lookup_selectors"] = {q: ec(lk_sel_poly[q]) for q in lcs.info.patterns}
+        if lk["rt"] is not None:
+            ev["runtime_lookup_table"] = ec(lk["rt"]["poly"]); ev["runtime_lookup_table_selector"] = ec(lk["rt"]["sel_poly"])
     zeta_srs = pow(zeta, size, p); zetaw_srs = pow(zetaw, size, p)
     zeta_n = pow(zeta, n, p)
     comb = lambda e: (_horner(p, e[0], zeta_srs), _horner(p, e[1], zetaw_srs))          # ProofEvaluations::combine (proof.rs:430-470)
@@ -348,7 +367,8 @@ def create_proof(ix: Index, witness: Sequence[Sequence[int]], rng: P.StdRng, pre
     lk_sponge, lk_open = [], []
     if lk is not None:
         sels = [ev["lookup_selectors"][q] for q in K.LOOKUP_PATTERN_ORDER if q in ev["lookup_selectors"]]
-        lk_sponge = [ev["lookup_aggregation"], ev["lookup_table"]] + ev["lookup_sorted"] + sels
+        rts = [ev["runtime_lookup_table"], ev["runtime_lookup_table_selector"]] if lk["rt"] is not None else []
+        lk_sponge = [ev["lookup_aggregation"], ev["lookup_table"]] + ev["lookup_sorted"] + rts + sels
     for e in order + lk_sponge:
         fr.absorb(e[0]); fr.absorb(e[1])
     v = P.challenge_to_field(F, fr.squeeze() & ((1 << 128) - 1), endo_r)
@@ -367,13 +387,18 @@ def create_proof(ix: Index, witness: Sequence[Sequence[int]], rng: P.StdRng, pre
         base = 0 if not lcs.table_cols else 1
         for _ in range(1, len(lcs.table_cols)):
             base = (1 + jc_ * base) % p
-        plnms.append((lk["table_poly"], [(base + tic_) % p] * nch))
+        if lk["rt"] is not None:                               # prover.rs:1402-1432: the runtime column's blinders enter the table's through the joint combiner
+            plnms.append((lk["table_poly"], [(jc_ * b_ + base + tic_) % p for b_ in lk["rt"]["blind"]]))
+            plnms.append((lk["rt"]["poly"], lk["rt"]["blind"]))
+            plnms.append((lk["rt"]["sel_poly"], zeros))
+        else:
+            plnms.append((lk["table_poly"], [(base + tic_) % p] * nch))
         plnms += [(lk_sel_poly[q], zeros) for q in K.LOOKUP_PATTERN_ORDER if q in lk_sel_poly]
     opening = P.ipa_open(curve, [None] * size, srs.h, plnms, [zeta, zetaw], v, u, fq_before, rng,
                          rounds_backend=lambda a, b, u_base: _Rounds(srs, a, b, u_base))
     proof = {"w_comm": w_comm, "z_comm": z_comm, "t_comm": t_comm, "evals": ev, "ft_eval1": ft_eval1,
              "opening": {k: opening[k] for k in ("lr", "delta", "z1", "z2", "sg")},
-             "lookup": None if lk is None else {"sorted": lk["s_comm"], "aggreg": lk["a_comm"], "runtime": None},
+             "lookup": None if lk is None else {"sorted": lk["s_comm"], "aggreg": lk["a_comm"], "runtime": lk["rt"]["comm"] if lk["rt"] else None},
              "prev_challenges": [(list(c), list(m)) for c, m in prev_challenges],
              "challenges": {"beta": beta, "gamma": gamma, "alpha": alpha, "zeta": zeta, "v": v, "u": u, "joint_combiner": lk["jc"] if lk else None}}
     return proof
@@ -424,6 +449,8 @@ def _quotient(ix: Index, w_poly, z_poly, public_poly, lk, alpha, beta, gamma) ->
                "sel": {q: lde(interp(lcs.selectors[q])) for q in lcs.info.patterns},
                "l0": lde(unnormalized_lagrange_poly(p, omega, n, 0)), "lfinal": lde(unnormalized_lagrange_poly(p, omega, n, -(zk + 1)))}
         lalpha = [pow(alpha, K.ALPHA_LOOKUP0 + k, p) for k in range(16)]
+        if lk["rt"] is not None:
+            lkc["rt"] = lde(lk["rt"]["poly"]); lkc["rtsel"] = lde(lk["rt"]["sel_poly"])
     f8 = [0] * n8
     for i in range(n8):
         x = x8[i]
@@ -463,6 +490,8 @@ def _quotient(ix: Index, w_poly, z_poly, public_poly, lk, alpha, beta, gamma) ->
                 vanish = vanish * ((x - pow(omega, k, p)) % p) % p
             atoms = {"vanish": vanish, "l0": lkc["l0"][i], "lfinal": lkc["lfinal"][i]}
             vals = L.constraint_values(cs["lookup"], lk["jc"], beta, gamma, cell, atoms)
+            if lk["rt"] is not None:                           # runtime_tables::constraints, at position 3 + 4 (constraints.rs:658-680)
+                vals.append(lkc["rt"][i] * lkc["rtsel"][i] % p)
             for k, val in enumerate(vals):
                 acc = (acc + lalpha[k] * val) % p
         f8[i] = acc

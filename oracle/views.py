@@ -47,8 +47,10 @@ def device_views(ix, proof):
         vix["lookup_index"] = {"joint_lookup_used": LI.joint_lookup_used, "lookup_table": [ch(t) for t in LI.table_comm],
                                "lookup_selectors": {q: (ch(LI.selector_comm[q]) if q in LI.patterns else None) for q in K.LOOKUP_PATTERN_ORDER},
                                "table_ids": ch(LI.table_ids_comm) if LI.table_ids_comm else None, "max_per_row": LI.max_per_row,
-                               "max_joint_size": LI.max_joint_size, "patterns": list(LI.patterns), "uses_runtime_tables": False, "runtime_tables_selector": None}
-        pr["lookup"] = {"sorted": [ch(t) for t in proof["lookup"]["sorted"]], "aggreg": ch(proof["lookup"]["aggreg"]), "runtime": None}
+                               "max_joint_size": LI.max_joint_size, "patterns": list(LI.patterns), "uses_runtime_tables": LI.runtime_selector is not None,
+                               "runtime_tables_selector": ch(LI.runtime_selector_comm) if getattr(LI, "runtime_selector_comm", None) else None}
+        rt = proof["lookup"].get("runtime")
+        pr["lookup"] = {"sorted": [ch(t) for t in proof["lookup"]["sorted"]], "aggreg": ch(proof["lookup"]["aggreg"]), "runtime": ch(rt) if rt is not None else None}
     return c, vix, pr
 
 

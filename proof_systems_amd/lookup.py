@@ -52,7 +52,9 @@ class LookupIndex:
     """LookupConstraintSystem::create without runtime tables: the selector columns, the concatenated table columns and
     the table-id column as d1 evaluations on the device (+ host copies as integers for `sorted`)."""
 
-    def __init__(self, fid: int, gates: Sequence[str], fixed_tables, log2_n: int, zk_rows: int = 3):
+    def __init__(self, fid: int, gates: Sequence[str], fixed_tables, log2_n: int, zk_rows: int = 3, runtime_tables=None):
+        """runtime_tables: None or [{"id", "first_column"}] (RuntimeTableCfg): tables whose first column is fixed in the index and whose
+        second column arrives with each proof (index.rs:241-311)."""
         self.fid, self.F = fid, Fld(fid)
         self.logn, self.n, self.zk_rows = log2_n, 1 << log2_n, zk_rows
         n, p = self.n, self.F.p
@@ -74,6 +76,17 @@ class LookupIndex:
         self.max_joint_size = OP.lookup_max_joint_size(self.patterns)
         self.joint_lookup_used = self.max_joint_size > 1
         tables = list(fixed_tables) + [gate_table(t) for t in sorted(gate_tables, key=lambda t: 0 if t == "RangeCheck" else 1)]
+        self.runtime_tables = None if runtime_tables is None else [(rt["id"], len(rt["first_column"])) for rt in runtime_tables]
+        self.runtime_offset, self.runtime_selector = None, None
+        if runtime_tables is not None:
+            if len({rt["id"] for rt in runtime_tables}) != len(runtime_tables):
+                raise ValueError("runtime table duplicates")
+            self.runtime_offset = sum(len(t["data"][0]) for t in tables)
+            rlen = sum(len(rt["first_column"]) for rt in runtime_tables)
+            rsel = [1] * self.runtime_offset + [0] * rlen + [1] * (n - self.runtime_offset - rlen)
+            rsel[n - zk_rows:] = [0] * zk_rows
+            self.runtime_selector = rsel
+            tables += [{"id": rt["id"], "data": [list(rt["first_column"]), [0] * len(rt["first_column"])]} for rt in runtime_tables]
         ids = [t["id"] for t in tables]
         if len(set(ids)) != len(ids):
             raise ValueError("lookup table id collision")
@@ -97,6 +110,7 @@ class LookupIndex:
         self.d_selectors = {q: up(self.selectors[q]) for q in self.patterns}
         self.d_table_cols = [up(c) for c in self.table_cols]
         self.d_table_ids = up(self.table_ids) if self.table_ids is not None else None
+        self.d_runtime_selector = up(self.runtime_selector) if self.runtime_selector is not None else None
 
     def combiners(self, joint_combiner: int):
         p = self.F.p
@@ -108,22 +122,28 @@ class LookupIndex:
         return joint_combiner % self.F.p, pow(joint_combiner, self.max_joint_size, self.F.p)
 
     # ---- the combined table (prover.rs:500-572) on the device: Horner over the table columns + table_id_combiner * ids
-    def joint_table_dev(self, joint_combiner: int) -> "khip.DevBuf":
+    def joint_table_dev(self, joint_combiner: int, runtime_dev=None) -> "khip.DevBuf":
+        """runtime_dev: the proof's runtime contribution on d1 (added to the second table column, prover.rs:455-464)."""
         jc, tic = self.combiners(joint_combiner)
         ncol = len(self.d_table_cols)
-        toks = [OP.cell(ncol - 1)]
+        nb = ncol + (1 if self.d_table_ids is not None else 0)          # buffer index of the runtime column
+        col = lambda k: [OP.cell(k)] + ([OP.cell(nb), (OP.TOK_ADD, 0)] if (k == 1 and runtime_dev is not None) else [])
+        toks = col(ncol - 1)
         for k in range(ncol - 2, -1, -1):
-            toks += [(OP.TOK_CONST, 0), (OP.TOK_MUL, 0), OP.cell(k), (OP.TOK_ADD, 0)]
+            toks += [(OP.TOK_CONST, 0), (OP.TOK_MUL, 0)] + col(k) + [(OP.TOK_ADD, 0)]
         bufs = list(self.d_table_cols)
         if self.d_table_ids is not None:
             toks += [(OP.TOK_CONST, 1), OP.cell(ncol), (OP.TOK_MUL, 0), (OP.TOK_ADD, 0)]
             bufs.append(self.d_table_ids)
+        if runtime_dev is not None:
+            bufs.append(runtime_dev)
         out = khip.DevBuf(self.n * 32)
         khip.expr_evaluations_dev(self.fid, toks, bufs, [self.n] * len(bufs), self.F.limbs_many([jc, tic]), self.n, out, stride=1, next_shift=1)
         return out
 
     def free(self):
-        for b in list(self.d_selectors.values()) + self.d_table_cols + ([self.d_table_ids] if self.d_table_ids is not None else []):
+        for b in list(self.d_selectors.values()) + self.d_table_cols + ([self.d_table_ids] if self.d_table_ids is not None else []) + \
+                ([self.d_runtime_selector] if self.d_runtime_selector is not None else []):
             b.free()
 
 
@@ -188,6 +208,9 @@ def column_layout(ix: LookupIndex, w0: int = 0):
     c += len(ix.patterns)
     cols["vanish"], cols["l0"], cols["lfinal"] = c, c + 1, c + 2
     cols["count"] = c + 3
+    if ix.runtime_selector is not None:
+        cols["runtime"], cols["runtime_selector"] = c + 3, c + 4
+        cols["count"] = c + 5
     return cols
 
 
@@ -200,8 +223,8 @@ def aggregation_dev(ix: LookupIndex, d_witness, d_sorted, d_table, joint_combine
     lookup_rows = n - ix.zk_rows - 1
     (num_t, num_c), (den_t, den_c) = OP.lookup_aggregation_programs(F.p, ix.patterns, cols, jc, tic, beta, gamma)
     dummy = khip.DevBuf(32)                                      # columns the aggregation programs never touch
-    bufs = list(d_witness) + list(d_sorted) + [dummy, d_table] + [ix.d_selectors[q] for q in ix.patterns] + [dummy] * 3
-    lens = [n] * 15 + [n] * len(d_sorted) + [1, n] + [n] * len(ix.patterns) + [1] * 3
+    bufs = list(d_witness) + list(d_sorted) + [dummy, d_table] + [ix.d_selectors[q] for q in ix.patterns] + [dummy] * (cols["count"] - cols["vanish"])
+    lens = [n] * 15 + [n] * len(d_sorted) + [1, n] + [n] * len(ix.patterns) + [1] * (cols["count"] - cols["vanish"])
     num, den, agg = khip.DevBuf(n * 32), khip.DevBuf(n * 32), khip.DevBuf(n * 32)
     num.zero(); den.zero()
     khip.expr_evaluations_dev(fid, num_t, bufs, lens, F.limbs_many(num_c), lookup_rows, num, stride=1, next_shift=1, out_offset=1)

@@ -278,11 +278,17 @@ class ProverIndex:
             e = khip.DevBuf(8 * n * 32); khip.lde_dev(fid, c, logn, 3, e, 1)
             LI.sel_c[q], LI.sel8[q] = c, e
         LI.atoms8 = LK.atom_columns(LI, 3)
+        LI.rtsel_c = LI.rtsel8 = LI.runtime_selector_comm = None
+        if LI.d_runtime_selector is not None:                           # the runtime selector: coefficient form, d8, committed non-hiding
+            LI.rtsel_c = khip.DevBuf(n * 32); khip.dev_copy(LI.rtsel_c.ptr, LI.d_runtime_selector.ptr, n * 32); khip.ntt_dev(fid, LI.rtsel_c, logn, True, 1)
+            LI.rtsel8 = khip.DevBuf(8 * n * 32); khip.lde_dev(fid, LI.rtsel_c, logn, 3, LI.rtsel8, 1)
+            LI.runtime_selector_comm = self.commit_evals(LI.d_runtime_selector.ptr, 1)[0]
         ones = [1] * self.num_chunks
         LI.table_comm = [self.mask(self.commit_evals(b.ptr, 1), ones)[0] for b in LI.d_table_cols]
         LI.table_ids_comm = self.mask(self.commit_evals(LI.d_table_ids.ptr, 1), ones)[0] if LI.d_table_ids is not None else None
         LI.selector_comm = {q: self.commit_evals(LI.d_selectors[q].ptr, 1)[0] for q in LI.patterns}
-        self._digest(LI.table_comm + ([LI.table_ids_comm] if LI.table_ids_comm else []) + [LI.selector_comm[q] for q in LI.patterns])
+        self._digest(LI.table_comm + ([LI.table_ids_comm] if LI.table_ids_comm else []) + ([LI.runtime_selector_comm] if LI.runtime_selector_comm else []) +
+                     [LI.selector_comm[q] for q in LI.patterns])
         khip.sync()
 
     def free(self):
@@ -307,11 +313,13 @@ def _horner(p: int, coeffs, x: int) -> int:
     return acc
 
 
-def create_proof(ix: ProverIndex, witness, rng, timings=None, check: bool = True, witness_on_device=None, prev_challenges=(), all_gates: bool = False):
+def create_proof(ix: ProverIndex, witness, rng, timings=None, check: bool = True, witness_on_device=None, prev_challenges=(), all_gates: bool = False,
+                 runtime_tables=()):
     """ProverProof::create_recursive.  witness: (15, rows, 4) Montgomery limbs, rows <= n - zk_rows (padded with zeros, the last zk_rows
     rows randomised, prover.rs:254-266) -- or witness_on_device: a DevBuf already holding the padded (15, n, 4) columns.
     rng: the caller's generator (Fld.rand_many: blinders, zero-knowledge rows, in the reference's draw order).
     prev_challenges: [(chals as integers, (xy (chunks, 8), inf (chunks,)))] (RecursionChallenge, proof.rs:117-131).
+    runtime_tables: [(id, data as integers)] in the order the index configured them (RuntimeTable, lookup/runtime_tables.rs:52-58).
     Returns the proof as a dict of limb arrays / Python ints; evaluations are pairs of chunk lists (at zeta, at zeta omega)."""
     F, fid, n, logn, curve, srs = ix.F, ix.fid, ix.n, ix.log2_n, ix.curve, ix.srs
     size, nch, zk = ix.size, ix.num_chunks, ix.zk_rows
@@ -380,8 +388,24 @@ def create_proof(ix: ProverIndex, witness, rng, timings=None, check: bool = True
     lkp = None
     if LI is not None:                                      # prover.rs:383-633: joint combiner, combined table, sorted columns
         from . import lookup as LK
+        rt = None
+        if LI.runtime_selector is not None:                 # prover.rs:397-470: the runtime contribution to the table's second column
+            if [(i_, len(d_)) for i_, d_ in runtime_tables] != LI.runtime_tables:
+                raise ValueError("RuntimeTablesInconsistent")
+            rte = np.zeros((n, 4), dtype=np.uint64)
+            off = LI.runtime_offset
+            for _id, data in runtime_tables:
+                rte[off:off + len(data)] = F.limbs_many(list(data)); off += len(data)
+            rte[n - zk:] = F.limbs_many(F.rand_many(rng, zk))[::-1]             # zero-knowledge rows, drawn from the last row backwards
+            d_rt = khip.DevBuf(NB).upload(rte)
+            d_rtc = khip.DevBuf(NB); khip.dev_copy(d_rtc.ptr, d_rt.ptr, NB); khip.ntt_dev(fid, d_rtc, logn, True, 1)
+            rcom = ix.commit_coeffs(d_rtc.ptr, n, nch)       # srs.commit(&runtime_table_contribution, num_chunks, rng)
+            rt_blind = F.rand_many(rng, len(rcom[1]))
+            rt_comm = ix.mask([rcom], rt_blind)[0]
+            fq.absorb_g(rt_comm[0], rt_comm[1])
+            rt = {"d": d_rt, "c": d_rtc, "blind": rt_blind, "comm": rt_comm}
         jc = scalar_challenge(curve, F, fq.challenge() if LI.joint_lookup_used else 0)
-        d_table = LI.joint_table_dev(jc)
+        d_table = LI.joint_table_dev(jc, rt["d"] if rt else None)
         table_ints = F.values(d_table.download((n, 4)))
         wcols = ev.download((COLUMNS, n, 4))
         used = sorted({c for q in LI.patterns for tid, entry in OP.LOOKUP_PATTERNS[q] for c in (list(entry) + ([tid[1]] if isinstance(tid, tuple) else []))})
@@ -395,7 +419,7 @@ def create_proof(ix: ProverIndex, witness, rng, timings=None, check: bool = True
             s_blind.append(bl_); s_comm.append(cm)
         for c_, i_ in s_comm:
             fq.absorb_g(c_, i_)
-        lkp = {"jc": jc, "d_table": d_table, "d_sorted": d_sorted, "s_blind": s_blind, "s_comm": s_comm}
+        lkp = {"jc": jc, "d_table": d_table, "d_sorted": d_sorted, "s_blind": s_blind, "s_comm": s_comm, "rt": rt}
     mark("witness_commit")
     beta = F.value(fq.challenge_field()); gamma = F.value(fq.challenge_field())
     if lkp is not None:                                     # prover.rs:635-673: the lookup aggregation, committed before z
@@ -464,6 +488,9 @@ def create_proof(ix: ProverIndex, witness, rng, timings=None, check: bool = True
         _, tic_expr = LI.constraint_combiners(lkp["jc"])
         ltoks, lconsts = OP.lookup_program(F.p, LI.patterns, cols, lkp["jc"], tic_expr, beta, gamma, alpha, alpha0=ALPHA_PERM0 + 3)
         lbufs = [e8.view(i * N8) for i in range(COLUMNS)] + [lk8.view(k_ * N8) for k_ in range(nl)] + [LI.sel8[q] for q in LI.patterns] + list(LI.atoms8)
+        if lkp["rt"] is not None:                           # RT(x) * selector_RT(x) (runtime_tables.rs:59-66)
+            rt8 = khip.DevBuf(N8); khip.lde_dev(fid, lkp["rt"]["c"], logn, 3, rt8, 1)
+            lbufs += [rt8, LI.rtsel8]; lkp["rt"]["d8"] = rt8
         assert len(lbufs) == cols["count"]
         khip.expr_evaluations_dev(fid, ltoks, lbufs, [8 * n] * len(lbufs), F.limbs_many(lconsts), 8 * n, t8, stride=1, next_shift=8, accumulate=True)
         lkp.update({"lkc": lkc, "lk8": lk8, "nl": nl})
@@ -500,7 +527,8 @@ def create_proof(ix: ProverIndex, witness, rng, timings=None, check: bool = True
             [ix.colc(COLUMNS + 2 + i) for i in range(PERMUTS - 1)] + [ix.colc(ix.OPT0 + k_) for k_ in range(len(ix.optional))]
     lk_polys = []
     if lkp is not None:                                     # opening order (prover.rs:1368-1420): sorted ..., aggregation, combined table, pattern selectors
-        lk_polys = [lkp["lkc"].view(k_ * NB) for k_ in range(lkp["nl"])] + [LI.sel_c[q] for q in LI.patterns]
+        rt_polys = [lkp["rt"]["c"], LI.rtsel_c] if lkp["rt"] is not None else []     # ... combined table, runtime table, runtime selector, pattern selectors
+        lk_polys = [lkp["lkc"].view(k_ * NB) for k_ in range(lkp["nl"])] + rt_polys + [LI.sel_c[q] for q in LI.patterns]
     pts = F.limbs_many([zeta, zetaw])
     npoly = len(polys) + len(lk_polys)
     evl = khip.evaluate_chunks_batch_dev(fid, polys + lk_polys, [n] * npoly, [nch] * npoly, size, pts)
@@ -517,10 +545,14 @@ def create_proof(ix: ProverIndex, witness, rng, timings=None, check: bool = True
     L0 = 43 + no
     if lkp is not None:
         ns = len(lkp["d_sorted"])
+        nr = 2 if lkp["rt"] is not None else 0
         evals["lookup_sorted"] = E[L0:L0 + ns]; evals["lookup_aggregation"] = E[L0 + ns]; evals["lookup_table"] = E[L0 + ns + 1]
-        evals["lookup_selectors"] = {q: E[L0 + ns + 2 + k_] for k_, q in enumerate(LI.patterns)}
+        if nr:
+            evals["runtime_lookup_table"], evals["runtime_lookup_table_selector"] = E[L0 + ns + 2], E[L0 + ns + 3]
+        evals["lookup_selectors"] = {q: E[L0 + ns + 2 + nr + k_] for k_, q in enumerate(LI.patterns)}
         lk_evals_open = E[L0:]
-        lk_evals_sponge = [evals["lookup_aggregation"], evals["lookup_table"]] + list(evals["lookup_sorted"]) + [evals["lookup_selectors"][q] for q in LI.patterns]
+        lk_evals_sponge = [evals["lookup_aggregation"], evals["lookup_table"]] + list(evals["lookup_sorted"]) + list(E[L0 + ns + 2:L0 + ns + 2 + nr]) + \
+                          [evals["lookup_selectors"][q] for q in LI.patterns]
     # ---- ft = perm_scalar * sigma_6 - (zeta^n - 1) * t, both chunk-linearised with zeta^max_poly_size (Maller; prover.rs:1147-1200)
     zeta1 = pow(zeta, n, F.p)
     zeta_srs = pow(zeta, size, F.p); zetaw_srs = pow(zetaw, size, F.p)
@@ -574,7 +606,11 @@ def create_proof(ix: ProverIndex, witness, rng, timings=None, check: bool = True
     if lkp is not None:                                     # the combined table's blinder: sum_i jc^i over its masked columns + the table-id combiner (prover.rs:1384-1400)
         jc_, tic_ = LI.combiners(lkp["jc"])
         tb = sum(pow(jc_, i, F.p) for i in range(len(LI.table_cols))) + tic_
-        blinders += [x for bl_ in lkp["s_blind"] for x in bl_] + lkp["a_blind"] + [tb % F.p] * nch + zeros_c * len(LI.patterns)
+        if lkp["rt"] is not None:                           # the runtime column's blinders enter the combined table's through the joint combiner (prover.rs:1402-1415)
+            tbl = [(jc_ * b_ + tb) % F.p for b_ in lkp["rt"]["blind"]] + lkp["rt"]["blind"] + zeros_c
+        else:
+            tbl = [tb % F.p] * nch
+        blinders += [x for bl_ in lkp["s_blind"] for x in bl_] + lkp["a_blind"] + tbl + zeros_c * len(LI.patterns)
     for chals, _c in prev_challenges:
         ln = 1 << len(chals)
         ch_l = list(chals)
@@ -610,8 +646,8 @@ def create_proof(ix: ProverIndex, witness, rng, timings=None, check: bool = True
         pub_c.free()
     lk_out = {}
     if lkp is not None:
-        lk_out = {"lookup": {"sorted": lkp["s_comm"], "aggreg": lkp["a_comm"]}}
-        for b in lkp["d_sorted"] + [lkp["d_agg"], lkp["d_table"], lkp["lkc"], lkp["lk8"]]:
+        lk_out = {"lookup": {"sorted": lkp["s_comm"], "aggreg": lkp["a_comm"], "runtime": lkp["rt"]["comm"] if lkp["rt"] else None}}
+        for b in lkp["d_sorted"] + [lkp["d_agg"], lkp["d_table"], lkp["lkc"], lkp["lk8"]] + ([lkp["rt"]["d"], lkp["rt"]["c"], lkp["rt"]["d8"]] if lkp["rt"] else []):
             b.free()
     if timings is not None:
         prev = t_start

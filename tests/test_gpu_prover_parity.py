@@ -37,7 +37,7 @@ def _limbs(F, vals):
     return cref.ints_to_limbs([F.to_mont(v % F.p) for v in vals])
 
 
-def device_index(khip, cs, curve_id, srs):
+def device_index(khip, cs, curve_id, srs, runtime_cfg=None):
     """A proof_systems_amd.prover.ProverIndex for a constraint system of oracle/circuit.py::build (the circuit description is the
     caller's in the reference too: gates, wires, coefficients)."""
     from proof_systems_amd import prover, lookup as LK
@@ -47,7 +47,7 @@ def device_index(khip, cs, curve_id, srs):
     ix = prover.ProverIndex(curve_id, cs["log2_n"], co, srs=srs, gate_types=cs["gate_types"][:rows], public=cs["public"], zk_rows=cs["zk_rows"])
     ix.set_wiring([g["wires"] for g in cs["gates"][:rows]])
     if cs["lookup"] is not None:
-        ix.attach_lookup(LK.LookupIndex(ix.fid, cs["gate_types"], [], cs["log2_n"], cs["zk_rows"]))
+        ix.attach_lookup(LK.LookupIndex(ix.fid, cs["gate_types"], [], cs["log2_n"], cs["zk_rows"], runtime_tables=runtime_cfg))
     return ix
 
 
@@ -237,4 +237,47 @@ def test_optional_gate_circuit_proof_equals_the_oracle_provers_proof(khip):
     c, vix, pr = V.device_views(ix, dproof)
     assert compare(C, oproof, pr) is None, compare(C, oproof, pr)
     assert OPR.serialize_proof(C, pr) == OPR.serialize_proof(C, oproof)
+    ix.free()
+
+
+def runtime_table_circuit(F, seed=5):
+    """kimchi/src/tests/lookup.rs:249-330 (test_runtime_table): 20 Lookup gates into five runtime tables with ids 1..5, first column
+    [8, 9, 8, 7, 1] fixed in the index, second column [0, 2, 3, 4, 5] supplied with the proof."""
+    import random
+    rnd = random.Random(seed)
+    first, data = [8, 9, 8, 7, 1], [0, 2, 3, 4, 5]
+    cfg = [{"id": tid, "first_column": list(first)} for tid in range(1, 6)]
+    rts = [(c["id"], list(data)) for c in cfg]
+    gates = [CC.gate("Lookup", r) for r in range(20)]
+    wit = [[0] * 20 for _ in range(15)]
+    for r in range(20):
+        wit[0][r] = rnd.randrange(1, 6)
+        for k in range(3):
+            idx = rnd.randrange(5)
+            wit[1 + 2 * k][r], wit[2 + 2 * k][r] = first[idx], data[idx]
+    return CC.build(F, gates, runtime_tables=cfg), cfg, rts, wit
+
+
+def test_runtime_table_proof_equals_the_oracle_provers_proof(khip):
+    """Runtime tables (prover.rs:397-470): the proof's contribution to the table's second column is committed first, enters the combined
+    table through the joint combiner (blinders included), is evaluated and opened with its selector, and adds one lookup constraint."""
+    from proof_systems_amd import prover
+    C = P.VESTA; F = C.scalar
+    cs, cfg, rts, wit = runtime_table_circuit(F)
+    seed = bytes([61] * 32)
+    osrs = OPR.Srs(C, 1 << cs["log2_n"])
+    oix = OPR.Index(C, cs, osrs)
+    oproof = OPR.create_proof(oix, wit, P.StdRng(seed), runtime_tables=rts)
+    assert K.verify(C, dict(oix.vindex), oproof, None, osrs.h, P.StdRng(bytes([5] * 32)), final_msm=V.final_msm_c(C, osrs.g, osrs.size))
+    srs = khip.Srs.create(khip.VESTA, 1 << cs["log2_n"])
+    ix = device_index(khip, cs, khip.VESTA, srs, runtime_cfg=cfg)
+    c, vix, _ = V.device_views(ix, None)
+    assert K.verifier_index_digest(C, vix | {"lookup_index": None}) is not None
+    dproof = prover.create_proof(ix, np.stack([_limbs(F, col) for col in wit]), V.RefRng(P.StdRng(seed)), runtime_tables=rts)
+    c, vix, pr = V.device_views(ix, dproof)
+    assert vix["lookup_index"]["runtime_tables_selector"] == oix.vindex["lookup_index"]["runtime_tables_selector"]
+    assert compare(C, oproof, pr) is None, compare(C, oproof, pr)
+    assert OPR.serialize_proof(C, pr) == OPR.serialize_proof(C, oproof)
+    with pytest.raises(ValueError):
+        prover.create_proof(ix, np.stack([_limbs(F, col) for col in wit]), V.RefRng(P.StdRng(seed)), runtime_tables=rts[:4])      # RuntimeTablesInconsistent
     ix.free()
