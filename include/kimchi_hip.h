@@ -224,6 +224,22 @@ int kh_expr_evaluations_dev(int field, const uint32_t *tokens, size_t ntok, cons
                             size_t ncols, const uint64_t *constants, size_t nconsts, size_t rows, unsigned stride,
                             unsigned next_shift, int accumulate, uint64_t *out_dev);
 
+/* The gate library (kimchi/src/circuits/polynomials/{poseidon,complete_add,varbasemul,endosclmul,endomul_scalar,xor,rot}.rs, range_check/, foreign_field_add/,
+ * foreign_field_mul/) as COMPILED kernels: index(gate) * sum_i alpha^i constraint_i per row (prover.rs:824-868), the same value the token program of that gate
+ * gives through kh_expr_evaluations_dev, several times faster (no operand stack in LDS).  cols_dev: 31 device columns of col_len elements -- witness 0..14,
+ * coefficients 15..29, the gate's selector 30 --, addressed like KH_TOK_CELL (stride, next_shift); constants: the table the caller builds for the gate
+ * (literals, MDS entries, the endo coefficient, powers of alpha: kh_gate_num_constants entries, layout fixed per gate at build time by
+ * tools/gen_gate_kernels.py -- proof_systems_amd/polish.py::gate_program returns it).  Gates are numbered 0 .. kh_gate_count() - 1; kh_gate_name gives the
+ * reference's GateType name.  Two more ids follow the library, for the arguments every circuit has: "Generic" (generic.rs:100-131; witness 0..5, coefficients
+ * 15..24, the generic selector 30; constants [1, alpha]) and "Permutation" (permutation.rs:225-288: alpha0 zkpm (z prod_i (w_i + gamma + x beta shift_i) -
+ * z(xw) prod_i (w_i + gamma + sigma_i beta)); witness 0..6, sigma_i at 15 + i, z 22, x 23, zkpm 24; constants [gamma, beta, alpha0, beta shift_0..6]).
+ * Columns an expression does not read may be any valid pointer. */
+int kh_gate_count(void);
+const char *kh_gate_name(int gate);
+int kh_gate_num_constants(int gate);
+int kh_gate_evaluations_dev(int field, int gate, const uint64_t *const *cols_dev, size_t col_len, const uint64_t *constants, size_t nconsts,
+                            size_t rows, unsigned stride, unsigned next_shift, int accumulate, uint64_t *out_dev);
+
 /* ---- scans, batch inversion, division by a linear factor: the permutation argument's vector steps ----
  * kh_field_scan_dev: in-place inclusive prefix (reverse = 0) or suffix (reverse = 1) scan under + or *
  *   (the running product z[j+1] = z[j] * ..., kimchi/src/circuits/polynomials/permutation.rs:556-563).

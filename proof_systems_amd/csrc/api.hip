@@ -1085,6 +1085,21 @@ int kh_expr_evaluations_dev(int field, const uint32_t* tokens, size_t ntok, cons
     return rc;
 }
 
+int kh_gate_count(void) { return gate_count(); }
+const char* kh_gate_name(int gate) { return gate_name(gate); }
+int kh_gate_num_constants(int gate) { return gate_num_constants(gate); }
+int kh_gate_evaluations_dev(int field, int gate, const uint64_t* const* cols_dev, size_t col_len, const uint64_t* constants, size_t nconsts, size_t rows,
+                            unsigned stride, unsigned next_shift, int accumulate, uint64_t* out_dev) {
+    KH_REQUIRE(field == KH_FIELD_FP || field == KH_FIELD_FQ, "unknown field id %d", field);
+    KH_REQUIRE(cols_dev && constants && (out_dev || rows == 0) && stride > 0, "kh_gate_evaluations_dev: bad argument");
+    int rc = ensure_init(); if (rc) return rc;
+    Context& C = ctx();
+    std::lock_guard<std::mutex> lk(C.mu);
+    rc = gate_run(C, field, gate, cols_dev, col_len, constants, nconsts, rows, stride, next_shift, accumulate, out_dev);
+    if (rc == KH_OK) C.mark_async();
+    return rc;
+}
+
 // ---------------------------------------------------------------------------------- challenge polynomials (verifier side)
 #define g_bp_chals (kh::ctx().scratch("bp_chals"))
 #define g_bp_out (kh::ctx().scratch("bp_out"))

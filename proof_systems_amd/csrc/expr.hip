@@ -36,7 +36,7 @@ __device__ __forceinline__ Fe<F> lds_get(const u32* lds, int slot) {
 template <class F>
 __global__ void __launch_bounds__(EXPR_T)
 k_expr(const u32* __restrict__ prog, u32 ntok, const u64* const* __restrict__ cols, const u64* __restrict__ col_len,
-       const u64* __restrict__ consts, size_t rows, u32 stride, u32 next_shift, int stack_slots, int accumulate, u64* __restrict__ out) {
+       const u64* __restrict__ consts, size_t rows, u32 stride, u32 next_shift, int stack_slots, int accumulate, int nowrap, u64* __restrict__ out) {
     extern __shared__ u32 lds[];
     const size_t i = (size_t)blockIdx.x * EXPR_T + threadIdx.x;
     const size_t row = i < rows ? i : rows - 1;          // idle lanes shadow the last row (uniform control flow)
@@ -56,7 +56,10 @@ k_expr(const u32* __restrict__ prog, u32 ntok, const u64* const* __restrict__ co
                 else if (op == KH_TOK_CELL) {
                     const u32 c = arg >> 1;
                     const size_t len = col_len[c];
-                    const size_t idx = ((size_t)stride * row + ((arg & 1u) ? next_shift : 0u)) % len;
+                    size_t idx = (size_t)stride * row + ((arg & 1u) ? next_shift : 0u);
+                    // a 64-bit remainder is ~100 VALU instructions per cell read; when stride * rows <= len and the shift < len (every call
+                    // of the provers: `nowrap`, decided on the host) the index wraps at most once
+                    if (nowrap) { if (idx >= len) idx -= len; } else idx %= len;
                     top = Fe<F>::load(cols[c] + 4 * idx);
                 } else if (op == KH_TOK_LOAD) top = lds_get<F>(lds, stack_slots + (int)arg);
                 /* DUP: top unchanged */
@@ -114,7 +117,11 @@ int expr_run(Context& C, int field, const uint32_t* prog, size_t ntok, const uin
     int rc = expr_check(prog, ntok, ncols, nconsts, &slots, &cslots); if (rc) return rc;
     const size_t lds = (size_t)(slots + cslots) * 32 * EXPR_T;
     KH_REQUIRE(lds <= 160 * 1024, "expression needs %d stack + %d cache slots: more than the 160 KB of LDS holds for %d rows", slots, cslots, EXPR_T);
-    for (size_t c = 0; c < ncols; c++) KH_REQUIRE(col_len[c] > 0 && cols_dev[c], "column %zu is empty", c);
+    int nowrap = 1;
+    for (size_t c = 0; c < ncols; c++) {
+        KH_REQUIRE(col_len[c] > 0 && cols_dev[c], "column %zu is empty", c);
+        if (!((size_t)stride * (rows ? rows - 1 : 0) < col_len[c] && next_shift < col_len[c])) nowrap = 0;
+    }
     if (rows == 0) return KH_OK;
     const size_t bytes = ntok * 8 + ncols * 16 + nconsts * 32 + 64;
     if ((rc = g_expr_tab.reserve(bytes))) return rc;
@@ -131,10 +138,10 @@ int expr_run(Context& C, int field, const uint32_t* prog, size_t ntok, const uin
     C.timer.begin(s);
     if (field == KH_FIELD_FP)
         hipLaunchKernelGGL((k_expr<FpParams>), grid, dim3(EXPR_T), lds, s, (const u32*)d_prog, (u32)ntok, (const u64* const*)d_cols, (const u64*)d_len,
-                           (const u64*)d_consts, rows, (u32)stride, (u32)next_shift, slots, accumulate, out_dev);
+                           (const u64*)d_consts, rows, (u32)stride, (u32)next_shift, slots, accumulate, nowrap, out_dev);
     else
         hipLaunchKernelGGL((k_expr<FqParams>), grid, dim3(EXPR_T), lds, s, (const u32*)d_prog, (u32)ntok, (const u64* const*)d_cols, (const u64*)d_len,
-                           (const u64*)d_consts, rows, (u32)stride, (u32)next_shift, slots, accumulate, out_dev);
+                           (const u64*)d_consts, rows, (u32)stride, (u32)next_shift, slots, accumulate, nowrap, out_dev);
     KH_HIP(hipGetLastError());
     C.timer.mark("expr", s);
     return KH_OK;                 // asynchronous on the main stream, like kh_ntt_dev

@@ -56,6 +56,12 @@ int poly_scan(Context& C, int field, int op, int rev, uint64_t* data_dev, size_t
 int poly_batch_inversion(Context& C, int field, uint64_t* v_dev, size_t n);
 int poly_divide_by_linear(Context& C, int field, const uint64_t* f_dev, size_t len, const uint64_t a[4], uint64_t* q_dev, uint64_t rem[4]);
 // expr.hip
+// the gate library as compiled kernels (gates.hip; generated from the same expression DAGs as the token programs)
+int gate_count();
+const char* gate_name(int gate);
+int gate_num_constants(int gate);
+int gate_run(Context& C, int field, int gate, const uint64_t* const* cols_dev, size_t len, const uint64_t* consts, size_t nconsts, size_t rows,
+             unsigned stride, unsigned next_shift, int accumulate, uint64_t* out_dev);
 int expr_run(Context& C, int field, const uint32_t* prog, size_t ntok, const uint64_t* const* cols_dev, const size_t* col_len, size_t ncols,
              const uint64_t* consts, size_t nconsts, size_t rows, unsigned stride, unsigned next_shift, int accumulate, uint64_t* out_dev);
 // host_srs.cpp

@@ -37,7 +37,7 @@ SYMBOLS = [
     "kh_dev_alloc", "kh_dev_free", "kh_dev_upload", "kh_dev_download", "kh_dev_upload_2d",
     "kh_msm_batch_dev", "kh_ntt_dev", "kh_lde_dev", "kh_coset_ntt_dev", "kh_sync", "kh_last_timings",
     "kh_debug_field_op", "kh_debug_point_op", "kh_srs_generate", "kh_srs_h",
-    "kh_msm_sharded", "kh_msm_sharded_dev",
+    "kh_msm_sharded", "kh_msm_sharded_dev", "kh_gate_count", "kh_gate_name", "kh_gate_num_constants", "kh_gate_evaluations_dev",
     "kh_commit_non_hiding", "kh_commit_evaluations_non_hiding", "kh_srs_set_blinding_base",
     "kh_srs_get_blinding_base", "kh_mask_custom", "kh_domain_generator", "kh_msm_points_batch", "kh_msm_submit", "kh_msm_wait",
     "kh_ipa_fold_scalars", "kh_inner_product", "kh_ipa_fold_points", "kh_ipa_fold_points_endo", "kh_endos", "kh_scalar_challenge_to_field",
@@ -555,6 +555,31 @@ def expr_evaluations_dev(field: int, tokens, cols, col_len, constants, rows: int
     cs = _c64(constants, (-1, 4))
     _check(_lib.kh_expr_evaluations_dev(field, tk.ctypes.data_as(C.POINTER(C.c_uint32)), tk.shape[0], ptrs, lens, m, _p64(cs), cs.shape[0],
                                         rows, stride, next_shift, int(accumulate), C.c_void_p(out.ptr + 32 * out_offset)))
+
+
+_GATE_IDS = {}
+
+
+def gate_ids():
+    """{name: id} of the compiled kernels (kh_gate_evaluations_dev): the gate library's GateType names, "Generic", "Permutation"."""
+    if not _GATE_IDS:
+        _lib.kh_gate_name.restype = C.c_char_p
+        _GATE_IDS.update({_lib.kh_gate_name(g).decode(): g for g in range(_lib.kh_gate_count())})
+    return _GATE_IDS
+
+
+def gate_num_constants(gate: int) -> int:
+    return _lib.kh_gate_num_constants(C.c_int(gate))
+
+
+def gate_evaluations_dev(field: int, gate: int, cols, col_len: int, constants, rows: int, out, stride: int = 1, next_shift: int = 8, accumulate: bool = False,
+                         out_offset: int = 0):
+    """kh_gate_evaluations_dev: cols = 31 DevBuf (witness 0..14, coefficients 15..29, the gate's selector); constants (k, 4) Montgomery limbs."""
+    assert len(cols) == 31
+    ptrs = (C.c_void_p * 31)(*[C.c_void_p(c.ptr) for c in cols])
+    cs = _c64(constants, (-1, 4))
+    _check(_lib.kh_gate_evaluations_dev(C.c_int(field), C.c_int(gate), ptrs, C.c_size_t(col_len), _p64(cs), C.c_size_t(cs.shape[0]), C.c_size_t(rows),
+                                        C.c_uint(stride), C.c_uint(next_shift), C.c_int(int(accumulate)), C.c_void_p(out.ptr + 32 * out_offset)))
 
 
 def polycomm_multi_scalar_mul(curve: int, comms, scalars):

@@ -111,6 +111,12 @@ class Env:
             self._index[v] = len(self.consts); self.consts.append(v)
         return Node(TOK_CONST, arg=self._index[v])
 
+    def param(self, v: int = 0) -> Node:
+        """a constant slot of its own (a per-proof value: a challenge, a power of alpha): never merged with an equal literal, so that the
+        LAYOUT of the constants table does not depend on the values"""
+        self.consts.append(v % self.p)
+        return Node(TOK_CONST, arg=len(self.consts) - 1)
+
     def witness_curr(self, i): return Node(TOK_CELL, arg=2 * (self.w0 + i))
     def witness_next(self, i): return Node(TOK_CELL, arg=2 * (self.w0 + i) + 1)
     def coeff(self, i): return Node(TOK_CELL, arg=2 * (self.c0 + i))
@@ -400,6 +406,43 @@ POSEIDON_MDS = {
     0: [[12035446894107573964500871153637039653510326950134440362813193268448863222019, 25461374787957152039031444204194007219326765802730624564074257060397341542093, 27667907157110496066452777015908813333407980290333709698851344970789663080149], [4491931056866994439025447213644536587424785196363427220456343191847333476930, 14743631939509747387607291926699970421064627808101543132147270746750887019919, 9448400033389617131295304336481030167723486090288313334230651810071857784477], [10525578725509990281643336361904863911009900817790387635342941550657754064843, 27437632000253211280915908546961303399777448677029255413769125486614773776695, 27566319851776897085443681456689352477426926500749993803132851225169606086988]],
     1: [[28115781186772277486790024060542467295096710153315236019619365740021995624782, 22098002279041163367053200604969603243328318626084412751290336872362628294144, 10518156075882958317589806716220047551309200159506906232124952575033472931386], [8515206633865386306014865142947895502833797732365705727001733785057042819852, 19310731234716792175834594131802557577955166208124819468043130037927500684373, 361439796332338311597104753147071943681730695313819021679602959964518909239], [2193808570710678216879007026210418088296432071066284289131688133644970611483, 1201496953174589855481629688627002262719699487577300614284420648015658009380, 11619800255560837597192574795389782851917036920101027584480912719351481334717]],
 }
+
+
+# The two arguments every circuit has, in the gate kernels' column convention, so that tools/gen_gate_kernels.py compiles them beside
+# the library (the token lists at the top of this file are the same expressions for the token machine).
+def generic_expression(env: Env, alpha: int = 0):
+    """index(Generic) * (c1 + alpha c2), c = q_l l + q_r r + q_o o + q_m l r + q_c on either half of the double generic gate
+    (generic.rs:100-131).  Columns: witness 0..5, coefficients 15..24, the generic selector 30; constants [1, alpha]."""
+    acc = None
+    for g, a in ((0, env.param(1)), (1, env.param(alpha))):
+        w = [env.witness_curr(3 * g + i) for i in range(3)]
+        c = [env.coeff(5 * g + i) for i in range(5)]
+        term = a * (c[0] * w[0] + c[1] * w[1] + c[2] * w[2] + c[3] * w[0] * w[1] + c[4])
+        acc = term if acc is None else acc + term
+    return env.column(30) * acc
+
+
+PERM_Z_COL, PERM_X_COL, PERM_ZKPM_COL = 22, 23, 24
+
+
+def permutation_expression(env: Env, gamma: int = 0, beta: int = 0, alpha0: int = 0, bshifts=(0,) * 7):
+    """alpha0 zkpm(x) (z(x) prod_i (w_i + gamma + x beta shift_i) - z(x w) prod_i (w_i + gamma + sigma_i beta)) (permutation.rs:225-288).
+    Columns: witness 0..6, sigma_i at 15 + i, z 22, x 23, zkpm 24; constants [gamma, beta, alpha0, beta shift_0 .. beta shift_6]."""
+    g, b, a0 = env.param(gamma), env.param(beta), env.param(alpha0)
+    bs = [env.param(v) for v in bshifts]
+    x = env.column(PERM_X_COL)
+    lhs = rhs = None
+    for i in range(7):
+        wg = env.witness_curr(i) + g
+        wg.cached = True
+        l = wg + x * bs[i]
+        r = wg + env.coeff(i) * b
+        lhs = l if lhs is None else lhs * l
+        rhs = r if rhs is None else rhs * r
+    return (lhs * env.column(PERM_Z_COL) - rhs * env.column_next(PERM_Z_COL)) * a0 * env.column(PERM_ZKPM_COL)
+
+
+COMPILED_EXTRA = {"Generic": generic_expression, "Permutation": permutation_expression}
 
 
 def gate_program(name: str, p: int, alpha: int, selector_col: int = 30, mds=None, endo: int = 0, w0: int = 0, c0: int = 15):

@@ -35,6 +35,8 @@ ALPHA_PERM0 = 21                    # the gates register 21 powers of alpha firs
 MOD = {khip.FP: 0x40000000000000000000000000000000224698fc094cf91b992d30ed00000001,
        khip.FQ: 0x40000000000000000000000000000000224698fc0994a8dd8c46eb2100000001}
 R256 = 1 << 256
+import os as _os
+_TOKEN_GATES = bool(_os.environ.get("KH_TOKEN_GATES"))     # A/B: run the gate library through the token machine instead of the compiled kernels
 
 
 class Fld:
@@ -463,20 +465,32 @@ def create_proof(ix: ProverIndex, witness, rng, timings=None, check: bool = True
     alpha = scalar_challenge(curve, F, fq.challenge())
     alphas = [pow(alpha, ALPHA_PERM0 + i, F.p) for i in range(3)]
     # ---- constraint rows on d8, quotient
-    gen_cols = [e8.view(i * N8) for i in range(6)] + [ix.col8(i) for i in range(10)] + [ix.col8(COLUMNS)]
     t4 = khip.DevBuf(4 * NB); t8 = khip.DevBuf(N8)
-    khip.expr_evaluations_dev(fid, OP.generic_gate_tokens(0, 6, 16, 0, 1), gen_cols, [8 * n] * 17, F.limbs_many([1, alpha]), 4 * n, t4, stride=2, next_shift=8)
-    perm_cols = [e8.view(i * N8) for i in range(PERMUTS)] + [ix.col8(COLUMNS + 2 + i) for i in range(PERMUTS)] + [e8.view(COLUMNS * N8), ix.col8(ix.X8), ix.col8(ix.ZKPM8)]
     pconsts = F.limbs_many([gamma, beta, alphas[0]] + [beta * s % F.p for s in ix.shifts])
-    khip.expr_evaluations_dev(fid, OP.perm_quot_tokens(w0=0, s0=7, z=14, x=15, zkpm=16, gamma=0, beta=1, bshift0=3, alpha0=2), perm_cols, [8 * n] * 17, pconsts,
-                              8 * n, t8, stride=1, next_shift=8)
+    gids = khip.gate_ids()
+    if _TOKEN_GATES:
+        gen_cols = [e8.view(i * N8) for i in range(6)] + [ix.col8(i) for i in range(10)] + [ix.col8(COLUMNS)]
+        khip.expr_evaluations_dev(fid, OP.generic_gate_tokens(0, 6, 16, 0, 1), gen_cols, [8 * n] * 17, F.limbs_many([1, alpha]), 4 * n, t4, stride=2, next_shift=8)
+        perm_cols = [e8.view(i * N8) for i in range(PERMUTS)] + [ix.col8(COLUMNS + 2 + i) for i in range(PERMUTS)] + [e8.view(COLUMNS * N8), ix.col8(ix.X8), ix.col8(ix.ZKPM8)]
+        khip.expr_evaluations_dev(fid, OP.perm_quot_tokens(w0=0, s0=7, z=14, x=15, zkpm=16, gamma=0, beta=1, bshift0=3, alpha0=2), perm_cols, [8 * n] * 17, pconsts,
+                                  8 * n, t8, stride=1, next_shift=8)
+    else:                                                   # the same two expressions as compiled kernels (csrc/gates.hip: "Generic", "Permutation")
+        wcols = [e8.view(i * N8) for i in range(COLUMNS)]
+        khip.gate_evaluations_dev(fid, gids["Generic"], wcols + [ix.col8(i) for i in range(COLUMNS)] + [ix.col8(COLUMNS)], 8 * n, F.limbs_many([1, alpha]), 4 * n, t4,
+                                  stride=2, next_shift=8)
+        pcols = wcols + [ix.col8(COLUMNS + 2 + i) for i in range(PERMUTS)] + [e8.view(COLUMNS * N8), ix.col8(ix.X8), ix.col8(ix.ZKPM8)]
+        pcols += [wcols[0]] * (31 - len(pcols))             # columns the expression does not read
+        khip.gate_evaluations_dev(fid, gids["Permutation"], pcols, 8 * n, pconsts, 8 * n, t8, stride=1, next_shift=8)
     live_gates = [(k_, name) for k_, name in enumerate(ix.GATE_TYPES + tuple(ix.optional)) if all_gates or name in ix.live_gate_types]
     if live_gates:                                          # the gate library on d8 (prover.rs:824-868): index(gate) * sum_i alpha^i constraint_i
         endo_q = F.value(khip.endos(1 - curve)[0])          # VerifierIndex::endo = endos::<OtherCurve>().0, an element of this scalar field
         gcols = [e8.view(i * N8) for i in range(COLUMNS)] + [ix.col8(i) for i in range(COLUMNS)]
-        for k_, name in live_gates:
+        for k_, name in live_gates:                         # compiled kernels (csrc/gates.hip); the token program of the same expression is the fallback
             gtoks, gconsts = OP.gate_program(name, F.p, alpha, selector_col=30, mds=OP.POSEIDON_MDS[fid], endo=endo_q)
-            khip.expr_evaluations_dev(fid, gtoks, gcols + [ix.col8(ix.SEL0 + k_)], [8 * n] * 31, F.limbs_many(gconsts), 8 * n, t8, stride=1, next_shift=8, accumulate=True)
+            if name in gids and not _TOKEN_GATES:
+                khip.gate_evaluations_dev(fid, gids[name], gcols + [ix.col8(ix.SEL0 + k_)], 8 * n, F.limbs_many(gconsts), 8 * n, t8, stride=1, next_shift=8, accumulate=True)
+            else:
+                khip.expr_evaluations_dev(fid, gtoks, gcols + [ix.col8(ix.SEL0 + k_)], [8 * n] * 31, F.limbs_many(gconsts), 8 * n, t8, stride=1, next_shift=8, accumulate=True)
     if lkp is not None:                                     # the lookup constraints on d8 (prover.rs:874-903), powers alpha^24 ...
         nl = len(lkp["d_sorted"]) + 2
         lkc = khip.DevBuf(nl * NB); lk8 = khip.DevBuf(nl * N8)   # coefficient forms / d8: [sorted ... | aggregation | combined table]

@@ -168,3 +168,24 @@ def test_every_constrained_cell_matters(name):
         wt[row][c] = (wt[row][c] + 1 + rnd.randrange(5)) % F.p
         vals = [G.combined_row(F, name, wt[r], wt[(r + 1) % len(wt)], co[r], 3, mds=mds, endo=endo) for r in gate_rows(name, ngate)]
         assert any(vals), (name, c)
+
+
+def test_generated_gate_kernels_are_current():
+    """csrc/gates_gen.inc is the output of tools/gen_gate_kernels.py for the expressions of proof_systems_amd/polish.py as they are now."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    assert subprocess.run([sys.executable, os.path.join(root, "tools", "gen_gate_kernels.py"), "--check"], cwd=root).returncode == 0
+
+
+def test_compiled_expressions_keep_the_constants_layout():
+    """The constants table a compiled kernel reads is laid out by the builder, independent of the values: per-proof values (challenges) take
+    env.param slots that never merge with literals or with each other."""
+    for p in (P.Fp.p, P.Fq.p):
+        env = OP.Env(p)
+        OP.permutation_expression(env, gamma=5, beta=5, alpha0=1, bshifts=[5] * 7)
+        assert env.consts == [5, 5, 1] + [5] * 7
+        env = OP.Env(p)
+        OP.generic_expression(env, alpha=1)
+        assert env.consts == [1, 1]

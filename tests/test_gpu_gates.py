@@ -60,6 +60,10 @@ def test_gate_on_device(khip, name):
         out = khip.DevBuf(n * 32)
         khip.expr_evaluations_dev(fid, toks, bufs, [n] * 31, _limbs(consts), n, out, stride=1, next_shift=1)
         got = _ints(out.download((n, 4)))
+        out2 = khip.DevBuf(n * 32)                                 # the compiled kernel of the same expression (csrc/gates.hip)
+        khip.gate_evaluations_dev(fid, khip.gate_ids()[name], bufs, n, _limbs(consts), n, out2, stride=1, next_shift=1)
+        assert _ints(out2.download((n, 4))) == got, (name, variant, "compiled kernel != token program")
+        out2.free()
         want = [sel[r] * G.combined_row(F, name, wt[r], wt[(r + 1) % n], ct[r], alpha, mds=mds, endo=endo) % F.p for r in range(n)]
         assert got == want, (name, variant)
         if name == "ForeignFieldMul":                              # random rows (tests/test_gates.py): the program equals the row machine; nothing to divide
@@ -75,6 +79,10 @@ def test_gate_on_device(khip, name):
         t8 = khip.DevBuf(8 * n * 32)
         khip.expr_evaluations_dev(fid, toks, bufs8, [8 * n] * 31, _limbs(consts), 8 * n, t8, stride=1, next_shift=8)
         ev8 = t8.download((8 * n, 4))
+        t8c = khip.DevBuf(8 * n * 32).upload(ev8)                  # compiled kernel, accumulating on top of the token program's rows: 2x
+        khip.gate_evaluations_dev(fid, khip.gate_ids()[name], bufs8, 8 * n, _limbs(consts), 8 * n, t8c, stride=1, next_shift=8, accumulate=True)
+        assert _ints(t8c.download((8 * n, 4))) == [2 * v % F.p for v in _ints(ev8)], (name, "compiled kernel on d8")
+        t8c.free()
         assert _ints(ev8[::8]) == want                              # d1 is the stride-8 sub-grid of d8
         khip.ntt_dev(fid, t8, logn + 3, True, 1)
         q = khip.DevBuf(7 * n * 32); r = khip.DevBuf(n * 32)
@@ -82,3 +90,34 @@ def test_gate_on_device(khip, name):
         assert r.download((n, 4)).any() == (variant == "violated"), (name, variant)
         for b in bufs + bufs8 + [out, t8, q, r]:
             b.free()
+
+
+@pytest.mark.parametrize("fid", [0, 1])
+def test_generic_and_permutation_kernels(khip, fid):
+    """The two arguments every circuit has, as compiled kernels ("Generic" on every second row of d8 into t4, "Permutation" on d8), equal
+    their token lists run by the token machine -- which the oracle prover pins through the whole-proof parity tests."""
+    Fd = P.Fp if fid == 0 else P.Fq
+    rnd = random.Random(77 + fid)
+    n = 1 << 9
+    lim = lambda vals: cref.ints_to_limbs([Fd.to_mont(v) for v in vals])
+    cols = [khip.DevBuf(n * 32).upload(lim([rnd.randrange(Fd.p) for _ in range(n)])) for _ in range(31)]
+    gids = khip.gate_ids()
+    assert khip.gate_num_constants(gids["Generic"]) == 2 and khip.gate_num_constants(gids["Permutation"]) == 10
+    alpha = rnd.randrange(Fd.p)
+    a = khip.DevBuf(n // 2 * 32); b = khip.DevBuf(n // 2 * 32)
+    gen_cols = cols[:6] + cols[15:25] + [cols[30]]
+    khip.expr_evaluations_dev(fid, OP.generic_gate_tokens(0, 6, 16, 0, 1), gen_cols, [n] * 17, lim([1, alpha]), n // 2, a, stride=2, next_shift=8)
+    khip.gate_evaluations_dev(fid, gids["Generic"], cols, n, lim([1, alpha]), n // 2, b, stride=2, next_shift=8)
+    assert (a.download((n // 2, 4)) == b.download((n // 2, 4))).all() and a.download((n // 2, 4)).any()
+    pc = lim([rnd.randrange(Fd.p) for _ in range(10)])             # gamma, beta, alpha0, beta * shift_i
+    perm_cols = cols[:7] + cols[15:22] + [cols[OP.PERM_Z_COL], cols[OP.PERM_X_COL], cols[OP.PERM_ZKPM_COL]]
+    a2 = khip.DevBuf(n * 32); b2 = khip.DevBuf(n * 32)
+    khip.expr_evaluations_dev(fid, OP.perm_quot_tokens(w0=0, s0=7, z=14, x=15, zkpm=16, gamma=0, beta=1, bshift0=3, alpha0=2), perm_cols, [n] * 17, pc, n, a2, stride=1, next_shift=8)
+    khip.gate_evaluations_dev(fid, gids["Permutation"], cols, n, pc, n, b2, stride=1, next_shift=8)
+    assert (a2.download((n, 4)) == b2.download((n, 4))).all() and a2.download((n, 4)).any()
+    with pytest.raises(khip.KhError):                            # wrong constants count
+        khip.gate_evaluations_dev(fid, gids["Permutation"], cols, n, pc[:9], n, b2)
+    with pytest.raises(khip.KhError):                            # rows past the column
+        khip.gate_evaluations_dev(fid, gids["Generic"], cols, n, lim([1, alpha]), n, b, stride=2)
+    for x in cols + [a, b, a2, b2]:
+        x.free()
