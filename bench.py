@@ -193,7 +193,25 @@ def prover_block(khip, srs20, check_with_oracle=True, log_n=16, reps=5):
         prover.create_proof(ix, wit, rng, timings=t, all_gates=True)
         if best_all is None or t["total"] < best_all["total"]:
             best_all = t
+    # the same proof through kh_prove: the host loop in C++ (csrc/prover.cpp) -- what a Rust / C caller of the library pays
+    prover.create_proof_native(ix, wit, rng)
+    best_nat, best_nat_all = None, None
+    for _ in range(reps):
+        t = {}
+        khip.sync()
+        nproof = prover.create_proof_native(ix, wit, rng, timings=t)
+        if best_nat is None or t["total"] < best_nat["total"]:
+            best_nat = t
+    for _ in range(3):
+        t = {}
+        khip.sync()
+        prover.create_proof_native(ix, wit, rng, timings=t, all_gates=True)
+        if best_nat_all is None or t["total"] < best_nat_all["total"]:
+            best_nat_all = t
     out = {"workload": "ProverProof::create, benchmark circuit (2^%d - 10 generic gates), Vesta, SRS 2^%d, one chunk" % (log_n, log_n),
+           "native": {"entry": "kh_prove (host loop in C++ over the C ABI; same proof as the Python loop for the same randomness, tests/test_gpu_native_prover.py)",
+                      "seconds": best_nat["total"], "constraints_per_s": n / best_nat["total"], "phases_s": {k: v for k, v in best_nat.items() if k != "total"},
+                      "seconds_all_gates": best_nat_all["total"], "constraints_per_s_all_gates": n / best_nat_all["total"]},
            "seconds": best["total"], "constraints_per_s": n / best["total"], "phases_s": {k: v for k, v in best.items() if k != "total"},
            "seconds_resident": best_res["total"], "constraints_per_s_resident": n / best_res["total"],
            "seconds_all_gates": best_all["total"], "constraints_per_s_all_gates": n / best_all["total"],
@@ -254,19 +272,20 @@ def prover_block(khip, srs20, check_with_oracle=True, log_n=16, reps=5):
                              "the zero padding never crosses PCIe); witness commitments + interpolations + 8x extensions of one proof; PCIe-bound (pageable host memory)"}
     if check_with_oracle:
         out["proof_accepted_by_oracle_verifier"] = bool(oracle_verifies(khip, ix, proof))
+        out["native"]["proof_accepted_by_oracle_verifier"] = bool(oracle_verifies(khip, ix, nproof))
         out["cpu_baseline"] = prover_cpu_baseline(khip, ix, padded, log_n)
     # several provers in flight (one host thread and one SRS handle each): a single proof is mostly latency chains, independent proofs overlap
     T, per = 4, 5
     ixs = [ix] + [prover.bench_circuit_index(khip.VESTA, log_n) for _ in range(T - 1)]
     for j in ixs[1:]:
         prover.create_proof(j, wit, np.random.default_rng(2), check=False)
+    nxs = [prover.native_index(j) for j in ixs]
     bar = threading.Barrier(T + 1)
 
     def run(t):
-        r_ = np.random.default_rng(50 + t)
         bar.wait()
-        for _ in range(per):
-            prover.create_proof(ixs[t], wit, r_, check=False)
+        for _ in range(per):                             # kh_prove, randomness from the library: no Python between the steps of a proof
+            nxs[t].prove(witness=wit, randomness=None, flags=0)
         bar.wait()
     th = [threading.Thread(target=run, args=(t,)) for t in range(T)]
     for t_ in th:
@@ -275,7 +294,7 @@ def prover_block(khip, srs20, check_with_oracle=True, log_n=16, reps=5):
     for t_ in th:
         t_.join()
     out["concurrent"] = {"provers_in_flight": T, "proofs_per_s": T * per / dt, "constraints_per_s": T * per * (1 << log_n) / dt,
-                         "note": "throughput of independent proofs on one GPU; `seconds` above is the latency of one"}
+                         "note": "throughput of independent proofs on one GPU through kh_prove (host loop in C++, one thread per prover); `seconds` above is the latency of one"}
     for j in ixs:
         j.free()
     return out
@@ -301,7 +320,7 @@ def pair_block(khip, log_n=16, per=4, check_with_oracle=True):
         F = prover.Fld(ix.fid)
         wit = np.tile(F.limbs(1), (15, n - 10, 1))
         rng = np.random.default_rng(90 + k)
-        proof = prover.create_proof(ix, wit, rng)
+        proof = prover.create_proof_native(ix, wit, rng)                 # kh_prove: the host loop in C++, so the two curves' threads do not share a GIL
         state[k] = (ix, proof)
         bar.wait()                                                       # 1: both warm
         if k == 0:                                                       # latencies alone, one curve after the other
@@ -312,13 +331,14 @@ def pair_block(khip, log_n=16, per=4, check_with_oracle=True):
                 best = None
                 for _ in range(3):
                     t = {}
-                    prover.create_proof(ix, wit, rng, timings=t, check=False)
+                    prover.create_proof_native(ix, wit, rng, timings=t, check=False)
                     best = t["total"] if best is None else min(best, t["total"])
                 res["seconds_alone_" + ("vesta", "pallas")[k]] = best
             bar.wait()
         bar.wait()                                                       # both in flight
+        nx = prover.native_index(ix)
         for _ in range(per):
-            prover.create_proof(ix, wit, rng, check=False)
+            nx.prove(witness=wit, randomness=None, flags=0)
         bar.wait()
     th = [threading.Thread(target=run, args=(k,)) for k in range(2)]
     for t_ in th:

@@ -70,6 +70,7 @@ const char *kh_last_error(void);
 int kh_srs_create(int curve, const uint64_t *g_xy /* n x 8 limbs */, size_t n, kh_srs_t **out);
 void kh_srs_free(kh_srs_t *srs);
 size_t kh_srs_size(const kh_srs_t *srs);
+int kh_srs_curve(const kh_srs_t *srs);    /* KH_CURVE_VESTA / KH_CURVE_PALLAS */
 int kh_srs_device(const kh_srs_t *srs);   /* the device the handle's tables live on */
 
 /* SRS::create (poly-commitment/src/ipa.rs:751-778) on the host: g_start .. g_{start+count-1}
@@ -237,6 +238,10 @@ int kh_expr_evaluations_dev(int field, const uint32_t *tokens, size_t ntok, cons
 int kh_gate_count(void);
 const char *kh_gate_name(int gate);
 int kh_gate_num_constants(int gate);
+/* The constants table of `gate` for one proof, built on the host (no device call): the protocol's literals and Poseidon MDS entries, alpha^i for the
+ * gate's constraints (alpha: Montgomery limbs; may be NULL for "Generic" / "Permutation"), the endo coefficient (endo: VerifierIndex::endo, NULL if
+ * the gate has none), and for "Generic" / "Permutation" the caller's per-proof values `params` in the order given above.  out: kh_gate_num_constants x 4 limbs. */
+int kh_gate_constants(int field, int gate, const uint64_t alpha[4], const uint64_t endo[4], const uint64_t *params, size_t nparams, uint64_t *out);
 int kh_gate_evaluations_dev(int field, int gate, const uint64_t *const *cols_dev, size_t col_len, const uint64_t *constants, size_t nconsts,
                             size_t rows, unsigned stride, unsigned next_shift, int accumulate, uint64_t *out_dev);
 
@@ -421,6 +426,59 @@ int kh_debug_field_op(int field, int op, const uint64_t *a, const uint64_t *b, u
 int kh_debug_point_op(int curve, int op, const uint64_t *p_xy, const uint8_t *p_inf,
                       const uint64_t *q_xy, const uint8_t *q_inf,
                       uint64_t *out_xy, uint8_t *out_inf, size_t n);
+
+/* ---- ProverProof::create as ONE native call (kimchi/src/prover.rs:187-1515, the part this library accelerates end to end) ----
+ * The host loop of the prover -- witness columns -> commitments -> z -> quotient -> evaluations -> opening, with the transcript -- written
+ * against the entry points above, so that a Rust / C caller pays neither an interpreter nor 60 FFI crossings per proof.  Scope: circuits
+ * without lookups and without recursion (prev_challenges); generic + the five library gates + the optional gates (RangeCheck0/1, Rot64, Xor16
+ * as a plain gate, ForeignFieldAdd/Mul), public inputs, any num_chunks.  (proof_systems_amd/prover.py runs the same protocol from Python and
+ * covers lookups / runtime tables / recursion; tests/test_gpu_native_prover.py: both give the same proof, field element for field element.)
+ *
+ * kh_prover_index_new: the caller has built the index columns on the device (ProverIndex of prover_index.rs:30-70; column order below) on the
+ * device of `srs`, whose Lagrange basis for 2^log2_n is registered (kh_srs_compute_lagrange).  Three blocks of columns of n = 2^log2_n
+ * (d1_dev: evaluations on the domain; dc_dev: coefficient forms) resp. 8n (d8_dev: evaluations on the 8x extended domain) elements:
+ *     column 0..14 coefficients | 15 generic selector | 16 sid (omega^j) | 17..23 sigma_0..6 | 24..28 selectors of Poseidon, CompleteAdd,
+ *     VarBaseMul, EndoMul, EndoMulScalar | 29.. the n_optional optional-gate selectors (optional_gates: their kh_gate ids, in column order);
+ *     dc_dev / d8_dev hold two more columns after those: x and the permutation vanishing polynomial (permutation.rs:107-118).
+ *   live_mask: bit k set = the circuit HAS rows of the k-th selector column after the generic one (24 + k): only those gates' constraints are
+ *   evaluated unless KH_PROVE_ALL_GATES asks for the reference's behaviour (prover.rs:824-868 evaluates every always-present gate type).
+ *   shifts: the 7 permutation shifts (Shifts::new); digest: VerifierIndex::digest (an element of the curve's base field).
+ *   The index keeps the pointers (no copy): they must outlive it.
+ * kh_prove: witness = 15 columns x rows x 4 Montgomery limbs on the host (rows + zk_rows <= n; the zero-knowledge rows are drawn here), or
+ *   witness_dev = the padded 15 x n columns already on the device (then no zero-knowledge rows are drawn: the caller has).
+ *   randomness: the field elements the reference draws from its RNG, IN ITS ORDER (kh_prove_randomness_count of them; uniform scalar-field
+ *   elements, Montgomery limbs) -- zero-knowledge rows per column from the last row backwards (prover.rs:254-266, host witness only), 15 x
+ *   num_chunks witness blinders, z's two random rows, num_chunks blinders of z, 7 num_chunks of t, then the opening's (rand_l, rand_r) per round,
+ *   d, r_delta (ipa.rs:940-941, 1036) -- or NULL: drawn from the operating system's generator (getrandom).
+ * kh_proof_section: a view into the proof (valid until kh_proof_free).  Point sections give limbs = count x 8 (affine x | y) and flags =
+ *   count infinity flags; element sections give limbs = count x 4 and flags = NULL. */
+typedef struct kh_prover_index kh_prover_index_t;
+typedef struct kh_proof kh_proof_t;
+#define KH_PROVE_CHECK 1          /* assert the intermediate invariants (z ends at 1, zero remainders): costs three small downloads */
+#define KH_PROVE_ALL_GATES 2      /* evaluate the constraints of every always-present gate type, as the reference does */
+#define KH_PROOF_W_COMM 0         /* 15 x num_chunks points */
+#define KH_PROOF_Z_COMM 1         /* num_chunks points */
+#define KH_PROOF_T_COMM 2         /* 7 num_chunks points */
+#define KH_PROOF_PUBLIC_COMM 3    /* num_chunks points (verifier side; not part of the serialised proof) */
+#define KH_PROOF_EVALS 4          /* per polynomial num_chunks values at zeta, then num_chunks at zeta omega; polynomials: z, generic selector, the five
+                                     selectors, w x 15, coefficients x 15, sigma x 6, the optional selectors in column order */
+#define KH_PROOF_PUBLIC_EVALS 5   /* num_chunks at zeta, num_chunks at zeta omega */
+#define KH_PROOF_FT_EVAL1 6
+#define KH_PROOF_LR 7             /* (L, R) per round: 2 log2(srs size) points */
+#define KH_PROOF_DELTA 8
+#define KH_PROOF_Z1_Z2 9
+#define KH_PROOF_SG 10
+#define KH_PROOF_CHALLENGES 11    /* beta, gamma, alpha, zeta, v (polyscale), u (evalscale) */
+int kh_prover_index_new(kh_srs_t *srs, unsigned log2_n, unsigned zk_rows, unsigned public_inputs, const uint64_t *d1_dev, const uint64_t *dc_dev,
+                        const uint64_t *d8_dev, const int *optional_gates, size_t n_optional, unsigned live_mask, const uint64_t *shifts,
+                        const uint64_t digest[4], kh_prover_index_t **out);
+void kh_prover_index_free(kh_prover_index_t *index);
+size_t kh_prove_randomness_count(const kh_prover_index_t *index, int witness_on_host);
+int kh_prove(kh_prover_index_t *index, const uint64_t *witness, size_t rows, const uint64_t *witness_dev, const uint64_t *randomness,
+             size_t n_random, unsigned flags, kh_proof_t **out);
+int kh_proof_section(const kh_proof_t *proof, int section, const uint64_t **limbs, const uint8_t **flags, size_t *count);
+int kh_proof_phase_seconds(const kh_proof_t *proof, double *seconds, size_t cap);   /* witness_upload, witness_commit, z, quotient, evaluations, opening */
+void kh_proof_free(kh_proof_t *proof);
 
 /* ---- Fiat-Shamir sponges (host side) --------------------------------------
  * The transcript of kimchi's prover / verifier: Kimchi Poseidon (width 3, rate 2, 55 full rounds, x^7) under

@@ -340,6 +340,7 @@ void kh_srs_free(kh_srs_t* srs) {
     delete srs;                       // the handle's buffers (tables, Lagrange chunks, opening workspace) free themselves
 }
 size_t kh_srs_size(const kh_srs_t* srs) { return srs ? srs->n : 0; }
+int kh_srs_curve(const kh_srs_t* srs) { return srs ? srs->curve : -1; }
 
 int kh_srs_set_lagrange(kh_srs_t* srs, unsigned log2_domain, unsigned chunk, const uint64_t* xy, const uint8_t* inf, size_t n) {
     KH_ON_DEVICE_OF(srs);
@@ -1088,6 +1089,10 @@ int kh_expr_evaluations_dev(int field, const uint32_t* tokens, size_t ntok, cons
 int kh_gate_count(void) { return gate_count(); }
 const char* kh_gate_name(int gate) { return gate_name(gate); }
 int kh_gate_num_constants(int gate) { return gate_num_constants(gate); }
+int kh_gate_constants(int field, int gate, const uint64_t alpha[4], const uint64_t endo[4], const uint64_t* params, size_t nparams, uint64_t* out) {
+    KH_REQUIRE(out, "kh_gate_constants: null output");
+    return gate_constants(field, gate, alpha, endo, params, nparams, out);
+}
 int kh_gate_evaluations_dev(int field, int gate, const uint64_t* const* cols_dev, size_t col_len, const uint64_t* constants, size_t nconsts, size_t rows,
                             unsigned stride, unsigned next_shift, int accumulate, uint64_t* out_dev) {
     KH_REQUIRE(field == KH_FIELD_FP || field == KH_FIELD_FQ, "unknown field id %d", field);

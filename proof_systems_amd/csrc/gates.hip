@@ -10,6 +10,7 @@
 #include "common.hpp"
 #include "field.cuh"
 #include "msm.hpp"
+#include "host_ec.hpp"
 
 namespace kh {
 
@@ -50,6 +51,35 @@ KH_FOR_EACH_GATE(KH_GATE_KERNEL)
 int gate_count() { return GATE_COUNT; }
 const char* gate_name(int gate) { return gate >= 0 && gate < GATE_COUNT ? GATE_NAMES[gate] : nullptr; }
 int gate_num_constants(int gate) { return gate >= 0 && gate < GATE_COUNT ? GATE_NCONST[gate] : -1; }
+
+// the constants table of one gate for one proof, on the host (gates_gen.inc: GATE_CONST_TABLE): literals of the protocol, powers of alpha, the endo
+// coefficient, the caller's per-proof values -- so that a caller needs no copy of the expression builder to drive kh_gate_evaluations_dev
+int gate_constants(int field, int gate, const uint64_t* alpha, const uint64_t* endo, const uint64_t* params, size_t nparams, uint64_t* out) {
+    KH_REQUIRE(gate >= 0 && gate < GATE_COUNT, "unknown gate id %d", gate);
+    KH_REQUIRE(field == KH_FIELD_FP || field == KH_FIELD_FQ, "unknown field %d", field);
+    const khost::Fld F(field == KH_FIELD_FP ? 0 : 1);
+    const GateConst* rc = GATE_CONST_TABLE[gate];
+    khost::fe apow[64]; int have = 0;                     // alpha^1 .. alpha^have
+    for (int k = 0; k < GATE_NCONST[gate]; k++) {
+        khost::fe v;
+        switch (rc[k].kind) {
+            case 0: { khost::fe c; for (int i = 0; i < 4; i++) c.l[i] = rc[k].lit[field == KH_FIELD_FP ? 0 : 1][i]; v = F.to_mont(c); break; }
+            case 1: {
+                KH_REQUIRE(alpha, "gate %s needs alpha", GATE_NAMES[gate]);
+                KH_REQUIRE(rc[k].arg >= 1 && rc[k].arg < 64, "bad power in the constants recipe");
+                if (!have) { memcpy(&apow[1], alpha, 32); have = 1; }
+                while (have < rc[k].arg) { apow[have + 1] = F.mul(apow[have], apow[1]); have++; }
+                v = apow[rc[k].arg]; break;
+            }
+            case 2: KH_REQUIRE(endo, "gate %s needs the endo coefficient", GATE_NAMES[gate]); memcpy(&v, endo, 32); break;
+            default:
+                KH_REQUIRE(params && (size_t)rc[k].arg < nparams, "gate %s takes %d per-proof values, got %zu", GATE_NAMES[gate], rc[k].arg + 1, nparams);
+                memcpy(&v, params + 4 * (size_t)rc[k].arg, 32); break;
+        }
+        memcpy(out + 4 * (size_t)k, &v, 32);
+    }
+    return KH_OK;
+}
 
 #define g_gate_consts (kh::ctx().scratch("gate_consts"))
 

@@ -60,6 +60,7 @@ int poly_divide_by_linear(Context& C, int field, const uint64_t* f_dev, size_t l
 int gate_count();
 const char* gate_name(int gate);
 int gate_num_constants(int gate);
+int gate_constants(int field, int gate, const uint64_t* alpha, const uint64_t* endo, const uint64_t* params, size_t nparams, uint64_t* out);
 int gate_run(Context& C, int field, int gate, const uint64_t* const* cols_dev, size_t len, const uint64_t* consts, size_t nconsts, size_t rows,
              unsigned stride, unsigned next_shift, int accumulate, uint64_t* out_dev);
 int expr_run(Context& C, int field, const uint32_t* prog, size_t ntok, const uint64_t* const* cols_dev, const size_t* col_len, size_t ncols,

@@ -1,0 +1,536 @@
+// prover.cpp -- ProverProof::create (kimchi/src/prover.rs:187-1515) as a native host loop over this library's own C ABI.
+//
+// The same protocol proof_systems_amd/prover.py runs from Python, for circuits without lookups and recursion, written against the public
+// entry points only (kh_ntt_dev, kh_gate_evaluations_dev, kh_msm_submit, kh_ipa_open, kh_sponge_*, ...): a Rust or C caller gets a whole proof
+// with one call, no interpreter in the measured latency, and several prover threads do not share a GIL.  Every device step is the entry
+// point the Python prover calls at the same place, with the same arguments, so the two give the same proof for the same randomness
+// (tests/test_gpu_native_prover.py compares them field element for field element; the Python prover is pinned on the reference's whole-proof
+// vector through the oracle prover).  Host arithmetic: khost::Fld on Montgomery limbs (the wire form).
+//
+//   round 1  prover.rs:254-327   zero-knowledge rows, public polynomial, 15 witness commitments (one batched MSM over the Lagrange basis)
+//   round 2  prover.rs:676-707   beta, gamma; permutation aggregation z (permutation.rs:510-568), commitment
+//   round 3  prover.rs:709-985   alpha; generic + permutation + gate constraints on d8, division by Z_H, boundary quotients, t commitment
+//   round 4  prover.rs:987-1263  zeta; chunked evaluations, ft (Maller), Fr-sponge -> v, u
+//   round 5  prover.rs:1265-1500 SRS::open over (public, ft, z, selectors, w, coefficients, sigma, optional selectors)
+#include <stdint.h>
+#include <string.h>
+#include <sys/random.h>
+#include <chrono>
+#include <new>
+#include <vector>
+
+#include "../../include/kimchi_hip.h"
+#include "host_ec.hpp"
+
+namespace kh { void set_error(const char* fmt, ...); }
+
+namespace {
+using khost::fe;
+constexpr size_t COLUMNS = 15, PERMUTS = 7, SEL0 = COLUMNS + 2 + PERMUTS, OPT0 = SEL0 + 5;
+constexpr int ALPHA_PERM0 = 21;                      // the gates take the first 21 powers of alpha (linearization.rs:56-58), the permutation the next 3
+const char* const LIB_GATES[5] = {"Poseidon", "CompleteAdd", "VarBaseMul", "EndoMul", "EndoMulScalar"};
+
+struct Dev {                                         // a device allocation that lives as long as the proof is being made
+    uint64_t* p = nullptr;
+    Dev() = default;
+    Dev(const Dev&) = delete;
+    Dev& operator=(const Dev&) = delete;
+    ~Dev() { if (p) (void)kh_dev_free(p); }
+    int alloc(size_t elems) { return kh_dev_alloc((void**)&p, elems * 32); }
+    uint64_t* at(size_t elem) const { return p + 4 * elem; }
+};
+struct SpongeH {
+    kh_sponge_t* s = nullptr;
+    ~SpongeH() { if (s) kh_sponge_free(s); }
+};
+fe load(const uint64_t* l) { fe r; memcpy(&r, l, 32); return r; }
+fe fpow(const khost::Fld& F, fe base, uint64_t e) {
+    fe acc = F.f.one;
+    while (e) { if (e & 1) acc = F.mul(acc, base); base = F.sqr(base); e >>= 1; }
+    return acc;
+}
+// sum_k c[k] x^k over `cnt` consecutive elements (ProofEvaluations::combine: the chunks of one evaluation)
+fe horner(const khost::Fld& F, const fe* c, size_t cnt, const fe& x) {
+    fe acc = {{0, 0, 0, 0}};
+    for (size_t k = cnt; k-- > 0;) acc = F.add(F.mul(acc, x), c[k]);
+    return acc;
+}
+int os_random(int fid, size_t k, fe* out) {          // uniform elements of the field, used as Montgomery limbs
+    const fe& p = khost::field(fid).p;
+    for (size_t i = 0; i < k;) {
+        fe buf[8];
+        if (getrandom(buf, sizeof(buf), 0) != (ssize_t)sizeof(buf)) { kh::set_error("getrandom failed"); return KH_E_DEVICE; }
+        for (int j = 0; j < 8 && i < k; j++) {
+            buf[j].l[3] &= 0x7fffffffffffffffULL;
+            if (!khost::geq(buf[j], p)) out[i++] = buf[j];
+        }
+    }
+    return KH_OK;
+}
+}  // namespace
+
+struct kh_prover_index {
+    kh_srs_t* srs = nullptr;
+    int curve = 0, fid = 0;
+    unsigned logn = 0, live = 0;
+    size_t n = 0, size = 0, nch = 1, zk = 3, pub = 0, ncol = 0;
+    const uint64_t *d1 = nullptr, *dc = nullptr, *d8 = nullptr;
+    std::vector<int> optional;                       // kh gate ids of the optional selector columns
+    int lib_gate[5] = {0, 0, 0, 0, 0}, gid_generic = -1, gid_perm = -1;
+    fe shifts[7], digest, omega, endo;
+    uint64_t* zero_poly = nullptr;                   // n zeros on the device: the public polynomial of a circuit without public inputs
+    std::vector<uint64_t> zsel_xy; std::vector<uint8_t> zsel_inf;   // commitment to the zero polynomial masked with 1 (= h per chunk)
+    const uint64_t* col1(size_t k) const { return d1 + 4 * k * n; }
+    const uint64_t* colc(size_t k) const { return dc + 4 * k * n; }
+    const uint64_t* col8(size_t k) const { return d8 + 4 * k * 8 * n; }
+};
+
+struct kh_proof {
+    struct Sec { std::vector<uint64_t> limbs; std::vector<uint8_t> flags; size_t count = 0; bool points = false; };
+    Sec sec[12];
+    double phase[6] = {0, 0, 0, 0, 0, 0};
+    void set_points(int s, const uint64_t* xy, const uint8_t* inf, size_t cnt) {
+        sec[s].limbs.assign(xy, xy + 8 * cnt); sec[s].flags.assign(inf, inf + cnt); sec[s].count = cnt; sec[s].points = true;
+    }
+    void set_elems(int s, const fe* v, size_t cnt) {
+        sec[s].limbs.resize(4 * cnt); if (cnt) memcpy(sec[s].limbs.data(), v, 32 * cnt); sec[s].flags.clear(); sec[s].count = cnt; sec[s].points = false;
+    }
+};
+
+extern "C" {
+
+#define KP(expr)                                   \
+    do {                                           \
+        int rc_ = (expr);                          \
+        if (rc_ != KH_OK) { (void)kh_sync(); return rc_; }   \
+    } while (0)
+#define KP_REQUIRE(cond, ...)                                        \
+    do {                                                             \
+        if (!(cond)) { kh::set_error(__VA_ARGS__); (void)kh_sync(); return KH_E_INVALID; } \
+    } while (0)
+
+int kh_prover_index_new(kh_srs_t* srs, unsigned log2_n, unsigned zk_rows, unsigned public_inputs, const uint64_t* d1_dev, const uint64_t* dc_dev,
+                        const uint64_t* d8_dev, const int* optional_gates, size_t n_optional, unsigned live_mask, const uint64_t* shifts,
+                        const uint64_t digest[4], kh_prover_index_t** out) {
+    if (!srs || !d1_dev || !dc_dev || !d8_dev || !shifts || !digest || !out || (n_optional && !optional_gates) || log2_n > 26) {
+        kh::set_error("kh_prover_index_new: bad argument"); return KH_E_INVALID;
+    }
+    kh_prover_index* ix = new (std::nothrow) kh_prover_index();
+    if (!ix) { kh::set_error("out of memory"); return KH_E_NOMEM; }
+    ix->srs = srs; ix->curve = kh_srs_curve(srs); ix->fid = ix->curve == KH_CURVE_VESTA ? KH_FIELD_FP : KH_FIELD_FQ;
+    ix->logn = log2_n; ix->n = (size_t)1 << log2_n; ix->size = kh_srs_size(srs);
+    ix->nch = ix->n < ix->size ? 1 : ix->n / ix->size;
+    ix->zk = zk_rows; ix->pub = public_inputs; ix->live = live_mask;
+    ix->d1 = d1_dev; ix->dc = dc_dev; ix->d8 = d8_dev;
+    ix->optional.assign(optional_gates, optional_gates + n_optional);
+    ix->ncol = OPT0 + n_optional;
+    int rc = KH_OK;
+    auto fail = [&](int code) { kh_prover_index_free(ix); return code; };
+    if (zk_rows <= (2 * (PERMUTS + 1) * ix->nch - 2) / PERMUTS || zk_rows >= ix->n) { kh::set_error("NotZeroKnowledge: zk_rows %u for %zu chunks", zk_rows, ix->nch); return fail(KH_E_INVALID); }
+    if (kh_srs_lagrange_chunks(srs, log2_n) == 0) { kh::set_error("the Lagrange basis of 2^%u is not registered on this SRS (kh_srs_compute_lagrange)", log2_n); return fail(KH_E_NOTFOUND); }
+    const int ngates = kh_gate_count();
+    for (int g = 0; g < ngates; g++) {
+        const char* nm = kh_gate_name(g);
+        for (int k = 0; k < 5; k++) if (!strcmp(nm, LIB_GATES[k])) ix->lib_gate[k] = g;
+        if (!strcmp(nm, "Generic")) ix->gid_generic = g;
+        if (!strcmp(nm, "Permutation")) ix->gid_perm = g;
+    }
+    for (int g : ix->optional) if (g < 0 || g >= ngates) { kh::set_error("unknown optional gate id %d", g); return fail(KH_E_INVALID); }
+    for (int i = 0; i < 7; i++) ix->shifts[i] = load(shifts + 4 * i);
+    ix->digest = load(digest);
+    uint64_t w[4], eq[4], er[4];
+    if ((rc = kh_domain_generator(ix->fid, log2_n, w))) return fail(rc);
+    ix->omega = load(w);
+    if ((rc = kh_endos(1 - ix->curve, eq, er))) return fail(rc);          // VerifierIndex::endo = endos::<OtherCurve>().0: an element of this scalar field
+    ix->endo = load(eq);
+    if ((rc = kh_dev_alloc((void**)&ix->zero_poly, ix->n * 32))) return fail(rc);
+    if ((rc = kh_dev_memset_zero(ix->zero_poly, ix->n * 32))) return fail(rc);
+    // the commitment to the zero public polynomial: infinity per chunk (commit_non_hiding), masked with blinders 1 (prover.rs:296-309)
+    const khost::Fld F(ix->fid);
+    std::vector<uint64_t> zxy(8 * ix->nch, 0), ones(4 * ix->nch); std::vector<uint8_t> zinf(ix->nch, 1);
+    for (size_t c = 0; c < ix->nch; c++) memcpy(&ones[4 * c], &F.f.one, 32);
+    ix->zsel_xy.resize(8 * ix->nch); ix->zsel_inf.resize(ix->nch);
+    if ((rc = kh_mask_custom(srs, zxy.data(), zinf.data(), ix->nch, ones.data(), ix->nch, ix->zsel_xy.data(), ix->zsel_inf.data()))) return fail(rc);
+    if ((rc = kh_sync())) return fail(rc);
+    *out = ix;
+    return KH_OK;
+}
+void kh_prover_index_free(kh_prover_index_t* ix) {
+    if (!ix) return;
+    if (ix->zero_poly) (void)kh_dev_free(ix->zero_poly);
+    delete ix;
+}
+size_t kh_prove_randomness_count(const kh_prover_index_t* ix, int witness_on_host) {
+    if (!ix) return 0;
+    size_t logs = 0; while (((size_t)1 << logs) < ix->size) logs++;
+    return (witness_on_host ? COLUMNS * ix->zk : 0) + COLUMNS * ix->nch + 2 + ix->nch + 7 * ix->nch + 2 * logs + 2;
+}
+
+int kh_prove(kh_prover_index_t* ix, const uint64_t* witness, size_t rows, const uint64_t* witness_dev, const uint64_t* randomness, size_t n_random,
+             unsigned flags, kh_proof_t** out) {
+    if (!ix || !out || (!witness == !witness_dev)) { kh::set_error("kh_prove: give the witness either on the host or on the device"); return KH_E_INVALID; }
+    const bool check = flags & KH_PROVE_CHECK, all_gates = flags & KH_PROVE_ALL_GATES;
+    const int fid = ix->fid, curve = ix->curve;
+    const unsigned logn = ix->logn;
+    const size_t n = ix->n, size = ix->size, nch = ix->nch, zk = ix->zk, nopt = ix->optional.size();
+    kh_srs_t* srs = ix->srs;
+    const khost::Fld F(fid);
+    const fe one = F.f.one, zero = {{0, 0, 0, 0}};
+    struct DeviceRestore { int prev; ~DeviceRestore() { if (prev >= 0) (void)kh_set_device(prev); } } device_restore{kh_get_device()};
+    KP(kh_set_device(kh_srs_device(srs)));           // the index lives on the SRS's device: this thread works there until the proof is made
+    // ---- the randomness of the whole proof, in the reference's draw order
+    const size_t need = kh_prove_randomness_count(ix, witness != nullptr);
+    std::vector<fe> rnd(need);
+    if (randomness) {
+        KP_REQUIRE(n_random == need, "kh_prove: %zu random elements given, %zu drawn (kh_prove_randomness_count)", n_random, need);
+        memcpy(rnd.data(), randomness, 32 * need);
+    } else KP(os_random(fid, need, rnd.data()));
+    size_t rpos = 0;
+    auto draw = [&](size_t k) { const fe* p = rnd.data() + rpos; rpos += k; return p; };
+    kh_proof* pr = new (std::nothrow) kh_proof();
+    if (!pr) { kh::set_error("out of memory"); return KH_E_NOMEM; }
+    struct Guard { kh_proof* p; ~Guard() { delete p; } } guard{pr};
+    auto t_prev = std::chrono::steady_clock::now();
+    int phase_i = 0;
+    auto mark = [&]() { auto t = std::chrono::steady_clock::now(); pr->phase[phase_i++] = std::chrono::duration<double>(t - t_prev).count(); t_prev = t; };
+    const size_t NB = n, N8 = 8 * n;                 // elements per d1 / d8 column
+    // commitments: chunk lists, flat (commitment after commitment)
+    auto commit_evals = [&](const uint64_t* ptr, size_t k, std::vector<uint64_t>& xy, std::vector<uint8_t>& inf) -> int {
+        // SRS::commit_evaluations_non_hiding of k columns: per chunk of the Lagrange basis one batched MSM over all n evaluations
+        xy.assign(8 * k * nch, 0); inf.assign(k * nch, 0);
+        std::vector<uint64_t> o(8 * k); std::vector<uint8_t> oi(k);
+        for (size_t c = 0; c < nch; c++) {
+            int rc = kh_msm_batch_dev(srs, (int)logn, (unsigned)c, 0, ptr, n, k, 1, o.data(), oi.data());
+            if (rc) return rc;
+            for (size_t i = 0; i < k; i++) { memcpy(&xy[8 * (i * nch + c)], &o[8 * i], 64); inf[i * nch + c] = oi[i]; }
+        }
+        return KH_OK;
+    };
+    auto commit_coeffs = [&](const uint64_t* ptr, size_t length, size_t chunks, std::vector<uint64_t>& xy, std::vector<uint8_t>& inf) -> int {
+        // SRS::commit_non_hiding (ipa.rs:638-683): chunks of the SRS size, padded with the point at infinity
+        size_t cnt = (length + size - 1) / size; if (cnt < chunks) cnt = chunks; if (cnt < 1) cnt = 1;
+        xy.assign(8 * cnt, 0); inf.assign(cnt, 1);
+        const size_t full = length / size, rem = length - full * size;
+        if (full) { int rc = kh_msm_batch_dev(srs, KH_BASIS_G, 0, 0, ptr, size, full, 1, xy.data(), inf.data()); if (rc) return rc; }
+        if (rem) { int rc = kh_msm_batch_dev(srs, KH_BASIS_G, 0, 0, ptr + 4 * full * size, rem, 1, 1, &xy[8 * full], &inf[full]); if (rc) return rc; }
+        return KH_OK;
+    };
+    auto mask = [&](const std::vector<uint64_t>& xy, const std::vector<uint8_t>& inf, const fe* blinders, std::vector<uint64_t>& oxy, std::vector<uint8_t>& oinf) -> int {
+        const size_t k = inf.size();
+        oxy.resize(8 * k); oinf.resize(k);
+        return kh_mask_custom(srs, xy.data(), inf.data(), k, (const uint64_t*)blinders, k, oxy.data(), oinf.data());
+    };
+    auto scalar_challenge = [&](kh_sponge_t* sp, fe& o) -> int {
+        uint64_t ch[2];
+        int rc = kh_sponge_challenge(sp, ch); if (rc) return rc;
+        return kh_scalar_challenge_to_field(curve, ch, o.l);
+    };
+    // ---- witness on the device: [w 0..14 | z] in evaluation form
+    Dev ev; KP(ev.alloc(16 * NB));
+    if (witness) {
+        KP_REQUIRE(rows + zk <= n, "NoRoomForZkInWitness: %zu rows + %zu zero-knowledge rows > %zu", rows, zk, n);
+        if (rows + zk < n) KP(kh_dev_memset_zero(ev.p, 16 * NB * 32));
+        const fe* z = draw(COLUMNS * zk);            // per column, from the LAST row backwards (prover.rs:254-266)
+        std::vector<fe> zkr(COLUMNS * zk);
+        for (size_t c = 0; c < COLUMNS; c++) for (size_t j = 0; j < zk; j++) zkr[c * zk + j] = z[c * zk + (zk - 1 - j)];
+        if (rows) KP(kh_dev_upload_2d(ev.p, NB * 32, witness, rows * 32, rows * 32, COLUMNS));
+        KP(kh_dev_upload_2d(ev.at(n - zk), NB * 32, zkr.data(), zk * 32, zk * 32, COLUMNS));
+    } else KP(kh_dev_copy(ev.p, witness_dev, COLUMNS * NB * 32));
+    mark();
+    SpongeH fq; KP(kh_sponge_new(KH_SPONGE_FQ, curve, &fq.s));
+    KP(kh_sponge_absorb(fq.s, ix->digest.l, 1));
+    Dev pub_c;
+    std::vector<uint64_t> pub_xy; std::vector<uint8_t> pub_inf;
+    if (ix->pub) {                                    // the negated public-input polynomial (prover.rs:281-309)
+        KP_REQUIRE(ix->pub <= n, "more public inputs than rows");
+        std::vector<fe> pe(n, zero);
+        KP(kh_dev_download(pe.data(), ev.p, ix->pub * 32));
+        for (size_t i = 0; i < ix->pub; i++) pe[i] = F.neg(pe[i]);
+        KP(pub_c.alloc(NB)); KP(kh_dev_upload(pub_c.p, pe.data(), NB * 32));
+        std::vector<uint64_t> cxy; std::vector<uint8_t> cinf;
+        KP(commit_evals(pub_c.p, 1, cxy, cinf));
+        std::vector<fe> ones(nch, one);
+        KP(mask(cxy, cinf, ones.data(), pub_xy, pub_inf));
+        KP(kh_ntt_dev(fid, pub_c.p, logn, 1, 1));
+    } else { pub_xy = ix->zsel_xy; pub_inf = ix->zsel_inf; }
+    KP(kh_sponge_absorb_g(fq.s, pub_xy.data(), pub_inf.data(), nch));
+    pr->set_points(KH_PROOF_PUBLIC_COMM, pub_xy.data(), pub_inf.data(), nch);
+    // ---- witness commitments: one batched MSM per chunk of the Lagrange basis, queued before the columns are interpolated
+    uint64_t tk = 0; bool have_tk = false;
+    if (nch == 1) { KP(kh_msm_submit(srs, (int)logn, 0, 0, ev.p, n, COLUMNS, 1, &tk)); have_tk = true; }
+    Dev cf; KP(cf.alloc(16 * NB));                    // coefficient forms [w | z]
+    KP(kh_dev_copy(cf.p, ev.p, COLUMNS * NB * 32));
+    KP(kh_ntt_dev(fid, cf.p, logn, 1, COLUMNS));
+    Dev e8; KP(e8.alloc(16 * N8));
+    bool any_lib = (ix->live != 0) || nopt > 0;
+    const size_t w8 = (!any_lib && !all_gates) ? PERMUTS : COLUMNS;     // generic + permutation read w0..w6 only
+    KP(kh_lde_dev(fid, cf.p, logn, 3, e8.p, w8));
+    std::vector<uint64_t> wxy; std::vector<uint8_t> winf;
+    if (have_tk) { wxy.resize(8 * COLUMNS); winf.resize(COLUMNS); KP(kh_msm_wait(tk, wxy.data(), winf.data())); }
+    else KP(commit_evals(ev.p, COLUMNS, wxy, winf));
+    const fe* w_blind = draw(COLUMNS * nch);          // blinder(num_chunks) per column, column by column (prover.rs:316-327)
+    std::vector<uint64_t> wcx; std::vector<uint8_t> wci;
+    KP(mask(wxy, winf, w_blind, wcx, wci));
+    KP(kh_sponge_absorb_g(fq.s, wcx.data(), wci.data(), COLUMNS * nch));
+    pr->set_points(KH_PROOF_W_COMM, wcx.data(), wci.data(), COLUMNS * nch);
+    mark();
+    fe beta, gamma;
+    KP(kh_sponge_challenge_field(fq.s, beta.l)); KP(kh_sponge_challenge_field(fq.s, gamma.l));
+    // ---- permutation aggregation z: numerators / denominators, batch inversion, running product (permutation.rs:510-568)
+    fe bshift[7];
+    for (int i = 0; i < 7; i++) bshift[i] = F.mul(beta, ix->shifts[i]);
+    uint64_t* zcol = ev.at(COLUMNS * NB);
+    Dev num, den; KP(num.alloc(NB)); KP(den.alloc(NB));
+    {
+        const uint64_t* cols[15]; size_t lens[15];
+        for (size_t i = 0; i < PERMUTS; i++) { cols[i] = ev.at(i * NB); cols[PERMUTS + i] = ix->col1(COLUMNS + 2 + i); }
+        cols[14] = ix->col1(COLUMNS + 1);
+        for (int i = 0; i < 15; i++) lens[i] = n;
+        fe consts[9]; consts[0] = gamma; consts[1] = beta; for (int i = 0; i < 7; i++) consts[2 + i] = bshift[i];
+        std::vector<uint32_t> nt, dt;
+        auto tok = [](std::vector<uint32_t>& v, uint32_t op, uint32_t a) { v.push_back(op); v.push_back(a); };
+        for (uint32_t i = 0; i < 7; i++) {            // prod_i (w_i + sid beta shift_i + gamma), prod_i (w_i + sigma_i beta + gamma)
+            tok(nt, KH_TOK_CELL, 2 * i); tok(nt, KH_TOK_CELL, 2 * 14); tok(nt, KH_TOK_CONST, 2 + i); tok(nt, KH_TOK_MUL, 0); tok(nt, KH_TOK_ADD, 0);
+            tok(nt, KH_TOK_CONST, 0); tok(nt, KH_TOK_ADD, 0); if (i) tok(nt, KH_TOK_MUL, 0);
+            tok(dt, KH_TOK_CELL, 2 * i); tok(dt, KH_TOK_CELL, 2 * (7 + i)); tok(dt, KH_TOK_CONST, 1); tok(dt, KH_TOK_MUL, 0); tok(dt, KH_TOK_ADD, 0);
+            tok(dt, KH_TOK_CONST, 0); tok(dt, KH_TOK_ADD, 0); if (i) tok(dt, KH_TOK_MUL, 0);
+        }
+        KP(kh_dev_upload(num.p, one.l, 32)); KP(kh_dev_upload(den.p, one.l, 32));
+        KP(kh_expr_evaluations_dev(fid, nt.data(), nt.size() / 2, cols, lens, 15, (const uint64_t*)consts, 9, n - 1, 1, 8, 0, num.at(1)));
+        KP(kh_expr_evaluations_dev(fid, dt.data(), dt.size() / 2, cols, lens, 15, (const uint64_t*)consts, 9, n - 1, 1, 8, 0, den.at(1)));
+        KP(kh_batch_inversion_dev(fid, den.at(1), n - 1));
+        const uint32_t prod[6] = {KH_TOK_CELL, 0, KH_TOK_CELL, 2, KH_TOK_MUL, 0};
+        const uint64_t* pc[2] = {num.p, den.p}; const size_t pl[2] = {n, n};
+        KP(kh_expr_evaluations_dev(fid, prod, 3, pc, pl, 2, one.l, 1, n, 1, 8, 0, zcol));
+        KP(kh_field_scan_dev(fid, KH_SCAN_MUL, 0, zcol, n - zk + 1));
+        if (check) {
+            fe last; KP(kh_dev_download(last.l, zcol + 4 * (n - zk), 32));
+            KP_REQUIRE(khost::eq(last, one), "final value of the permutation accumulator is not 1 (permutation.rs:566-568)");
+        }
+        KP(kh_dev_upload(zcol + 4 * (n - zk + 1), draw(2), 64));       // z's two random rows, in that order
+        if (zk > 3) KP(kh_field_scan_dev(fid, KH_SCAN_MUL, 0, zcol + 4 * (n - zk + 2), zk - 2));
+    }
+    uint64_t* zc = cf.at(COLUMNS * NB);
+    KP(kh_dev_copy(zc, zcol, NB * 32));
+    KP(kh_ntt_dev(fid, zc, logn, 1, 1));
+    have_tk = false;
+    if (nch == 1 && size == n) { KP(kh_msm_submit(srs, KH_BASIS_G, 0, 0, zc, n, 1, 1, &tk)); have_tk = true; }   // ... while z is extended to d8
+    KP(kh_lde_dev(fid, zc, logn, 3, e8.at(COLUMNS * N8), 1));
+    std::vector<uint64_t> zxy; std::vector<uint8_t> zinf;
+    if (have_tk) { zxy.resize(8); zinf.resize(1); KP(kh_msm_wait(tk, zxy.data(), zinf.data())); }
+    else KP(commit_coeffs(zc, n, nch, zxy, zinf));
+    const size_t nzb = zinf.size();
+    const fe* z_blind = draw(nzb);
+    KP_REQUIRE(nzb == nch, "unexpected chunk count of z");
+    std::vector<uint64_t> zcx; std::vector<uint8_t> zci;
+    KP(mask(zxy, zinf, z_blind, zcx, zci));
+    KP(kh_sponge_absorb_g(fq.s, zcx.data(), zci.data(), nzb));
+    pr->set_points(KH_PROOF_Z_COMM, zcx.data(), zci.data(), nzb);
+    mark();
+    fe alpha; KP(scalar_challenge(fq.s, alpha));
+    fe alphas[3]; alphas[0] = fpow(F, alpha, ALPHA_PERM0); alphas[1] = F.mul(alphas[0], alpha); alphas[2] = F.mul(alphas[1], alpha);
+    // ---- constraint rows on d8, quotient (prover.rs:794-917)
+    Dev t4, t8; KP(t4.alloc(4 * NB)); KP(t8.alloc(N8));
+    {
+        const uint64_t* cols[31];
+        std::vector<uint64_t> consts(4 * 64);
+        for (size_t i = 0; i < COLUMNS; i++) { cols[i] = e8.at(i * N8); cols[COLUMNS + i] = ix->col8(i); }
+        cols[30] = ix->col8(COLUMNS);
+        fe gp[2] = {one, alpha};
+        KP(kh_gate_constants(fid, ix->gid_generic, nullptr, nullptr, (const uint64_t*)gp, 2, consts.data()));
+        KP(kh_gate_evaluations_dev(fid, ix->gid_generic, cols, N8, consts.data(), (size_t)kh_gate_num_constants(ix->gid_generic), 4 * n, 2, 8, 0, t4.p));
+        const uint64_t* pc[31];
+        for (size_t i = 0; i < COLUMNS; i++) pc[i] = e8.at(i * N8);
+        for (size_t i = 0; i < PERMUTS; i++) pc[COLUMNS + i] = ix->col8(COLUMNS + 2 + i);
+        pc[22] = e8.at(COLUMNS * N8); pc[23] = ix->col8(ix->ncol); pc[24] = ix->col8(ix->ncol + 1);
+        for (int i = 25; i < 31; i++) pc[i] = pc[0];
+        fe pp[10]; pp[0] = gamma; pp[1] = beta; pp[2] = alphas[0]; for (int i = 0; i < 7; i++) pp[3 + i] = bshift[i];
+        KP(kh_gate_constants(fid, ix->gid_perm, nullptr, nullptr, (const uint64_t*)pp, 10, consts.data()));
+        KP(kh_gate_evaluations_dev(fid, ix->gid_perm, pc, N8, consts.data(), (size_t)kh_gate_num_constants(ix->gid_perm), N8, 1, 8, 0, t8.p));
+        for (size_t k = 0; k < 5 + nopt; k++) {      // the gate library on d8 (prover.rs:824-868): index(gate) * sum_i alpha^i constraint_i
+            const bool live = k < 5 ? (((ix->live >> k) & 1u) || all_gates) : true;
+            if (!live) continue;
+            const int gid = k < 5 ? ix->lib_gate[k] : ix->optional[k - 5];
+            const int nc = kh_gate_num_constants(gid);
+            KP_REQUIRE(nc >= 0 && nc <= 64, "constants table of gate %d too large", gid);
+            KP(kh_gate_constants(fid, gid, alpha.l, ix->endo.l, nullptr, 0, consts.data()));
+            cols[30] = ix->col8(SEL0 + k);
+            KP(kh_gate_evaluations_dev(fid, gid, cols, N8, consts.data(), (size_t)nc, N8, 1, 8, 1, t8.p));
+        }
+    }
+    KP(kh_ntt_dev(fid, t4.p, logn + 2, 1, 1));
+    KP(kh_ntt_dev(fid, t8.p, logn + 3, 1, 1));
+    {                                                 // f = t4 + t8 + public (prover.rs:906-908)
+        const uint64_t* ps[3] = {t8.p, t4.p, pub_c.p}; const size_t ls[3] = {8 * n, 4 * n, n};
+        fe sc[3] = {one, one, one};
+        KP(kh_poly_lincomb_dev(fid, ps, ls, (const uint64_t*)sc, pub_c.p ? 3 : 2, t8.p, 8 * n));
+    }
+    Dev quot, rem; KP(quot.alloc(7 * NB)); KP(rem.alloc(NB));
+    KP(kh_divide_by_vanishing_poly_dev(fid, t8.p, 8 * n, logn, quot.p, rem.p));
+    if (check) {
+        std::vector<uint64_t> r(4 * n);
+        KP(kh_dev_download(r.data(), rem.p, NB * 32));
+        bool nz = false; for (uint64_t x : r) nz |= x != 0;
+        KP_REQUIRE(!nz, "rest of division by vanishing polynomial (prover.rs:913-917): the witness does not satisfy the constraints");
+    }
+    Dev zm1, b1, b2; KP(zm1.alloc(NB)); KP(b1.alloc(NB)); KP(b2.alloc(NB));
+    {
+        const uint64_t* ps[1] = {zc}; const size_t ls[1] = {n};
+        KP(kh_poly_lincomb_dev(fid, ps, ls, one.l, 1, zm1.p, n));
+        fe z0; KP(kh_dev_download(z0.l, zm1.p, 32));
+        z0 = F.sub(z0, one);
+        KP(kh_dev_upload(zm1.p, z0.l, 32));
+        KP(kh_dev_memset_zero(b1.p, NB * 32)); KP(kh_dev_memset_zero(b2.p, NB * 32));
+        const fe pts2[2] = {one, fpow(F, ix->omega, n - zk)};
+        uint64_t* dst[2] = {b1.p, b2.p};
+        for (int i = 0; i < 2; i++) {                 // (z - 1) / (x - 1), (z - 1) / (x - omega^(n - zk)) (permutation.rs:301-321)
+            uint64_t r[4];
+            KP(kh_divide_by_linear_dev(fid, zm1.p, n, pts2[i].l, dst[i], r));
+            if (check) KP_REQUIRE((r[0] | r[1] | r[2] | r[3]) == 0, "permutation boundary division rest (permutation.rs:301-321)");
+        }
+        const uint64_t* qs[3] = {quot.p, b1.p, b2.p}; const size_t ql[3] = {7 * n, n - 1, n - 1};
+        fe sc[3] = {one, alphas[1], alphas[2]};
+        KP(kh_poly_lincomb_dev(fid, qs, ql, (const uint64_t*)sc, 3, quot.p, 7 * n));
+    }
+    std::vector<uint64_t> txy; std::vector<uint8_t> tinf;
+    KP(commit_coeffs(quot.p, 7 * n, 7 * nch, txy, tinf));
+    const size_t ntb = tinf.size();
+    KP_REQUIRE(ntb == 7 * nch, "unexpected chunk count of t");
+    const fe* t_blind = draw(ntb);
+    std::vector<uint64_t> tcx; std::vector<uint8_t> tci;
+    KP(mask(txy, tinf, t_blind, tcx, tci));
+    KP(kh_sponge_absorb_g(fq.s, tcx.data(), tci.data(), ntb));
+    pr->set_points(KH_PROOF_T_COMM, tcx.data(), tci.data(), ntb);
+    mark();
+    fe zeta; KP(scalar_challenge(fq.s, zeta));
+    const fe zetaw = F.mul(zeta, ix->omega);
+    SpongeH fq_before; KP(kh_sponge_clone(fq.s, &fq_before.s));
+    // ---- chunked evaluations at zeta, zeta omega (prover.rs:989-1004)
+    std::vector<const uint64_t*> polys;
+    polys.push_back(zc); polys.push_back(ix->colc(COLUMNS));
+    for (size_t k = 0; k < 5; k++) polys.push_back(ix->colc(SEL0 + k));
+    for (size_t i = 0; i < COLUMNS; i++) polys.push_back(cf.at(i * NB));
+    for (size_t i = 0; i < COLUMNS; i++) polys.push_back(ix->colc(i));
+    for (size_t i = 0; i + 1 < PERMUTS; i++) polys.push_back(ix->colc(COLUMNS + 2 + i));
+    for (size_t k = 0; k < nopt; k++) polys.push_back(ix->colc(OPT0 + k));
+    const size_t npoly = polys.size();
+    const fe pts[2] = {zeta, zetaw};
+    std::vector<fe> E(npoly * 2 * nch);               // polynomial j: E[(2 j + p) nch + c]
+    {
+        std::vector<size_t> lens(npoly, n), chs(npoly, nch);
+        KP(kh_evaluate_chunks_batch_dev(fid, polys.data(), lens.data(), chs.data(), npoly, size, (const uint64_t*)pts, 2, (uint64_t*)E.data()));
+    }
+    std::vector<fe> pub_eval(2 * nch, zero);
+    if (pub_c.p) KP(kh_evaluate_chunks_dev(fid, pub_c.p, n, size, nch, (const uint64_t*)pts, 2, (uint64_t*)pub_eval.data()));
+    // ---- ft = perm_scalar sigma_6 - (zeta^n - 1) t, chunk-linearised with zeta^max_poly_size (Maller; prover.rs:1147-1200)
+    const fe zeta1 = fpow(F, zeta, n), zeta_srs = fpow(F, zeta, size), zetaw_srs = fpow(F, zetaw, size);
+    auto comb = [&](size_t j, int p) { return horner(F, &E[(2 * j + p) * nch], nch, p ? zetaw_srs : zeta_srs); };
+    const fe wz = fpow(F, ix->omega, n - zk);
+    fe zkp = F.mul(F.mul(F.sub(zeta, wz), F.sub(zeta, F.mul(wz, ix->omega))), F.sub(zeta, fpow(F, ix->omega, n - 1)));
+    fe scal = F.mul(F.mul(F.mul(comb(0, 1), beta), alphas[0]), zkp);
+    for (size_t i = 0; i + 1 < PERMUTS; i++)          // w_i: polynomial 7 + i; sigma_i: polynomial 37 + i
+        scal = F.mul(scal, F.add(F.add(gamma, F.mul(beta, comb(37 + i, 0))), comb(7 + i, 0)));
+    scal = F.neg(scal);
+    const fe m1 = F.neg(F.sub(zeta1, one));
+    const size_t ft_len = size < 7 * n ? size : 7 * n;
+    Dev ft; KP(ft.alloc(ft_len));
+    {
+        std::vector<const uint64_t*> segs; std::vector<size_t> lens; std::vector<fe> scs;
+        const uint64_t* sig6 = ix->colc(COLUMNS + 2 + PERMUTS - 1);
+        fe pw = one;
+        for (size_t c = 0; c < nch; c++) {            // f_chunked.linearize(zeta^srs_len)
+            if (c * size < n) { const size_t ln = n - c * size < size ? n - c * size : size; segs.push_back(sig6 + 4 * c * size); lens.push_back(ln); scs.push_back(F.mul(scal, pw)); }
+            pw = F.mul(pw, zeta_srs);
+        }
+        pw = one;
+        for (size_t c = 0; c < 7 * nch; c++) {        // t_chunked.linearize(zeta^srs_len) * -(zeta^n - 1)
+            if (c * size < 7 * n) { const size_t ln = 7 * n - c * size < size ? 7 * n - c * size : size; segs.push_back(quot.at(c * size)); lens.push_back(ln); scs.push_back(F.mul(m1, pw)); }
+            pw = F.mul(pw, zeta_srs);
+        }
+        KP(kh_poly_lincomb_dev(fid, segs.data(), lens.data(), (const uint64_t*)scs.data(), segs.size(), ft.p, ft_len));
+    }
+    fe fte[2];
+    KP(kh_evaluate_chunks_dev(fid, ft.p, ft_len, ft_len, 1, (const uint64_t*)pts, 2, (uint64_t*)fte));
+    const fe blinding_ft = F.mul(m1, horner(F, t_blind, ntb, zeta_srs));
+    // ---- Fr-sponge: v, u (prover.rs:1206-1250, plonk_sponge.rs:92-155)
+    fe v, u;
+    {
+        SpongeH fr, pd; KP(kh_sponge_new(KH_SPONGE_FR, curve, &fr.s)); KP(kh_sponge_new(KH_SPONGE_FR, curve, &pd.s));
+        fe d; KP(kh_sponge_digest(fq.s, d.l)); KP(kh_sponge_absorb(fr.s, d.l, 1));
+        KP(kh_sponge_digest(pd.s, d.l)); KP(kh_sponge_absorb(fr.s, d.l, 1));           // the digest of no previous challenges
+        std::vector<fe> flat; flat.reserve(1 + 2 * nch * (npoly + 1));
+        flat.push_back(fte[1]);
+        flat.insert(flat.end(), pub_eval.begin(), pub_eval.end());
+        flat.insert(flat.end(), E.begin(), E.end());
+        KP(kh_sponge_absorb(fr.s, (const uint64_t*)flat.data(), flat.size()));
+        KP(scalar_challenge(fr.s, v)); KP(scalar_challenge(fr.s, u));
+    }
+    pr->set_elems(KH_PROOF_EVALS, E.data(), E.size());
+    pr->set_elems(KH_PROOF_PUBLIC_EVALS, pub_eval.data(), pub_eval.size());
+    pr->set_elems(KH_PROOF_FT_EVAL1, &fte[1], 1);
+    mark();
+    // ---- SRS::open on (public, ft, z, 6 selectors, w x 15, coefficients x 15, sigma x 6, optional selectors)
+    size_t logs = 0; while (((size_t)1 << logs) < size) logs++;
+    std::vector<uint64_t> lr_xy(16 * logs); std::vector<uint8_t> lr_inf(2 * logs);
+    uint64_t delta[8], sg[8], z1[4], z2[4]; uint8_t dinf = 0, sginf = 0;
+    {
+        std::vector<const uint64_t*> op; std::vector<size_t> ol, oc;
+        op.push_back(pub_c.p ? pub_c.p : ix->zero_poly); ol.push_back(pub_c.p ? n : 0); oc.push_back(nch);
+        op.push_back(ft.p); ol.push_back(ft_len); oc.push_back(1);
+        for (size_t j = 0; j < npoly; j++) { op.push_back(polys[j]); ol.push_back(n); oc.push_back(nch); }
+        std::vector<fe> bl;                            // one blinder per chunk of every opened polynomial
+        bl.insert(bl.end(), nch, one); bl.push_back(blinding_ft);
+        bl.insert(bl.end(), z_blind, z_blind + nch);
+        bl.insert(bl.end(), 6 * nch, one);
+        bl.insert(bl.end(), w_blind, w_blind + COLUMNS * nch);
+        bl.insert(bl.end(), (COLUMNS + PERMUTS - 1 + nopt) * nch, zero);
+        Dev a_dev, b_dev; KP(a_dev.alloc(size)); KP(b_dev.alloc(size));
+        size_t out_len = 0;
+        KP(kh_combine_polys_dev(fid, op.data(), ol.data(), oc.data(), op.size(), v.l, size, a_dev.p, &out_len));
+        KP(kh_b_init_dev(fid, (const uint64_t*)pts, 2, u.l, size, b_dev.p));
+        // per chunk: combined_inner_product (commitment.rs:622-657) and the combined blinder
+        fe blinding_factor = zero, cip = zero, ps = one;
+        size_t bi = 0;
+        auto take = [&](const fe& c0, const fe& c1) {
+            blinding_factor = F.add(blinding_factor, F.mul(bl[bi++], ps));
+            cip = F.add(cip, F.mul(ps, F.add(c0, F.mul(u, c1))));
+            ps = F.mul(ps, v);
+        };
+        for (size_t c = 0; c < nch; c++) take(pub_eval[c], pub_eval[nch + c]);
+        take(fte[0], fte[1]);
+        for (size_t j = 0; j < npoly; j++) for (size_t c = 0; c < nch; c++) take(E[(2 * j) * nch + c], E[(2 * j + 1) * nch + c]);
+        KP_REQUIRE(bi == bl.size(), "blinders / evaluation chunks mismatch");
+        const fe* ob = draw(2 * logs + 2);            // (rand_l, rand_r) per round, then d, r_delta
+        KP(kh_ipa_open(srs, a_dev.p, size, b_dev.p, size, cip.l, blinding_factor.l, fq_before.s, (const uint64_t*)ob, 2 * logs + 2, lr_xy.data(), lr_inf.data(),
+                       delta, &dinf, z1, z2, sg, &sginf));
+    }
+    KP_REQUIRE(rpos == need, "randomness count mismatch");
+    pr->set_points(KH_PROOF_LR, lr_xy.data(), lr_inf.data(), 2 * logs);
+    pr->set_points(KH_PROOF_DELTA, delta, &dinf, 1);
+    pr->set_points(KH_PROOF_SG, sg, &sginf, 1);
+    fe zz[2] = {load(z1), load(z2)};
+    pr->set_elems(KH_PROOF_Z1_Z2, zz, 2);
+    fe ch[6] = {beta, gamma, alpha, zeta, v, u};
+    pr->set_elems(KH_PROOF_CHALLENGES, ch, 6);
+    KP(kh_sync());                                   // every queued user of the buffers released below has finished
+    mark();
+    guard.p = nullptr;
+    *out = pr;
+    return KH_OK;
+}
+
+int kh_proof_section(const kh_proof_t* proof, int section, const uint64_t** limbs, const uint8_t** flags, size_t* count) {
+    if (!proof || section < 0 || section > KH_PROOF_CHALLENGES || !limbs || !count) { kh::set_error("kh_proof_section: bad argument"); return KH_E_INVALID; }
+    const kh_proof::Sec& s = proof->sec[section];
+    *limbs = s.limbs.data(); *count = s.count;
+    if (flags) *flags = s.points ? s.flags.data() : nullptr;
+    return KH_OK;
+}
+int kh_proof_phase_seconds(const kh_proof_t* proof, double* seconds, size_t cap) {
+    if (!proof || !seconds) { kh::set_error("kh_proof_phase_seconds: null argument"); return KH_E_INVALID; }
+    for (size_t i = 0; i < cap && i < 6; i++) seconds[i] = proof->phase[i];
+    return 6;
+}
+void kh_proof_free(kh_proof_t* proof) { delete proof; }
+
+}  // extern "C"

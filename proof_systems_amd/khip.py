@@ -37,7 +37,8 @@ SYMBOLS = [
     "kh_dev_alloc", "kh_dev_free", "kh_dev_upload", "kh_dev_download", "kh_dev_upload_2d",
     "kh_msm_batch_dev", "kh_ntt_dev", "kh_lde_dev", "kh_coset_ntt_dev", "kh_sync", "kh_last_timings",
     "kh_debug_field_op", "kh_debug_point_op", "kh_srs_generate", "kh_srs_h",
-    "kh_msm_sharded", "kh_msm_sharded_dev", "kh_gate_count", "kh_gate_name", "kh_gate_num_constants", "kh_gate_evaluations_dev",
+    "kh_msm_sharded", "kh_msm_sharded_dev", "kh_gate_count", "kh_gate_name", "kh_gate_num_constants", "kh_gate_evaluations_dev", "kh_gate_constants", "kh_srs_curve",
+    "kh_prover_index_new", "kh_prover_index_free", "kh_prove_randomness_count", "kh_prove", "kh_proof_section", "kh_proof_phase_seconds", "kh_proof_free",
     "kh_commit_non_hiding", "kh_commit_evaluations_non_hiding", "kh_srs_set_blinding_base",
     "kh_srs_get_blinding_base", "kh_mask_custom", "kh_domain_generator", "kh_msm_points_batch", "kh_msm_submit", "kh_msm_wait",
     "kh_ipa_fold_scalars", "kh_inner_product", "kh_ipa_fold_points", "kh_ipa_fold_points_endo", "kh_endos", "kh_scalar_challenge_to_field",
@@ -572,6 +573,18 @@ def gate_num_constants(gate: int) -> int:
     return _lib.kh_gate_num_constants(C.c_int(gate))
 
 
+def gate_constants(field: int, gate: int, alpha=None, endo=None, params=None):
+    """kh_gate_constants: the (k, 4) constants table of a compiled gate kernel for one proof (host only)."""
+    k = gate_num_constants(gate)
+    out = np.zeros((k, 4), dtype=np.uint64)
+    a = _c64(alpha, (4,)) if alpha is not None else None
+    e = _c64(endo, (4,)) if endo is not None else None
+    ps = _c64(params, (-1, 4)) if params is not None else None
+    _check(_lib.kh_gate_constants(C.c_int(field), C.c_int(gate), _p64(a) if a is not None else None, _p64(e) if e is not None else None,
+                                  _p64(ps) if ps is not None else None, C.c_size_t(ps.shape[0] if ps is not None else 0), _p64(out)))
+    return out
+
+
 def gate_evaluations_dev(field: int, gate: int, cols, col_len: int, constants, rows: int, out, stride: int = 1, next_shift: int = 8, accumulate: bool = False,
                          out_offset: int = 0):
     """kh_gate_evaluations_dev: cols = 31 DevBuf (witness 0..14, coefficients 15..29, the gate's selector); constants (k, 4) Montgomery limbs."""
@@ -580,6 +593,58 @@ def gate_evaluations_dev(field: int, gate: int, cols, col_len: int, constants, r
     cs = _c64(constants, (-1, 4))
     _check(_lib.kh_gate_evaluations_dev(C.c_int(field), C.c_int(gate), ptrs, C.c_size_t(col_len), _p64(cs), C.c_size_t(cs.shape[0]), C.c_size_t(rows),
                                         C.c_uint(stride), C.c_uint(next_shift), C.c_int(int(accumulate)), C.c_void_p(out.ptr + 32 * out_offset)))
+
+
+PROVE_CHECK, PROVE_ALL_GATES = 1, 2
+PROOF_SECTIONS = {"w_comm": 0, "z_comm": 1, "t_comm": 2, "public_comm": 3, "evals": 4, "public_evals": 5, "ft_eval1": 6, "lr": 7, "delta": 8, "z1_z2": 9, "sg": 10,
+                  "challenges": 11}
+PROOF_PHASES = ("witness_upload", "witness_commit", "z", "quotient", "evaluations", "opening")
+
+
+class NativeProverIndex:
+    """kh_prover_index_new: the C++ prover's view of device-resident index columns (they must outlive the handle)."""
+
+    def __init__(self, srs, log2_n: int, zk_rows: int, public: int, d1, dc, d8, optional_gate_ids, live_mask: int, shifts, digest):
+        self._h = C.c_void_p()
+        opt = (C.c_int * max(len(optional_gate_ids), 1))(*optional_gate_ids)
+        sh = _c64(shifts, (7, 4)); dg = _c64(digest, (4,))
+        _check(_lib.kh_prover_index_new(srs._h, C.c_uint(log2_n), C.c_uint(zk_rows), C.c_uint(public), C.c_void_p(d1.ptr), C.c_void_p(dc.ptr), C.c_void_p(d8.ptr),
+                                        opt, C.c_size_t(len(optional_gate_ids)), C.c_uint(live_mask), _p64(sh), _p64(dg), C.byref(self._h)))
+        self._keep = (srs, d1, dc, d8)
+
+    def randomness_count(self, witness_on_host: bool) -> int:
+        _lib.kh_prove_randomness_count.restype = C.c_size_t
+        return _lib.kh_prove_randomness_count(self._h, C.c_int(int(witness_on_host)))
+
+    def prove(self, witness=None, witness_dev=None, randomness=None, flags: int = PROVE_CHECK):
+        """kh_prove.  witness: (15, rows, 4) limbs on the host, or witness_dev: DevBuf with the padded columns.  randomness: (k, 4) limbs in
+        the reference's draw order, or None (the library draws from the OS).  Returns ({section: limbs[, flags]}, {phase: seconds})."""
+        pr = C.c_void_p()
+        w = _c64(witness, (15, -1, 4)) if witness is not None else None
+        rnd = _c64(randomness, (-1, 4)) if randomness is not None else None
+        _check(_lib.kh_prove(self._h, _p64(w) if w is not None else None, C.c_size_t(w.shape[1] if w is not None else 0),
+                             C.c_void_p(witness_dev.ptr) if witness_dev is not None else None, _p64(rnd) if rnd is not None else None,
+                             C.c_size_t(rnd.shape[0] if rnd is not None else 0), C.c_uint(flags), C.byref(pr)))
+        try:
+            out = {}
+            for name, sid in PROOF_SECTIONS.items():
+                lp = C.POINTER(C.c_uint64)(); fp = C.POINTER(C.c_uint8)(); cnt = C.c_size_t(0)
+                _check(_lib.kh_proof_section(pr, C.c_int(sid), C.byref(lp), C.byref(fp), C.byref(cnt)))
+                k = cnt.value
+                if fp:                                    # points
+                    out[name] = (np.ctypeslib.as_array(lp, shape=(k, 8)).copy() if k else np.zeros((0, 8), np.uint64),
+                                 np.ctypeslib.as_array(fp, shape=(k,)).copy() if k else np.zeros(0, np.uint8))
+                else:
+                    out[name] = np.ctypeslib.as_array(lp, shape=(k, 4)).copy() if k else np.zeros((0, 4), np.uint64)
+            ph = (C.c_double * 6)()
+            _lib.kh_proof_phase_seconds(pr, ph, C.c_size_t(6))
+            return out, dict(zip(PROOF_PHASES, list(ph)))
+        finally:
+            _lib.kh_proof_free(pr)
+
+    def free(self):
+        if self._h:
+            _lib.kh_prover_index_free(self._h); self._h = C.c_void_p()
 
 
 def polycomm_multi_scalar_mul(curve: int, comms, scalars):

@@ -103,7 +103,7 @@ class Env:
 
     def __init__(self, p: int, w0: int = 0, c0: int = 15, mds=None, endo: int = 0):
         self.p, self.w0, self.c0, self._mds, self._endo = p, w0, c0, mds, endo
-        self.consts, self._index = [], {}
+        self.consts, self._index, self.param_slots = [], {}, set()
 
     def const(self, v: int) -> Node:
         v %= self.p
@@ -115,6 +115,7 @@ class Env:
         """a constant slot of its own (a per-proof value: a challenge, a power of alpha): never merged with an equal literal, so that the
         LAYOUT of the constants table does not depend on the values"""
         self.consts.append(v % self.p)
+        self.param_slots.add(len(self.consts) - 1)
         return Node(TOK_CONST, arg=len(self.consts) - 1)
 
     def witness_curr(self, i): return Node(TOK_CELL, arg=2 * (self.w0 + i))

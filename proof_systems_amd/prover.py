@@ -294,6 +294,8 @@ class ProverIndex:
         khip.sync()
 
     def free(self):
+        if getattr(self, "_native", None) is not None:
+            self._native[0].free(); self._native = None
         for b in (self.d1, self.dc, self.d8, self.zero_poly):
             b.free()
 
@@ -313,6 +315,53 @@ def _horner(p: int, coeffs, x: int) -> int:
     for c in reversed(coeffs):
         acc = (acc * x + c) % p
     return acc
+
+
+def native_index(ix: "ProverIndex"):
+    """The C++ prover's handle on this index (kh_prover_index_new), made once; None when the circuit is outside kh_prove's scope (lookups)."""
+    if getattr(ix, "lookup", None) is not None or ix.prev_challenges:
+        return None
+    h = getattr(ix, "_native", None)
+    if h is None or h[1] is not ix.d8:
+        gids = khip.gate_ids()
+        live = sum(1 << k for k, name in enumerate(ix.GATE_TYPES) if name in ix.live_gate_types)
+        h = (khip.NativeProverIndex(ix.srs, ix.log2_n, ix.zk_rows, ix.public, ix.d1, ix.dc, ix.d8, [gids[t] for t in ix.optional], live,
+                                    ix.F.limbs_many(ix.shifts), ix.digest), ix.d8)
+        ix._native = h
+    return h[0]
+
+
+def create_proof_native(ix: "ProverIndex", witness, rng, timings=None, check: bool = True, witness_on_device=None, all_gates: bool = False):
+    """create_proof through kh_prove: the host loop in C++ (csrc/prover.cpp), same protocol, same draws from `rng` in the same order, same result
+    dict.  rng=None: the library draws from the operating system's generator."""
+    F, nch = ix.F, ix.num_chunks
+    nx = native_index(ix)
+    if nx is None:
+        raise ValueError("kh_prove covers circuits without lookups and recursion; use create_proof")
+    on_host = witness_on_device is None
+    rnd = F.limbs_many(F.rand_many(rng, nx.randomness_count(on_host))) if rng is not None else None
+    flags = (khip.PROVE_CHECK if check else 0) | (khip.PROVE_ALL_GATES if all_gates else 0)
+    sec, phases = nx.prove(witness=np.asarray(witness, dtype=np.uint64).reshape(COLUMNS, -1, 4) if on_host else None, witness_dev=witness_on_device,
+                           randomness=rnd, flags=flags)
+    comms = lambda key, k: [(sec[key][0][i * nch:(i + 1) * nch], sec[key][1][i * nch:(i + 1) * nch]) for i in range(k)]
+    ev = F.values(sec["evals"])
+    E = [(ev[(2 * j) * nch:(2 * j + 1) * nch], ev[(2 * j + 1) * nch:(2 * j + 2) * nch]) for j in range(len(ev) // (2 * nch))]
+    pe = F.values(sec["public_evals"])
+    evals = {"public": (pe[:nch], pe[nch:]), "z": E[0], "generic_selector": E[1], "poseidon_selector": E[2], "complete_add_selector": E[3], "mul_selector": E[4],
+             "emul_selector": E[5], "endomul_scalar_selector": E[6], "w": E[7:22], "coefficients": E[22:37], "s": E[37:43],
+             "optional_gate_selectors": [E[43 + ix.optional.index(t)] if t in ix.optional else None for t in OPTIONAL_GATES]}
+    lr_xy, lr_inf = sec["lr"]
+    z12 = F.values(sec["z1_z2"])
+    opening = {"lr": [(lr_xy[2 * r:2 * r + 2], lr_inf[2 * r:2 * r + 2]) for r in range(lr_xy.shape[0] // 2)], "delta": (sec["delta"][0][0], bool(sec["delta"][1][0])),
+               "z1": z12[0], "z2": z12[1], "sg": (sec["sg"][0][0], bool(sec["sg"][1][0]))}
+    ch = F.values(sec["challenges"])
+    if timings is not None:
+        for k_, v_ in phases.items():
+            timings[k_] = timings.get(k_, 0.0) + v_
+        timings["total"] = timings.get("total", 0.0) + sum(phases.values())
+    return {"w_comm": comms("w_comm", COLUMNS), "z_comm": comms("z_comm", 1)[0], "t_comm": (sec["t_comm"][0], sec["t_comm"][1]), "public_comm": comms("public_comm", 1)[0],
+            "evals": evals, "ft_eval1": F.values(sec["ft_eval1"])[0], "opening": opening, "prev_challenges": [],
+            "challenges": {"beta": ch[0], "gamma": ch[1], "alpha": ch[2], "zeta": ch[3], "v": ch[4], "u": ch[5], "joint_combiner": None}}
 
 
 def create_proof(ix: ProverIndex, witness, rng, timings=None, check: bool = True, witness_on_device=None, prev_challenges=(), all_gates: bool = False,

@@ -189,3 +189,29 @@ def test_compiled_expressions_keep_the_constants_layout():
         env = OP.Env(p)
         OP.generic_expression(env, alpha=1)
         assert env.consts == [1, 1]
+
+
+@pytest.mark.parametrize("fid", [0, 1])
+def test_gate_constants_from_the_library_equal_the_builders(fid):
+    """kh_gate_constants (host only: the recipe tools/gen_gate_kernels.py derived from the expression DAGs) returns, for every compiled gate, the
+    constants table polish.gate_program builds for the same alpha / endo coefficient -- a C or Rust caller needs no copy of the builder."""
+    import random
+    import numpy as np
+    from oracle import cref
+    import proof_systems_amd.khip as khip
+    Fd = P.Fp if fid == 0 else P.Fq
+    rnd = random.Random(5 + fid)
+    lim = lambda vals: cref.ints_to_limbs([Fd.to_mont(v % Fd.p) for v in vals])
+    gids = khip.gate_ids()
+    for name in OP.GATES:
+        alpha, endo = rnd.randrange(Fd.p), rnd.randrange(Fd.p)
+        _, consts = OP.gate_program(name, Fd.p, alpha, selector_col=30, mds=OP.POSEIDON_MDS[fid], endo=endo)
+        got = khip.gate_constants(fid, gids[name], lim([alpha])[0], lim([endo])[0])
+        assert (got == lim(consts)).all(), name
+    params = [rnd.randrange(Fd.p) for _ in range(10)]
+    assert (khip.gate_constants(fid, gids["Permutation"], params=lim(params)) == lim(params)).all()
+    assert (khip.gate_constants(fid, gids["Generic"], params=lim(params[:2])) == lim(params[:2])).all()
+    with pytest.raises(khip.KhError):
+        khip.gate_constants(fid, gids["Permutation"], params=lim(params[:9]))
+    with pytest.raises(khip.KhError):
+        khip.gate_constants(fid, gids["Poseidon"])                       # needs alpha

@@ -1,0 +1,149 @@
+"""kh_prove -- ProverProof::create as one native call (csrc/prover.cpp, the host loop in C++ over the library's own C ABI) -- against the
+oracle's CPU prover (oracle/prover.py, pinned on the reference's whole-proof vector) and against the Python device prover, on the same
+circuit, witness and random stream: the same proof, byte for byte.  Covers generic circuits with copy constraints and public inputs, both
+curves, an SRS longer than the domain, chunked proofs (domain larger than the SRS), the whole gate library with an optional gate, the
+all-gates mode, a device-resident witness, the library's own randomness, and the error paths."""
+import random
+
+import numpy as np
+import pytest
+
+from oracle import circuit as CC
+from oracle import kimchi as K
+from oracle import pasta as P
+from oracle import prover as OPR
+from oracle import views as V
+
+from test_gpu_prover_parity import _limbs, compare, device_index
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def khip():
+    import proof_systems_amd.khip as k
+    k.init(0)
+    return k
+
+
+def generic_circuit(F, logn, log_srs, rnd, npub=3):
+    p = F.p
+    n = 1 << logn
+    nch = 1 << max(0, logn - log_srs)
+    zk = (16 * nch + 5) // 7
+    rows = n - zk - 5
+    gates, wit = [], [[0] * rows for _ in range(15)]
+    for r in range(rows):
+        a, b = int(rnd.integers(1, 1 << 62)), int(rnd.integers(1, 1 << 62))
+        if r < npub:
+            gates.append(CC.generic_gadget(p, r, CC.generic_spec(p, "Pub")))
+            wit[0][r] = a
+        else:
+            gates.append(CC.generic_gadget(p, r, CC.generic_spec(p, "Add"), CC.generic_spec(p, "Mul")))
+            wit[0][r], wit[1][r], wit[2][r] = a, b, (a + b) % p
+            wit[3][r], wit[4][r], wit[5][r] = b, a, a * b % p
+    for r in range(npub, rows - 1, 2):
+        CC.connect_cell_pair(gates, (r, 0), (r, 4))
+    cs = CC.build(F, gates, public=npub, max_poly_size=1 << log_srs)
+    assert cs["log2_n"] == logn and cs["zk_rows"] == zk
+    return cs, wit
+
+
+@pytest.mark.parametrize("cid,logn,log_srs", [(0, 7, 7), (1, 7, 7), (0, 8, 10), (0, 9, 7), (1, 8, 7)])
+def test_native_proof_equals_the_oracle_provers_proof(khip, cid, logn, log_srs):
+    from proof_systems_amd import prover
+    C = P.CURVES[cid]; F = C.scalar
+    cs, wit = generic_circuit(F, logn, log_srs, np.random.default_rng(300 * cid + logn))
+    CC.verify_witness(cs, wit)
+    seed = bytes([17 + logn, cid] + [9] * 30)
+    osrs = OPR.Srs(C, 1 << log_srs)
+    oix = OPR.Index(C, cs, osrs)
+    oproof = OPR.create_proof(oix, wit, P.StdRng(seed))
+    srs = khip.Srs.create(cid, 1 << log_srs)
+    ix = device_index(khip, cs, cid, srs)
+    w = np.stack([_limbs(F, col) for col in wit])
+    nproof = prover.create_proof_native(ix, w, V.RefRng(P.StdRng(seed)))
+    c, vix, pr = V.device_views(ix, nproof)
+    assert compare(C, oproof, pr) is None, compare(C, oproof, pr)
+    assert OPR.serialize_proof(C, pr) == OPR.serialize_proof(C, oproof)
+    # ... and the Python device prover's, challenge for challenge
+    dproof = prover.create_proof(ix, w, V.RefRng(P.StdRng(seed)))
+    assert dproof["challenges"] == nproof["challenges"]
+    assert V.device_views(ix, dproof)[2] == pr
+    ix.free()
+
+
+def library_circuit(F, rnd, optional=("ForeignFieldAdd",)):
+    """generic rows + one instance of every library gate + optional gates that need no lookup table"""
+    from test_gates import gate_rows, tables
+    wrows, crows, types = [], [], []
+    for r in range(6):
+        wrows.append([5] + [0] * 14); crows.append([1, 0, 0, 0, F.p - 5] + [0] * 10); types.append("Generic")
+    for name in ("Poseidon", "CompleteAdd", "VarBaseMul", "EndoMul", "EndoMulScalar") + tuple(optional):
+        w, co, ngate = tables(name, rnd)
+        live = set(gate_rows(name, ngate))
+        for r, (wr, cr) in enumerate(zip(w, co)):
+            wrows.append(list(wr)); crows.append([c % F.p for c in cr]); types.append(name if r in live else "Zero")
+    return wrows, crows, types
+
+
+def test_native_proof_over_the_gate_library(khip):
+    """every always-present gate type and an optional one live in one circuit: native = Python device prover (same challenges, same proof),
+    accepted by the oracle verifier; all-gates mode gives the same proof; a broken row fails the zero-remainder check with the reference's message"""
+    from proof_systems_amd import prover
+    from test_gpu_prover import _verify
+    rnd = random.Random(77)
+    F = prover.Fld(khip.FP)
+    wrows, crows, types = library_circuit(P.Fp, rnd)
+    rows = len(wrows)
+    logn = 7
+    assert rows + 3 <= 1 << logn
+    ix = prover.ProverIndex(khip.VESTA, logn, np.stack([F.limbs_many(r) for r in crows]), gate_types=types)
+    assert ix.optional == ["ForeignFieldAdd"]
+    wit = np.stack([F.limbs_many([wrows[r][c] for r in range(rows)]) for c in range(15)])
+    dproof = prover.create_proof(ix, wit, np.random.default_rng(12))
+    nproof = prover.create_proof_native(ix, wit, np.random.default_rng(12))
+    assert nproof["challenges"] == dproof["challenges"]
+    assert V.device_views(ix, nproof)[2] == V.device_views(ix, dproof)[2]
+    assert _verify(khip, ix, nproof)[0]
+    for key in ("poseidon_selector", "complete_add_selector", "mul_selector", "emul_selector", "endomul_scalar_selector"):
+        assert nproof["evals"][key][0][0] != 0
+    assert nproof["evals"]["optional_gate_selectors"][2] is not None and nproof["evals"]["optional_gate_selectors"][0] is None
+    aproof = prover.create_proof_native(ix, wit, np.random.default_rng(12), all_gates=True)
+    assert V.device_views(ix, aproof)[2] == V.device_views(ix, nproof)[2]
+    tm = {}
+    prover.create_proof_native(ix, wit, np.random.default_rng(13), timings=tm, check=False)
+    assert set(tm) == set(khip.PROOF_PHASES) | {"total"} and all(v > 0 for v in tm.values())
+    r0 = types.index("Poseidon") + 3
+    wrows[r0][7] = (wrows[r0][7] + 1) % F.p
+    bad = np.stack([F.limbs_many([wrows[r][c] for r in range(rows)]) for c in range(15)])
+    with pytest.raises(khip.KhError, match="vanishing polynomial"):
+        prover.create_proof_native(ix, bad, np.random.default_rng(12))
+    ix.free()
+
+
+def test_native_prover_draws_its_own_randomness_and_takes_a_resident_witness(khip):
+    from proof_systems_amd import prover
+    from test_gpu_prover import _verify
+    ix = prover.bench_circuit_index(khip.VESTA, 10)
+    F = ix.F
+    n, zk = ix.n, ix.zk_rows
+    wit = np.zeros((15, n - 10, 4), dtype=np.uint64); wit[0, :, :] = F.limbs(1)
+    p1 = prover.create_proof_native(ix, wit, None)                       # getrandom
+    p2 = prover.create_proof_native(ix, wit, None)
+    assert _verify(khip, ix, p1)[0] and _verify(khip, ix, p2)[0]
+    assert p1["challenges"]["zeta"] != p2["challenges"]["zeta"]          # blinded: two proofs of the same statement differ
+    # the padded columns already on the device (the caller has randomised the zero-knowledge rows)
+    rng = np.random.default_rng(5)
+    full = np.zeros((15, n, 4), dtype=np.uint64); full[:, :n - 10, :] = wit
+    full[:, n - zk:, :] = F.limbs_many(F.rand_many(rng, 15 * zk)).reshape(15, zk, 4)
+    dev = khip.DevBuf(15 * n * 32).upload(full)
+    a = prover.create_proof_native(ix, None, np.random.default_rng(6), witness_on_device=dev)
+    b = prover.create_proof(ix, None, np.random.default_rng(6), witness_on_device=dev)
+    assert V.device_views(ix, a)[2] == V.device_views(ix, b)[2] and _verify(khip, ix, a)[0]
+    nx = prover.native_index(ix)
+    with pytest.raises(khip.KhError, match="random elements"):
+        nx.prove(witness=wit, randomness=np.zeros((3, 4), np.uint64))
+    with pytest.raises(khip.KhError, match="NoRoomForZkInWitness"):
+        nx.prove(witness=np.zeros((15, n, 4), np.uint64))
+    dev.free(); ix.free()

@@ -40,7 +40,7 @@ def _shape_rs(t):
     return levels, (first[-1] == "const") if first else False, base       # the innermost pointer's mutability describes the base
 
 
-MAP = {"int": "c_int", "unsigned": "c_uint", "size_t": "usize", "uint64_t": "u64", "uint8_t": "u8", "uint32_t": "u32", "float": "f32", "void": "c_void", "char": "c_char"}
+MAP = {"int": "c_int", "unsigned": "c_uint", "size_t": "usize", "uint64_t": "u64", "uint8_t": "u8", "uint32_t": "u32", "float": "f32", "double": "f64", "void": "c_void", "char": "c_char"}
 
 
 def test_sys_crate_matches_the_header():

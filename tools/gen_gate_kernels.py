@@ -23,6 +23,7 @@ P_FP = 0x40000000000000000000000000000000224698fc094cf91b992d30ed00000001
 P_FQ = 0x40000000000000000000000000000000224698fc0994a8dd8c46eb2100000001
 ALPHA = 0x1d2c3b4a59687796a5b4c3d2e1f00112233445566778899aabbccddeeff00123      # placeholder: only the LAYOUT of the constants table matters
 ENDO = 0x2d33357cb532458ed3552a23a8554e5005270d29d19fc7d27b7fd22f0201b547       # (any value different from every literal)
+RECIPES = {}
 GATE_IDS = list(OP.GATES) + list(OP.COMPILED_EXTRA)       # the library, then the two arguments every circuit has (generic, permutation)
 
 
@@ -92,6 +93,21 @@ def emit(name):
     root = go(expr)
     nmul = sum(1 for l in lines if "mul<F>" in l or "sqr<F>" in l)
     body = "\n".join("    " + l for l in lines)
+    recipe = []
+    powers = {f: {pow(ALPHA, i, P) : i for i in range(1, 64)} for f, P in ((0, P_FP), (1, P_FQ))}
+    params = getattr(env, "param_slots", set())
+    for k in range(len(env.consts)):
+        a, b = env.consts[k], env_q.consts[k]
+        if k in params:
+            recipe.append((3, sorted(params).index(k), 0, 0))
+        elif a == ENDO % P_FP and b == ENDO % P_FQ:
+            recipe.append((2, 0, 0, 0))
+        elif a in powers[0]:
+            assert powers[1].get(b) == powers[0][a]
+            recipe.append((1, powers[0][a], 0, 0))
+        else:
+            recipe.append((0, 0, a, b))
+    RECIPES[name] = recipe
     return ("// %s: %d constraints, %d products, %d constants\ntemplate <class F>\n__device__ __forceinline__ Fe<F> gate_%s(const GateCtx<F>& g) {\n%s\n    return %s;\n}\n"
             % (name, OP.GATES[name][1] if name in OP.GATES else {"Generic": 2, "Permutation": 1}[name], nmul, len(env.consts), name, body, root)), len(env.consts)
 
@@ -108,6 +124,14 @@ def render():
     out.append("static constexpr int GATE_COUNT = %d;" % len(GATE_IDS))
     out.append("static const char* const GATE_NAMES[GATE_COUNT] = {%s};" % ", ".join('"%s"' % n for n in GATE_IDS))
     out.append("static constexpr int GATE_NCONST[GATE_COUNT] = {%s};" % ", ".join(map(str, counts)))
+    # how the caller's constants table is made (kh_gate_constants): kind 0 = a literal of the protocol (canonical value per field: small integers, 2^k,
+    # the Poseidon MDS), 1 = alpha^arg, 2 = the endo coefficient, 3 = the caller's arg-th per-proof value (challenges)
+    limbs = lambda v: ", ".join("0x%016xULL" % ((v >> (64 * i)) & 0xffffffffffffffff) for i in range(4))
+    out.append("struct GateConst { int kind, arg; unsigned long long lit[2][4]; };")
+    for name in GATE_IDS:
+        rows = ["    {%d, %d, {{%s}, {%s}}}," % (k, a, limbs(x), limbs(y)) for k, a, x, y in RECIPES[name]]
+        out.append("static const GateConst GATE_CONSTS_%s[] = {\n%s\n};" % (name, "\n".join(rows)))
+    out.append("static const GateConst* const GATE_CONST_TABLE[GATE_COUNT] = {%s};" % ", ".join("GATE_CONSTS_" + n for n in GATE_IDS))
     return "\n".join(out) + "\n"
 
 

@@ -9,7 +9,8 @@ import proof_systems_amd.khip as khip
 from proof_systems_amd import prover
 khip.init(0)
 logn = int(sys.argv[1]) if len(sys.argv) > 1 else 16
-counts = [int(x) for x in sys.argv[2:]] or [1, 2, 4]
+NATIVE = "--native" in sys.argv                        # kh_prove (C++ host loop, the library draws the randomness: no Python between the steps, no GIL)
+counts = [int(x) for x in sys.argv[2:] if not x.startswith("--")] or [1, 2, 4]
 tmax = max(counts)
 ixs = [prover.bench_circuit_index(khip.VESTA, logn) for _ in range(tmax)]
 F = prover.Fld(ixs[0].fid)
@@ -17,6 +18,7 @@ wit = np.tile(F.limbs(1), (15, (1 << logn) - 10, 1))
 for ix in ixs:
     prover.create_proof(ix, wit, np.random.default_rng(1), check=False)
 PROOFS = 6
+nxs = [prover.native_index(ix) for ix in ixs] if NATIVE else []
 for T in counts:
     bar = threading.Barrier(T + 1)
 
@@ -25,7 +27,10 @@ for T in counts:
         try:
             bar.wait()
             for _ in range(PROOFS):
-                prover.create_proof(ixs[t], wit, rng, check=False)
+                if NATIVE:
+                    nxs[t].prove(witness=wit, randomness=None, flags=0)
+                else:
+                    prover.create_proof(ixs[t], wit, rng, check=False)
             bar.wait()
         except BaseException:
             bar.abort()                  # a failing prover must not leave the others (and the GPU box) waiting at the barrier

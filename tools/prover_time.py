@@ -23,3 +23,16 @@ for check in (True, False):
         if best is None or t["total"] < best["total"]:
             best = t
     print(f"check={check}: " + "  ".join(f"{k} {1e3 * v:.2f} ms" for k, v in best.items()), f" -> {(1 << logn) / best['total'] / 1e6:.2f} M constraints/s")
+if "--native" in sys.argv or os.environ.get("KH_TIME_NATIVE"):      # the same proof through kh_prove (host loop in C++, csrc/prover.cpp)
+    prover.create_proof_native(ix, wit, rng)
+    for check in (True, False):
+        best = None
+        for _ in range(5):
+            t = {}
+            khip.sync()
+            t0 = time.perf_counter()
+            prover.create_proof_native(ix, wit, rng, timings=t, check=check)
+            t["wall_incl_python_glue"] = time.perf_counter() - t0
+            if best is None or t["total"] < best["total"]:
+                best = t
+        print(f"native check={check}: " + "  ".join(f"{k} {1e3 * v:.2f} ms" for k, v in best.items()), f" -> {(1 << logn) / best['total'] / 1e6:.2f} M constraints/s")
