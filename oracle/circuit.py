@@ -146,6 +146,9 @@ def build(F: P.Field, gates, public: int = 0, lookup_tables=(), max_poly_size: O
         for c, v in enumerate(g["coeffs"][:COLUMNS]):
             coeffs[c][r] = v % p
     sigma = [[shifts[g["wires"][c][1]] * sid[g["wires"][c][0]] % p for g in gates] for c in range(PERMUTS)]
+    for row in range(n + 2 - zk_rows, n - 1):                          # constraints.rs:523-530: the sigmas of the zero-knowledge rows the permutation
+        for c in range(PERMUTS):                                       # argument still checks (none for zk_rows = 3) are zero
+            sigma[c][row] = 0
     sel = lambda names: [1 if t in names else 0 for t in types]
     selectors = {"Generic": sel(("Generic",)), "Poseidon": sel(("Poseidon",)), "CompleteAdd": sel(("CompleteAdd",)), "VarBaseMul": sel(("VarBaseMul",)),
                  "EndoMul": sel(("EndoMul",)), "EndoMulScalar": sel(("EndoMulScalar",))}

@@ -466,6 +466,10 @@ def dev_copy(dst_ptr: int, src_ptr: int, nbytes: int):
     _check(_lib.kh_dev_copy(C.c_void_p(dst_ptr), C.c_void_p(src_ptr), nbytes))
 
 
+def dev_memset_zero(dst_ptr: int, nbytes: int):
+    _check(_lib.kh_dev_memset_zero(C.c_void_p(dst_ptr), C.c_size_t(nbytes)))
+
+
 def group_map_to_group(curve: int, t):
     out = np.zeros(8, dtype=np.uint64)
     _check(_lib.kh_group_map_to_group(curve, _p64(_c64(t, (4,))), _p64(out)))

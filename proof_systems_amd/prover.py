@@ -161,7 +161,15 @@ class ProverIndex:
         khip.ntt_dev(fid, sid, log2_n, False, 1)                                                 # sid[j] = omega^j
         for i in range(PERMUTS):                                                                 # identity wiring: sigma_i = shift_i * sid
             khip.expr_evaluations_dev(fid, [OP.cell(0), (OP.TOK_CONST, 0), (OP.TOK_MUL, 0)], [sid], [n], F.limbs_many([self.shifts[i]]), n, self.col1(COLUMNS + 2 + i))
+        self._zero_sigma_zk_rows()
         self._finish_columns()
+
+    def _zero_sigma_zk_rows(self):
+        """constraints.rs:523-530: sigma is zero on the zero-knowledge rows n + 2 - zk_rows .. n - 2 (the ones the permutation argument still
+        checks; none when zk_rows = 3, i.e. for unchunked circuits)."""
+        cnt = self.zk_rows - 3
+        for i in range(PERMUTS if cnt > 0 else 0):
+            khip.dev_memset_zero(self.col1(COLUMNS + 2 + i).ptr + (self.n + 2 - self.zk_rows) * 32, cnt * 32)
 
     # d1 / coefficient / d8 column views --------------------------------------------------------
     def col1(self, k):
@@ -189,6 +197,9 @@ class ProverIndex:
             for c in range(PERMUTS):
                 r2, c2 = w[c]
                 sg[c][r] = self.shifts[c2] * sid[r2] % F.p
+        for r in range(n + 2 - self.zk_rows, n - 1):
+            for c in range(PERMUTS):
+                sg[c][r] = 0
         self.set_sigma(np.stack([F.limbs_many(col) for col in sg]))
 
     # commitments: (xy (chunks, 8), inf (chunks,)) ------------------------------------------------
