@@ -13,6 +13,7 @@
 //!   * `get_lagrange_basis*`                                                -> the CPU cache of the inner SRS (what the verifier
 //!     and the index read); the device computes its own copy of the same basis once (`kh_srs_compute_lagrange`)
 //!   * `OpenProof::open`                                                    -> host transcript, device rounds (`kh_ipa_*`)
+//!   * `prover::GpuProver::create`                                         -> `kh_prove`: the WHOLE of `ProverProof::create` in one call (no lookups / recursion)
 //!   * `OpenProof::verify`                                                  -> `ipa::SRS::verify` of the inner SRS (batch verifier MSM:
 //!     `kh_ipa_verify_msm` is available to a caller that restructures `verify`; not needed for proving)
 //!
@@ -38,6 +39,7 @@ use rand_core::{CryptoRng, RngCore};
 use std::{ffi::CStr, sync::Arc};
 
 pub mod ntt;
+pub mod prover;
 
 /// Non-zero status -> panic with the library's message: the trait methods return values, and the reference itself
 /// unwraps at these sites (poly-commitment/src/ipa.rs:649-659).
@@ -163,6 +165,11 @@ where
 
     fn chunks(&self, xy: Vec<u64>, inf: Vec<u8>, count: usize) -> PolyComm<G> {
         PolyComm::new(unpack::<G>(&xy[..8 * count], &inf[..count]))
+    }
+
+    /// the library's handle (prover.rs: `kh_prover_index_new` takes it)
+    pub(crate) fn handle(&self) -> *mut sys::kh_srs_t {
+        self.dev.0
     }
 }
 

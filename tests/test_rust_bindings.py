@@ -80,7 +80,7 @@ def test_generated_file_is_current():
 
 def test_safe_crate_calls_exist_with_the_right_arity():
     hdr, _ = _header()
-    for f in ("lib.rs", "ntt.rs"):
+    for f in ("lib.rs", "ntt.rs", "prover.rs"):
         src = open(os.path.join(ROOT, "rust", "kimchi-hip", "src", f)).read()
         src = re.sub(r"//.*", "", src)
         for m in re.finditer(r"sys::(kh_[a-z_0-9]+)\s*\(", src):
