@@ -430,8 +430,8 @@ int kh_debug_point_op(int curve, int op, const uint64_t *p_xy, const uint8_t *p_
 /* ---- ProverProof::create as ONE native call (kimchi/src/prover.rs:187-1515, the part this library accelerates end to end) ----
  * The host loop of the prover -- witness columns -> commitments -> z -> quotient -> evaluations -> opening, with the transcript -- written
  * against the entry points above, so that a Rust / C caller pays neither an interpreter nor 60 FFI crossings per proof.  Scope: circuits
- * without lookups and without recursion (prev_challenges); generic + the five library gates + the optional gates (RangeCheck0/1, Rot64, Xor16
- * as a plain gate, ForeignFieldAdd/Mul), public inputs, any num_chunks.  (proof_systems_amd/prover.py runs the same protocol from Python and
+ * without lookups; generic + the five library gates + the optional gates (RangeCheck0/1, Rot64, Xor16
+ * as a plain gate, ForeignFieldAdd/Mul), public inputs, any num_chunks, previous challenges (kh_prove_recursive).  (proof_systems_amd/prover.py runs the same protocol from Python and
  * covers lookups / runtime tables / recursion; tests/test_gpu_native_prover.py: both give the same proof, field element for field element.)
  *
  * kh_prover_index_new: the caller has built the index columns on the device (ProverIndex of prover_index.rs:30-70; column order below) on the
@@ -476,6 +476,12 @@ void kh_prover_index_free(kh_prover_index_t *index);
 size_t kh_prove_randomness_count(const kh_prover_index_t *index, int witness_on_host);
 int kh_prove(kh_prover_index_t *index, const uint64_t *witness, size_t rows, const uint64_t *witness_dev, const uint64_t *randomness,
              size_t n_random, unsigned flags, kh_proof_t **out);
+/* create_recursive with previous challenges (RecursionChallenge, proof.rs:117-131; prover.rs:276-279, 1212-1262): n_prev accumulators, the j-th with
+ * prev_rounds[j] challenges (prev_chals: all of them concatenated, Montgomery limbs) and a commitment of prev_comm_chunks[j] chunks (prev_comm_xy /
+ * prev_comm_inf: all chunks concatenated).  2^rounds must be the SRS size (one chunk) or twice it (two chunks). */
+int kh_prove_recursive(kh_prover_index_t *index, const uint64_t *witness, size_t rows, const uint64_t *witness_dev, const uint64_t *randomness,
+                       size_t n_random, unsigned flags, const uint64_t *prev_chals, const unsigned *prev_rounds, const uint64_t *prev_comm_xy,
+                       const uint8_t *prev_comm_inf, const size_t *prev_comm_chunks, size_t n_prev, kh_proof_t **out);
 int kh_proof_section(const kh_proof_t *proof, int section, const uint64_t **limbs, const uint8_t **flags, size_t *count);
 int kh_proof_phase_seconds(const kh_proof_t *proof, double *seconds, size_t cap);   /* witness_upload, witness_commit, z, quotient, evaluations, opening */
 void kh_proof_free(kh_proof_t *proof);

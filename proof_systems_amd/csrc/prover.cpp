@@ -1,6 +1,6 @@
 // prover.cpp -- ProverProof::create (kimchi/src/prover.rs:187-1515) as a native host loop over this library's own C ABI.
 //
-// The same protocol proof_systems_amd/prover.py runs from Python, for circuits without lookups and recursion, written against the public
+// The same protocol proof_systems_amd/prover.py runs from Python, for circuits without lookups (previous challenges included: kh_prove_recursive), written against the public
 // entry points only (kh_ntt_dev, kh_gate_evaluations_dev, kh_msm_submit, kh_ipa_open, kh_sponge_*, ...): a Rust or C caller gets a whole proof
 // with one call, no interpreter in the measured latency, and several prover threads do not share a GIL.  Every device step is the entry
 // point the Python prover calls at the same place, with the same arguments, so the two give the same proof for the same randomness
@@ -168,7 +168,14 @@ size_t kh_prove_randomness_count(const kh_prover_index_t* ix, int witness_on_hos
 
 int kh_prove(kh_prover_index_t* ix, const uint64_t* witness, size_t rows, const uint64_t* witness_dev, const uint64_t* randomness, size_t n_random,
              unsigned flags, kh_proof_t** out) {
+    return kh_prove_recursive(ix, witness, rows, witness_dev, randomness, n_random, flags, nullptr, nullptr, nullptr, nullptr, nullptr, 0, out);
+}
+
+int kh_prove_recursive(kh_prover_index_t* ix, const uint64_t* witness, size_t rows, const uint64_t* witness_dev, const uint64_t* randomness, size_t n_random,
+                       unsigned flags, const uint64_t* prev_chals, const unsigned* prev_rounds, const uint64_t* prev_comm_xy, const uint8_t* prev_comm_inf,
+                       const size_t* prev_comm_chunks, size_t n_prev, kh_proof_t** out) {
     if (!ix || !out || (!witness == !witness_dev)) { kh::set_error("kh_prove: give the witness either on the host or on the device"); return KH_E_INVALID; }
+    if (n_prev && (!prev_chals || !prev_rounds || !prev_comm_xy || !prev_comm_inf || !prev_comm_chunks)) { kh::set_error("kh_prove_recursive: null previous-challenge argument"); return KH_E_INVALID; }
     const bool check = flags & KH_PROVE_CHECK, all_gates = flags & KH_PROVE_ALL_GATES;
     const int fid = ix->fid, curve = ix->curve;
     const unsigned logn = ix->logn;
@@ -239,6 +246,10 @@ int kh_prove(kh_prover_index_t* ix, const uint64_t* witness, size_t rows, const 
     mark();
     SpongeH fq; KP(kh_sponge_new(KH_SPONGE_FQ, curve, &fq.s));
     KP(kh_sponge_absorb(fq.s, ix->digest.l, 1));
+    {                                                 // prover.rs:276-279: the previous proofs' accumulator commitments
+        size_t pos = 0;
+        for (size_t j = 0; j < n_prev; j++) { KP(kh_sponge_absorb_g(fq.s, prev_comm_xy + 8 * pos, prev_comm_inf + pos, prev_comm_chunks[j])); pos += prev_comm_chunks[j]; }
+    }
     Dev pub_c;
     std::vector<uint64_t> pub_xy; std::vector<uint8_t> pub_inf;
     if (ix->pub) {                                    // the negated public-input polynomial (prover.rs:281-309)
@@ -457,7 +468,11 @@ int kh_prove(kh_prover_index_t* ix, const uint64_t* witness, size_t rows, const 
     {
         SpongeH fr, pd; KP(kh_sponge_new(KH_SPONGE_FR, curve, &fr.s)); KP(kh_sponge_new(KH_SPONGE_FR, curve, &pd.s));
         fe d; KP(kh_sponge_digest(fq.s, d.l)); KP(kh_sponge_absorb(fr.s, d.l, 1));
-        KP(kh_sponge_digest(pd.s, d.l)); KP(kh_sponge_absorb(fr.s, d.l, 1));           // the digest of no previous challenges
+        {                                             // the digest of the previous challenges (prover.rs:1212-1219)
+            size_t pos = 0;
+            for (size_t j = 0; j < n_prev; j++) { KP(kh_sponge_absorb(pd.s, prev_chals + 4 * pos, prev_rounds[j])); pos += prev_rounds[j]; }
+        }
+        KP(kh_sponge_digest(pd.s, d.l)); KP(kh_sponge_absorb(fr.s, d.l, 1));
         std::vector<fe> flat; flat.reserve(1 + 2 * nch * (npoly + 1));
         flat.push_back(fte[1]);
         flat.insert(flat.end(), pub_eval.begin(), pub_eval.end());
@@ -475,10 +490,44 @@ int kh_prove(kh_prover_index_t* ix, const uint64_t* witness, size_t rows, const 
     uint64_t delta[8], sg[8], z1[4], z2[4]; uint8_t dinf = 0, sginf = 0;
     {
         std::vector<const uint64_t*> op; std::vector<size_t> ol, oc;
+        // the previous challenges' polynomials b_poly_coefficients(chals), non-hiding, opened first (prover.rs:1220-1262); their evaluations are
+        // closed-form (RecursionChallenge::evals, proof.rs:455-494): one chunk, or two when the polynomial is twice the SRS size
+        std::vector<Dev> prev_bufs(n_prev);
+        std::vector<fe> prev_e0, prev_e1;             // chunk evaluations at zeta / zeta omega, polynomial after polynomial
+        {
+            size_t cpos = 0;
+            for (size_t j = 0; j < n_prev; j++) {
+                const unsigned k = prev_rounds[j];
+                KP_REQUIRE(k <= 26, "previous challenge %zu has %u rounds", j, k);
+                const size_t ln = (size_t)1 << k;
+                const size_t want_chunks = ln <= size ? 1 : 2;
+                KP_REQUIRE((ln == size || ln == 2 * size) && prev_comm_chunks[j] == want_chunks, "previous challenge %zu: 2^%u coefficients / %zu commitment chunks do not fit an SRS of %zu", j, k, prev_comm_chunks[j], size);
+                std::vector<fe> bc(ln);
+                KP(kh_b_poly_coefficients(fid, prev_chals + 4 * cpos, k, 1, (uint64_t*)bc.data()));
+                KP(prev_bufs[j].alloc(ln)); KP(kh_dev_upload(prev_bufs[j].p, bc.data(), ln * 32));
+                op.push_back(prev_bufs[j].p); ol.push_back(ln); oc.push_back(want_chunks);
+                fe full[2];
+                for (int p = 0; p < 2; p++) {         // b_poly(chals, x) = prod_i (1 + chals[i] x^(2^(k-1-i))) (commitment.rs:426-436)
+                    std::vector<fe> pw(k ? k : 1); pw[0] = pts[p];
+                    for (unsigned i = 1; i < k; i++) pw[i] = F.sqr(pw[i - 1]);
+                    fe r = one;
+                    for (unsigned i = 0; i < k; i++) r = F.mul(r, F.add(one, F.mul(load(prev_chals + 4 * (cpos + i)), pw[k - 1 - i])));
+                    full[p] = r;
+                }
+                if (want_chunks == 1) { prev_e0.push_back(full[0]); prev_e1.push_back(full[1]); }
+                else {
+                    const fe d0 = horner(F, bc.data() + size, ln - size, zeta), d1 = horner(F, bc.data() + size, ln - size, zetaw);
+                    prev_e0.push_back(F.sub(full[0], F.mul(d0, zeta_srs))); prev_e0.push_back(d0);
+                    prev_e1.push_back(F.sub(full[1], F.mul(d1, zetaw_srs))); prev_e1.push_back(d1);
+                }
+                cpos += k;
+            }
+        }
         op.push_back(pub_c.p ? pub_c.p : ix->zero_poly); ol.push_back(pub_c.p ? n : 0); oc.push_back(nch);
         op.push_back(ft.p); ol.push_back(ft_len); oc.push_back(1);
         for (size_t j = 0; j < npoly; j++) { op.push_back(polys[j]); ol.push_back(n); oc.push_back(nch); }
         std::vector<fe> bl;                            // one blinder per chunk of every opened polynomial
+        bl.insert(bl.end(), prev_e0.size(), zero);
         bl.insert(bl.end(), nch, one); bl.push_back(blinding_ft);
         bl.insert(bl.end(), z_blind, z_blind + nch);
         bl.insert(bl.end(), 6 * nch, one);
@@ -496,6 +545,7 @@ int kh_prove(kh_prover_index_t* ix, const uint64_t* witness, size_t rows, const 
             cip = F.add(cip, F.mul(ps, F.add(c0, F.mul(u, c1))));
             ps = F.mul(ps, v);
         };
+        for (size_t c = 0; c < prev_e0.size(); c++) take(prev_e0[c], prev_e1[c]);
         for (size_t c = 0; c < nch; c++) take(pub_eval[c], pub_eval[nch + c]);
         take(fte[0], fte[1]);
         for (size_t j = 0; j < npoly; j++) for (size_t c = 0; c < nch; c++) take(E[(2 * j) * nch + c], E[(2 * j + 1) * nch + c]);

@@ -38,7 +38,7 @@ SYMBOLS = [
     "kh_msm_batch_dev", "kh_ntt_dev", "kh_lde_dev", "kh_coset_ntt_dev", "kh_sync", "kh_last_timings",
     "kh_debug_field_op", "kh_debug_point_op", "kh_srs_generate", "kh_srs_h",
     "kh_msm_sharded", "kh_msm_sharded_dev", "kh_gate_count", "kh_gate_name", "kh_gate_num_constants", "kh_gate_evaluations_dev", "kh_gate_constants", "kh_srs_curve",
-    "kh_prover_index_new", "kh_prover_index_free", "kh_prove_randomness_count", "kh_prove", "kh_proof_section", "kh_proof_phase_seconds", "kh_proof_free",
+    "kh_prover_index_new", "kh_prover_index_free", "kh_prove_randomness_count", "kh_prove", "kh_prove_recursive", "kh_proof_section", "kh_proof_phase_seconds", "kh_proof_free",
     "kh_commit_non_hiding", "kh_commit_evaluations_non_hiding", "kh_srs_set_blinding_base",
     "kh_srs_get_blinding_base", "kh_mask_custom", "kh_domain_generator", "kh_msm_points_batch", "kh_msm_submit", "kh_msm_wait",
     "kh_ipa_fold_scalars", "kh_inner_product", "kh_ipa_fold_points", "kh_ipa_fold_points_endo", "kh_endos", "kh_scalar_challenge_to_field",
@@ -620,15 +620,23 @@ class NativeProverIndex:
         _lib.kh_prove_randomness_count.restype = C.c_size_t
         return _lib.kh_prove_randomness_count(self._h, C.c_int(int(witness_on_host)))
 
-    def prove(self, witness=None, witness_dev=None, randomness=None, flags: int = PROVE_CHECK):
-        """kh_prove.  witness: (15, rows, 4) limbs on the host, or witness_dev: DevBuf with the padded columns.  randomness: (k, 4) limbs in
-        the reference's draw order, or None (the library draws from the OS).  Returns ({section: limbs[, flags]}, {phase: seconds})."""
+    def prove(self, witness=None, witness_dev=None, randomness=None, flags: int = PROVE_CHECK, prev=()):
+        """kh_prove / kh_prove_recursive.  witness: (15, rows, 4) limbs on the host, or witness_dev: DevBuf with the padded columns.  randomness:
+        (k, 4) limbs in the reference's draw order, or None (the library draws from the OS).  prev: [(chals (k, 4) limbs, (xy (chunks, 8), inf
+        (chunks,)))].  Returns ({section: limbs[, flags]}, {phase: seconds})."""
         pr = C.c_void_p()
         w = _c64(witness, (15, -1, 4)) if witness is not None else None
         rnd = _c64(randomness, (-1, 4)) if randomness is not None else None
-        _check(_lib.kh_prove(self._h, _p64(w) if w is not None else None, C.c_size_t(w.shape[1] if w is not None else 0),
-                             C.c_void_p(witness_dev.ptr) if witness_dev is not None else None, _p64(rnd) if rnd is not None else None,
-                             C.c_size_t(rnd.shape[0] if rnd is not None else 0), C.c_uint(flags), C.byref(pr)))
+        m = len(prev)
+        chals = _c64(np.concatenate([np.asarray(c, dtype=np.uint64).reshape(-1, 4) for c, _ in prev]), (-1, 4)) if m else None
+        rounds = (C.c_uint * max(m, 1))(*[np.asarray(c).reshape(-1, 4).shape[0] for c, _ in prev])
+        cxy = np.ascontiguousarray(np.concatenate([np.asarray(cm[0], dtype=np.uint64).reshape(-1, 8) for _, cm in prev])) if m else None
+        cinf = np.ascontiguousarray(np.concatenate([np.asarray(cm[1], dtype=np.uint8).reshape(-1) for _, cm in prev])) if m else None
+        cch = (C.c_size_t * max(m, 1))(*[np.asarray(cm[1]).reshape(-1).shape[0] for _, cm in prev])
+        _check(_lib.kh_prove_recursive(self._h, _p64(w) if w is not None else None, C.c_size_t(w.shape[1] if w is not None else 0),
+                                       C.c_void_p(witness_dev.ptr) if witness_dev is not None else None, _p64(rnd) if rnd is not None else None,
+                                       C.c_size_t(rnd.shape[0] if rnd is not None else 0), C.c_uint(flags), _p64(chals) if m else None, rounds,
+                                       _p64(cxy) if m else None, _p8(cinf) if m else None, cch, C.c_size_t(m), C.byref(pr)))
         try:
             out = {}
             for name, sid in PROOF_SECTIONS.items():

@@ -330,7 +330,7 @@ def _horner(p: int, coeffs, x: int) -> int:
 
 def native_index(ix: "ProverIndex"):
     """The C++ prover's handle on this index (kh_prover_index_new), made once; None when the circuit is outside kh_prove's scope (lookups)."""
-    if getattr(ix, "lookup", None) is not None or ix.prev_challenges:
+    if getattr(ix, "lookup", None) is not None:
         return None
     h = getattr(ix, "_native", None)
     if h is None or h[1] is not ix.d8:
@@ -342,18 +342,18 @@ def native_index(ix: "ProverIndex"):
     return h[0]
 
 
-def create_proof_native(ix: "ProverIndex", witness, rng, timings=None, check: bool = True, witness_on_device=None, all_gates: bool = False):
+def create_proof_native(ix: "ProverIndex", witness, rng, timings=None, check: bool = True, witness_on_device=None, all_gates: bool = False, prev_challenges=()):
     """create_proof through kh_prove: the host loop in C++ (csrc/prover.cpp), same protocol, same draws from `rng` in the same order, same result
     dict.  rng=None: the library draws from the operating system's generator."""
     F, nch = ix.F, ix.num_chunks
     nx = native_index(ix)
     if nx is None:
-        raise ValueError("kh_prove covers circuits without lookups and recursion; use create_proof")
+        raise ValueError("kh_prove covers circuits without lookups; use create_proof")
     on_host = witness_on_device is None
     rnd = F.limbs_many(F.rand_many(rng, nx.randomness_count(on_host))) if rng is not None else None
     flags = (khip.PROVE_CHECK if check else 0) | (khip.PROVE_ALL_GATES if all_gates else 0)
     sec, phases = nx.prove(witness=np.asarray(witness, dtype=np.uint64).reshape(COLUMNS, -1, 4) if on_host else None, witness_dev=witness_on_device,
-                           randomness=rnd, flags=flags)
+                           randomness=rnd, flags=flags, prev=[(F.limbs_many(list(ch)), cm) for ch, cm in prev_challenges])
     comms = lambda key, k: [(sec[key][0][i * nch:(i + 1) * nch], sec[key][1][i * nch:(i + 1) * nch]) for i in range(k)]
     ev = F.values(sec["evals"])
     E = [(ev[(2 * j) * nch:(2 * j + 1) * nch], ev[(2 * j + 1) * nch:(2 * j + 2) * nch]) for j in range(len(ev) // (2 * nch))]
@@ -371,7 +371,7 @@ def create_proof_native(ix: "ProverIndex", witness, rng, timings=None, check: bo
             timings[k_] = timings.get(k_, 0.0) + v_
         timings["total"] = timings.get("total", 0.0) + sum(phases.values())
     return {"w_comm": comms("w_comm", COLUMNS), "z_comm": comms("z_comm", 1)[0], "t_comm": (sec["t_comm"][0], sec["t_comm"][1]), "public_comm": comms("public_comm", 1)[0],
-            "evals": evals, "ft_eval1": F.values(sec["ft_eval1"])[0], "opening": opening, "prev_challenges": [],
+            "evals": evals, "ft_eval1": F.values(sec["ft_eval1"])[0], "opening": opening, "prev_challenges": [(list(c), m) for c, m in prev_challenges],
             "challenges": {"beta": ch[0], "gamma": ch[1], "alpha": ch[2], "zeta": ch[3], "v": ch[4], "u": ch[5], "joint_combiner": None}}
 
 

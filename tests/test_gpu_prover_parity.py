@@ -192,6 +192,9 @@ def test_recursive_proof_equals_the_oracle_provers_proof(khip, cid, logn, log_sr
     c, vix, pr = V.device_views(ix, dproof)
     assert compare(C, oproof, pr) is None, compare(C, oproof, pr)
     assert OPR.serialize_proof(C, pr) == OPR.serialize_proof(C, oproof)
+    # the same through kh_prove_recursive (host loop in C++)
+    nproof = prover.create_proof_native(ix, np.stack([_limbs(F, col) for col in wit]), V.RefRng(P.StdRng(seed)), prev_challenges=dprev)
+    assert OPR.serialize_proof(C, V.device_views(ix, nproof)[2]) == OPR.serialize_proof(C, oproof)
     ix.free()
 
 
