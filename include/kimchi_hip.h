@@ -427,6 +427,14 @@ int kh_debug_point_op(int curve, int op, const uint64_t *p_xy, const uint8_t *p_
                       const uint64_t *q_xy, const uint8_t *q_inf,
                       uint64_t *out_xy, uint8_t *out_inf, size_t n);
 
+/* ---- the lookup argument's `sorted` step (kimchi/src/circuits/lookup/constraints.rs:90-194), host code as in the reference ----
+ * table: the first lookup_rows = n - zk_rows - 1 entries of the combined table (4 limbs each, host memory); values: max_per_row columns of looked-up
+ * joint values, column s at values + 4 s value_stride, lookup_rows entries each (a row with fewer lookups than max_per_row holds the dummy value 0 in
+ * the remaining slots).  out: max_per_row + 1 columns of lookup_rows + 1 values: every table entry repeated (times looked up + 1), in table order,
+ * snake layout (consecutive columns share one element, odd columns reversed).  A value that is not in the table: KH_E_INVALID and *bad_row = its row. */
+int kh_lookup_sorted(const uint64_t *table, size_t lookup_rows, const uint64_t *values, size_t value_stride, size_t max_per_row, uint64_t *out,
+                     size_t *bad_row);
+
 /* ---- ProverProof::create as ONE native call (kimchi/src/prover.rs:187-1515, the part this library accelerates end to end) ----
  * The host loop of the prover -- witness columns -> commitments -> z -> quotient -> evaluations -> opening, with the transcript -- written
  * against the entry points above, so that a Rust / C caller pays neither an interpreter nor 60 FFI crossings per proof.  Scope: circuits

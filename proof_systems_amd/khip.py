@@ -37,7 +37,7 @@ SYMBOLS = [
     "kh_dev_alloc", "kh_dev_free", "kh_dev_upload", "kh_dev_download", "kh_dev_upload_2d",
     "kh_msm_batch_dev", "kh_ntt_dev", "kh_lde_dev", "kh_coset_ntt_dev", "kh_sync", "kh_last_timings",
     "kh_debug_field_op", "kh_debug_point_op", "kh_srs_generate", "kh_srs_h",
-    "kh_msm_sharded", "kh_msm_sharded_dev", "kh_gate_count", "kh_gate_name", "kh_gate_num_constants", "kh_gate_evaluations_dev", "kh_gate_constants", "kh_srs_curve",
+    "kh_msm_sharded", "kh_msm_sharded_dev", "kh_gate_count", "kh_gate_name", "kh_gate_num_constants", "kh_gate_evaluations_dev", "kh_gate_constants", "kh_srs_curve", "kh_lookup_sorted",
     "kh_prover_index_new", "kh_prover_index_free", "kh_prove_randomness_count", "kh_prove", "kh_prove_recursive", "kh_proof_section", "kh_proof_phase_seconds", "kh_proof_free",
     "kh_commit_non_hiding", "kh_commit_evaluations_non_hiding", "kh_srs_set_blinding_base",
     "kh_srs_get_blinding_base", "kh_mask_custom", "kh_domain_generator", "kh_msm_points_batch", "kh_msm_submit", "kh_msm_wait",
@@ -597,6 +597,19 @@ def gate_evaluations_dev(field: int, gate: int, cols, col_len: int, constants, r
     cs = _c64(constants, (-1, 4))
     _check(_lib.kh_gate_evaluations_dev(C.c_int(field), C.c_int(gate), ptrs, C.c_size_t(col_len), _p64(cs), C.c_size_t(cs.shape[0]), C.c_size_t(rows),
                                         C.c_uint(stride), C.c_uint(next_shift), C.c_int(int(accumulate)), C.c_void_p(out.ptr + 32 * out_offset)))
+
+
+def lookup_sorted(table, lookup_rows: int, values, max_per_row: int):
+    """kh_lookup_sorted: table (>= lookup_rows, 4) limbs, values (max_per_row, stride, 4) limbs -> (max_per_row + 1, lookup_rows + 1, 4).
+    Raises ValueError(row) for a value that is not in the table."""
+    t = _c64(table, (-1, 4)); v = _c64(values, (max_per_row, -1, 4))
+    out = np.zeros((max_per_row + 1, lookup_rows + 1, 4), dtype=np.uint64)
+    bad = C.c_size_t(0)
+    rc = _lib.kh_lookup_sorted(_p64(t), C.c_size_t(lookup_rows), _p64(v), C.c_size_t(v.shape[1]), C.c_size_t(max_per_row), _p64(out), C.byref(bad))
+    if rc != 0 and bad.value != C.c_size_t(-1).value:
+        raise ValueError(bad.value)
+    _check(rc)
+    return out
 
 
 PROVE_CHECK, PROVE_ALL_GATES = 1, 2

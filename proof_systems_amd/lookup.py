@@ -191,6 +191,44 @@ def sorted_columns(ix: LookupIndex, witness: Sequence[Sequence[int]], joint_tabl
     return cols
 
 
+def lookup_values_dev(ix: LookupIndex, d_witness, joint_combiner: int) -> "khip.DevBuf":
+    """The looked-up joint values on the device: max_per_row columns of n values, slot s of row r = sum_k jc^k w[entry_k][r] + tic * table_id for
+    the s-th lookup of the row's pattern (lookups.rs:417-487), 0 -- the dummy entry's value -- where the row looks up fewer than max_per_row."""
+    F, n = ix.F, ix.n
+    jc, tic = ix.combiners(joint_combiner)
+    out = khip.DevBuf(ix.max_per_row * n * 32)
+    bufs = list(d_witness) + [ix.d_selectors[q] for q in ix.patterns]
+    for s in range(ix.max_per_row):
+        consts, toks, first = [jc, tic], [], True
+        for k, q in enumerate(ix.patterns):
+            spec = OP.LOOKUP_PATTERNS[q]
+            if s >= len(spec):
+                continue
+            tid, entry = spec[s]
+            t = [OP.cell(entry[-1])]
+            for c in reversed(entry[:-1]):
+                t += [(OP.TOK_CONST, 0), (OP.TOK_MUL, 0), OP.cell(c), (OP.TOK_ADD, 0)]
+            if isinstance(tid, tuple):
+                t += [OP.cell(tid[1]), (OP.TOK_CONST, 1), (OP.TOK_MUL, 0), (OP.TOK_ADD, 0)]
+            elif tid:
+                consts.append(tic * tid % F.p)
+                t += [(OP.TOK_CONST, len(consts) - 1), (OP.TOK_ADD, 0)]
+            toks += t + [OP.cell(15 + k), (OP.TOK_MUL, 0)] + ([] if first else [(OP.TOK_ADD, 0)])
+            first = False
+        khip.expr_evaluations_dev(ix.fid, toks, bufs, [n] * len(bufs), F.limbs_many(consts), n, out, stride=1, next_shift=1, out_offset=s * n)
+    return out
+
+
+def sorted_columns_dev(ix: LookupIndex, d_witness, d_table, joint_combiner: int):
+    """`sorted` (constraints.rs:90-194) without Python integers: looked-up values by the device, the hash join natively on the host
+    (kh_lookup_sorted).  Returns (max_per_row + 1, n - zk_rows, 4) limbs; ValueError(row) for a value that is not in the table."""
+    n = ix.n
+    d_vals = lookup_values_dev(ix, d_witness, joint_combiner)
+    vals = d_vals.download((ix.max_per_row, n, 4))
+    d_vals.free()
+    return khip.lookup_sorted(d_table.download((n, 4)), n - ix.zk_rows - 1, vals, ix.max_per_row)
+
+
 def zk_patch(F: Fld, vals: Sequence[int], n: int, zk_rows: int, rng) -> List[int]:
     """constraints.rs:35-48."""
     return list(vals) + [0] * (n - zk_rows - len(vals)) + [F.rand(rng) for _ in range(zk_rows)]

@@ -36,6 +36,7 @@ MOD = {khip.FP: 0x40000000000000000000000000000000224698fc094cf91b992d30ed000000
        khip.FQ: 0x40000000000000000000000000000000224698fc0994a8dd8c46eb2100000001}
 R256 = 1 << 256
 import os as _os
+_PY_LOOKUP_SORT = bool(_os.environ.get("KH_PY_LOOKUP_SORT"))   # A/B: the lookup argument's sorted columns in Python instead of kh_lookup_sorted
 _TOKEN_GATES = bool(_os.environ.get("KH_TOKEN_GATES"))     # A/B: run the gate library through the token machine instead of the compiled kernels
 
 
@@ -468,20 +469,27 @@ def create_proof(ix: ProverIndex, witness, rng, timings=None, check: bool = True
             rt = {"d": d_rt, "c": d_rtc, "blind": rt_blind, "comm": rt_comm}
         jc = scalar_challenge(curve, F, fq.challenge() if LI.joint_lookup_used else 0)
         d_table = LI.joint_table_dev(jc, rt["d"] if rt else None)
-        table_ints = F.values(d_table.download((n, 4)))
-        wcols = ev.download((COLUMNS, n, 4))
-        used = sorted({c for q in LI.patterns for tid, entry in OP.LOOKUP_PATTERNS[q] for c in (list(entry) + ([tid[1]] if isinstance(tid, tuple) else []))})
-        wit_ints = [F.values(wcols[c]) if c in used else None for c in range(COLUMNS)]
-        srt = [LK.zk_patch(F, c, n, zk, rng) for c in LK.sorted_columns(LI, wit_ints, table_ints, jc)]    # ValueError(row): value not in the table
-        d_sorted = [khip.DevBuf(NB).upload(F.limbs_many(c)) for c in srt]
-        s_blind, s_comm = [], []
-        for b in d_sorted:                                  # commit_evaluations(d1, v, rng): non-hiding, then one blinder per chunk
-            bl_ = F.rand_many(rng, nch)
-            cm = ix.mask(ix.commit_evals(b.ptr, 1), bl_)[0]
-            s_blind.append(bl_); s_comm.append(cm)
+        if _PY_LOOKUP_SORT:                                 # A/B: the sorted columns by the Python restatement of constraints.rs:90-194
+            table_ints = F.values(d_table.download((n, 4)))
+            wcols = ev.download((COLUMNS, n, 4))
+            used = sorted({c for q in LI.patterns for tid, entry in OP.LOOKUP_PATTERNS[q] for c in (list(entry) + ([tid[1]] if isinstance(tid, tuple) else []))})
+            wit_ints = [F.values(wcols[c]) if c in used else None for c in range(COLUMNS)]
+            srt = [LK.zk_patch(F, c, n, zk, rng) for c in LK.sorted_columns(LI, wit_ints, table_ints, jc)]    # ValueError(row): value not in the table
+            full = np.stack([F.limbs_many(c) for c in srt])
+        else:                                               # looked-up values on the device, hash join natively on the host (kh_lookup_sorted)
+            sl = LK.sorted_columns_dev(LI, [ev.view(i * NB) for i in range(COLUMNS)], d_table, jc)
+            full = np.zeros((sl.shape[0], n, 4), dtype=np.uint64)
+            full[:, :n - zk] = sl
+            for k_ in range(sl.shape[0]):                   # zk_patch (constraints.rs:35-48): the last zk_rows of every column random, column by column
+                full[k_, n - zk:] = F.limbs_many(F.rand_many(rng, zk))
+        d_sorted_base = khip.DevBuf(full.shape[0] * NB).upload(full)
+        d_sorted = [d_sorted_base.view(k_ * NB) for k_ in range(full.shape[0])]
+        scom = ix.commit_evals(d_sorted_base.ptr, len(d_sorted))    # commit_evaluations(d1, v, rng): non-hiding (one batched MSM), then one blinder per chunk
+        s_blind = [F.rand_many(rng, nch) for _ in d_sorted]
+        s_comm = ix.mask(scom, [x for bl_ in s_blind for x in bl_])
         for c_, i_ in s_comm:
             fq.absorb_g(c_, i_)
-        lkp = {"jc": jc, "d_table": d_table, "d_sorted": d_sorted, "s_blind": s_blind, "s_comm": s_comm, "rt": rt}
+        lkp = {"jc": jc, "d_table": d_table, "d_sorted": d_sorted, "d_sorted_base": d_sorted_base, "s_blind": s_blind, "s_comm": s_comm, "rt": rt}
     mark("witness_commit")
     beta = F.value(fq.challenge_field()); gamma = F.value(fq.challenge_field())
     if lkp is not None:                                     # prover.rs:635-673: the lookup aggregation, committed before z
@@ -721,7 +729,7 @@ def create_proof(ix: ProverIndex, witness, rng, timings=None, check: bool = True
     lk_out = {}
     if lkp is not None:
         lk_out = {"lookup": {"sorted": lkp["s_comm"], "aggreg": lkp["a_comm"], "runtime": lkp["rt"]["comm"] if lkp["rt"] else None}}
-        for b in lkp["d_sorted"] + [lkp["d_agg"], lkp["d_table"], lkp["lkc"], lkp["lk8"]] + ([lkp["rt"]["d"], lkp["rt"]["c"], lkp["rt"]["d8"]] if lkp["rt"] else []):
+        for b in [lkp["d_sorted_base"], lkp["d_agg"], lkp["d_table"], lkp["lkc"], lkp["lk8"]] + ([lkp["rt"]["d"], lkp["rt"]["c"], lkp["rt"]["d8"]] if lkp["rt"] else []):
             b.free()
     if timings is not None:
         prev = t_start
