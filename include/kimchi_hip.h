@@ -427,6 +427,24 @@ int kh_debug_point_op(int curve, int op, const uint64_t *p_xy, const uint8_t *p_
                       const uint64_t *q_xy, const uint8_t *q_inf,
                       uint64_t *out_xy, uint8_t *out_inf, size_t n);
 
+/* ---- one process per GPU: the path's only collective, over RCCL / xGMI ----
+ * A point-range-sharded MSM (BASELINE config 4) exchanges ONE partial point per rank: RCCL has no elliptic-curve reduction, so the "all-reduce" is an
+ * all-gather of the partials and a local fold on every rank.  kh_comm_unique_id on one rank, its 128 bytes handed to the others by any means (file,
+ * socket, the launcher's store), then kh_comm_init on every rank (collective; binds the communicator to the calling thread's current device).
+ * librccl.so is loaded with dlopen at that point -- single-GPU users never need it (KH_E_NOTFOUND if it is absent).
+ * kh_comm_allgather_points: out = rank 0's k points, rank 1's k points, ... (host buffers).  kh_msm_allreduce: this rank's shard (its kh_srs_t over its
+ * point range, kh_srs_create_device_range) times its slice of the scalars, all-gathered and folded: every rank gets the whole MSM. */
+typedef struct kh_comm kh_comm_t;
+#define KH_COMM_ID_BYTES 128
+int kh_comm_unique_id(uint8_t id[128]);
+int kh_comm_init(int world_size, int rank, const uint8_t id[128], kh_comm_t **out);
+void kh_comm_free(kh_comm_t *comm);
+int kh_comm_world_size(const kh_comm_t *comm);
+int kh_comm_rank(const kh_comm_t *comm);
+int kh_comm_allgather_points(kh_comm_t *comm, const uint64_t *xy, const uint8_t *inf, size_t k, uint64_t *out_xy, uint8_t *out_inf);
+int kh_msm_allreduce(kh_comm_t *comm, kh_srs_t *shard, const uint64_t *scalars, size_t n, int scalars_are_montgomery, uint64_t out_xy[8],
+                     uint8_t *out_is_inf);
+
 /* ---- the lookup argument's `sorted` step (kimchi/src/circuits/lookup/constraints.rs:90-194), host code as in the reference ----
  * table: the first lookup_rows = n - zk_rows - 1 entries of the combined table (4 limbs each, host memory); values: max_per_row columns of looked-up
  * joint values, column s at values + 4 s value_stride, lookup_rows entries each (a row with fewer lookups than max_per_row holds the dummy value 0 in

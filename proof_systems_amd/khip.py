@@ -37,7 +37,8 @@ SYMBOLS = [
     "kh_dev_alloc", "kh_dev_free", "kh_dev_upload", "kh_dev_download", "kh_dev_upload_2d",
     "kh_msm_batch_dev", "kh_ntt_dev", "kh_lde_dev", "kh_coset_ntt_dev", "kh_sync", "kh_last_timings",
     "kh_debug_field_op", "kh_debug_point_op", "kh_srs_generate", "kh_srs_h",
-    "kh_msm_sharded", "kh_msm_sharded_dev", "kh_gate_count", "kh_gate_name", "kh_gate_num_constants", "kh_gate_evaluations_dev", "kh_gate_constants", "kh_srs_curve", "kh_lookup_sorted",
+    "kh_msm_sharded", "kh_msm_sharded_dev", "kh_gate_count", "kh_gate_name", "kh_gate_num_constants", "kh_gate_evaluations_dev", "kh_gate_constants", "kh_srs_curve", "kh_lookup_sorted", "kh_comm_unique_id", "kh_comm_init", "kh_comm_free", "kh_comm_world_size", "kh_comm_rank", "kh_comm_allgather_points",
+    "kh_msm_allreduce",
     "kh_prover_index_new", "kh_prover_index_free", "kh_prove_randomness_count", "kh_prove", "kh_prove_recursive", "kh_proof_section", "kh_proof_phase_seconds", "kh_proof_free",
     "kh_commit_non_hiding", "kh_commit_evaluations_non_hiding", "kh_srs_set_blinding_base",
     "kh_srs_get_blinding_base", "kh_mask_custom", "kh_domain_generator", "kh_msm_points_batch", "kh_msm_submit", "kh_msm_wait",
@@ -610,6 +611,40 @@ def lookup_sorted(table, lookup_rows: int, values, max_per_row: int):
         raise ValueError(bad.value)
     _check(rc)
     return out
+
+
+class Comm:
+    """kh_comm_*: the in-library RCCL communicator of the one-process-per-GPU deployment (no torch).  Comm.unique_id() on one rank, the bytes to
+    the others, Comm(world, rank, id) on every rank."""
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = (C.c_uint8 * 128)()
+        _check(_lib.kh_comm_unique_id(buf))
+        return bytes(buf)
+
+    def __init__(self, world: int, rank: int, uid: bytes):
+        self._h = C.c_void_p()
+        buf = (C.c_uint8 * 128)(*uid)
+        _check(_lib.kh_comm_init(C.c_int(world), C.c_int(rank), buf, C.byref(self._h)))
+        self.world, self.rank = world, rank
+
+    def allgather_points(self, xy, inf):
+        xy = _c64(xy, (-1, 8)); i8 = np.ascontiguousarray(inf, dtype=np.uint8).reshape(-1)
+        k = xy.shape[0]
+        out = np.zeros((self.world * k, 8), dtype=np.uint64); oinf = np.zeros(self.world * k, dtype=np.uint8)
+        _check(_lib.kh_comm_allgather_points(self._h, _p64(xy), _p8(i8), C.c_size_t(k), _p64(out), _p8(oinf)))
+        return out, oinf
+
+    def msm_allreduce(self, shard, scalars, mont: bool = True):
+        sc = _c64(scalars, (-1, 4))
+        out = np.zeros(8, dtype=np.uint64); inf = np.zeros(1, dtype=np.uint8)
+        _check(_lib.kh_msm_allreduce(self._h, shard._h, _p64(sc), C.c_size_t(sc.shape[0]), C.c_int(int(mont)), _p64(out), _p8(inf)))
+        return out, bool(inf[0])
+
+    def free(self):
+        if self._h:
+            _lib.kh_comm_free(self._h); self._h = C.c_void_p()
 
 
 PROVE_CHECK, PROVE_ALL_GATES = 1, 2
