@@ -455,9 +455,9 @@ int kh_lookup_sorted(const uint64_t *table, size_t lookup_rows, const uint64_t *
 
 /* ---- ProverProof::create as ONE native call (kimchi/src/prover.rs:187-1515, the part this library accelerates end to end) ----
  * The host loop of the prover -- witness columns -> commitments -> z -> quotient -> evaluations -> opening, with the transcript -- written
- * against the entry points above, so that a Rust / C caller pays neither an interpreter nor 60 FFI crossings per proof.  Scope: circuits
- * without lookups; generic + the five library gates + the optional gates (RangeCheck0/1, Rot64, Xor16
- * as a plain gate, ForeignFieldAdd/Mul), public inputs, any num_chunks, previous challenges (kh_prove_recursive).  (proof_systems_amd/prover.py runs the same protocol from Python and
+ * against the entry points above, so that a Rust / C caller pays neither an interpreter nor 60 FFI crossings per proof.  Scope: everything
+ * create_recursive takes except runtime tables: generic + the five library gates + the optional gates (RangeCheck0/1, Rot64, Xor16
+ * as a plain gate, ForeignFieldAdd/Mul), public inputs, any num_chunks, previous challenges (kh_prove_recursive), lookups into fixed tables (kh_prover_index_attach_lookup).  (proof_systems_amd/prover.py runs the same protocol from Python and
  * covers lookups / runtime tables / recursion; tests/test_gpu_native_prover.py: both give the same proof, field element for field element.)
  *
  * kh_prover_index_new: the caller has built the index columns on the device (ProverIndex of prover_index.rs:30-70; column order below) on the
@@ -494,10 +494,23 @@ typedef struct kh_proof kh_proof_t;
 #define KH_PROOF_DELTA 8
 #define KH_PROOF_Z1_Z2 9
 #define KH_PROOF_SG 10
-#define KH_PROOF_CHALLENGES 11    /* beta, gamma, alpha, zeta, v (polyscale), u (evalscale) */
+#define KH_PROOF_CHALLENGES 11    /* beta, gamma, alpha, zeta, v (polyscale), u (evalscale); with lookups a seventh: the joint combiner */
+#define KH_PROOF_LOOKUP_SORTED_COMM 12   /* (max lookups per row + 1) x num_chunks points; empty without lookups */
+#define KH_PROOF_LOOKUP_AGGREG_COMM 13   /* num_chunks points */
 int kh_prover_index_new(kh_srs_t *srs, unsigned log2_n, unsigned zk_rows, unsigned public_inputs, const uint64_t *d1_dev, const uint64_t *dc_dev,
                         const uint64_t *d8_dev, const int *optional_gates, size_t n_optional, unsigned live_mask, const uint64_t *shifts,
                         const uint64_t digest[4], kh_prover_index_t **out);
+/* Adds the lookup constraint system of the index (LookupConstraintSystem, lookup/index.rs:189-311; fixed tables, no runtime tables): patterns = the
+ * ids of the lookup patterns the circuit uses -- 0 Xor, 1 Lookup, 2 RangeCheck, 3 ForeignFieldMul --, increasing; per pattern its selector column as
+ * d1 evaluations, coefficient form and d8 evaluations; the concatenated table columns and (nullable) the table-id column as d1 evaluations; and the d8
+ * evaluations of the three row-set atoms the constraints use (expr.rs:883-893): VanishesOnZeroKnowledgeAndPreviousRows, UnnormalizedLagrangeBasis(0),
+ * UnnormalizedLagrangeBasis(-zk_rows - 1).  The digest given to kh_prover_index_new must cover the lookup index.  kh_prove then runs the lookup argument
+ * (joint combiner, combined table, sorted columns via kh_lookup_sorted, aggregation, the lookup constraints on d8, the extra evaluations and openings);
+ * KH_PROOF_EVALS carries, after the polynomials listed above: sorted x (max_per_row + 1), aggregation, combined table, one selector per pattern;
+ * the randomness grows by (max_per_row + 1) (zk_rows + num_chunks) after the witness blinders and zk_rows + num_chunks before z's two rows. */
+int kh_prover_index_attach_lookup(kh_prover_index_t *index, const int *patterns, size_t n_patterns, const uint64_t *const *selectors_d1,
+                                  const uint64_t *const *selectors_c, const uint64_t *const *selectors_d8, const uint64_t *const *table_cols_d1,
+                                  size_t n_table_cols, const uint64_t *table_ids_d1, const uint64_t *const *atoms_d8);
 void kh_prover_index_free(kh_prover_index_t *index);
 size_t kh_prove_randomness_count(const kh_prover_index_t *index, int witness_on_host);
 int kh_prove(kh_prover_index_t *index, const uint64_t *witness, size_t rows, const uint64_t *witness_dev, const uint64_t *randomness,

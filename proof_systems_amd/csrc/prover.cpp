@@ -67,7 +67,77 @@ int os_random(int fid, size_t k, fe* out) {          // uniform elements of the 
     }
     return KH_OK;
 }
+
+// ---- the lookup argument (kimchi/src/circuits/lookup/): protocol data and the expressions of its constraints as token programs ----
+// LookupPattern::lookups (lookups.rs:417-487): per pattern the joint lookups of a row -- table id (a constant, or a witness column) and the
+// witness columns of the entry.  Pattern ids: 0 Xor, 1 Lookup, 2 RangeCheck, 3 ForeignFieldMul (the reference's order).
+struct JointLookup { int tid_is_column, tid, ncell, cells[3]; };
+struct Pattern { int n; JointLookup l[4]; };
+const Pattern PATTERNS[4] = {
+    {4, {{0, 0, 3, {3, 7, 11}}, {0, 0, 3, {4, 8, 12}}, {0, 0, 3, {5, 9, 13}}, {0, 0, 3, {6, 10, 14}}}},
+    {3, {{1, 0, 2, {1, 2, 0}}, {1, 0, 2, {3, 4, 0}}, {1, 0, 2, {5, 6, 0}}, {0, 0, 0, {0, 0, 0}}}},
+    {4, {{0, 1, 1, {3, 0, 0}}, {0, 1, 1, {4, 0, 0}}, {0, 1, 1, {5, 0, 0}}, {0, 1, 1, {6, 0, 0}}}},
+    {4, {{0, 1, 1, {7, 0, 0}}, {0, 1, 1, {8, 0, 0}}, {0, 1, 1, {9, 0, 0}}, {0, 1, 1, {10, 0, 0}}}},
+};
+// a postfix token program under construction (KH_TOK_*), constants interned by value
+struct Prog {
+    std::vector<uint32_t> t;
+    std::vector<fe> consts;
+    void push(uint32_t op, uint32_t a) { t.push_back(op); t.push_back(a); }
+    void C(const fe& v) {
+        for (size_t i = 0; i < consts.size(); i++) if (khost::eq(consts[i], v)) { push(KH_TOK_CONST, (uint32_t)i); return; }
+        consts.push_back(v); push(KH_TOK_CONST, (uint32_t)(consts.size() - 1));
+    }
+    void cell(uint32_t col, int next = 0) { push(KH_TOK_CELL, 2 * col + (next ? 1u : 0u)); }
+    void add() { push(KH_TOK_ADD, 0); }
+    void sub() { push(KH_TOK_SUB, 0); }
+    void mul() { push(KH_TOK_MUL, 0); }
+    int run(int fid, const std::vector<const uint64_t*>& cols, const std::vector<size_t>& lens, size_t rows, unsigned stride, unsigned next_shift, int accumulate, uint64_t* out) const {
+        return kh_expr_evaluations_dev(fid, t.data(), t.size() / 2, cols.data(), lens.data(), cols.size(), (const uint64_t*)consts.data(), consts.size(), rows, stride,
+                                       next_shift, accumulate, out);
+    }
+};
+struct LookupChallenges { fe jc, tic, beta, gamma, gb1; fe prefactor[5]; };   // prefactor[k] = (gamma + dummy)^k (1 + beta)^max_per_row, dummy = 0
+// combine_table_entry (tables/mod.rs:147-162) of one joint lookup: Horner in the joint combiner from the last cell + table_id_combiner * id
+void emit_joint(Prog& p, const khost::Fld& F, const JointLookup& L, const LookupChallenges& ch) {
+    p.cell((uint32_t)L.cells[L.ncell - 1]);
+    for (int i = L.ncell - 2; i >= 0; i--) { p.C(ch.jc); p.mul(); p.cell((uint32_t)L.cells[i]); p.add(); }
+    if (L.tid_is_column) { p.cell((uint32_t)L.tid); p.C(ch.tic); p.mul(); p.add(); }
+    else if (L.tid) { fe id = {{(uint64_t)L.tid, 0, 0, 0}}; p.C(F.mul(ch.tic, F.to_mont(id))); p.add(); }
+}
+// (1 + beta)^max_per_row (gamma + dummy)^padding prod (gamma + joint value)   (constraints.rs:497-523)
+void emit_fterm(Prog& p, const khost::Fld& F, const Pattern* pat, size_t mpr, const LookupChallenges& ch) {
+    const int n = pat ? pat->n : 0;
+    p.C(ch.prefactor[mpr - (size_t)n]);
+    for (int i = 0; i < n; i++) { p.C(ch.gamma); emit_joint(p, F, pat->l[i], ch); p.add(); p.mul(); }
+}
+// numerator of an aggregation row: f_chunk * t_chunk, with the pattern selectors at columns sel0.., the combined table at column `table`
+void emit_numerator(Prog& p, const khost::Fld& F, const std::vector<int>& pats, size_t mpr, const LookupChallenges& ch, uint32_t sel0, uint32_t table) {
+    p.C(F.f.one);
+    for (size_t k = 0; k < pats.size(); k++) { p.cell(sel0 + (uint32_t)k); if (k) p.add(); }
+    p.sub();                                                            // 1 - sum of the selectors: a row without lookups
+    emit_fterm(p, F, nullptr, mpr, ch); p.mul();
+    for (size_t k = 0; k < pats.size(); k++) { p.cell(sel0 + (uint32_t)k); emit_fterm(p, F, &PATTERNS[pats[k]], mpr, ch); p.mul(); p.add(); }
+    p.C(ch.gb1); p.cell(table); p.add(); p.C(ch.beta); p.cell(table, 1); p.mul(); p.add();      // t_chunk = gamma (1 + beta) + t + beta t'
+    p.mul();
+}
+// denominator: prod_i (gamma (1 + beta) + s_i + beta s_i') with the roles of s_i, s_i' swapped for odd i (the snake)
+void emit_denominator(Prog& p, size_t mpr, const LookupChallenges& ch, uint32_t sorted0) {
+    for (size_t i = 0; i <= mpr; i++) {
+        const int odd = (int)(i & 1);
+        p.C(ch.gb1); p.cell(sorted0 + (uint32_t)i, odd); p.add(); p.C(ch.beta); p.cell(sorted0 + (uint32_t)i, !odd); p.mul(); p.add();
+        if (i) p.mul();
+    }
+}
 }  // namespace
+
+struct kh_lookup_index {
+    std::vector<int> pats;                           // pattern ids present, in the reference's order
+    std::vector<const uint64_t*> sel1, selc, sel8, tcols;
+    const uint64_t* tids = nullptr;
+    const uint64_t* atoms8[3] = {nullptr, nullptr, nullptr};
+    size_t mpr = 0, mjs = 0;
+};
 
 struct kh_prover_index {
     kh_srs_t* srs = nullptr;
@@ -80,6 +150,7 @@ struct kh_prover_index {
     fe shifts[7], digest, omega, endo;
     uint64_t* zero_poly = nullptr;                   // n zeros on the device: the public polynomial of a circuit without public inputs
     std::vector<uint64_t> zsel_xy; std::vector<uint8_t> zsel_inf;   // commitment to the zero polynomial masked with 1 (= h per chunk)
+    kh_lookup_index* lk = nullptr;                   // kh_prover_index_attach_lookup
     const uint64_t* col1(size_t k) const { return d1 + 4 * k * n; }
     const uint64_t* colc(size_t k) const { return dc + 4 * k * n; }
     const uint64_t* col8(size_t k) const { return d8 + 4 * k * 8 * n; }
@@ -87,7 +158,7 @@ struct kh_prover_index {
 
 struct kh_proof {
     struct Sec { std::vector<uint64_t> limbs; std::vector<uint8_t> flags; size_t count = 0; bool points = false; };
-    Sec sec[12];
+    Sec sec[14];
     double phase[6] = {0, 0, 0, 0, 0, 0};
     void set_points(int s, const uint64_t* xy, const uint8_t* inf, size_t cnt) {
         sec[s].limbs.assign(xy, xy + 8 * cnt); sec[s].flags.assign(inf, inf + cnt); sec[s].count = cnt; sec[s].points = true;
@@ -158,12 +229,40 @@ int kh_prover_index_new(kh_srs_t* srs, unsigned log2_n, unsigned zk_rows, unsign
 void kh_prover_index_free(kh_prover_index_t* ix) {
     if (!ix) return;
     if (ix->zero_poly) (void)kh_dev_free(ix->zero_poly);
+    delete ix->lk;
     delete ix;
 }
+int kh_prover_index_attach_lookup(kh_prover_index_t* ix, const int* patterns, size_t n_patterns, const uint64_t* const* selectors_d1,
+                                  const uint64_t* const* selectors_c, const uint64_t* const* selectors_d8, const uint64_t* const* table_cols_d1, size_t n_table_cols,
+                                  const uint64_t* table_ids_d1, const uint64_t* const* atoms_d8) {
+    if (!ix || !patterns || !n_patterns || n_patterns > 4 || !selectors_d1 || !selectors_c || !selectors_d8 || !table_cols_d1 || !n_table_cols || !atoms_d8) {
+        kh::set_error("kh_prover_index_attach_lookup: bad argument"); return KH_E_INVALID;
+    }
+    kh_lookup_index* lk = new (std::nothrow) kh_lookup_index();
+    if (!lk) { kh::set_error("out of memory"); return KH_E_NOMEM; }
+    for (size_t k = 0; k < n_patterns; k++) {
+        if (patterns[k] < 0 || patterns[k] > 3 || (k && patterns[k] <= patterns[k - 1]) || !selectors_d1[k] || !selectors_c[k] || !selectors_d8[k]) {
+            kh::set_error("lookup patterns must be distinct ids 0..3 in increasing order, with their selector columns"); delete lk; return KH_E_INVALID;
+        }
+        lk->pats.push_back(patterns[k]);
+        lk->sel1.push_back(selectors_d1[k]); lk->selc.push_back(selectors_c[k]); lk->sel8.push_back(selectors_d8[k]);
+        const Pattern& P = PATTERNS[patterns[k]];
+        if ((size_t)P.n > lk->mpr) lk->mpr = (size_t)P.n;
+        for (int i = 0; i < P.n; i++) if ((size_t)P.l[i].ncell > lk->mjs) lk->mjs = (size_t)P.l[i].ncell;
+    }
+    for (size_t k = 0; k < n_table_cols; k++) { if (!table_cols_d1[k]) { kh::set_error("null table column"); delete lk; return KH_E_INVALID; } lk->tcols.push_back(table_cols_d1[k]); }
+    lk->tids = table_ids_d1;
+    for (int a = 0; a < 3; a++) { if (!atoms_d8[a]) { kh::set_error("null atom column"); delete lk; return KH_E_INVALID; } lk->atoms8[a] = atoms_d8[a]; }
+    delete ix->lk;
+    ix->lk = lk;
+    return KH_OK;
+}
+
 size_t kh_prove_randomness_count(const kh_prover_index_t* ix, int witness_on_host) {
     if (!ix) return 0;
     size_t logs = 0; while (((size_t)1 << logs) < ix->size) logs++;
-    return (witness_on_host ? COLUMNS * ix->zk : 0) + COLUMNS * ix->nch + 2 + ix->nch + 7 * ix->nch + 2 * logs + 2;
+    const size_t lookups = ix->lk ? (ix->lk->mpr + 1) * (ix->zk + ix->nch) + ix->zk + ix->nch : 0;   // sorted columns: zk rows + blinders; aggregation: zk rows + blinders
+    return (witness_on_host ? COLUMNS * ix->zk : 0) + COLUMNS * ix->nch + lookups + 2 + ix->nch + 7 * ix->nch + 2 * logs + 2;
 }
 
 int kh_prove(kh_prover_index_t* ix, const uint64_t* witness, size_t rows, const uint64_t* witness_dev, const uint64_t* randomness, size_t n_random,
@@ -284,9 +383,113 @@ int kh_prove_recursive(kh_prover_index_t* ix, const uint64_t* witness, size_t ro
     KP(mask(wxy, winf, w_blind, wcx, wci));
     KP(kh_sponge_absorb_g(fq.s, wcx.data(), wci.data(), COLUMNS * nch));
     pr->set_points(KH_PROOF_W_COMM, wcx.data(), wci.data(), COLUMNS * nch);
+    // ---- lookup argument, part 1 (prover.rs:383-633): joint combiner, combined table, sorted columns
+    const kh_lookup_index* lk = ix->lk;
+    const size_t ns = lk ? lk->mpr + 1 : 0, npat = lk ? lk->pats.size() : 0, lookup_rows = n - zk - 1;
+    fe jc = zero, tic_t = zero, tic_c = zero;
+    Dev d_table, d_sorted;
+    const fe* s_blind = nullptr;
+    if (lk) {
+        uint64_t chal[2] = {0, 0};
+        if (lk->mjs > 1) KP(kh_sponge_challenge(fq.s, chal));       // joint_lookup_used (lookups.rs:90-110)
+        KP(kh_scalar_challenge_to_field(curve, chal, jc.l));
+        tic_c = fpow(F, jc, lk->mjs);                               // the constraints' table-id combiner (constraints.rs:424-440)
+        tic_t = lk->tids ? tic_c : zero;                            // ... the table's, when the index has a table-id column (prover.rs:500-572)
+        const size_t ntc = lk->tcols.size();
+        {                                                           // the combined table: Horner over the table columns + tic * ids
+            Prog p;
+            p.cell((uint32_t)(ntc - 1));
+            for (size_t k = ntc - 1; k-- > 0;) { p.C(jc); p.mul(); p.cell((uint32_t)k); p.add(); }
+            std::vector<const uint64_t*> cols(lk->tcols);
+            if (lk->tids) { p.C(tic_t); p.cell((uint32_t)ntc); p.mul(); p.add(); cols.push_back(lk->tids); }
+            std::vector<size_t> lens(cols.size(), n);
+            KP(d_table.alloc(NB));
+            KP(p.run(fid, cols, lens, n, 1, 1, 0, d_table.p));
+        }
+        std::vector<fe> vals(lk->mpr * n), table(n);
+        {                                                           // the looked-up joint values, one column per lookup slot (0 = the dummy entry's value)
+            Dev d_vals; KP(d_vals.alloc(lk->mpr * NB));
+            LookupChallenges ch{}; ch.jc = jc; ch.tic = tic_t;
+            std::vector<const uint64_t*> cols;
+            for (size_t i = 0; i < COLUMNS; i++) cols.push_back(ev.at(i * NB));
+            for (size_t k = 0; k < npat; k++) cols.push_back(lk->sel1[k]);
+            std::vector<size_t> lens(cols.size(), n);
+            for (size_t sl = 0; sl < lk->mpr; sl++) {
+                Prog p; bool first = true;
+                for (size_t k = 0; k < npat; k++) {
+                    const Pattern& P = PATTERNS[lk->pats[k]];
+                    if (sl >= (size_t)P.n) continue;
+                    emit_joint(p, F, P.l[sl], ch); p.cell((uint32_t)(COLUMNS + k)); p.mul();
+                    if (!first) p.add();
+                    first = false;
+                }
+                KP(p.run(fid, cols, lens, n, 1, 1, 0, d_vals.at(sl * NB)));
+            }
+            KP(kh_dev_download(vals.data(), d_vals.p, lk->mpr * NB * 32));
+            KP(kh_dev_download(table.data(), d_table.p, NB * 32));
+        }
+        std::vector<fe> srt(ns * (lookup_rows + 1)), full(ns * n, zero);
+        size_t bad = 0;
+        KP(kh_lookup_sorted((const uint64_t*)table.data(), lookup_rows, (const uint64_t*)vals.data(), n, lk->mpr, (uint64_t*)srt.data(), &bad));
+        for (size_t k = 0; k < ns; k++) {                           // zk_patch (constraints.rs:35-48): the last zk_rows random, column by column
+            memcpy(&full[k * n], &srt[k * (lookup_rows + 1)], (lookup_rows + 1) * 32);
+            memcpy(&full[k * n + (n - zk)], draw(zk), zk * 32);
+        }
+        KP(d_sorted.alloc(ns * NB)); KP(kh_dev_upload(d_sorted.p, full.data(), ns * NB * 32));
+        std::vector<uint64_t> sxy, scx; std::vector<uint8_t> sinf, sci;
+        KP(commit_evals(d_sorted.p, ns, sxy, sinf));
+        s_blind = draw(ns * nch);
+        KP(mask(sxy, sinf, s_blind, scx, sci));
+        KP(kh_sponge_absorb_g(fq.s, scx.data(), sci.data(), ns * nch));
+        pr->set_points(KH_PROOF_LOOKUP_SORTED_COMM, scx.data(), sci.data(), ns * nch);
+    }
     mark();
     fe beta, gamma;
     KP(kh_sponge_challenge_field(fq.s, beta.l)); KP(kh_sponge_challenge_field(fq.s, gamma.l));
+    // ---- lookup argument, part 2 (prover.rs:635-673; constraints.rs:233-338): the aggregation, committed before z
+    Dev d_agg;
+    const fe* a_blind = nullptr;
+    LookupChallenges lch{};
+    if (lk) {
+        const size_t mpr = lk->mpr;
+        lch.jc = jc; lch.tic = tic_t; lch.beta = beta; lch.gamma = gamma; lch.gb1 = F.mul(gamma, F.add(one, beta));
+        const fe b1m = fpow(F, F.add(one, beta), mpr);
+        fe gp = one;
+        for (size_t k = 0; k <= mpr; k++) { lch.prefactor[k] = F.mul(gp, b1m); gp = F.mul(gp, gamma); }     // the dummy entry's value is 0
+        // columns: witness 0..14 | sorted 15..15+mpr | combined table | pattern selectors
+        std::vector<const uint64_t*> cols;
+        for (size_t i = 0; i < COLUMNS; i++) cols.push_back(ev.at(i * NB));
+        for (size_t k = 0; k < ns; k++) cols.push_back(d_sorted.at(k * NB));
+        const uint32_t c_table = (uint32_t)cols.size(); cols.push_back(d_table.p);
+        const uint32_t c_sel0 = (uint32_t)cols.size();
+        for (size_t k = 0; k < npat; k++) cols.push_back(lk->sel1[k]);
+        std::vector<size_t> lens(cols.size(), n);
+        Prog pn, pd;
+        emit_numerator(pn, F, lk->pats, mpr, lch, c_sel0, c_table);
+        emit_denominator(pd, mpr, lch, (uint32_t)COLUMNS);
+        Dev num, den; KP(num.alloc(NB)); KP(den.alloc(NB)); KP(d_agg.alloc(NB));
+        KP(kh_dev_memset_zero(num.p, NB * 32)); KP(kh_dev_memset_zero(den.p, NB * 32));
+        KP(pn.run(fid, cols, lens, lookup_rows, 1, 1, 0, num.at(1)));
+        KP(pd.run(fid, cols, lens, lookup_rows, 1, 1, 0, den.at(1)));
+        KP(kh_batch_inversion_dev(fid, den.at(1), lookup_rows));
+        KP(kh_dev_upload(num.p, one.l, 32)); KP(kh_dev_upload(den.p, one.l, 32));
+        const uint32_t prod[6] = {KH_TOK_CELL, 0, KH_TOK_CELL, 2, KH_TOK_MUL, 0};
+        const uint64_t* pc[2] = {num.p, den.p}; const size_t pl[2] = {n, n};
+        KP(kh_expr_evaluations_dev(fid, prod, 3, pc, pl, 2, one.l, 1, n, 1, 1, 0, d_agg.p));
+        KP(kh_field_scan_dev(fid, KH_SCAN_MUL, 0, d_agg.p, lookup_rows + 1));
+        KP(kh_dev_upload(d_agg.at(n - zk), draw(zk), zk * 32));
+        if (check) {
+            fe last; KP(kh_dev_download(last.l, d_agg.at(lookup_rows), 32));
+            KP_REQUIRE(khost::eq(last, one), "final value of the lookup aggregation is not 1 (lookup/constraints.rs:325-331)");
+        }
+        a_blind = draw(nch);
+        std::vector<uint64_t> axy, acx; std::vector<uint8_t> ainf, aci;
+        KP(commit_evals(d_agg.p, 1, axy, ainf));
+        KP(mask(axy, ainf, a_blind, acx, aci));
+        KP(kh_sponge_absorb_g(fq.s, acx.data(), aci.data(), nch));
+        pr->set_points(KH_PROOF_LOOKUP_AGGREG_COMM, acx.data(), aci.data(), nch);
+        KP(kh_sync());                                              // num / den are released at the end of this block
+    }
     // ---- permutation aggregation z: numerators / denominators, batch inversion, running product (permutation.rs:510-568)
     fe bshift[7];
     for (int i = 0; i < 7; i++) bshift[i] = F.mul(beta, ix->shifts[i]);
@@ -369,6 +572,42 @@ int kh_prove_recursive(kh_prover_index_t* ix, const uint64_t* witness, size_t ro
             KP(kh_gate_evaluations_dev(fid, gid, cols, N8, consts.data(), (size_t)nc, N8, 1, 8, 1, t8.p));
         }
     }
+    Dev lkc, lk8;                                      // coefficient forms / d8 of [sorted ... | aggregation | combined table]
+    const size_t nl = lk ? ns + 2 : 0;
+    if (lk) {                                         // the lookup constraints on d8 (prover.rs:874-903), powers alpha^24 ...
+        const size_t mpr = lk->mpr;
+        KP(lkc.alloc(nl * NB)); KP(lk8.alloc(nl * N8));
+        KP(kh_dev_copy(lkc.p, d_sorted.p, ns * NB * 32));
+        KP(kh_dev_copy(lkc.at(ns * NB), d_agg.p, NB * 32));
+        KP(kh_dev_copy(lkc.at((ns + 1) * NB), d_table.p, NB * 32));
+        KP(kh_ntt_dev(fid, lkc.p, logn, 1, nl));
+        KP(kh_lde_dev(fid, lkc.p, logn, 3, lk8.p, nl));
+        LookupChallenges cch = lch; cch.tic = tic_c;
+        // columns: witness 0..14 | sorted | aggregation | table | pattern selectors | vanish, l0, lfinal (expr.rs:883-893)
+        std::vector<const uint64_t*> cols;
+        for (size_t i = 0; i < COLUMNS; i++) cols.push_back(e8.at(i * N8));
+        for (size_t k = 0; k < nl; k++) cols.push_back(lk8.at(k * N8));
+        const uint32_t c_sorted = (uint32_t)COLUMNS, c_agg = (uint32_t)(COLUMNS + ns), c_table = c_agg + 1, c_sel0 = c_table + 1;
+        for (size_t k = 0; k < npat; k++) cols.push_back(lk->sel8[k]);
+        const uint32_t c_vanish = (uint32_t)cols.size(), c_l0 = c_vanish + 1, c_lfinal = c_vanish + 2;
+        for (int a = 0; a < 3; a++) cols.push_back(lk->atoms8[a]);
+        std::vector<size_t> lens(cols.size(), N8);
+        fe ap = fpow(F, alpha, ALPHA_PERM0 + 3);
+        Prog p;
+        // alpha^24 vanish (aggreg' denominator - aggreg numerator)
+        p.C(ap); p.cell(c_vanish);
+        p.cell(c_agg, 1); emit_denominator(p, mpr, cch, c_sorted); p.mul();
+        p.cell(c_agg); emit_numerator(p, F, lk->pats, mpr, cch, c_sel0, c_table); p.mul();
+        p.sub(); p.mul(); p.mul();
+        // alpha^25 l0 (aggreg - 1), alpha^26 lfinal (aggreg - 1)
+        for (int i = 0; i < 2; i++) { ap = F.mul(ap, alpha); p.C(ap); p.cell(i ? c_lfinal : c_l0); p.cell(c_agg); p.C(one); p.sub(); p.mul(); p.mul(); p.add(); }
+        // the snake's shared elements: lfinal (s_i - s_i+1) for even i, l0 (...) for odd i
+        for (size_t i = 0; i < mpr; i++) {
+            ap = F.mul(ap, alpha);
+            p.C(ap); p.cell((i & 1) ? c_l0 : c_lfinal); p.cell(c_sorted + (uint32_t)i); p.cell(c_sorted + (uint32_t)i + 1); p.sub(); p.mul(); p.mul(); p.add();
+        }
+        KP(p.run(fid, cols, lens, N8, 1, 8, 1, t8.p));
+    }
     KP(kh_ntt_dev(fid, t4.p, logn + 2, 1, 1));
     KP(kh_ntt_dev(fid, t8.p, logn + 3, 1, 1));
     {                                                 // f = t4 + t8 + public (prover.rs:906-908)
@@ -424,6 +663,9 @@ int kh_prove_recursive(kh_prover_index_t* ix, const uint64_t* witness, size_t ro
     for (size_t i = 0; i < COLUMNS; i++) polys.push_back(ix->colc(i));
     for (size_t i = 0; i + 1 < PERMUTS; i++) polys.push_back(ix->colc(COLUMNS + 2 + i));
     for (size_t k = 0; k < nopt; k++) polys.push_back(ix->colc(OPT0 + k));
+    const size_t L0 = polys.size();                   // opening order of the lookup polynomials (prover.rs:1368-1420): sorted ..., aggregation, table, selectors
+    for (size_t k = 0; k < nl; k++) polys.push_back(lkc.at(k * NB));
+    for (size_t k = 0; k < npat; k++) polys.push_back(lk->selc[k]);
     const size_t npoly = polys.size();
     const fe pts[2] = {zeta, zetaw};
     std::vector<fe> E(npoly * 2 * nch);               // polynomial j: E[(2 j + p) nch + c]
@@ -476,7 +718,13 @@ int kh_prove_recursive(kh_prover_index_t* ix, const uint64_t* witness, size_t ro
         std::vector<fe> flat; flat.reserve(1 + 2 * nch * (npoly + 1));
         flat.push_back(fte[1]);
         flat.insert(flat.end(), pub_eval.begin(), pub_eval.end());
-        flat.insert(flat.end(), E.begin(), E.end());
+        flat.insert(flat.end(), E.begin(), E.begin() + 2 * nch * L0);
+        if (lk) {                                     // plonk_sponge.rs:92-155: aggregation, table, sorted ..., pattern selectors
+            auto both = [&](size_t j) { flat.insert(flat.end(), E.begin() + 2 * nch * j, E.begin() + 2 * nch * (j + 1)); };
+            both(L0 + ns); both(L0 + ns + 1);
+            for (size_t k = 0; k < ns; k++) both(L0 + k);
+            for (size_t k = 0; k < npat; k++) both(L0 + nl + k);
+        }
         KP(kh_sponge_absorb(fr.s, (const uint64_t*)flat.data(), flat.size()));
         KP(scalar_challenge(fr.s, v)); KP(scalar_challenge(fr.s, u));
     }
@@ -533,6 +781,14 @@ int kh_prove_recursive(kh_prover_index_t* ix, const uint64_t* witness, size_t ro
         bl.insert(bl.end(), 6 * nch, one);
         bl.insert(bl.end(), w_blind, w_blind + COLUMNS * nch);
         bl.insert(bl.end(), (COLUMNS + PERMUTS - 1 + nopt) * nch, zero);
+        if (lk) {                                     // sorted, aggregation, the combined table -- sum_i jc^i over its masked columns + the table-id combiner
+            bl.insert(bl.end(), s_blind, s_blind + ns * nch);                       // (prover.rs:1384-1400) --, the non-hiding pattern selectors
+            bl.insert(bl.end(), a_blind, a_blind + nch);
+            fe tb = tic_t, pw = one;
+            for (size_t i = 0; i < lk->tcols.size(); i++) { tb = F.add(tb, pw); pw = F.mul(pw, jc); }
+            bl.insert(bl.end(), nch, tb);
+            bl.insert(bl.end(), npat * nch, zero);
+        }
         Dev a_dev, b_dev; KP(a_dev.alloc(size)); KP(b_dev.alloc(size));
         size_t out_len = 0;
         KP(kh_combine_polys_dev(fid, op.data(), ol.data(), oc.data(), op.size(), v.l, size, a_dev.p, &out_len));
@@ -560,8 +816,8 @@ int kh_prove_recursive(kh_prover_index_t* ix, const uint64_t* witness, size_t ro
     pr->set_points(KH_PROOF_SG, sg, &sginf, 1);
     fe zz[2] = {load(z1), load(z2)};
     pr->set_elems(KH_PROOF_Z1_Z2, zz, 2);
-    fe ch[6] = {beta, gamma, alpha, zeta, v, u};
-    pr->set_elems(KH_PROOF_CHALLENGES, ch, 6);
+    fe ch[7] = {beta, gamma, alpha, zeta, v, u, jc};
+    pr->set_elems(KH_PROOF_CHALLENGES, ch, lk ? 7 : 6);
     KP(kh_sync());                                   // every queued user of the buffers released below has finished
     mark();
     guard.p = nullptr;
@@ -570,7 +826,7 @@ int kh_prove_recursive(kh_prover_index_t* ix, const uint64_t* witness, size_t ro
 }
 
 int kh_proof_section(const kh_proof_t* proof, int section, const uint64_t** limbs, const uint8_t** flags, size_t* count) {
-    if (!proof || section < 0 || section > KH_PROOF_CHALLENGES || !limbs || !count) { kh::set_error("kh_proof_section: bad argument"); return KH_E_INVALID; }
+    if (!proof || section < 0 || section > KH_PROOF_LOOKUP_AGGREG_COMM || !limbs || !count) { kh::set_error("kh_proof_section: bad argument"); return KH_E_INVALID; }
     const kh_proof::Sec& s = proof->sec[section];
     *limbs = s.limbs.data(); *count = s.count;
     if (flags) *flags = s.points ? s.flags.data() : nullptr;

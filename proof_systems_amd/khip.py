@@ -39,7 +39,7 @@ SYMBOLS = [
     "kh_debug_field_op", "kh_debug_point_op", "kh_srs_generate", "kh_srs_h",
     "kh_msm_sharded", "kh_msm_sharded_dev", "kh_gate_count", "kh_gate_name", "kh_gate_num_constants", "kh_gate_evaluations_dev", "kh_gate_constants", "kh_srs_curve", "kh_lookup_sorted", "kh_comm_unique_id", "kh_comm_init", "kh_comm_free", "kh_comm_world_size", "kh_comm_rank", "kh_comm_allgather_points",
     "kh_msm_allreduce",
-    "kh_prover_index_new", "kh_prover_index_free", "kh_prove_randomness_count", "kh_prove", "kh_prove_recursive", "kh_proof_section", "kh_proof_phase_seconds", "kh_proof_free",
+    "kh_prover_index_new", "kh_prover_index_attach_lookup", "kh_prover_index_free", "kh_prove_randomness_count", "kh_prove", "kh_prove_recursive", "kh_proof_section", "kh_proof_phase_seconds", "kh_proof_free",
     "kh_commit_non_hiding", "kh_commit_evaluations_non_hiding", "kh_srs_set_blinding_base",
     "kh_srs_get_blinding_base", "kh_mask_custom", "kh_domain_generator", "kh_msm_points_batch", "kh_msm_submit", "kh_msm_wait",
     "kh_ipa_fold_scalars", "kh_inner_product", "kh_ipa_fold_points", "kh_ipa_fold_points_endo", "kh_endos", "kh_scalar_challenge_to_field",
@@ -649,7 +649,8 @@ class Comm:
 
 PROVE_CHECK, PROVE_ALL_GATES = 1, 2
 PROOF_SECTIONS = {"w_comm": 0, "z_comm": 1, "t_comm": 2, "public_comm": 3, "evals": 4, "public_evals": 5, "ft_eval1": 6, "lr": 7, "delta": 8, "z1_z2": 9, "sg": 10,
-                  "challenges": 11}
+                  "challenges": 11, "lookup_sorted_comm": 12, "lookup_aggreg_comm": 13}
+LOOKUP_PATTERN_IDS = {"Xor": 0, "Lookup": 1, "RangeCheck": 2, "ForeignFieldMul": 3}
 PROOF_PHASES = ("witness_upload", "witness_commit", "z", "quotient", "evaluations", "opening")
 
 
@@ -663,6 +664,15 @@ class NativeProverIndex:
         _check(_lib.kh_prover_index_new(srs._h, C.c_uint(log2_n), C.c_uint(zk_rows), C.c_uint(public), C.c_void_p(d1.ptr), C.c_void_p(dc.ptr), C.c_void_p(d8.ptr),
                                         opt, C.c_size_t(len(optional_gate_ids)), C.c_uint(live_mask), _p64(sh), _p64(dg), C.byref(self._h)))
         self._keep = (srs, d1, dc, d8)
+
+    def attach_lookup(self, patterns, sel_d1, sel_c, sel_d8, table_cols, table_ids, atoms8):
+        """kh_prover_index_attach_lookup: patterns = names in the reference's order; per pattern three DevBufs; table columns / ids / atoms: DevBufs."""
+        m = len(patterns)
+        arr = lambda bufs: (C.c_void_p * max(len(bufs), 1))(*[C.c_void_p(b.ptr) for b in bufs])
+        ids = (C.c_int * m)(*[LOOKUP_PATTERN_IDS[q] for q in patterns])
+        _check(_lib.kh_prover_index_attach_lookup(self._h, ids, C.c_size_t(m), arr(sel_d1), arr(sel_c), arr(sel_d8), arr(table_cols), C.c_size_t(len(table_cols)),
+                                                  C.c_void_p(table_ids.ptr) if table_ids is not None else None, arr(atoms8)))
+        self._keep += (sel_d1, sel_c, sel_d8, table_cols, table_ids, atoms8)
 
     def randomness_count(self, witness_on_host: bool) -> int:
         _lib.kh_prove_randomness_count.restype = C.c_size_t

@@ -330,8 +330,9 @@ def _horner(p: int, coeffs, x: int) -> int:
 
 
 def native_index(ix: "ProverIndex"):
-    """The C++ prover's handle on this index (kh_prover_index_new), made once; None when the circuit is outside kh_prove's scope (lookups)."""
-    if getattr(ix, "lookup", None) is not None:
+    """The C++ prover's handle on this index (kh_prover_index_new), made once; None when the circuit is outside kh_prove's scope (runtime tables)."""
+    LI = getattr(ix, "lookup", None)
+    if LI is not None and LI.runtime_selector is not None:
         return None
     h = getattr(ix, "_native", None)
     if h is None or h[1] is not ix.d8:
@@ -339,6 +340,9 @@ def native_index(ix: "ProverIndex"):
         live = sum(1 << k for k, name in enumerate(ix.GATE_TYPES) if name in ix.live_gate_types)
         h = (khip.NativeProverIndex(ix.srs, ix.log2_n, ix.zk_rows, ix.public, ix.d1, ix.dc, ix.d8, [gids[t] for t in ix.optional], live,
                                     ix.F.limbs_many(ix.shifts), ix.digest), ix.d8)
+        if LI is not None:
+            h[0].attach_lookup(LI.patterns, [LI.d_selectors[q] for q in LI.patterns], [LI.sel_c[q] for q in LI.patterns], [LI.sel8[q] for q in LI.patterns],
+                               LI.d_table_cols, LI.d_table_ids, LI.atoms8)
         ix._native = h
     return h[0]
 
@@ -349,7 +353,7 @@ def create_proof_native(ix: "ProverIndex", witness, rng, timings=None, check: bo
     F, nch = ix.F, ix.num_chunks
     nx = native_index(ix)
     if nx is None:
-        raise ValueError("kh_prove covers circuits without lookups; use create_proof")
+        raise ValueError("kh_prove does not take runtime tables; use create_proof")
     on_host = witness_on_device is None
     rnd = F.limbs_many(F.rand_many(rng, nx.randomness_count(on_host))) if rng is not None else None
     flags = (khip.PROVE_CHECK if check else 0) | (khip.PROVE_ALL_GATES if all_gates else 0)
@@ -367,13 +371,21 @@ def create_proof_native(ix: "ProverIndex", witness, rng, timings=None, check: bo
     opening = {"lr": [(lr_xy[2 * r:2 * r + 2], lr_inf[2 * r:2 * r + 2]) for r in range(lr_xy.shape[0] // 2)], "delta": (sec["delta"][0][0], bool(sec["delta"][1][0])),
                "z1": z12[0], "z2": z12[1], "sg": (sec["sg"][0][0], bool(sec["sg"][1][0]))}
     ch = F.values(sec["challenges"])
+    lk_out = {}
+    LI = getattr(ix, "lookup", None)
+    if LI is not None:                                       # after the 43 + optional polynomials: sorted ..., aggregation, combined table, pattern selectors
+        L0 = 43 + len(ix.optional); ns = LI.max_per_row + 1
+        evals["lookup_sorted"] = E[L0:L0 + ns]; evals["lookup_aggregation"] = E[L0 + ns]; evals["lookup_table"] = E[L0 + ns + 1]
+        evals["lookup_selectors"] = {q: E[L0 + ns + 2 + k_] for k_, q in enumerate(LI.patterns)}
+        lk_out = {"lookup": {"sorted": comms("lookup_sorted_comm", ns), "aggreg": comms("lookup_aggreg_comm", 1)[0], "runtime": None}}
     if timings is not None:
         for k_, v_ in phases.items():
             timings[k_] = timings.get(k_, 0.0) + v_
         timings["total"] = timings.get("total", 0.0) + sum(phases.values())
     return {"w_comm": comms("w_comm", COLUMNS), "z_comm": comms("z_comm", 1)[0], "t_comm": (sec["t_comm"][0], sec["t_comm"][1]), "public_comm": comms("public_comm", 1)[0],
             "evals": evals, "ft_eval1": F.values(sec["ft_eval1"])[0], "opening": opening, "prev_challenges": [(list(c), m) for c, m in prev_challenges],
-            "challenges": {"beta": ch[0], "gamma": ch[1], "alpha": ch[2], "zeta": ch[3], "v": ch[4], "u": ch[5], "joint_combiner": None}}
+            "challenges": {"beta": ch[0], "gamma": ch[1], "alpha": ch[2], "zeta": ch[3], "v": ch[4], "u": ch[5], "joint_combiner": ch[6] if len(ch) > 6 else None},
+            **lk_out}
 
 
 def create_proof(ix: ProverIndex, witness, rng, timings=None, check: bool = True, witness_on_device=None, prev_challenges=(), all_gates: bool = False,

@@ -144,6 +144,8 @@ def test_proof_with_lookups_is_accepted_by_the_reference_pinned_verifier(khip, c
     ok, (c, vix, pr) = _verify(khip, ix, proof)
     assert ok
     assert len(pr["lookup"]["sorted"]) == 4 and vix["lookup_index"]["table_ids"] is not None
+    nproof = prover.create_proof_native(ix, w, np.random.default_rng(8))           # kh_prove: Lookup gates into user tables with ids, both curves
+    assert nproof["challenges"] == proof["challenges"] and V.device_views(ix, nproof)[2] == pr
     bad = dict(proof); be = dict(proof["evals"]); be["lookup_aggregation"] = _bump(be["lookup_aggregation"], 1, F.p); bad["evals"] = be
     assert not _verify(khip, ix, bad)[0]
     bad = dict(proof); be = dict(proof["evals"]); srt = list(be["lookup_sorted"]); srt[1] = _bump(srt[1], 0, F.p); be["lookup_sorted"] = srt; bad["evals"] = be
@@ -151,6 +153,8 @@ def test_proof_with_lookups_is_accepted_by_the_reference_pinned_verifier(khip, c
     wit[2][ngen + 5] = (wit[2][ngen + 5] + 1) % F.p                     # a looked-up value that is not in its table
     with pytest.raises(ValueError):
         prover.create_proof(ix, np.stack([F.limbs_many(c) for c in wit]), np.random.default_rng(8))
+    with pytest.raises(khip.KhError, match="not in the table"):
+        prover.create_proof_native(ix, np.stack([F.limbs_many(c) for c in wit]), np.random.default_rng(8))
 
 
 def test_proof_over_the_gate_library_is_accepted(khip):

@@ -88,6 +88,10 @@ def test_device_prover_reproduces_the_reference_whole_proof_bytes(khip):
     proof = prover.create_proof(ix, wit, V.RefRng(std))
     c, vix, pr = V.device_views(ix, proof)
     got = OPR.serialize_proof(C, pr)
+    # ... and through kh_prove (host loop in C++, lookups included), from a fresh copy of the same random stream
+    std2 = P.StdRng(seed); CC.gen_field_with_bits(std2, 64); CC.gen_field_with_bits(std2, 64)
+    nproof = prover.create_proof_native(ix, wit, V.RefRng(std2))
+    assert OPR.serialize_proof(C, V.device_views(ix, nproof)[2]) == want, "kh_prove differs from the reference's bytes"
     if got != want:
         import msgpack
         first = next(i for i, (a, b) in enumerate(zip(got, want)) if a != b)
@@ -240,6 +244,8 @@ def test_optional_gate_circuit_proof_equals_the_oracle_provers_proof(khip):
     c, vix, pr = V.device_views(ix, dproof)
     assert compare(C, oproof, pr) is None, compare(C, oproof, pr)
     assert OPR.serialize_proof(C, pr) == OPR.serialize_proof(C, oproof)
+    nproof = prover.create_proof_native(ix, np.stack([_limbs(F, col) for col in wit]), V.RefRng(P.StdRng(seed)))      # kh_prove: optional gates + RangeCheck lookups
+    assert OPR.serialize_proof(C, V.device_views(ix, nproof)[2]) == OPR.serialize_proof(C, oproof)
     ix.free()
 
 
