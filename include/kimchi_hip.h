@@ -456,8 +456,8 @@ int kh_lookup_sorted(const uint64_t *table, size_t lookup_rows, const uint64_t *
 /* ---- ProverProof::create as ONE native call (kimchi/src/prover.rs:187-1515, the part this library accelerates end to end) ----
  * The host loop of the prover -- witness columns -> commitments -> z -> quotient -> evaluations -> opening, with the transcript -- written
  * against the entry points above, so that a Rust / C caller pays neither an interpreter nor 60 FFI crossings per proof.  Scope: everything
- * create_recursive takes except runtime tables: generic + the five library gates + the optional gates (RangeCheck0/1, Rot64, Xor16
- * as a plain gate, ForeignFieldAdd/Mul), public inputs, any num_chunks, previous challenges (kh_prove_recursive), lookups into fixed tables (kh_prover_index_attach_lookup).  (proof_systems_amd/prover.py runs the same protocol from Python and
+ * create_recursive takes: generic + the five library gates + the optional gates (RangeCheck0/1, Rot64, Xor16
+ * as a plain gate, ForeignFieldAdd/Mul), public inputs, any num_chunks, previous challenges (kh_prove_recursive), lookups into fixed and runtime tables (kh_prover_index_attach_lookup, kh_prover_index_attach_runtime_tables, kh_prove_full).  (proof_systems_amd/prover.py runs the same protocol from Python and
  * covers lookups / runtime tables / recursion; tests/test_gpu_native_prover.py: both give the same proof, field element for field element.)
  *
  * kh_prover_index_new: the caller has built the index columns on the device (ProverIndex of prover_index.rs:30-70; column order below) on the
@@ -497,6 +497,7 @@ typedef struct kh_proof kh_proof_t;
 #define KH_PROOF_CHALLENGES 11    /* beta, gamma, alpha, zeta, v (polyscale), u (evalscale); with lookups a seventh: the joint combiner */
 #define KH_PROOF_LOOKUP_SORTED_COMM 12   /* (max lookups per row + 1) x num_chunks points; empty without lookups */
 #define KH_PROOF_LOOKUP_AGGREG_COMM 13   /* num_chunks points */
+#define KH_PROOF_LOOKUP_RUNTIME_COMM 14  /* num_chunks points; empty without runtime tables */
 int kh_prover_index_new(kh_srs_t *srs, unsigned log2_n, unsigned zk_rows, unsigned public_inputs, const uint64_t *d1_dev, const uint64_t *dc_dev,
                         const uint64_t *d8_dev, const int *optional_gates, size_t n_optional, unsigned live_mask, const uint64_t *shifts,
                         const uint64_t digest[4], kh_prover_index_t **out);
@@ -511,6 +512,13 @@ int kh_prover_index_new(kh_srs_t *srs, unsigned log2_n, unsigned zk_rows, unsign
 int kh_prover_index_attach_lookup(kh_prover_index_t *index, const int *patterns, size_t n_patterns, const uint64_t *const *selectors_d1,
                                   const uint64_t *const *selectors_c, const uint64_t *const *selectors_d8, const uint64_t *const *table_cols_d1,
                                   size_t n_table_cols, const uint64_t *table_ids_d1, const uint64_t *const *atoms_d8);
+/* Runtime tables (lookup/runtime_tables.rs, index.rs:241-311): `length` rows of the combined table, starting at row `offset`, whose second column arrives
+ * with each proof (kh_prove_full: runtime_values, all runtime tables' data concatenated in the index's order); selector = the runtime-table selector column
+ * (1 outside the runtime rows, 0 on them and on the zero-knowledge rows) as d1 evaluations, coefficient form, d8 evaluations.  After
+ * kh_prover_index_attach_lookup.  KH_PROOF_EVALS then carries runtime table + runtime selector between the combined table and the pattern selectors; the
+ * randomness grows by zk_rows + num_chunks right after the witness blinders. */
+int kh_prover_index_attach_runtime_tables(kh_prover_index_t *index, const uint64_t *selector_d1, const uint64_t *selector_c, const uint64_t *selector_d8,
+                                          size_t offset, size_t length);
 void kh_prover_index_free(kh_prover_index_t *index);
 size_t kh_prove_randomness_count(const kh_prover_index_t *index, int witness_on_host);
 int kh_prove(kh_prover_index_t *index, const uint64_t *witness, size_t rows, const uint64_t *witness_dev, const uint64_t *randomness,
@@ -521,6 +529,10 @@ int kh_prove(kh_prover_index_t *index, const uint64_t *witness, size_t rows, con
 int kh_prove_recursive(kh_prover_index_t *index, const uint64_t *witness, size_t rows, const uint64_t *witness_dev, const uint64_t *randomness,
                        size_t n_random, unsigned flags, const uint64_t *prev_chals, const unsigned *prev_rounds, const uint64_t *prev_comm_xy,
                        const uint8_t *prev_comm_inf, const size_t *prev_comm_chunks, size_t n_prev, kh_proof_t **out);
+/* everything create_recursive takes: previous challenges and (n_runtime = the index's runtime rows, else 0) the runtime tables' second column */
+int kh_prove_full(kh_prover_index_t *index, const uint64_t *witness, size_t rows, const uint64_t *witness_dev, const uint64_t *randomness, size_t n_random,
+                  unsigned flags, const uint64_t *prev_chals, const unsigned *prev_rounds, const uint64_t *prev_comm_xy, const uint8_t *prev_comm_inf,
+                  const size_t *prev_comm_chunks, size_t n_prev, const uint64_t *runtime_values, size_t n_runtime, kh_proof_t **out);
 int kh_proof_section(const kh_proof_t *proof, int section, const uint64_t **limbs, const uint8_t **flags, size_t *count);
 int kh_proof_phase_seconds(const kh_proof_t *proof, double *seconds, size_t cap);   /* witness_upload, witness_commit, z, quotient, evaluations, opening */
 void kh_proof_free(kh_proof_t *proof);

@@ -1,6 +1,6 @@
 // prover.cpp -- ProverProof::create (kimchi/src/prover.rs:187-1515) as a native host loop over this library's own C ABI.
 //
-// The same protocol proof_systems_amd/prover.py runs from Python, for circuits without lookups (previous challenges included: kh_prove_recursive), written against the public
+// The same protocol proof_systems_amd/prover.py runs from Python, for everything create_recursive takes (previous challenges, lookups, runtime tables), written against the public
 // entry points only (kh_ntt_dev, kh_gate_evaluations_dev, kh_msm_submit, kh_ipa_open, kh_sponge_*, ...): a Rust or C caller gets a whole proof
 // with one call, no interpreter in the measured latency, and several prover threads do not share a GIL.  Every device step is the entry
 // point the Python prover calls at the same place, with the same arguments, so the two give the same proof for the same randomness
@@ -137,6 +137,9 @@ struct kh_lookup_index {
     const uint64_t* tids = nullptr;
     const uint64_t* atoms8[3] = {nullptr, nullptr, nullptr};
     size_t mpr = 0, mjs = 0;
+    // runtime tables (lookup/runtime_tables.rs): the rows of the combined table whose second column arrives with each proof
+    const uint64_t *rtsel1 = nullptr, *rtselc = nullptr, *rtsel8 = nullptr;
+    size_t rt_offset = 0, rt_len = 0;
 };
 
 struct kh_prover_index {
@@ -158,7 +161,7 @@ struct kh_prover_index {
 
 struct kh_proof {
     struct Sec { std::vector<uint64_t> limbs; std::vector<uint8_t> flags; size_t count = 0; bool points = false; };
-    Sec sec[14];
+    Sec sec[15];
     double phase[6] = {0, 0, 0, 0, 0, 0};
     void set_points(int s, const uint64_t* xy, const uint8_t* inf, size_t cnt) {
         sec[s].limbs.assign(xy, xy + 8 * cnt); sec[s].flags.assign(inf, inf + cnt); sec[s].count = cnt; sec[s].points = true;
@@ -257,22 +260,43 @@ int kh_prover_index_attach_lookup(kh_prover_index_t* ix, const int* patterns, si
     ix->lk = lk;
     return KH_OK;
 }
+int kh_prover_index_attach_runtime_tables(kh_prover_index_t* ix, const uint64_t* selector_d1, const uint64_t* selector_c, const uint64_t* selector_d8, size_t offset,
+                                          size_t length) {
+    if (!ix || !ix->lk || !selector_d1 || !selector_c || !selector_d8 || !length || offset + length + ix->zk >= ix->n || ix->lk->tcols.size() < 2) {
+        kh::set_error("kh_prover_index_attach_runtime_tables: attach the lookup index first; %zu runtime rows at %zu must fit the table (two columns at least)", length, offset);
+        return KH_E_INVALID;
+    }
+    ix->lk->rtsel1 = selector_d1; ix->lk->rtselc = selector_c; ix->lk->rtsel8 = selector_d8;
+    ix->lk->rt_offset = offset; ix->lk->rt_len = length;
+    return KH_OK;
+}
 
 size_t kh_prove_randomness_count(const kh_prover_index_t* ix, int witness_on_host) {
     if (!ix) return 0;
     size_t logs = 0; while (((size_t)1 << logs) < ix->size) logs++;
-    const size_t lookups = ix->lk ? (ix->lk->mpr + 1) * (ix->zk + ix->nch) + ix->zk + ix->nch : 0;   // sorted columns: zk rows + blinders; aggregation: zk rows + blinders
+    size_t lookups = ix->lk ? (ix->lk->mpr + 1) * (ix->zk + ix->nch) + ix->zk + ix->nch : 0;   // sorted columns: zk rows + blinders; aggregation: zk rows + blinders
+    if (ix->lk && ix->lk->rtsel1) lookups += ix->zk + ix->nch;                               // the runtime table column: zk rows + blinders
     return (witness_on_host ? COLUMNS * ix->zk : 0) + COLUMNS * ix->nch + lookups + 2 + ix->nch + 7 * ix->nch + 2 * logs + 2;
 }
 
 int kh_prove(kh_prover_index_t* ix, const uint64_t* witness, size_t rows, const uint64_t* witness_dev, const uint64_t* randomness, size_t n_random,
              unsigned flags, kh_proof_t** out) {
-    return kh_prove_recursive(ix, witness, rows, witness_dev, randomness, n_random, flags, nullptr, nullptr, nullptr, nullptr, nullptr, 0, out);
+    return kh_prove_full(ix, witness, rows, witness_dev, randomness, n_random, flags, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0, out);
 }
-
 int kh_prove_recursive(kh_prover_index_t* ix, const uint64_t* witness, size_t rows, const uint64_t* witness_dev, const uint64_t* randomness, size_t n_random,
                        unsigned flags, const uint64_t* prev_chals, const unsigned* prev_rounds, const uint64_t* prev_comm_xy, const uint8_t* prev_comm_inf,
                        const size_t* prev_comm_chunks, size_t n_prev, kh_proof_t** out) {
+    return kh_prove_full(ix, witness, rows, witness_dev, randomness, n_random, flags, prev_chals, prev_rounds, prev_comm_xy, prev_comm_inf, prev_comm_chunks, n_prev,
+                         nullptr, 0, out);
+}
+
+int kh_prove_full(kh_prover_index_t* ix, const uint64_t* witness, size_t rows, const uint64_t* witness_dev, const uint64_t* randomness, size_t n_random,
+                  unsigned flags, const uint64_t* prev_chals, const unsigned* prev_rounds, const uint64_t* prev_comm_xy, const uint8_t* prev_comm_inf,
+                  const size_t* prev_comm_chunks, size_t n_prev, const uint64_t* runtime_values, size_t n_runtime, kh_proof_t** out) {
+    if (ix && ((ix->lk && ix->lk->rtsel1) ? (!runtime_values || n_runtime != ix->lk->rt_len) : n_runtime != 0)) {
+        kh::set_error("RuntimeTablesInconsistent: the index has %zu runtime table rows, the proof brings %zu", (ix->lk && ix->lk->rtsel1) ? ix->lk->rt_len : (size_t)0, n_runtime);
+        return KH_E_INVALID;
+    }
     if (!ix || !out || (!witness == !witness_dev)) { kh::set_error("kh_prove: give the witness either on the host or on the device"); return KH_E_INVALID; }
     if (n_prev && (!prev_chals || !prev_rounds || !prev_comm_xy || !prev_comm_inf || !prev_comm_chunks)) { kh::set_error("kh_prove_recursive: null previous-challenge argument"); return KH_E_INVALID; }
     const bool check = flags & KH_PROVE_CHECK, all_gates = flags & KH_PROVE_ALL_GATES;
@@ -389,6 +413,26 @@ int kh_prove_recursive(kh_prover_index_t* ix, const uint64_t* witness, size_t ro
     fe jc = zero, tic_t = zero, tic_c = zero;
     Dev d_table, d_sorted;
     const fe* s_blind = nullptr;
+    Dev d_rt, d_rtc, rt8;                             // the proof's runtime contribution to the table's second column: d1, coefficients, d8
+    const fe* rt_blind = nullptr;
+    const bool has_rt = lk && lk->rtsel1;
+    if (has_rt) {                                     // prover.rs:397-470: placed at the runtime rows, zero-knowledge rows drawn from the last row backwards, committed hiding
+        std::vector<fe> rte(n, zero);
+        memcpy(&rte[lk->rt_offset], runtime_values, n_runtime * 32);
+        const fe* z = draw(zk);
+        for (size_t j = 0; j < zk; j++) rte[n - zk + j] = z[zk - 1 - j];
+        KP(d_rt.alloc(NB)); KP(d_rtc.alloc(NB));
+        KP(kh_dev_upload(d_rt.p, rte.data(), NB * 32));
+        KP(kh_dev_copy(d_rtc.p, d_rt.p, NB * 32));
+        KP(kh_ntt_dev(fid, d_rtc.p, logn, 1, 1));
+        std::vector<uint64_t> rxy, rcx; std::vector<uint8_t> rinf, rci;
+        KP(commit_coeffs(d_rtc.p, n, nch, rxy, rinf));
+        KP_REQUIRE(rinf.size() == nch, "unexpected chunk count of the runtime table");
+        rt_blind = draw(nch);
+        KP(mask(rxy, rinf, rt_blind, rcx, rci));
+        KP(kh_sponge_absorb_g(fq.s, rcx.data(), rci.data(), nch));
+        pr->set_points(KH_PROOF_LOOKUP_RUNTIME_COMM, rcx.data(), rci.data(), nch);
+    }
     if (lk) {
         uint64_t chal[2] = {0, 0};
         if (lk->mjs > 1) KP(kh_sponge_challenge(fq.s, chal));       // joint_lookup_used (lookups.rs:90-110)
@@ -398,10 +442,13 @@ int kh_prove_recursive(kh_prover_index_t* ix, const uint64_t* witness, size_t ro
         const size_t ntc = lk->tcols.size();
         {                                                           // the combined table: Horner over the table columns + tic * ids
             Prog p;
-            p.cell((uint32_t)(ntc - 1));
-            for (size_t k = ntc - 1; k-- > 0;) { p.C(jc); p.mul(); p.cell((uint32_t)k); p.add(); }
+            const uint32_t c_rt = (uint32_t)(ntc + (lk->tids ? 1 : 0));               // the runtime column goes to the table's second column (prover.rs:455-464)
+            auto col = [&](size_t k) { p.cell((uint32_t)k); if (k == 1 && has_rt) { p.cell(c_rt); p.add(); } };
+            col(ntc - 1);
+            for (size_t k = ntc - 1; k-- > 0;) { p.C(jc); p.mul(); col(k); p.add(); }
             std::vector<const uint64_t*> cols(lk->tcols);
             if (lk->tids) { p.C(tic_t); p.cell((uint32_t)ntc); p.mul(); p.add(); cols.push_back(lk->tids); }
+            if (has_rt) cols.push_back(d_rt.p);
             std::vector<size_t> lens(cols.size(), n);
             KP(d_table.alloc(NB));
             KP(p.run(fid, cols, lens, n, 1, 1, 0, d_table.p));
@@ -606,6 +653,12 @@ int kh_prove_recursive(kh_prover_index_t* ix, const uint64_t* witness, size_t ro
             ap = F.mul(ap, alpha);
             p.C(ap); p.cell((i & 1) ? c_l0 : c_lfinal); p.cell(c_sorted + (uint32_t)i); p.cell(c_sorted + (uint32_t)i + 1); p.sub(); p.mul(); p.mul(); p.add();
         }
+        if (has_rt) {                                 // the constraints are padded to 3 + 4, then RT(x) selector_RT(x) (constraints.rs:658-680, runtime_tables.rs:59-66)
+            KP(rt8.alloc(N8)); KP(kh_lde_dev(fid, d_rtc.p, logn, 3, rt8.p, 1));
+            const uint32_t c_rt8 = (uint32_t)cols.size(); cols.push_back(rt8.p); cols.push_back(lk->rtsel8);
+            lens.assign(cols.size(), N8);
+            p.C(fpow(F, alpha, ALPHA_PERM0 + 3 + 7)); p.cell(c_rt8); p.cell(c_rt8 + 1); p.mul(); p.mul(); p.add();
+        }
         KP(p.run(fid, cols, lens, N8, 1, 8, 1, t8.p));
     }
     KP(kh_ntt_dev(fid, t4.p, logn + 2, 1, 1));
@@ -665,6 +718,8 @@ int kh_prove_recursive(kh_prover_index_t* ix, const uint64_t* witness, size_t ro
     for (size_t k = 0; k < nopt; k++) polys.push_back(ix->colc(OPT0 + k));
     const size_t L0 = polys.size();                   // opening order of the lookup polynomials (prover.rs:1368-1420): sorted ..., aggregation, table, selectors
     for (size_t k = 0; k < nl; k++) polys.push_back(lkc.at(k * NB));
+    const size_t nrt = has_rt ? 2 : 0;                // ... combined table, runtime table, runtime selector, pattern selectors
+    if (has_rt) { polys.push_back(d_rtc.p); polys.push_back(lk->rtselc); }
     for (size_t k = 0; k < npat; k++) polys.push_back(lk->selc[k]);
     const size_t npoly = polys.size();
     const fe pts[2] = {zeta, zetaw};
@@ -723,7 +778,7 @@ int kh_prove_recursive(kh_prover_index_t* ix, const uint64_t* witness, size_t ro
             auto both = [&](size_t j) { flat.insert(flat.end(), E.begin() + 2 * nch * j, E.begin() + 2 * nch * (j + 1)); };
             both(L0 + ns); both(L0 + ns + 1);
             for (size_t k = 0; k < ns; k++) both(L0 + k);
-            for (size_t k = 0; k < npat; k++) both(L0 + nl + k);
+            for (size_t k = 0; k < nrt + npat; k++) both(L0 + nl + k);
         }
         KP(kh_sponge_absorb(fr.s, (const uint64_t*)flat.data(), flat.size()));
         KP(scalar_challenge(fr.s, v)); KP(scalar_challenge(fr.s, u));
@@ -786,7 +841,11 @@ int kh_prove_recursive(kh_prover_index_t* ix, const uint64_t* witness, size_t ro
             bl.insert(bl.end(), a_blind, a_blind + nch);
             fe tb = tic_t, pw = one;
             for (size_t i = 0; i < lk->tcols.size(); i++) { tb = F.add(tb, pw); pw = F.mul(pw, jc); }
-            bl.insert(bl.end(), nch, tb);
+            if (has_rt) {                              // the runtime column's blinders enter the combined table's through the joint combiner (prover.rs:1402-1415)
+                for (size_t c = 0; c < nch; c++) bl.push_back(F.add(F.mul(jc, rt_blind[c]), tb));
+                bl.insert(bl.end(), rt_blind, rt_blind + nch);
+                bl.insert(bl.end(), nch, zero);
+            } else bl.insert(bl.end(), nch, tb);
             bl.insert(bl.end(), npat * nch, zero);
         }
         Dev a_dev, b_dev; KP(a_dev.alloc(size)); KP(b_dev.alloc(size));
@@ -826,7 +885,7 @@ int kh_prove_recursive(kh_prover_index_t* ix, const uint64_t* witness, size_t ro
 }
 
 int kh_proof_section(const kh_proof_t* proof, int section, const uint64_t** limbs, const uint8_t** flags, size_t* count) {
-    if (!proof || section < 0 || section > KH_PROOF_LOOKUP_AGGREG_COMM || !limbs || !count) { kh::set_error("kh_proof_section: bad argument"); return KH_E_INVALID; }
+    if (!proof || section < 0 || section > KH_PROOF_LOOKUP_RUNTIME_COMM || !limbs || !count) { kh::set_error("kh_proof_section: bad argument"); return KH_E_INVALID; }
     const kh_proof::Sec& s = proof->sec[section];
     *limbs = s.limbs.data(); *count = s.count;
     if (flags) *flags = s.points ? s.flags.data() : nullptr;

@@ -39,7 +39,7 @@ SYMBOLS = [
     "kh_debug_field_op", "kh_debug_point_op", "kh_srs_generate", "kh_srs_h",
     "kh_msm_sharded", "kh_msm_sharded_dev", "kh_gate_count", "kh_gate_name", "kh_gate_num_constants", "kh_gate_evaluations_dev", "kh_gate_constants", "kh_srs_curve", "kh_lookup_sorted", "kh_comm_unique_id", "kh_comm_init", "kh_comm_free", "kh_comm_world_size", "kh_comm_rank", "kh_comm_allgather_points",
     "kh_msm_allreduce",
-    "kh_prover_index_new", "kh_prover_index_attach_lookup", "kh_prover_index_free", "kh_prove_randomness_count", "kh_prove", "kh_prove_recursive", "kh_proof_section", "kh_proof_phase_seconds", "kh_proof_free",
+    "kh_prover_index_new", "kh_prover_index_attach_lookup", "kh_prover_index_free", "kh_prove_randomness_count", "kh_prove", "kh_prove_recursive", "kh_prove_full", "kh_prover_index_attach_runtime_tables", "kh_proof_section", "kh_proof_phase_seconds", "kh_proof_free",
     "kh_commit_non_hiding", "kh_commit_evaluations_non_hiding", "kh_srs_set_blinding_base",
     "kh_srs_get_blinding_base", "kh_mask_custom", "kh_domain_generator", "kh_msm_points_batch", "kh_msm_submit", "kh_msm_wait",
     "kh_ipa_fold_scalars", "kh_inner_product", "kh_ipa_fold_points", "kh_ipa_fold_points_endo", "kh_endos", "kh_scalar_challenge_to_field",
@@ -649,7 +649,7 @@ class Comm:
 
 PROVE_CHECK, PROVE_ALL_GATES = 1, 2
 PROOF_SECTIONS = {"w_comm": 0, "z_comm": 1, "t_comm": 2, "public_comm": 3, "evals": 4, "public_evals": 5, "ft_eval1": 6, "lr": 7, "delta": 8, "z1_z2": 9, "sg": 10,
-                  "challenges": 11, "lookup_sorted_comm": 12, "lookup_aggreg_comm": 13}
+                  "challenges": 11, "lookup_sorted_comm": 12, "lookup_aggreg_comm": 13, "lookup_runtime_comm": 14}
 LOOKUP_PATTERN_IDS = {"Xor": 0, "Lookup": 1, "RangeCheck": 2, "ForeignFieldMul": 3}
 PROOF_PHASES = ("witness_upload", "witness_commit", "z", "quotient", "evaluations", "opening")
 
@@ -674,12 +674,16 @@ class NativeProverIndex:
                                                   C.c_void_p(table_ids.ptr) if table_ids is not None else None, arr(atoms8)))
         self._keep += (sel_d1, sel_c, sel_d8, table_cols, table_ids, atoms8)
 
+    def attach_runtime_tables(self, sel_d1, sel_c, sel_d8, offset: int, length: int):
+        _check(_lib.kh_prover_index_attach_runtime_tables(self._h, C.c_void_p(sel_d1.ptr), C.c_void_p(sel_c.ptr), C.c_void_p(sel_d8.ptr), C.c_size_t(offset), C.c_size_t(length)))
+        self._keep += (sel_d1, sel_c, sel_d8)
+
     def randomness_count(self, witness_on_host: bool) -> int:
         _lib.kh_prove_randomness_count.restype = C.c_size_t
         return _lib.kh_prove_randomness_count(self._h, C.c_int(int(witness_on_host)))
 
-    def prove(self, witness=None, witness_dev=None, randomness=None, flags: int = PROVE_CHECK, prev=()):
-        """kh_prove / kh_prove_recursive.  witness: (15, rows, 4) limbs on the host, or witness_dev: DevBuf with the padded columns.  randomness:
+    def prove(self, witness=None, witness_dev=None, randomness=None, flags: int = PROVE_CHECK, prev=(), runtime=None):
+        """kh_prove_full (runtime: (k, 4) limbs, the runtime tables' second column).  witness: (15, rows, 4) limbs on the host, or witness_dev: DevBuf with the padded columns.  randomness:
         (k, 4) limbs in the reference's draw order, or None (the library draws from the OS).  prev: [(chals (k, 4) limbs, (xy (chunks, 8), inf
         (chunks,)))].  Returns ({section: limbs[, flags]}, {phase: seconds})."""
         pr = C.c_void_p()
@@ -691,10 +695,12 @@ class NativeProverIndex:
         cxy = np.ascontiguousarray(np.concatenate([np.asarray(cm[0], dtype=np.uint64).reshape(-1, 8) for _, cm in prev])) if m else None
         cinf = np.ascontiguousarray(np.concatenate([np.asarray(cm[1], dtype=np.uint8).reshape(-1) for _, cm in prev])) if m else None
         cch = (C.c_size_t * max(m, 1))(*[np.asarray(cm[1]).reshape(-1).shape[0] for _, cm in prev])
-        _check(_lib.kh_prove_recursive(self._h, _p64(w) if w is not None else None, C.c_size_t(w.shape[1] if w is not None else 0),
+        rtv = _c64(runtime, (-1, 4)) if runtime is not None else None
+        _check(_lib.kh_prove_full(self._h, _p64(w) if w is not None else None, C.c_size_t(w.shape[1] if w is not None else 0),
                                        C.c_void_p(witness_dev.ptr) if witness_dev is not None else None, _p64(rnd) if rnd is not None else None,
                                        C.c_size_t(rnd.shape[0] if rnd is not None else 0), C.c_uint(flags), _p64(chals) if m else None, rounds,
-                                       _p64(cxy) if m else None, _p8(cinf) if m else None, cch, C.c_size_t(m), C.byref(pr)))
+                                       _p64(cxy) if m else None, _p8(cinf) if m else None, cch, C.c_size_t(m), _p64(rtv) if rtv is not None else None,
+                                       C.c_size_t(rtv.shape[0] if rtv is not None else 0), C.byref(pr)))
         try:
             out = {}
             for name, sid in PROOF_SECTIONS.items():

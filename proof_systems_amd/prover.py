@@ -330,10 +330,8 @@ def _horner(p: int, coeffs, x: int) -> int:
 
 
 def native_index(ix: "ProverIndex"):
-    """The C++ prover's handle on this index (kh_prover_index_new), made once; None when the circuit is outside kh_prove's scope (runtime tables)."""
+    """The C++ prover's handle on this index (kh_prover_index_new + the lookup / runtime-table attachments), made once."""
     LI = getattr(ix, "lookup", None)
-    if LI is not None and LI.runtime_selector is not None:
-        return None
     h = getattr(ix, "_native", None)
     if h is None or h[1] is not ix.d8:
         gids = khip.gate_ids()
@@ -343,22 +341,29 @@ def native_index(ix: "ProverIndex"):
         if LI is not None:
             h[0].attach_lookup(LI.patterns, [LI.d_selectors[q] for q in LI.patterns], [LI.sel_c[q] for q in LI.patterns], [LI.sel8[q] for q in LI.patterns],
                                LI.d_table_cols, LI.d_table_ids, LI.atoms8)
+            if LI.runtime_selector is not None:
+                h[0].attach_runtime_tables(LI.d_runtime_selector, LI.rtsel_c, LI.rtsel8, LI.runtime_offset, sum(l_ for _i, l_ in LI.runtime_tables))
         ix._native = h
     return h[0]
 
 
-def create_proof_native(ix: "ProverIndex", witness, rng, timings=None, check: bool = True, witness_on_device=None, all_gates: bool = False, prev_challenges=()):
+def create_proof_native(ix: "ProverIndex", witness, rng, timings=None, check: bool = True, witness_on_device=None, all_gates: bool = False, prev_challenges=(),
+                        runtime_tables=()):
     """create_proof through kh_prove: the host loop in C++ (csrc/prover.cpp), same protocol, same draws from `rng` in the same order, same result
     dict.  rng=None: the library draws from the operating system's generator."""
     F, nch = ix.F, ix.num_chunks
     nx = native_index(ix)
-    if nx is None:
-        raise ValueError("kh_prove does not take runtime tables; use create_proof")
+    LI = getattr(ix, "lookup", None)
+    rtv = None
+    if LI is not None and LI.runtime_selector is not None:
+        if [(i_, len(d_)) for i_, d_ in runtime_tables] != LI.runtime_tables:
+            raise ValueError("RuntimeTablesInconsistent")
+        rtv = F.limbs_many([x for _i, d_ in runtime_tables for x in d_])
     on_host = witness_on_device is None
     rnd = F.limbs_many(F.rand_many(rng, nx.randomness_count(on_host))) if rng is not None else None
     flags = (khip.PROVE_CHECK if check else 0) | (khip.PROVE_ALL_GATES if all_gates else 0)
     sec, phases = nx.prove(witness=np.asarray(witness, dtype=np.uint64).reshape(COLUMNS, -1, 4) if on_host else None, witness_dev=witness_on_device,
-                           randomness=rnd, flags=flags, prev=[(F.limbs_many(list(ch)), cm) for ch, cm in prev_challenges])
+                           randomness=rnd, flags=flags, prev=[(F.limbs_many(list(ch)), cm) for ch, cm in prev_challenges], runtime=rtv)
     comms = lambda key, k: [(sec[key][0][i * nch:(i + 1) * nch], sec[key][1][i * nch:(i + 1) * nch]) for i in range(k)]
     ev = F.values(sec["evals"])
     E = [(ev[(2 * j) * nch:(2 * j + 1) * nch], ev[(2 * j + 1) * nch:(2 * j + 2) * nch]) for j in range(len(ev) // (2 * nch))]
@@ -372,12 +377,15 @@ def create_proof_native(ix: "ProverIndex", witness, rng, timings=None, check: bo
                "z1": z12[0], "z2": z12[1], "sg": (sec["sg"][0][0], bool(sec["sg"][1][0]))}
     ch = F.values(sec["challenges"])
     lk_out = {}
-    LI = getattr(ix, "lookup", None)
-    if LI is not None:                                       # after the 43 + optional polynomials: sorted ..., aggregation, combined table, pattern selectors
+    if LI is not None:                                       # after the 43 + optional polynomials: sorted ..., aggregation, combined table, (runtime table, its selector,) pattern selectors
         L0 = 43 + len(ix.optional); ns = LI.max_per_row + 1
+        nr = 2 if rtv is not None else 0
         evals["lookup_sorted"] = E[L0:L0 + ns]; evals["lookup_aggregation"] = E[L0 + ns]; evals["lookup_table"] = E[L0 + ns + 1]
-        evals["lookup_selectors"] = {q: E[L0 + ns + 2 + k_] for k_, q in enumerate(LI.patterns)}
-        lk_out = {"lookup": {"sorted": comms("lookup_sorted_comm", ns), "aggreg": comms("lookup_aggreg_comm", 1)[0], "runtime": None}}
+        if nr:
+            evals["runtime_lookup_table"], evals["runtime_lookup_table_selector"] = E[L0 + ns + 2], E[L0 + ns + 3]
+        evals["lookup_selectors"] = {q: E[L0 + ns + 2 + nr + k_] for k_, q in enumerate(LI.patterns)}
+        lk_out = {"lookup": {"sorted": comms("lookup_sorted_comm", ns), "aggreg": comms("lookup_aggreg_comm", 1)[0],
+                             "runtime": comms("lookup_runtime_comm", 1)[0] if nr else None}}
     if timings is not None:
         for k_, v_ in phases.items():
             timings[k_] = timings.get(k_, 0.0) + v_

@@ -1,5 +1,5 @@
 //! `GpuProver`: `ProverProof::create` (kimchi/src/prover.rs:147-1515) as ONE call into `libkimchi_hip.so` (`kh_prove`, the host loop
-//! in C++ over the library's own entry points), for circuits without lookups (this wrapper: without previous challenges; `kh_prove_recursive` takes them).  The index columns are built once on the
+//! in C++ over the library's own entry points), (this wrapper: circuits without lookups and previous challenges; `kh_prover_index_attach_lookup` / `kh_prove_full` take those).  The index columns are built once on the
 //! device from the reference's own `ConstraintSystem` (gates, wiring, shifts), the witness goes in as the 15 columns the reference
 //! takes, and what comes back is the reference's `ProverProof` value -- byte-identical to what `ProverProof::create` produces for
 //! the same random stream (tests/test_gpu_native_prover.py pins `kh_prove` on the oracle prover, which is pinned on

@@ -289,4 +289,12 @@ def test_runtime_table_proof_equals_the_oracle_provers_proof(khip):
     assert OPR.serialize_proof(C, pr) == OPR.serialize_proof(C, oproof)
     with pytest.raises(ValueError):
         prover.create_proof(ix, np.stack([_limbs(F, col) for col in wit]), V.RefRng(P.StdRng(seed)), runtime_tables=rts[:4])      # RuntimeTablesInconsistent
+    # the same through kh_prove_full (host loop in C++): runtime column committed hiding, folded into the combined table, opened with its selector
+    nproof = prover.create_proof_native(ix, np.stack([_limbs(F, col) for col in wit]), V.RefRng(P.StdRng(seed)), runtime_tables=rts)
+    assert OPR.serialize_proof(C, V.device_views(ix, nproof)[2]) == OPR.serialize_proof(C, oproof)
+    with pytest.raises(ValueError):
+        prover.create_proof_native(ix, np.stack([_limbs(F, col) for col in wit]), V.RefRng(P.StdRng(seed)), runtime_tables=rts[:4])
+    nx = prover.native_index(ix)
+    with pytest.raises(khip.KhError, match="RuntimeTablesInconsistent"):
+        nx.prove(witness=np.stack([_limbs(F, col) for col in wit]), runtime=np.zeros((3, 4), np.uint64))
     ix.free()

@@ -40,3 +40,12 @@ for _ in range(3):
     if best is None or t["total"] < best["total"]:
         best = t
 print(f"2^{logn} rows, {nlook} Lookup gates: " + "  ".join(f"{k} {1e3 * v:.2f} ms" for k, v in best.items()))
+
+prover.create_proof_native(ix, w, np.random.default_rng(8))
+best = None
+for _ in range(3):
+    t = {}
+    prover.create_proof_native(ix, w, np.random.default_rng(8), timings=t, check=False)
+    if best is None or t["total"] < best["total"]:
+        best = t
+print(f"kh_prove: " + "  ".join(f"{k} {1e3 * v:.2f} ms" for k, v in best.items()))
