@@ -147,3 +147,38 @@ def test_native_prover_draws_its_own_randomness_and_takes_a_resident_witness(khi
     with pytest.raises(khip.KhError, match="NoRoomForZkInWitness"):
         nx.prove(witness=np.zeros((15, n, 4), np.uint64))
     dev.free(); ix.free()
+
+
+def test_native_provers_on_several_threads(khip):
+    """kh_prove from four host threads at once -- two on ONE index / SRS handle (openings on a handle queue), two on their own --, randomness from
+    the library: every proof is accepted, and a seeded proof made while the others run equals the one made alone."""
+    import threading
+    from proof_systems_amd import prover
+    from test_gpu_prover import _verify
+    ixs = [prover.bench_circuit_index(khip.VESTA, 10) for _ in range(3)]
+    F = ixs[0].F
+    n = ixs[0].n
+    wit = np.zeros((15, n - 10, 4), dtype=np.uint64); wit[0, :, :] = F.limbs(1)
+    alone = prover.create_proof_native(ixs[0], wit, np.random.default_rng(77))
+    out, errs = {}, []
+
+    def work(t, ix, seeded):
+        try:
+            for r in range(4):
+                out[(t, r)] = prover.create_proof_native(ix, wit, np.random.default_rng(77) if seeded else None, check=(r == 0))
+        except BaseException as e:                                  # noqa: BLE001 -- reported by the main thread
+            errs.append(e)
+    th = [threading.Thread(target=work, args=(0, ixs[0], True)), threading.Thread(target=work, args=(1, ixs[0], False)),
+          threading.Thread(target=work, args=(2, ixs[1], False)), threading.Thread(target=work, args=(3, ixs[2], False))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=300)
+    assert not errs, errs
+    assert len(out) == 16
+    for r in range(4):
+        assert V.device_views(ixs[0], out[(0, r)])[2] == V.device_views(ixs[0], alone)[2]
+    for t, ix in ((1, ixs[0]), (2, ixs[1]), (3, ixs[2])):
+        assert _verify(khip, ix, out[(t, 3)])[0]
+    for ix in ixs:
+        ix.free()
