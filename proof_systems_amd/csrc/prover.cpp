@@ -310,7 +310,7 @@ int kh_prove_full(kh_prover_index_t* ix, const uint64_t* witness, size_t rows, c
     KP(kh_set_device(kh_srs_device(srs)));           // the index lives on the SRS's device: this thread works there until the proof is made
     // ---- the randomness of the whole proof, in the reference's draw order
     const size_t need = kh_prove_randomness_count(ix, witness != nullptr);
-    std::vector<fe> rnd(need);
+    std::vector<fe> rnd(need + 64, fe{{0, 0, 0, 0}});   // (slack: a miscounted draw reads zeros, and the count check at the end reports it)
     if (randomness) {
         KP_REQUIRE(n_random == need, "kh_prove: %zu random elements given, %zu drawn (kh_prove_randomness_count)", n_random, need);
         memcpy(rnd.data(), randomness, 32 * need);

@@ -20,7 +20,8 @@ def _built_library():
     lib = os.path.join(ROOT, "proof_systems_amd", "libkimchi_hip.so")
     ora = os.path.join(ROOT, "oracle", "_build", "libpasta_ref.so")
     exe = os.path.join(ROOT, "tests", "cpp", "test_mirror")
-    if not (os.path.exists(lib) and os.path.exists(ora) and os.path.exists(exe)):
+    exe2 = os.path.join(ROOT, "tests", "cpp", "test_prove")
+    if not (os.path.exists(lib) and os.path.exists(ora) and os.path.exists(exe) and os.path.exists(exe2)):
         import __graft_entry__ as ge
         ge.build()
     yield

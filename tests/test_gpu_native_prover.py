@@ -182,3 +182,43 @@ def test_native_provers_on_several_threads(khip):
         assert _verify(khip, ix, out[(t, 3)])[0]
     for ix in ixs:
         ix.free()
+
+
+def test_a_c_program_proves_and_the_oracle_verifier_accepts(khip, tmp_path):
+    """tests/cpp/test_prove.cpp: index columns, proof and randomness through the C ABI alone (no Python in the process); the proof it writes
+    verifies against the verifier index of the same circuit built here -- the recipe a Rust shim follows (rust/kimchi-hip/src/prover.rs)."""
+    import os
+    import subprocess
+    from proof_systems_amd import prover
+    from test_gpu_prover import _verify
+    logn = 10
+    ix = prover.bench_circuit_index(khip.VESTA, logn)
+    F = ix.F; nch = ix.num_chunks
+    inp, outp = str(tmp_path / "in.bin"), str(tmp_path / "proof.bin")
+    np.concatenate([np.array([logn], dtype=np.uint64), F.limbs_many(ix.shifts).reshape(-1), np.asarray(ix.digest, dtype=np.uint64).reshape(-1)]).tofile(inp)
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cpp", "test_prove")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    r = subprocess.run([exe, inp, outp], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "PROVE_OK" in r.stdout, r.stdout + r.stderr
+    raw = np.fromfile(outp, dtype=np.uint8)
+    pos, sec = 0, []
+    for _ in range(12):
+        cnt, pts = (int(x) for x in raw[pos:pos + 16].view(np.uint64)); pos += 16
+        w = 8 if pts else 4
+        limbs = raw[pos:pos + 8 * w * cnt].view(np.uint64).reshape(cnt, w).copy(); pos += 8 * w * cnt
+        flags = raw[pos:pos + cnt].copy() if pts else None
+        pos += cnt if pts else 0
+        sec.append((limbs, flags))
+    assert pos == raw.size
+    comms = lambda s, k: [(sec[s][0][i * nch:(i + 1) * nch], sec[s][1][i * nch:(i + 1) * nch]) for i in range(k)]
+    ev = F.values(sec[4][0])
+    E = [(ev[(2 * j) * nch:(2 * j + 1) * nch], ev[(2 * j + 1) * nch:(2 * j + 2) * nch]) for j in range(len(ev) // (2 * nch))]
+    pe = F.values(sec[5][0]); z12 = F.values(sec[9][0])
+    proof = {"w_comm": comms(0, 15), "z_comm": comms(1, 1)[0], "t_comm": sec[2], "public_comm": comms(3, 1)[0], "ft_eval1": F.values(sec[6][0])[0], "prev_challenges": [],
+             "evals": {"public": (pe[:nch], pe[nch:]), "z": E[0], "generic_selector": E[1], "poseidon_selector": E[2], "complete_add_selector": E[3], "mul_selector": E[4],
+                       "emul_selector": E[5], "endomul_scalar_selector": E[6], "w": E[7:22], "coefficients": E[22:37], "s": E[37:43], "optional_gate_selectors": [None] * 6},
+             "opening": {"lr": [(sec[7][0][2 * r:2 * r + 2], sec[7][1][2 * r:2 * r + 2]) for r in range(sec[7][0].shape[0] // 2)], "delta": (sec[8][0][0], bool(sec[8][1][0])),
+                         "z1": z12[0], "z2": z12[1], "sg": (sec[10][0][0], bool(sec[10][1][0]))}}
+    assert len(E) == 43
+    assert _verify(khip, ix, proof)[0]
+    ix.free()
