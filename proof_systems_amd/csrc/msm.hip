@@ -1009,6 +1009,59 @@ k_marginals_q(const uint8_t* __restrict__ buckets, MargGeom g, uint8_t* __restri
         if (threadIdx.x < 4) quad_store<BF>(out + ((q * 3 + j) * 32 + v) * 128, acc);
     }
 }
+// Hybrid of the two: the sequential part with ONE LANE per addition, the tree with quads.  These tails are bound by VALU ISSUE, not only by the
+// dependent chain (a cooperative addition is 5 product rounds x 4 lanes = 20 lane-products, the ordinary one 14 in one lane: per addition 78 against 55
+// wave-instruction slots), so where every lane has its own bucket the ordinary addition is the cheaper one, and where the tree leaves lanes idle the
+// cooperative one is the shorter one.  256 threads: each lane adds its cnt / 256 buckets (4 at 2^15 buckets), parks the sum in LDS (word-major: no bank
+// conflicts), then each quad folds four parked points of its wave and the 16 quads / 4 waves finish as in k_marginals_q.
+template <class BF>
+__global__ void __launch_bounds__(256)
+k_marginals_h(const uint8_t* __restrict__ buckets, MargGeom g, uint8_t* __restrict__ out) {
+    KH_HIGH_PRIO();
+    __shared__ u32 stage[4][32][64];                    // [wave][word of the XYZZ record][lane]
+    __shared__ u32 sh[16 * 32];
+    const u32 v = blockIdx.x, j = blockIdx.y; const size_t q = blockIdx.z;
+    const u32 s = g.sh[j], f = g.wd[j];
+    if (v >= (1u << f)) return;
+    const uint8_t* B = buckets + q * (size_t)g.nb * 128;
+    const u32 cnt = g.nb >> f, lowmask = (1u << s) - 1u;
+    const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u, role = threadIdx.x & 3u, quad = lane >> 2, nw = blockDim.x >> 6;
+    Xyzz<BF> a = Xyzz<BF>::identity();
+    bool have = false;
+    for (u32 e = threadIdx.x; e < cnt; e += blockDim.x) {
+        const u32 t = ((e >> s) << (s + f)) | (v << s) | (e & lowmask);
+        const Xyzz<BF> b = Xyzz<BF>::load(B + (size_t)t * 128);
+        a = have ? add<BF>(a, b) : b;
+        have = true;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) { stage[wave][k][lane] = a.x.v[k]; stage[wave][8 + k][lane] = a.y.v[k]; stage[wave][16 + k][lane] = a.zz.v[k]; stage[wave][24 + k][lane] = a.zzz.v[k]; }
+    __syncthreads();
+    auto parked = [&](u32 point) {                       // this lane's coordinate (role) of a point parked by lane `point` of this wave
+        Fe<BF> r;
+#pragma unroll
+        for (int k = 0; k < 8; k++) r.v[k] = stage[wave][role * 8 + k][point];
+        return r;
+    };
+    Fe<BF> acc = parked(quad);
+    for (u32 k = 1; k < 4; k++) acc = quad_add<BF>(acc, parked(quad + 16 * k));
+    for (int d = 8; d >= 1; d >>= 1) acc = quad_add<BF>(acc, quad_shfl_down<BF>(acc, d));       // 16 quads of the wave
+    if (lane < 4) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) sh[(wave * 4 + role) * 8 + k] = acc.v[k];
+    }
+    __syncthreads();
+    if (wave == 0) {                                        // quad w of wave 0 takes wave w's sum
+        Fe<BF> o = Fe<BF>::zero();
+        if (quad < nw) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) o.v[k] = sh[(quad * 4 + role) * 8 + k];
+        }
+        acc = o;
+        for (int d = 8; d >= 1; d >>= 1) if ((u32)d < nw) acc = quad_add<BF>(acc, quad_shfl_down<BF>(acc, d));
+        if (threadIdx.x < 4) quad_store<BF>(out + ((q * 3 + j) * 32 + v) * 128, acc);
+    }
+}
 // block (j, q), 128 threads = 32 quads, one per marginal: suffix scan + sum as in k_marginal_fin, exchanges through LDS
 template <class BF>
 __global__ void __launch_bounds__(128)
@@ -1367,7 +1420,11 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
         // per marginal (16 + 6 additions deep, but 2.2x less issue work -- batches are throughput-bound)
         static const int quad_threads = getenv("KH_QUAD") ? atoi(getenv("KH_QUAD")) : 256;   // 0: scalar additions
         static const size_t quad_maxg = getenv("KH_QUAD_MAXG") ? (size_t)atol(getenv("KH_QUAD_MAXG")) : 8;
+        static const bool marg_hybrid = !(getenv("KH_MARG_HYBRID") && atoi(getenv("KH_MARG_HYBRID")) == 0) && !getenv("KH_QUAD");
         if (ngroups <= quad_maxg && quad_threads > 0) {    // latency path: lane-cooperative additions (coop.cuh)
+            if (marg_hybrid && (mg.nb >> mg.wd[0]) >= 256)  // ... for the tree; one lane per addition where every lane has its own buckets (k_marginals_h)
+                hipLaunchKernelGGL((k_marginals_h<BF>), dim3(32, 3, (unsigned)ngroups), dim3(256), 0, s, C.ws_buckets.as<uint8_t>(), mg, C.ws_seg.as<uint8_t>());
+            else
             hipLaunchKernelGGL((k_marginals_q<BF>), dim3(32, 3, (unsigned)ngroups), dim3(quad_threads), 0, s, C.ws_buckets.as<uint8_t>(), mg, C.ws_seg.as<uint8_t>());
             hipLaunchKernelGGL((k_marginal_fin_q<BF>), dim3(3, (unsigned)ngroups), dim3(128), 0, s, C.ws_seg.as<uint8_t>(), mg, (uint8_t*)C.pinned);   // straight into the pinned host staging
             direct_out = true;
