@@ -44,6 +44,8 @@ template <class F>
 __device__ __forceinline__ Fe<F> quad_add(const Fe<F>& a, const Fe<F>& b) {
     const int role = (int)(threadIdx.x & 3u);
     const bool a_id = quad_flag<QP_BCAST2>(a.is_zero()), b_id = quad_flag<QP_BCAST2>(b.is_zero());
+    // sparse inputs (a witness of small values leaves most buckets empty): when every quad of the wave has an identity operand no product is needed
+    if (__ballot(!a_id && !b_id) == 0ull) return b_id ? a : b;
     // round 1
     const Fe<F> t1 = mul<F>(a, quad_get<F, QP_XOR2>(b));
     // round 2

@@ -1429,6 +1429,10 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
             hipLaunchKernelGGL((k_marginal_fin_q<BF>), dim3(3, (unsigned)ngroups), dim3(128), 0, s, C.ws_seg.as<uint8_t>(), mg, (uint8_t*)C.pinned);   // straight into the pinned host staging
             direct_out = true;
         } else {
+        static const bool marg_h_batch = !(getenv("KH_MARG_H_BATCH") && atoi(getenv("KH_MARG_H_BATCH")) == 0);
+        if (marg_h_batch && marg_hybrid && (mg.nb >> mg.wd[0]) >= 256)      // batches too: the same sums, the 6-level lane tree replaced by the quads' 4 + 4 steps
+            hipLaunchKernelGGL((k_marginals_h<BF>), dim3(32, 3, (unsigned)ngroups), dim3(256), 0, s, C.ws_buckets.as<uint8_t>(), mg, C.ws_seg.as<uint8_t>());
+        else
         hipLaunchKernelGGL((k_marginals<BF>), dim3(32, 3, (unsigned)ngroups), dim3(ngroups <= 4 ? 256 : 64), 0, s, C.ws_buckets.as<uint8_t>(), mg, C.ws_seg.as<uint8_t>());
         // the weighted tail is 3 x ngroups blocks however many MSMs there are: a pure latency chain (10 additions deep), so it takes the
         // lane-cooperative kernel for batches too (15 witness columns: 96 -> 35 us); the records have the same 128-byte layout
