@@ -27,6 +27,7 @@
 // With precomputed window multiples 2^(cw) * P_i (static bases; uses the 288 GB of HBM)
 // all windows share one bucket set and step 8's Horner disappears.
 #include <hip/hip_ext.h>
+#include <math.h>
 #include "common.hpp"
 #include "curve.cuh"
 #include "coop.cuh"
@@ -345,17 +346,31 @@ static constexpr u32 MAX_K = 256;           // upper bound of the task length (l
 // K (entries per task) is chosen HERE from the actual number of entries off[nkeys]: zero digits
 // produce no entry, and the reference's own benchmark witness is almost all ones (one non-zero
 // digit per scalar) -- sizing K from the n*W upper bound left the chip 5 % occupied on it.
-__device__ __forceinline__ u32 pick_K(u32 total, u32 room, u32 kmin) {
+// For SMALL jobs (a few blocks per CU) the task length also decides how the blocks quantise onto the chip: k_accumulate29 is issue-bound, a CU that
+// gets three blocks where its neighbours get two makes the whole launch take three task-lengths.  Measured on the L / R pair of an opening round
+// (tools/kmin_sweep.sh; 2^16: K = 8 / 10 / 11 -> 5.68 / 5.88 / 5.47 ms of rounds, 2^14: 4.25 / 3.73 / 3.74) and reproduced by the model
+//     cost(K) = ceil(blocks(K) / CUs) * min(K, m + 2.3 sqrt(m)) + 2 * tasks-per-bucket(K),   bucket sizes ~ Poisson(m), m = entries / buckets
+// (the second term: every further task of a bucket is one more partial for the bucket sums).  The host tabulates argmin_K over m in quarter octaves
+// for the launch's bucket count (KTab, 0 = no opinion: a big job, where only the total matters); the device looks m up from the ACTUAL entry count.
+struct KTab { uint8_t k[48]; };
+__device__ __forceinline__ u32 pick_K(u32 total, u32 room, u32 kmin, const KTab& tab, u32 nkeys) {
     u32 K = (total + room - 1) / room;
-    return K < kmin ? kmin : (K > MAX_K ? MAX_K : K);
+    u32 lo = kmin;
+    if (total && nkeys) {
+        const float m = (float)total / (float)nkeys;
+        int idx = (int)(4.0f * __log2f(m) + 8.5f);
+        idx = idx < 0 ? 0 : (idx > 47 ? 47 : idx);
+        if (tab.k[idx]) lo = tab.k[idx];
+    }
+    return K < lo ? lo : (K > MAX_K ? MAX_K : K);
 }
-__global__ void k_ntask(const u32* __restrict__ off, size_t nkeys, u32 room, u32 kmin, u32* __restrict__ nt, u32* __restrict__ len_hist, u32* __restrict__ handed) {
+__global__ void k_ntask(const u32* __restrict__ off, size_t nkeys, u32 room, u32 kmin, KTab ktab, u32* __restrict__ nt, u32* __restrict__ len_hist, u32* __restrict__ handed) {
     KH_HIGH_PRIO();
     __shared__ u32 h[MAX_K + 1];
     if (handed && blockIdx.x == 0 && threadIdx.x == 0) handed[0] = 0;          // hand-over list of the accumulation that follows
     for (u32 i = threadIdx.x; i <= MAX_K; i += blockDim.x) h[i] = 0;
     __syncthreads();
-    const u32 K = pick_K(off[nkeys], room, kmin);
+    const u32 K = pick_K(off[nkeys], room, kmin, ktab, (u32)nkeys);
     size_t key = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (key <= nkeys) {
         u32 n_t = 0;
@@ -416,6 +431,7 @@ k_len_rank(const u32* __restrict__ off, const u32* __restrict__ nt, size_t nkeys
 // chunk.  Outputs are exactly those of the multi-launch path (off / toff / entries, empty hand-over and big-bucket lists).
 struct FusedGeom {
     u32 n, nb, W, k, bpg, split, sub, kpt, nkeys, room, kmin;     // sub = nb / split buckets per block
+    KTab ktab;
     size_t pt_stride, pt_offset, pt_batch;
 };
 static constexpr int FUSED_T = 1024, FUSED_KPT = 2, FUSED_G = 16, FUSED_B = 64;      // chunks per job <= FUSED_G, blocks <= FUSED_B
@@ -567,7 +583,7 @@ k_sort_fused(const int32_t* __restrict__ digits, FusedGeom g, u32* __restrict__ 
     u32 base, total;
     lane_sums(bsums, G, blk, &base, &total);
     KH_TS(9);
-    const u32 K = pick_K(total, g.room, g.kmin);
+    const u32 K = pick_K(total, g.room, g.kmin, g.ktab, g.nkeys);
     u32 run = base + ex1, ntm = 0, nt[FUSED_KPT];
 #pragma unroll
     for (int i = 0; i < FUSED_KPT; i++) {
@@ -1151,6 +1167,33 @@ struct CaptureGuard {              // never leave a stream in capture mode on an
     hipStream_t s; bool active = false;
     ~CaptureGuard() { if (active) { hipGraph_t g = nullptr; (void)hipStreamEndCapture(s, &g); if (g) (void)hipGraphDestroy(g); } }
 };
+// the task-length table of pick_K for a launch with `nkeys` buckets on `cus` compute units (cached per bucket count)
+static KTab task_length_table(size_t nkeys, u32 cus) {
+    static std::mutex mu;
+    static std::map<std::pair<size_t, u32>, KTab> cache;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = cache.find({nkeys, cus});
+    if (it != cache.end()) return it->second;
+    KTab t{};
+    for (int idx = 0; idx < 48; idx++) {
+        const double m = pow(2.0, (idx - 8) / 4.0);
+        std::vector<double> p(1, exp(-m));                                   // Poisson(m), up to the far tail
+        for (int c = 1; c < (int)(m + 12 * sqrt(m) + 24); c++) p.push_back(p.back() * m / c);
+        auto tasks_per_bucket = [&](int K) { double s = 0; for (size_t c = 1; c < p.size(); c++) s += p[c] * (double)((c + K - 1) / K); return s; };
+        if (ceil(ceil((double)nkeys * tasks_per_bucket(8) / 256.0) / cus) > 6) { t.k[idx] = 0; continue; }     // a big job: the total decides
+        double best = 1e300; int bk = 8;
+        for (int K = 4; K <= 32; K++) {
+            const double tpb = tasks_per_bucket(K);
+            const double blocks = ceil((double)nkeys * tpb / 256.0);
+            const double len = std::min<double>(K, m + 2.3 * sqrt(m));
+            const double cost = ceil(blocks / cus) * len + 2.0 * tpb;
+            if (cost < best - 1e-9) { best = cost; bk = K; }
+        }
+        t.k[idx] = (uint8_t)bk;
+    }
+    cache[{nkeys, cus}] = t;
+    return t;
+}
 static inline uint64_t fnv(uint64_t h, uint64_t v) { for (int i = 0; i < 8; i++) { h ^= (v >> (8 * i)) & 0xff; h *= 0x100000001b3ull; } return h; }
 
 template <class CFG>
@@ -1183,7 +1226,9 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
     if (nkeys < cap / 2) room_sz = cap - cap / 16 - nkeys / 2;   // ~ half of the buckets add a remainder task
     const u32 room = (u32)room_sz;                          // K = clamp(ceil(entries / room), 8, MAX_K), on the device
     static const u32 kmin = getenv("KH_KMIN") ? (u32)atoi(getenv("KH_KMIN")) : 8u;
-    const size_t max_tasks = M / kmin + nkeys + 1;          // bound for the smallest K
+    static const bool ktab_on = !getenv("KH_KMIN") && !(getenv("KH_KTAB") && atoi(getenv("KH_KTAB")) == 0);
+    const KTab ktab = ktab_on && precomp ? task_length_table(nkeys, (u32)Ctx.num_cus) : KTab{};
+    const size_t max_tasks = M / (kmin < 4 ? kmin : 4) + nkeys + 1;          // bound for the smallest K (the table's entries are >= 4)
     KH_REQUIRE(M < ((size_t)1 << 31) && (tab_stride * (size_t)(precomp ? W : 1) + basis.batch_stride * k) < ((size_t)1 << 31), "MSM too large for 31-bit entry indices (n=%zu k=%zu)", n, k);
 
     int rc;
@@ -1244,7 +1289,7 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
     if (fused) {
         fg.n = (u32)n; fg.nb = nb; fg.W = (u32)W; fg.k = (u32)k; fg.bpg = (u32)std::min<size_t>(FUSED_G, FUSED_B / (2 * k)); fg.nkeys = (u32)nkeys;
         fg.split = 2; fg.sub = nb / fg.split;              // 64 blocks of 64 KB LDS: two per CU, so four (even eight) jobs in flight stay co-resident
-        fg.room = room; fg.kmin = kmin; fg.pt_stride = tab_stride; fg.pt_offset = offset; fg.pt_batch = basis.batch_stride;
+        fg.room = room; fg.kmin = kmin; fg.ktab = ktab; fg.pt_stride = tab_stride; fg.pt_offset = offset; fg.pt_batch = basis.batch_stride;
         const size_t threads = (size_t)fg.bpg * k * fg.split * FUSED_T;
         fg.kpt = (u32)((nkeys + 1 + threads - 1) / threads);
         const size_t tot4 = (size_t)W * n / 4, chunk4 = (tot4 + fg.bpg - 1) / fg.bpg + 1;
@@ -1356,7 +1401,7 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
     if (!fused) {
         // tasks
         KH_HIP(hipMemsetAsync(len_hist, 0, (MAX_K + 1) * sizeof(u32), s));
-        hipLaunchKernelGGL(k_ntask, dim3((unsigned)((nkeys + 1 + 255) / 256)), dim3(256), 0, s, C.ws_off.as<u32>(), nkeys, room, kmin, C.ws_ntask.as<u32>(), len_hist, C.ws_handed.as<u32>());
+        hipLaunchKernelGGL(k_ntask, dim3((unsigned)((nkeys + 1 + 255) / 256)), dim3(256), 0, s, C.ws_off.as<u32>(), nkeys, room, kmin, ktab, C.ws_ntask.as<u32>(), len_hist, C.ws_handed.as<u32>());
         if ((rc = exclusive_scan_u32(C.ws_ntask.as<u32>(), C.ws_toff.as<u32>(), nkeys + 1, C.ws_scan_tmp, s))) return rc;
         static const int rank_min_log = getenv("KH_RANK_MIN_LOG") ? atoi(getenv("KH_RANK_MIN_LOG")) : 22;   // below ~4M entries the three extra launches cost more than the ordering saves
         if (M >= ((size_t)1 << rank_min_log)) {
