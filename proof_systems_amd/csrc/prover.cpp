@@ -591,15 +591,13 @@ int kh_prove_full(kh_prover_index_t* ix, const uint64_t* witness, size_t rows, c
     fe alpha; KP(scalar_challenge(fq.s, alpha));
     fe alphas[3]; alphas[0] = fpow(F, alpha, ALPHA_PERM0); alphas[1] = F.mul(alphas[0], alpha); alphas[2] = F.mul(alphas[1], alpha);
     // ---- constraint rows on d8, quotient (prover.rs:794-917)
-    Dev t4, t8; KP(t4.alloc(4 * NB)); KP(t8.alloc(N8));
+    Dev t8; KP(t8.alloc(N8));                         // the constraint rows on d8 (the reference keeps the generic gate's on d4: same polynomial, see below)
     {
         const uint64_t* cols[31];
         std::vector<uint64_t> consts(4 * 64);
         for (size_t i = 0; i < COLUMNS; i++) { cols[i] = e8.at(i * N8); cols[COLUMNS + i] = ix->col8(i); }
         cols[30] = ix->col8(COLUMNS);
         fe gp[2] = {one, alpha};
-        KP(kh_gate_constants(fid, ix->gid_generic, nullptr, nullptr, (const uint64_t*)gp, 2, consts.data()));
-        KP(kh_gate_evaluations_dev(fid, ix->gid_generic, cols, N8, consts.data(), (size_t)kh_gate_num_constants(ix->gid_generic), 4 * n, 2, 8, 0, t4.p));
         const uint64_t* pc[31];
         for (size_t i = 0; i < COLUMNS; i++) pc[i] = e8.at(i * N8);
         for (size_t i = 0; i < PERMUTS; i++) pc[COLUMNS + i] = ix->col8(COLUMNS + 2 + i);
@@ -608,6 +606,11 @@ int kh_prove_full(kh_prover_index_t* ix, const uint64_t* witness, size_t rows, c
         fe pp[10]; pp[0] = gamma; pp[1] = beta; pp[2] = alphas[0]; for (int i = 0; i < 7; i++) pp[3 + i] = bshift[i];
         KP(kh_gate_constants(fid, ix->gid_perm, nullptr, nullptr, (const uint64_t*)pp, 10, consts.data()));
         KP(kh_gate_evaluations_dev(fid, ix->gid_perm, pc, N8, consts.data(), (size_t)kh_gate_num_constants(ix->gid_perm), N8, 1, 8, 0, t8.p));
+        // the double generic gate on ALL of d8, accumulated onto the permutation rows: the reference evaluates it on d4 and interpolates separately
+        // (prover.rs:794-822, t4); its degree is below 4n, so the 8n-point interpolation of the sum gives the same polynomial -- the 4n-point iNTT and
+        // the t4 buffer go away, and the kernel, memory-bound on whole cache lines either way, reads the same lines it read with stride 2
+        KP(kh_gate_constants(fid, ix->gid_generic, nullptr, nullptr, (const uint64_t*)gp, 2, consts.data()));
+        KP(kh_gate_evaluations_dev(fid, ix->gid_generic, cols, N8, consts.data(), (size_t)kh_gate_num_constants(ix->gid_generic), N8, 1, 8, 1, t8.p));
         for (size_t k = 0; k < 5 + nopt; k++) {      // the gate library on d8 (prover.rs:824-868): index(gate) * sum_i alpha^i constraint_i
             const bool live = k < 5 ? (((ix->live >> k) & 1u) || all_gates) : true;
             if (!live) continue;
@@ -661,12 +664,11 @@ int kh_prove_full(kh_prover_index_t* ix, const uint64_t* witness, size_t rows, c
         }
         KP(p.run(fid, cols, lens, N8, 1, 8, 1, t8.p));
     }
-    KP(kh_ntt_dev(fid, t4.p, logn + 2, 1, 1));
     KP(kh_ntt_dev(fid, t8.p, logn + 3, 1, 1));
-    {                                                 // f = t4 + t8 + public (prover.rs:906-908)
-        const uint64_t* ps[3] = {t8.p, t4.p, pub_c.p}; const size_t ls[3] = {8 * n, 4 * n, n};
-        fe sc[3] = {one, one, one};
-        KP(kh_poly_lincomb_dev(fid, ps, ls, (const uint64_t*)sc, pub_c.p ? 3 : 2, t8.p, 8 * n));
+    if (pub_c.p) {                                    // f = t + public (prover.rs:906-908)
+        const uint64_t* ps[2] = {t8.p, pub_c.p}; const size_t ls[2] = {8 * n, n};
+        fe sc[2] = {one, one};
+        KP(kh_poly_lincomb_dev(fid, ps, ls, (const uint64_t*)sc, 2, t8.p, 8 * n));
     }
     Dev quot, rem; KP(quot.alloc(7 * NB)); KP(rem.alloc(NB));
     KP(kh_divide_by_vanishing_poly_dev(fid, t8.p, 8 * n, logn, quot.p, rem.p));

@@ -553,22 +553,25 @@ def create_proof(ix: ProverIndex, witness, rng, timings=None, check: bool = True
     alpha = scalar_challenge(curve, F, fq.challenge())
     alphas = [pow(alpha, ALPHA_PERM0 + i, F.p) for i in range(3)]
     # ---- constraint rows on d8, quotient
-    t4 = khip.DevBuf(4 * NB); t8 = khip.DevBuf(N8)
+    t8 = khip.DevBuf(N8)
     pconsts = F.limbs_many([gamma, beta, alphas[0]] + [beta * s % F.p for s in ix.shifts])
     gids = khip.gate_ids()
+    # The double generic gate is evaluated on ALL of d8 and accumulated onto the permutation rows: the reference evaluates it on d4 and interpolates it
+    # separately (prover.rs:794-822); its degree is below 4n, so the 8n-point interpolation of the sum is the same polynomial -- no t4, no 4n-point iNTT.
     if _TOKEN_GATES:
-        gen_cols = [e8.view(i * N8) for i in range(6)] + [ix.col8(i) for i in range(10)] + [ix.col8(COLUMNS)]
-        khip.expr_evaluations_dev(fid, OP.generic_gate_tokens(0, 6, 16, 0, 1), gen_cols, [8 * n] * 17, F.limbs_many([1, alpha]), 4 * n, t4, stride=2, next_shift=8)
         perm_cols = [e8.view(i * N8) for i in range(PERMUTS)] + [ix.col8(COLUMNS + 2 + i) for i in range(PERMUTS)] + [e8.view(COLUMNS * N8), ix.col8(ix.X8), ix.col8(ix.ZKPM8)]
         khip.expr_evaluations_dev(fid, OP.perm_quot_tokens(w0=0, s0=7, z=14, x=15, zkpm=16, gamma=0, beta=1, bshift0=3, alpha0=2), perm_cols, [8 * n] * 17, pconsts,
                                   8 * n, t8, stride=1, next_shift=8)
-    else:                                                   # the same two expressions as compiled kernels (csrc/gates.hip: "Generic", "Permutation")
+        gen_cols = [e8.view(i * N8) for i in range(6)] + [ix.col8(i) for i in range(10)] + [ix.col8(COLUMNS)]
+        khip.expr_evaluations_dev(fid, OP.generic_gate_tokens(0, 6, 16, 0, 1), gen_cols, [8 * n] * 17, F.limbs_many([1, alpha]), 8 * n, t8, stride=1, next_shift=8,
+                                  accumulate=True)
+    else:                                                   # the same two expressions as compiled kernels (csrc/gates.hip: "Permutation", "Generic")
         wcols = [e8.view(i * N8) for i in range(COLUMNS)]
-        khip.gate_evaluations_dev(fid, gids["Generic"], wcols + [ix.col8(i) for i in range(COLUMNS)] + [ix.col8(COLUMNS)], 8 * n, F.limbs_many([1, alpha]), 4 * n, t4,
-                                  stride=2, next_shift=8)
         pcols = wcols + [ix.col8(COLUMNS + 2 + i) for i in range(PERMUTS)] + [e8.view(COLUMNS * N8), ix.col8(ix.X8), ix.col8(ix.ZKPM8)]
         pcols += [wcols[0]] * (31 - len(pcols))             # columns the expression does not read
         khip.gate_evaluations_dev(fid, gids["Permutation"], pcols, 8 * n, pconsts, 8 * n, t8, stride=1, next_shift=8)
+        khip.gate_evaluations_dev(fid, gids["Generic"], wcols + [ix.col8(i) for i in range(COLUMNS)] + [ix.col8(COLUMNS)], 8 * n, F.limbs_many([1, alpha]), 8 * n, t8,
+                                  stride=1, next_shift=8, accumulate=True)
     live_gates = [(k_, name) for k_, name in enumerate(ix.GATE_TYPES + tuple(ix.optional)) if all_gates or name in ix.live_gate_types]
     if live_gates:                                          # the gate library on d8 (prover.rs:824-868): index(gate) * sum_i alpha^i constraint_i
         endo_q = F.value(khip.endos(1 - curve)[0])          # VerifierIndex::endo = endos::<OtherCurve>().0, an element of this scalar field
@@ -596,12 +599,9 @@ def create_proof(ix: ProverIndex, witness, rng, timings=None, check: bool = True
         assert len(lbufs) == cols["count"]
         khip.expr_evaluations_dev(fid, ltoks, lbufs, [8 * n] * len(lbufs), F.limbs_many(lconsts), 8 * n, t8, stride=1, next_shift=8, accumulate=True)
         lkp.update({"lkc": lkc, "lk8": lk8, "nl": nl})
-    khip.ntt_dev(fid, t4, logn + 2, True, 1)
     khip.ntt_dev(fid, t8, logn + 3, True, 1)
     if pub_c is not None:
-        khip.poly_lincomb_dev(fid, [t8, t4, pub_c], [8 * n, 4 * n, n], F.limbs_many([1, 1, 1]), t8, 8 * n)    # f = t4 + t8 + public (prover.rs:906-908)
-    else:
-        khip.poly_lincomb_dev(fid, [t8, t4], [8 * n, 4 * n], F.limbs_many([1, 1]), t8, 8 * n)
+        khip.poly_lincomb_dev(fid, [t8, pub_c], [8 * n, n], F.limbs_many([1, 1]), t8, 8 * n)    # f = t + public (prover.rs:906-908)
     quot = khip.DevBuf(7 * NB); rem = khip.DevBuf(NB)
     khip.divide_by_vanishing_poly_dev(fid, t8, 8 * n, logn, quot, rem)
     if check and rem.download((n, 4)).any():
@@ -742,7 +742,7 @@ def create_proof(ix: ProverIndex, witness, rng, timings=None, check: bool = True
     opening = {"lr": [(lr_xy[r], lr_inf[r]) for r in range(logs)], "delta": (delta, dinf), "z1": F.value(z1_l), "z2": F.value(z2_l), "sg": (sg, sg_inf)}
     sp.free(); fq.free()
     mark("opening")
-    for b in [ev, cf, e8, t4, t8, quot, rem, zm1, b1, b2, ft, a_dev, b_dev, num, den] + [b for b, _l, _k in prev_bufs]:
+    for b in [ev, cf, e8, t8, quot, rem, zm1, b1, b2, ft, a_dev, b_dev, num, den] + [b for b, _l, _k in prev_bufs]:
         b.free()
     if pub_c is not None:
         pub_c.free()
