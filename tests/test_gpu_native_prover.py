@@ -222,3 +222,52 @@ def test_a_c_program_proves_and_the_oracle_verifier_accepts(khip, tmp_path):
     assert len(E) == 43
     assert _verify(khip, ix, proof)[0]
     ix.free()
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_randomised_configurations_native_equals_python_and_verifies(khip, seed):
+    """Differential fuzz over what the parity tests fix by hand: a random subset of the library / optional gates (in random order, between random
+    numbers of generic rows), a random number of public inputs, the domain 1x / 2x / 4x the SRS or half of it -- kh_prove and the Python loop give the
+    same proof from the same random stream, and the oracle verifier accepts it."""
+    from proof_systems_amd import prover
+    from test_gates import gate_rows, tables
+    from test_gpu_prover import _verify
+    rnd = random.Random(9000 + seed)
+    F = prover.Fld(khip.FP)
+    names = ["Poseidon", "CompleteAdd", "VarBaseMul", "EndoMul", "EndoMulScalar", "ForeignFieldAdd", "Rot64"]
+    rnd.shuffle(names)
+    names = names[:rnd.randrange(0, len(names) + 1)]
+    npub = rnd.randrange(0, 4)
+    wrows, crows, types = [], [], []
+
+    def generic_rows(k, public=False):
+        for _ in range(k):
+            v = rnd.randrange(1, F.p)
+            wrows.append([v] + [0] * 14)
+            crows.append([1, 0, 0, 0, 0 if public else (F.p - v)] + [0] * 10)           # public rows: w0 - p_i = 0 through the public polynomial
+            types.append("Generic")
+    generic_rows(npub, public=True)
+    generic_rows(rnd.randrange(1, 6))
+    for name in names:
+        w, co, ngate = tables(name, rnd)
+        live = set(gate_rows(name, ngate))
+        for r, (wr, cr) in enumerate(zip(w, co)):
+            wrows.append(list(wr)); crows.append([c % F.p for c in cr]); types.append(name if r in live else "Zero")
+        generic_rows(rnd.randrange(0, 3))
+    rows = len(wrows)
+    logn = 7 if rows + 9 <= 128 else 8
+    log_srs = logn + rnd.choice([-2, -1, 0, 0, 1])
+    nch = 1 << max(0, logn - log_srs)
+    assert rows + (16 * nch + 5) // 7 <= 1 << logn
+    srs = khip.Srs.create(khip.VESTA, 1 << log_srs)
+    ix = prover.ProverIndex(khip.VESTA, logn, np.stack([F.limbs_many(r) for r in crows]), srs=srs, gate_types=types, public=npub)
+    assert ix.num_chunks == nch
+    wit = np.stack([F.limbs_many([wrows[r][c] for r in range(rows)]) for c in range(15)])
+    a = prover.create_proof(ix, wit, np.random.default_rng(seed))
+    b = prover.create_proof_native(ix, wit, np.random.default_rng(seed))
+    assert a["challenges"] == b["challenges"], (names, npub, logn, log_srs)
+    assert V.device_views(ix, a)[2] == V.device_views(ix, b)[2]
+    assert _verify(khip, ix, b)[0], (names, npub, logn, log_srs)
+    c = prover.create_proof_native(ix, wit, np.random.default_rng(seed), all_gates=True)
+    assert V.device_views(ix, c)[2] == V.device_views(ix, b)[2]
+    ix.free()
