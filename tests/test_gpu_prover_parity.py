@@ -102,6 +102,40 @@ def test_device_prover_reproduces_the_reference_whole_proof_bytes(khip):
     assert len(got) == 6160
 
 
+@pytest.mark.parametrize("log_srs", [8, 7])
+def test_chunked_proof_with_lookups_equals_the_oracle_provers_proof(khip, log_srs):
+    """The two features together, which no reference fixture and no other test combines: the AND circuit of the whole-proof vector (Xor16 rows + XOR-table
+    lookups, a 2^9 domain) over an SRS of 2^8 / 2^7 -- 2 / 4 chunks, zk_rows 5 / 9: every lookup commitment a chunk list, the sorted / aggregation /
+    table evaluations chunked, the combined table's blinder per chunk.  Python loop and kh_prove = the oracle prover, byte for byte; verifier accepts."""
+    from proof_systems_amd import prover
+    C = P.VESTA; F = C.scalar
+    std = P.StdRng(bytes([61] * 32))
+    gates = []
+    CC.extend_and(F.p, gates, 8)
+    in1 = CC.gen_field_with_bits(std, 64); in2 = CC.gen_field_with_bits(std, 64)
+    rows = G.and_witness(F, in1, in2, 8)
+    cs = CC.build(F, gates, max_poly_size=1 << log_srs)
+    nch = (1 << cs["log2_n"]) >> log_srs
+    assert cs["log2_n"] == 9 and cs["zk_rows"] == (16 * nch + 5) // 7 and cs["lookup"] is not None
+    wit = [[r[c] for r in rows] for c in range(15)]
+    seed = bytes([62, log_srs] + [1] * 30)
+    osrs = OPR.Srs(C, 1 << log_srs)
+    oix = OPR.Index(C, cs, osrs)
+    oproof = OPR.create_proof(oix, wit, P.StdRng(seed))
+    assert K.verify(C, dict(oix.vindex), oproof, None, osrs.h, P.StdRng(bytes([5] * 32)), final_msm=V.final_msm_c(C, osrs.g, osrs.size))
+    srs = khip.Srs.create(khip.VESTA, 1 << log_srs)
+    ix = device_index(khip, cs, khip.VESTA, srs)
+    assert ix.num_chunks == nch
+    w = np.stack([_limbs(F, col) for col in wit])
+    dproof = prover.create_proof(ix, w, V.RefRng(P.StdRng(seed)))
+    c, vix, pr = V.device_views(ix, dproof)
+    assert compare(C, oproof, pr) is None, compare(C, oproof, pr)
+    assert OPR.serialize_proof(C, pr) == OPR.serialize_proof(C, oproof)
+    nproof = prover.create_proof_native(ix, w, V.RefRng(P.StdRng(seed)))
+    assert OPR.serialize_proof(C, V.device_views(ix, nproof)[2]) == OPR.serialize_proof(C, oproof)
+    ix.free()
+
+
 @pytest.mark.parametrize("cid,logn,log_srs", [(0, 7, 7), (1, 7, 7), (0, 10, 10), (0, 8, 10), (0, 9, 7), (1, 8, 7), (0, 12, 11)])
 def test_device_proof_equals_the_oracle_provers_proof(khip, cid, logn, log_srs):
     """generic-gate circuits with copy constraints and public inputs; log_srs > logn: SRS longer than the domain; log_srs < logn:
