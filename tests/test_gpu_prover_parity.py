@@ -181,7 +181,7 @@ def test_device_proof_equals_the_oracle_provers_proof(khip, cid, logn, log_srs):
     ix.free()
 
 
-@pytest.mark.parametrize("cid,logn,log_srs,nprev", [(0, 6, 7, 1), (1, 7, 7, 2)])
+@pytest.mark.parametrize("cid,logn,log_srs,nprev", [(0, 6, 7, 1), (1, 7, 7, 2), (0, 7, 6, 1)])
 def test_recursive_proof_equals_the_oracle_provers_proof(khip, cid, logn, log_srs, nprev):
     """create_recursive with previous challenges (kimchi/src/tests/recursion.rs:44-75: chals random, comm = commit_non_hiding of
     b_poly_coefficients(chals)): absorbed into both sponges, their polynomials opened first."""
@@ -196,14 +196,16 @@ def test_recursive_proof_equals_the_oracle_provers_proof(khip, cid, logn, log_sr
         wit[3][r], wit[4][r], wit[5][r] = 11, 23, 11 * 23 * 2
     for r in range(10, 20):
         wit[0][r], wit[3][r] = 3, 5
-    cs = CC.build(F, gates + [CC.gate("Zero", len(gates) + k) for k in range((1 << logn) - 3 - len(gates))], prev_challenges=nprev)
+    cs = CC.build(F, gates + [CC.gate("Zero", len(gates) + k) for k in range((1 << logn) - 9 - len(gates))], prev_challenges=nprev,
+                  max_poly_size=(1 << log_srs) if log_srs < logn else None)
     assert cs["log2_n"] == logn
     CC.verify_witness(cs, wit)
     osrs = OPR.Srs(C, 1 << log_srs)
     std = P.StdRng(bytes([11] * 32))
     prev = []
     for _ in range(nprev):
-        chals = [P.field_rand(F, std) for _ in range(log_srs)]
+        # (logn > log_srs: the accumulator's polynomial is twice the SRS size -- its commitment has two chunks, its evaluations are chunked: proof.rs:455-494)
+        chals = [P.field_rand(F, std) for _ in range(max(log_srs, logn))]
         prev.append((chals, osrs.commit_non_hiding(P.b_poly_coefficients(F, chals), 1)))
     seed = bytes([21, cid] + [5] * 30)
     oix = OPR.Index(C, cs, osrs)
@@ -223,7 +225,7 @@ def test_recursive_proof_equals_the_oracle_provers_proof(khip, cid, logn, log_sr
         return xy, inf
     dprev = [(chals, dev_comm(cm)) for chals, cm in prev]
     # the device computes the same accumulator commitment (kh_b_poly_coefficients + commit_non_hiding)
-    bc = khip.b_poly_coefficients(ix.fid, _limbs(F, prev[0][0]), log_srs)[0]
+    bc = khip.b_poly_coefficients(ix.fid, _limbs(F, prev[0][0]), len(prev[0][0]))[0]
     com, inf = srs.commit_non_hiding(bc, 1)
     assert V.chunks(C, (com, inf)) == prev[0][1]
     dproof = prover.create_proof(ix, np.stack([_limbs(F, col) for col in wit]), V.RefRng(P.StdRng(seed)), prev_challenges=dprev)
