@@ -303,19 +303,27 @@ def runtime_table_circuit(F, seed=5):
     return CC.build(F, gates, runtime_tables=cfg), cfg, rts, wit
 
 
-def test_runtime_table_proof_equals_the_oracle_provers_proof(khip):
+@pytest.mark.parametrize("chunks", [1, 2])
+def test_runtime_table_proof_equals_the_oracle_provers_proof(khip, chunks):
     """Runtime tables (prover.rs:397-470): the proof's contribution to the table's second column is committed first, enters the combined
-    table through the joint combiner (blinders included), is evaluated and opened with its selector, and adds one lookup constraint."""
+    table through the joint combiner (blinders included), is evaluated and opened with its selector, and adds one lookup constraint.
+    chunks = 2: the same over an SRS half the domain (the runtime column's commitment, blinders and evaluations per chunk)."""
     from proof_systems_amd import prover
     C = P.VESTA; F = C.scalar
     cs, cfg, rts, wit = runtime_table_circuit(F)
+    if chunks > 1:
+        from oracle import circuit as CCm
+        cs = CCm.build(F, [CCm.gate("Lookup", r) for r in range(20)], runtime_tables=cfg, max_poly_size=(1 << cs["log2_n"]) // chunks)
+        assert ((1 << cs["log2_n"]) // chunks) * chunks == 1 << cs["log2_n"]
+    size = (1 << cs["log2_n"]) // chunks
     seed = bytes([61] * 32)
-    osrs = OPR.Srs(C, 1 << cs["log2_n"])
+    osrs = OPR.Srs(C, size)
     oix = OPR.Index(C, cs, osrs)
     oproof = OPR.create_proof(oix, wit, P.StdRng(seed), runtime_tables=rts)
     assert K.verify(C, dict(oix.vindex), oproof, None, osrs.h, P.StdRng(bytes([5] * 32)), final_msm=V.final_msm_c(C, osrs.g, osrs.size))
-    srs = khip.Srs.create(khip.VESTA, 1 << cs["log2_n"])
+    srs = khip.Srs.create(khip.VESTA, size)
     ix = device_index(khip, cs, khip.VESTA, srs, runtime_cfg=cfg)
+    assert ix.num_chunks == chunks
     c, vix, _ = V.device_views(ix, None)
     assert K.verifier_index_digest(C, vix | {"lookup_index": None}) is not None
     dproof = prover.create_proof(ix, np.stack([_limbs(F, col) for col in wit]), V.RefRng(P.StdRng(seed)), runtime_tables=rts)
