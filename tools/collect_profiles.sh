@@ -7,6 +7,7 @@ mkdir -p gpurun_out
 tools/microbench > gpurun_out/${R}_microbench.txt 2>&1
 python tools/profile_msm.py gpurun_out/${R}_msm20 > gpurun_out/${R}_profile_msm.log 2>&1
 python tools/profile_msm.py gpurun_out/${R}_ntt --workload ntt > gpurun_out/${R}_profile_ntt.log 2>&1
+python tools/profile_msm.py gpurun_out/${R}_gates --workload gates > gpurun_out/${R}_profile_gates.log 2>&1
 python bench.py > gpurun_out/${R}_bench_n1.json 2> gpurun_out/${R}_bench_n1.err
 ( cd /tmp && export TMPDIR=/tmp && PYTHONPATH=$GRAFT_REPO_ROOT rocprofv3 --kernel-trace -d /tmp/pp_${R} -o pp -- python $GRAFT_REPO_ROOT/tools/prover_time.py 16 > $GRAFT_REPO_ROOT/gpurun_out/${R}_prover_time.txt 2>&1 )
 python tools/rocpd_stats.py /tmp/pp_${R}/pp_results.db gpurun_out/${R}_prover_kernel_stats.csv > /dev/null 2>&1

@@ -12,6 +12,7 @@ python3 tools/valu_mix.py profiles/${R}_k_accumulate29_valu_mix.json > /dev/null
 [ -f gpurun_out/${R}_ntt_pmc.json ] && cp gpurun_out/${R}_ntt_pmc.json profiles/${R}_ntt_pmc.json && cp gpurun_out/${R}_ntt_kernel_stats.csv profiles/${R}_ntt_kernel_stats.csv
 python3 tools/valu_mix.py profiles/${R}_k_ntt_pass_valu_mix.json --kernel ntt > /dev/null
 [ -f gpurun_out/${R}_bench_n1.json ] && tail -1 gpurun_out/${R}_bench_n1.json > profiles/${R}_bench_line.json
+[ -f gpurun_out/${R}_gates_pmc.json ] && cp gpurun_out/${R}_gates_pmc.json gpurun_out/${R}_gates_kernel_stats.csv profiles/
 for f in prover_native gate_kernels lookup_prover kmin_sweep prover_kernel_stats.csv prover_timeline; do
   for g in gpurun_out/${R}_${f}.txt gpurun_out/${R}_${f}; do [ -f "$g" ] && cp "$g" profiles/; done
 done

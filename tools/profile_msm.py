@@ -11,7 +11,7 @@ Output: <out>.json = {"source_sha256": <hash of csrc/ at collection time>, "kern
 plus <out>_kernel_stats.csv.  bench.py refuses to quote traffic / instruction counts from a file whose source hash is
 not the hash of the sources it is running (a stale PMC file is how round 1's roofline block went wrong).
 
-Usage (from the repo root on the GPU box):  python tools/profile_msm.py gpurun_out/r02_msm20 [--workload msm|ntt]"""
+Usage (from the repo root on the GPU box):  python tools/profile_msm.py gpurun_out/r02_msm20 [--workload msm|ntt|gates]"""
 import glob
 import hashlib
 import json
@@ -77,6 +77,8 @@ def main():
     os.makedirs(outdir, exist_ok=True)
     if workload == "msm":
         cmd = [sys.executable, "bench.py", "--no-pipeline", "--no-cpu-baseline", "--no-oplist", "--steps", "10", "--warmup", "2"]
+    elif workload == "gates":
+        cmd = [sys.executable, "tools/gate_expr_time.py"]                   # every gate of the library on 2^19 rows: token machine and compiled kernel
     else:
         cmd = [sys.executable, "tools/bench_ntt.py", "--bench-shapes"]      # iNTT 2^16 x 19 + LDE 2^16 -> 2^19 x 16: what bench.py's ntt_kernels quotes
     res = {"source_sha256": source_hash(), "command": " ".join(cmd[1:]), "kernels": {}}
