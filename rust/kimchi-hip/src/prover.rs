@@ -70,7 +70,7 @@ where
 {
     /// `cs`: the constraint system of `ProverIndex::cs`; `digest`: `ProverIndex::verifier_index_digest` (prover_index.rs:130-146).
     pub fn new(cs: &ConstraintSystem<G::ScalarField>, srs: GpuSrs<G>, digest: G::BaseField) -> Self {
-        assert!(cs.lookup_constraint_system.get().is_none() && cs.prev_challenges == 0, "kh_prove: no lookups / recursion; use ProverProof::create");
+        assert!(matches!(cs.lookup_constraint_system.try_get_or_err(), Ok(None)) && cs.prev_challenges == 0, "kh_prove: no lookups / recursion; use ProverProof::create");
         let n = cs.domain.d1.size as usize;
         let log2_n = cs.domain.d1.log_size_of_group;
         let optional: Vec<usize> = (0..6).filter(|&k| cs.gates.iter().any(|g| g.typ == OPTIONAL[k].0)).collect();
