@@ -306,6 +306,37 @@ def atom_columns(ix: LookupIndex, log2_blowup: int = 3):
     return [khip.DevBuf(m * 32).upload(F.limbs_many(c)) for c in (vanish, l0, lfinal)]
 
 
+def atom_columns_dev(ix: LookupIndex, x8, log2_blowup: int = 3):
+    """The same three columns computed on the device from the d8 evaluations of x (`x8`: DevBuf / view of 8n elements): products of (x - w^k) for
+    `vanish`; (x^n - 1) * (x - a)^-1 with one batched inversion per atom, the removable singularity (x = a, a point of d1) patched with its limit
+    n * a^-1.  atom_columns above is the host restatement this is tested against (tests/test_gpu_lookup.py); at 2^16 rows it takes ~50 s, this ~1 ms."""
+    F, n, p, fid = ix.F, ix.n, ix.F.p, ix.fid
+    m = n << log2_blowup
+    w = khip_root(F, ix.logn)
+    last = [pow(w, k, p) for k in range(n - ix.zk_rows - 1, n)]
+    wf = pow(w, n - ix.zk_rows - 1, p)
+    out = []
+    toks = []
+    for i in range(len(last)):
+        toks += [OP.cell(0), (OP.TOK_CONST, i), (OP.TOK_SUB, 0)] + ([(OP.TOK_MUL, 0)] if i else [])
+    vanish = khip.DevBuf(m * 32)
+    khip.expr_evaluations_dev(fid, toks, [x8], [m], F.limbs_many(last), m, vanish, stride=1, next_shift=1)
+    out.append(vanish)
+    for a, row in ((1, 0), (wf, (n - ix.zk_rows - 1) << log2_blowup)):
+        den = khip.DevBuf(m * 32)
+        khip.expr_evaluations_dev(fid, [OP.cell(0), (OP.TOK_CONST, 0), (OP.TOK_SUB, 0)], [x8], [m], F.limbs_many([a]), m, den, stride=1, next_shift=1)
+        den.upload_at(row * 32, F.limbs(1).reshape(1, 4))                # x = a: any non-zero value, the product below is 0 there and patched
+        khip.batch_inversion_dev(fid, den, m)
+        col = khip.DevBuf(m * 32)
+        khip.expr_evaluations_dev(fid, [OP.cell(0), (OP.TOK_POW, n), (OP.TOK_CONST, 0), (OP.TOK_SUB, 0), OP.cell(1), (OP.TOK_MUL, 0)], [x8, den], [m, m],
+                                  F.limbs_many([1]), m, col, stride=1, next_shift=1)
+        col.upload_at(row * 32, F.limbs(n * pow(a, p - 2, p) % p).reshape(1, 4))
+        khip.sync()
+        den.free()
+        out.append(col)
+    return out
+
+
 def khip_root(F: Fld, log2_n: int) -> int:
     """w_{2^k} = (5^T)^(2^(32 - k)), T = (p - 1) >> 32 (kimchi/src/circuits/domains.rs:40-69)."""
     return pow(pow(5, (F.p - 1) >> 32, F.p), 1 << (32 - log2_n), F.p)

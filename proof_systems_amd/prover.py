@@ -291,7 +291,7 @@ class ProverIndex:
             c = khip.DevBuf(n * 32); khip.dev_copy(c.ptr, LI.d_selectors[q].ptr, n * 32); khip.ntt_dev(fid, c, logn, True, 1)
             e = khip.DevBuf(8 * n * 32); khip.lde_dev(fid, c, logn, 3, e, 1)
             LI.sel_c[q], LI.sel8[q] = c, e
-        LI.atoms8 = LK.atom_columns(LI, 3)
+        LI.atoms8 = LK.atom_columns_dev(LI, self.col8(self.X8), 3)      # (LK.atom_columns is the host restatement: ~50 s at 2^16 rows)
         LI.rtsel_c = LI.rtsel8 = LI.runtime_selector_comm = None
         if LI.d_runtime_selector is not None:                           # the runtime selector: coefficient form, d8, committed non-hiding
             LI.rtsel_c = khip.DevBuf(n * 32); khip.dev_copy(LI.rtsel_c.ptr, LI.d_runtime_selector.ptr, n * 32); khip.ntt_dev(fid, LI.rtsel_c, logn, True, 1)

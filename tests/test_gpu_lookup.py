@@ -126,3 +126,29 @@ def test_lookup_argument_on_device(env):
         quo = khip.DevBuf(7 * N * 32); rem = khip.DevBuf(N * 32)
         khip.divide_by_vanishing_poly_dev(fid, q8, 8 * N, LOGN, quo, rem)
         assert rem.download((N, 4)).any() == (variant == "violated"), variant
+
+
+@pytest.mark.parametrize("zk", [3, 5])
+def test_atom_columns_on_the_device_equal_the_host_restatement(zk):
+    """VanishesOnZeroKnowledgeAndPreviousRows, UnnormalizedLagrangeBasis(0), UnnormalizedLagrangeBasis(-zk_rows - 1) on d8 (expr.rs:883-893): the device
+    version (products / one batched inversion per atom / the removable singularity patched) against the host loop over every point."""
+    import proof_systems_amd.khip as khip
+    from proof_systems_amd import lookup as LK, prover
+    khip.init(0)
+    logn = 7; n = 1 << logn
+    F = prover.Fld(khip.FP)
+    tables = [{"id": 0, "data": [list(range(8)), [0] + list(range(11, 18))]}]
+    gates = ["Lookup"] * 20 + ["Zero"] * (n - zk - 20)
+    LI = LK.LookupIndex(khip.FP, gates, tables, logn, zk_rows=zk)
+    root = LK.khip_root(F, logn + 3)
+    xs = [1] * (8 * n)
+    for k in range(1, 8 * n):
+        xs[k] = xs[k - 1] * root % F.p
+    x8 = khip.DevBuf(8 * n * 32).upload(F.limbs_many(xs))
+    host = LK.atom_columns(LI, 3)
+    dev = LK.atom_columns_dev(LI, x8, 3)
+    for a, b, name in zip(host, dev, ("vanish", "l0", "lfinal")):
+        assert (a.download((8 * n, 4)) == b.download((8 * n, 4))).all(), name
+    for b in host + dev + [x8]:
+        b.free()
+    LI.free()
