@@ -16,13 +16,14 @@ if len(sys.argv) > 4 and sys.argv[4] == "worker":
     F = prover.Fld(ix.fid)
     wit = np.tile(F.limbs(1), (15, (1 << int(logn)) - 10, 1))
     rng = np.random.default_rng(os.getpid())
+    nx = prover.native_index(ix)                                  # kh_prove with the library's randomness: the same call the threads of prover_concurrent.py --native make
     for _ in range(3):
-        prover.create_proof(ix, wit, rng, check=False)
+        nx.prove(witness=wit, randomness=None, flags=0)
     print("ready", flush=True)
     sys.stdin.readline()
     t0 = time.perf_counter()
     for _ in range(K):
-        prover.create_proof(ix, wit, rng, check=False)
+        nx.prove(witness=wit, randomness=None, flags=0)
     print(f"done {time.perf_counter() - t0:.4f}", flush=True)
     sys.exit(0)
 procs = [subprocess.Popen([sys.executable, __file__, logn, str(P), str(K), "worker"], stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True) for _ in range(P)]
