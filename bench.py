@@ -286,6 +286,7 @@ def prover_block(khip, srs20, check_with_oracle=True, log_n=16, reps=5):
     bar = threading.Barrier(T + 1)
 
     def run(t):
+        nxs[t].prove(witness=wit, randomness=None, flags=0)      # warm this thread's own library context (kh_prove works on a private one)
         bar.wait()
         for _ in range(per):                             # kh_prove, randomness from the library: no Python between the steps of a proof
             nxs[t].prove(witness=wit, randomness=None, flags=0)

@@ -27,16 +27,39 @@ static int g_default_dev = -1;                 // first device initialised (guar
 static thread_local int tl_dev = -1;           // this thread's choice (kh_set_device / kh_init / DeviceScope); -1: process default
 static thread_local int tl_hip_dev = -1;       // what this thread last passed to hipSetDevice
 
+// A prover thread may take a context of its OWN for a stretch of work (kh_private_context_begin / _end; kh_prove does): own main stream, pipeline slots,
+// workspaces and lock, so that several provers in one process neither queue their vector steps on one stream nor serialise their launches on one mutex
+// (four single-prover processes: 177 proofs/s, four threads on the shared context: 128).  Private contexts are pooled per device and never destroyed,
+// like the shared ones.  What belongs to an SRS HANDLE (its Lagrange-basis map, the one opening it can run at a time) has its own locks (kh_srs).
+static thread_local Context* tl_private[KH_MAX_DEVICES];
+static std::vector<Context*> g_private_pool[KH_MAX_DEVICES];           // idle private contexts (guarded by g_ctx_mu)
+// a thread keeps the context it used last (its workspaces, captured graphs and staging ring stay warm for its next proof) and hands it to the pool when it
+// exits -- no HIP call in the destructor, only the list
+struct ThreadContextCache {
+    Context* c[KH_MAX_DEVICES] = {nullptr};
+    ~ThreadContextCache();
+};
+static thread_local ThreadContextCache tl_ctx_cache;
+
+ThreadContextCache::~ThreadContextCache() {
+    std::lock_guard<std::mutex> lk(g_ctx_mu);
+    for (int d = 0; d < KH_MAX_DEVICES; d++) if (c[d]) { g_private_pool[d].push_back(c[d]); c[d] = nullptr; }
+}
 static int current_device() {
     if (tl_dev >= 0) return tl_dev;
     std::lock_guard<std::mutex> lk(g_ctx_mu);
     return g_default_dev;
 }
-static Context& ctx_of(int dev) {
+static Context& shared_ctx_of(int dev) {
     if (dev < 0 || dev >= KH_MAX_DEVICES) dev = 0;
     std::lock_guard<std::mutex> lk(g_ctx_mu);
     if (!g_ctx[dev]) g_ctx[dev] = new Context;
     return *g_ctx[dev];
+}
+static Context& ctx_of(int dev) {
+    if (dev < 0 || dev >= KH_MAX_DEVICES) dev = 0;
+    if (tl_private[dev]) return *tl_private[dev];
+    return shared_ctx_of(dev);
 }
 Context& ctx() { return ctx_of(current_device()); }
 
@@ -73,6 +96,24 @@ DeviceScope::DeviceScope(int device) : prev(tl_dev) {
 }
 DeviceScope::~DeviceScope() { tl_dev = prev; }
 
+// streams, events and device facts of one context (the calling thread is bound to device_id, C.mu held or C not yet published)
+static int init_context(Context& C, int device_id) {
+    if (C.ready) return KH_OK;
+    for (int i = 0; i < MSM_SLOTS; i++) {
+        KH_HIP(hipStreamCreateWithFlags(&C.slot[i].stream, hipStreamNonBlocking));
+        KH_HIP(hipEventCreateWithFlags(&C.slot[i].done, hipEventDisableTiming));
+        int rc2 = C.slot[i].timer.init(); if (rc2) return rc2;
+    }
+    C.stream = C.slot[0].stream;         // four streams = the four hardware queues HIP gives a process by default; a fifth would share one
+    KH_HIP(hipEventCreateWithFlags(&C.order_ev, hipEventDisableTiming));
+    hipDeviceProp_t prop;
+    KH_HIP(hipGetDeviceProperties(&prop, device_id));
+    C.num_cus = prop.multiProcessorCount;
+    int rc = C.timer.init(); if (rc) return rc;
+    C.device = device_id;
+    C.ready = true;
+    return KH_OK;
+}
 static int do_init(int device_id) {
     if (!(__builtin_cpu_supports("bmi2") && __builtin_cpu_supports("adx"))) {      // the host code is built with -mbmi2 -madx (__graft_entry__.py)
         set_error("this build needs a host CPU with BMI2 and ADX"); return KH_E_DEVICE;
@@ -92,21 +133,7 @@ static int do_init(int device_id) {
     Context& C = ctx_of(device_id);
     std::lock_guard<std::mutex> lk(C.mu);
     int rc = bind_thread(device_id); if (rc) return rc;
-    if (!C.ready) {
-        for (int i = 0; i < MSM_SLOTS; i++) {
-            KH_HIP(hipStreamCreateWithFlags(&C.slot[i].stream, hipStreamNonBlocking));
-            KH_HIP(hipEventCreateWithFlags(&C.slot[i].done, hipEventDisableTiming));
-            int rc2 = C.slot[i].timer.init(); if (rc2) return rc2;
-        }
-        C.stream = C.slot[0].stream;         // four streams = the four hardware queues HIP gives a process by default; a fifth would share one
-        KH_HIP(hipEventCreateWithFlags(&C.order_ev, hipEventDisableTiming));
-        hipDeviceProp_t prop;
-        KH_HIP(hipGetDeviceProperties(&prop, device_id));
-        C.num_cus = prop.multiProcessorCount;
-        if ((rc = C.timer.init())) return rc;
-        C.device = device_id;
-        C.ready = true;
-    }
+    if ((rc = init_context(C, device_id))) return rc;
     {
         std::lock_guard<std::mutex> g(g_ctx_mu);
         if (g_default_dev < 0) g_default_dev = device_id;
@@ -158,6 +185,9 @@ struct kh_srs {
     DevBuf g2; int g2_c = 0;
     std::vector<uint64_t> h_multiples2;
     std::mutex h_mu;
+    // handle-level locks (callers may be on different contexts, kh_private_context_begin): the basis map, and the one opening a handle runs at a time
+    std::mutex map_mu;
+    std::mutex ipa_mu; std::condition_variable ipa_cv;
     std::map<unsigned, std::vector<std::unique_ptr<LagrangeChunk>>> lagrange;
     ~kh_srs() { if (ipa_ev) (void)hipEventDestroy(ipa_ev); }      // the DevBufs free themselves
 };
@@ -177,6 +207,7 @@ static int resolve_basis(kh_srs_t* srs, int basis, unsigned chunk, MsmBasis& out
         out.pts = srs->g.p; out.inf = nullptr; out.n = srs->n; out.stride = srs->g_stride; out.precomp_c = srs->g_precomp_c;
         return KH_OK;
     }
+    std::lock_guard<std::mutex> ml(srs->map_mu);
     auto it = srs->lagrange.find((unsigned)basis);
     if (it == srs->lagrange.end() || chunk >= it->second.size() || !it->second[chunk]) {
         set_error("Lagrange basis for domain 2^%d chunk %u is not registered on this SRS", basis, chunk);
@@ -270,6 +301,53 @@ int kh_trim(void) {
     ntt_trim(C);
     return KH_OK;
 }
+
+int kh_private_context_begin(void) {
+    int rc = ensure_init(); if (rc) return rc;
+    const int dev = current_device();
+    KH_REQUIRE(dev >= 0 && dev < KH_MAX_DEVICES, "no current device");
+    KH_REQUIRE(!tl_private[dev], "kh_private_context_begin: this thread already has a private context on device %d", dev);
+    Context& S = shared_ctx_of(dev);
+    Context* c = tl_ctx_cache.c[dev];
+    tl_ctx_cache.c[dev] = nullptr;
+    if (!c) {
+        std::lock_guard<std::mutex> lk(g_ctx_mu);
+        if (!g_private_pool[dev].empty()) { c = g_private_pool[dev].back(); g_private_pool[dev].pop_back(); }
+    }
+    if (!c) {
+        c = new (std::nothrow) Context;
+        KH_REQUIRE(c, "out of memory");
+        if ((rc = bind_thread(dev)) || (rc = init_context(*c, dev))) { std::lock_guard<std::mutex> lk(g_ctx_mu); g_private_pool[dev].push_back(c); return rc; }
+    }
+    {   // whatever the caller queued on the shared context's main stream (uploads, index columns) is ordered before this context's work
+        std::lock_guard<std::mutex> lk(S.mu);
+        KH_HIP(hipEventRecord(S.order_ev, S.stream));
+        KH_HIP(hipStreamWaitEvent(c->stream, S.order_ev, 0));
+    }
+    c->mark_async();                                      // ... and this context's side slots wait for its main stream in turn
+    tl_private[dev] = c;
+    return KH_OK;
+}
+int kh_private_context_active(void) {
+    const int dev = current_device();
+    return dev >= 0 && dev < KH_MAX_DEVICES && tl_private[dev] != nullptr;
+}
+int kh_private_context_end(void) {
+    const int dev = current_device();
+    if (dev < 0 || dev >= KH_MAX_DEVICES || !tl_private[dev]) return KH_OK;
+    Context* c = tl_private[dev];
+    hipError_t e = hipSuccess;
+    {
+        std::lock_guard<std::mutex> lk(c->mu);
+        for (int i = 0; i < MSM_SLOTS && e == hipSuccess; i++) e = hipStreamSynchronize(c->slot[i].stream);      // nothing of this stretch is in flight afterwards
+        c->main_dirty = false;
+    }
+    tl_private[dev] = nullptr;
+    if (!tl_ctx_cache.c[dev]) tl_ctx_cache.c[dev] = c;
+    else { std::lock_guard<std::mutex> lk(g_ctx_mu); g_private_pool[dev].push_back(c); }
+    if (e != hipSuccess) { set_error("hipStreamSynchronize failed: %s", hipGetErrorString(e)); return KH_E_DEVICE; }
+    return KH_OK;
+}
 const char* kh_last_error(void) { return g_err.c_str(); }
 
 int kh_srs_create(int curve, const uint64_t* g_xy, size_t n, kh_srs_t** out) {
@@ -349,6 +427,7 @@ int kh_srs_set_lagrange(kh_srs_t* srs, unsigned log2_domain, unsigned chunk, con
     int rc = ensure_init(); if (rc) return rc;
     Context& C = ctx();
     std::lock_guard<std::mutex> lk(C.mu);
+    std::lock_guard<std::mutex> ml(srs->map_mu);
     auto& vec = srs->lagrange[log2_domain];
     if (vec.size() <= chunk) vec.resize(chunk + 1);
     std::unique_ptr<LagrangeChunk> L(new LagrangeChunk);
@@ -377,7 +456,8 @@ int kh_srs_lagrange_chunks(const kh_srs_t* srs, unsigned log2_domain) {
     if (!srs) return 0;
     KH_ON_DEVICE_OF(srs);
     Context& C = ctx();
-    std::lock_guard<std::mutex> lk(C.mu);              // kh_srs_set_lagrange / kh_srs_compute_lagrange mutate the map under it
+    std::lock_guard<std::mutex> lk(C.mu);
+    std::lock_guard<std::mutex> ml(const_cast<kh_srs_t*>(srs)->map_mu);      // kh_srs_set_lagrange / kh_srs_compute_lagrange mutate the map under it
     auto it = srs->lagrange.find(log2_domain);
     return it == srs->lagrange.end() ? 0 : (int)it->second.size();
 }
@@ -388,6 +468,7 @@ int kh_srs_compute_lagrange(kh_srs_t* srs, unsigned log2_domain) {
     int rc = ensure_init(); if (rc) return rc;
     Context& C = ctx();
     std::lock_guard<std::mutex> lk(C.mu);
+    std::lock_guard<std::mutex> ml(srs->map_mu);
     const size_t n = (size_t)1 << log2_domain;
     const unsigned num_chunks = (unsigned)((n + srs->n - 1) / srs->n);            // ipa.rs:1143-1144
     auto& vec = srs->lagrange[log2_domain];
@@ -1249,12 +1330,21 @@ static int ipa_begin_common(kh_srs_t* srs, const uint64_t* a, size_t a_len, cons
     KH_REQUIRE(a_len <= n && a_len > 0, "polynomial of %zu coefficients does not fit the SRS (%zu)", a_len, n);
     KH_REQUIRE(b_len == n, "b must hold padded_length = %zu evaluation-point powers (got %zu)", n, b_len);
     int rc = ensure_init(); if (rc) return rc;
+    // the reference's SRS::open takes &self and is called from several threads on clones of one SRS (GpuSrs is Clone + Sync): a second
+    // opening on the same handle waits for the first to be freed; only the SAME thread beginning twice is a programming error.  The claim is
+    // the HANDLE's (its own lock: the callers may be on different contexts) and is given back by kh_ipa_free -- or here, if beginning fails.
+    {
+        std::unique_lock<std::mutex> hl(srs->ipa_mu);
+        KH_REQUIRE(!(srs->ipa_live && srs->ipa_owner == std::this_thread::get_id()), "another opening is in progress on this SRS in this thread (kh_ipa_free it first)");
+        srs->ipa_cv.wait(hl, [&] { return !srs->ipa_live; });
+        srs->ipa_live = true; srs->ipa_owner = std::this_thread::get_id();
+    }
+    struct Claim {
+        kh_srs_t* s; bool keep = false;
+        ~Claim() { if (!keep) { { std::lock_guard<std::mutex> hl(s->ipa_mu); s->ipa_live = false; } s->ipa_cv.notify_all(); } }
+    } claim{srs};
     Context& C = ctx();
     std::unique_lock<std::mutex> lk(C.mu);
-    // the reference's SRS::open takes &self and is called from several threads on clones of one SRS (GpuSrs is Clone + Sync): a second
-    // opening on the same handle waits for the first to be freed; only the SAME thread beginning twice is a programming error
-    KH_REQUIRE(!(srs->ipa_live && srs->ipa_owner == std::this_thread::get_id()), "another opening is in progress on this SRS in this thread (kh_ipa_free it first)");
-    C.cv.wait(lk, [&] { return !srs->ipa_live; });
     // A graph of the round MSM is captured and replayed WITHIN one opening only (nothing allocates or frees device memory
     // between the rounds of an opening); replaying it after the caller has freed and allocated buffers in between faulted
     // on ROCm 7.2 when another HIP user (PyTorch) shared the process.  Re-capturing costs one extra un-graphed round.
@@ -1326,7 +1416,7 @@ static int ipa_begin_common(kh_srs_t* srs, const uint64_t* a, size_t a_len, cons
         auto us = [](std::chrono::steady_clock::time_point x, std::chrono::steady_clock::time_point y) { return std::chrono::duration<double, std::micro>(y - x).count(); };
         fprintf(stderr, "kh_ipa_begin: graph reset %.0f us, workspace %.0f, U multiples %.0f, uploads + copies %.0f\n", us(b0_, b1_), us(b1_, b2_), us(b2_, b3_), us(b3_, std::chrono::steady_clock::now()));
     }
-    srs->ipa_live = true; srs->ipa_owner = std::this_thread::get_id();
+    claim.keep = true;
     st->retired = std::move(retired);
     *out = st.release();
     return KH_OK;
@@ -1421,7 +1511,9 @@ static int ipa_finish_impl(kh_ipa_t* st, uint64_t a0[4], uint64_t b0[4], uint64_
     int rc;
     if (st->pending) {                                     // the last round's fold (vectors of length 2 -> 1, the full challenge tensor)
         const int p0 = st->pp, q0 = p0 ^ 1;
-        if ((rc = ipa_round_fold(S.stream, st->field, st->a[p0].as<uint64_t>(), st->b[p0].as<uint64_t>(), st->coef[p0].as<uint64_t>(), 2 * st->cur, st->ncoef / 2,
+        // With the halves of sg in flight (sg_xy == nullptr) the full tensor is not needed -- and must not be written: it would land in the
+        // buffer k_sg_split reads on the side slot's stream, which nothing orders before this fold when the GPU is busy with other provers.
+        if ((rc = ipa_round_fold(S.stream, st->field, st->a[p0].as<uint64_t>(), st->b[p0].as<uint64_t>(), st->coef[p0].as<uint64_t>(), 2 * st->cur, sg_xy ? st->ncoef / 2 : 0,
                                  st->u_p, st->ui_p, st->a[q0].as<uint64_t>(), st->b[q0].as<uint64_t>(), st->coef[q0].as<uint64_t>()))) return rc;
         st->pp = q0; st->pending = false;
     }
@@ -1510,9 +1602,13 @@ void kh_ipa_free(kh_ipa_t* st) {
     }
     std::lock_guard<std::mutex> lk(C.mu);
     (void)hipStreamSynchronize(C.stream);                 // a fold may still be in flight on the library stream
-    if (st->srs) st->srs->ipa_live = false;
+    kh_srs_t* const srs = st->srs;
     delete st;
-    C.cv.notify_all();                                    // an opening another thread wants to begin on this handle can start
+    if (srs) {                                            // an opening another thread wants to begin on this handle can start
+        { std::lock_guard<std::mutex> hl(srs->ipa_mu); srs->ipa_live = false; }
+        srs->ipa_cv.notify_all();
+    }
+    C.cv.notify_all();
 }
 
 // The whole tail of SRS::open (ipa.rs:898-1060) in one call, so that a device-resident prover has no per-round host

@@ -69,12 +69,12 @@ class HostHelper {
     void run(std::function<void()> j) { { std::lock_guard<std::mutex> lk(m_); job_ = std::move(j); has_job_ = true; } cv_.notify_all(); }
     void wait() { std::unique_lock<std::mutex> lk(m_); done_cv_.wait(lk, [&] { return !has_job_ && !busy_; }); }
 };
-static HostHelper& host_helper(int device) {           // one per device context (msm_finish runs under that context's lock)
-    static std::unique_ptr<HostHelper> h[KH_MAX_DEVICES]; static std::mutex mu;
+static HostHelper& host_helper(Context* c) {            // one per context (msm_finish runs under that context's lock; a helper takes one job at a time)
+    static std::map<Context*, std::unique_ptr<HostHelper>> h; static std::mutex mu;
     std::lock_guard<std::mutex> lk(mu);
-    const int d = device >= 0 && device < KH_MAX_DEVICES ? device : 0;
-    if (!h[d]) h[d].reset(new HostHelper);
-    return *h[d];
+    auto& p = h[c];
+    if (!p) p.reset(new HostHelper);
+    return *p;
 }
 
 // ------------------------------------------------------------------------------------ scan
@@ -1584,7 +1584,7 @@ int msm_finish(Context& C, MsmSlot& S, uint64_t* out_xy, uint8_t* out_inf) {
     };
     if ((!S.precomp && S.k >= 2) || (S.planes && S.k >= 16)) {      // split the Horner folds with the helper thread (a hand-over costs ~10 us: not for a few doublings)
         const size_t half = S.k / 2, kk = S.k;
-        HostHelper& hh = host_helper(C.device);
+        HostHelper& hh = host_helper(&C);
         hh.run([finish_one, half, kk] { for (size_t j = half; j < kk; j++) finish_one(j); });
         for (size_t j = 0; j < half; j++) finish_one(j);
         hh.wait();

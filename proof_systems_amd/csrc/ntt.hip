@@ -356,6 +356,9 @@ static int get_twiddles(Context& C, int field, unsigned logn, int inverse, TwEnt
     u64 count = logn ? ((u64)1 << (logn - 1)) : 1;
     int rc = E.tab.reserve(count * 32 + 32 * 32); if (rc) { g_tw.erase(key); return rc; }
     if ((rc = ntt_build_twiddles(C, field, logn, inverse, E.tab.as<u64>()))) { g_tw.erase(key); return rc; }
+    // the tables are per DEVICE, the streams per context: another context (kh_private_context_begin) may pick the entry up at once, so it is published
+    // complete (once per (field, size, direction): ~20 us)
+    if (hipStreamSynchronize(C.stream) != hipSuccess) { g_tw.erase(key); set_error("hipStreamSynchronize failed while building a twiddle table"); return KH_E_DEVICE; }
     khost::fe nn = {{(u64)1 << logn, 0, 0, 0}};
     E.inv_n = F.inv(F.to_mont(nn));
     *out = &E;
@@ -382,6 +385,7 @@ static int launch_pass(Context& C, const PassArgs& A, u64 tiles) {
 
 static int get_scaled_table(Context& C, int field, unsigned log_ntot, TwEntry* E, const u64** out) {
     u64 count = log_ntot ? ((u64)1 << (log_ntot - 1)) : 1;
+    std::lock_guard<std::mutex> lk(g_tw_mu);            // (callers of different contexts share the entry)
     if (!E->tab_scaled.p) {
         int rc = E->tab_scaled.reserve(count * 32 + 32); if (rc) return rc;
         u32* c8 = (u32*)(E->tab_scaled.as<u64>() + count * 4);
@@ -390,6 +394,7 @@ static int get_scaled_table(Context& C, int field, unsigned log_ntot, TwEntry* E
         if (field == KH_FIELD_FP) hipLaunchKernelGGL((k_scale_table<FpParams>), grid, dim3(256), 0, C.stream, E->tab_scaled.as<u64>(), E->tab.as<u64>(), c8, count);
         else hipLaunchKernelGGL((k_scale_table<FqParams>), grid, dim3(256), 0, C.stream, E->tab_scaled.as<u64>(), E->tab.as<u64>(), c8, count);
         KH_HIP(hipGetLastError());
+        KH_HIP(hipStreamSynchronize(C.stream));         // published complete, as the table itself
     }
     *out = E->tab_scaled.as<u64>();
     return KH_OK;

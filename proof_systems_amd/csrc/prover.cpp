@@ -308,6 +308,12 @@ int kh_prove_full(kh_prover_index_t* ix, const uint64_t* witness, size_t rows, c
     const fe one = F.f.one, zero = {{0, 0, 0, 0}};
     struct DeviceRestore { int prev; ~DeviceRestore() { if (prev >= 0) (void)kh_set_device(prev); } } device_restore{kh_get_device()};
     KP(kh_set_device(kh_srs_device(srs)));           // the index lives on the SRS's device: this thread works there until the proof is made
+    // a context of this thread's own for the proof (own main stream, pipeline slots, lock): provers on several threads do not queue behind each other
+    struct PrivateContext {
+        bool mine = false;
+        ~PrivateContext() { if (mine) (void)kh_private_context_end(); }
+    } private_context;
+    if (!(flags & KH_PROVE_SHARED_CONTEXT) && !kh_private_context_active()) { KP(kh_private_context_begin()); private_context.mine = true; }
     // ---- the randomness of the whole proof, in the reference's draw order
     const size_t need = kh_prove_randomness_count(ix, witness != nullptr);
     std::vector<fe> rnd(need + 64, fe{{0, 0, 0, 0}});   // (slack: a miscounted draw reads zeros, and the count check at the end reports it)

@@ -37,7 +37,7 @@ SYMBOLS = [
     "kh_dev_alloc", "kh_dev_free", "kh_dev_upload", "kh_dev_download", "kh_dev_upload_2d",
     "kh_msm_batch_dev", "kh_ntt_dev", "kh_lde_dev", "kh_coset_ntt_dev", "kh_sync", "kh_last_timings",
     "kh_debug_field_op", "kh_debug_point_op", "kh_srs_generate", "kh_srs_h",
-    "kh_msm_sharded", "kh_msm_sharded_dev", "kh_gate_count", "kh_gate_name", "kh_gate_num_constants", "kh_gate_evaluations_dev", "kh_gate_constants", "kh_srs_curve", "kh_lookup_sorted", "kh_comm_unique_id", "kh_comm_init", "kh_comm_free", "kh_comm_world_size", "kh_comm_rank", "kh_comm_allgather_points",
+    "kh_msm_sharded", "kh_msm_sharded_dev", "kh_gate_count", "kh_gate_name", "kh_gate_num_constants", "kh_gate_evaluations_dev", "kh_gate_constants", "kh_srs_curve", "kh_lookup_sorted", "kh_private_context_begin", "kh_private_context_end", "kh_private_context_active", "kh_comm_unique_id", "kh_comm_init", "kh_comm_free", "kh_comm_world_size", "kh_comm_rank", "kh_comm_allgather_points",
     "kh_msm_allreduce",
     "kh_prover_index_new", "kh_prover_index_attach_lookup", "kh_prover_index_free", "kh_prove_randomness_count", "kh_prove", "kh_prove_recursive", "kh_prove_full", "kh_prover_index_attach_runtime_tables", "kh_proof_section", "kh_proof_phase_seconds", "kh_proof_free",
     "kh_commit_non_hiding", "kh_commit_evaluations_non_hiding", "kh_srs_set_blinding_base",
@@ -647,7 +647,7 @@ class Comm:
             _lib.kh_comm_free(self._h); self._h = C.c_void_p()
 
 
-PROVE_CHECK, PROVE_ALL_GATES = 1, 2
+PROVE_CHECK, PROVE_ALL_GATES, PROVE_SHARED_CONTEXT = 1, 2, 4
 PROOF_SECTIONS = {"w_comm": 0, "z_comm": 1, "t_comm": 2, "public_comm": 3, "evals": 4, "public_evals": 5, "ft_eval1": 6, "lr": 7, "delta": 8, "z1_z2": 9, "sg": 10,
                   "challenges": 11, "lookup_sorted_comm": 12, "lookup_aggreg_comm": 13, "lookup_runtime_comm": 14}
 LOOKUP_PATTERN_IDS = {"Xor": 0, "Lookup": 1, "RangeCheck": 2, "ForeignFieldMul": 3}

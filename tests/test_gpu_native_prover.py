@@ -184,6 +184,40 @@ def test_native_provers_on_several_threads(khip):
         ix.free()
 
 
+def test_every_seeded_proof_under_four_saturating_provers_is_the_one_made_alone(khip):
+    """Four threads, each on its own index and its own private context (kh_prove's default), 2^14 gates so that the GPU is saturated and
+    kernels of different provers queue behind each other: EVERY proof is compared with the seeded proof made alone (a stale or early read
+    anywhere in the pipeline -- the halves of sg against the last fold was one -- shows up as a differing component).  Then the same with
+    KH_PROVE_SHARED_CONTEXT (all four on the library's one context)."""
+    import threading
+    from proof_systems_amd import prover
+    T, reps, logn = 4, 60, 14
+    ixs = [prover.bench_circuit_index(khip.VESTA, logn) for _ in range(T)]
+    F = ixs[0].F
+    wit = np.tile(F.limbs(1), (15, (1 << logn) - 10, 1))
+    ref = [V.device_views(ixs[t], prover.create_proof_native(ixs[t], wit, np.random.default_rng(100 + t)))[2] for t in range(T)]
+    for shared in (False, True):
+        bad, errs = [], []
+
+        def work(t):
+            try:
+                for i in range(reps if not shared else reps // 3):
+                    pr = V.device_views(ixs[t], prover.create_proof_native(ixs[t], wit, np.random.default_rng(100 + t), check=False, shared_context=shared))[2]
+                    if pr != ref[t]:
+                        bad.append((t, i, [k for k in pr if pr[k] != ref[t][k]]))
+            except BaseException as e:                              # noqa: BLE001
+                errs.append(e)
+        th = [threading.Thread(target=work, args=(t,)) for t in range(T)]
+        for x in th:
+            x.start()
+        for x in th:
+            x.join(timeout=600)
+        assert not errs, errs
+        assert not bad, (shared, bad[:5])
+    for ix in ixs:
+        ix.free()
+
+
 def test_a_c_program_proves_and_the_oracle_verifier_accepts(khip, tmp_path):
     """tests/cpp/test_prove.cpp: index columns, proof and randomness through the C ABI alone (no Python in the process); the proof it writes
     verifies against the verifier index of the same circuit built here -- the recipe a Rust shim follows (rust/kimchi-hip/src/prover.rs)."""

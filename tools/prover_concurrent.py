@@ -25,6 +25,8 @@ for T in counts:
     def work(t):
         rng = np.random.default_rng(100 + t)
         try:
+            if NATIVE:                                  # this thread's own library context: warm it (workspaces, graphs) outside the timed region
+                nxs[t].prove(witness=wit, randomness=None, flags=0)
             bar.wait()
             for _ in range(PROOFS):
                 if NATIVE:

@@ -24,6 +24,7 @@ print(f"{n1} seeded proofs identical ({1e3 * (time.perf_counter() - t0) / n1:.2f
 errs, kept = [], []
 def work(t):
     try:
+        prover.create_proof_native(ixs[t], wit, None)
         for i in range(n2):
             p = prover.create_proof_native(ixs[t], wit, None, check=(i % 10 == 0))
             if i % 25 == 0:
