@@ -63,7 +63,7 @@ int kh_set_device(int device_id);     /* thread-local: this thread's current dev
 int kh_get_device(void);              /* the calling thread's current device (-1 before any initialisation) */
 /* Several prover threads in one process: between _begin and _end the calling thread works on a library context of its own on its current device -- own
  * main stream, MSM pipeline slots, workspaces and lock -- instead of the device's shared one, so that independent provers neither queue their vector steps
- * on one stream nor serialise their launches on one mutex (measured: four provers 128 -> ~175 proofs/s, what four processes reach).  Everything the thread
+ * on one stream nor serialise their launches on one mutex (measured: four provers 150 -> 165-176 proofs/s; four processes: 177).  Everything the thread
  * queues in between is complete when _end returns; tickets of kh_msm_submit must be waited for before _end; work the thread queued on the shared context
  * before _begin is ordered in front.  SRS handles, device buffers and indexes are process-wide as before (a handle still runs one opening at a time).
  * kh_prove* do this themselves.  Contexts are pooled per device and reused. */
