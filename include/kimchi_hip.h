@@ -149,6 +149,11 @@ int kh_msm_points_batch(int curve, const uint64_t *xy, const uint8_t *inf, const
 /* Sum of n affine points on the host (a handful of group additions): the fold of the per-GPU partial
  * sums of a point-range-sharded MSM after the all-gather, or `(r1 + r2).into_affine()` of ipa.rs:661. */
 int kh_points_sum(int curve, const uint64_t *xy, const uint8_t *inf, size_t n, uint64_t out_xy[8], uint8_t *out_is_inf);
+/* out_j = a_j + b_j for n pairs of affine points on the host (one field inversion in all; NULL flags = no point at infinity).  With
+ * kh_mask_custom over commitments at infinity -- the blinding points [r_j] H, which do not depend on the commitment -- this is SRS::mask_custom
+ * (ipa.rs:605-622) in two halves: the scalar multiplications run while the device computes the commitment, only n additions follow its result. */
+int kh_points_add(int curve, const uint64_t *a_xy, const uint8_t *a_inf, const uint64_t *b_xy, const uint8_t *b_inf, size_t n,
+                  uint64_t *out_xy /* n x 8 */, uint8_t *out_is_inf /* n */);
 
 /* One MSM over a basis sharded by POINT RANGE over R handles (BASELINE config 4): shard r holds g[o_r, o_r + n_r), o_r =
  * n_0 + ... + n_(r-1), n_r = kh_srs_size(shards[r]), on whatever device it was created on (kh_srs_create_device_range after

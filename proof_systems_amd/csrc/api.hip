@@ -917,6 +917,24 @@ int kh_srs_get_blinding_base(const kh_srs_t* srs, uint64_t h_xy[8]) {
     memcpy(h_xy, srs->h, 64);
     return KH_OK;
 }
+// XYZZ -> affine for a list of points with ONE field inversion (Montgomery's trick over the ZZZ's)
+static void xyzz_to_affine_batch(const khost::Crv& crv, const std::vector<khost::xyzz>& acc, uint64_t* out_xy, uint8_t* out_inf) {
+    const khost::Fld& F = crv.F;
+    const size_t k = acc.size();
+    std::vector<khost::fe> pre(k + 1);
+    pre[0] = F.f.one;
+    for (size_t j = 0; j < k; j++) pre[j + 1] = crv.is_identity(acc[j]) ? pre[j] : F.mul(pre[j], acc[j].zzz);
+    khost::fe inv = F.inv(pre[k]);
+    for (size_t j = k; j-- > 0;) {
+        if (crv.is_identity(acc[j])) { memset(out_xy + 8 * j, 0, 64); out_inf[j] = 1; continue; }
+        const khost::fe izzz = F.mul(inv, pre[j]);
+        inv = F.mul(inv, acc[j].zzz);
+        const khost::fe izz = F.sqr(F.mul(izzz, acc[j].zz));
+        const khost::fe x = F.mul(acc[j].x, izz), y = F.mul(acc[j].y, izzz);
+        memcpy(out_xy + 8 * j, &x, 32); memcpy(out_xy + 8 * j + 4, &y, 32);
+        out_inf[j] = 0;
+    }
+}
 int kh_mask_custom(kh_srs_t* srs, const uint64_t* com_xy, const uint8_t* com_inf, size_t com_len,
                    const uint64_t* blinders, size_t blinders_len, uint64_t* out_xy, uint8_t* out_inf) {
     KH_REQUIRE(srs && com_xy && blinders && out_xy && out_inf, "kh_mask_custom: null argument");
@@ -950,21 +968,7 @@ int kh_mask_custom(kh_srs_t* srs, const uint64_t* com_xy, const uint8_t* com_inf
         if (!(com_inf && com_inf[j])) { khost::aff c; memcpy(&c, com_xy + 8 * j, 64); s = crv.add(s, crv.from_affine(c)); }
         acc[j] = s;
     }
-    // XYZZ -> affine for all chunks with ONE field inversion (Montgomery's trick over the ZZZ's)
-    const khost::Fld& F = crv.F;
-    std::vector<khost::fe> pre(com_len + 1);
-    pre[0] = F.f.one;
-    for (size_t j = 0; j < com_len; j++) pre[j + 1] = crv.is_identity(acc[j]) ? pre[j] : F.mul(pre[j], acc[j].zzz);
-    khost::fe inv = F.inv(pre[com_len]);
-    for (size_t j = com_len; j-- > 0;) {
-        if (crv.is_identity(acc[j])) { memset(out_xy + 8 * j, 0, 64); out_inf[j] = 1; continue; }
-        const khost::fe izzz = F.mul(inv, pre[j]);
-        inv = F.mul(inv, acc[j].zzz);
-        const khost::fe izz = F.sqr(F.mul(izzz, acc[j].zz));
-        const khost::fe x = F.mul(acc[j].x, izz), y = F.mul(acc[j].y, izzz);
-        memcpy(out_xy + 8 * j, &x, 32); memcpy(out_xy + 8 * j + 4, &y, 32);
-        out_inf[j] = 0;
-    }
+    xyzz_to_affine_batch(crv, acc, out_xy, out_inf);
     return KH_OK;
 }
 
@@ -981,6 +985,23 @@ int kh_points_sum(int curve, const uint64_t* xy, const uint8_t* inf, size_t n, u
     }
     khost::aff r; bool isinf = crv.to_affine(acc, r);
     memcpy(out_xy, &r, 64); *out_is_inf = isinf ? 1 : 0;
+    return KH_OK;
+}
+
+// out_j = a_j + b_j for n pairs of affine points on the host, one field inversion in all: the second half of a masking whose blinding points
+// [r_j] H (kh_mask_custom over commitments at infinity) were computed while the device was still busy with the commitment itself
+int kh_points_add(int curve, const uint64_t* a_xy, const uint8_t* a_inf, const uint64_t* b_xy, const uint8_t* b_inf, size_t n, uint64_t* out_xy, uint8_t* out_inf) {
+    KH_REQUIRE(curve == KH_CURVE_VESTA || curve == KH_CURVE_PALLAS, "unknown curve id %d", curve);
+    KH_REQUIRE(n == 0 || (a_xy && b_xy && out_xy && out_inf), "kh_points_add: null argument");
+    khost::Crv crv(curve);
+    std::vector<khost::xyzz> acc(n);
+    for (size_t j = 0; j < n; j++) {
+        khost::xyzz s = crv.identity();
+        if (!(a_inf && a_inf[j])) { khost::aff p; memcpy(&p, a_xy + 8 * j, 64); s = crv.from_affine(p); }
+        if (!(b_inf && b_inf[j])) { khost::aff p; memcpy(&p, b_xy + 8 * j, 64); s = crv.add(s, crv.from_affine(p)); }
+        acc[j] = s;
+    }
+    xyzz_to_affine_batch(crv, acc, out_xy, out_inf);
     return KH_OK;
 }
 

@@ -356,6 +356,19 @@ int kh_prove_full(kh_prover_index_t* ix, const uint64_t* witness, size_t rows, c
         oxy.resize(8 * k); oinf.resize(k);
         return kh_mask_custom(srs, xy.data(), inf.data(), k, (const uint64_t*)blinders, k, oxy.data(), oinf.data());
     };
+    // SRS::mask_custom in two halves around a commitment still running on the device: the blinding points [r_j] H first (host, ~5 us each), ...
+    auto blinding_points = [&](const fe* blinders, size_t k, std::vector<uint64_t>& bxy, std::vector<uint8_t>& binf) -> int {
+        std::vector<uint64_t> none(8 * k, 0); std::vector<uint8_t> at_inf(k, 1);
+        bxy.resize(8 * k); binf.resize(k);
+        return kh_mask_custom(srs, none.data(), at_inf.data(), k, (const uint64_t*)blinders, k, bxy.data(), binf.data());
+    };
+    // ... then one addition per commitment once its result is there
+    auto mask_with = [&](const std::vector<uint64_t>& xy, const std::vector<uint8_t>& inf, const std::vector<uint64_t>& bxy, const std::vector<uint8_t>& binf,
+                         std::vector<uint64_t>& oxy, std::vector<uint8_t>& oinf) -> int {
+        const size_t k = inf.size();
+        oxy.resize(8 * k); oinf.resize(k);
+        return kh_points_add(curve, xy.data(), inf.data(), bxy.data(), binf.data(), k, oxy.data(), oinf.data());
+    };
     auto scalar_challenge = [&](kh_sponge_t* sp, fe& o) -> int {
         uint64_t ch[2];
         int rc = kh_sponge_challenge(sp, ch); if (rc) return rc;
@@ -363,14 +376,21 @@ int kh_prove_full(kh_prover_index_t* ix, const uint64_t* witness, size_t rows, c
     };
     // ---- witness on the device: [w 0..14 | z] in evaluation form
     Dev ev; KP(ev.alloc(16 * NB));
+    struct Tickets {                                  // un-waited MSM tickets: an error on the way out must not leave their pipeline slots taken
+        uint64_t t[4] = {0, 0, 0, 0}; bool live[4] = {false, false, false, false};
+        ~Tickets() { for (int i = 0; i < 4; i++) if (live[i]) { uint64_t xy[8 * COLUMNS]; uint8_t inf[COLUMNS]; (void)kh_msm_wait(t[i], xy, inf); } }
+        int wait(int i, uint64_t* xy, uint8_t* inf) { live[i] = false; return kh_msm_wait(t[i], xy, inf); }
+    } tickets;
     if (witness) {
         KP_REQUIRE(rows + zk <= n, "NoRoomForZkInWitness: %zu rows + %zu zero-knowledge rows > %zu", rows, zk, n);
         if (rows + zk < n) KP(kh_dev_memset_zero(ev.p, 16 * NB * 32));
         const fe* z = draw(COLUMNS * zk);            // per column, from the LAST row backwards (prover.rs:254-266)
         std::vector<fe> zkr(COLUMNS * zk);
         for (size_t c = 0; c < COLUMNS; c++) for (size_t j = 0; j < zk; j++) zkr[c * zk + j] = z[c * zk + (zk - 1 - j)];
-        if (rows) KP(kh_dev_upload_2d(ev.p, NB * 32, witness, rows * 32, rows * 32, COLUMNS));
         KP(kh_dev_upload_2d(ev.at(n - zk), NB * 32, zkr.data(), zk * 32, zk * 32, COLUMNS));
+        // (uploading in column groups with each group's commitment submitted behind it was measured: three submits cost the host 0.2 ms each,
+        // which delays the next transfer more than the overlap gives back -- 10.86 against 10.48 ms per proof)
+        if (rows) KP(kh_dev_upload_2d(ev.p, NB * 32, witness, rows * 32, rows * 32, COLUMNS));
     } else KP(kh_dev_copy(ev.p, witness_dev, COLUMNS * NB * 32));
     mark();
     SpongeH fq; KP(kh_sponge_new(KH_SPONGE_FQ, curve, &fq.s));
@@ -396,7 +416,7 @@ int kh_prove_full(kh_prover_index_t* ix, const uint64_t* witness, size_t rows, c
     KP(kh_sponge_absorb_g(fq.s, pub_xy.data(), pub_inf.data(), nch));
     pr->set_points(KH_PROOF_PUBLIC_COMM, pub_xy.data(), pub_inf.data(), nch);
     // ---- witness commitments: one batched MSM per chunk of the Lagrange basis, queued before the columns are interpolated
-    uint64_t tk = 0; bool have_tk = false;
+    uint64_t& tk = tickets.t[3]; bool& have_tk = tickets.live[3];
     if (nch == 1) { KP(kh_msm_submit(srs, (int)logn, 0, 0, ev.p, n, COLUMNS, 1, &tk)); have_tk = true; }
     Dev cf; KP(cf.alloc(16 * NB));                    // coefficient forms [w | z]
     KP(kh_dev_copy(cf.p, ev.p, COLUMNS * NB * 32));
@@ -405,12 +425,13 @@ int kh_prove_full(kh_prover_index_t* ix, const uint64_t* witness, size_t rows, c
     bool any_lib = (ix->live != 0) || nopt > 0;
     const size_t w8 = (!any_lib && !all_gates) ? PERMUTS : COLUMNS;     // generic + permutation read w0..w6 only
     KP(kh_lde_dev(fid, cf.p, logn, 3, e8.p, w8));
-    std::vector<uint64_t> wxy; std::vector<uint8_t> winf;
-    if (have_tk) { wxy.resize(8 * COLUMNS); winf.resize(COLUMNS); KP(kh_msm_wait(tk, wxy.data(), winf.data())); }
-    else KP(commit_evals(ev.p, COLUMNS, wxy, winf));
+    std::vector<uint64_t> wxy, wbx; std::vector<uint8_t> winf, wbi;
     const fe* w_blind = draw(COLUMNS * nch);          // blinder(num_chunks) per column, column by column (prover.rs:316-327)
+    KP(blinding_points(w_blind, COLUMNS * nch, wbx, wbi));              // (underneath the MSM)
+    if (have_tk) { wxy.resize(8 * COLUMNS); winf.resize(COLUMNS); KP(tickets.wait(3, wxy.data(), winf.data())); }
+    else KP(commit_evals(ev.p, COLUMNS, wxy, winf));
     std::vector<uint64_t> wcx; std::vector<uint8_t> wci;
-    KP(mask(wxy, winf, w_blind, wcx, wci));
+    KP(mask_with(wxy, winf, wbx, wbi, wcx, wci));
     KP(kh_sponge_absorb_g(fq.s, wcx.data(), wci.data(), COLUMNS * nch));
     pr->set_points(KH_PROOF_W_COMM, wcx.data(), wci.data(), COLUMNS * nch);
     // ---- lookup argument, part 1 (prover.rs:383-633): joint combiner, combined table, sorted columns
@@ -580,17 +601,17 @@ int kh_prove_full(kh_prover_index_t* ix, const uint64_t* witness, size_t rows, c
     uint64_t* zc = cf.at(COLUMNS * NB);
     KP(kh_dev_copy(zc, zcol, NB * 32));
     KP(kh_ntt_dev(fid, zc, logn, 1, 1));
-    have_tk = false;
     if (nch == 1 && size == n) { KP(kh_msm_submit(srs, KH_BASIS_G, 0, 0, zc, n, 1, 1, &tk)); have_tk = true; }   // ... while z is extended to d8
     KP(kh_lde_dev(fid, zc, logn, 3, e8.at(COLUMNS * N8), 1));
-    std::vector<uint64_t> zxy; std::vector<uint8_t> zinf;
-    if (have_tk) { zxy.resize(8); zinf.resize(1); KP(kh_msm_wait(tk, zxy.data(), zinf.data())); }
+    std::vector<uint64_t> zxy, zbx; std::vector<uint8_t> zinf, zbi;
+    const fe* z_blind = draw(nch);
+    KP(blinding_points(z_blind, nch, zbx, zbi));
+    if (have_tk) { zxy.resize(8); zinf.resize(1); KP(tickets.wait(3, zxy.data(), zinf.data())); }
     else KP(commit_coeffs(zc, n, nch, zxy, zinf));
     const size_t nzb = zinf.size();
-    const fe* z_blind = draw(nzb);
     KP_REQUIRE(nzb == nch, "unexpected chunk count of z");
     std::vector<uint64_t> zcx; std::vector<uint8_t> zci;
-    KP(mask(zxy, zinf, z_blind, zcx, zci));
+    KP(mask_with(zxy, zinf, zbx, zbi, zcx, zci));
     KP(kh_sponge_absorb_g(fq.s, zcx.data(), zci.data(), nzb));
     pr->set_points(KH_PROOF_Z_COMM, zcx.data(), zci.data(), nzb);
     mark();
@@ -703,13 +724,16 @@ int kh_prove_full(kh_prover_index_t* ix, const uint64_t* witness, size_t rows, c
         fe sc[3] = {one, alphas[1], alphas[2]};
         KP(kh_poly_lincomb_dev(fid, qs, ql, (const uint64_t*)sc, 3, quot.p, 7 * n));
     }
-    std::vector<uint64_t> txy; std::vector<uint8_t> tinf;
-    KP(commit_coeffs(quot.p, 7 * n, 7 * nch, txy, tinf));
-    const size_t ntb = tinf.size();
-    KP_REQUIRE(ntb == 7 * nch, "unexpected chunk count of t");
+    std::vector<uint64_t> txy, tbx; std::vector<uint8_t> tinf, tbi;
+    if (nch == 1 && size == n) { KP(kh_msm_submit(srs, KH_BASIS_G, 0, 0, quot.p, n, 7, 1, &tk)); have_tk = true; }   // the seven chunks as one batch
+    const size_t ntb = 7 * nch;
     const fe* t_blind = draw(ntb);
+    KP(blinding_points(t_blind, ntb, tbx, tbi));
+    if (have_tk) { txy.resize(8 * 7); tinf.resize(7); KP(tickets.wait(3, txy.data(), tinf.data())); }
+    else KP(commit_coeffs(quot.p, 7 * n, 7 * nch, txy, tinf));
+    KP_REQUIRE(tinf.size() == ntb, "unexpected chunk count of t");
     std::vector<uint64_t> tcx; std::vector<uint8_t> tci;
-    KP(mask(txy, tinf, t_blind, tcx, tci));
+    KP(mask_with(txy, tinf, tbx, tbi, tcx, tci));
     KP(kh_sponge_absorb_g(fq.s, tcx.data(), tci.data(), ntb));
     pr->set_points(KH_PROOF_T_COMM, tcx.data(), tci.data(), ntb);
     mark();

@@ -44,7 +44,7 @@ SYMBOLS = [
     "kh_srs_get_blinding_base", "kh_mask_custom", "kh_domain_generator", "kh_msm_points_batch", "kh_msm_submit", "kh_msm_wait",
     "kh_ipa_fold_scalars", "kh_inner_product", "kh_ipa_fold_points", "kh_ipa_fold_points_endo", "kh_endos", "kh_scalar_challenge_to_field",
     "kh_polycomm_multi_scalar_mul", "kh_expr_evaluations_dev", "kh_field_scan_dev", "kh_batch_inversion_dev", "kh_divide_by_linear_dev", "kh_b_poly_coefficients", "kh_batch_dlog_accumulator_generate", "kh_batch_dlog_accumulator_check", "kh_ipa_verify_msm",
-    "kh_ipa_begin", "kh_ipa_begin_dev", "kh_combine_polys_dev", "kh_poly_lincomb_dev", "kh_b_init_dev", "kh_evaluate_chunks_dev", "kh_evaluate_chunks_batch_dev", "kh_divide_by_vanishing_poly_dev", "kh_ipa_rounds_left", "kh_ipa_round_lr", "kh_ipa_round_fold", "kh_ipa_finish", "kh_ipa_free", "kh_points_sum", "kh_srs_create_device", "kh_srs_create_device_range", "kh_srs_get_g",
+    "kh_ipa_begin", "kh_ipa_begin_dev", "kh_combine_polys_dev", "kh_poly_lincomb_dev", "kh_b_init_dev", "kh_evaluate_chunks_dev", "kh_evaluate_chunks_batch_dev", "kh_divide_by_vanishing_poly_dev", "kh_ipa_rounds_left", "kh_ipa_round_lr", "kh_ipa_round_fold", "kh_ipa_finish", "kh_ipa_free", "kh_points_sum", "kh_points_add", "kh_srs_create_device", "kh_srs_create_device_range", "kh_srs_get_g",
 ]
 
 _lib.kh_last_error.restype = C.c_char_p
@@ -111,6 +111,7 @@ _lib.kh_srs_create_device.argtypes = [C.c_int, C.c_size_t, C.POINTER(C.c_void_p)
 _lib.kh_srs_create_device_range.argtypes = [C.c_int, C.c_size_t, C.c_size_t, C.POINTER(C.c_void_p)]
 _lib.kh_srs_get_g.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, U64P]
 _lib.kh_points_sum.argtypes = [C.c_int, U64P, U8P, C.c_size_t, U64P, U8P]
+_lib.kh_points_add.argtypes = [C.c_int, U64P, U8P, U64P, U8P, C.c_size_t, U64P, U8P]
 _lib.kh_msm_submit.argtypes = [C.c_void_p, C.c_int, C.c_uint, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.POINTER(C.c_uint64)]
 _lib.kh_msm_wait.argtypes = [C.c_uint64, U64P, U8P]
 _lib.kh_msm_points_batch.argtypes = [C.c_int, U64P, U8P, U64P, C.c_size_t, C.c_size_t, C.c_int, U64P, U8P]
@@ -497,6 +498,17 @@ def points_sum(curve: int, xy, inf=None):
     out = np.zeros(8, dtype=np.uint64); oinf = np.zeros(1, dtype=np.uint8)
     _check(_lib.kh_points_sum(curve, _p64(xy), _p8(inf), xy.shape[0], _p64(out), _p8(oinf)))
     return out, bool(oinf[0])
+
+
+def points_add(curve: int, a_xy, a_inf, b_xy, b_inf):
+    """Pairwise host sums a_j + b_j of affine points (the second half of a masking whose blinding points were computed ahead)."""
+    a_xy = _c64(a_xy, (-1, 8)); b_xy = _c64(b_xy, (-1, 8))
+    n = a_xy.shape[0]
+    a_inf = None if a_inf is None else np.ascontiguousarray(a_inf, dtype=np.uint8)
+    b_inf = None if b_inf is None else np.ascontiguousarray(b_inf, dtype=np.uint8)
+    out = np.zeros((n, 8), dtype=np.uint64); oinf = np.zeros(n, dtype=np.uint8)
+    _check(_lib.kh_points_add(curve, _p64(a_xy), _p8(a_inf), _p64(b_xy), _p8(b_inf), n, _p64(out), _p8(oinf)))
+    return out, oinf
 
 
 def ipa_fold_scalars(field: int, lo, hi, u):

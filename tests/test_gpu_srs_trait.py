@@ -563,6 +563,24 @@ def test_points_sum_matches_oracle(khip):
         assert ginf == ainf and np.array_equal(got, acc)
         z, zinf = khip.points_sum(cid, pts[[1, 7]])
         assert zinf
+        # kh_points_add: pairwise, one inversion: generic pairs, an operand at infinity on either side, P + P, P + (-P)
+        a = pts[[0, 1, 2, 3, 1, 1, 4]]; b = pts[[5, 2, 3, 4, 1, 7, 0]]
+        ai = np.array([0, 0, 1, 0, 0, 0, 1], np.uint8); bi = np.array([0, 0, 0, 1, 0, 0, 1], np.uint8)
+        got, gi = khip.points_add(cid, a, ai, b, bi)
+        for j in range(7):
+            if ai[j] and bi[j]:
+                assert gi[j]
+                continue
+            want, winf = (b[j], False) if ai[j] else (a[j], False) if bi[j] else cref.point_add(cid, a[j], b[j], False, False)
+            assert bool(gi[j]) == bool(winf) and (winf or np.array_equal(got[j], want)), j
+        assert gi[5] and not gi[4]
+        # ... and the two-step masking equals kh_mask_custom
+        srs = khip.Srs(cid, g)
+        bl = np.random.default_rng(5).integers(0, 1 << 62, size=(3, 4), dtype=np.uint64)
+        direct = srs.mask_custom(pts[:3], np.zeros(3, np.uint8), bl)
+        bp = srs.mask_custom(np.zeros((3, 8), np.uint64), np.ones(3, np.uint8), bl)
+        two = khip.points_add(cid, pts[:3], None, bp[0], bp[1])
+        assert np.array_equal(direct[0], two[0]) and np.array_equal(np.asarray(direct[1], np.uint8), two[1])
 
 
 @pytest.mark.parametrize("name", ["vesta", "pallas"])

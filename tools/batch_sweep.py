@@ -9,7 +9,7 @@ def rs(k):
     a = rng.integers(0, 1 << 63, size=(k, 4), dtype=np.uint64); a[:, 3] &= np.uint64((1 << 61) - 1); return a
 n = 1 << 16
 srs = khip.Srs.create(0, n)
-for k in (4, 8, 15, 23, 32):
+for k in ([int(x) for x in sys.argv[1:]] or [4, 8, 15, 23, 32]):
     sc = rs(n * k)
     d = khip.DevBuf(sc.nbytes).upload(sc)
     ts = []
