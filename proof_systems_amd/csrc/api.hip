@@ -370,6 +370,9 @@ int kh_srs_create(int curve, const uint64_t* g_xy, size_t n, kh_srs_t** out) {
         if ((rc = msm_precompute(C, curve, s->g.p, nullptr, s->g_stride, MSM_PRECOMP_C))) return rc;
         s->g_precomp_c = MSM_PRECOMP_C;
     }
+    // tables are per HANDLE, streams per context: another context (kh_private_context_begin on another thread) may use the handle at once, so it is
+    // handed out complete (a one-time cost)
+    KH_HIP(hipStreamSynchronize(C.stream));
     if ((rc = kh_srs_h(curve, s->h))) return rc;
     *out = s.release();
     return KH_OK;
@@ -396,6 +399,9 @@ int kh_srs_create_device_range(int curve, size_t start, size_t depth, kh_srs_t**
         if ((rc = msm_precompute(C, curve, s->g.p, nullptr, s->g_stride, MSM_PRECOMP_C))) return rc;
         s->g_precomp_c = MSM_PRECOMP_C;
     }
+    // tables are per HANDLE, streams per context: another context (kh_private_context_begin on another thread) may use the handle at once, so it is
+    // handed out complete (a one-time cost)
+    KH_HIP(hipStreamSynchronize(C.stream));
     if ((rc = kh_srs_h(curve, s->h))) return rc;
     *out = s.release();
     return KH_OK;
@@ -449,6 +455,7 @@ int kh_srs_set_lagrange(kh_srs_t* srs, unsigned log2_domain, unsigned chunk, con
         if ((rc = msm_precompute(C, srs->curve, L->pts.p, L->has_inf ? L->inf.as<uint8_t>() : nullptr, n, MSM_PRECOMP_C))) return rc;
         L->precomp_c = MSM_PRECOMP_C;
     }
+    KH_HIP(hipStreamSynchronize(C.stream));              // published complete (callers of other contexts resolve the basis without this stream)
     vec[chunk] = std::move(L);
     return KH_OK;
 }
@@ -495,6 +502,7 @@ int kh_srs_compute_lagrange(kh_srs_t* srs, unsigned log2_domain) {
             if ((rc = msm_precompute(C, srs->curve, L->pts.p, L->has_inf ? L->inf.as<uint8_t>() : nullptr, n, MSM_PRECOMP_C))) return rc;
             L->precomp_c = MSM_PRECOMP_C;
         }
+        KH_HIP(hipStreamSynchronize(C.stream));          // published complete (callers of other contexts resolve the basis without this stream)
         vec[c] = std::move(L);
     }
     return KH_OK;
@@ -1405,6 +1413,7 @@ static int ipa_begin_common(kh_srs_t* srs, const uint64_t* a, size_t a_len, cons
         if ((rc = srs->g2.reserve(srs->g_stride * 64 * W2))) return rc;
         KH_HIP(hipMemcpyAsync(srs->g2.p, srs->g.p, srs->g_stride * 64, hipMemcpyDeviceToDevice, C.stream));
         if ((rc = msm_precompute(C, srs->curve, srs->g2.p, nullptr, srs->g_stride, ipa_c))) return rc;
+        KH_HIP(hipStreamSynchronize(C.stream));
         srs->g2_c = ipa_c; srs->h_multiples2.clear();
     }
     const int rc_c = second ? srs->g2_c : srs->g_precomp_c;                        // window width of the rounds' tables
