@@ -342,6 +342,7 @@ where
         let (_endo_q, endo_r) = endos::<G>();
         let n = srs.inner.g.len();
         assert!(n.is_power_of_two(), "the device opening needs a power-of-two SRS");
+        let _ctx = PrivateContext::enter(); // the reference opens from rayon workers: each gets its own streams and pipeline slots for the rounds
         let rounds = n.trailing_zeros() as usize;
 
         // ipa.rs:851-888: p = sum_i polyscale^i p_i and the combined blinder; b_init[j] = sum_i evalscale^i elm_i^j
@@ -450,6 +451,31 @@ where
 
 /// combined_inner_product is re-exported for callers that assemble `BatchEvaluationProof`s (verifier.rs:491-520).
 pub use combined_inner_product as combined_inner_product_of_evaluations;
+
+/// Several prover threads in one process: while a `PrivateContext` is alive the calling thread works on a library context of its own (own main
+/// stream, MSM pipeline slots, workspaces, lock) instead of the device's shared one (include/kimchi_hip.h, `kh_private_context_begin`), so independent
+/// provers do not queue their vector steps on one stream.  `GpuProver::create` needs none (`kh_prove` takes one itself); `open` below takes one when
+/// the thread has none yet.  Not `Send`: the context belongs to the thread that began it.
+pub struct PrivateContext {
+    began: bool,
+    _not_send: core::marker::PhantomData<*mut ()>,
+}
+impl PrivateContext {
+    pub fn enter() -> Self {
+        let began = unsafe { sys::kh_private_context_active() } == 0;
+        if began {
+            ok(unsafe { sys::kh_private_context_begin() });
+        }
+        PrivateContext { began, _not_send: core::marker::PhantomData }
+    }
+}
+impl Drop for PrivateContext {
+    fn drop(&mut self) {
+        if self.began {
+            ok(unsafe { sys::kh_private_context_end() });
+        }
+    }
+}
 
 /// One process, several GPUs: bind the calling thread (e.g. a rayon worker) to `device` before creating a `GpuSrs`;
 /// the handle then runs on that device from any thread (include/kimchi_hip.h, "device").
