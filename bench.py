@@ -107,13 +107,14 @@ def ntt_block(khip):
 def prover_cpu_baseline(khip, ix, wit_padded, log_n=16):
     """BASELINE config 3's operation list (15 Lagrange-basis MSMs of the benchmark witness + 1 + 7 monomial MSMs + the 32
     round MSMs of the opening, 19 iNTT(2^16) + 16 LDE(-> 2^19) + iNTT(2^18) + iNTT(2^19)) on THIS box's host cores with the C port
-    (oracle/pasta_ref.c: signed-window Pippenger and radix-2 NTT over std threads) -- `kind: "port"`: the Rust reference cannot be
+    (oracle/pasta_ref.c: signed-window Pippenger with (window, point-slice) jobs from a shared queue, radix-2 NTT parallel over
+    columns or, for fewer columns than threads, over the butterflies of a stage) -- `kind: "port"`: the Rust reference cannot be
     built here.  It is the data-parallel part of ProverProof::create only (no gate evaluation, no transcript), i.e. a LOWER bound on
     what a CPU prover of this family needs on this host.  Never the target; checker-side code, outside every timed region."""
     from oracle import cref
     n = 1 << log_n
     cores = os.cpu_count() or 1
-    thr = min(cores, 64)
+    thr = cores                                                                # the port schedules jobs over every hardware thread (oracle/pasta_ref.c: pick_schedule, ntt_flat_worker)
     rng = np.random.default_rng(5)
     g = ix.srs.get_g()
     lag, linf = ix.srs.get_lagrange(log_n)
@@ -571,7 +572,7 @@ def main():
         if world == 1:
             ok = (winf == result[1]) and (winf or bool(np.array_equal(want, result[0])))
             line["cpu_baseline"] = {"value": n / t_cpu / 1e6, "unit": "Mscalar/s", "cores": cref.last_threads(), "host_cores": cores, "kind": "port",
-                                    "sample": "the same 2^%d-point MSM (oracle/pasta_ref.c signed-window Pippenger, threads = windows x point slices)" % args.log_n,
+                                    "sample": "the same 2^%d-point MSM (oracle/pasta_ref.c signed-window Pippenger; jobs = windows x point slices over all hardware threads, window width chosen for that)" % args.log_n,
                                     "seconds": t_cpu, "gpu_result_matches": bool(ok)}
         else:
             mine = torch.from_numpy(np.concatenate([want, np.array([int(winf)], dtype=np.uint64)]).view(np.int64).copy()).to(coll_dev)

@@ -20,11 +20,24 @@ U64P = C.POINTER(C.c_uint64)
 U8P = C.POINTER(C.c_uint8)
 
 
+def _cpu_has(flag: str) -> bool:
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("flags"):
+                    return flag in line.split()
+    except OSError:
+        pass
+    return False
+
+
 def build(force: bool = False) -> str:
     src = os.path.join(_HERE, "pasta_ref.c")
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
         os.makedirs(os.path.dirname(_SO), exist_ok=True)
-        subprocess.check_call(["gcc", "-O3", "-fPIC", "-shared", "-pthread", "-o", _SO, src])
+        # BMI2 / ADX: the hosts an MI355X sits in have both (the product's host code requires them too); a build machine without them falls back
+        fast = ["-mbmi2", "-madx"] if _cpu_has("bmi2") and _cpu_has("adx") else []
+        subprocess.check_call(["gcc", "-O3"] + fast + ["-fPIC", "-shared", "-pthread", "-o", _SO, src])
     return _SO
 
 

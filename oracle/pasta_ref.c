@@ -94,26 +94,31 @@ static inline void f_neg(const field_t *f, fe *r, const fe *a) {
 }
 static inline void f_dbl(const field_t *f, fe *r, const fe *a) { f_add(f, r, a, a); }
 
-/* CIOS Montgomery multiplication, R = 2^256 */
+/* CIOS Montgomery multiplication, R = 2^256; unrolled.  p < 2^255 and a, b < p keep the running value below 2p, so the fifth word is 0 or 1.
+ * (The variant that folds the two carry words into one chain -- possible because the top bit of p is clear -- measured SLOWER with gcc and clang:
+ * it serialises the product and the reduction of a round.) */
 static inline void f_mul(const field_t *f, fe *r, const fe *a, const fe *b) {
-    u64 t[6] = {0, 0, 0, 0, 0, 0};
-    for (int i = 0; i < 4; i++) {
-        u128 c = 0;
-        for (int j = 0; j < 4; j++) {
-            c += (u128)a->l[j] * b->l[i] + t[j];
-            t[j] = (u64)c; c >>= 64;
-        }
-        c += t[4]; t[4] = (u64)c; t[5] = (u64)(c >> 64);
-        u64 m = t[0] * f->inv;
-        c = (u128)m * f->p.l[0] + t[0]; c >>= 64;
-        for (int j = 1; j < 4; j++) {
-            c += (u128)m * f->p.l[j] + t[j];
-            t[j - 1] = (u64)c; c >>= 64;
-        }
-        c += t[4]; t[3] = (u64)c; t[4] = t[5] + (u64)(c >> 64);
-    }
-    fe out = {{t[0], t[1], t[2], t[3]}};
-    if (t[4] || ge4(&out, &f->p)) sub4(&out, &out, &f->p);
+    const u64 *A = a->l, *B = b->l, *P = f->p.l;
+    const u64 inv = f->inv;
+    u64 t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
+#define KO_MUL_ROUND(i)                                                        \
+    do {                                                                       \
+        u128 c = (u128)A[0] * B[i] + t0; t0 = (u64)c; c >>= 64;                \
+        c += (u128)A[1] * B[i] + t1; t1 = (u64)c; c >>= 64;                    \
+        c += (u128)A[2] * B[i] + t2; t2 = (u64)c; c >>= 64;                    \
+        c += (u128)A[3] * B[i] + t3; t3 = (u64)c; c >>= 64;                    \
+        c += t4; t4 = (u64)c; const u64 t5 = (u64)(c >> 64);                   \
+        const u64 m = t0 * inv;                                                \
+        c = (u128)m * P[0] + t0; c >>= 64;                                     \
+        c += (u128)m * P[1] + t1; t0 = (u64)c; c >>= 64;                       \
+        c += (u128)m * P[2] + t2; t1 = (u64)c; c >>= 64;                       \
+        c += (u128)m * P[3] + t3; t2 = (u64)c; c >>= 64;                       \
+        c += t4; t3 = (u64)c; t4 = t5 + (u64)(c >> 64);                        \
+    } while (0)
+    KO_MUL_ROUND(0); KO_MUL_ROUND(1); KO_MUL_ROUND(2); KO_MUL_ROUND(3);
+#undef KO_MUL_ROUND
+    fe out = {{t0, t1, t2, t3}};
+    if (t4 || ge4(&out, &f->p)) sub4(&out, &out, &f->p);
     *r = out;
 }
 static inline void f_sqr(const field_t *f, fe *r, const fe *a) { f_mul(f, r, a, a); }
@@ -345,35 +350,69 @@ int ko_is_on_curve(int curve, const u64 *xy) {
 }
 
 /* ---------------------------------------------------------------- MSM */
-/* digits are precomputed once (n * nwin int32): signed digits in [-2^(c-1), 2^(c-1)] */
+/* Signed-window Pippenger (what VariableBaseMSM::msm does in ark-ec, commitment.rs:382), scheduled for a many-core host:
+ *   - digits precomputed in parallel (n * nwin int32, signed digits in [-2^(c-1), 2^(c-1)]);
+ *   - job = (window w, point slice s): its own bucket set over points [n*s/slices, n*(s+1)/slices); the window width is chosen so that
+ *     a bucket set stays cache-resident and there are at least as many jobs as threads (the reference parallelises over windows with rayon
+ *     and splits the points in two, ipa.rs:652-662; with 2 x 128 hardware threads that alone would leave most of the machine idle);
+ *   - jobs are handed out from a shared counter (a slice with many zero digits finishes early). */
 typedef struct {
-    const field_t *f; const aff *pts; const uint8_t *inf; const int32_t *digits; size_t n;
-    int c, nwin, job_begin, job_end, slices; jac *win_sums;   /* win_sums[w * slices + s] */
-} msm_job2;
+    const field_t *f, *sf; const aff *pts; const uint8_t *inf; const u64 *scalars; int32_t *digits; size_t n;
+    int c, nwin, slices, njobs, mont, nthreads; jac *win_sums;   /* win_sums[w * slices + s] */
+    volatile int next_job;
+} msm_shared;
+typedef struct { msm_shared *S; int tid; } msm_arg;
 
-/* job = (window w, point slice s): its own bucket set over points [n*s/slices, n*(s+1)/slices) */
-static void *msm_worker2(void *arg) {
-    msm_job2 *J = (msm_job2 *)arg;
-    const field_t *f = J->f;
-    size_t nb = (size_t)1 << (J->c - 1);
+static void msm_digits_range(msm_shared *S, size_t i0, size_t i1) {
+    const int c = S->c, nwin = S->nwin; const size_t nb = (size_t)1 << (c - 1), n = S->n;
+    for (size_t i = i0; i < i1; i++) {
+        fe s; memcpy(&s, S->scalars + 4 * i, 32);
+        if (S->mont) f_from_mont(S->sf, &s, &s);
+        else if (ge4(&s, &S->sf->p)) { /* reduce non-canonical input once */ sub4(&s, &s, &S->sf->p); }
+        int carry = 0;
+        const int skip = S->inf && S->inf[i];
+        for (int w = 0; w < nwin; w++) {
+            int bit = w * c; u64 raw = 0;
+            if (bit < 256) {
+                raw = s.l[bit >> 6] >> (bit & 63);
+                if ((bit & 63) + c > 64 && (bit >> 6) < 3) raw |= s.l[(bit >> 6) + 1] << (64 - (bit & 63));
+                raw &= ((u64)1 << c) - 1;
+            }
+            int64_t v = (int64_t)raw + carry;
+            if (v > (int64_t)nb) { v -= (int64_t)1 << c; carry = 1; } else carry = 0;
+            S->digits[(size_t)w * n + i] = skip ? 0 : (int32_t)v;
+        }
+    }
+}
+static void *msm_digit_worker(void *arg) {
+    msm_arg *A = (msm_arg *)arg; msm_shared *S = A->S;
+    msm_digits_range(S, S->n * (size_t)A->tid / (size_t)S->nthreads, S->n * (size_t)(A->tid + 1) / (size_t)S->nthreads);
+    return NULL;
+}
+static void *msm_bucket_worker(void *arg) {
+    msm_shared *S = ((msm_arg *)arg)->S;
+    const field_t *f = S->f;
+    const size_t nb = (size_t)1 << (S->c - 1);
     jac *buckets = (jac *)malloc(sizeof(jac) * nb);
-    for (int job = J->job_begin; job < J->job_end; job++) {
-        int w = job / J->slices, sl = job % J->slices;
-        size_t i0 = J->n * (size_t)sl / (size_t)J->slices, i1 = J->n * (size_t)(sl + 1) / (size_t)J->slices;
+    for (;;) {
+        const int job = __atomic_fetch_add(&S->next_job, 1, __ATOMIC_RELAXED);
+        if (job >= S->njobs) break;
+        const int w = job / S->slices, sl = job % S->slices;
+        const size_t i0 = S->n * (size_t)sl / (size_t)S->slices, i1 = S->n * (size_t)(sl + 1) / (size_t)S->slices;
         for (size_t b = 0; b < nb; b++) j_set_inf(f, &buckets[b]);
-        const int32_t *dg = J->digits + (size_t)w * J->n;
+        const int32_t *dg = S->digits + (size_t)w * S->n;
         for (size_t i = i0; i < i1; i++) {
-            int32_t d = dg[i];
+            const int32_t d = dg[i];
             if (d == 0) continue;
-            size_t b = (size_t)(d < 0 ? -d : d) - 1;
-            j_madd(f, &buckets[b], &buckets[b], &J->pts[i], d < 0);
+            const size_t b = (size_t)(d < 0 ? -d : d) - 1;
+            j_madd(f, &buckets[b], &buckets[b], &S->pts[i], d < 0);
         }
         jac run, acc; j_set_inf(f, &run); j_set_inf(f, &acc);
         for (size_t b = nb; b-- > 0;) {
             j_add(f, &run, &run, &buckets[b]);
             j_add(f, &acc, &acc, &run);
         }
-        J->win_sums[job] = acc;
+        S->win_sums[job] = acc;
     }
     free(buckets);
     return NULL;
@@ -382,11 +421,26 @@ static void *msm_worker2(void *arg) {
 static int g_last_threads = 1;
 int ko_last_threads(void) { return g_last_threads; }
 
-static int pick_window(size_t n) {
+/* window width and point slices for n points on `threads` threads: the cheapest schedule among c = 4..16 and the slice counts around
+ * threads / windows -- per thread, in field multiplications: the mixed additions of the jobs it runs (11 products + the additions and
+ * subtractions around them ~ 14) + the running sums of their bucket sets (two full additions of 16 products per bucket) */
+static void pick_schedule(size_t n, int threads, int *c_out, int *slices_out) {
+    double best = 0; int bc = 3, bs = 1;
     int lg = 0; while (((size_t)1 << (lg + 1)) <= n) lg++;
-    int c = lg < 6 ? 3 : lg - 3;           /* ~ln(n)+2 family, like ark-ec */
-    if (c > 16) c = 16;
-    return c;
+    if (lg < 6) { *c_out = 3; *slices_out = 1; return; }
+    for (int c = 4; c <= 16; c++) {
+        const int nwin = (255 + c - 1) / c + 1;
+        const double nb = (double)((size_t)1 << (c - 1));
+        for (int up = 0; up < 2; up++) {
+            int slices = threads / nwin + up; if (slices < 1) slices = 1;
+            while (slices > 1 && (double)n / slices < 4 * nb) slices--;     /* a slice should fill its buckets a few times over */
+            const int njobs = nwin * slices;
+            const int rounds = (njobs + threads - 1) / threads;              /* jobs one thread runs, worst case */
+            const double cost = rounds * ((double)n / slices * 14.0 + nb * 32.0);
+            if (best == 0 || cost < best) { best = cost; bc = c; bs = slices; }
+        }
+    }
+    *c_out = bc; *slices_out = bs;
 }
 
 /*
@@ -399,52 +453,37 @@ int ko_msm(int curve, const u64 *xy, const uint8_t *inf, const u64 *scalars, siz
     const field_t *f = base_field(curve), *sf = scalar_field(curve);
     jac total; j_set_inf(f, &total);
     if (n == 0) { store_aff(f, &total, out_xy, out_inf); return 0; }
-    int c = pick_window(n);
-    int nwin = (255 + c - 1) / c + 1;      /* +1: room for the final carry */
-    size_t nb = (size_t)1 << (c - 1);
-    int32_t *digits = (int32_t *)malloc(sizeof(int32_t) * n * (size_t)nwin);
-    for (size_t i = 0; i < n; i++) {
-        fe s; memcpy(&s, scalars + 4 * i, 32);
-        if (scalars_are_montgomery) f_from_mont(sf, &s, &s);
-        else if (ge4(&s, &sf->p)) { /* reduce non-canonical input once */ sub4(&s, &s, &sf->p); }
-        int carry = 0;
-        int skip = inf && inf[i];
-        for (int w = 0; w < nwin; w++) {
-            int bit = w * c; u64 raw = 0;
-            if (bit < 256) {
-                raw = s.l[bit >> 6] >> (bit & 63);
-                if ((bit & 63) + c > 64 && (bit >> 6) < 3) raw |= s.l[(bit >> 6) + 1] << (64 - (bit & 63));
-                raw &= ((u64)1 << c) - 1;
-            }
-            int64_t v = (int64_t)raw + carry;
-            if (v > (int64_t)nb) { v -= (int64_t)1 << c; carry = 1; } else carry = 0;
-            digits[(size_t)w * n + i] = skip ? 0 : (int32_t)v;
-        }
-    }
     if (threads < 1) threads = 1;
-    /* like the reference (rayon over windows, plus the 2-way "vertical" split of ipa.rs:652-662), but
-     * with as many point slices as the thread budget allows */
-    int slices = threads / nwin; if (slices < 1) slices = 1;
-    while (slices > 1 && n / (size_t)slices < (nb << 3)) slices--;    /* keep >= 8 points per bucket and slice */
-    int njobs = nwin * slices;
-    if (threads > njobs) threads = njobs;
-    jac *win_sums = (jac *)malloc(sizeof(jac) * (size_t)njobs);
+    if (threads > 1024) threads = 1024;
+    int c, slices; pick_schedule(n, threads, &c, &slices);
+    const int nwin = (255 + c - 1) / c + 1;      /* +1: room for the final carry */
+    const int njobs = nwin * slices;
+    msm_shared S = {f, sf, (const aff *)xy, inf, scalars, NULL, n, c, nwin, slices, njobs, scalars_are_montgomery, threads, NULL, 0};
+    S.digits = (int32_t *)malloc(sizeof(int32_t) * n * (size_t)nwin);
+    S.win_sums = (jac *)malloc(sizeof(jac) * (size_t)njobs);
     pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)threads);
-    msm_job2 *jobs = (msm_job2 *)malloc(sizeof(msm_job2) * (size_t)threads);
-    for (int t = 0; t < threads; t++) {
-        jobs[t] = (msm_job2){f, (const aff *)xy, inf, digits, n, c, nwin,
-                             (int)((long)njobs * t / threads), (int)((long)njobs * (t + 1) / threads), slices, win_sums};
-        if (threads == 1) msm_worker2(&jobs[t]);
-        else pthread_create(&th[t], NULL, msm_worker2, &jobs[t]);
+    msm_arg *args = (msm_arg *)malloc(sizeof(msm_arg) * (size_t)threads);
+    for (int t = 0; t < threads; t++) args[t] = (msm_arg){&S, t};
+    const int dthreads = n < 4096 ? 1 : threads;
+    S.nthreads = dthreads;
+    if (dthreads == 1) msm_digit_worker(&args[0]);
+    else {
+        for (int t = 0; t < dthreads; t++) pthread_create(&th[t], NULL, msm_digit_worker, &args[t]);
+        for (int t = 0; t < dthreads; t++) pthread_join(th[t], NULL);
     }
-    if (threads > 1) for (int t = 0; t < threads; t++) pthread_join(th[t], NULL);
+    const int bthreads = threads < njobs ? threads : njobs;
+    if (bthreads == 1) msm_bucket_worker(&args[0]);
+    else {
+        for (int t = 0; t < bthreads; t++) pthread_create(&th[t], NULL, msm_bucket_worker, &args[t]);
+        for (int t = 0; t < bthreads; t++) pthread_join(th[t], NULL);
+    }
     for (int w = nwin - 1; w >= 0; w--) {
         for (int k = 0; k < c; k++) j_dbl(f, &total, &total);
-        for (int sl = 0; sl < slices; sl++) j_add(f, &total, &total, &win_sums[w * slices + sl]);
+        for (int sl = 0; sl < slices; sl++) j_add(f, &total, &total, &S.win_sums[w * slices + sl]);
     }
-    g_last_threads = threads;
+    g_last_threads = bthreads;
     store_aff(f, &total, out_xy, out_inf);
-    free(jobs); free(th); free(win_sums); free(digits);
+    free(args); free(th); free(S.win_sums); free(S.digits);
     return 0;
 }
 
@@ -475,18 +514,18 @@ static inline size_t bitrev(size_t x, unsigned bits) {
     for (unsigned i = 0; i < bits; i++) { r = (r << 1) | (x & 1); x >>= 1; }
     return r;
 }
-static void ntt_one(const field_t *f, fe *a, unsigned log2_n, const fe *tw /* n/2 powers of w */, int inverse, const fe *ninv) {
+static void ntt_one(const field_t *f, fe *a, unsigned log2_n, const fe *tw /* stage-major twiddles, see ko_ntt */, int inverse, const fe *ninv) {
     size_t n = (size_t)1 << log2_n;
     for (size_t i = 0; i < n; i++) {
         size_t j = bitrev(i, log2_n);
         if (i < j) { fe t = a[i]; a[i] = a[j]; a[j] = t; }
     }
     for (size_t m = 1; m < n; m <<= 1) {
-        size_t step = n / (2 * m);
+        const fe *twm = tw + m;                              /* stage-major table: twm[j] = w^(j n / 2m), contiguous */
         for (size_t k = 0; k < n; k += 2 * m)
             for (size_t j = 0; j < m; j++) {
                 fe u = a[k + j], v;
-                f_mul(f, &v, &a[k + j + m], &tw[j * step]);
+                f_mul(f, &v, &a[k + j + m], &twm[j]);
                 f_add(f, &a[k + j], &u, &v);
                 f_sub(f, &a[k + j + m], &u, &v);
             }
@@ -500,6 +539,38 @@ static void *ntt_worker(void *arg) {
     for (size_t b = J->b0; b < J->b1; b++) ntt_one(J->f, J->data + b * n, J->log2_n, J->tw, J->inverse, J->ninv);
     return NULL;
 }
+/* more threads than transforms: all threads walk all transforms stage by stage (the butterflies of a stage are independent), a barrier between
+ * stages -- the parallel FFT of ark-poly splits a large transform over the rayon pool too */
+typedef struct {
+    const field_t *f; fe *data; unsigned log2_n; const fe *tw; int inverse; const fe *ninv; size_t batch; int tid, nthreads; pthread_barrier_t *bar;
+} ntt_flat_job;
+static void *ntt_flat_worker(void *arg) {
+    ntt_flat_job *J = (ntt_flat_job *)arg;
+    const field_t *f = J->f;
+    const size_t n = (size_t)1 << J->log2_n, half = n / 2, T = (size_t)J->nthreads, t = (size_t)J->tid;
+    const size_t all = J->batch * n;
+    for (size_t x = all * t / T; x < all * (t + 1) / T; x++) {
+        const size_t b = x / n, i = x % n, j = bitrev(i, J->log2_n);
+        if (i < j) { fe *a = J->data + b * n; fe tmp = a[i]; a[i] = a[j]; a[j] = tmp; }
+    }
+    pthread_barrier_wait(J->bar);
+    const size_t total = J->batch * half;
+    unsigned lm = 0;
+    for (size_t m = 1; m < n; m <<= 1, lm++) {
+        const fe *twm = J->tw + m;
+        for (size_t x = total * t / T; x < total * (t + 1) / T; x++) {
+            const size_t b = x >> (J->log2_n - 1), r = x & (half - 1), k = (r >> lm) << (lm + 1), j = r & (m - 1);
+            fe *a = J->data + b * n;
+            fe u = a[k + j], v;
+            f_mul(f, &v, &a[k + j + m], &twm[j]);
+            f_add(f, &a[k + j], &u, &v);
+            f_sub(f, &a[k + j + m], &u, &v);
+        }
+        pthread_barrier_wait(J->bar);
+    }
+    if (J->inverse) for (size_t x = all * t / T; x < all * (t + 1) / T; x++) f_mul(f, &J->data[x], &J->data[x], J->ninv);
+    return NULL;
+}
 /* data: batch x N x 4 limbs, Montgomery, natural order in and out; inverse includes 1/N. */
 int ko_ntt(int field, u64 *data, unsigned log2_n, int inverse, size_t batch, int threads) {
     ko_init();
@@ -508,11 +579,31 @@ int ko_ntt(int field, u64 *data, unsigned log2_n, int inverse, size_t batch, int
     size_t n = (size_t)1 << log2_n;
     fe w; root_of_unity(f, &w, log2_n, inverse);
     size_t half = n > 1 ? n / 2 : 1;
-    fe *tw = (fe *)malloc(sizeof(fe) * half);
+    /* the n/2 powers of w, then regrouped stage by stage: tw[m + j] = w^(j n / 2m) for the stage of half-size m (a butterfly loop then walks
+     * its twiddles contiguously instead of with a stride of n / 2m elements -- at 8 KB strides every access is a new line in one cache set) */
+    fe *pw = (fe *)malloc(sizeof(fe) * half);
+    pw[0] = f->one;
+    for (size_t i = 1; i < half; i++) f_mul(f, &pw[i], &pw[i - 1], &w);
+    fe *tw = (fe *)malloc(sizeof(fe) * (n > 1 ? n : 2));
     tw[0] = f->one;
-    for (size_t i = 1; i < half; i++) f_mul(f, &tw[i], &tw[i - 1], &w);
+    for (size_t m = 1; m < n; m <<= 1) { const size_t step = n / (2 * m); for (size_t j = 0; j < m; j++) tw[m + j] = pw[j * step]; }
+    free(pw);
     fe nn = {{n, 0, 0, 0}}, ninv; f_to_mont(f, &nn, &nn); f_inv(f, &ninv, &nn);
     if (threads < 1) threads = 1;
+    if ((size_t)threads > batch && log2_n >= 12) {          /* fewer transforms than threads, and large enough to be worth the barriers */
+        if ((size_t)threads > batch * (n / 1024)) threads = (int)(batch * (n / 1024));
+        pthread_barrier_t bar; pthread_barrier_init(&bar, NULL, (unsigned)threads);
+        pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)threads);
+        ntt_flat_job *jobs = (ntt_flat_job *)malloc(sizeof(ntt_flat_job) * (size_t)threads);
+        for (int t = 0; t < threads; t++) {
+            jobs[t] = (ntt_flat_job){f, (fe *)data, log2_n, tw, inverse, &ninv, batch, t, threads, &bar};
+            pthread_create(&th[t], NULL, ntt_flat_worker, &jobs[t]);
+        }
+        for (int t = 0; t < threads; t++) pthread_join(th[t], NULL);
+        pthread_barrier_destroy(&bar);
+        free(jobs); free(th); free(tw);
+        return 0;
+    }
     if ((size_t)threads > batch) threads = (int)batch;
     if (threads <= 1) {
         ntt_job J = {f, (fe *)data, log2_n, tw, inverse, &ninv, 0, batch};
