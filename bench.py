@@ -104,6 +104,29 @@ def ntt_block(khip):
     return out
 
 
+def cpu_quota():
+    """CPUs this container may actually use at once (cgroup v2 cpu.max / v1 cfs quota; None = no limit): os.cpu_count() reports the host's threads
+    whatever the quota is, and a CPU baseline on `cores` threads under a smaller quota is throttled, not parallel."""
+    try:
+        q, p_ = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(p_)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); p_ = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / p_
+    except (OSError, ValueError):
+        return None
+
+
+def usable_threads():
+    """threads for the CPU baselines: the host's hardware threads, the affinity mask and the cgroup quota, whichever is smallest (256 threads
+    under a 16-CPU quota are throttled in bursts: slower than 16)"""
+    n = min(os.cpu_count() or 1, len(os.sched_getaffinity(0)))
+    q = cpu_quota()
+    return max(1, min(n, int(q + 0.999))) if q else n
+
+
 def prover_cpu_baseline(khip, ix, wit_padded, log_n=16):
     """BASELINE config 3's operation list (15 Lagrange-basis MSMs of the benchmark witness + 1 + 7 monomial MSMs + the 32
     round MSMs of the opening, 19 iNTT(2^16) + 16 LDE(-> 2^19) + iNTT(2^18) + iNTT(2^19)) on THIS box's host cores with the C port
@@ -114,7 +137,7 @@ def prover_cpu_baseline(khip, ix, wit_padded, log_n=16):
     from oracle import cref
     n = 1 << log_n
     cores = os.cpu_count() or 1
-    thr = cores                                                                # the port schedules jobs over every hardware thread (oracle/pasta_ref.c: pick_schedule, ntt_flat_worker)
+    thr = usable_threads()                                                     # every CPU this container may use (oracle/pasta_ref.c schedules its jobs over them: pick_schedule, ntt_flat_worker)
     rng = np.random.default_rng(5)
     g = ix.srs.get_g()
     lag, linf = ix.srs.get_lagrange(log_n)
@@ -131,18 +154,20 @@ def prover_cpu_baseline(khip, ix, wit_padded, log_n=16):
         m //= 2
     t_msm = time.perf_counter() - t0
     cols = rand_scalars(rng, 19 * n).reshape(19, n, 4)
+    c19, c16 = cols.copy(), cols[:16].copy()                                  # inputs made before the clock starts
+    q4, q8 = rand_scalars(rng, 4 * n).reshape(1, 4 * n, 4), rand_scalars(rng, 8 * n).reshape(1, 8 * n, 4)
     t0 = time.perf_counter()
-    cref.ntt(0, cols.copy(), log_n, True, threads=thr)
-    cref.lde(0, cols[:16].copy(), log_n, 3, threads=thr)
-    cref.ntt(0, rand_scalars(rng, 4 * n).reshape(1, 4 * n, 4), log_n + 2, True, threads=thr)
-    cref.ntt(0, rand_scalars(rng, 8 * n).reshape(1, 8 * n, 4), log_n + 3, True, threads=thr)
+    cref.ntt(0, c19, log_n, True, threads=thr)
+    cref.lde(0, c16, log_n, 3, threads=thr)
+    cref.ntt(0, q4, log_n + 2, True, threads=thr)
+    cref.ntt(0, q8, log_n + 3, True, threads=thr)
     t_ntt = time.perf_counter() - t0
     model = ""
     try:
         model = next(l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name"))
     except (OSError, StopIteration):
         pass
-    return {"seconds": t_msm + t_ntt, "msm_seconds": t_msm, "ntt_seconds": t_ntt, "constraints_per_s": n / (t_msm + t_ntt), "cores": thr, "host_cores": cores,
+    return {"seconds": t_msm + t_ntt, "msm_seconds": t_msm, "ntt_seconds": t_ntt, "constraints_per_s": n / (t_msm + t_ntt), "cores": thr, "host_cores": cores, "cgroup_cpu_quota": cpu_quota(), "usable_cpus": len(os.sched_getaffinity(0)),
             "cpu_model": model, "kind": "port",
             "sample": "the whole operation list of one 2^16 proof once: 23 commitment MSMs + 32 opening-round MSMs, 19 iNTT(2^16), 16 LDE(2^16 -> 2^19), iNTT(2^18), iNTT(2^19)",
             "note": "data-parallel part only (no constraint evaluation, no sponge): a lower bound for a CPU prover of this algorithmic family on this host; not the reference binary"}
@@ -565,14 +590,14 @@ def main():
     if not args.no_cpu_baseline:
         from oracle import cref          # cpu_baseline / checker leg only
         g = srs.get_g()
-        threads = max(1, cores // world)
+        threads = max(1, usable_threads() // world)
         t0 = time.perf_counter()
         want, winf = cref.msm(CID, g, sc, scalars_mont=True, threads=threads)
         t_cpu = time.perf_counter() - t0
         if world == 1:
             ok = (winf == result[1]) and (winf or bool(np.array_equal(want, result[0])))
-            line["cpu_baseline"] = {"value": n / t_cpu / 1e6, "unit": "Mscalar/s", "cores": cref.last_threads(), "host_cores": cores, "kind": "port",
-                                    "sample": "the same 2^%d-point MSM (oracle/pasta_ref.c signed-window Pippenger; jobs = windows x point slices over all hardware threads, window width chosen for that)" % args.log_n,
+            line["cpu_baseline"] = {"value": n / t_cpu / 1e6, "unit": "Mscalar/s", "cores": cref.last_threads(), "host_cores": cores, "cgroup_cpu_quota": cpu_quota(), "usable_cpus": len(os.sched_getaffinity(0)), "kind": "port",
+                                    "sample": "the same 2^%d-point MSM (oracle/pasta_ref.c signed-window Pippenger; jobs = windows x point slices over the CPUs this container may use, window width chosen for that)" % args.log_n,
                                     "seconds": t_cpu, "gpu_result_matches": bool(ok)}
         else:
             mine = torch.from_numpy(np.concatenate([want, np.array([int(winf)], dtype=np.uint64)]).view(np.int64).copy()).to(coll_dev)

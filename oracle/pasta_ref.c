@@ -422,7 +422,7 @@ static int g_last_threads = 1;
 int ko_last_threads(void) { return g_last_threads; }
 
 /* window width and point slices for n points on `threads` threads: the cheapest schedule among c = 4..16 and the slice counts around
- * threads / windows -- per thread, in field multiplications: the mixed additions of the jobs it runs (11 products + the additions and
+ * threads / windows (up to ~4 jobs per thread) -- per thread, in field multiplications: the mixed additions of the jobs it runs (11 products + the additions and
  * subtractions around them ~ 14) + the running sums of their bucket sets (two full additions of 16 products per bucket) */
 static void pick_schedule(size_t n, int threads, int *c_out, int *slices_out) {
     double best = 0; int bc = 3, bs = 1;
@@ -431,9 +431,9 @@ static void pick_schedule(size_t n, int threads, int *c_out, int *slices_out) {
     for (int c = 4; c <= 16; c++) {
         const int nwin = (255 + c - 1) / c + 1;
         const double nb = (double)((size_t)1 << (c - 1));
-        for (int up = 0; up < 2; up++) {
-            int slices = threads / nwin + up; if (slices < 1) slices = 1;
-            while (slices > 1 && (double)n / slices < 4 * nb) slices--;     /* a slice should fill its buckets a few times over */
+        const int smax = 4 * threads / nwin + 2;                          /* up to ~4 jobs per thread: the queue evens out what remains */
+        for (int slices = 1; slices <= smax; slices++) {
+            if (slices > 1 && (double)n / slices < 4 * nb) break;           /* a slice should fill its buckets a few times over */
             const int njobs = nwin * slices;
             const int rounds = (njobs + threads - 1) / threads;              /* jobs one thread runs, worst case */
             const double cost = rounds * ((double)n / slices * 14.0 + nb * 32.0);
@@ -455,6 +455,10 @@ int ko_msm(int curve, const u64 *xy, const uint8_t *inf, const u64 *scalars, siz
     if (n == 0) { store_aff(f, &total, out_xy, out_inf); return 0; }
     if (threads < 1) threads = 1;
     if (threads > 1024) threads = 1024;
+    {   /* starting a thread costs tens of microseconds: no more threads than there are ~16K-addition (a few ms) shares of the work */
+        const size_t shares = n * 22 / 16384 + 1;
+        if ((size_t)threads > shares) threads = (int)shares;
+    }
     int c, slices; pick_schedule(n, threads, &c, &slices);
     const int nwin = (255 + c - 1) / c + 1;      /* +1: room for the final carry */
     const int njobs = nwin * slices;
@@ -464,7 +468,7 @@ int ko_msm(int curve, const u64 *xy, const uint8_t *inf, const u64 *scalars, siz
     pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)threads);
     msm_arg *args = (msm_arg *)malloc(sizeof(msm_arg) * (size_t)threads);
     for (int t = 0; t < threads; t++) args[t] = (msm_arg){&S, t};
-    const int dthreads = n < 4096 ? 1 : threads;
+    const int dthreads = n < 4096 ? 1 : ((size_t)threads > n / 4096 ? (int)(n / 4096) : threads);
     S.nthreads = dthreads;
     if (dthreads == 1) msm_digit_worker(&args[0]);
     else {
@@ -591,7 +595,7 @@ int ko_ntt(int field, u64 *data, unsigned log2_n, int inverse, size_t batch, int
     fe nn = {{n, 0, 0, 0}}, ninv; f_to_mont(f, &nn, &nn); f_inv(f, &ninv, &nn);
     if (threads < 1) threads = 1;
     if ((size_t)threads > batch && log2_n >= 12) {          /* fewer transforms than threads, and large enough to be worth the barriers */
-        if ((size_t)threads > batch * (n / 1024)) threads = (int)(batch * (n / 1024));
+        if ((size_t)threads > batch * (n / 4096)) threads = (int)(batch * (n / 4096));      /* >= 2048 butterflies per thread and stage */
         pthread_barrier_t bar; pthread_barrier_init(&bar, NULL, (unsigned)threads);
         pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)threads);
         ntt_flat_job *jobs = (ntt_flat_job *)malloc(sizeof(ntt_flat_job) * (size_t)threads);
@@ -622,11 +626,29 @@ int ko_ntt(int field, u64 *data, unsigned log2_n, int inverse, size_t batch, int
     return 0;
 }
 /* evaluate_over_domain: zero-extend n coeffs to n<<b, forward NTT. out: batch x (n<<b) x 4 limbs. */
+typedef struct { const u64 *coeffs; u64 *out; size_t n, N, b0, b1; } lde_pad_job;
+static void *lde_pad_worker(void *arg) {
+    lde_pad_job *J = (lde_pad_job *)arg;
+    for (size_t b = J->b0; b < J->b1; b++) {
+        memcpy(J->out + b * J->N * 4, J->coeffs + b * J->n * 4, J->n * 32);
+        memset(J->out + b * J->N * 4 + J->n * 4, 0, (J->N - J->n) * 32);
+    }
+    return NULL;
+}
 int ko_lde(int field, const u64 *coeffs, unsigned log2_n, unsigned log2_blowup, u64 *out, size_t batch, int threads) {
     size_t n = (size_t)1 << log2_n, N = n << log2_blowup;
-    for (size_t b = 0; b < batch; b++) {
-        memcpy(out + b * N * 4, coeffs + b * n * 4, n * 32);
-        memset(out + b * N * 4 + n * 4, 0, (N - n) * 32);
+    int pt = threads < 1 ? 1 : threads;
+    if ((size_t)pt > batch) pt = (int)batch;
+    if (pt <= 1 || N < 65536) { lde_pad_job J = {coeffs, out, n, N, 0, batch}; lde_pad_worker(&J); }
+    else {                                                  /* the zero extension is 7/8 of the output: one thread per column */
+        pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)pt);
+        lde_pad_job *jobs = (lde_pad_job *)malloc(sizeof(lde_pad_job) * (size_t)pt);
+        for (int t = 0; t < pt; t++) {
+            jobs[t] = (lde_pad_job){coeffs, out, n, N, batch * (size_t)t / (size_t)pt, batch * (size_t)(t + 1) / (size_t)pt};
+            pthread_create(&th[t], NULL, lde_pad_worker, &jobs[t]);
+        }
+        for (int t = 0; t < pt; t++) pthread_join(th[t], NULL);
+        free(jobs); free(th);
     }
     return ko_ntt(field, out, log2_n + log2_blowup, 0, batch, threads);
 }
