@@ -11,10 +11,13 @@
  *   - Fp/Fq Montgomery arithmetic ....... curves/src/pasta/fields/fp.rs:8-80, fq.rs:8-79
  *   - Pallas/Vesta group law ............ curves/src/pasta/curves/{pallas,vesta}.rs
  *   - VariableBaseMSM::msm_bigint ....... called at poly-commitment/src/ipa.rs:649-672,
- *                                         commitment.rs:382 (signed-window Pippenger,
- *                                         one thread per window like ark-ec's rayon path)
+ *                                         commitment.rs:382 (signed-window Pippenger; threads over
+ *                                         (window, point slice) jobs: ark-ec's rayon path over the
+ *                                         windows + the point split of ipa.rs:652-662)
  *   - Radix2EvaluationDomain fft/ifft ... called at kimchi/src/prover.rs:289,377,907,
- *                                         circuits/constraints.rs:490-495
+ *                                         circuits/constraints.rs:490-495 (threads over the columns
+ *                                         of a batch, or over the butterflies of a stage when there
+ *                                         are fewer columns than threads)
  *   - SRS::create ........................ poly-commitment/src/ipa.rs:751-778, 234-265,
  *                                         groupmap/src/lib.rs:74-189
  *   - compressed point codec ............ utils/src/serialization.rs:67-104
