@@ -29,6 +29,39 @@ from . import poseidon as S
 
 COLUMNS, PERMUTS = 15, 7
 
+# Transforms of 2^FAST_LOG points and more run in the C oracle (oracle/pasta_ref.c::ko_ntt, held to oracle/pasta.py::ntt point for point by
+# tests/test_oracle_kats.py) instead of on Python integers: the same values, and what lets this prover reach BASELINE config 3's own size
+# (2^16 gates: 8n = 2^19-point extensions) in minutes.  FAST_LOG = None puts everything back on Python integers; tests/test_reference_kat.py
+# reproduces the reference's whole-proof bytes on BOTH paths.
+FAST_LOG: Optional[int] = 8
+THREADS = 16
+
+
+def _fid(F) -> int:
+    return 0 if F is P.Fp else 1
+
+
+def to_limbs(F, vals: Sequence[int]) -> np.ndarray:
+    """canonical integers -> (k, 4) Montgomery limbs (the C oracle's wire format)"""
+    buf = b"".join(int(v).to_bytes(32, "little") for v in vals)
+    a = np.frombuffer(buf, dtype=np.uint64).reshape(-1, 4)
+    return cref.field_op(_fid(F), "to_mont", a) if len(vals) else a.copy()
+
+
+def from_limbs(F, a: np.ndarray) -> List[int]:
+    b = cref.field_op(_fid(F), "from_mont", np.ascontiguousarray(a).reshape(-1, 4)).tobytes()
+    return [int.from_bytes(b[i:i + 32], "little") for i in range(0, len(b), 32)]
+
+
+def ntt(F, a: Sequence[int], log2_n: int, inverse: bool = False) -> List[int]:
+    """oracle/pasta.py::ntt (ark-poly Radix2EvaluationDomain semantics), through the C oracle from 2^FAST_LOG points on."""
+    if FAST_LOG is None or log2_n < FAST_LOG:
+        return P.ntt(F, a, log2_n, inverse)
+    n = 1 << log2_n
+    assert len(a) <= n
+    x = to_limbs(F, [v % F.p for v in a] + [0] * (n - len(a)))
+    return from_limbs(F, cref.ntt(_fid(F), x, log2_n, inverse, threads=THREADS))
+
 
 # ---------------------------------------------------------------------------------------------------- SRS + commitments
 class Srs:
@@ -49,7 +82,7 @@ class Srs:
 
     def msm(self, points_xy, scalars: Sequence[int], inf=None):
         F = self.curve.scalar
-        sc = cref.ints_to_limbs([F.to_mont(s % F.p) for s in scalars])
+        sc = to_limbs(F, [s % F.p for s in scalars])
         xy, i = cref.msm(self.cid, points_xy, sc, inf=inf, threads=self.threads)
         return self._aff(xy, i)
 
@@ -242,7 +275,7 @@ def create_proof(ix: Index, witness: Sequence[Sequence[int]], rng: P.StdRng, pre
         fq.absorb_g(comm)
     # ---- the negated public-input polynomial, committed non-hiding and masked with ones (prover.rs:281-309)
     pub = w[0][:cs["public"]]
-    public_poly = _trim(P.ntt(F, [(-x) % p for x in pub] + [0] * (n - len(pub)), logn, inverse=True))
+    public_poly = _trim(ntt(F, [(-x) % p for x in pub] + [0] * (n - len(pub)), logn, inverse=True))
     public_comm = srs.mask(srs.commit_non_hiding(public_poly, nch), [1] * nch)
     fq.absorb_g(public_comm)
     # ---- witness commitments over the Lagrange basis, blinded (prover.rs:316-363)
@@ -251,7 +284,7 @@ def create_proof(ix: Index, witness: Sequence[Sequence[int]], rng: P.StdRng, pre
     for c in w_comm:
         fq.absorb_g(c)
     tr["w_comm"] = w_comm
-    w_poly = [P.ntt(F, w[i], logn, inverse=True) for i in range(COLUMNS)]
+    w_poly = [ntt(F, w[i], logn, inverse=True) for i in range(COLUMNS)]
     # ---- lookup: joint combiner, combined table, sorted columns (prover.rs:383-633)
     lcs = cs["lookup"]
     lk = None
@@ -267,15 +300,15 @@ def create_proof(ix: Index, witness: Sequence[Sequence[int]], rng: P.StdRng, pre
                 off += len(data)
             for r in range(n - 1, n - 1 - zk, -1):             # zero-knowledge rows, from the last row backwards
                 rte[r] = rand()
-            rt_poly = P.ntt(F, rte, logn, inverse=True)
+            rt_poly = ntt(F, rte, logn, inverse=True)
             com = srs.commit_non_hiding(rt_poly, nch)
             rt_blind = [rand() for _ in com]
             rt_comm = srs.mask(com, rt_blind)
             fq.absorb_g(rt_comm)
-            rt = {"evals": rte, "poly": rt_poly, "blind": rt_blind, "comm": rt_comm, "sel_poly": P.ntt(F, lcs.runtime_selector, logn, inverse=True)}
+            rt = {"evals": rte, "poly": rt_poly, "blind": rt_blind, "comm": rt_comm, "sel_poly": ntt(F, lcs.runtime_selector, logn, inverse=True)}
         jc = P.challenge_to_field(F, fq.challenge() if lcs.info.joint_lookup_used else 0, endo_r)
         table = lcs.joint_table(jc, rt["evals"] if rt else None)
-        table_poly = P.ntt(F, table, logn, inverse=True)
+        table_poly = ntt(F, table, logn, inverse=True)
         srt = L.sorted_columns(lcs, types, w, jc, table=table)
         srt = [L.zk_patch(c, n, zk, [rand() for _ in range(zk)]) for c in srt]
         s_blind, s_comm = [], []
@@ -286,7 +319,7 @@ def create_proof(ix: Index, witness: Sequence[Sequence[int]], rng: P.StdRng, pre
         for c in s_comm:
             fq.absorb_g(c)
         lk = {"jc": jc, "table": table, "table_poly": table_poly, "sorted": srt, "s_blind": s_blind, "s_comm": s_comm, "rt": rt,
-              "sorted_poly": [P.ntt(F, c, logn, inverse=True) for c in srt]}
+              "sorted_poly": [ntt(F, c, logn, inverse=True) for c in srt]}
     beta = fq.challenge(); gamma = fq.challenge()
     if lk is not None:                                         # prover.rs:635-673
         agg = L.aggregation(lcs, types, w, lk["jc"], beta, gamma, lk["sorted"], None, draw=rand, table=lk["table"])
@@ -295,11 +328,11 @@ def create_proof(ix: Index, witness: Sequence[Sequence[int]], rng: P.StdRng, pre
         a_blind = [rand() for _ in com]
         a_comm = srs.mask(com, a_blind)
         fq.absorb_g(a_comm)
-        lk.update({"agg": agg, "a_blind": a_blind, "a_comm": a_comm, "agg_poly": P.ntt(F, agg, logn, inverse=True)})
+        lk.update({"agg": agg, "a_blind": a_blind, "a_comm": a_comm, "agg_poly": ntt(F, agg, logn, inverse=True)})
     # ---- permutation accumulator (permutation.rs:447-577): the two random rows are drawn inside the running product
     z = _perm_aggreg(F, w, cs["sigma"], cs["shifts"], cs["sid"], beta, gamma, zk, rand)
     assert z[n - zk] == 1, "Permutation: final value"
-    z_poly = P.ntt(F, z, logn, inverse=True)
+    z_poly = ntt(F, z, logn, inverse=True)
     com = srs.commit_non_hiding(z_poly, nch)
     z_blind = [rand() for _ in com]
     z_comm = srs.mask(com, z_blind)
@@ -318,7 +351,7 @@ def create_proof(ix: Index, witness: Sequence[Sequence[int]], rng: P.StdRng, pre
     zetaw = zeta * omega % p
     # ---- chunked evaluations (prover.rs:942-1130)
     ec = lambda poly: (evaluate_chunks(p, poly, zeta, nch, size), evaluate_chunks(p, poly, zetaw, nch, size))
-    interp = lambda col: P.ntt(F, col, logn, inverse=True)
+    interp = lambda col: ntt(F, col, logn, inverse=True)
     sel_poly = {k: interp(v) for k, v in cs["selectors"].items()}
     coef_poly = [interp(c) for c in cs["coefficients"]]
     sigma_poly = [interp(c) for c in cs["sigma"]]
@@ -426,8 +459,8 @@ def _quotient(ix: Index, w_poly, z_poly, public_poly, lk, alpha, beta, gamma) ->
     n, logn, zk = cs["n"], cs["log2_n"], cs["zk_rows"]
     omega = cs["omega"]
     n8 = 8 * n
-    lde = lambda poly: P.ntt(F, list(poly), logn + 3)
-    interp = lambda col: P.ntt(F, col, logn, inverse=True)
+    lde = lambda poly: ntt(F, list(poly), logn + 3)
+    interp = lambda col: ntt(F, col, logn, inverse=True)
     w8 = [lde(q) for q in w_poly]
     z8 = lde(z_poly)
     co8 = [lde(interp(c)) for c in cs["coefficients"]]
@@ -495,7 +528,7 @@ def _quotient(ix: Index, w_poly, z_poly, public_poly, lk, alpha, beta, gamma) ->
             for k, val in enumerate(vals):
                 acc = (acc + lalpha[k] * val) % p
         f8[i] = acc
-    f = P.ntt(F, f8, logn + 3, inverse=True)
+    f = ntt(F, f8, logn + 3, inverse=True)
     for i, c in enumerate(public_poly):
         f[i] = (f[i] + c) % p
     # divide by x^n - 1: q[i] = sum_{k >= 1} f[i + k n]; remainder must vanish

@@ -27,13 +27,14 @@ use ark_poly::{univariate::DensePolynomial, EvaluationDomain, Evaluations, Radix
 use core::ops::Deref;
 use groupmap::GroupMap;
 use kimchi_hip_sys as sys;
+use kimchi::curve::KimchiCurve;
 use mina_poseidon::{sponge::ScalarChallenge, FqSponge};
 use poly_commitment::{
     commitment::{combined_inner_product, shift_scalar, BatchEvaluationProof, BlindedCommitment, CommitmentCurve, EndoCurve, PolyComm},
     error::CommitmentError,
     ipa::{self, endos, OpeningProof},
-    utils::combine_polys,
-    OpenProof, PolynomialsToCombine, SRS,
+    utils::{combine_polys, DensePolynomialOrEvaluations},
+    OpenProof, SRS,
 };
 use rand_core::{CryptoRng, RngCore};
 use std::{ffi::CStr, sync::Arc};
@@ -315,7 +316,9 @@ where
 #[derive(Clone, Debug)]
 pub struct GpuOpeningProof<G: HipCurve, const FULL_ROUNDS: usize>(pub OpeningProof<G, FULL_ROUNDS>);
 
-impl<G: HipCurve, const FULL_ROUNDS: usize> OpenProof<G, FULL_ROUNDS> for GpuOpeningProof<G, FULL_ROUNDS>
+// `KimchiCurve<FULL_ROUNDS>` (kimchi/src/curve.rs:20-38; both Pasta curves implement it) is an impl-level bound, not one on the
+// trait methods: `verify` needs `other_curve_sponge_params()` to build the placeholder sponges it swaps in (see there).
+impl<G: HipCurve + KimchiCurve<FULL_ROUNDS>, const FULL_ROUNDS: usize> OpenProof<G, FULL_ROUNDS> for GpuOpeningProof<G, FULL_ROUNDS>
 where
     G::BaseField: PrimeField,
 {
@@ -328,7 +331,9 @@ where
     fn open<EFqSponge, RNG, Dom: EvaluationDomain<<G as AffineRepr>::ScalarField>>(
         srs: &Self::SRS,
         group_map: &<G as CommitmentCurve>::Map,
-        plnms: PolynomialsToCombine<G, Dom>,
+        // `poly_commitment::PolynomialsToCombine<G, Dom>` spelled out: the alias is private to the crate (poly-commitment/src/lib.rs:249,
+        // `type`, not `pub type`), so an implementor outside it has to write the slice type itself
+        plnms: &[(DensePolynomialOrEvaluations<'_, <G as AffineRepr>::ScalarField, Dom>, PolyComm<<G as AffineRepr>::ScalarField>)],
         elm: &[<G as AffineRepr>::ScalarField],
         polyscale: <G as AffineRepr>::ScalarField,
         evalscale: <G as AffineRepr>::ScalarField,
@@ -432,20 +437,31 @@ where
         EFqSponge: FqSponge<G::BaseField, G, G::ScalarField, FULL_ROUNDS>,
         RNG: RngCore + CryptoRng,
     {
-        // The verifier is not on the proving path: re-wrap the batch for the inner SRS (ipa.rs:301-502).
-        let mut inner: Vec<BatchEvaluationProof<G, EFqSponge, OpeningProof<G, FULL_ROUNDS>, FULL_ROUNDS>> = batch
-            .iter()
-            .map(|b| BatchEvaluationProof {
-                sponge: b.sponge.clone(),
-                evaluations: b.evaluations.clone(),
-                evaluation_points: b.evaluation_points.clone(),
+        // The verifier is not on the proving path: hand the batch to the inner SRS (`ipa::SRS::verify`, ipa.rs:301-502).  Its element
+        // type differs (`opening: &OpeningProof` instead of `&GpuOpeningProof`), so every element is rebuilt BY MOVING its parts:
+        // `EFqSponge` is not `Clone` here (lib.rs:289-297 of poly-commitment: only `FqSponge`), so the sponge is swapped against a
+        // fresh one (`FqSponge::new`, poseidon/src/sponge.rs:16) and -- like the vectors -- put back afterwards in the state the inner
+        // verifier left it in, which is what the reference's own `verify` does to the caller's batch.
+        let mut inner: Vec<BatchEvaluationProof<G, EFqSponge, OpeningProof<G, FULL_ROUNDS>, FULL_ROUNDS>> = Vec::with_capacity(batch.len());
+        for b in batch.iter_mut() {
+            let opening: &GpuOpeningProof<G, FULL_ROUNDS> = b.opening; // `&'a Self` is `Copy`: not a borrow of `batch`
+            inner.push(BatchEvaluationProof {
+                sponge: core::mem::replace(&mut b.sponge, EFqSponge::new(G::other_curve_sponge_params())),
+                evaluations: core::mem::take(&mut b.evaluations),
+                evaluation_points: core::mem::take(&mut b.evaluation_points),
                 polyscale: b.polyscale,
                 evalscale: b.evalscale,
-                opening: &b.opening.0,
+                opening: &opening.0,
                 combined_inner_product: b.combined_inner_product,
-            })
-            .collect();
-        srs.inner.verify(group_map, &mut inner, rng)
+            });
+        }
+        let accepted = srs.inner.verify(group_map, &mut inner, rng);
+        for (b, i) in batch.iter_mut().zip(inner) {
+            b.sponge = i.sponge;
+            b.evaluations = i.evaluations;
+            b.evaluation_points = i.evaluation_points;
+        }
+        accepted
     }
 }
 

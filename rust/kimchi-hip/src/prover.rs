@@ -42,6 +42,14 @@ impl Drop for DevCols {
     }
 }
 
+/// Owns a `kh_proof_t` between `kh_prove` and the end of the conversion (like the `kh_ipa_t` guard of `open`, lib.rs).
+struct ProofGuard(*mut sys::kh_proof_t);
+impl Drop for ProofGuard {
+    fn drop(&mut self) {
+        unsafe { sys::kh_proof_free(self.0) }
+    }
+}
+
 pub struct GpuProver<G: HipCurve> {
     index: *mut sys::kh_prover_index_t,
     optional: Vec<usize>, // indices into OPTIONAL of the gate types the circuit has
@@ -152,6 +160,7 @@ where
         let rnd: Vec<G::ScalarField> = (0..need).map(|_| <G::ScalarField as ark_ff::UniformRand>::rand(rng)).collect();
         let mut proof = core::ptr::null_mut();
         ok(unsafe { sys::kh_prove(self.index, limbs(&flat), rows, core::ptr::null(), limbs(&rnd), need, sys::KH_PROVE_CHECK as u32, &mut proof) });
+        let _free = ProofGuard(proof); // `ok()` / a slice conversion below may panic: the library's proof object is released on every path
         let section = |s: i32| {
             let (mut l, mut f, mut k) = (core::ptr::null(), core::ptr::null(), 0usize);
             ok(unsafe { sys::kh_proof_section(proof, s, &mut l, &mut f, &mut k) });
@@ -219,7 +228,6 @@ where
             ft_eval1: elems(sys::KH_PROOF_FT_EVAL1)[0],
             prev_challenges: vec![],
         };
-        unsafe { sys::kh_proof_free(proof) };
         let _ = pack::<G>; // (the wire format helpers are shared with lib.rs)
         out
     }

@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""Whole-proof fixtures at BASELINE config 3's OWN size (and config 5's Pallas half, and one chunked proof), made by the oracle's
+CPU prover (oracle/prover.py -- pinned on the reference's seeded whole-proof regression, kimchi/src/tests/and.rs:404-731, by
+tests/test_reference_kat.py; its transforms run in the C oracle from 2^8 points on, the SAME code path that reproduces those bytes).
+
+Circuit = the reference's benchmark circuit, kimchi/src/bench.rs:59-122: 2^k - 10 generic gates `Const(1)`, every cell wired to
+itself, a witness of ones, no public input.  The reference proves it with `OsRng`; a fixture needs a stream, so the draws come
+from `StdRng::from_seed(seed)` (the oracle's restatement of rand 0.8.5 + ark-ff's `Fp::rand`, pinned by the commit / opening /
+whole-proof vectors) -- the `rng: &mut RNG` a Rust caller would pass.  Written per case: the rmp-serde bytes of the `ProverProof`
+(`<name>.proof.bin`, ~6 kB) and a JSON record (seed, sizes, sha256, verifier-index digest).  The `-m gpu` tests make `kh_prove` and the
+Python device prover draw from the same stream and demand the same bytes (tests/test_gpu_proof_fixtures.py); a CPU test re-derives the
+small case and checks the records (tests/test_proof_fixtures.py).
+
+    python tests/golden/make_proof_fixtures.py [name ...]        # minutes per 2^16 case on 16 cores; nothing is read from /root/reference
+"""
+import hashlib
+import json
+import os
+import sys
+import time
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+from oracle import circuit as CC  # noqa: E402
+from oracle import kimchi as K  # noqa: E402
+from oracle import pasta as P  # noqa: E402
+from oracle import prover as OPR  # noqa: E402
+from oracle import views as V  # noqa: E402
+
+OUT = os.path.join(HERE, "proof_fixtures")
+
+# name -> (curve id, log2 of the domain the circuit must land on, log2 of the SRS, seed)
+CASES = {
+    "bench_vesta_2_10": (0, 10, 10, bytes([16, 0] + [42] * 30)),          # small: re-derived by the CPU suite in seconds
+    "bench_vesta_2_16": (0, 16, 16, bytes([16, 0] + [42] * 30)),          # BASELINE config 3
+    "bench_pallas_2_16": (1, 16, 16, bytes([16, 1] + [42] * 30)),         # BASELINE config 5's other half
+    "bench_vesta_2_17_over_2_16": (0, 17, 16, bytes([17, 0] + [42] * 30)),  # 2 chunks, zk_rows 5 (kimchi/src/tests/chunked.rs)
+}
+
+
+def bench_circuit(F, log2_n: int, log_srs: int):
+    """BenchmarkCtx::new(log2_n) (bench.rs:59-96) as an oracle constraint system; over a shorter SRS the zero-knowledge rows grow
+    (constraints.rs:769-771), so the gate count is what still fits: n - zk_rows - 7 (= 2^k - 10 for one chunk)."""
+    p = F.p
+    n = 1 << log2_n
+    nch = 1 << max(0, log2_n - log_srs)
+    zk = (16 * nch + 5) // 7
+    rows = n - zk - 7
+    gates = [CC.generic_gadget(p, r, CC.generic_spec(p, "Const", cst=1)) for r in range(rows)]
+    cs = CC.build(F, gates, max_poly_size=(1 << log_srs) if log_srs < log2_n else None)
+    assert cs["log2_n"] == log2_n and cs["zk_rows"] == zk, (cs["log2_n"], cs["zk_rows"])
+    return cs, rows
+
+
+def make(name: str, verify: bool = True):
+    cid, log2_n, log_srs, seed = CASES[name]
+    C = P.CURVES[cid]; F = C.scalar
+    t0 = time.time()
+    cs, rows = bench_circuit(F, log2_n, log_srs)
+    srs = OPR.Srs(C, 1 << log_srs, threads=OPR.THREADS)
+    ix = OPR.Index(C, cs, srs)
+    t1 = time.time()
+    proof = OPR.create_proof(ix, [[1] * rows for _ in range(15)], P.StdRng(seed))
+    t2 = time.time()
+    raw = OPR.serialize_proof(C, proof)
+    ok = None
+    if verify:
+        ok = bool(K.verify(C, dict(ix.vindex), proof, None, srs.h, P.StdRng(bytes([5] * 32)), final_msm=V.final_msm_c(C, srs.g, srs.size)))
+        assert ok, "the oracle verifier rejects the oracle prover's proof"
+    rec = {"_generated_by": "tests/golden/make_proof_fixtures.py (oracle/prover.py; circuit kimchi/src/bench.rs:59-122, rng StdRng::from_seed(seed))",
+           "name": name, "curve": ["vesta", "pallas"][cid], "log2_n": log2_n, "log2_srs": log_srs, "num_chunks": ix.num_chunks, "zk_rows": cs["zk_rows"],
+           "gates": rows, "witness": "15 columns of ones", "seed_hex": seed.hex(), "proof_len": len(raw), "proof_sha256": hashlib.sha256(raw).hexdigest(),
+           "verifier_index_digest_hex": hex(ix.digest), "accepted_by_oracle_verifier": ok,
+           "challenges_hex": {k: (None if v is None else hex(v)) for k, v in proof["challenges"].items()},
+           "seconds": {"index": round(t1 - t0, 1), "prove": round(t2 - t1, 1)}}
+    os.makedirs(OUT, exist_ok=True)
+    with open(os.path.join(OUT, name + ".proof.bin"), "wb") as f:
+        f.write(raw)
+    with open(os.path.join(OUT, name + ".json"), "w") as f:
+        json.dump(rec, f, indent=1)
+    print(name, rec["proof_len"], "bytes", rec["proof_sha256"][:16], rec["seconds"], flush=True)
+
+
+if __name__ == "__main__":
+    for nm in (sys.argv[1:] or list(CASES)):
+        make(nm)
