@@ -388,6 +388,53 @@ def pair_block(khip, log_n=16, per=4, check_with_oracle=True):
     return res
 
 
+def make_lib_comm(khip, dist, rank, world):
+    """kh_comm_init on every rank over ONE id: rank 0 draws it (kh_comm_unique_id), torch.distributed only carries the 128 bytes."""
+    uid = [khip.Comm.unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(uid, src=0)
+    return khip.Comm(world, rank, uid[0])
+
+
+def other_collective_check(khip, dist, sm, lib_comm, partial, result, rank, world, coll_dev, timeout_s=60.0):
+    """Runs the combine of `partial` through the collective the timed loop did NOT use (in-library RCCL if torch carried the loop, torch's nccl
+    all_gather if KH_BENCH_COMM=lib did) and compares with `result`.  Returns (report, hung)."""
+    import threading
+    from proof_systems_amd import sharded
+    rep = {"backend": "nccl-torch" if lib_comm is not None else "rccl-lib"}
+
+    import torch
+    cuda_dev = torch.cuda.current_device() if coll_dev == "cuda" else None
+
+    def work():
+        try:
+            if cuda_dev is not None:
+                torch.cuda.set_device(cuda_dev)        # the current device is per thread: a fresh thread would use cuda:0 on every rank
+            t0 = time.perf_counter()
+            comm = None if lib_comm is not None else make_lib_comm(khip, dist, rank, world)
+            rep["init_s"] = time.perf_counter() - t0
+            other = sharded.RankShardedMsm.__new__(sharded.RankShardedMsm)
+            other.curve, other.dist, other.coll_device, other.rank, other.world = sm.curve, dist, coll_dev, rank, world
+            other.comm, other.always_collective, other.engine, other.collective_backend = comm, True, sm.engine, None
+            o, i = other.combine(*partial)
+            ts = []
+            for _ in range(20):
+                t0 = time.perf_counter(); other.combine(*partial); ts.append(time.perf_counter() - t0)
+            rep["combine_us_median"] = 1e6 * float(np.median(ts))
+            rep["ran"] = other.collective_backend
+            rep["same_point_as_timed_collective"] = bool(bool(i[0]) == result[1] and (result[1] or np.array_equal(o[0], result[0])))
+            if comm is not None:
+                comm.free()
+        except Exception as e:                        # noqa: BLE001 -- reported in the line, the measurement stands
+            rep["error"] = "%s: %s" % (type(e).__name__, e)
+    th = threading.Thread(target=work, daemon=True)
+    th.start()
+    th.join(timeout_s)
+    if th.is_alive():
+        rep["error"] = "timed out after %.0f s inside the collective" % timeout_s
+        return rep, True
+    return rep, False
+
+
 def oracle_verifies(khip, ix, proof):
     """Checker leg (never timed): oracle/kimchi.py restates the reference verifier; the final MSM runs in the C oracle."""
     from oracle import kimchi as K
@@ -487,9 +534,15 @@ def main():
     dist = None
     coll_dev = "cpu"
     backend = None
-    if world > 1:
+    # KH_BENCH_FORCE_COLLECTIVE=1: form the process group and run the combine's collective even in a world of ONE -- how the 1-GPU box
+    # exercises the RCCL call paths (torch's `nccl` all-gather of device tensors, and the in-library kh_comm_* one) that N > 1 uses
+    force_coll = os.environ.get("KH_BENCH_FORCE_COLLECTIVE", "0") not in ("", "0")
+    if world > 1 or force_coll:
         import torch.distributed as dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            import socket
+            s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); os.environ["MASTER_PORT"] = str(s_.getsockname()[1]); s_.close()
         # KH_BENCH_BACKEND=gloo lets several ranks share ONE GPU (functional check of the N>1 path on a single-GPU box);
         # the driver's multi-GPU runs use nccl (= RCCL over xGMI) with one GPU per rank
         backend = os.environ.get("KH_BENCH_BACKEND", "nccl")
@@ -511,13 +564,23 @@ def main():
     # bases: this rank's point range of SRS::<curve>::create(total).g, generated and table-expanded on its own GPU
     t0 = time.perf_counter()
     CID = khip.VESTA if args.curve == "vesta" else khip.PALLAS
-    sm = sharded.RankShardedMsm(CID, total, dist=dist, coll_device=coll_dev, engine=sharded.KhipEngine(dev), rank=rank, world=world)
+    # KH_BENCH_COMM=lib: the combine of the timed loop through the library's OWN collective (kh_comm_allgather_points + kh_points_sum = what
+    # kh_msm_allreduce does and a Rust / C caller gets; librccl by dlopen, no torch in the data path) instead of torch.distributed's all_gather
+    lib_comm = None
+    if os.environ.get("KH_BENCH_COMM", "torch") == "lib" and dist is not None:
+        khip.init(dev)
+        lib_comm = make_lib_comm(khip, dist, rank, world)
+    sm = sharded.RankShardedMsm(CID, total, dist=dist, coll_device=coll_dev, engine=sharded.KhipEngine(dev), rank=rank, world=world, comm=lib_comm,
+                                always_collective=force_coll)
     srs, n = sm.shard, sm.count
     t_gen = time.perf_counter() - t0
     sc = rand_scalars(np.random.default_rng(1234 + rank), n)
     d_sc = khip.DevBuf(sc.nbytes).upload(sc)
 
+    last_partial = [None]
+
     def combine(out, inf):
+        last_partial[0] = (np.array(out[:1], dtype=np.uint64).reshape(1, 8), np.array(inf[:1], dtype=np.uint8).reshape(1))
         o, i = sm.combine(out[:1], inf[:1])          # all-gather of the partial sums + local fold (no-op at N = 1)
         return o[0], bool(i[0])
 
@@ -578,7 +641,8 @@ def main():
         "data": "synthetic",
         "config": {"workload": ("msm_2^%d_%s_srs" % (args.log_n, args.curve)) + ("_sharded" if args.strong else ""), "points_per_gpu": n, "points_total": total,
                    "bases": "SRS::<%s>::create" % args.curve.capitalize(),
-                   "scalars": "uniform 254-bit, seed 1234+rank", "parallelism": "point-range x%d" % world, "collective_backend": backend, "world_size_seen": world},
+                   "scalars": "uniform 254-bit, seed 1234+rank", "parallelism": "point-range x%d" % world,
+                   "collective_backend": sm.collective_backend, "process_group_backend": backend, "world_size_seen": world},
         "latency_value": total / (latency * 1e-3) / 1e6, "latency_note": "one MSM at a time (submit -> wait -> combine): `value` keeps 4 in flight",
         "ms_per_step_synchronous": latency, "msm_in_flight": depth,
         "roofline": roofline_block(kname, acc, n, args.log_n) if not args.strong else roofline_block(kname, acc, n, -1),
@@ -620,8 +684,18 @@ def main():
         if not args.no_pair:
             line["prover"]["pair"] = pair_block(khip, check_with_oracle=not args.no_cpu_baseline)
 
+    # Both collectives in ONE run: whichever did not carry the timed loop repeats the last step's combine afterwards (never timed into `value`) and
+    # must land on the same point -- the driver's N > 1 runs thereby execute the in-library RCCL path too.  Guarded by a watchdog: a collective
+    # that hangs costs the check, not the line.
+    hung = False
+    if dist is not None and backend == "nccl" and last_partial[0] is not None:
+        line["other_collective"], hung = other_collective_check(khip, dist, sm, lib_comm, last_partial[0], result, rank, world, coll_dev)
     if rank == 0:
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
+    if hung:
+        os._exit(0)                                   # a thread is stuck inside a collective: no orderly teardown is possible
+    if lib_comm is not None:
+        lib_comm.free()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -236,15 +236,20 @@ static hipStream_t thread_copy_stream() {
 
 // kh_dev_alloc / kh_dev_free go through a small caching pool: hipFree synchronises the device and takes ~0.25 ms, and a prover frees
 // ~15 column buffers per proof (3.8 ms of a 16 ms proof, measured with cProfile on proof_systems_amd/prover.py).  Freed blocks are
-// kept per device, keyed by their (4 KiB-rounded) size, and handed out again to a request of nearly that size; reuse is safe because
-// every consumer of such buffers is either synchronous or ordered on the context's main stream.  kh_trim empties the pool;
+// kept per device, keyed by their (4 KiB-rounded) size, and handed out again to a request of nearly that size.  Within ONE context reuse is
+// safe because every consumer of such buffers is either synchronous or ordered on that context's main stream.  Across contexts
+// (kh_private_context_begin gives every prover thread its own streams) it is not: thread A may free a block with work still queued on its
+// main stream and thread B would write into it from another stream.  A cached block therefore remembers the context that freed it; a request
+// prefers a block of its own context, and one that takes another context's block first makes its main stream wait for an event recorded on
+// the previous owner's main stream (everything that owner queued before the free precedes the event).  kh_trim empties the pool;
 // KH_POOL_MAX_MB (default 2048: a 2^16 proof cycles ~0.6 GiB of column buffers) bounds what it may hold, KH_POOL_MAX_MB=0 disables it.
 // A co-tenant of the process (PyTorch's allocator) that runs short of memory can ask for the cached blocks back with kh_trim(); the
 // library itself trims before reporting an allocation failure.
 namespace {
 struct DevPool {
     std::mutex mu;
-    std::multimap<size_t, void*> free_blocks[KH_MAX_DEVICES];
+    struct Block { void* p; kh::Context* owner; };
+    std::multimap<size_t, Block> free_blocks[KH_MAX_DEVICES];
     std::map<void*, std::pair<int, size_t>> live;          // pointer -> (device, rounded size)
     size_t cached[KH_MAX_DEVICES] = {0};
 };
@@ -255,7 +260,7 @@ static void dev_pool_trim(int device) {
     DevPool& P = dev_pool();
     std::lock_guard<std::mutex> lk(P.mu);
     const int d = device >= 0 && device < KH_MAX_DEVICES ? device : 0;
-    for (auto& kv : P.free_blocks[d]) (void)hipFree(kv.second);
+    for (auto& kv : P.free_blocks[d]) (void)hipFree(kv.second.p);
     P.free_blocks[d].clear(); P.cached[d] = 0;
 }
 
@@ -317,12 +322,16 @@ int kh_private_context_begin(void) {
     if (!c) {
         c = new (std::nothrow) Context;
         KH_REQUIRE(c, "out of memory");
-        if ((rc = bind_thread(dev)) || (rc = init_context(*c, dev))) { std::lock_guard<std::mutex> lk(g_ctx_mu); g_private_pool[dev].push_back(c); return rc; }
     }
+    // init_context is idempotent (C.ready): a context that came back from the pool or the thread's cache half-initialised -- an earlier begin failed
+    // part-way -- is completed here instead of being used with null streams.  Whatever fails below, the context goes back to the pool (never lost).
+    auto give_back = [&](int status) { std::lock_guard<std::mutex> lk(g_ctx_mu); g_private_pool[dev].push_back(c); return status; };
+    if ((rc = bind_thread(dev)) || (rc = init_context(*c, dev))) return give_back(rc);
     {   // whatever the caller queued on the shared context's main stream (uploads, index columns) is ordered before this context's work
         std::lock_guard<std::mutex> lk(S.mu);
-        KH_HIP(hipEventRecord(S.order_ev, S.stream));
-        KH_HIP(hipStreamWaitEvent(c->stream, S.order_ev, 0));
+        hipError_t e = hipEventRecord(S.order_ev, S.stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, S.order_ev, 0);
+        if (e != hipSuccess) { set_error("kh_private_context_begin: ordering behind the shared context failed: %s", hipGetErrorString(e)); return give_back(KH_E_DEVICE); }
     }
     c->mark_async();                                      // ... and this context's side slots wait for its main stream in turn
     tl_private[dev] = c;
@@ -536,6 +545,7 @@ static int free_slot(Context& C) {
 // is itself blocked in here (or is the caller) -- nobody is left to call kh_msm_wait.
 static int acquire_slot(std::unique_lock<std::mutex>* lk, Context& C, bool side_first = false) {
     const auto me = std::this_thread::get_id();
+    const auto t_start = std::chrono::steady_clock::now();
     for (;;) {
         int si = -1;
         if (side_first) for (int i = MSM_SLOTS - 1; i >= 1; i--) if (!C.slot[i].busy) { si = i; break; }
@@ -547,8 +557,12 @@ static int acquire_slot(std::unique_lock<std::mutex>* lk, Context& C, bool side_
                 if (C.slot[i].busy && C.slot[i].owner != me && !C.blocked_owners.count(C.slot[i].owner)) progress = true;
             if (!progress) return -1;
         }
+        // A slot whose owner leaked its ticket (an exception between kh_msm_submit and kh_msm_wait, a thread that exited) never frees: after a
+        // long deadline -- far beyond any MSM, KH_SLOT_WAIT_S, default 30 s -- give up with an error instead of hanging every later caller.
+        static const long slot_wait_s = getenv("KH_SLOT_WAIT_S") ? atol(getenv("KH_SLOT_WAIT_S")) : 30;
+        if (std::chrono::steady_clock::now() - t_start > std::chrono::seconds(slot_wait_s)) return -2;
         C.blocked_owners.insert(me);
-        C.cv.wait_for(*lk, std::chrono::milliseconds(50));  // (the time-out only re-evaluates the deadlock test; it never gives up)
+        C.cv.wait_for(*lk, std::chrono::milliseconds(50));  // (the time-out re-evaluates the deadlock test and the deadline)
         C.blocked_owners.erase(C.blocked_owners.find(me));
     }
 }
@@ -559,7 +573,7 @@ static int msm_submit_locked(Context& C, kh_srs_t* srs, int basis, unsigned chun
     KH_REQUIRE(offset <= b.n, "offset %zu beyond basis length %zu", offset, b.n);
     size_t use = n < b.n - offset ? n : b.n - offset;      // msm_bigint semantics: min(len) pairs
     int si = acquire_slot(lk, C);
-    KH_REQUIRE(si >= 0, "all %d MSM pipeline slots hold an un-waited job (kh_msm_wait first)", MSM_SLOTS);
+    KH_REQUIRE(si >= 0, "all %d MSM pipeline slots hold an un-waited job (kh_msm_wait first; a ticket whose owner never waits blocks later callers for KH_SLOT_WAIT_S, default 30 s, then fails them)", MSM_SLOTS);
     if (lk && (rc = resolve_basis(srs, basis, chunk, b))) return rc;     // acquire_slot may have dropped the lock: the basis map can have changed
     MsmSlot& S = C.slot[si];
     const uint64_t* sdev = scalars;
@@ -684,7 +698,7 @@ static int msm_common(kh_srs_t* srs, int basis, unsigned chunk, size_t offset, c
     auto run = [&]() -> int {
         MsmBasis b; int r;
         int si = acquire_slot(&lk, C);
-        KH_REQUIRE(si >= 0, "all %d MSM pipeline slots hold an un-waited job (kh_msm_wait first)", MSM_SLOTS);
+        KH_REQUIRE(si >= 0, "all %d MSM pipeline slots hold an un-waited job (kh_msm_wait first; a ticket whose owner never waits blocks later callers for KH_SLOT_WAIT_S, default 30 s, then fails them)", MSM_SLOTS);
         if ((r = resolve_basis(srs, basis, chunk, b))) return r;         // after the wait: the lock was dropped meanwhile
         MsmSlot& S = C.slot[si];
         if ((r = S.ws_scalars.reserve(kk * n * 32))) return r;
@@ -809,7 +823,7 @@ int kh_msm_points_batch(int curve, const uint64_t* xy, const uint8_t* inf, const
     if (n == 0 || k == 0) { for (size_t j = 0; j < k; j++) { memset(out_xy + 8 * j, 0, 64); out_is_inf[j] = 1; } return KH_OK; }
     const size_t tot = n * k;
     int si = acquire_slot(&lk, C);
-    KH_REQUIRE(si >= 0, "all %d MSM pipeline slots hold an un-waited job (kh_msm_wait first)", MSM_SLOTS);
+    KH_REQUIRE(si >= 0, "all %d MSM pipeline slots hold an un-waited job (kh_msm_wait first; a ticket whose owner never waits blocks later callers for KH_SLOT_WAIT_S, default 30 s, then fails them)", MSM_SLOTS);
     MsmSlot& S = C.slot[si];
     if ((rc = S.ws_points.reserve(tot * 64 + tot))) return rc;
     if ((rc = S.ws_scalars.reserve(tot * 32))) return rc;
@@ -1487,7 +1501,7 @@ int kh_ipa_round_lr(kh_ipa_t* st, const uint64_t rand_l[4], const uint64_t rand_
     Context& C = ctx();
     std::unique_lock<std::mutex> lk(C.mu);
     int si = acquire_slot(&lk, C, /*side_first=*/true);
-    KH_REQUIRE(si >= 0, "all %d MSM pipeline slots hold an un-waited job (kh_msm_wait first)", MSM_SLOTS);
+    KH_REQUIRE(si >= 0, "all %d MSM pipeline slots hold an un-waited job (kh_msm_wait first; a ticket whose owner never waits blocks later callers for KH_SLOT_WAIT_S, default 30 s, then fails them)", MSM_SLOTS);
     MsmSlot& S = C.slot[si];
     KH_HIP(hipStreamWaitEvent(S.stream, st->ev, 0));
     const int p = st->pp, q = p ^ 1;
@@ -1535,7 +1549,7 @@ static int ipa_finish_impl(kh_ipa_t* st, uint64_t a0[4], uint64_t b0[4], uint64_
     Context& C = ctx();
     std::unique_lock<std::mutex> lk(C.mu);
     int si = acquire_slot(&lk, C);
-    KH_REQUIRE(si >= 0, "all %d MSM pipeline slots hold an un-waited job (kh_msm_wait first)", MSM_SLOTS);
+    KH_REQUIRE(si >= 0, "all %d MSM pipeline slots hold an un-waited job (kh_msm_wait first; a ticket whose owner never waits blocks later callers for KH_SLOT_WAIT_S, default 30 s, then fails them)", MSM_SLOTS);
     MsmSlot& S = C.slot[si];
     KH_HIP(hipStreamWaitEvent(S.stream, st->ev, 0));
     int rc;
@@ -1831,11 +1845,26 @@ int kh_dev_alloc(void** ptr, size_t bytes) {
     const int d = ctx().device >= 0 && ctx().device < KH_MAX_DEVICES ? ctx().device : 0;
     DevPool& P = dev_pool();
     {
-        std::lock_guard<std::mutex> lk(P.mu);
-        auto it = P.free_blocks[d].lower_bound(want);
-        if (it != P.free_blocks[d].end() && it->first <= want + want / 4) {
-            *ptr = it->second; P.live[*ptr] = {d, it->first}; P.cached[d] -= it->first;
+        Context* const me = &ctx_of(d);
+        Context* prev = nullptr;
+        std::unique_lock<std::mutex> lk(P.mu);
+        auto lo = P.free_blocks[d].lower_bound(want), it = P.free_blocks[d].end();
+        for (auto c = lo; c != P.free_blocks[d].end() && c->first <= want + want / 4; ++c) {
+            if (it == P.free_blocks[d].end()) it = c;                      // the tightest fit, unless a block of this context fits too
+            if (c->second.owner == me) { it = c; break; }
+        }
+        if (it != P.free_blocks[d].end()) {
+            *ptr = it->second.p; prev = it->second.owner; P.live[*ptr] = {d, it->first}; P.cached[d] -= it->first;
             P.free_blocks[d].erase(it);
+            lk.unlock();
+            if (prev && prev != me) {                                      // another context's block: order this context behind that one's queued work
+                static thread_local hipEvent_t hand_over[KH_MAX_DEVICES] = {nullptr};
+                if (!hand_over[d]) KH_HIP(hipEventCreateWithFlags(&hand_over[d], hipEventDisableTiming));
+                std::lock_guard<std::mutex> g(me->mu);
+                KH_HIP(hipEventRecord(hand_over[d], prev->stream));         // (main streams are never captured into a graph: recording from here is fine)
+                KH_HIP(hipStreamWaitEvent(me->stream, hand_over[d], 0));
+                me->mark_async();                                          // ... and this context's side slots behind its main stream
+            }
             return KH_OK;
         }
     }
@@ -1858,7 +1887,7 @@ int kh_dev_free(void* ptr) {
         if (it != P.live.end()) {
             const int d = it->second.first; const size_t sz = it->second.second;
             P.live.erase(it);
-            if (P.cached[d] + sz <= pool_limit()) { P.free_blocks[d].emplace(sz, ptr); P.cached[d] += sz; return KH_OK; }
+            if (P.cached[d] + sz <= pool_limit()) { P.free_blocks[d].emplace(sz, DevPool::Block{ptr, &ctx_of(d)}); P.cached[d] += sz; return KH_OK; }
         }
     }
     KH_HIP(hipFree(ptr));

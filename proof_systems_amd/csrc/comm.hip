@@ -5,9 +5,10 @@
 // with the full single-GPU pipeline; what has to cross GPUs is ONE point per rank and MSM (72 bytes).  RCCL has no elliptic-curve reduction
 // operator, so "all-reduce" = ncclAllGather of the partial points + a local fold (kh_points_sum) on every rank -- latency-bound, one collective
 // per batch of MSMs.  (Several handles in ONE process need no collective at all: kh_msm_sharded.)  librccl is resolved with dlopen at
-// kh_comm_init, so the library has no link-time dependency on it and single-GPU users never load it.
+// kh_comm_init, so the library has no link-time dependency on it and single-GPU users never load it -- and no BUILD-time dependency either:
+// the five entry points and the few types they take are declared here (RCCL keeps NCCL's stable C ABI: rccl.h, "ncclUniqueId",
+// "ncclDataType_t", "ncclResult_t"), so a ROCm install without the RCCL headers still builds the library.
 #include <dlfcn.h>
-#include <rccl/rccl.h>
 
 #include "common.hpp"
 #include "msm.hpp"
@@ -15,6 +16,13 @@
 using namespace kh;
 
 namespace {
+// ---- the slice of the NCCL / RCCL C ABI this file uses
+typedef struct ncclComm* ncclComm_t;
+#define NCCL_UNIQUE_ID_BYTES 128
+typedef struct { char internal[NCCL_UNIQUE_ID_BYTES]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;                       // any other value is an error; the text comes from ncclGetErrorString
+typedef enum { ncclUint64 = 5 } ncclDataType_t;                      // (ncclInt8 0, ncclUint8 1, ncclInt32 2, ncclUint32 3, ncclInt64 4, ncclUint64 5, ...)
+
 struct Rccl {
     void* lib = nullptr;
     ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;

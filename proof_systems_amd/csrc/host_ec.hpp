@@ -82,7 +82,7 @@ struct Fld {
     fe sqr(const fe& a) const { return mul(a, a); }
     fe from_mont(const fe& a) const { fe one = {{1, 0, 0, 0}}; return mul(a, one); }
     fe to_mont(const fe& a) const { return mul(a, f.r2); }
-    fe inv(const fe& a) const {           // a^(p-2)
+    fe inv_fermat(const fe& a) const {    // a^(p-2): the definition; kept as the cross-check of inv() (tests/cpp/test_host_inv.cpp)
         fe e = f.p; e.l[0] -= 2;
         fe acc = f.one, base = a;
         for (int i = 0; i < 255; i++) {
@@ -90,6 +90,105 @@ struct Fld {
             base = sqr(base);
         }
         return acc;
+    }
+    // Inversion by batched division steps (Bernstein-Yang "safegcd", variable time -- nothing here is secret-dependent in a way that
+    // matters: the prover's transcript values are public): 62 divsteps at a time on the low words of (f, g) give a 2 x 2 transition
+    // matrix, which is applied to the full-width (f, g) and, modulo p, to (d, e); ~10 batches of ~62 cheap word steps + 10 small
+    // matrix-vector updates against ~315 Montgomery products for a^(p-2): ~1.5 us instead of ~8 us.  An opening round waits for two
+    // sequential inversions (L, R -> affine, then 1/u), a proof for ~50.  0 -> 0, like the exponentiation.
+    // Input and output in Montgomery form: inv(aR) as integers is a^-1 R^-1, and one product with R^3 makes it a^-1 R.
+    struct s62 { int64_t v[5]; };
+    static s62 to_s62(const fe& a) {
+        const u64 M = ~0ull >> 2;
+        s62 r;
+        r.v[0] = (int64_t)(a.l[0] & M);
+        r.v[1] = (int64_t)(((a.l[0] >> 62) | (a.l[1] << 2)) & M);
+        r.v[2] = (int64_t)(((a.l[1] >> 60) | (a.l[2] << 4)) & M);
+        r.v[3] = (int64_t)(((a.l[2] >> 58) | (a.l[3] << 6)) & M);
+        r.v[4] = (int64_t)(a.l[3] >> 56);
+        return r;
+    }
+    fe inv(const fe& a) const {
+        typedef __int128 i128;
+        const u64 M62 = ~0ull >> 2;
+        const s62 P = to_s62(f.p);
+        // p^-1 mod 2^62 (Newton: each step doubles the number of correct low bits; p is odd)
+        u64 pinv = f.p.l[0];
+        for (int k = 0; k < 6; k++) pinv *= 2 - f.p.l[0] * pinv;
+        pinv &= M62;
+        s62 F = P, G = to_s62(a), D = {{0, 0, 0, 0, 0}}, E = {{1, 0, 0, 0, 0}};
+        int64_t eta = -1;                                   // eta = -delta of the paper, delta = 1 at the start
+        for (int round = 0; round < 16; round++) {          // <= 12 rounds of 62 steps suffice for 256-bit inputs (741 steps); 16 is slack
+            // ---- 62 division steps on the low words
+            u64 u = 1, v = 0, q = 0, r = 1, fl = (u64)F.v[0] | ((u64)F.v[1] << 62), gl = (u64)G.v[0] | ((u64)G.v[1] << 62);
+            for (int i = 62;;) {
+                const int zeros = __builtin_ctzll(gl | (~0ull << i));
+                gl >>= zeros; u <<= zeros; v <<= zeros; eta -= zeros; i -= zeros;
+                if (i == 0) break;
+                if (eta < 0) {                              // delta > 0 and g odd: (f, g) <- (g, -f)
+                    eta = -eta;
+                    u64 t = fl; fl = gl; gl = 0 - t;
+                    t = u; u = q; q = 0 - t;
+                    t = v; v = r; r = 0 - t;
+                }
+                gl += fl; q += u; r += v;                   // g <- g + f (both odd): even, halved by the next shift
+            }
+            const int64_t U = (int64_t)u, V = (int64_t)v, Q = (int64_t)q, R = (int64_t)r;
+            // ---- (d, e) <- T (d, e) / 2^62 mod p, kept in (-2p, p)
+            {
+                const int64_t sd = D.v[4] >> 63, se = E.v[4] >> 63;
+                int64_t md = (U & sd) + (V & se), me = (Q & sd) + (R & se);
+                i128 cd = (i128)U * D.v[0] + (i128)V * E.v[0], ce = (i128)Q * D.v[0] + (i128)R * E.v[0];
+                md -= (int64_t)((pinv * (u64)cd + (u64)md) & M62);
+                me -= (int64_t)((pinv * (u64)ce + (u64)me) & M62);
+                cd += (i128)P.v[0] * md; ce += (i128)P.v[0] * me;
+                cd >>= 62; ce >>= 62;                       // the low 62 bits are zero by the choice of md, me
+                for (int k = 1; k < 5; k++) {
+                    cd += (i128)U * D.v[k] + (i128)V * E.v[k] + (i128)P.v[k] * md;
+                    ce += (i128)Q * D.v[k] + (i128)R * E.v[k] + (i128)P.v[k] * me;
+                    D.v[k - 1] = (int64_t)((u64)cd & M62); cd >>= 62;
+                    E.v[k - 1] = (int64_t)((u64)ce & M62); ce >>= 62;
+                }
+                D.v[4] = (int64_t)cd; E.v[4] = (int64_t)ce;
+            }
+            // ---- (f, g) <- T (f, g) / 2^62 (exact)
+            {
+                i128 cf = (i128)U * F.v[0] + (i128)V * G.v[0], cg = (i128)Q * F.v[0] + (i128)R * G.v[0];
+                cf >>= 62; cg >>= 62;
+                for (int k = 1; k < 5; k++) {
+                    cf += (i128)U * F.v[k] + (i128)V * G.v[k];
+                    cg += (i128)Q * F.v[k] + (i128)R * G.v[k];
+                    F.v[k - 1] = (int64_t)((u64)cf & M62); cf >>= 62;
+                    G.v[k - 1] = (int64_t)((u64)cg & M62); cg >>= 62;
+                }
+                F.v[4] = (int64_t)cf; G.v[4] = (int64_t)cg;
+            }
+            if ((G.v[0] | G.v[1] | G.v[2] | G.v[3] | G.v[4]) == 0) break;
+        }
+        // f = +-gcd.  gcd = p only for a = 0 (p is prime): the inverse of 0 is reported as 0, like a^(p-2)
+        const bool fneg = F.v[4] < 0;
+        {
+            s62 T = F;
+            if (fneg) { int64_t c = 0; for (int k = 0; k < 5; k++) { int64_t x = -T.v[k] + c; if (k < 4) { c = x >> 62; x &= (int64_t)M62; } T.v[k] = x; } }
+            if (!(T.v[0] == 1 && (T.v[1] | T.v[2] | T.v[3] | T.v[4]) == 0)) { fe z = {{0, 0, 0, 0}}; return z; }
+        }
+        // d (or -d if f = -1) into [0, p): d is in (-2p, p)
+        s62 X = D;
+        if (fneg) for (int k = 0; k < 5; k++) X.v[k] = -X.v[k];
+        for (int pass = 0; pass < 3; pass++) {              // carry-normalise, then add p while negative
+            int64_t c = 0;
+            for (int k = 0; k < 4; k++) { const int64_t x = X.v[k] + c; c = x >> 62; X.v[k] = x & (int64_t)M62; }
+            X.v[4] += c;
+            if (X.v[4] >= 0) break;
+            for (int k = 0; k < 5; k++) X.v[k] += P.v[k];
+        }
+        fe t;
+        t.l[0] = (u64)X.v[0] | ((u64)X.v[1] << 62);
+        t.l[1] = ((u64)X.v[1] >> 2) | ((u64)X.v[2] << 60);
+        t.l[2] = ((u64)X.v[2] >> 4) | ((u64)X.v[3] << 58);
+        t.l[3] = ((u64)X.v[3] >> 6) | ((u64)X.v[4] << 56);
+        while (geq(t, f.p)) sub_n(t, t, f.p);
+        return mul(t, mul(f.r2, f.r2));                     // a^-1 R^-1 (as an integer) x R^3 -> Montgomery form of a^-1
     }
 };
 

@@ -466,6 +466,11 @@ __device__ __forceinline__ bool grid_barrier(u32* ctr, u32 target, u32* abort_de
     // it).  Everything another block wrote is read with coherent (agent-scope, sc1) loads instead: coh_load below.
 }
 __device__ __forceinline__ u32 coh_load(const u32* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// A k_sort_fused launch that gave up at a barrier leaves off / toff / entries / the big-bucket list partly written -- on the first job of a
+// process that is uninitialised hipMalloc memory, and a garbage 31-bit entry index would read far out of bounds before the host ever sees
+// *host_abort.  Every kernel queued behind a fused sort that INDEXES through those arrays therefore gets the sort's abort word and leaves at
+// once when it is set (the marginal kernels read fixed ranges of the bucket array: garbage in, garbage out, and msm_finish redoes the job).
+__device__ __forceinline__ bool sort_gave_up(const u32* abort_dev) { return abort_dev && coh_load(abort_dev) != 0u; }
 // exclusive prefix of v over the block's 1024 threads; *total = the block sum (sh: >= 16 words)
 __device__ __forceinline__ u32 block_scan_1024(u32 v, u32* sh, u32* total) {
     const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -655,8 +660,9 @@ template <class BF>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(112)))
 k_accumulate(const u32* __restrict__ entries, const u32* __restrict__ off, const u32* __restrict__ toff,
              const u32* __restrict__ roff, const u32* __restrict__ order,
-             size_t nkeys, const uint8_t* __restrict__ pts, uint8_t* __restrict__ partial, const u32* __restrict__ only) {
+             size_t nkeys, const uint8_t* __restrict__ pts, uint8_t* __restrict__ partial, const u32* __restrict__ only, const u32* __restrict__ abort_dev) {
     KH_HIGH_PRIO();
+    if (sort_gave_up(abort_dev)) return;
   // `only` = the hand-over list of k_accumulate29 ([0] = count, then task ids): a small persistent grid walks it (almost always
   // empty -- a full-size grid of early-exit blocks took 0.6 ms to drain underneath the next job's accumulation)
   const size_t first = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = only ? (size_t)gridDim.x * blockDim.x : 0;
@@ -704,7 +710,8 @@ template <class BF>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(112), amdgpu_waves_per_eu(4, 4)))
 k_accumulate29(const u32* __restrict__ entries, const u32* __restrict__ off, const u32* __restrict__ toff,
                const u32* __restrict__ roff, const u32* __restrict__ order,
-               size_t nkeys, const uint8_t* __restrict__ pts, uint8_t* __restrict__ partial, u32* __restrict__ handed) {
+               size_t nkeys, const uint8_t* __restrict__ pts, uint8_t* __restrict__ partial, u32* __restrict__ handed, const u32* __restrict__ abort_dev) {
+    if (sort_gave_up(abort_dev)) return;
     const size_t t0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     u32 NT = roff[nkeys];
     if (t0 >= NT) return;
@@ -751,8 +758,9 @@ static constexpr u32 CHUNK = 128;            // partials per chunk item = 8 per 
 template <class BF>
 __global__ void __launch_bounds__(256)
 k_bucket_sum(const u32* __restrict__ toff, size_t nkeys, const uint8_t* __restrict__ partial,
-             uint8_t* __restrict__ buckets, u32* __restrict__ big, size_t cap, u32 SMALL_NT) {
+             uint8_t* __restrict__ buckets, u32* __restrict__ big, size_t cap, u32 SMALL_NT, const u32* __restrict__ abort_dev) {
     KH_HIGH_PRIO();
+    if (sort_gave_up(abort_dev)) return;
     size_t key = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (key >= nkeys) return;
     u32 t0 = toff[key], nt = toff[key + 1] - t0;
@@ -785,8 +793,9 @@ __device__ __forceinline__ Xyzz<F> shfl_down(const Xyzz<F>& a, int delta) {
 template <class BF>
 __global__ void __launch_bounds__(64)
 k_bucket_chunk(const u32* __restrict__ toff, const uint8_t* __restrict__ partial, const u32* __restrict__ big, size_t cap,
-               uint8_t* __restrict__ chunk_out) {
+               uint8_t* __restrict__ chunk_out, const u32* __restrict__ abort_dev) {
     KH_HIGH_PRIO();
+    if (sort_gave_up(abort_dev)) return;
     // one wave = 16 quads per chunk item; every addition is the lane-cooperative one (coop.cuh): 8 sequential + 4 tree levels
     u32 nitems = big[1];
     const u32 quad = threadIdx.x >> 2;
@@ -803,8 +812,9 @@ k_bucket_chunk(const u32* __restrict__ toff, const uint8_t* __restrict__ partial
 template <class BF>
 __global__ void __launch_bounds__(256)
 k_bucket_big(const u32* __restrict__ toff, const uint8_t* __restrict__ chunk_out, uint8_t* __restrict__ buckets,
-             const u32* __restrict__ big, size_t cap) {
+             const u32* __restrict__ big, size_t cap, const u32* __restrict__ abort_dev) {
     KH_HIGH_PRIO();
+    if (sort_gave_up(abort_dev)) return;
     // one 256-thread block = 64 quads per hot bucket: a bucket holding 2^20 entries has ~1000 chunk sums
     __shared__ u32 sh[4 * 32];
     u32 nbig = big[0];
@@ -965,8 +975,9 @@ k_marginal_fin(const uint8_t* __restrict__ marg, MargGeom g, uint8_t* __restrict
 template <class BF>
 __global__ void __launch_bounds__(256)
 k_bucket_sum_q(const u32* __restrict__ toff, size_t nkeys, const uint8_t* __restrict__ partial,
-               uint8_t* __restrict__ buckets, u32* __restrict__ big, size_t cap, u32 SMALL_NT) {
+               uint8_t* __restrict__ buckets, u32* __restrict__ big, size_t cap, u32 SMALL_NT, const u32* __restrict__ abort_dev) {
     KH_HIGH_PRIO();
+    if (sort_gave_up(abort_dev)) return;
     size_t key = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
     const bool live = key < nkeys;
     if (!live) key = nkeys - 1;
@@ -1416,6 +1427,7 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
     }
     // 5 accumulate: the lazy 29-bit-limb kernel, then the exact kernel over the (almost always zero) tasks it handed over
     static const bool acc29 = !(getenv("KH_ACC29") && atoi(getenv("KH_ACC29")) == 0);
+    const u32* abort_dev = fused ? C.ws_sync.as<u32>() + 2 + 2 * FUSED_B + 32 : nullptr;     // the fused sort's give-up word (sort_gave_up)
     const u32* handed = acc29 ? C.ws_handed.as<u32>() : nullptr;
     const dim3 agrid((unsigned)((max_tasks + 255) / 256));
     if (acc29) {
@@ -1423,24 +1435,24 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
         if (C.timer.enabled && C.timer.created && !gcap.active) {     // the dominant kernel's own start / stop timestamps (bench.py roofline)
             hipExtLaunchKernelGGL(kern, agrid, dim3(256), 0, s, C.timer.k0, C.timer.k1, 0,
                                   C.ws_entries.as<u32>(), C.ws_off.as<u32>(), C.ws_toff.as<u32>(), roff, order, nkeys,
-                                  (const uint8_t*)basis.pts, C.ws_partial.as<uint8_t>(), C.ws_handed.as<u32>());
+                                  (const uint8_t*)basis.pts, C.ws_partial.as<uint8_t>(), C.ws_handed.as<u32>(), abort_dev);
             C.timer.kname = "k_accumulate29";
         } else
         hipLaunchKernelGGL(kern, agrid, dim3(256), 0, s,
                            C.ws_entries.as<u32>(), C.ws_off.as<u32>(), C.ws_toff.as<u32>(), roff, order, nkeys,
-                           (const uint8_t*)basis.pts, C.ws_partial.as<uint8_t>(), C.ws_handed.as<u32>());
+                           (const uint8_t*)basis.pts, C.ws_partial.as<uint8_t>(), C.ws_handed.as<u32>(), abort_dev);
         hipLaunchKernelGGL((k_accumulate<BF>), dim3(128), dim3(256), 0, s,
                            C.ws_entries.as<u32>(), C.ws_off.as<u32>(), C.ws_toff.as<u32>(), roff, order, nkeys,
-                           (const uint8_t*)basis.pts, C.ws_partial.as<uint8_t>(), handed);
+                           (const uint8_t*)basis.pts, C.ws_partial.as<uint8_t>(), handed, abort_dev);
     } else if (C.timer.enabled && C.timer.created && !gcap.active) {
         hipExtLaunchKernelGGL((k_accumulate<BF>), agrid, dim3(256), 0, s, C.timer.k0, C.timer.k1, 0,
                               C.ws_entries.as<u32>(), C.ws_off.as<u32>(), C.ws_toff.as<u32>(), roff, order, nkeys,
-                              (const uint8_t*)basis.pts, C.ws_partial.as<uint8_t>(), handed);
+                              (const uint8_t*)basis.pts, C.ws_partial.as<uint8_t>(), handed, abort_dev);
         C.timer.kname = "k_accumulate";
     } else
     hipLaunchKernelGGL((k_accumulate<BF>), agrid, dim3(256), 0, s,
                        C.ws_entries.as<u32>(), C.ws_off.as<u32>(), C.ws_toff.as<u32>(), roff, order, nkeys,
-                       (const uint8_t*)basis.pts, C.ws_partial.as<uint8_t>(), handed);
+                       (const uint8_t*)basis.pts, C.ws_partial.as<uint8_t>(), handed, abort_dev);
     C.timer.mark("accumulate", s);
     // 6 bucket sums
     static const bool bsum_quad = !getenv("KH_NO_BSUM_QUAD");
@@ -1448,15 +1460,15 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
     if (precomp && ngroups <= bsum_maxg && bsum_quad)
         hipLaunchKernelGGL((k_bucket_sum_q<BF>), dim3((unsigned)((4 * nkeys + 255) / 256)), dim3(256), 0, s,
                            C.ws_toff.as<u32>(), nkeys, C.ws_partial.as<uint8_t>(), C.ws_buckets.as<uint8_t>(), C.ws_biglist.as<u32>(),
-                           bigcap, 16u);
+                           bigcap, 16u, abort_dev);
     else
     hipLaunchKernelGGL((k_bucket_sum<BF>), dim3((unsigned)((nkeys + 255) / 256)), dim3(256), 0, s,
                        C.ws_toff.as<u32>(), nkeys, C.ws_partial.as<uint8_t>(), C.ws_buckets.as<uint8_t>(), C.ws_biglist.as<u32>(),
-                       bigcap, nkeys <= 16384 ? 4u : 16u);
+                       bigcap, nkeys <= 16384 ? 4u : 16u, abort_dev);
     hipLaunchKernelGGL((k_bucket_chunk<BF>), dim3(2048), dim3(64), 0, s,
-                       C.ws_toff.as<u32>(), C.ws_partial.as<uint8_t>(), C.ws_biglist.as<u32>(), bigcap, C.ws_chunks.as<uint8_t>());
+                       C.ws_toff.as<u32>(), C.ws_partial.as<uint8_t>(), C.ws_biglist.as<u32>(), bigcap, C.ws_chunks.as<uint8_t>(), abort_dev);
     hipLaunchKernelGGL((k_bucket_big<BF>), dim3(1024), dim3(256), 0, s,
-                       C.ws_toff.as<u32>(), C.ws_chunks.as<uint8_t>(), C.ws_buckets.as<uint8_t>(), C.ws_biglist.as<u32>(), bigcap);
+                       C.ws_toff.as<u32>(), C.ws_chunks.as<uint8_t>(), C.ws_buckets.as<uint8_t>(), C.ws_biglist.as<u32>(), bigcap, abort_dev);
     C.timer.mark("bucket_sum", s);
     // 7 reduce
     bool direct_out = false;                              // latency path: the last kernel writes the (768-byte) result to host memory itself -- no copy node

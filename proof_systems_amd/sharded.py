@@ -75,9 +75,15 @@ def pack_partials(xy_list, inf_list):
 class RankShardedMsm:
     """One process per GPU.  `dist` is an initialised torch.distributed module (or None for a single rank)."""
 
-    def __init__(self, curve: int, total_points: int, dist=None, coll_device: str = "cpu", engine=None, rank: int = 0, world: int = 1):
+    def __init__(self, curve: int, total_points: int, dist=None, coll_device: str = "cpu", engine=None, rank: int = 0, world: int = 1, comm=None,
+                 always_collective: bool = False):
+        """comm: a proof_systems_amd.khip.Comm (kh_comm_*: the IN-LIBRARY RCCL all-gather, what a Rust / C caller of kh_msm_allreduce gets) -- the
+        combine then never touches torch.distributed.  always_collective: run the collective even in a world of one (how a 1-GPU box exercises
+        the RCCL call path; by default a lone rank skips it)."""
         self.curve, self.total, self.dist, self.coll_device = curve, total_points, dist, coll_device
         self.rank, self.world = rank, world
+        self.comm, self.always_collective = comm, always_collective
+        self.collective_backend = None                      # set by the first combine that ran a collective: "rccl-lib" | "nccl-torch" | "gloo-torch"
         self.engine = engine if engine is not None else KhipEngine()
         self.start, self.count = shard_range(total_points, world, rank)
         self.shard = self.engine.make_shard(curve, self.start, self.count)
@@ -91,13 +97,20 @@ class RankShardedMsm:
         xy = np.asarray(partial_xy, dtype=np.uint64).reshape(-1, 8)
         inf = np.asarray(partial_inf).reshape(-1)
         k = xy.shape[0]
-        if self.dist is None or self.world == 1:
+        if (self.dist is None and self.comm is None) or (self.world == 1 and not self.always_collective):
             return xy, inf.astype(bool)
-        import torch
-        mine = torch.from_numpy(pack_partials(list(xy), list(inf)).view(np.int64)).to(self.coll_device)
-        allp = [torch.empty_like(mine) for _ in range(self.world)]
-        self.dist.all_gather(allp, mine)
-        parts = torch.stack(allp).cpu().numpy().view(np.uint64)            # [world, k, 9]
+        if self.comm is not None:                                            # csrc/comm.hip: ncclAllGather on the communicator's own stream
+            axy, ainf = self.comm.allgather_points(xy, inf.astype(np.uint8))
+            parts = np.concatenate([np.asarray(axy, dtype=np.uint64).reshape(self.world, k, 8),
+                                    np.asarray(ainf, dtype=np.uint64).reshape(self.world, k, 1)], axis=2)
+            self.collective_backend = "rccl-lib"
+        else:
+            import torch
+            mine = torch.from_numpy(pack_partials(list(xy), list(inf)).view(np.int64)).to(self.coll_device)
+            allp = [torch.empty_like(mine) for _ in range(self.world)]
+            self.dist.all_gather(allp, mine)
+            parts = torch.stack(allp).cpu().numpy().view(np.uint64)        # [world, k, 9]
+            self.collective_backend = ("nccl" if self.coll_device == "cuda" else "gloo") + "-torch"
         out = np.zeros((k, 8), dtype=np.uint64); oinf = np.zeros(k, dtype=bool)
         for j in range(k):
             out[j], oinf[j] = self.engine.points_sum(self.curve, parts[:, j, :8].copy(), parts[:, j, 8].astype(np.uint8))

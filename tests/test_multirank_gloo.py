@@ -58,6 +58,18 @@ assert bool(binf[0]) == winf and np.array_equal(both[0], want)
 s, c = sharded.shard_range(n_total, world, rank)
 want2, winf2 = cref.msm(0, gs, np.concatenate([sc[::-1][sharded.shard_range(n_total, world, r)[0]:][:sharded.shard_range(n_total, world, r)[1]] for r in range(world)]), threads=8)
 assert bool(binf[1]) == winf2 and np.array_equal(both[1], want2)
+# the `comm=` route of combine (the in-library collective's shape: kh_comm_allgather_points returns [world * k] points, rank-major), with a
+# stand-in that moves the same records over gloo -- RCCL needs one GPU per rank, which no test box has
+class WireComm:
+    def __init__(self, world): self.world = world
+    def allgather_points(self, xy, inf):
+        rec = [None] * self.world
+        dist.all_gather_object(rec, (np.asarray(xy).copy(), np.asarray(inf).copy()))
+        return np.concatenate([r[0].reshape(-1, 8) for r in rec]), np.concatenate([r[1].reshape(-1) for r in rec])
+sm2 = sharded.RankShardedMsm.__new__(sharded.RankShardedMsm)
+sm2.__dict__.update(sm.__dict__); sm2.comm = WireComm(world); sm2.dist = None; sm2.collective_backend = None
+both2, binf2 = sm2.combine([p1[0], p2[0]], [p1[1], p2[1]])
+assert np.array_equal(both2, both) and np.array_equal(binf2, binf) and sm2.collective_backend == "rccl-lib" and sm.collective_backend == "gloo-torch"
 sm.close()
 dist.barrier()
 if rank == 0:
