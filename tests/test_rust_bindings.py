@@ -96,7 +96,7 @@ def test_safe_crate_calls_exist_with_the_right_arity():
                 elif ch == "," and depth == 1:
                     args += 1 if cur.strip() else 0; cur = ""; i += 1; continue
                 cur += ch; i += 1
-            args += 1 if cur.strip(" )") else 0
+            args += 1 if cur.strip(" )\n\t") else 0
             assert args == len(hdr[name][1]), (f, name, args, len(hdr[name][1]))
     # the trait surface: every method of poly_commitment::SRS (lib.rs:61-241) is implemented
     src = open(os.path.join(ROOT, "rust", "kimchi-hip", "src", "lib.rs")).read()

@@ -225,3 +225,92 @@ def test_proof_handles_are_freed_on_every_path():
     src = _strip(open(os.path.join(ROOT, "rust", "kimchi-hip", "src", "prover.rs")).read())
     assert re.search(r"impl\s+Drop\s+for\s+ProofGuard", src) and "kh_proof_free" in _block(src, r"impl\s+Drop\s+for\s+ProofGuard\s*\{")
     assert len(re.findall(r"sys::kh_proof_free", src)) == 1               # only the guard frees
+
+
+# ---------------------------------------------------------------------------------------------------------------- struct literals
+def _struct_fields(path: str, name: str):
+    """names of the `pub` fields of `pub struct name` in a reference source file"""
+    body = _block(_strip(open(os.path.join(REF, path)).read()), r"pub\s+struct\s+%s\b[^{;]*\{" % name)
+    clean, i = "", 0
+    while i < len(body):                                     # drop #[...] attributes (their arguments may nest brackets and hold strings)
+        if body.startswith("#[", i):
+            depth, i = 1, i + 2
+            while depth:
+                depth += body[i] == "["
+                depth -= body[i] == "]"
+                i += 1
+        else:
+            clean += body[i]; i += 1
+    body = clean
+    out, depth, cur = [], 0, ""
+    for ch in body + ",":
+        if ch in "<([{":
+            depth += 1
+        elif ch in ">)]}":
+            depth -= 1
+        if ch == "," and depth == 0:
+            m = re.match(r"\s*pub\s+(\w+)\s*:", cur)
+            if m:
+                out.append(m.group(1))
+            cur = ""
+        else:
+            cur += ch
+    return out
+
+
+def _literal_fields(src: str, name: str):
+    """field names of the first struct literal `name { ... }` in our source (a field may be shorthand: `prev_challenges,`)"""
+    m = re.search(r"\b%s\s*\{" % name, src)
+    assert m, name
+    depth, j = 0, m.end() - 1
+    while True:
+        depth += src[j] == "{"
+        depth -= src[j] == "}"
+        if depth == 0:
+            break
+        j += 1
+    body, out, depth, cur = src[m.end():j], [], 0, ""
+    for ch in body + ",":
+        if ch in "([{":
+            depth += 1
+        elif ch in ")]}":
+            depth -= 1
+        if ch == "," and depth == 0:
+            mm = re.match(r"\s*(\w+)\s*(?::|$)", cur.strip())
+            if mm and cur.strip():
+                out.append(mm.group(1))
+            cur = ""
+        else:
+            cur += ch
+    return out
+
+
+@pytest.mark.parametrize("name,path", [("ProverProof", "kimchi/src/proof.rs"), ("ProverCommitments", "kimchi/src/proof.rs"), ("ProofEvaluations", "kimchi/src/proof.rs"),
+                                       ("LookupCommitments", "kimchi/src/proof.rs"), ("PointEvaluations", "kimchi/src/proof.rs"),
+                                       ("OpeningProof", "poly-commitment/src/ipa.rs"), ("BlindedCommitment", "poly-commitment/src/commitment.rs")])
+def test_struct_literals_name_exactly_the_references_fields(name, path):
+    src = "".join(_strip(open(f).read()) for f in RUST_FILES)
+    got, want = _literal_fields(src, name), _struct_fields(path, name)
+    assert want, name
+    assert sorted(got) == sorted(want), (name, sorted(set(got) ^ set(want)))
+
+
+def test_fields_read_from_reference_values_exist():
+    """`x.field` accesses on reference types in prover.rs: the fields must be public in the reference"""
+    for path, struct, fields in [("kimchi/src/circuits/lookup/index.rs", "LookupConstraintSystem", ["lookup_table8", "table_ids8", "lookup_selectors", "runtime_selector",
+                                                                                                "runtime_tables", "runtime_table_offset", "configuration"]),
+                                 ("kimchi/src/circuits/lookup/index.rs", "LookupSelectors", ["xor", "lookup", "range_check", "ffmul"]),
+                                 ("kimchi/src/circuits/lookup/lookups.rs", "LookupInfo", ["max_per_row"]),
+                                 ("kimchi/src/circuits/lookup/runtime_tables.rs", "RuntimeTable", ["id", "data"]),
+                                 ("kimchi/src/circuits/lookup/runtime_tables.rs", "RuntimeTableSpec", ["id", "len"]),
+                                 ("kimchi/src/proof.rs", "RecursionChallenge", ["chals", "comm"]),
+                                 ("kimchi/src/circuits/constraints.rs", "ConstraintSystem", ["public", "prev_challenges", "domain", "gates", "zk_rows", "sid", "shift", "lookup_constraint_system"]),
+                                 ("kimchi/src/circuits/domain_constant_evaluation.rs", "DomainConstantEvaluations", ["vanishes_on_zero_knowledge_and_previous_rows"])]:
+        have = _struct_fields(path, struct)
+        for f in fields:
+            assert f in have, (struct, f, have)
+    src = _strip(open(RUST_FILES[2]).read())
+    for m in re.finditer(r"\blcs\.(\w+)\b(?!\s*\()", src):
+        assert m.group(1) in _struct_fields("kimchi/src/circuits/lookup/index.rs", "LookupConstraintSystem"), m.group(1)
+    for m in re.finditer(r"\bcs\.(\w+)\b(?!\s*\()", src):
+        assert m.group(1) in _struct_fields("kimchi/src/circuits/constraints.rs", "ConstraintSystem"), m.group(1)

@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""What would c = 20 windows buy the 2^20-point MSM?    Measured with the kernels that exist:
+
+  accumulation side   13 instead of 16 table additions per scalar.  The SAME number of mixed additions (13 * 2^20) is what today's c = 16
+                      pipeline does for n = 13 * 2^16 points: its k_accumulate29 time is the time a c = 20 accumulation would take
+                      (identical kernel, identical per-addition cost; only the bucket load differs: 416 instead of 26 entries per bucket).
+  bucket side         2^19 buckets instead of 2^15.  A batch of 16 MSMs of 2^16 points has 16 * 2^15 = 2^19 buckets holding 32 entries
+                      each (c = 20 at 2^20: 26): its task planning + bucket sums + marginal reduction is what the reduction over 2^19 buckets
+                      costs with today's kernels -- an upper bound for a dedicated two-plane reduction, whose floor is 2 full XYZZ additions
+                      per bucket (14 products in exact arithmetic each = ~2.9 mixed additions of the lazy 29-bit kernel).
+
+Prints the synchronous phase times (HIP events, median of 7) of the three jobs and the resulting estimate."""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import proof_systems_amd.khip as khip  # noqa: E402
+
+khip.init(0)
+rng = np.random.default_rng(20)
+
+
+def scalars(n):
+    sc = rng.integers(0, 1 << 64, size=(n, 4), dtype=np.uint64)
+    sc[:, 3] &= np.uint64((1 << 61) - 1)
+    return sc
+
+
+def phases(srs, n, k, reps=7):
+    sc = scalars(n * k)
+    d = khip.DevBuf(sc.nbytes).upload(sc)
+    acc = {}
+    for _ in range(2):
+        srs.msm_batch_dev(d.ptr, n, k)
+    for _ in range(reps):
+        srs.msm_batch_dev(d.ptr, n, k)
+        for name, ms in khip.last_timings():
+            acc.setdefault(name, []).append(ms)
+    d.free()
+    return {k_: float(np.median(v)) for k_, v in acc.items()}
+
+
+full = khip.Srs.create(khip.VESTA, 1 << 20)
+p20 = phases(full, 1 << 20, 1)
+p13 = phases(full, 13 << 16, 1)                  # the first 13 * 2^16 points of the same tables
+full.close()
+small = khip.Srs.create(khip.VESTA, 1 << 16)
+p16x16 = phases(small, 1 << 16, 16)
+small.close()
+fmt = lambda p: "  ".join(f"{k} {v * 1e3:.0f}" for k, v in p.items())
+print("us per phase, synchronous")
+print("  2^20 x 1        :", fmt(p20))
+print("  13 * 2^16 x 1   :", fmt(p13))
+print("  2^16 x 16       :", fmt(p16x16))
+tot = lambda p: sum(v for k, v in p.items() if k not in ("k_accumulate29", "k_accumulate"))
+acc_now, acc_c20 = p20["accumulate"], p13["accumulate"]
+side_now = p20["tasks"] + p20["bucket_sum"] + p20["reduce"]
+side_c20 = p16x16["tasks"] + p16x16["bucket_sum"] + p16x16["reduce"]
+print(f"accumulation  c=16: {acc_now * 1e3:.0f} us   c=20 (13/16 of the additions): {acc_c20 * 1e3:.0f} us   saving {(acc_now - acc_c20) * 1e3:.0f} us")
+print(f"bucket side   2^15 buckets: {side_now * 1e3:.0f} us   2^19 buckets (today's batch kernels): {side_c20 * 1e3:.0f} us   cost {(side_c20 - side_now) * 1e3:.0f} us")
+floor_us = 2 * (1 << 19) * 2.9 / (13 * (1 << 20)) * acc_c20 * 1e3
+print(f"floor of a dedicated 2-plane reduction (2 full additions per bucket at the accumulation kernel's efficiency): {floor_us:.0f} us")
+now_us, save_us = tot(p20) * 1e3, (acc_now - acc_c20) * 1e3
+print(f"synchronous 2^20 MSM today {now_us:.0f} us; with c = 20: between {now_us - save_us + floor_us:.0f} (floor) and {now_us - save_us + (side_c20 - side_now) * 1e3:.0f} us (today's batch kernels)")
