@@ -249,6 +249,8 @@ def prover_block(khip, srs20, check_with_oracle=True, log_n=16, reps=5):
            "reference_readme_seconds": 6.3, "reference_note": "o1-labs README figure for 2^16 gates, hardware unspecified; not measured here (no Rust toolchain)",
            "note": "complete proof: 15 + 1 + 7 commitments, 16 + 2 iNTT, 16 LDE, generic + permutation rows, division by Z_H (zero remainder asserted), 43 x 2 evaluations, ft, "
                    "16 opening rounds; sponges native on the host; constraints of the five gate types whose selectors are zero for this circuit are not evaluated (they add 0)"}
+    if check_with_oracle and log_n == 16:
+        out.update(fixture_parity(khip, ix, wit))
     # ---- the reference's call pattern, unchanged: host buffers, 15 concurrent callers
     cols = [np.ascontiguousarray(padded[i]) for i in range(15)]
     res = [None] * 15
@@ -433,6 +435,29 @@ def other_collective_check(khip, dist, sm, lib_comm, partial, result, rank, worl
         rep["error"] = "timed out after %.0f s inside the collective" % timeout_s
         return rep, True
     return rep, False
+
+
+def fixture_parity(khip, ix, wit):
+    """Checker leg (never timed): the SAME index and witness the timed proofs used, proved once more through kh_prove with the random stream of
+    tests/golden/proof_fixtures/bench_vesta_2_16.json (StdRng::from_seed, the oracle's restatement), serialised as rmp-serde writes a ProverProof
+    and compared with the committed bytes -- the proof the oracle's CPU prover (pinned on the reference's whole-proof vector) makes for BASELINE
+    config 3 at its own size.  Imports oracle/ for the RNG restatement and the serialiser only."""
+    import hashlib
+    from oracle import pasta as P
+    from oracle import prover as OPR
+    from oracle import views as V
+    from proof_systems_amd import prover
+    d = os.path.join(ROOT, "tests", "golden", "proof_fixtures")
+    try:
+        rec = json.load(open(os.path.join(d, "bench_vesta_2_16.json")))
+        want = open(os.path.join(d, "bench_vesta_2_16.proof.bin"), "rb").read()
+    except OSError:
+        return {"byte_identical_to_oracle": None, "byte_parity_note": "tests/golden/proof_fixtures/bench_vesta_2_16.* not found"}
+    proof = prover.create_proof_native(ix, wit, V.RefRng(P.StdRng(bytes.fromhex(rec["seed_hex"]))))
+    got = OPR.serialize_proof(P.VESTA, V.device_views(ix, proof)[2])
+    return {"byte_identical_to_oracle": bool(got == want), "byte_parity_fixture": "tests/golden/proof_fixtures/bench_vesta_2_16.proof.bin",
+            "byte_parity_sha256": hashlib.sha256(got).hexdigest(), "byte_parity_fixture_sha256": rec["proof_sha256"],
+            "byte_parity_note": "kh_prove on this run's index and witness with the fixture's StdRng stream: the %d serialised bytes of the ProverProof against the oracle prover's" % len(want)}
 
 
 def oracle_verifies(khip, ix, proof):

@@ -2,6 +2,7 @@
 #include <stdlib.h>
 #include <algorithm>
 #include <chrono>
+#include <atomic>
 #include <map>
 #include <memory>
 
@@ -33,6 +34,7 @@ static thread_local int tl_hip_dev = -1;       // what this thread last passed t
 // like the shared ones.  What belongs to an SRS HANDLE (its Lagrange-basis map, the one opening it can run at a time) has its own locks (kh_srs).
 static thread_local Context* tl_private[KH_MAX_DEVICES];
 static std::vector<Context*> g_private_pool[KH_MAX_DEVICES];           // idle private contexts (guarded by g_ctx_mu)
+static std::atomic<int> g_private_made[KH_MAX_DEVICES];                 // private contexts ever created per device (they are never destroyed)
 // a thread keeps the context it used last (its workspaces, captured graphs and staging ring stay warm for its next proof) and hands it to the pool when it
 // exits -- no HIP call in the destructor, only the list
 struct ThreadContextCache {
@@ -303,7 +305,10 @@ int kh_trim(void) {
     C.ws_ntt_a.release(); C.ws_ntt_b.release();
     dev_pool_trim(C.device);
     C.trim_scratch();
-    ntt_trim(C);
+    // The twiddle tables belong to the DEVICE and are shared by every context on it: a private context of another thread may be between two
+    // passes of a transform that reads them, and this call holds only its own context's lock.  They are dropped only while no private context
+    // exists on the device (a few MB per transform size otherwise stay cached until the process ends).
+    if (g_private_made[C.device >= 0 && C.device < KH_MAX_DEVICES ? C.device : 0].load() == 0) ntt_trim(C);
     return KH_OK;
 }
 
@@ -322,6 +327,7 @@ int kh_private_context_begin(void) {
     if (!c) {
         c = new (std::nothrow) Context;
         KH_REQUIRE(c, "out of memory");
+        g_private_made[dev]++;
     }
     // init_context is idempotent (C.ready): a context that came back from the pool or the thread's cache half-initialised -- an earlier begin failed
     // part-way -- is completed here instead of being used with null streams.  Whatever fails below, the context goes back to the pool (never lost).

@@ -36,7 +36,14 @@ CASES = {
     "bench_vesta_2_16": (0, 16, 16, bytes([16, 0] + [42] * 30)),          # BASELINE config 3
     "bench_pallas_2_16": (1, 16, 16, bytes([16, 1] + [42] * 30)),         # BASELINE config 5's other half
     "bench_vesta_2_17_over_2_16": (0, 17, 16, bytes([17, 0] + [42] * 30)),  # 2 chunks, zk_rows 5 (kimchi/src/tests/chunked.rs)
+    # create_recursive at config 3's size: one previous challenge (16 folding challenges, its accumulator commitment), kimchi/src/tests/recursion.rs:44-75
+    "bench_vesta_2_16_prev1": (0, 16, 16, bytes([16, 2] + [42] * 30)),
+    # the lookup argument at size: AND gadgets (Xor16 rows with their 4-bit XOR-table lookups + generic rows, kimchi/src/tests/and.rs:126-160) filling a
+    # 2^13 domain -- the circuit family of the reference's own whole-proof vector, 16 times its size
+    "and_lookup_vesta_2_13": (0, 13, 13, bytes([13, 3] + [42] * 30)),
 }
+PREV_SEED = bytes([11] * 32)           # the previous challenges of *_prev1 are drawn from StdRng::from_seed(PREV_SEED)
+AND_SEED = bytes([12] * 32)            # the AND gadgets' 64-bit inputs
 
 
 def bench_circuit(F, log2_n: int, log_srs: int):
@@ -53,15 +60,53 @@ def bench_circuit(F, log2_n: int, log_srs: int):
     return cs, rows
 
 
+def and_circuit(F, log2_n: int):
+    """as many 8-byte AND gadgets (extend_and, and.rs:126-160) as fit the domain, with their witness (create_and_witness) on inputs from
+    gen_field_with_bits(StdRng::from_seed(AND_SEED), 64)"""
+    from oracle import gates as G
+    p = F.p
+    std = P.StdRng(AND_SEED)
+    gates, rows = [], []
+    per = None
+    while per is None or len(gates) + per + 3 + 1 <= (1 << log2_n) - 1:
+        before = len(gates)
+        CC.extend_and(p, gates, 8)
+        per = len(gates) - before
+        rows += G.and_witness(F, CC.gen_field_with_bits(std, 64), CC.gen_field_with_bits(std, 64), 8)
+    cs = CC.build(F, gates)
+    assert cs["log2_n"] == log2_n and cs["lookup"] is not None and len(rows) == len(gates), (cs["log2_n"], len(rows), len(gates))
+    CC.verify_witness(cs, [[r[c] for r in rows] for c in range(15)])
+    return cs, rows
+
+
+def previous_challenges(C, srs, log_srs: int, count: int):
+    """RecursionChallenge values as recursion.rs:56-70 makes them: random challenges, comm = commit_non_hiding(b_poly_coefficients(chals))"""
+    std = P.StdRng(PREV_SEED)
+    prev = []
+    for _ in range(count):
+        chals = [P.field_rand(C.scalar, std) for _ in range(log_srs)]
+        prev.append((chals, srs.commit_non_hiding(P.b_poly_coefficients(C.scalar, chals), 1)))
+    return prev
+
+
 def make(name: str, verify: bool = True):
     cid, log2_n, log_srs, seed = CASES[name]
     C = P.CURVES[cid]; F = C.scalar
     t0 = time.time()
-    cs, rows = bench_circuit(F, log2_n, log_srs)
+    nprev = 1 if name.endswith("_prev1") else 0
     srs = OPR.Srs(C, 1 << log_srs, threads=OPR.THREADS)
+    if name.startswith("and_lookup"):
+        cs, wrows = and_circuit(F, log2_n)
+        rows, witness, desc = len(wrows), [[r[c] for r in wrows] for c in range(15)], "AND gadgets (create_and_witness)"
+    else:
+        cs, rows = bench_circuit(F, log2_n, log_srs)
+        if nprev:
+            cs["prev_challenges"] = nprev
+        witness, desc = [[1] * rows for _ in range(15)], "15 columns of ones"
+    prev = previous_challenges(C, srs, log_srs, nprev)
     ix = OPR.Index(C, cs, srs)
     t1 = time.time()
-    proof = OPR.create_proof(ix, [[1] * rows for _ in range(15)], P.StdRng(seed))
+    proof = OPR.create_proof(ix, witness, P.StdRng(seed), prev_challenges=prev)
     t2 = time.time()
     raw = OPR.serialize_proof(C, proof)
     ok = None
@@ -70,7 +115,7 @@ def make(name: str, verify: bool = True):
         assert ok, "the oracle verifier rejects the oracle prover's proof"
     rec = {"_generated_by": "tests/golden/make_proof_fixtures.py (oracle/prover.py; circuit kimchi/src/bench.rs:59-122, rng StdRng::from_seed(seed))",
            "name": name, "curve": ["vesta", "pallas"][cid], "log2_n": log2_n, "log2_srs": log_srs, "num_chunks": ix.num_chunks, "zk_rows": cs["zk_rows"],
-           "gates": rows, "witness": "15 columns of ones", "seed_hex": seed.hex(), "proof_len": len(raw), "proof_sha256": hashlib.sha256(raw).hexdigest(),
+           "gates": rows, "witness": desc, "prev_challenges": nprev, "lookup": cs["lookup"] is not None, "seed_hex": seed.hex(), "proof_len": len(raw), "proof_sha256": hashlib.sha256(raw).hexdigest(),
            "verifier_index_digest_hex": hex(ix.digest), "accepted_by_oracle_verifier": ok,
            "challenges_hex": {k: (None if v is None else hex(v)) for k, v in proof["challenges"].items()},
            "seconds": {"index": round(t1 - t0, 1), "prove": round(t2 - t1, 1)}}

@@ -16,7 +16,7 @@ from oracle import prover as OPR
 HERE = os.path.dirname(os.path.abspath(__file__))
 FIX = os.path.join(HERE, "golden", "proof_fixtures")
 sys.path.insert(0, os.path.join(HERE, "golden"))
-NAMES = ["bench_vesta_2_10", "bench_vesta_2_16", "bench_pallas_2_16", "bench_vesta_2_17_over_2_16"]
+NAMES = ["bench_vesta_2_10", "bench_vesta_2_16", "bench_pallas_2_16", "bench_vesta_2_17_over_2_16", "bench_vesta_2_16_prev1", "and_lookup_vesta_2_13"]
 
 
 def _load(name):
@@ -34,8 +34,9 @@ def test_record_matches_bytes_and_layout(name):
     assert rec["accepted_by_oracle_verifier"] is True
     commitments, opening, evals, ft_eval1, prev = msgpack.unpackb(raw, raw=True)
     nch = rec["num_chunks"]
-    assert len(commitments[0]) == 15 and all(len(c[0]) == nch for c in commitments[0]) and len(commitments[2][0]) == 7 * nch and commitments[3] is None
-    assert len(opening[0]) == rec["log2_srs"] and len(ft_eval1) == 32 and prev == []
+    assert len(commitments[0]) == 15 and all(len(c[0]) == nch for c in commitments[0]) and len(commitments[2][0]) == 7 * nch
+    assert (commitments[3] is not None) == bool(rec.get("lookup")) and len(prev) == rec.get("prev_challenges", 0)
+    assert len(opening[0]) == rec["log2_srs"] and len(ft_eval1) == 32
     assert len(evals[1]) == 15 and all(len(e[0]) == nch and len(e[1]) == nch for e in evals[1])
 
 
