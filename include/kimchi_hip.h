@@ -270,6 +270,13 @@ enum { KH_SCAN_ADD = 0, KH_SCAN_MUL = 1 };
 int kh_field_scan_dev(int field, int op, int reverse, uint64_t *data_dev, size_t n);
 int kh_batch_inversion_dev(int field, uint64_t *v_dev, size_t n);
 int kh_divide_by_linear_dev(int field, const uint64_t *f_dev, size_t len, const uint64_t a[4], uint64_t *q_dev, uint64_t rem[4]);
+/* The same division with the remainder left ON THE DEVICE (rem_dev: 4 limbs, nullable) -- nothing waits for the stream -- and a deferred check:
+ * kh_check_equal_dev sets bit `bit` of *flags_dev (a uint32_t in device memory the caller zeroed) when any of the n elements at v_dev differs
+ * from `expect` (4 limbs; NULL = zero).  A device-resident prover queues its invariants (remainders are zero, the accumulators end at 1:
+ * prover.rs:913-917, permutation.rs:301-321, 566-568) behind the steps that produce them and reads the one word at the end of the proof, instead
+ * of stalling the stream once per check; both are asynchronous on the library's main stream like the other vector steps. */
+int kh_divide_by_linear_async_dev(int field, const uint64_t *f_dev, size_t len, const uint64_t a[4], uint64_t *q_dev, uint64_t *rem_dev);
+int kh_check_equal_dev(const uint64_t *v_dev, size_t n, const uint64_t *expect, uint32_t *flags_dev, unsigned bit);
 
 /* ---- challenge polynomials (verifier side) ----
  * kh_b_poly_coefficients = b_poly_coefficients (poly-commitment/src/commitment.rs:464-476) for k challenge sets of

@@ -1202,6 +1202,25 @@ int kh_divide_by_linear_dev(int field, const uint64_t* f_dev, size_t len, const 
     std::lock_guard<std::mutex> lk(C.mu);
     return poly_divide_by_linear(C, field, f_dev, len, a, q_dev, rem);
 }
+int kh_divide_by_linear_async_dev(int field, const uint64_t* f_dev, size_t len, const uint64_t a[4], uint64_t* q_dev, uint64_t* rem_dev) {
+    KH_REQUIRE(field == KH_FIELD_FP || field == KH_FIELD_FQ, "unknown field id %d", field);
+    KH_REQUIRE(a && (f_dev || len == 0) && (q_dev || len <= 1), "kh_divide_by_linear_async_dev: null argument");
+    int rc = ensure_init(); if (rc) return rc;
+    Context& C = ctx();
+    std::lock_guard<std::mutex> lk(C.mu);
+    rc = poly_divide_by_linear(C, field, f_dev, len, a, q_dev, nullptr, rem_dev);
+    if (rc == KH_OK) C.mark_async();
+    return rc;
+}
+int kh_check_equal_dev(const uint64_t* v_dev, size_t n, const uint64_t* expect, uint32_t* flags_dev, unsigned bit) {
+    KH_REQUIRE((v_dev || n == 0) && flags_dev && bit < 32, "kh_check_equal_dev: bad argument");
+    int rc = ensure_init(); if (rc) return rc;
+    Context& C = ctx();
+    std::lock_guard<std::mutex> lk(C.mu);
+    rc = poly_check_equal(C, v_dev, n, expect, flags_dev, bit);
+    if (rc == KH_OK) C.mark_async();
+    return rc;
+}
 int kh_expr_evaluations_dev(int field, const uint32_t* tokens, size_t ntok, const uint64_t* const* cols_dev, const size_t* col_len, size_t ncols,
                             const uint64_t* constants, size_t nconsts, size_t rows, unsigned stride, unsigned next_shift, int accumulate,
                             uint64_t* out_dev) {

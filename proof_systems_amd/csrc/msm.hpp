@@ -54,7 +54,8 @@ int poly_div_vanishing(Context& C, int field, const uint64_t* f_dev, size_t len,
 int poly_coset_ntt(Context& C, int field, const uint64_t* coeffs_dev, unsigned log2_n, const uint64_t shift[4], uint64_t* out_dev, size_t batch);
 int poly_scan(Context& C, int field, int op, int rev, uint64_t* data_dev, size_t n);
 int poly_batch_inversion(Context& C, int field, uint64_t* v_dev, size_t n);
-int poly_divide_by_linear(Context& C, int field, const uint64_t* f_dev, size_t len, const uint64_t a[4], uint64_t* q_dev, uint64_t rem[4]);
+int poly_divide_by_linear(Context& C, int field, const uint64_t* f_dev, size_t len, const uint64_t a[4], uint64_t* q_dev, uint64_t rem[4], uint64_t* rem_dev = nullptr);
+int poly_check_equal(Context& C, const uint64_t* v_dev, size_t n, const uint64_t* expect, uint32_t* flags_dev, unsigned bit);
 // expr.hip
 // the gate library as compiled kernels (gates.hip; generated from the same expression DAGs as the token programs)
 int gate_count();

@@ -385,13 +385,14 @@ int poly_batch_inversion(Context& C, int field, uint64_t* v_dev, size_t n) {
     return KH_OK;
 }
 // f = q (x - a) + rem, rem = f(a): q_i = a^-(i+1) sum_{k > i} c_k a^k
-int poly_divide_by_linear(Context& C, int field, const uint64_t* f_dev, size_t len, const uint64_t a[4], uint64_t* q_dev, uint64_t rem[4]) {
-    if (len == 0) { memset(rem, 0, 32); return KH_OK; }
+// rem: the remainder to the HOST (synchronises the stream), or -- rem == nullptr -- rem_dev: four limbs on the device, nothing waits
+int poly_divide_by_linear(Context& C, int field, const uint64_t* f_dev, size_t len, const uint64_t a[4], uint64_t* q_dev, uint64_t rem[4], uint64_t* rem_dev) {
     hipStream_t s = C.stream;
+    if (len == 0) { if (rem) memset(rem, 0, 32); else if (rem_dev) KH_HIP(hipMemsetAsync(rem_dev, 0, 32, s)); return KH_OK; }
     if ((a[0] | a[1] | a[2] | a[3]) == 0) {                 // division by x: a shift
         if (len > 1) KH_HIP(hipMemcpyAsync(q_dev, f_dev + 4, (len - 1) * 32, hipMemcpyDeviceToDevice, s));
-        KH_HIP(hipMemcpyAsync(rem, f_dev, 32, hipMemcpyDeviceToHost, s));
-        KH_HIP(hipStreamSynchronize(s));
+        if (rem) { KH_HIP(hipMemcpyAsync(rem, f_dev, 32, hipMemcpyDeviceToHost, s)); KH_HIP(hipStreamSynchronize(s)); }
+        else if (rem_dev) KH_HIP(hipMemcpyAsync(rem_dev, f_dev, 32, hipMemcpyDeviceToDevice, s));
         return KH_OK;
     }
     int rc;
@@ -401,8 +402,26 @@ int poly_divide_by_linear(Context& C, int field, const uint64_t* f_dev, size_t l
     KH_FIELD_DISPATCH(k_scale_powers, g, dim3(256), s, f_dev, av, len, (size_t)0, g_scan_a.as<u64>());
     if ((rc = scan_enqueue(s, field, 0, 1, g_scan_a.as<u64>(), len))) return rc;      // suffix sums
     if (len > 1) KH_FIELD_DISPATCH(k_linear_quotient, g, dim3(256), s, (const u64*)g_scan_a.as<u64>(), ai, len, q_dev);
-    KH_HIP(hipMemcpyAsync(rem, g_scan_a.p, 32, hipMemcpyDeviceToHost, s));
-    KH_HIP(hipStreamSynchronize(s));
+    if (rem) { KH_HIP(hipMemcpyAsync(rem, g_scan_a.p, 32, hipMemcpyDeviceToHost, s)); KH_HIP(hipStreamSynchronize(s)); }
+    else if (rem_dev) KH_HIP(hipMemcpyAsync(rem_dev, g_scan_a.p, 32, hipMemcpyDeviceToDevice, s));
+    return KH_OK;
+}
+
+// Deferred invariant checks: *flags |= 1 << bit when any of the n elements of v differs from `expect` (as 4 x u64 words; no field arithmetic)
+__global__ void k_check_equal(const u64* __restrict__ v, size_t nwords, Fe4p expect, u32* __restrict__ flags, u32 bit) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    bool bad = false;
+    for (; i < nwords; i += stride) bad |= v[i] != expect.l[i & 3];
+    if (__any(bad) && (threadIdx.x & 63u) == 0) atomicOr(flags, 1u << bit);
+}
+int poly_check_equal(Context& C, const uint64_t* v_dev, size_t n, const uint64_t* expect, uint32_t* flags_dev, unsigned bit) {
+    if (n == 0) return KH_OK;
+    Fe4p e; if (expect) memcpy(e.l, expect, 32); else memset(e.l, 0, 32);
+    const size_t nwords = 4 * n;
+    unsigned blocks = (unsigned)std::min<size_t>((nwords + 255) / 256, 1024);
+    hipLaunchKernelGGL(k_check_equal, dim3(blocks), dim3(256), 0, C.stream, v_dev, nwords, e, flags_dev, (u32)bit);
+    KH_HIP(hipGetLastError());
     return KH_OK;
 }
 

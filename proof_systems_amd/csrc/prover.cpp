@@ -415,6 +415,18 @@ int kh_prove_full(kh_prover_index_t* ix, const uint64_t* witness, size_t rows, c
     } else { pub_xy = ix->zsel_xy; pub_inf = ix->zsel_inf; }
     KP(kh_sponge_absorb_g(fq.s, pub_xy.data(), pub_inf.data(), nch));
     pr->set_points(KH_PROOF_PUBLIC_COMM, pub_xy.data(), pub_inf.data(), nch);
+    // ---- the proof's invariants (the accumulators end at 1, the divisions leave no remainder) are queued as device-side checks behind the steps that
+    // produce them (kh_check_equal_dev: one bit each in a word on the device) and read ONCE, after the opening: a synchronous download per check
+    // stalled the stream five times per proof, and the small host <-> device patches below (a one, two random rows, z_0 - 1) four times more.
+    Dev chk; KP(chk.alloc(4));                         // [0]: the flags word; [1], [2]: the remainders of the two boundary divisions
+    KP(kh_dev_memset_zero(chk.p, 4 * 32));
+    uint32_t* const chk_flags = (uint32_t*)chk.p;
+    enum { CHK_AGG = 0, CHK_Z = 1, CHK_REM = 2, CHK_BND = 3 };
+    auto set_const = [&](uint64_t* dst, const fe& val) {    // *dst = val, queued on the main stream (a one-row constant expression)
+        const uint32_t prog[2] = {KH_TOK_CONST, 0};
+        const uint64_t* c0[1] = {ev.p}; const size_t l0[1] = {n};
+        return kh_expr_evaluations_dev(fid, prog, 1, c0, l0, 1, val.l, 1, 1, 1, 0, 0, dst);
+    };
     // ---- witness commitments: one batched MSM per chunk of the Lagrange basis, queued before the columns are interpolated
     uint64_t& tk = tickets.t[3]; bool& have_tk = tickets.live[3];
     if (nch == 1) { KP(kh_msm_submit(srs, (int)logn, 0, 0, ev.p, n, COLUMNS, 1, &tk)); have_tk = true; }
@@ -424,7 +436,10 @@ int kh_prove_full(kh_prover_index_t* ix, const uint64_t* witness, size_t rows, c
     Dev e8; KP(e8.alloc(16 * N8));
     bool any_lib = (ix->live != 0) || nopt > 0;
     const size_t w8 = (!any_lib && !all_gates) ? PERMUTS : COLUMNS;     // generic + permutation read w0..w6 only
-    KP(kh_lde_dev(fid, cf.p, logn, 3, e8.p, w8));
+    // The witness extension (0.35 ms of throughput work) either right behind the interpolation -- it then runs underneath the witness commitment, and the
+    // small kernels of the permutation aggregation queue behind it -- or (KH_LDE_LATE=1) behind the aggregation, underneath the z commitment.
+    static const bool lde_late = getenv("KH_LDE_LATE") && atoi(getenv("KH_LDE_LATE")) != 0;
+    if (!lde_late) KP(kh_lde_dev(fid, cf.p, logn, 3, e8.p, w8));
     std::vector<uint64_t> wxy, wbx; std::vector<uint8_t> winf, wbi;
     const fe* w_blind = draw(COLUMNS * nch);          // blinder(num_chunks) per column, column by column (prover.rs:316-327)
     KP(blinding_points(w_blind, COLUMNS * nch, wbx, wbi));              // (underneath the MSM)
@@ -546,16 +561,13 @@ int kh_prove_full(kh_prover_index_t* ix, const uint64_t* witness, size_t rows, c
         KP(pn.run(fid, cols, lens, lookup_rows, 1, 1, 0, num.at(1)));
         KP(pd.run(fid, cols, lens, lookup_rows, 1, 1, 0, den.at(1)));
         KP(kh_batch_inversion_dev(fid, den.at(1), lookup_rows));
-        KP(kh_dev_upload(num.p, one.l, 32)); KP(kh_dev_upload(den.p, one.l, 32));
+        KP(set_const(num.p, one)); KP(set_const(den.p, one));
         const uint32_t prod[6] = {KH_TOK_CELL, 0, KH_TOK_CELL, 2, KH_TOK_MUL, 0};
         const uint64_t* pc[2] = {num.p, den.p}; const size_t pl[2] = {n, n};
         KP(kh_expr_evaluations_dev(fid, prod, 3, pc, pl, 2, one.l, 1, n, 1, 1, 0, d_agg.p));
         KP(kh_field_scan_dev(fid, KH_SCAN_MUL, 0, d_agg.p, lookup_rows + 1));
-        KP(kh_dev_upload(d_agg.at(n - zk), draw(zk), zk * 32));
-        if (check) {
-            fe last; KP(kh_dev_download(last.l, d_agg.at(lookup_rows), 32));
-            KP_REQUIRE(khost::eq(last, one), "final value of the lookup aggregation is not 1 (lookup/constraints.rs:325-331)");
-        }
+        if (check) KP(kh_check_equal_dev(d_agg.at(lookup_rows), 1, one.l, chk_flags, CHK_AGG));      // before the random rows overwrite anything: row lookup_rows = n - zk - 1 is not one of them
+        { const fe* rr = draw(zk); for (size_t j = 0; j < zk; j++) KP(set_const(d_agg.at(n - zk + j), rr[j])); }
         a_blind = draw(nch);
         std::vector<uint64_t> axy, acx; std::vector<uint8_t> ainf, aci;
         KP(commit_evals(d_agg.p, 1, axy, ainf));
@@ -583,7 +595,7 @@ int kh_prove_full(kh_prover_index_t* ix, const uint64_t* witness, size_t rows, c
             tok(dt, KH_TOK_CELL, 2 * i); tok(dt, KH_TOK_CELL, 2 * (7 + i)); tok(dt, KH_TOK_CONST, 1); tok(dt, KH_TOK_MUL, 0); tok(dt, KH_TOK_ADD, 0);
             tok(dt, KH_TOK_CONST, 0); tok(dt, KH_TOK_ADD, 0); if (i) tok(dt, KH_TOK_MUL, 0);
         }
-        KP(kh_dev_upload(num.p, one.l, 32)); KP(kh_dev_upload(den.p, one.l, 32));
+        KP(set_const(num.p, one)); KP(set_const(den.p, one));
         KP(kh_expr_evaluations_dev(fid, nt.data(), nt.size() / 2, cols, lens, 15, (const uint64_t*)consts, 9, n - 1, 1, 8, 0, num.at(1)));
         KP(kh_expr_evaluations_dev(fid, dt.data(), dt.size() / 2, cols, lens, 15, (const uint64_t*)consts, 9, n - 1, 1, 8, 0, den.at(1)));
         KP(kh_batch_inversion_dev(fid, den.at(1), n - 1));
@@ -591,17 +603,15 @@ int kh_prove_full(kh_prover_index_t* ix, const uint64_t* witness, size_t rows, c
         const uint64_t* pc[2] = {num.p, den.p}; const size_t pl[2] = {n, n};
         KP(kh_expr_evaluations_dev(fid, prod, 3, pc, pl, 2, one.l, 1, n, 1, 8, 0, zcol));
         KP(kh_field_scan_dev(fid, KH_SCAN_MUL, 0, zcol, n - zk + 1));
-        if (check) {
-            fe last; KP(kh_dev_download(last.l, zcol + 4 * (n - zk), 32));
-            KP_REQUIRE(khost::eq(last, one), "final value of the permutation accumulator is not 1 (permutation.rs:566-568)");
-        }
-        KP(kh_dev_upload(zcol + 4 * (n - zk + 1), draw(2), 64));       // z's two random rows, in that order
+        if (check) KP(kh_check_equal_dev(zcol + 4 * (n - zk), 1, one.l, chk_flags, CHK_Z));
+        { const fe* rr = draw(2); KP(set_const(zcol + 4 * (n - zk + 1), rr[0])); KP(set_const(zcol + 4 * (n - zk + 2), rr[1])); }   // z's two random rows, in that order
         if (zk > 3) KP(kh_field_scan_dev(fid, KH_SCAN_MUL, 0, zcol + 4 * (n - zk + 2), zk - 2));
     }
     uint64_t* zc = cf.at(COLUMNS * NB);
     KP(kh_dev_copy(zc, zcol, NB * 32));
     KP(kh_ntt_dev(fid, zc, logn, 1, 1));
     if (nch == 1 && size == n) { KP(kh_msm_submit(srs, KH_BASIS_G, 0, 0, zc, n, 1, 1, &tk)); have_tk = true; }   // ... while z is extended to d8
+    if (lde_late) KP(kh_lde_dev(fid, cf.p, logn, 3, e8.p, w8));
     KP(kh_lde_dev(fid, zc, logn, 3, e8.at(COLUMNS * N8), 1));
     std::vector<uint64_t> zxy, zbx; std::vector<uint8_t> zinf, zbi;
     const fe* z_blind = draw(nch);
@@ -699,26 +709,22 @@ int kh_prove_full(kh_prover_index_t* ix, const uint64_t* witness, size_t rows, c
     }
     Dev quot, rem; KP(quot.alloc(7 * NB)); KP(rem.alloc(NB));
     KP(kh_divide_by_vanishing_poly_dev(fid, t8.p, 8 * n, logn, quot.p, rem.p));
-    if (check) {
-        std::vector<uint64_t> r(4 * n);
-        KP(kh_dev_download(r.data(), rem.p, NB * 32));
-        bool nz = false; for (uint64_t x : r) nz |= x != 0;
-        KP_REQUIRE(!nz, "rest of division by vanishing polynomial (prover.rs:913-917): the witness does not satisfy the constraints");
-    }
+    if (check) KP(kh_check_equal_dev(rem.p, n, nullptr, chk_flags, CHK_REM));
     Dev zm1, b1, b2; KP(zm1.alloc(NB)); KP(b1.alloc(NB)); KP(b2.alloc(NB));
     {
         const uint64_t* ps[1] = {zc}; const size_t ls[1] = {n};
         KP(kh_poly_lincomb_dev(fid, ps, ls, one.l, 1, zm1.p, n));
-        fe z0; KP(kh_dev_download(z0.l, zm1.p, 32));
-        z0 = F.sub(z0, one);
-        KP(kh_dev_upload(zm1.p, z0.l, 32));
+        {   // z_0 - 1, in place, on the stream
+            const uint32_t prog[6] = {KH_TOK_CELL, 0, KH_TOK_CONST, 0, KH_TOK_SUB, 0};
+            const uint64_t* c0[1] = {zm1.p}; const size_t l0[1] = {n};
+            KP(kh_expr_evaluations_dev(fid, prog, 3, c0, l0, 1, one.l, 1, 1, 1, 0, 0, zm1.p));
+        }
         KP(kh_dev_memset_zero(b1.p, NB * 32)); KP(kh_dev_memset_zero(b2.p, NB * 32));
         const fe pts2[2] = {one, fpow(F, ix->omega, n - zk)};
         uint64_t* dst[2] = {b1.p, b2.p};
         for (int i = 0; i < 2; i++) {                 // (z - 1) / (x - 1), (z - 1) / (x - omega^(n - zk)) (permutation.rs:301-321)
-            uint64_t r[4];
-            KP(kh_divide_by_linear_dev(fid, zm1.p, n, pts2[i].l, dst[i], r));
-            if (check) KP_REQUIRE((r[0] | r[1] | r[2] | r[3]) == 0, "permutation boundary division rest (permutation.rs:301-321)");
+            KP(kh_divide_by_linear_async_dev(fid, zm1.p, n, pts2[i].l, dst[i], chk.at(1 + i)));
+            if (check) KP(kh_check_equal_dev(chk.at(1 + i), 1, nullptr, chk_flags, CHK_BND));
         }
         const uint64_t* qs[3] = {quot.p, b1.p, b2.p}; const size_t ql[3] = {7 * n, n - 1, n - 1};
         fe sc[3] = {one, alphas[1], alphas[2]};
@@ -902,6 +908,14 @@ int kh_prove_full(kh_prover_index_t* ix, const uint64_t* witness, size_t rows, c
                        delta, &dinf, z1, z2, sg, &sginf));
     }
     KP_REQUIRE(rpos == need, "randomness count mismatch");
+    if (check) {                                     // the deferred invariants, earliest first (the reference returns the first it meets)
+        uint32_t fl = 0;
+        KP(kh_dev_download(&fl, chk.p, 4));
+        KP_REQUIRE(!(fl & (1u << CHK_AGG)), "final value of the lookup aggregation is not 1 (lookup/constraints.rs:325-331)");
+        KP_REQUIRE(!(fl & (1u << CHK_Z)), "final value of the permutation accumulator is not 1 (permutation.rs:566-568)");
+        KP_REQUIRE(!(fl & (1u << CHK_REM)), "rest of division by vanishing polynomial (prover.rs:913-917): the witness does not satisfy the constraints");
+        KP_REQUIRE(!(fl & (1u << CHK_BND)), "permutation boundary division rest (permutation.rs:301-321)");
+    }
     pr->set_points(KH_PROOF_LR, lr_xy.data(), lr_inf.data(), 2 * logs);
     pr->set_points(KH_PROOF_DELTA, delta, &dinf, 1);
     pr->set_points(KH_PROOF_SG, sg, &sginf, 1);

@@ -43,7 +43,7 @@ SYMBOLS = [
     "kh_commit_non_hiding", "kh_commit_evaluations_non_hiding", "kh_srs_set_blinding_base",
     "kh_srs_get_blinding_base", "kh_mask_custom", "kh_domain_generator", "kh_msm_points_batch", "kh_msm_submit", "kh_msm_wait",
     "kh_ipa_fold_scalars", "kh_inner_product", "kh_ipa_fold_points", "kh_ipa_fold_points_endo", "kh_endos", "kh_scalar_challenge_to_field",
-    "kh_polycomm_multi_scalar_mul", "kh_expr_evaluations_dev", "kh_field_scan_dev", "kh_batch_inversion_dev", "kh_divide_by_linear_dev", "kh_b_poly_coefficients", "kh_batch_dlog_accumulator_generate", "kh_batch_dlog_accumulator_check", "kh_ipa_verify_msm",
+    "kh_polycomm_multi_scalar_mul", "kh_expr_evaluations_dev", "kh_field_scan_dev", "kh_batch_inversion_dev", "kh_divide_by_linear_dev", "kh_divide_by_linear_async_dev", "kh_check_equal_dev", "kh_b_poly_coefficients", "kh_batch_dlog_accumulator_generate", "kh_batch_dlog_accumulator_check", "kh_ipa_verify_msm",
     "kh_ipa_begin", "kh_ipa_begin_dev", "kh_combine_polys_dev", "kh_poly_lincomb_dev", "kh_b_init_dev", "kh_evaluate_chunks_dev", "kh_evaluate_chunks_batch_dev", "kh_divide_by_vanishing_poly_dev", "kh_ipa_rounds_left", "kh_ipa_round_lr", "kh_ipa_round_fold", "kh_ipa_finish", "kh_ipa_free", "kh_points_sum", "kh_points_add", "kh_srs_create_device", "kh_srs_create_device_range", "kh_srs_get_g",
 ]
 
@@ -86,6 +86,8 @@ _lib.kh_expr_evaluations_dev.argtypes = [C.c_int, C.POINTER(C.c_uint32), C.c_siz
 _lib.kh_field_scan_dev.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
 _lib.kh_batch_inversion_dev.argtypes = [C.c_int, C.c_void_p, C.c_size_t]
 _lib.kh_divide_by_linear_dev.argtypes = [C.c_int, C.c_void_p, C.c_size_t, U64P, C.c_void_p, U64P]
+_lib.kh_divide_by_linear_async_dev.argtypes = [C.c_int, C.c_void_p, C.c_size_t, U64P, C.c_void_p, C.c_void_p]
+_lib.kh_check_equal_dev.argtypes = [C.c_void_p, C.c_size_t, U64P, C.c_void_p, C.c_uint]
 _lib.kh_polycomm_multi_scalar_mul.argtypes = [C.c_int, U64P, U8P, C.POINTER(C.c_size_t), C.c_size_t, U64P, U64P, U8P, C.POINTER(C.c_size_t)]
 _lib.kh_b_poly_coefficients.argtypes = [C.c_int, U64P, C.c_uint, C.c_size_t, U64P]
 _lib.kh_batch_dlog_accumulator_generate.argtypes = [C.c_void_p, C.c_size_t, U64P, C.c_size_t, U64P, U8P]
@@ -557,6 +559,18 @@ def divide_by_linear_dev(field: int, f, length: int, a, q):
     rem = np.zeros(4, dtype=np.uint64)
     _check(_lib.kh_divide_by_linear_dev(field, C.c_void_p(f.ptr), length, _p64(_c64(a, (4,))), C.c_void_p(q.ptr if q is not None else 0), _p64(rem)))
     return rem
+
+
+def divide_by_linear_async_dev(field: int, f, length: int, a, q, rem_dev):
+    """kh_divide_by_linear_async_dev: quotient into q, remainder into the DevBuf rem_dev (4 limbs); nothing waits."""
+    _check(_lib.kh_divide_by_linear_async_dev(field, C.c_void_p(f.ptr), length, _p64(_c64(a, (4,))), C.c_void_p(q.ptr if q is not None else 0),
+                                              C.c_void_p(rem_dev.ptr if rem_dev is not None else 0)))
+
+
+def check_equal_dev(v, n: int, expect, flags, bit: int, offset: int = 0):
+    """kh_check_equal_dev: flags (a DevBuf holding a uint32) |= 1 << bit when any of the n elements at v (+ offset elements) differs from expect (None: zero)."""
+    e = None if expect is None else _c64(expect, (4,))
+    _check(_lib.kh_check_equal_dev(C.c_void_p(v.ptr + 32 * offset), n, _p64(e) if e is not None else None, C.c_void_p(flags.ptr), bit))
 
 
 TOK_CONST, TOK_CELL, TOK_DUP, TOK_POW, TOK_ADD, TOK_MUL, TOK_SUB, TOK_STORE, TOK_LOAD = range(9)

@@ -81,7 +81,17 @@ def test_divide_by_linear(khip, fid, F):
                 back[i] = (back[i] - a * v) % F.p
             back[0] = (back[0] + rem) % F.p
             assert back == f
-            fd.free(); qd.free()
+            # the asynchronous form: same quotient, the remainder stays on the device; kh_check_equal_dev flags it (or not) without a stall
+            q2 = khip.DevBuf(max(length - 1, 1) * 32); rd = khip.DevBuf(32); flags = khip.DevBuf(4).upload(np.zeros(1, dtype=np.uint32))
+            khip.divide_by_linear_async_dev(fid, fd, length, _limbs(F, [a])[0], q2, rd)
+            khip.check_equal_dev(rd, 1, None, flags, 3)                        # bit 3: remainder != 0
+            khip.check_equal_dev(rd, 1, _limbs(F, [rem])[0], flags, 4)        # bit 4: remainder != f(a)  (never)
+            khip.check_equal_dev(fd, length, _limbs(F, [f[0]])[0], flags, 5)  # bit 5: some coefficient differs from the first
+            khip.sync()
+            assert _ints(F, rd.download((1, 4))) == [rem] and (length == 1 or q2.download((length - 1, 4)).tobytes() == qd.download((length - 1, 4)).tobytes())
+            want = (8 if rem else 0) | (32 if any(c != f[0] for c in f) else 0)
+            assert int(flags.download((1,), dtype=np.uint32)[0]) == want
+            fd.free(); qd.free(); q2.free(); rd.free(); flags.free()
 
 
 def test_permutation_argument_on_device(khip):
