@@ -44,11 +44,11 @@ sys.path.insert(0, ROOT)
 LOG_N = 20
 ALG_BYTES_PER_PAIR = 96          # 64 B affine point + 32 B scalar, each read once
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec
-PMC_FILE = "r03_msm20_pmc.json"                 # tools/profile_msm.py (rocprofv3 PMC passes), keyed by the hash of csrc/
-MIX_FILE = "r03_k_accumulate29_valu_mix.json"   # tools/valu_mix.py (static opcode histogram of the loop body)
-RATES_FILE = "r03_valu_rates.json"              # per-opcode issue cycles measured by tools/microbench.hip
-NTT_PMC_FILE = "r03_ntt_pmc.json"               # tools/profile_msm.py --workload ntt (tools/bench_ntt.py --bench-shapes)
-NTT_MIX_FILE = "r03_k_ntt_pass_valu_mix.json"   # tools/valu_mix.py --kernel ntt
+PMC_FILE = "r04_msm20_pmc.json"                 # tools/profile_msm.py (rocprofv3 PMC passes), keyed by the hash of csrc/
+MIX_FILE = "r04_k_accumulate29_valu_mix.json"   # tools/valu_mix.py (static opcode histogram of the loop body)
+RATES_FILE = "r04_valu_rates.json"              # per-opcode issue cycles measured by tools/microbench.hip
+NTT_PMC_FILE = "r04_ntt_pmc.json"               # tools/profile_msm.py --workload ntt (tools/bench_ntt.py --bench-shapes)
+NTT_MIX_FILE = "r04_k_ntt_pass_valu_mix.json"   # tools/valu_mix.py --kernel ntt
 
 
 def rand_scalars(rng, n):
