@@ -142,3 +142,18 @@ def test_no_dependency_cycle():
     assert "resize" not in fwd and "kimchi_hip_dispatch::forward" in fwd
     assert "TypeId" not in patch.replace("`TypeId::of::<T>()`", "")        # DomainCoeff has no 'static bound
     assert "sys::kh_lde(" in patch and "sys::kh_ntt(" in patch
+
+
+def test_rust_sources_are_delimiter_balanced():
+    """no compiler here: at least every bracket of the Rust files closes (comments, strings, char literals and lifetimes stripped)"""
+    for f in ("kimchi-hip/src/lib.rs", "kimchi-hip/src/prover.rs", "kimchi-hip/src/ntt.rs", "kimchi-hip-sys/src/lib.rs"):
+        s = open(os.path.join(ROOT, "rust", f)).read()
+        s = re.sub(r"//[^\n]*", "", s); s = re.sub(r"/\*.*?\*/", "", s, flags=re.S)
+        s = re.sub(r'"(?:\\.|[^"\\])*"', '""', s); s = re.sub(r"'(?:\\.|[^'\\])'", "''", s)
+        stack, pairs = [], {")": "(", "]": "[", "}": "{"}
+        for ch in s:
+            if ch in "([{":
+                stack.append(ch)
+            elif ch in ")]}":
+                assert stack and stack.pop() == pairs[ch], f
+        assert not stack, f
