@@ -624,17 +624,36 @@ def main():
         sync_ms.append(1e3 * (time.perf_counter() - ts))
     # timed region: EXACTLY `steps` MSMs, four in flight (kh_msm_submit / kh_msm_wait): the sort of step i+2 and the
     # bucket-reduction tail of step i run underneath the accumulation of step i+1.  Every step is a full MSM whose affine
-    # result is fetched and (N>1) combined across ranks.
+    # result is fetched and (N>1) combined across ranks INSIDE the region; the partial sums of up to `depth` finished MSMs travel in ONE
+    # collective ("batch the partials of all MSMs in a phase into one collective" -- a prover combines the commitments of a
+    # phase together; KH_BENCH_COMBINE_EVERY=1 gives one collective per MSM).
     fence()
     t0 = time.perf_counter()
     depth = 1 if args.no_pipeline else int(os.environ.get('KH_BENCH_DEPTH', '4'))
-    pending = []
+    combine_every = max(1, int(os.environ.get('KH_BENCH_COMBINE_EVERY', str(depth))))
+    pending, done = [], []
+
+    def flush():
+        nonlocal result
+        if not done:
+            return
+        last_partial[0] = (np.array(done[-1][0], dtype=np.uint64).reshape(1, 8), np.array([done[-1][1]], dtype=np.uint8))
+        o, i = sm.combine([d[0] for d in done], [d[1] for d in done])
+        result = (o[-1], bool(i[-1]))
+        done.clear()
+
+    def collect(ticket):
+        xy, inf = srs.msm_wait(ticket)
+        done.append((xy[0], inf[0]))
+        if len(done) >= combine_every:
+            flush()
     for _ in range(args.steps):
         pending.append(srs.msm_submit(d_sc.ptr, n, 1))
         if len(pending) >= depth:
-            result = combine(*srs.msm_wait(pending.pop(0)))
+            collect(pending.pop(0))
     while pending:
-        result = combine(*srs.msm_wait(pending.pop(0)))
+        collect(pending.pop(0))
+    flush()
     fence()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -667,7 +686,8 @@ def main():
         "config": {"workload": ("msm_2^%d_%s_srs" % (args.log_n, args.curve)) + ("_sharded" if args.strong else ""), "points_per_gpu": n, "points_total": total,
                    "bases": "SRS::<%s>::create" % args.curve.capitalize(),
                    "scalars": "uniform 254-bit, seed 1234+rank", "parallelism": "point-range x%d" % world,
-                   "collective_backend": sm.collective_backend, "process_group_backend": backend, "world_size_seen": world},
+                   "collective_backend": sm.collective_backend, "process_group_backend": backend, "world_size_seen": world,
+                   "partials_per_collective": (combine_every if sm.collective_backend else None)},
         "latency_value": total / (latency * 1e-3) / 1e6, "latency_note": "one MSM at a time (submit -> wait -> combine): `value` keeps 4 in flight",
         "ms_per_step_synchronous": latency, "msm_in_flight": depth,
         "roofline": roofline_block(kname, acc, n, args.log_n) if not args.strong else roofline_block(kname, acc, n, -1),
