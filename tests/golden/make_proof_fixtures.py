@@ -41,6 +41,9 @@ CASES = {
     # the lookup argument at size: AND gadgets (Xor16 rows with their 4-bit XOR-table lookups + generic rows, kimchi/src/tests/and.rs:126-160) filling a
     # 2^13 domain -- the circuit family of the reference's own whole-proof vector, 16 times its size
     "and_lookup_vesta_2_13": (0, 13, 13, bytes([13, 3] + [42] * 30)),
+    # config 3's size with everything the benchmark circuit lacks: a RANDOM witness (uniform 62-bit values and their products: the fifteen witness
+    # commitments are unskewed 2^16-point MSMs), addition + multiplication gates, three public inputs, copy constraints on every second row
+    "generic_public_vesta_2_16": (0, 16, 16, bytes([16, 4] + [42] * 30)),
 }
 PREV_SEED = bytes([11] * 32)           # the previous challenges of *_prev1 are drawn from StdRng::from_seed(PREV_SEED)
 AND_SEED = bytes([12] * 32)            # the AND gadgets' 64-bit inputs
@@ -79,6 +82,35 @@ def and_circuit(F, log2_n: int):
     return cs, rows
 
 
+def generic_circuit(F, log2_n: int, log_srs: int, npub: int = 3, rng_seed: int = 20260926):
+    """double generic gates a + b - c = 0 / a' b' - c' = 0 on random 62-bit operands, the first `npub` rows public inputs, (r, 0) ~ (r, 4) wired on every
+    second row (generic.rs:380-470 style circuits; the shape tests/test_gpu_native_prover.py uses at small sizes)"""
+    import numpy as np
+    p = F.p
+    rnd = np.random.default_rng(rng_seed)
+    n = 1 << log2_n
+    nch = 1 << max(0, log2_n - log_srs)
+    zk = (16 * nch + 5) // 7
+    rows = n - zk - 5
+    ab = rnd.integers(1, 1 << 62, size=(rows, 2), dtype=np.int64)
+    gates, wit = [], [[0] * rows for _ in range(15)]
+    pub_spec, add_spec, mul_spec = CC.generic_spec(p, "Pub"), CC.generic_spec(p, "Add"), CC.generic_spec(p, "Mul")
+    for r in range(rows):
+        a, b = int(ab[r, 0]), int(ab[r, 1])
+        if r < npub:
+            gates.append(CC.generic_gadget(p, r, pub_spec))
+            wit[0][r] = a
+        else:
+            gates.append(CC.generic_gadget(p, r, add_spec, mul_spec))
+            wit[0][r], wit[1][r], wit[2][r] = a, b, (a + b) % p
+            wit[3][r], wit[4][r], wit[5][r] = b, a, a * b % p
+    for r in range(npub, rows - 1, 2):
+        CC.connect_cell_pair(gates, (r, 0), (r, 4))
+    cs = CC.build(F, gates, public=npub, max_poly_size=(1 << log_srs) if log_srs < log2_n else None)
+    assert cs["log2_n"] == log2_n and cs["zk_rows"] == zk
+    return cs, wit
+
+
 def previous_challenges(C, srs, log_srs: int, count: int):
     """RecursionChallenge values as recursion.rs:56-70 makes them: random challenges, comm = commit_non_hiding(b_poly_coefficients(chals))"""
     std = P.StdRng(PREV_SEED)
@@ -98,6 +130,10 @@ def make(name: str, verify: bool = True):
     if name.startswith("and_lookup"):
         cs, wrows = and_circuit(F, log2_n)
         rows, witness, desc = len(wrows), [[r[c] for r in wrows] for c in range(15)], "AND gadgets (create_and_witness)"
+    elif name.startswith("generic_public"):
+        cs, witness = generic_circuit(F, log2_n, log_srs)
+        CC.verify_witness(cs, witness)
+        rows, desc = len(witness[0]), "random 62-bit operands of addition / multiplication gates, 3 public inputs, copy constraints"
     else:
         cs, rows = bench_circuit(F, log2_n, log_srs)
         if nprev:
@@ -111,11 +147,16 @@ def make(name: str, verify: bool = True):
     raw = OPR.serialize_proof(C, proof)
     ok = None
     if verify:
-        ok = bool(K.verify(C, dict(ix.vindex), proof, None, srs.h, P.StdRng(bytes([5] * 32)), final_msm=V.final_msm_c(C, srs.g, srs.size)))
+        vix = dict(ix.vindex)
+        if cs["public"]:                                   # the verifier's own rule (verifier.rs:834-858): from the inputs and the Lagrange-basis points
+            xy, inf = srs.lagrange_basis(log2_n)[0]
+            lag = [V.aff(C, xy[i], inf[i]) for i in range(cs["public"])]
+            vix["public_comm"] = K.public_commitment(C, srs.h, lag, [witness[0][i] for i in range(cs["public"])])
+        ok = bool(K.verify(C, vix, proof, None, srs.h, P.StdRng(bytes([5] * 32)), final_msm=V.final_msm_c(C, srs.g, srs.size)))
         assert ok, "the oracle verifier rejects the oracle prover's proof"
     rec = {"_generated_by": "tests/golden/make_proof_fixtures.py (oracle/prover.py; circuit kimchi/src/bench.rs:59-122, rng StdRng::from_seed(seed))",
            "name": name, "curve": ["vesta", "pallas"][cid], "log2_n": log2_n, "log2_srs": log_srs, "num_chunks": ix.num_chunks, "zk_rows": cs["zk_rows"],
-           "gates": rows, "witness": desc, "prev_challenges": nprev, "lookup": cs["lookup"] is not None, "seed_hex": seed.hex(), "proof_len": len(raw), "proof_sha256": hashlib.sha256(raw).hexdigest(),
+           "gates": rows, "witness": desc, "prev_challenges": nprev, "lookup": cs["lookup"] is not None, "public": cs["public"], "seed_hex": seed.hex(), "proof_len": len(raw), "proof_sha256": hashlib.sha256(raw).hexdigest(),
            "verifier_index_digest_hex": hex(ix.digest), "accepted_by_oracle_verifier": ok,
            "challenges_hex": {k: (None if v is None else hex(v)) for k, v in proof["challenges"].items()},
            "seconds": {"index": round(t1 - t0, 1), "prove": round(t2 - t1, 1)}}
