@@ -44,6 +44,9 @@ CASES = {
     # config 3's size with everything the benchmark circuit lacks: a RANDOM witness (uniform 62-bit values and their products: the fifteen witness
     # commitments are unskewed 2^16-point MSMs), addition + multiplication gates, three public inputs, copy constraints on every second row
     "generic_public_vesta_2_16": (0, 16, 16, bytes([16, 4] + [42] * 30)),
+    # the gate library against BYTES: instances of Poseidon (11 rows = one 55-round permutation), CompleteAdd (incl. doubling, P + (-P)),
+    # VarBaseMul, EndoMul, EndoMulScalar (witnesses by the reference's generators restated in oracle/gates.py) on a 2^13 domain (~120 instances each)
+    "library_gates_vesta_2_13": (0, 13, 13, bytes([13, 5] + [42] * 30)),
 }
 PREV_SEED = bytes([11] * 32)           # the previous challenges of *_prev1 are drawn from StdRng::from_seed(PREV_SEED)
 AND_SEED = bytes([12] * 32)            # the AND gadgets' 64-bit inputs
@@ -111,6 +114,36 @@ def generic_circuit(F, log2_n: int, log_srs: int, npub: int = 3, rng_seed: int =
     return cs, wit
 
 
+def library_circuit(F, log2_n: int, rng_seed: int = 55):
+    """instances of the five always-present library gates until the domain is full; rows a gate only READS as `next` are Zero rows"""
+    import random
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_gates import gate_rows, tables        # the satisfied instances the gate tests use (oracle/gates.py witness generators)
+    p = F.p
+    rnd = random.Random(rng_seed)
+    gates, rows = [], []
+    for r in range(4):                                # a few generic rows first: 1 * w0 - 5 = 0
+        gates.append(CC.generic_gadget(p, r, CC.generic_spec(p, "Const", cst=5))); rows.append([5] + [0] * 14)
+    full = False
+    while not full:
+        for name in ("Poseidon", "CompleteAdd", "VarBaseMul", "EndoMul", "EndoMulScalar"):
+            w, co, ngate = tables(name, rnd)
+            if len(gates) + len(w) + 3 + 1 > (1 << log2_n) - 1:
+                full = True
+                break
+            live = set(gate_rows(name, ngate))
+            base = len(gates)
+            for k, (wr, cr) in enumerate(zip(w, co)):
+                typ = name if k in live else "Zero"
+                gates.append(CC.gate(typ, base + k, [c % p for c in cr] if typ != "Zero" else []))
+                rows.append(list(wr))
+    cs = CC.build(F, gates)
+    assert cs["log2_n"] == log2_n, cs["log2_n"]
+    witness = [[r[c] for r in rows] for c in range(15)]
+    CC.verify_witness(cs, witness)
+    return cs, witness
+
+
 def previous_challenges(C, srs, log_srs: int, count: int):
     """RecursionChallenge values as recursion.rs:56-70 makes them: random challenges, comm = commit_non_hiding(b_poly_coefficients(chals))"""
     std = P.StdRng(PREV_SEED)
@@ -130,6 +163,9 @@ def make(name: str, verify: bool = True):
     if name.startswith("and_lookup"):
         cs, wrows = and_circuit(F, log2_n)
         rows, witness, desc = len(wrows), [[r[c] for r in wrows] for c in range(15)], "AND gadgets (create_and_witness)"
+    elif name.startswith("library_gates"):
+        cs, witness = library_circuit(F, log2_n)
+        rows, desc = len(witness[0]), "instances of Poseidon, CompleteAdd, VarBaseMul, EndoMul, EndoMulScalar (oracle/gates.py witness generators)"
     elif name.startswith("generic_public"):
         cs, witness = generic_circuit(F, log2_n, log_srs)
         CC.verify_witness(cs, witness)

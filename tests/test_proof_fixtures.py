@@ -16,7 +16,7 @@ from oracle import prover as OPR
 HERE = os.path.dirname(os.path.abspath(__file__))
 FIX = os.path.join(HERE, "golden", "proof_fixtures")
 sys.path.insert(0, os.path.join(HERE, "golden"))
-NAMES = ["bench_vesta_2_10", "bench_vesta_2_16", "bench_pallas_2_16", "bench_vesta_2_17_over_2_16", "bench_vesta_2_16_prev1", "and_lookup_vesta_2_13", "generic_public_vesta_2_16"]
+NAMES = ["bench_vesta_2_10", "bench_vesta_2_16", "bench_pallas_2_16", "bench_vesta_2_17_over_2_16", "bench_vesta_2_16_prev1", "and_lookup_vesta_2_13", "generic_public_vesta_2_16", "library_gates_vesta_2_13"]
 
 
 def _load(name):
