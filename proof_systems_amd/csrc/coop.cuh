@@ -79,6 +79,44 @@ __device__ __forceinline__ Fe<F> quad_add(const Fe<F>& a, const Fe<F>& b) {
     if (a_id) res = b;
     return res;
 }
+// this lane's coordinate of 2 A (dbl-2008-s-1 on the curve y^2 = x^3 + b), given its coordinate of A: 4 product rounds instead of 9 products
+//   round 1   role0: XX = X^2            role1: V = U^2, U = 2 Y
+//   round 2   role0: S = X V             role1: W = U V             role2: ZZ3 = V ZZ           role3: MM = M^2, M = 3 XX
+//   round 3   role1: W Y                 role3: ZZZ3 = W ZZZ        (role0: X3 = MM - 2 S, no product)
+//   round 4   role1: Y3 = M (S - X3) - W Y
+// The identity (ZZ = 0) doubles to ZZ3 = ZZZ3 = 0 by itself; the Pasta curves have no point of order two.
+template <class F>
+__device__ __forceinline__ Fe<F> quad_dbl(const Fe<F>& a) {
+    const int role = (int)(threadIdx.x & 3u);
+    const Fe<F> U = add<F>(a, a);                                         // meaningful in role 1
+    const Fe<F> p1 = role == 1 ? U : a;
+    const Fe<F> m1 = mul<F>(p1, p1);                                      // XX | V | - | -
+    const Fe<F> Vb = quad_get<F, QP_BCAST1>(m1), XXb = quad_get<F, QP_BCAST0>(m1);
+    const Fe<F> M = add<F>(add<F>(XXb, XXb), XXb);                         // every lane
+    const Fe<F> x2 = role == 1 ? U : (role == 3 ? M : a);
+    const Fe<F> y2 = role == 1 ? m1 : (role == 3 ? M : Vb);
+    const Fe<F> m2 = mul<F>(x2, y2);                                      // S | W | ZZ3 | MM
+    const Fe<F> Wb = quad_get<F, QP_BCAST1>(m2), Sb = quad_get<F, QP_BCAST0>(m2), MMb = quad_get<F, QP_BCAST3>(m2);
+    const Fe<F> X3 = sub<F>(sub<F>(MMb, Sb), Sb);                          // every lane
+    const Fe<F> m3 = mul<F>(role == 1 ? m2 : Wb, a);                       // - | W Y | - | ZZZ3
+    const Fe<F> m4 = mul<F>(M, sub<F>(Sb, X3));                            // role1: M (S - X3)
+    return role == 0 ? X3 : (role == 1 ? sub<F>(m4, m3) : (role == 2 ? m2 : m3));
+}
+// k A for a canonical 256-bit k (eight 32-bit words), left to right; quads of one wave may hold different k (the DPP moves stay inside the quad)
+template <class F>
+__device__ __forceinline__ Fe<F> quad_scalar_mul(const Fe<F>& a, const u32 k[8]) {
+    Fe<F> acc = Fe<F>::zero();
+    int top = 7;
+    while (top > 0 && k[top] == 0) top--;
+    for (int w = top; w >= 0; w--) {
+        const u32 word = k[w];
+        for (int b = 31; b >= 0; b--) {
+            acc = quad_dbl<F>(acc);
+            if ((word >> b) & 1u) acc = quad_add<F>(acc, a);
+        }
+    }
+    return acc;
+}
 // the quad's piece of a 128-byte XYZZ record (x | y | zz | zzz, 32 bytes each)
 template <class F>
 __device__ __forceinline__ Fe<F> quad_load(const uint8_t* rec) { return Fe<F>::load(rec + 32 * (threadIdx.x & 3u)); }

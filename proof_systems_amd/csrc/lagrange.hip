@@ -9,6 +9,7 @@
 // n/2 * log2(n) scalar multiplications: ~0.1 s at n = 2^16 on an MI355X (minutes on the CPU path).
 #include "common.hpp"
 #include "curve.cuh"
+#include "coop.cuh"
 #include "host_ec.hpp"
 #include "msm.hpp"
 
@@ -50,6 +51,37 @@ k_lag_stage(uint8_t* __restrict__ A, const u64* __restrict__ tw_plain, unsigned 
     }
     add<BF>(u, v).store(A + (k + j) * 128);
     add<BF>(u, negate<BF>(v)).store(A + (k + j + m) * 128);
+}
+// The same butterfly by FOUR lanes (coop.cuh): a stage is one long dependent chain per butterfly -- 255 doublings and as many additions as the twiddle has
+// bits set, 23 products per bit with one lane -- on a GPU that n / 2 threads leave half empty at 2^16; with a point spread over a quad a doubling is 4
+// product rounds and an addition 5: a 2.5 times shorter chain at four times the lanes.
+template <class BF>
+__global__ void __launch_bounds__(256)
+k_lag_stage_q(uint8_t* __restrict__ A, const u64* __restrict__ tw_plain, unsigned log_n, unsigned log_m) {
+    size_t t = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
+    const size_t half = (size_t)1 << (log_n - 1);
+    const bool live = t < half;
+    if (!live) t = half - 1;                                 // keep whole quads in the DPP moves
+    const u32 role = threadIdx.x & 3u;
+    const size_t m = (size_t)1 << log_m;
+    // n / 2m butterflies share the twiddle w^j: while that is at least a wave's sixteen quads, the quads of a wave take the SAME j (and sixteen
+    // different k), so the ladder's additions are executed for the set bits of one twiddle only, not for the union over sixteen
+    const size_t per = half >> log_m;
+    const size_t j = per >= 16 ? t / per : (t & (m - 1));
+    const size_t k = (per >= 16 ? t % per : (t >> log_m)) << (log_m + 1);
+    const Fe<BF> u = quad_load<BF>(A + (k + j) * 128);
+    Fe<BF> v = quad_load<BF>(A + (k + j + m) * 128);
+    const bool v_id = quad_flag<QP_BCAST2>(v.is_zero());
+    if (j != 0 && !v_id) {
+        u32 kw[8];
+        const uint4* q = (const uint4*)(tw_plain + 4 * (j << (log_n - 1 - log_m)));
+        const uint4 a = q[0], b = q[1];
+        kw[0] = a.x; kw[1] = a.y; kw[2] = a.z; kw[3] = a.w; kw[4] = b.x; kw[5] = b.y; kw[6] = b.z; kw[7] = b.w;
+        v = quad_scalar_mul<BF>(v, kw);
+    }
+    const Fe<BF> s = quad_add<BF>(u, v);
+    const Fe<BF> d = quad_add<BF>(u, role == 1 ? neg<BF>(v) : v);
+    if (live) { quad_store<BF>(A + (k + j) * 128, s); quad_store<BF>(A + (k + j + m) * 128, d); }
 }
 // A[i] <- n^-1 * A[i], normalised to affine; identity -> zeros + flag
 template <class BF>
@@ -104,8 +136,13 @@ static int lagrange_t(Context& C, int sfield, const void* g_dev, size_t srs_size
     KH_HIP(hipMemcpyAsync(ninv_dev, &ninv, 32, hipMemcpyHostToDevice, s));
     KH_HIP(hipStreamSynchronize(s));
     hipLaunchKernelGGL((k_lag_init<BF>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const uint8_t*)g_dev, start, num_terms, log_n, A.as<uint8_t>());
-    for (unsigned lm = 0; lm < log_n; lm++)
-        hipLaunchKernelGGL((k_lag_stage<BF>), dim3((unsigned)((n / 2 + 127) / 128)), dim3(128), 0, s, A.as<uint8_t>(), tw_plain, log_n, lm);
+    static const bool lag_quad = !(getenv("KH_LAG_QUAD") && atoi(getenv("KH_LAG_QUAD")) == 0);      // 0: one lane per butterfly (round 1's kernel)
+    for (unsigned lm = 0; lm < log_n; lm++) {
+        if (lag_quad && n >= 8)
+            hipLaunchKernelGGL((k_lag_stage_q<BF>), dim3((unsigned)((4 * (n / 2) + 255) / 256)), dim3(256), 0, s, A.as<uint8_t>(), tw_plain, log_n, lm);
+        else
+            hipLaunchKernelGGL((k_lag_stage<BF>), dim3((unsigned)((n / 2 + 127) / 128)), dim3(128), 0, s, A.as<uint8_t>(), tw_plain, log_n, lm);
+    }
     hipLaunchKernelGGL((k_lag_finish<BF>), dim3((unsigned)((n + 127) / 128)), dim3(128), 0, s, A.as<uint8_t>(), n, ninv_dev, (uint8_t*)out_xy_dev, out_inf_dev);
     KH_HIP(hipGetLastError());
     KH_HIP(hipStreamSynchronize(s));
