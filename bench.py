@@ -5,7 +5,7 @@ Workload at N=1 (BASELINE.json configs[1]): ONE 2^20-point Pippenger MSM over th
 (bases = SRS::<Vesta>::create(1<<20).g, generated on the device by kh_srs_create_device;
 scalars = uniform 254-bit Fp Montgomery limbs from a fixed-seed PRNG), inputs resident in HBM
 when the timed region starts.  A "step" is one such MSM through the C ABI (digits -> sort ->
-bucket accumulation -> reduction -> host finish); the timed loop keeps four of them in flight
+bucket accumulation -> reduction -> host finish); the timed loop keeps two of them in flight (KH_BENCH_DEPTH; round 4: two beat three and four at 20 and at 60 steps)
 (kh_msm_submit / kh_msm_wait); the warm-up steps are synchronous and give the latency, five more
 synchronous steps after the timed loop give the per-phase HIP-event timings and the dominant
 kernel's own duration at the clocks the loop ran at.
@@ -622,14 +622,14 @@ def main():
         ts = time.perf_counter()
         result = combine(*srs.msm_batch_dev(d_sc.ptr, n, 1))
         sync_ms.append(1e3 * (time.perf_counter() - ts))
-    # timed region: EXACTLY `steps` MSMs, four in flight (kh_msm_submit / kh_msm_wait): the sort of step i+2 and the
-    # bucket-reduction tail of step i run underneath the accumulation of step i+1.  Every step is a full MSM whose affine
+    # timed region: EXACTLY `steps` MSMs, `depth` in flight (kh_msm_submit / kh_msm_wait; two by default): the sort of step i+1 and the
+    # bucket-reduction tail of step i-1 run underneath the accumulation of step i.  Every step is a full MSM whose affine
     # result is fetched and (N>1) combined across ranks INSIDE the region; the partial sums of up to `depth` finished MSMs travel in ONE
     # collective ("batch the partials of all MSMs in a phase into one collective" -- a prover combines the commitments of a
     # phase together; KH_BENCH_COMBINE_EVERY=1 gives one collective per MSM).
     fence()
     t0 = time.perf_counter()
-    depth = 1 if args.no_pipeline else int(os.environ.get('KH_BENCH_DEPTH', '4'))
+    depth = 1 if args.no_pipeline else int(os.environ.get('KH_BENCH_DEPTH', '2'))      # measured round 4 (profiles/r04_depth_steps.txt): 2 / 3 / 4 in flight = 852 / 836 / 821 Mscalar/s at 20 steps, 902 / 895 / 892 at 60
     combine_every = max(1, int(os.environ.get('KH_BENCH_COMBINE_EVERY', str(depth))))
     pending, done = [], []
 
@@ -647,10 +647,15 @@ def main():
         done.append((xy[0], inf[0]))
         if len(done) >= combine_every:
             flush()
+    # KH_BENCH_RAMP=r: the number in flight starts at r and grows by one per finished MSM up to `depth` (an experiment on the pipeline's fill:
+    # four jobs submitted at once run their sorts and accumulations in lockstep until they drift apart)
+    ramp = int(os.environ.get('KH_BENCH_RAMP', '0'))
+    cur_depth = min(depth, ramp) if ramp > 0 else depth
     for _ in range(args.steps):
         pending.append(srs.msm_submit(d_sc.ptr, n, 1))
-        if len(pending) >= depth:
+        if len(pending) >= cur_depth:
             collect(pending.pop(0))
+            cur_depth = min(depth, cur_depth + 1)
     while pending:
         collect(pending.pop(0))
     flush()
@@ -688,7 +693,7 @@ def main():
                    "scalars": "uniform 254-bit, seed 1234+rank", "parallelism": "point-range x%d" % world,
                    "collective_backend": sm.collective_backend, "process_group_backend": backend, "world_size_seen": world,
                    "partials_per_collective": (combine_every if sm.collective_backend else None)},
-        "latency_value": total / (latency * 1e-3) / 1e6, "latency_note": "one MSM at a time (submit -> wait -> combine): `value` keeps 4 in flight",
+        "latency_value": total / (latency * 1e-3) / 1e6, "latency_note": "one MSM at a time (submit -> wait -> combine): `value` keeps %d in flight" % depth,
         "ms_per_step_synchronous": latency, "msm_in_flight": depth,
         "roofline": roofline_block(kname, acc, n, args.log_n) if not args.strong else roofline_block(kname, acc, n, -1),
         "phases_ms": phase_avg, "srs_create_device_s": t_gen,
