@@ -171,6 +171,7 @@ struct kh_srs {
     DevBuf g;                 // window tables of g_stride = n + 2 points: g[0..n), then the slots of H and U
     size_t g_stride = 0;      // (the two extra bases of the opening rounds, written by kh_ipa_begin)
     int g_precomp_c = 0;
+    DevBuf g_wide; int g_wide_c = 0;   // second table set with wide windows (MSM_WIDE_C) for bases of >= msm_wide_min_n() points: big single MSMs
     bool ipa_live = false;    // the U slot belongs to one opening at a time
     std::thread::id ipa_owner;   // ... begun by this thread (a second opening from ANOTHER thread waits for it: SRS::open is re-entrant on &self)
     // workspace of the opening rounds, kept across openings (hipMalloc / hipFree cost ~0.1 ms each: 1 ms per proof)
@@ -207,6 +208,7 @@ static int resolve_basis(kh_srs_t* srs, int basis, unsigned chunk, MsmBasis& out
     if (basis == KH_BASIS_G) {
         KH_REQUIRE(chunk == 0, "chunk must be 0 for the monomial basis");
         out.pts = srs->g.p; out.inf = nullptr; out.n = srs->n; out.stride = srs->g_stride; out.precomp_c = srs->g_precomp_c;
+        out.wide_pts = srs->g_wide_c ? srs->g_wide.p : nullptr; out.wide_c = srs->g_wide_c;
         return KH_OK;
     }
     std::lock_guard<std::mutex> ml(srs->map_mu);
@@ -365,6 +367,18 @@ int kh_private_context_end(void) {
 }
 const char* kh_last_error(void) { return g_err.c_str(); }
 
+// the wide-window table set of a big basis (table 0 = a copy of the basis; H / U slots unused)
+static int build_wide_tables(Context& C, kh_srs* s) {
+    if (!s->g_precomp_c || s->n < msm_wide_min_n()) return KH_OK;
+    const int W = (256 + MSM_WIDE_C - 1) / MSM_WIDE_C;
+    int rc;
+    if ((rc = s->g_wide.reserve(s->g_stride * 64 * (size_t)W))) return rc;
+    KH_HIP(hipMemcpyAsync(s->g_wide.p, s->g.p, s->g_stride * 64, hipMemcpyDeviceToDevice, C.stream));
+    if ((rc = msm_precompute(C, s->curve, s->g_wide.p, nullptr, s->g_stride, MSM_WIDE_C))) return rc;
+    s->g_wide_c = MSM_WIDE_C;
+    return KH_OK;
+}
+int kh_msm_set_wide_min_n(size_t n) { msm_set_wide_min_n(n); return KH_OK; }
 int kh_srs_create(int curve, const uint64_t* g_xy, size_t n, kh_srs_t** out) {
     KH_REQUIRE(out && g_xy && n > 0, "kh_srs_create: null argument or n == 0");
     KH_REQUIRE(curve == KH_CURVE_VESTA || curve == KH_CURVE_PALLAS, "unknown curve id %d", curve);
@@ -384,6 +398,7 @@ int kh_srs_create(int curve, const uint64_t* g_xy, size_t n, kh_srs_t** out) {
     if (pre) {
         if ((rc = msm_precompute(C, curve, s->g.p, nullptr, s->g_stride, MSM_PRECOMP_C))) return rc;
         s->g_precomp_c = MSM_PRECOMP_C;
+        if ((rc = build_wide_tables(C, s.get()))) return rc;
     }
     // tables are per HANDLE, streams per context: another context (kh_private_context_begin on another thread) may use the handle at once, so it is
     // handed out complete (a one-time cost)
@@ -413,6 +428,7 @@ int kh_srs_create_device_range(int curve, size_t start, size_t depth, kh_srs_t**
     if (pre) {
         if ((rc = msm_precompute(C, curve, s->g.p, nullptr, s->g_stride, MSM_PRECOMP_C))) return rc;
         s->g_precomp_c = MSM_PRECOMP_C;
+        if ((rc = build_wide_tables(C, s.get()))) return rc;
     }
     // tables are per HANDLE, streams per context: another context (kh_private_context_begin on another thread) may use the handle at once, so it is
     // handed out complete (a one-time cost)

@@ -100,7 +100,8 @@ struct MsmSlot {
     hipStream_t stream = nullptr;
     PhaseTimer timer;
     DevBuf ws_scalars, ws_digits, ws_hist, ws_cnt, ws_off, ws_ntask, ws_toff, ws_entries, ws_partial,
-        ws_buckets, ws_seg, ws_out, ws_scan_tmp, ws_biglist, ws_points, ws_order, ws_chunks, ws_handed, ws_sync, ws_mid;
+        ws_buckets, ws_seg, ws_out, ws_scan_tmp, ws_biglist, ws_points, ws_order, ws_chunks, ws_handed, ws_sync, ws_mid,
+        ws_b29, ws_a1, ws_a2, ws_xlist;                              // wide windows (c = 20): lazy buckets, first-level chunk sums, the 2 x 2^lo marginals
     void* pinned = nullptr; size_t pinned_cap = 0;      // host staging of the group sums (XYZZ)
     hipEvent_t done = nullptr;
     // pending job (set by enqueue, consumed by finish)
@@ -108,6 +109,7 @@ struct MsmSlot {
     std::thread::id owner;             // the host thread that queued the pending job (acquire_slot: another thread's ticket will be waited for)
     uint64_t ticket = 0;
     int curve = 0, W = 0, c = 0, precomp = 0, planes = 0, plane_shift[2] = {0, 0};
+    int wide_lo = 0, g_wide_lo = 0;    // wide windows: bits of the low bucket digit (0: the narrow path); msm_finish folds two marginal groups per MSM
     size_t k = 0, ngroups = 0;
     // hipGraph of one MSM's launch sequence (the opening rounds repeat the same MSM -- same basis, scalar buffer, sizes --
     // 16 times: ~22 launches per round replayed as one graph).  Keyed by every pointer and size the launches bake in.

@@ -193,4 +193,80 @@ __device__ __forceinline__ bool madd29(Acc29<F>& a, const Fe29<F>& px, const Fe2
     return true;
 }
 
+// a += b, both lazy XYZZ points with the bounds of Acc29 (the full addition add-2008-s, 12M + 2S as 10 products + 2 squarings + one fused
+// product pair; limb model: tools/gen_field29_asm.py Madd29Model.add).  Neither operand may be the identity (the callers skip all-zero
+// records; a lazy point that went through madd29 / add29 never is one).  Returns false -- a untouched -- when P = U2 - U1 = 0 (mod p)
+// cannot be excluded, i.e. the points may be equal or opposite: the caller hands its work item to the exact 32-bit path.
+template <class F>
+__device__ __forceinline__ bool add29(Acc29<F>& a, const Acc29<F>& b) {
+    typedef typename C29<F>::T K;
+    const Fe29<F> U1 = mul29<F>(a.x, b.zz), U2 = mul29<F>(b.x, a.zz);
+    Fe29<F> P, R;
+    KH29_SUBN(P, U2, U1, K::s51)
+    if (__builtin_expect(P.v[0] <= 8u, 0) && is_kp29<F>(P, P.v[0])) return false;                  // P = k p: same x
+    const Fe29<F> S1 = mul29<F>(a.y, b.zzz), S2 = mul29<F>(b.y, a.zzz);
+    KH29_SUBN(R, S2, S1, K::s51)
+    const Fe29<F> PP = sqr29<F>(P);
+    const Fe29<F> PPP = mul29<F>(P, PP), Q = mul29<F>(U1, PP), RR = sqr29<F>(R);
+    Fe29<F> sub, rx, t, yn;
+#pragma unroll
+    for (int i = 0; i < 9; i++) sub.v[i] = PPP.v[i] + 2u * Q.v[i];
+    KH29_SUBN(rx, RR, sub, K::s44)
+#pragma unroll
+    for (int i = 0; i < 9; i++) t.v[i] = Q.v[i] + K::s61(i) - rx.v[i];          // not normalised
+#pragma unroll
+    for (int i = 0; i < 9; i++) yn.v[i] = K::s51(i) - S1.v[i];                    // 5 p - S1, not normalised
+    a.y = muladd29<F>(R, t, yn, PPP);                                           // R (Q - X3) - S1 PPP
+    a.zz = mul29<F>(mul29<F>(a.zz, b.zz), PP);
+    a.zzz = mul29<F>(mul29<F>(a.zzz, b.zzz), PPP);
+    a.x = rx;
+    return true;
+}
+
+// A lazy XYZZ point in memory ("B29 record"): 36 words x | y | zz | zzz of nine limbs each, 144 bytes, 16-byte aligned.  The identity is the
+// record whose zz limbs are all zero (what to29 makes of the canonical identity; a lazy sum is never congruent to it, see add29).
+static constexpr size_t B29_BYTES = 144;
+template <class F>
+__device__ __forceinline__ Acc29<F> load_b29(const uint8_t* rec) {
+    const uint4* q = (const uint4*)rec;
+    u32 w[36];
+#pragma unroll
+    for (int i = 0; i < 9; i++) { const uint4 v = q[i]; w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w; }
+    Acc29<F> r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) { r.x.v[i] = w[i]; r.y.v[i] = w[9 + i]; r.zz.v[i] = w[18 + i]; r.zzz.v[i] = w[27 + i]; }
+    return r;
+}
+template <class F>
+__device__ __forceinline__ void store_b29(uint8_t* rec, const Acc29<F>& a) {
+    u32 w[36];
+#pragma unroll
+    for (int i = 0; i < 9; i++) { w[i] = a.x.v[i]; w[9 + i] = a.y.v[i]; w[18 + i] = a.zz.v[i]; w[27 + i] = a.zzz.v[i]; }
+    uint4* q = (uint4*)rec;
+#pragma unroll
+    for (int i = 0; i < 9; i++) q[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+}
+template <class F>
+__device__ __forceinline__ void store_b29_identity(uint8_t* rec) {
+    uint4* q = (uint4*)rec;
+#pragma unroll
+    for (int i = 0; i < 9; i++) q[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+template <class F>
+__device__ __forceinline__ bool is_identity29(const Acc29<F>& a) {
+    u32 o = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) o |= a.zz.v[i];
+    return o == 0u;
+}
+// exact point <-> B29 record (the exact kernels that feed or redo lazy work)
+template <class F>
+__device__ __forceinline__ Acc29<F> xyzz_to29(const Xyzz<F>& p) {
+    Acc29<F> r; r.x = to29<F>(p.x); r.y = to29<F>(p.y); r.zz = to29<F>(p.zz); r.zzz = to29<F>(p.zzz); return r;
+}
+template <class F>
+__device__ __forceinline__ Xyzz<F> xyzz_from29(const Acc29<F>& a) {
+    Xyzz<F> r; r.x = from29<F>(a.x); r.y = from29<F>(a.y); r.zz = from29<F>(a.zz); r.zzz = from29<F>(a.zzz); return r;
+}
+
 }  // namespace kh

@@ -255,7 +255,7 @@ __device__ __forceinline__ u32 lds_inc_agg(u32* ctr, u32 key, bool active) {
     return active ? atomicAdd(&ctr[key], 1u) : 0u;
 }
 __global__ void __launch_bounds__(PART_T)
-k_part_hist(const int32_t* __restrict__ digits, u32 tot_e, u32 nblk, u32* __restrict__ PH) {
+k_part_hist(const int32_t* __restrict__ digits, u32 tot_e, u32 nblk, u32 shift, u32* __restrict__ PH) {
     KH_HIGH_PRIO();
     __shared__ u32 cnt[PART_P];
     const u32 blk = blockIdx.x, j = blockIdx.y, tid = threadIdx.x;
@@ -268,7 +268,7 @@ k_part_hist(const int32_t* __restrict__ digits, u32 tot_e, u32 nblk, u32* __rest
 #pragma unroll
         for (int u = 0; u < 8; u++) { const u32 e = e0 + u * PART_T; v[u] = d[e < e_hi ? e : e_hi - 1]; if (e >= e_hi) v[u] = 0; }
 #pragma unroll
-        for (int u = 0; u < 8; u++) (void)lds_inc_agg(cnt, ((u32)(v[u] < 0 ? -v[u] : v[u]) - 1u) >> PART_LOW, v[u] != 0);
+        for (int u = 0; u < 8; u++) (void)lds_inc_agg(cnt, (((u32)(v[u] < 0 ? -v[u] : v[u]) - 1u) >> shift) & (PART_P - 1u), v[u] != 0);
     }
     __syncthreads();
     if (tid < PART_P) PH[((size_t)j * PART_P + tid) * nblk + blk] = cnt[tid];
@@ -655,6 +655,160 @@ k_sort_fused(const int32_t* __restrict__ digits, FusedGeom g, u32* __restrict__ 
         }
     }
 }
+// ------------------------------------------------------------------------------------ partitioned sort, wide windows (c = 20: 2^19 buckets)
+// The same two passes for 2^(8 + low) buckets, low <= PART2_MAXLOW: pass B then sorts a partition of 2^low buckets through 2^low LDS cursors.
+// A partition is the set of buckets with the same LOW 8 bits here: the top window of a 255-bit scalar holds only 15 bits, so its 2^20 entries fall
+// into the 2^14 lowest buckets (+64 entries each, on top of ~24) -- eight contiguous partitions would get 3.5 x the records of the others (pass B took
+// 300 us instead of 90) and a length ranking per partition would differ wildly between partitions; with the low bits every partition holds its share
+// of the heavy buckets.  Everything downstream of the sort therefore works on PERMUTED keys  key' = (bucket & 255) << low | bucket >> 8  (per MSM);
+// only the bucket records the reduction reads are stored by true bucket number (wide_true_bucket).  The
+// 32-bit record of pass A cannot carry 11 bucket bits + sign + window + 20 point bits any more; it carries the entry's position INSIDE ITS PASS-A
+// BLOCK instead (16 bits: a block reads a contiguous run of <= 65,536 digits of the [w][i] matrix): pass B knows from the scanned block matrix PO
+// which block wrote the record it is looking at (the partition's run is the concatenation of the blocks' runs, in block order) and rebuilds
+// (window, point) from block start + local position.
+static constexpr u32 PART2_MAXLOW = 11;
+__global__ void __launch_bounds__(PART_T)
+k_part2_scatter(const int32_t* __restrict__ digits, u32 tot_e, u32 nblk, u32 low, const u32* __restrict__ PO, u32* __restrict__ mid, u32* __restrict__ xlist) {
+    KH_HIGH_PRIO();
+    __shared__ u32 cur[PART_P];
+    const u32 blk = blockIdx.x, j = blockIdx.y, tid = threadIdx.x;
+    if (blk == 0 && j == 0 && tid == 0) xlist[0] = 0;        // the split-bucket list pass B appends to
+    if (tid < PART_P) cur[tid] = PO[((size_t)j * PART_P + tid) * nblk + blk];
+    __syncthreads();
+    const u32 e_lo = (u32)((u64)tot_e * blk / nblk), e_hi = (u32)((u64)tot_e * (blk + 1) / nblk);
+    const int32_t* d = digits + (size_t)j * tot_e;
+    for (u32 e0 = e_lo + tid; e0 < e_hi; e0 += 8 * PART_T) {
+        int32_t v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const u32 e = e0 + u * PART_T; v[u] = d[e < e_hi ? e : e_hi - 1]; if (e >= e_hi) v[u] = 0; }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const u32 b = (u32)(v[u] < 0 ? -v[u] : v[u]) - 1u;
+            const u32 pos = lds_inc_agg(cur, b & (PART_P - 1u), v[u] != 0);
+            if (v[u]) mid[pos] = ((b >> 8) << 17) | (v[u] < 0 ? 1u << 16 : 0u) | (e0 + u * PART_T - e_lo);
+        }
+    }
+}
+// Pass B also plans the accumulation: with ~26 entries per bucket a task IS a bucket (buckets above K entries are split as on the narrow path), so the
+// task counts, their prefix (toff) and the length ranking are partition-local here (the narrow path ranks all keys globally: two more kernels and
+// two more device-wide scans, 64 us at 2^19 keys).  toff is written relative to the partition (k_wide_fixup adds the partitions' task bases);
+// the order is INTERLEAVED over the partitions -- order[r * nparts + q] = the bucket of rank r (longest first) in partition q -- so that the
+// accumulation launch runs longest-first as a whole (partitions are statistically alike) and a wave holds one rank of 64 partitions; the extra
+// chunks of split buckets go to xlist as (key, chunk) pairs.
+struct WideTasks { u32 room, kmin, nkeys; KTab ktab; };
+__global__ void __launch_bounds__(PART_T)
+k_part2_sort(const u32* __restrict__ mid, const u32* __restrict__ PO, u32 nblk, u32 low, u32 nb, u32 tot_e, u32 n, size_t pt_stride, size_t pt_offset,
+             size_t pt_batch, u32 last_group, size_t total_idx, WideTasks ta, u32* __restrict__ off, u32* __restrict__ entries,
+             u32* __restrict__ toff, u32* __restrict__ order, u32* __restrict__ ptot, u32* __restrict__ xlist, u32 dbg) {
+    KH_HIGH_PRIO();
+    __shared__ u32 cur[1u << PART2_MAXLOW], pstart[1025], bi0[1024], bw0[1024], lh[MAX_K + 2], sh[PART_T / 64 + 1];
+    __shared__ u32 xl_key[1u << PART2_MAXLOW], xl_nt[1u << PART2_MAXLOW], xl_base[1u << PART2_MAXLOW], xl_n;
+    const u32 pidx = blockIdx.x, j = blockIdx.y, tid = threadIdx.x;
+    const size_t q = (size_t)j * PART_P + pidx;
+    const u32 nparts = gridDim.x * gridDim.y;
+    const u32 nbl = 1u << low;
+    for (u32 i = tid; i <= nblk; i += PART_T) pstart[i] = PO[q * nblk + i];           // (the scan has one element more than the matrix: the total)
+    for (u32 i = tid; i < nblk; i += PART_T) {                                        // (window, point) of the first digit of pass-A block i
+        const u32 est = (u32)((u64)tot_e * i / nblk), w0 = est / n;
+        bw0[i] = w0; bi0[i] = est - w0 * n;
+    }
+    for (u32 i = tid; i < nbl; i += PART_T) cur[i] = 0;
+    for (u32 i = tid; i < MAX_K + 2; i += PART_T) lh[i] = 0;
+    if (tid == 0) xl_n = 0;
+    __syncthreads();
+    const u32 base = pstart[0], end = pstart[nblk];
+    if (!(dbg & 4u))
+    for (u32 x0 = base + tid; x0 < end; x0 += 8 * PART_T) {
+        u32 m[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const u32 x = x0 + u * PART_T; m[u] = mid[x < end ? x : end - 1]; }
+#pragma unroll
+        for (int u = 0; u < 8; u++) (void)lds_inc_agg(cur, m[u] >> 17, x0 + u * PART_T < end);
+    }
+    __syncthreads();
+    {   // this thread's two consecutive buckets: entry offsets (off, the scatter cursors), task counts, their prefix, the length ranking
+        const u32 i0 = 2 * tid, a = i0 < nbl ? cur[i0] : 0u, b = i0 + 1 < nbl ? cur[i0 + 1] : 0u;
+        u32 btot;
+        const u32 ex = base + block_scan_1024(a + b, sh, &btot);
+        __syncthreads();
+        const size_t key0 = (size_t)j * nb + (size_t)pidx * nbl + i0;
+        if (i0 < nbl) { off[key0] = ex; cur[i0] = ex; }
+        if (i0 + 1 < nbl) { off[key0 + 1] = ex + a; cur[i0 + 1] = ex + a; }
+        if (tid == 0 && pidx == PART_P - 1 && j == last_group) off[(size_t)(j + 1) * nb] = end;          // off[nkeys] = number of entries
+        const u32 K = pick_K(PO[total_idx], ta.room, ta.kmin, ta.ktab, ta.nkeys);
+        const u32 nta = (a + K - 1) / K, ntb = (b + K - 1) / K;
+        const u32 la = nta ? (a + nta - 1) / nta : 0u, lb = ntb ? (b + ntb - 1) / ntb : 0u;
+        const u32 tex = block_scan_1024(nta + ntb, sh, &btot);
+        if (i0 < nbl) toff[key0] = tex;
+        if (i0 + 1 < nbl) toff[key0 + 1] = tex + nta;
+        if (tid == 0) ptot[q] = btot;
+        if (i0 < nbl) atomicAdd(&lh[la], 1u);
+        if (i0 + 1 < nbl) atomicAdd(&lh[lb], 1u);
+        if (nta > 1) { const u32 sl = atomicAdd(&xl_n, 1u); xl_key[sl] = (u32)key0; xl_nt[sl] = nta; xl_base[sl] = atomicAdd(&xlist[0], nta - 1u); }
+        if (ntb > 1) { const u32 sl = atomicAdd(&xl_n, 1u); xl_key[sl] = (u32)key0 + 1u; xl_nt[sl] = ntb; xl_base[sl] = atomicAdd(&xlist[0], ntb - 1u); }
+        __syncthreads();
+        // lh[L] <- number of buckets with a task length above L = first rank of length L (longest first)
+        const u32 L = MAX_K - (tid <= MAX_K ? tid : MAX_K), hv = tid <= MAX_K ? lh[L] : 0u;
+        const u32 above = block_scan_1024(hv, sh, &btot);
+        __syncthreads();
+        if (tid <= MAX_K) lh[L] = above;
+        __syncthreads();
+        const u32 og = dbg >> 8;                          // interleaving granularity (ranks per partition in a row)
+        if (i0 < nbl) { const u32 r = atomicAdd(&lh[la], 1u); order[(size_t)(r / og) * nparts * og + q * og + (r % og)] = (u32)key0; }
+        if (i0 + 1 < nbl) { const u32 r = atomicAdd(&lh[lb], 1u); order[(size_t)(r / og) * nparts * og + q * og + (r % og)] = (u32)key0 + 1u; }
+        // the chunks 1 .. nt - 1 of the split buckets, written by the whole block (one bucket may hold every entry of the MSM)
+        const u32 nx = xl_n;
+        for (u32 it = 0; it < nx; it++) {
+            const u32 key = xl_key[it], ntx = xl_nt[it], xb = xl_base[it];
+            for (u32 jt = 1 + tid; jt < ntx; jt += PART_T) { xlist[2 + 2 * (size_t)(xb + jt - 1)] = key; xlist[3 + 2 * (size_t)(xb + jt - 1)] = jt; }
+        }
+    }
+    __syncthreads();
+    const u32 pb0 = (u32)(pt_offset + (size_t)j * pt_batch);
+    u32 top = 1; while (top * 2 <= nblk) top *= 2;       // largest power of two <= nblk
+    for (u32 x0 = base + tid; x0 < end; x0 += 8 * PART_T) {
+        u32 m[8], blk[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const u32 x = x0 + u * PART_T; m[u] = mid[x < end ? x : end - 1]; blk[u] = 0; }
+        // the pass-A block that wrote record x: the largest blk with pstart[blk] <= x, all eight searches in lockstep (LDS latency overlaps)
+        if (!(dbg & 2u))
+        for (u32 st = top; st >= 1; st >>= 1) {
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const u32 x = x0 + u * PART_T, c = blk[u] + st;
+                if (c < nblk && pstart[c] <= (x < end ? x : end - 1)) blk[u] = c;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const bool live = x0 + u * PART_T < end;
+            const u32 pos = lds_inc_agg(cur, m[u] >> 17, live);
+            if (live) {
+                u32 w = bw0[blk[u]], i = bi0[blk[u]] + (m[u] & 0xffffu);
+                while (i >= n) { i -= n; w++; }
+                if (!(dbg & 1u)) entries[pos] = (pb0 + (u32)(w * pt_stride) + i) | ((m[u] & (1u << 16)) << 15);
+            }
+        }
+    }
+}
+// toff of k_part2_sort is relative to its partition: add the partitions' task bases; toff[nkeys] = number of tasks.  Block = 256 consecutive keys of
+// ONE partition (2^low is a multiple of 256).  Also empties the hand-over and hot-bucket lists of the kernels that follow.
+__global__ void __launch_bounds__(256)
+k_wide_fixup(u32* __restrict__ toff, const u32* __restrict__ ptot, u32 nparts, u32 low, u32 nkeys, u32* __restrict__ handed, u32* __restrict__ big) {
+    KH_HIGH_PRIO();
+    __shared__ u32 sh[4];
+    const u32 key = blockIdx.x * 256 + threadIdx.x, q = (blockIdx.x * 256) >> low;       // q == nparts for the block of key == nkeys
+    u32 v = 0;
+    for (u32 t = threadIdx.x; t < q && t < nparts; t += 256) v += ptot[t];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    if ((threadIdx.x & 63u) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const u32 bs = sh[0] + sh[1] + sh[2] + sh[3];
+    if (key < nkeys) toff[key] += bs;
+    else if (key == nkeys) toff[key] = bs;
+    if (key == 0) { handed[0] = 0; big[0] = 0; big[1] = 0; }
+}
 // ------------------------------------------------------------------------------------ 5 accumulate
 template <class BF>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(112)))
@@ -748,6 +902,106 @@ k_accumulate29(const u32* __restrict__ entries, const u32* __restrict__ off, con
     Xyzz<BF> r;
     r.x = from29<BF>(acc.x); r.y = from29<BF>(acc.y); r.zz = from29<BF>(acc.zz); r.zzz = from29<BF>(acc.zzz);
     r.store(partial + t * 128);
+}
+// ------------------------------------------------------------------------------------ 5w accumulate, wide windows
+// One thread per BUCKET, no task search: thread g of the launch takes the bucket order[g] of k_part2_sort's interleaved length ranking (the longest
+// bucket of every partition, then the second longest of every partition, ...: the 64 lanes of a wave run chains of nearly one length, and the launch
+// as a whole runs longest-first -- with two rounds of resident blocks that order is worth 30 % of the kernel).  The bucket's only task writes the bucket
+// itself, as a lazy B29 record (field29.cuh), into buckets29[key]: the two-plane reduction reads those.  A bucket above K entries (skewed scalars) is split
+// as on the narrow path: thread g runs its first chunk, the others are listed by k_part2_sort as (key, chunk) pairs for k_acc_wide_extra; split
+// buckets write wire-form partials for k_bucket_sum_wide.  Tasks whose lazy arithmetic cannot exclude an exceptional case are listed as (key, chunk)
+// pairs too and redone by k_acc_wide_exact.
+// permuted key of the wide sort -> index of the bucket's B29 record (group * nb + true bucket number)
+__device__ __forceinline__ u32 wide_true_bucket(u32 key, u32 low) {
+    const u32 nbl = 1u << low, grp = key >> (low + 8), kk = key & ((nbl << 8) - 1u);
+    return (grp << (low + 8)) | ((kk & (nbl - 1u)) << 8) | (kk >> low);
+}
+template <class BF>
+__device__ __forceinline__ void wide_task29(u32 key, u32 jt, const u32* __restrict__ entries, const u32* __restrict__ off, const u32* __restrict__ toff,
+                                            const uint8_t* __restrict__ pts, uint8_t* __restrict__ partial, uint8_t* __restrict__ buckets29, u32 low, u32* __restrict__ handed, u32 dbg = 0) {
+    const u32 o0 = off[key], cnt = off[key + 1] - o0;
+    if (cnt == 0) return;
+    const u32 t0 = toff[key], nt = toff[key + 1] - t0;
+    const u32 start = o0 + (u32)(((u64)jt * cnt) / nt), end = o0 + (u32)(((u64)(jt + 1) * cnt) / nt);
+    u32 e = entries[start];
+    Aff<BF> p = Aff<BF>::load(pts + (size_t)(e & 0x7fffffffu) * 64);
+    if (e >> 31) p.y = neg<BF>(p.y);
+    typedef typename C29<BF>::T K29;
+    Acc29<BF> acc;
+    acc.x = to29<BF>(p.x); acc.y = to29<BF>(p.y);
+#pragma unroll
+    for (int i = 0; i < 9; i++) { acc.zz.v[i] = K29::one(i); acc.zzz.v[i] = K29::one(i); }
+    bool ok = true;
+    const u32 e0 = e & 0x7fffffffu;
+    for (u32 k = start + 1; k < end; k++) {
+        if (dbg & 16u) e = entries[start + 1];
+        else if (dbg & 64u) e = (e0 + (k - start) * 104729u) % 13000000u;
+        else e = entries[k];
+        if (dbg & 32u) e = (e0 & 0xffffff00u) + (k - start);
+        p = Aff<BF>::load(pts + (size_t)(e & 0x7fffffffu) * 64);
+        if (e >> 31) p.y = neg<BF>(p.y);
+        ok = madd29<BF>(acc, pack29<BF, 5>(p.x), pack29<BF, 5>(p.y));
+        if (!ok && !(dbg & 0x70u)) break;
+    }
+    if (dbg & 0x70u) ok = true;
+    if (!ok) { const u32 slot = atomicAdd(&handed[0], 1u); handed[2 + 2 * slot] = key; handed[3 + 2 * slot] = jt; return; }
+    if (nt == 1) { store_b29<BF>(buckets29 + (size_t)wide_true_bucket(key, low) * B29_BYTES, acc); return; }
+    Xyzz<BF> r;
+    r.x = from29<BF>(acc.x); r.y = from29<BF>(acc.y); r.zz = from29<BF>(acc.zz); r.zzz = from29<BF>(acc.zzz);
+    r.store(partial + (size_t)(t0 + jt) * 128);
+}
+template <class BF>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(112), amdgpu_waves_per_eu(4, 4)))
+k_acc_wide29(const u32* __restrict__ entries, const u32* __restrict__ off, const u32* __restrict__ toff, const u32* __restrict__ order, u32 nkeys,
+             const uint8_t* __restrict__ pts, uint8_t* __restrict__ partial, uint8_t* __restrict__ buckets29, u32 low, u32* __restrict__ handed, u32 dbg) {
+    const u32 g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= nkeys) return;
+    unsigned long long t_0 = 0;
+    if (dbg & 128u) t_0 = wall_clock64();
+    wide_task29<BF>(order[g], 0u, entries, off, toff, pts, partial, buckets29, low, handed, dbg);
+    if ((dbg & 128u) && (threadIdx.x & 63u) == 0) {         // per WAVE: start, end, hardware id, XCC id
+        u32 hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        unsigned long long* tr = (unsigned long long*)partial + 4 * (size_t)(g >> 6);
+        const u32 key_ = order[g];
+        tr[0] = t_0; tr[1] = wall_clock64(); tr[2] = hw; tr[3] = (xcc & 0xffu) | ((unsigned long long)(off[key_ + 1] - off[key_]) << 32);
+    }
+}
+// xlist: [0] = number of extra chunks, then (key, chunk) pairs from word 2 on; a small persistent grid walks it (empty for unskewed scalars)
+template <class BF>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(112)))
+k_acc_wide_extra(const u32* __restrict__ entries, const u32* __restrict__ off, const u32* __restrict__ toff, const u32* __restrict__ xlist,
+                 const uint8_t* __restrict__ pts, uint8_t* __restrict__ partial, uint8_t* __restrict__ buckets29, u32 low, u32* __restrict__ handed) {
+    KH_HIGH_PRIO();
+    const u32 count = xlist[0];
+    for (u32 it = blockIdx.x * blockDim.x + threadIdx.x; it < count; it += gridDim.x * blockDim.x)
+        wide_task29<BF>(xlist[2 + 2 * it], xlist[3 + 2 * it], entries, off, toff, pts, partial, buckets29, low, handed);
+}
+template <class BF>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(112)))
+k_acc_wide_exact(const u32* __restrict__ entries, const u32* __restrict__ off, const u32* __restrict__ toff, const u32* __restrict__ handed,
+                 const uint8_t* __restrict__ pts, uint8_t* __restrict__ partial, uint8_t* __restrict__ buckets29, u32 low) {
+    KH_HIGH_PRIO();
+    const u32 count = handed[0];
+    for (u32 it = blockIdx.x * blockDim.x + threadIdx.x; it < count; it += gridDim.x * blockDim.x) {
+        const u32 key = handed[2 + 2 * it], jt = handed[3 + 2 * it];
+        const u32 o0 = off[key], cnt = off[key + 1] - o0, t0 = toff[key], nt = toff[key + 1] - t0;
+        const u32 start = o0 + (u32)(((u64)jt * cnt) / nt), end = o0 + (u32)(((u64)(jt + 1) * cnt) / nt);
+        u32 e = entries[start];
+        Aff<BF> p = Aff<BF>::load(pts + (size_t)(e & 0x7fffffffu) * 64);
+        if (e >> 31) p.y = neg<BF>(p.y);
+        Xyzz<BF> acc = Xyzz<BF>::from_affine(p);
+        for (u32 k = start + 1; k < end; k++) {
+            e = entries[k];
+            p = Aff<BF>::load(pts + (size_t)(e & 0x7fffffffu) * 64);
+            acc = madd<BF>(acc, p, (e >> 31) != 0);
+        }
+        if (nt == 1) {
+            uint8_t* const rec = buckets29 + (size_t)wide_true_bucket(key, low) * B29_BYTES;
+            if (acc.is_identity()) store_b29_identity<BF>(rec); else store_b29<BF>(rec, xyzz_to29<BF>(acc));
+        } else acc.store(partial + (size_t)(t0 + jt) * 128);
+    }
 }
 // ------------------------------------------------------------------------------------ 6 bucket sums
 // buckets with more partials than this go to the wave-per-bucket tree (k_bucket_big); the threshold is a
@@ -1127,6 +1381,144 @@ k_marginal_fin_q(const uint8_t* __restrict__ marg, MargGeom g, uint8_t* __restri
     if (threadIdx.x < 4) quad_store<BF>(out + (q * 3 + j) * 128, r);
 }
 
+// ------------------------------------------------------------------------------------ 6w / 7w wide windows: bucket sums + two-plane reduction
+// c = 20 leaves 2^19 buckets of ~26 entries: 13 instead of 16 table additions per scalar, paid for by a reduction over 16 x more buckets.
+// Bucket t = (a, b), a = its top `hi` bits, b = its low `lo` bits, has weight t + 1:
+//     sum_t (t + 1) B_t  =  2^lo  sum_a a H_a  +  sum_b (b + 1) L_b,      H_a = sum_b B_(a,b),   L_b = sum_a B_(a,b)
+// -- every bucket goes into ONE hi-digit and ONE lo-digit marginal: 2 x 2^19 full additions, all of them in the lazy 29-bit arithmetic
+// (add29: ~1.4 mixed additions each), then 2^hi + 2^lo = 1536 marginals take the 5-bit digit-marginal tail of the narrow path.
+//   k_bucket_sum_wide  buckets that are not a single task's output (empty: identity record; split: exact sum of the wire partials; hot: the
+//                      two-phase big-bucket kernels, then k_big_to29)
+//   k_wide_a1          thread (plane, marginal, chunk): the sum of r = 8 buckets, sequentially, B29 in -> B29 out (2^17 threads; plane 0 reads
+//                      r consecutive records, plane 1 a column: neighbouring lanes read neighbouring records).  A thread whose add29 cannot
+//                      exclude an exceptional case lists itself; k_wide_a1_exact redoes the listed chunks with the exact formulas.
+//   k_wide_a2          wave per marginal: its 2^lo / r (or 2^hi / r) chunk sums, converted to the wire form, one or two per lane, then the
+//                      lane-cooperative tree of k_marginals_h.  Output: 2 x 2^lo wire records per MSM laid out as TWO bucket groups of 2^lo
+//                      buckets for k_marginals_q / k_marginal_fin_q -- group 0 holds H_a at slot a - 1 (weight a; H_0 has weight 0 and is
+//                      dropped, slots >= 2^hi - 1 are the identity), group 1 holds L_b at slot b.
+struct WideGeom { u32 nb, lo, hi, rlog; };
+template <class BF>
+__global__ void __launch_bounds__(256)
+k_bucket_sum_wide(const u32* __restrict__ toff, size_t nkeys, const uint8_t* __restrict__ partial, uint8_t* __restrict__ buckets29,
+                  u32 low, u32* __restrict__ big, size_t cap, u32 SMALL_NT, u32* __restrict__ handed) {
+    KH_HIGH_PRIO();
+    size_t key = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (key == 0) handed[0] = 0;                           // the accumulation's hand-over list is consumed: k_wide_a1 starts its own
+    if (key >= nkeys) return;
+    u32 t0 = toff[key], nt = toff[key + 1] - t0;
+    if (nt == 1) return;                                   // written by the accumulation itself
+    uint8_t* const rec = buckets29 + (size_t)wide_true_bucket((u32)key, low) * B29_BYTES;
+    if (nt == 0) { store_b29_identity<BF>(rec); return; }
+    if (nt > SMALL_NT) {
+        u32 nch = (nt + CHUNK - 1) / CHUNK;
+        u32 slot = atomicAdd(&big[0], 1u);
+        u32 cbase = atomicAdd(&big[1], nch);
+        big[2 + slot] = (u32)key; big[2 + cap + slot] = cbase;
+        for (u32 j = 0; j < nch; j++) { big[2 + 2 * cap + cbase + j] = (u32)key; big[2 + 3 * cap + cbase + j] = j; }
+        return;
+    }
+    Xyzz<BF> acc = Xyzz<BF>::load(partial + (size_t)t0 * 128);
+    for (u32 k = 1; k < nt; k++) acc = add<BF>(acc, Xyzz<BF>::load(partial + (size_t)(t0 + k) * 128));
+    store_b29<BF>(rec, xyzz_to29<BF>(acc));
+}
+template <class BF>
+__global__ void __launch_bounds__(64)
+k_big_to29(const uint8_t* __restrict__ buckets, const u32* __restrict__ big, uint8_t* __restrict__ buckets29, u32 low) {
+    KH_HIGH_PRIO();
+    const u32 nbig = big[0];
+    for (u32 bi = blockIdx.x * blockDim.x + threadIdx.x; bi < nbig; bi += gridDim.x * blockDim.x) {
+        const u32 key = big[2 + bi];
+        store_b29<BF>(buckets29 + (size_t)wide_true_bucket(key, low) * B29_BYTES, xyzz_to29<BF>(Xyzz<BF>::load(buckets + (size_t)key * 128)));
+    }
+}
+// work item u of a group: first bucket, bucket stride, output record
+__device__ __forceinline__ void wide_a1_item(const WideGeom& g, u32 u, u32& t0, u32& tstride, u32& out) {
+    const u32 per = g.nb >> g.rlog;                        // items per plane
+    if (u < per) { t0 = u << g.rlog; tstride = 1u; out = u; return; }
+    const u32 v = u - per, b = v & ((1u << g.lo) - 1u), s = v >> g.lo;
+    t0 = ((s << g.rlog) << g.lo) + b; tstride = 1u << g.lo; out = per + b * ((1u << g.hi) >> g.rlog) + s;
+}
+template <class BF>
+__global__ void __launch_bounds__(256)
+k_wide_a1(const uint8_t* __restrict__ buckets29, WideGeom g, u32 ngroups, uint8_t* __restrict__ out29, u32* __restrict__ handed) {
+    KH_HIGH_PRIO();
+    const u32 items = 2u * (g.nb >> g.rlog);
+    const u32 gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= items * ngroups) return;
+    const u32 q = gid / items, u = gid - q * items;
+    u32 t0, ts, out;
+    wide_a1_item(g, u, t0, ts, out);
+    const uint8_t* B = buckets29 + ((size_t)q * g.nb + t0) * B29_BYTES;
+    Acc29<BF> acc;
+    bool have = false, ok = true;
+    const u32 r = 1u << g.rlog;
+#pragma unroll 1
+    for (u32 i = 0; i < r; i++) {
+        const Acc29<BF> b = load_b29<BF>(B + (size_t)i * ts * B29_BYTES);
+        if (is_identity29<BF>(b)) continue;
+        if (!have) { acc = b; have = true; continue; }
+        ok = add29<BF>(acc, b);
+        if (!ok) break;
+    }
+    if (!ok) { handed[1 + atomicAdd(&handed[0], 1u)] = gid; return; }
+    uint8_t* o = out29 + ((size_t)q * items + out) * B29_BYTES;
+    if (have) store_b29<BF>(o, acc); else store_b29_identity<BF>(o);
+}
+template <class BF>
+__global__ void __launch_bounds__(64)
+k_wide_a1_exact(const uint8_t* __restrict__ buckets29, WideGeom g, uint8_t* __restrict__ out29, const u32* __restrict__ handed) {
+    KH_HIGH_PRIO();
+    const u32 items = 2u * (g.nb >> g.rlog), count = handed[0], r = 1u << g.rlog;
+    for (u32 it = blockIdx.x * blockDim.x + threadIdx.x; it < count; it += gridDim.x * blockDim.x) {
+        const u32 gid = handed[1 + it], q = gid / items, u = gid - q * items;
+        u32 t0, ts, out;
+        wide_a1_item(g, u, t0, ts, out);
+        const uint8_t* B = buckets29 + ((size_t)q * g.nb + t0) * B29_BYTES;
+        Xyzz<BF> acc = Xyzz<BF>::identity();
+        for (u32 i = 0; i < r; i++) {
+            const Acc29<BF> b = load_b29<BF>(B + (size_t)i * ts * B29_BYTES);
+            if (!is_identity29<BF>(b)) acc = add<BF>(acc, xyzz_from29<BF>(b));
+        }
+        uint8_t* o = out29 + ((size_t)q * items + out) * B29_BYTES;
+        if (acc.is_identity()) store_b29_identity<BF>(o); else store_b29<BF>(o, xyzz_to29<BF>(acc));
+    }
+}
+template <class BF>
+__global__ void __launch_bounds__(64)
+k_wide_a2(const uint8_t* __restrict__ in29, WideGeom g, uint8_t* __restrict__ outw) {
+    KH_HIGH_PRIO();
+    __shared__ u32 stage[32][64];                        // [word of the XYZZ record][lane]
+    const u32 slot = blockIdx.x, q = blockIdx.y, plane = slot >> g.lo, sidx = slot & ((1u << g.lo) - 1u);
+    const u32 per = g.nb >> g.rlog, items = 2u * per;
+    const u32 lane = threadIdx.x, role = lane & 3u, quad = lane >> 2;
+    uint8_t* o = outw + (((size_t)q * 2 + plane) * (1u << g.lo) + sidx) * 128;
+    u32 cnt, first;
+    if (plane == 0) {
+        const u32 a = sidx + 1u;
+        if (a >= (1u << g.hi)) { if (lane < 4) quad_store<BF>(o, Fe<BF>::zero()); return; }
+        cnt = (1u << g.lo) >> g.rlog; first = a * cnt;
+    } else { cnt = (1u << g.hi) >> g.rlog; first = per + sidx * cnt; }
+    const uint8_t* src = in29 + ((size_t)q * items + first) * B29_BYTES;
+    Xyzz<BF> a = Xyzz<BF>::identity();
+    for (u32 k = lane; k < cnt; k += 64) {
+        const Acc29<BF> b = load_b29<BF>(src + (size_t)k * B29_BYTES);
+        if (!is_identity29<BF>(b)) a = add<BF>(a, xyzz_from29<BF>(b));
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) { stage[k][lane] = a.x.v[k]; stage[8 + k][lane] = a.y.v[k]; stage[16 + k][lane] = a.zz.v[k]; stage[24 + k][lane] = a.zzz.v[k]; }
+    __syncthreads();
+    auto parked = [&](u32 point) {
+        Fe<BF> r;
+#pragma unroll
+        for (int k = 0; k < 8; k++) r.v[k] = stage[role * 8 + k][point];
+        return r;
+    };
+    Fe<BF> acc = parked(quad);
+    for (u32 k = 1; k < 4; k++) acc = quad_add<BF>(acc, parked(quad + 16 * k));
+    for (int d = 8; d >= 1; d >>= 1) acc = quad_add<BF>(acc, quad_shfl_down<BF>(acc, d));
+    if (lane < 4) quad_store<BF>(o, acc);
+}
+
 // ------------------------------------------------------------------------------------ precomputed window tables
 // tables[w][i] = 2^(c*w) * P_i in affine form (w = 0 is the basis itself).  Thread per point:
 // (W-1) x c doublings in XYZZ, then ONE inversion per point (Montgomery's trick over its W-1
@@ -1166,6 +1558,12 @@ k_precompute(uint8_t* __restrict__ tables, const uint8_t* __restrict__ inf, size
 struct VestaCfg { typedef FqParams Base; typedef FpParams Scalar; };
 struct PallasCfg { typedef FpParams Base; typedef FqParams Scalar; };
 
+static std::atomic<size_t>& wide_min_n_cell() {
+    static std::atomic<size_t> v{getenv("KH_WIDE_MIN_N") ? (size_t)strtoull(getenv("KH_WIDE_MIN_N"), nullptr, 0) : ((size_t)1 << 20)};
+    return v;
+}
+size_t msm_wide_min_n() { const size_t v = wide_min_n_cell().load(); return v ? v : ~(size_t)0; }
+void msm_set_wide_min_n(size_t n) { wide_min_n_cell().store(n); }
 int msm_pick_window(size_t n) {
     int lg = 0; while (((size_t)1 << (lg + 1)) <= n) lg++;
     int c = lg - 3;
@@ -1212,10 +1610,15 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
                          int mont, int curve, int use_graph) {
     typedef typename CFG::Base BF; typedef typename CFG::Scalar SF;
     hipStream_t s = C.stream;
-    const int c = basis.precomp_c ? basis.precomp_c : msm_pick_window(n);
+    // wide windows (a second table set, c = 20: msm.hpp) for big single MSMs: 13 instead of 16 additions per scalar.  Needs the wide sort's
+    // record (<= 65,536 digits per pass-A block, <= 1024 blocks).
+    const bool wide = basis.wide_pts && basis.wide_c > 16 && basis.wide_c - 9 <= (int)PART2_MAXLOW && n >= msm_wide_min_n() && k <= 4 &&
+                      (size_t)((256 + basis.wide_c - 1) / basis.wide_c) * n <= ((size_t)1 << 26);
+    const void* const tab_pts = wide ? basis.wide_pts : basis.pts;
+    const int c = wide ? basis.wide_c : (basis.precomp_c ? basis.precomp_c : msm_pick_window(n));
     const int W = (256 + c - 1) / c;
     const u32 nb = 1u << (c - 1);
-    const int precomp = basis.precomp_c ? 1 : 0;
+    const int precomp = (wide || basis.precomp_c) ? 1 : 0;
     // slices per (window, msm): enough blocks to fill the chip (~512), no more -- the per-slice histograms
     // cost nkeys x W x S words of traffic in k_key_totals, which dominates the sort of a batch
     static const size_t slice_div = getenv("KH_SLICE_DIV") ? (size_t)atol(getenv("KH_SLICE_DIV")) : 32768;
@@ -1257,6 +1660,16 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
     if ((rc = C.ws_biglist.reserve((2 + 4 * bigcap) * sizeof(u32)))) return rc;
     if ((rc = C.ws_chunks.reserve(bigcap * 128))) return rc;
     if ((rc = C.ws_order.reserve((2 * (MAX_K + 1) + 3 * (nkeys + 2)) * sizeof(u32)))) return rc;
+    WideGeom wg{};
+    const u32 wide_dbg = (getenv("KH_WIDE_DBG") ? (u32)atoi(getenv("KH_WIDE_DBG")) : 0u) | ((getenv("KH_WIDE_OG") ? (u32)atoi(getenv("KH_WIDE_OG")) : 1u) << 8);     // experiments on k_part2_sort (results are wrong with it)
+    if (wide) {                                            // bucket = (hi digit, lo digit); chunks of 8 buckets in the first reduction level
+        if ((rc = C.ws_xlist.reserve((2 * max_tasks + 4) * sizeof(u32)))) return rc;
+        if ((rc = C.ws_handed.reserve((2 * max_tasks + 4) * sizeof(u32)))) return rc;
+        wg.nb = nb; wg.lo = (u32)c / 2; wg.hi = (u32)(c - 1) - wg.lo; wg.rlog = 3;
+        if ((rc = C.ws_b29.reserve(nkeys * B29_BYTES))) return rc;
+        if ((rc = C.ws_a1.reserve(ngroups * 2 * (size_t)(nb >> wg.rlog) * B29_BYTES))) return rc;
+        if ((rc = C.ws_a2.reserve(ngroups * 2 * ((size_t)1 << wg.lo) * 128))) return rc;
+    }
     // segment length of the weighted reduction: one bucket per thread (a 15-bit double-and-add each)
     // is the shortest chain, but its work grows with the bucket count -- for batches use running
     // sums over m buckets (2 additions per bucket + one double-and-add per segment), keeping about
@@ -1269,13 +1682,14 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
     const u32 nblk1 = (nseg + SUM_BLK - 1) / SUM_BLK;
     // one to four MSMs over the tables: digit marginals instead (k_marginals), three fields of <= 5 bits
     static const size_t marg_max = getenv("KH_MARG_MAX") ? (size_t)atol(getenv("KH_MARG_MAX")) : 4096;
-    const u32 planes = (precomp && ngroups <= marg_max && c >= 7 && c <= 16 && !getenv("KH_NO_PLANES")) ? 3u : 0u;
+    const u32 planes = wide ? 3u : ((precomp && ngroups <= marg_max && c >= 7 && c <= 16 && !getenv("KH_NO_PLANES")) ? 3u : 0u);
     MargGeom mg{};
-    if (planes) {
-        const u32 bits = (u32)c - 1, f0 = (bits + 2) / 3, f1 = (bits - f0 + 1) / 2, f2 = bits - f0 - f1;
-        mg.nb = nb; mg.sh[0] = 0; mg.wd[0] = f0; mg.sh[1] = f0; mg.wd[1] = f1; mg.sh[2] = f0 + f1; mg.wd[2] = f2;
+    if (planes) {                                          // (wide: the tail runs over the two marginal groups of 2^lo slots each, k_wide_a2)
+        const u32 bits = wide ? wg.lo : (u32)c - 1, f0 = (bits + 2) / 3, f1 = (bits - f0 + 1) / 2, f2 = bits - f0 - f1;
+        mg.nb = wide ? 1u << wg.lo : nb; mg.sh[0] = 0; mg.wd[0] = f0; mg.sh[1] = f0; mg.wd[1] = f1; mg.sh[2] = f0 + f1; mg.wd[2] = f2;
     }
-    const size_t nout = planes ? ngroups * planes : ngroups;
+    const size_t tail_groups = wide ? 2 * ngroups : ngroups;
+    const size_t nout = planes ? tail_groups * planes : ngroups;
     if ((rc = C.ws_seg.reserve(std::max(ngroups * (size_t)(nseg + nblk1), nout * (size_t)32) * 128))) return rc;
     if ((rc = C.ws_out.reserve(nout * 128))) return rc;
     if (C.pinned_cap < nout * 128) {                     // host staging of the group sums; the host part runs in msm_finish
@@ -1296,7 +1710,7 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
     static const unsigned long long fused_spin_ticks = 100ull * (getenv("KH_FUSED_SPIN_US") ? (unsigned long long)atoll(getenv("KH_FUSED_SPIN_US")) : 20000ull);
     FusedGeom fg{};
     // (co-residency of the spinning blocks is what makes the grid barriers safe: 64 blocks x 4 jobs in flight need 128 CUs -- not in a partitioned mode)
-    bool fused = precomp && !fused_off && !Ctx.fused_disabled && k <= 4 && M < fused_max && nb >= 2048 && Ctx.num_cus >= 128;
+    bool fused = precomp && !wide && !fused_off && !Ctx.fused_disabled && k <= 4 && M < fused_max && nb >= 2048 && Ctx.num_cus >= 128;
     if (fused) {
         fg.n = (u32)n; fg.nb = nb; fg.W = (u32)W; fg.k = (u32)k; fg.bpg = (u32)std::min<size_t>(FUSED_G, FUSED_B / (2 * k)); fg.nkeys = (u32)nkeys;
         fg.split = 2; fg.sub = nb / fg.split;              // 64 blocks of 64 KB LDS: two per CU, so four (even eight) jobs in flight stay co-resident
@@ -1308,8 +1722,10 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
     }
     // large jobs over the tables: the two-pass partitioned sort (k_part_*)
     static const bool part_off = getenv("KH_NO_PART_SORT") != nullptr;
-    const bool part = precomp && !fused && !part_off && nb == ((u32)PART_P << PART_LOW) && n <= ((size_t)1 << 20) && W <= 16 && M >= ((size_t)1 << 21);
-    const u32 part_nblk = part ? (u32)std::max<size_t>(1, std::min<size_t>(256, 512 / k)) : 0;
+    const bool part = wide || (precomp && !fused && !part_off && nb == ((u32)PART_P << PART_LOW) && n <= ((size_t)1 << 20) && W <= 16 && M >= ((size_t)1 << 21));
+    const u32 part_low = wide ? (u32)c - 9 : (u32)PART_LOW;
+    const u32 part_nblk = wide ? (u32)std::max<size_t>(std::max<size_t>(1, std::min<size_t>(256, 512 / k)), ((size_t)W * n + 65535) / 65536)
+                               : (part ? (u32)std::max<size_t>(1, std::min<size_t>(256, 512 / k)) : 0);
     const size_t part_size = (size_t)k * PART_P * part_nblk;
     if (part) {
         if ((rc = C.ws_hist.reserve((part_size + 1) * sizeof(u32)))) return rc;
@@ -1342,6 +1758,7 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
                                   (uint64_t)(uintptr_t)C.ws_buckets.p, (uint64_t)(uintptr_t)C.ws_seg.p, (uint64_t)(uintptr_t)C.ws_out.p, (uint64_t)(uintptr_t)C.ws_scan_tmp.p,
                                   (uint64_t)(uintptr_t)C.ws_biglist.p, (uint64_t)(uintptr_t)C.ws_order.p, (uint64_t)(uintptr_t)C.ws_chunks.p,
                                   (uint64_t)(uintptr_t)C.ws_handed.p, (uint64_t)(uintptr_t)C.ws_sync.p, (uint64_t)fused, (uint64_t)(uintptr_t)C.ws_mid.p, (uint64_t)part,
+                                  (uint64_t)(uintptr_t)tab_pts, (uint64_t)wide, (uint64_t)(uintptr_t)C.ws_xlist.p, (uint64_t)(uintptr_t)C.ws_b29.p, (uint64_t)(uintptr_t)C.ws_a1.p, (uint64_t)(uintptr_t)C.ws_a2.p,
                                   DevBuf::generation().load()};
         for (uint64_t v : parts) key = fnv(key, v);
         if (C.gexec && C.gkey == key) {                    // replay
@@ -1351,7 +1768,7 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
             KH_HIP(hipEventRecord(C.done, s));
             C.busy = true; C.owner = std::this_thread::get_id(); C.ticket = Ctx.next_ticket++;
             C.curve = curve; C.W = C.g_W; C.c = C.g_c; C.precomp = C.g_precomp; C.k = k; C.ngroups = C.g_ngroups; C.planes = C.g_planes;
-            C.plane_shift[0] = C.g_shift[0]; C.plane_shift[1] = C.g_shift[1];
+            C.plane_shift[0] = C.g_shift[0]; C.plane_shift[1] = C.g_shift[1]; C.wide_lo = C.g_wide_lo;
             C.timer.n = 0;                                 // no per-phase events inside a graph
             return KH_OK;
         }
@@ -1385,13 +1802,25 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
     } else if (part) {
         const u32 tot_e = (u32)((size_t)W * n);
         const dim3 pgrid(part_nblk, (unsigned)k);
-        hipLaunchKernelGGL(k_part_hist, pgrid, dim3(PART_T), 0, s, C.ws_digits.as<int32_t>(), tot_e, part_nblk, C.ws_hist.as<u32>());
+        hipLaunchKernelGGL(k_part_hist, pgrid, dim3(PART_T), 0, s, C.ws_digits.as<int32_t>(), tot_e, part_nblk, wide ? 0u : part_low, C.ws_hist.as<u32>());
         C.timer.mark("histogram", s);
         if ((rc = exclusive_scan_u32(C.ws_hist.as<u32>(), C.ws_cnt.as<u32>(), part_size + 1, C.ws_scan_tmp, s))) return rc;
         C.timer.mark("scan", s);
+        if (wide) {
+            hipLaunchKernelGGL(k_part2_scatter, pgrid, dim3(PART_T), 0, s, C.ws_digits.as<int32_t>(), tot_e, part_nblk, part_low, C.ws_cnt.as<u32>(), C.ws_mid.as<u32>(), C.ws_xlist.as<u32>());
+            // ... and the task plan (toff, the length-ranked order, roff): partition-local in pass B, made global by k_wide_fixup
+            const WideTasks wt{room, kmin, (u32)nkeys, ktab};
+            u32* const ptot = C.ws_ntask.as<u32>();        // k * 256 partition task totals (the narrow path's per-key task counts: unused here)
+            hipLaunchKernelGGL(k_part2_sort, dim3(PART_P, (unsigned)k), dim3(PART_T), 0, s, C.ws_mid.as<u32>(), C.ws_cnt.as<u32>(), part_nblk, part_low, nb, tot_e, (u32)n,
+                               tab_stride, offset, basis.batch_stride, (u32)(k - 1), part_size, wt, C.ws_off.as<u32>(), C.ws_entries.as<u32>(),
+                               C.ws_toff.as<u32>(), order, ptot, C.ws_xlist.as<u32>(), wide_dbg);
+            hipLaunchKernelGGL(k_wide_fixup, dim3((unsigned)(nkeys / 256 + 1)), dim3(256), 0, s, C.ws_toff.as<u32>(), ptot, (u32)(k * PART_P), part_low, (u32)nkeys,
+                               C.ws_handed.as<u32>(), C.ws_biglist.as<u32>());
+        } else {
         hipLaunchKernelGGL(k_part_scatter, pgrid, dim3(PART_T), 0, s, C.ws_digits.as<int32_t>(), tot_e, (u32)n, part_nblk, C.ws_cnt.as<u32>(), C.ws_mid.as<u32>());
         hipLaunchKernelGGL(k_part_sort, dim3(PART_P, (unsigned)k), dim3(PART_T), 0, s, C.ws_mid.as<u32>(), C.ws_cnt.as<u32>(), part_nblk, nb,
                            tab_stride, offset, basis.batch_stride, (u32)(k - 1), C.ws_off.as<u32>(), C.ws_entries.as<u32>());
+        }
         C.timer.mark("scatter", s);
     } else {
         // 2 histogram
@@ -1409,7 +1838,7 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
                            C.ws_off.as<u32>(), C.ws_entries.as<u32>());
         C.timer.mark("scatter", s);
     }
-    if (!fused) {
+    if (!fused && !wide) {
         // tasks
         KH_HIP(hipMemsetAsync(len_hist, 0, (MAX_K + 1) * sizeof(u32), s));
         hipLaunchKernelGGL(k_ntask, dim3((unsigned)((nkeys + 1 + 255) / 256)), dim3(256), 0, s, C.ws_off.as<u32>(), nkeys, room, kmin, ktab, C.ws_ntask.as<u32>(), len_hist, C.ws_handed.as<u32>());
@@ -1430,34 +1859,53 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
     const u32* abort_dev = fused ? C.ws_sync.as<u32>() + 2 + 2 * FUSED_B + 32 : nullptr;     // the fused sort's give-up word (sort_gave_up)
     const u32* handed = acc29 ? C.ws_handed.as<u32>() : nullptr;
     const dim3 agrid((unsigned)((max_tasks + 255) / 256));
+    uint8_t* const b29 = wide ? C.ws_b29.as<uint8_t>() : nullptr;
+    if (wide) {                                            // thread per bucket in pass B's interleaved length order, then the listed extra chunks / exact redos
+        const dim3 wgrid((unsigned)(nkeys / 256));
+        auto kern = k_acc_wide29<BF>;
+        if (C.timer.enabled && C.timer.created && !gcap.active) {
+            hipExtLaunchKernelGGL(kern, wgrid, dim3(256), 0, s, C.timer.k0, C.timer.k1, 0, C.ws_entries.as<u32>(), C.ws_off.as<u32>(), C.ws_toff.as<u32>(), order, (u32)nkeys,
+                                  (const uint8_t*)tab_pts, C.ws_partial.as<uint8_t>(), b29, part_low, C.ws_handed.as<u32>(), wide_dbg);
+            C.timer.kname = "k_acc_wide29";
+        } else
+        hipLaunchKernelGGL(kern, wgrid, dim3(256), 0, s, C.ws_entries.as<u32>(), C.ws_off.as<u32>(), C.ws_toff.as<u32>(), order, (u32)nkeys,
+                           (const uint8_t*)tab_pts, C.ws_partial.as<uint8_t>(), b29, part_low, C.ws_handed.as<u32>(), wide_dbg);
+        hipLaunchKernelGGL((k_acc_wide_extra<BF>), dim3(256), dim3(256), 0, s, C.ws_entries.as<u32>(), C.ws_off.as<u32>(), C.ws_toff.as<u32>(), C.ws_xlist.as<u32>(),
+                           (const uint8_t*)tab_pts, C.ws_partial.as<uint8_t>(), b29, part_low, C.ws_handed.as<u32>());
+        hipLaunchKernelGGL((k_acc_wide_exact<BF>), dim3(128), dim3(256), 0, s, C.ws_entries.as<u32>(), C.ws_off.as<u32>(), C.ws_toff.as<u32>(), C.ws_handed.as<u32>(),
+                           (const uint8_t*)tab_pts, C.ws_partial.as<uint8_t>(), b29, part_low);
+    } else
     if (acc29) {
         auto kern = k_accumulate29<BF>;
         if (C.timer.enabled && C.timer.created && !gcap.active) {     // the dominant kernel's own start / stop timestamps (bench.py roofline)
             hipExtLaunchKernelGGL(kern, agrid, dim3(256), 0, s, C.timer.k0, C.timer.k1, 0,
                                   C.ws_entries.as<u32>(), C.ws_off.as<u32>(), C.ws_toff.as<u32>(), roff, order, nkeys,
-                                  (const uint8_t*)basis.pts, C.ws_partial.as<uint8_t>(), C.ws_handed.as<u32>(), abort_dev);
+                                  (const uint8_t*)tab_pts, C.ws_partial.as<uint8_t>(), C.ws_handed.as<u32>(), abort_dev);
             C.timer.kname = "k_accumulate29";
         } else
         hipLaunchKernelGGL(kern, agrid, dim3(256), 0, s,
                            C.ws_entries.as<u32>(), C.ws_off.as<u32>(), C.ws_toff.as<u32>(), roff, order, nkeys,
-                           (const uint8_t*)basis.pts, C.ws_partial.as<uint8_t>(), C.ws_handed.as<u32>(), abort_dev);
+                           (const uint8_t*)tab_pts, C.ws_partial.as<uint8_t>(), C.ws_handed.as<u32>(), abort_dev);
         hipLaunchKernelGGL((k_accumulate<BF>), dim3(128), dim3(256), 0, s,
                            C.ws_entries.as<u32>(), C.ws_off.as<u32>(), C.ws_toff.as<u32>(), roff, order, nkeys,
-                           (const uint8_t*)basis.pts, C.ws_partial.as<uint8_t>(), handed, abort_dev);
+                           (const uint8_t*)tab_pts, C.ws_partial.as<uint8_t>(), handed, abort_dev);
     } else if (C.timer.enabled && C.timer.created && !gcap.active) {
         hipExtLaunchKernelGGL((k_accumulate<BF>), agrid, dim3(256), 0, s, C.timer.k0, C.timer.k1, 0,
                               C.ws_entries.as<u32>(), C.ws_off.as<u32>(), C.ws_toff.as<u32>(), roff, order, nkeys,
-                              (const uint8_t*)basis.pts, C.ws_partial.as<uint8_t>(), handed, abort_dev);
+                              (const uint8_t*)tab_pts, C.ws_partial.as<uint8_t>(), handed, abort_dev);
         C.timer.kname = "k_accumulate";
     } else
     hipLaunchKernelGGL((k_accumulate<BF>), agrid, dim3(256), 0, s,
                        C.ws_entries.as<u32>(), C.ws_off.as<u32>(), C.ws_toff.as<u32>(), roff, order, nkeys,
-                       (const uint8_t*)basis.pts, C.ws_partial.as<uint8_t>(), handed, abort_dev);
+                       (const uint8_t*)tab_pts, C.ws_partial.as<uint8_t>(), handed, abort_dev);
     C.timer.mark("accumulate", s);
     // 6 bucket sums
     static const bool bsum_quad = !getenv("KH_NO_BSUM_QUAD");
     static const size_t bsum_maxg = getenv("KH_QUAD_MAXG") ? (size_t)atol(getenv("KH_QUAD_MAXG")) : 8;     // 5 / 7 / 8 MSMs of 2^16: 0.94 / 1.09 / 1.14 -> 0.85 / 1.05 / 1.09 ms against 4
-    if (precomp && ngroups <= bsum_maxg && bsum_quad)
+    if (wide)
+        hipLaunchKernelGGL((k_bucket_sum_wide<BF>), dim3((unsigned)((nkeys + 255) / 256)), dim3(256), 0, s,
+                           C.ws_toff.as<u32>(), nkeys, C.ws_partial.as<uint8_t>(), b29, part_low, C.ws_biglist.as<u32>(), bigcap, 16u, C.ws_handed.as<u32>());
+    else if (precomp && ngroups <= bsum_maxg && bsum_quad)
         hipLaunchKernelGGL((k_bucket_sum_q<BF>), dim3((unsigned)((4 * nkeys + 255) / 256)), dim3(256), 0, s,
                            C.ws_toff.as<u32>(), nkeys, C.ws_partial.as<uint8_t>(), C.ws_buckets.as<uint8_t>(), C.ws_biglist.as<u32>(),
                            bigcap, 16u, abort_dev);
@@ -1469,10 +1917,20 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
                        C.ws_toff.as<u32>(), C.ws_partial.as<uint8_t>(), C.ws_biglist.as<u32>(), bigcap, C.ws_chunks.as<uint8_t>(), abort_dev);
     hipLaunchKernelGGL((k_bucket_big<BF>), dim3(1024), dim3(256), 0, s,
                        C.ws_toff.as<u32>(), C.ws_chunks.as<uint8_t>(), C.ws_buckets.as<uint8_t>(), C.ws_biglist.as<u32>(), bigcap, abort_dev);
+    if (wide) hipLaunchKernelGGL((k_big_to29<BF>), dim3(16), dim3(64), 0, s, C.ws_buckets.as<uint8_t>(), C.ws_biglist.as<u32>(), b29, part_low);
     C.timer.mark("bucket_sum", s);
     // 7 reduce
     bool direct_out = false;                              // latency path: the last kernel writes the (768-byte) result to host memory itself -- no copy node
-    if (planes) {
+    if (wide) {
+        const u32 items = 2u * (nb >> wg.rlog) * (u32)ngroups;
+        hipLaunchKernelGGL((k_wide_a1<BF>), dim3((items + 255) / 256), dim3(256), 0, s, b29, wg, (u32)ngroups, C.ws_a1.as<uint8_t>(), C.ws_handed.as<u32>());
+        hipLaunchKernelGGL((k_wide_a1_exact<BF>), dim3(64), dim3(64), 0, s, b29, wg, C.ws_a1.as<uint8_t>(), C.ws_handed.as<u32>());
+        C.timer.mark("reduce_a1", s);
+        hipLaunchKernelGGL((k_wide_a2<BF>), dim3(2u << wg.lo, (unsigned)ngroups), dim3(64), 0, s, C.ws_a1.as<uint8_t>(), wg, C.ws_a2.as<uint8_t>());
+        hipLaunchKernelGGL((k_marginals_q<BF>), dim3(32, 3, (unsigned)tail_groups), dim3(256), 0, s, C.ws_a2.as<uint8_t>(), mg, C.ws_seg.as<uint8_t>());
+        hipLaunchKernelGGL((k_marginal_fin_q<BF>), dim3(3, (unsigned)tail_groups), dim3(128), 0, s, C.ws_seg.as<uint8_t>(), mg, (uint8_t*)C.pinned);
+        direct_out = true;
+    } else if (planes) {
         // few groups: 256 threads per marginal (4 sequential additions + the tree: shortest chain); batches: one wave
         // per marginal (16 + 6 additions deep, but 2.2x less issue work -- batches are throughput-bound)
         static const int quad_threads = getenv("KH_QUAD") ? atoi(getenv("KH_QUAD")) : 256;   // 0: scalar additions
@@ -1520,12 +1978,12 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
         if (g) (void)hipGraphDestroy(g);
         if (e != hipSuccess) { C.gexec = nullptr; set_error("hipGraph capture of the MSM launch sequence failed: %s", hipGetErrorString(e)); return KH_E_DEVICE; }
         C.gkey = key; C.gnout = nout; C.gscalars = scalars_dev; C.g_fused = fused;
-        C.g_W = W; C.g_c = c; C.g_precomp = precomp; C.g_planes = (int)planes; C.g_shift[0] = (int)mg.wd[0]; C.g_shift[1] = (int)mg.wd[1]; C.g_ngroups = ngroups;
+        C.g_W = W; C.g_c = c; C.g_precomp = precomp; C.g_planes = (int)planes; C.g_shift[0] = (int)mg.wd[0]; C.g_shift[1] = (int)mg.wd[1]; C.g_ngroups = ngroups; C.g_wide_lo = wide ? (int)wg.lo : 0;
         KH_HIP(hipGraphLaunch(C.gexec, s));
     }
     KH_HIP(hipEventRecord(C.done, s));
     C.busy = true; C.owner = std::this_thread::get_id(); C.ticket = Ctx.next_ticket++;
-    C.curve = curve; C.W = W; C.c = c; C.precomp = precomp; C.k = k; C.ngroups = ngroups; C.planes = (int)planes; C.plane_shift[0] = (int)mg.wd[0]; C.plane_shift[1] = (int)mg.wd[1];
+    C.curve = curve; C.W = W; C.c = c; C.precomp = precomp; C.k = k; C.ngroups = ngroups; C.planes = (int)planes; C.plane_shift[0] = (int)mg.wd[0]; C.plane_shift[1] = (int)mg.wd[1]; C.wide_lo = wide ? (int)wg.lo : 0;
     C.fused_used = fused;
     C.retry = {basis.pts, basis.inf, basis.n, basis.stride, basis.batch_stride, basis.precomp_c, offset, scalars_dev, n, k, mont, curve};
     return KH_OK;
@@ -1560,6 +2018,12 @@ int msm_finish(Context& C, MsmSlot& S, uint64_t* out_xy, uint8_t* out_inf) {
         KH_HIP(hipEventSynchronize(S.done));
     }
     S.busy = false;
+    if (getenv("KH_WIDE_TRACE") && S.wide_lo) {           // experiment: per-wave (start, end, hw id, xcc) records of k_acc_wide29 (KH_WIDE_DBG & 128)
+        const size_t nw = ((size_t)S.k << 19) / 64;
+        std::vector<unsigned long long> tr(4 * nw);
+        (void)hipMemcpy(tr.data(), S.ws_partial.p, tr.size() * 8, hipMemcpyDeviceToHost);
+        if (FILE* f = fopen(getenv("KH_WIDE_TRACE"), "wb")) { fwrite(tr.data(), 8, tr.size(), f); fclose(f); }
+    }
     static const bool fused_dbg = getenv("KH_FUSED_DEBUG") != nullptr;
     if (fused_dbg && S.ws_sync.p) {                       // phase timestamps of the last k_sort_fused on this slot (block 0)
         unsigned long long ts[12]; (void)hipMemcpy(ts, S.ws_sync.as<u32>() + 2 + 2 * FUSED_B, sizeof(ts), hipMemcpyDeviceToHost);
@@ -1579,7 +2043,18 @@ int msm_finish(Context& C, MsmSlot& S, uint64_t* out_xy, uint8_t* out_inf) {
     auto finish_one = [res, Sp, tot](size_t j) {
         khost::Crv crv(Sp->curve);
         khost::xyzz& total = tot[j];
-        if (Sp->precomp && Sp->planes) {              // (M2 2^f1 + M1) 2^f0 + M0 over the three digit marginals
+        if (Sp->wide_lo) {                            // two marginal groups per MSM (k_wide_a2): 2^lo * fold(H) + fold(L)
+            for (int g2 = 0; g2 < 2; g2++) {
+                const khost::xyzz* r3 = res + (j * 2 + g2) * 3;
+                khost::xyzz f = r3[2];
+                for (int t = 0; t < Sp->plane_shift[1]; t++) f = crv.dbl(f);
+                f = crv.add(f, r3[1]);
+                for (int t = 0; t < Sp->plane_shift[0]; t++) f = crv.dbl(f);
+                f = crv.add(f, r3[0]);
+                if (g2 == 0) { for (int t = 0; t < Sp->wide_lo; t++) f = crv.dbl(f); total = f; }
+                else total = crv.add(total, f);
+            }
+        } else if (Sp->precomp && Sp->planes) {       // (M2 2^f1 + M1) 2^f0 + M0 over the three digit marginals
             total = res[j * 3 + 2];
             for (int t = 0; t < Sp->plane_shift[1]; t++) total = crv.dbl(total);
             total = crv.add(total, res[j * 3 + 1]);

@@ -12,12 +12,17 @@ struct MsmBasis {
     int precomp_c = 0;               // 0: plain basis; else window width of the precomputed tables
     size_t stride = 0;               // points between consecutive window tables (0: = n)
     size_t batch_stride = 0;         // >0: MSM j of a batch uses points [j*batch_stride, ...) (independent bases)
+    const void* wide_pts = nullptr;  // a second table set of the SAME basis with wide windows (same stride), used for big single MSMs
+    int wide_c = 0;
 };
 
 int msm_pick_window(size_t n);
 // builds the window tables 2^(c*w) * P_i in place: `tables` holds W x n x 64 B with table 0 = the basis
 int msm_precompute(Context& C, int curve, void* tables, const uint8_t* inf, size_t n, int c);
 static constexpr int MSM_PRECOMP_C = 16;          // window width of the precomputed tables
+static constexpr int MSM_WIDE_C = 20;             // ... of the second table set big bases get: 13 windows, 2^19 buckets (msm.hip, "wide windows")
+void msm_set_wide_min_n(size_t n);
+size_t msm_wide_min_n();                          // MSMs of at least this many points take the wide tables (KH_WIDE_MIN_N, default 2^20; 0 = never)
 static constexpr size_t MSM_PRECOMP_MIN_N = 1024; // smaller bases keep the plain per-window path
 static constexpr int IPA_ROUND_C = 16;            // window width of the opening rounds' table set (KH_IPA_C overrides; < 16: a second, narrower set)
 // enqueue all device work of k MSMs on slot S (returns immediately); msm_finish waits for it and does the host part

@@ -31,7 +31,7 @@ SYMBOLS = [
     "kh_sponge_new", "kh_sponge_clone", "kh_sponge_free", "kh_sponge_absorb_g", "kh_sponge_absorb", "kh_sponge_absorb_fr", "kh_sponge_challenge",
     "kh_sponge_challenge_field", "kh_sponge_squeeze_field", "kh_sponge_digest",
     "kh_group_map_to_group", "kh_dev_copy", "kh_dev_memset_zero", "kh_ipa_open",
-    "kh_device_count", "kh_init", "kh_set_device", "kh_get_device", "kh_trim", "kh_srs_device", "kh_last_error", "kh_srs_create", "kh_srs_free", "kh_srs_size",
+    "kh_device_count", "kh_init", "kh_set_device", "kh_get_device", "kh_trim", "kh_srs_device", "kh_last_error", "kh_srs_create", "kh_msm_set_wide_min_n", "kh_srs_free", "kh_srs_size",
     "kh_srs_set_lagrange", "kh_srs_compute_lagrange", "kh_srs_get_lagrange", "kh_srs_lagrange_chunks",
     "kh_msm", "kh_msm_batch", "kh_msm_points", "kh_ntt", "kh_lde",
     "kh_dev_alloc", "kh_dev_free", "kh_dev_upload", "kh_dev_download", "kh_dev_upload_2d",
@@ -67,6 +67,7 @@ _lib.kh_srs_size.argtypes = [C.c_void_p]
 _lib.kh_srs_free.restype = None
 _lib.kh_srs_free.argtypes = [C.c_void_p]
 _lib.kh_srs_create.argtypes = [C.c_int, U64P, C.c_size_t, C.POINTER(C.c_void_p)]
+_lib.kh_msm_set_wide_min_n.argtypes = [C.c_size_t]
 _lib.kh_srs_set_lagrange.argtypes = [C.c_void_p, C.c_uint, C.c_uint, U64P, U8P, C.c_size_t]
 _lib.kh_srs_compute_lagrange.argtypes = [C.c_void_p, C.c_uint]
 _lib.kh_srs_get_lagrange.argtypes = [C.c_void_p, C.c_uint, C.c_uint, U64P, U8P]
@@ -192,6 +193,11 @@ def get_device() -> int:
 
 def trim():
     _check(_lib.kh_trim())
+
+
+def set_wide_min_n(n: int):
+    """Bases of >= n points created from now on get the 20-bit-window table set, single MSMs of >= n scalars take it (kh_msm_set_wide_min_n; 0 = never)."""
+    _check(_lib.kh_msm_set_wide_min_n(n))
 
 
 class Srs:

@@ -320,6 +320,24 @@ class Madd29Model:
         ry = self.muladd(R, t, yn, PPP)                                                  # R (Q - rx) - y PPP with ONE reduction
         return (rx, ry, self.mul(zz, PP), self.mul(zzz, PPP))
 
+    def add(self, A, B):
+        """Full XYZZ addition of two lazy points (add29, field29.cuh): both operands as madd leaves an accumulator (x < 6p, y < 4p, zz, zzz < 2p,
+        normalised).  None when P = U2 - U1 = 0 (mod p) cannot be excluded (equal or opposite points: the exact path decides)."""
+        c = self.c
+        x1, y1, zz1, zzz1 = A
+        x2, y2, zz2, zzz2 = B
+        U1 = self.mul(x1, zz2); U2 = self.mul(x2, zz1); S1 = self.mul(y1, zzz2); S2 = self.mul(y2, zzz1)
+        P = self.subn(U2, U1, c["S51"]); R = self.subn(S2, S1, c["S51"])
+        if P[0] <= 8:
+            return None
+        PP = self.sqr(P); PPP = self.mul(P, PP); Q = self.mul(U1, PP); RR = self.sqr(R)
+        sub = [self.u32(PPP[i] + 2 * Q[i]) for i in range(9)]
+        rx = self.subn(RR, sub, c["S44"])
+        t = [self.u32(self.u32(Q[i] + c["S61"][i]) - rx[i]) for i in range(9)]
+        yn = [self.u32(c["S51"][i] - S1[i]) for i in range(9)]
+        ry = self.muladd(R, t, yn, PPP)
+        return (rx, ry, self.mul(self.mul(zz1, zz2), PP), self.mul(self.mul(zzz1, zzz2), PPP))
+
 
 def val29(l):
     return sum(x << (29 * i) for i, x in enumerate(l))
@@ -379,6 +397,76 @@ def check_madd(p, name, chains=12, length=40):
     print(f"{name}: madd29 limb model OK over {chains} x {length} additions; max value / p = " + ", ".join(f"{m:.2f}" for m in maxv))
 
 
+def check_add(p, name, trees=6, leaves=24):
+    """add29 through the limb model: random sums of sums (operands that are themselves results of madd / add chains) against affine arithmetic."""
+    rnd = random.Random(11)
+    M = Madd29Model(p)
+    R29inv = pow(1 << 261, -1, p)
+    R = 1 << 256
+
+    def sqrt(a):
+        q, s = p - 1, 0
+        while q % 2 == 0: q //= 2; s += 1
+        z = 5
+        while pow(z, (p - 1) // 2, p) != p - 1: z += 1
+        m_, c_, t_, r_ = s, pow(z, q, p), pow(a, q, p), pow(a, (q + 1) // 2, p)
+        while t_ != 1:
+            i, tt = 0, t_
+            while tt != 1: tt = tt * tt % p; i += 1
+            bb = pow(c_, 1 << (m_ - i - 1), p); m_, c_ = i, bb * bb % p; t_, r_ = t_ * c_ % p, r_ * bb % p
+        return r_
+
+    def rand_point():
+        while True:
+            x = rnd.randrange(p); y2 = (x * x * x + 5) % p
+            if pow(y2, (p - 1) // 2, p) == 1:
+                return x, sqrt(y2)
+
+    def aff_add(A, B):
+        (x1, y1), (x2, y2) = A, B
+        lam = (y2 - y1) * pow(x2 - x1, -1, p) % p
+        x3 = (lam * lam - x1 - x2) % p
+        return x3, (lam * (x1 - x3) - y1) % p
+
+    def lazy(A):                                   # an affine point as the accumulation kernel starts a task (to29 of the wire form, zz = zzz = 1)
+        X, Y = A[0] * R % p, A[1] * R % p
+        return (M.mul(limbs29(X), M.c["KIN"]), M.mul(limbs29(Y), M.c["KIN"]), list(M.c["ONE"]), list(M.c["ONE"]))
+
+    maxv = [0, 0, 0, 0]
+    for _ in range(trees):
+        items = []
+        for _ in range(leaves):
+            A = rand_point(); acc = lazy(A)
+            for _ in range(rnd.randrange(0, 3)):   # some leaves are short madd chains (a bucket of 1-3 entries)
+                B = rand_point()
+                px, py = limbs29((B[0] * R % p) << 5), limbs29((B[1] * R % p) << 5)
+                acc = M.madd(acc, px, py); A = aff_add(A, B)
+                assert acc is not None
+            items.append((acc, A))
+        while len(items) > 1:                      # sequential chain and pairwise tree mixed: every operand shape add29 meets
+            i = rnd.randrange(len(items) - 1)
+            (a, A), (b, B) = items[i], items[i + 1]
+            r = M.add(a, b)
+            assert r is not None, "filter fired on random points"
+            vals = [val29(v) for v in r]
+            maxv = [max(m, v / p) for m, v in zip(maxv, vals)]
+            assert vals[0] < 6 * p and vals[1] < 4 * p and vals[2] < 2 * p and vals[3] < 2 * p
+            assert all(l <= MASK for v in r for l in v[:8])
+            C = aff_add(A, B)
+            xs, ys, zzs, zzzs = [v * R29inv % p for v in vals]
+            assert xs * pow(zzs, -1, p) % p == C[0] and ys * pow(zzzs, -1, p) % p == C[1], f"{name}: add29 model mismatch"
+            items[i:i + 2] = [(r, C)]
+    # the filter: A + A and A + (-A) must be caught (P = U2 - U1 + 5p = 5p exactly when U1 = U2 as integers; 4p / 6p otherwise)
+    A = rand_point(); a = lazy(A)
+    B = rand_point(); px, py = limbs29((B[0] * R % p) << 5), limbs29((B[1] * R % p) << 5)
+    a2 = M.madd(lazy(A), px, py)                   # A + B through one route ...
+    b2 = M.madd(lazy(B), limbs29((A[0] * R % p) << 5), limbs29((A[1] * R % p) << 5))     # ... and B + A through another: same point, different representation
+    assert M.add(a, a) is None and M.add(a2, b2) is None
+    neg = (b2[0], limbs29((5 * p - val29(b2[1])) % (8 * p)), b2[2], b2[3])
+    assert M.add(a2, neg) is None
+    print(f"{name}: add29 limb model OK over {trees} trees of {leaves} leaves; max value / p = " + ", ".join(f"{m:.2f}" for m in maxv))
+
+
 def emit_consts():
     out = ["// GENERATED by tools/gen_field29_asm.py -- 29-bit-limb constants of the two Pasta primes (see that file)."]
     for name, p in (("Fp29C", P_FP), ("Fq29C", P_FQ)):
@@ -421,6 +509,7 @@ def main():
     if "--check" in sys.argv:
         check(P_FP, "Fp"); check(P_FQ, "Fq")
         check_madd(P_FP, "Fp"); check_madd(P_FQ, "Fq")
+        check_add(P_FP, "Fp"); check_add(P_FQ, "Fq")
     text = render()
     if not os.path.exists(INC_PATH) or open(INC_PATH).read() != text:      # leave the mtime alone when nothing changed
         open(INC_PATH, "w").write(text)
