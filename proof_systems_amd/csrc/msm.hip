@@ -672,7 +672,7 @@ k_part2_scatter(const int32_t* __restrict__ digits, u32 tot_e, u32 nblk, u32 low
     KH_HIGH_PRIO();
     __shared__ u32 cur[PART_P];
     const u32 blk = blockIdx.x, j = blockIdx.y, tid = threadIdx.x;
-    if (blk == 0 && j == 0 && tid == 0) xlist[0] = 0;        // the split-bucket list pass B appends to
+    if (blk == 0 && j == 0 && tid == 0) { xlist[0] = 0; xlist[1] = 0; }      // the split-bucket lists pass B appends to
     if (tid < PART_P) cur[tid] = PO[((size_t)j * PART_P + tid) * nblk + blk];
     __syncthreads();
     const u32 e_lo = (u32)((u64)tot_e * blk / nblk), e_hi = (u32)((u64)tot_e * (blk + 1) / nblk);
@@ -693,13 +693,16 @@ k_part2_scatter(const int32_t* __restrict__ digits, u32 tot_e, u32 nblk, u32 low
 // task counts, their prefix (toff) and the length ranking are partition-local here (the narrow path ranks all keys globally: two more kernels and
 // two more device-wide scans, 64 us at 2^19 keys).  toff is written relative to the partition (k_wide_fixup adds the partitions' task bases);
 // the order is INTERLEAVED over the partitions -- order[r * nparts + q] = the bucket of rank r (longest first) in partition q -- so that the
-// accumulation launch runs longest-first as a whole (partitions are statistically alike) and a wave holds one rank of 64 partitions; the extra
-// chunks of split buckets go to xlist as (key, chunk) pairs.
+// accumulation launch runs longest-first as a whole (partitions are statistically alike: see the choice of the partition bits above), `og`
+// consecutive ranks of a partition side by side (measured: og = 1 / 4 / 16 / 64 / 2048 -> 923 / 843 / 795 / 819 / 1710 us of accumulation).  The extra
+// chunks of split buckets go to xlist as (key, chunk) pairs ([0] = their number), the split buckets themselves to slist ([1] = their number);
+// empty buckets get their identity record here.
 struct WideTasks { u32 room, kmin, nkeys; KTab ktab; };
 __global__ void __launch_bounds__(PART_T)
 k_part2_sort(const u32* __restrict__ mid, const u32* __restrict__ PO, u32 nblk, u32 low, u32 nb, u32 tot_e, u32 n, size_t pt_stride, size_t pt_offset,
              size_t pt_batch, u32 last_group, size_t total_idx, WideTasks ta, u32* __restrict__ off, u32* __restrict__ entries,
-             u32* __restrict__ toff, u32* __restrict__ order, u32* __restrict__ ptot, u32* __restrict__ xlist, u32 dbg) {
+             u32* __restrict__ toff, u32* __restrict__ order, u32* __restrict__ ptot, u32* __restrict__ xlist, u32* __restrict__ slist,
+             uint8_t* __restrict__ buckets29, u32 og) {
     KH_HIGH_PRIO();
     __shared__ u32 cur[1u << PART2_MAXLOW], pstart[1025], bi0[1024], bw0[1024], lh[MAX_K + 2], sh[PART_T / 64 + 1];
     __shared__ u32 xl_key[1u << PART2_MAXLOW], xl_nt[1u << PART2_MAXLOW], xl_base[1u << PART2_MAXLOW], xl_n;
@@ -717,7 +720,6 @@ k_part2_sort(const u32* __restrict__ mid, const u32* __restrict__ PO, u32 nblk, 
     if (tid == 0) xl_n = 0;
     __syncthreads();
     const u32 base = pstart[0], end = pstart[nblk];
-    if (!(dbg & 4u))
     for (u32 x0 = base + tid; x0 < end; x0 += 8 * PART_T) {
         u32 m[8];
 #pragma unroll
@@ -744,8 +746,11 @@ k_part2_sort(const u32* __restrict__ mid, const u32* __restrict__ PO, u32 nblk, 
         if (tid == 0) ptot[q] = btot;
         if (i0 < nbl) atomicAdd(&lh[la], 1u);
         if (i0 + 1 < nbl) atomicAdd(&lh[lb], 1u);
-        if (nta > 1) { const u32 sl = atomicAdd(&xl_n, 1u); xl_key[sl] = (u32)key0; xl_nt[sl] = nta; xl_base[sl] = atomicAdd(&xlist[0], nta - 1u); }
-        if (ntb > 1) { const u32 sl = atomicAdd(&xl_n, 1u); xl_key[sl] = (u32)key0 + 1u; xl_nt[sl] = ntb; xl_base[sl] = atomicAdd(&xlist[0], ntb - 1u); }
+        if (nta > 1) { const u32 sl = atomicAdd(&xl_n, 1u); xl_key[sl] = (u32)key0; xl_nt[sl] = nta; xl_base[sl] = atomicAdd(&xlist[0], nta - 1u); slist[atomicAdd(&xlist[1], 1u)] = (u32)key0; }
+        if (ntb > 1) { const u32 sl = atomicAdd(&xl_n, 1u); xl_key[sl] = (u32)key0 + 1u; xl_nt[sl] = ntb; xl_base[sl] = atomicAdd(&xlist[0], ntb - 1u); slist[atomicAdd(&xlist[1], 1u)] = (u32)key0 + 1u; }
+        // an empty bucket's record is the identity (true bucket number = local index << 8 | partition)
+        if (i0 < nbl && a == 0) { uint4* rec = (uint4*)(buckets29 + ((size_t)j * nb + ((size_t)i0 << 8 | pidx)) * B29_BYTES); _Pragma("unroll") for (int t = 0; t < 9; t++) rec[t] = make_uint4(0u, 0u, 0u, 0u); }
+        if (i0 + 1 < nbl && b == 0) { uint4* rec = (uint4*)(buckets29 + ((size_t)j * nb + ((size_t)(i0 + 1) << 8 | pidx)) * B29_BYTES); _Pragma("unroll") for (int t = 0; t < 9; t++) rec[t] = make_uint4(0u, 0u, 0u, 0u); }
         __syncthreads();
         // lh[L] <- number of buckets with a task length above L = first rank of length L (longest first)
         const u32 L = MAX_K - (tid <= MAX_K ? tid : MAX_K), hv = tid <= MAX_K ? lh[L] : 0u;
@@ -753,7 +758,6 @@ k_part2_sort(const u32* __restrict__ mid, const u32* __restrict__ PO, u32 nblk, 
         __syncthreads();
         if (tid <= MAX_K) lh[L] = above;
         __syncthreads();
-        const u32 og = dbg >> 8;                          // interleaving granularity (ranks per partition in a row)
         if (i0 < nbl) { const u32 r = atomicAdd(&lh[la], 1u); order[(size_t)(r / og) * nparts * og + q * og + (r % og)] = (u32)key0; }
         if (i0 + 1 < nbl) { const u32 r = atomicAdd(&lh[lb], 1u); order[(size_t)(r / og) * nparts * og + q * og + (r % og)] = (u32)key0 + 1u; }
         // the chunks 1 .. nt - 1 of the split buckets, written by the whole block (one bucket may hold every entry of the MSM)
@@ -771,7 +775,6 @@ k_part2_sort(const u32* __restrict__ mid, const u32* __restrict__ PO, u32 nblk, 
 #pragma unroll
         for (int u = 0; u < 8; u++) { const u32 x = x0 + u * PART_T; m[u] = mid[x < end ? x : end - 1]; blk[u] = 0; }
         // the pass-A block that wrote record x: the largest blk with pstart[blk] <= x, all eight searches in lockstep (LDS latency overlaps)
-        if (!(dbg & 2u))
         for (u32 st = top; st >= 1; st >>= 1) {
 #pragma unroll
             for (int u = 0; u < 8; u++) {
@@ -786,7 +789,7 @@ k_part2_sort(const u32* __restrict__ mid, const u32* __restrict__ PO, u32 nblk, 
             if (live) {
                 u32 w = bw0[blk[u]], i = bi0[blk[u]] + (m[u] & 0xffffu);
                 while (i >= n) { i -= n; w++; }
-                if (!(dbg & 1u)) entries[pos] = (pb0 + (u32)(w * pt_stride) + i) | ((m[u] & (1u << 16)) << 15);
+                entries[pos] = (pb0 + (u32)(w * pt_stride) + i) | ((m[u] & (1u << 16)) << 15);
             }
         }
     }
@@ -918,7 +921,7 @@ __device__ __forceinline__ u32 wide_true_bucket(u32 key, u32 low) {
 }
 template <class BF>
 __device__ __forceinline__ void wide_task29(u32 key, u32 jt, const u32* __restrict__ entries, const u32* __restrict__ off, const u32* __restrict__ toff,
-                                            const uint8_t* __restrict__ pts, uint8_t* __restrict__ partial, uint8_t* __restrict__ buckets29, u32 low, u32* __restrict__ handed, u32 dbg = 0) {
+                                            const uint8_t* __restrict__ pts, uint8_t* __restrict__ partial, uint8_t* __restrict__ buckets29, u32 low, u32* __restrict__ handed) {
     const u32 o0 = off[key], cnt = off[key + 1] - o0;
     if (cnt == 0) return;
     const u32 t0 = toff[key], nt = toff[key + 1] - t0;
@@ -932,50 +935,32 @@ __device__ __forceinline__ void wide_task29(u32 key, u32 jt, const u32* __restri
 #pragma unroll
     for (int i = 0; i < 9; i++) { acc.zz.v[i] = K29::one(i); acc.zzz.v[i] = K29::one(i); }
     bool ok = true;
-    const u32 e0 = e & 0x7fffffffu;
     for (u32 k = start + 1; k < end; k++) {
-        if (dbg & 16u) e = entries[start + 1];
-        else if (dbg & 64u) e = (e0 + (k - start) * 104729u) % 13000000u;
-        else e = entries[k];
-        if (dbg & 32u) e = (e0 & 0xffffff00u) + (k - start);
+        e = entries[k];
         p = Aff<BF>::load(pts + (size_t)(e & 0x7fffffffu) * 64);
         if (e >> 31) p.y = neg<BF>(p.y);
         ok = madd29<BF>(acc, pack29<BF, 5>(p.x), pack29<BF, 5>(p.y));
-        if (!ok && !(dbg & 0x70u)) break;
+        if (!ok) break;
     }
-    if (dbg & 0x70u) ok = true;
     if (!ok) { const u32 slot = atomicAdd(&handed[0], 1u); handed[2 + 2 * slot] = key; handed[3 + 2 * slot] = jt; return; }
     if (nt == 1) { store_b29<BF>(buckets29 + (size_t)wide_true_bucket(key, low) * B29_BYTES, acc); return; }
     Xyzz<BF> r;
     r.x = from29<BF>(acc.x); r.y = from29<BF>(acc.y); r.zz = from29<BF>(acc.zz); r.zzz = from29<BF>(acc.zzz);
     r.store(partial + (size_t)(t0 + jt) * 128);
 }
+// Blocks [0, nkeys / 256): thread per bucket.  The WIDE_XB blocks behind them walk xlist ([0] = number of extra chunks, then (key, chunk) pairs
+// from word 2 on; empty for unskewed scalars).  Launched with enough dynamic LDS to hold the kernel to THREE blocks per CU (it is VALU-bound from
+// three waves per SIMD on; the fourth only keeps the neighbouring jobs' sort and reduction kernels off the CU: 886-930 -> 940-1000 Mscalar/s pipelined).
+static constexpr u32 WIDE_XB = 32;
 template <class BF>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(112), amdgpu_waves_per_eu(4, 4)))
 k_acc_wide29(const u32* __restrict__ entries, const u32* __restrict__ off, const u32* __restrict__ toff, const u32* __restrict__ order, u32 nkeys,
-             const uint8_t* __restrict__ pts, uint8_t* __restrict__ partial, uint8_t* __restrict__ buckets29, u32 low, u32* __restrict__ handed, u32 dbg) {
+             const uint8_t* __restrict__ pts, uint8_t* __restrict__ partial, uint8_t* __restrict__ buckets29, u32 low, u32* __restrict__ handed,
+             const u32* __restrict__ xlist) {
     const u32 g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= nkeys) return;
-    unsigned long long t_0 = 0;
-    if (dbg & 128u) t_0 = wall_clock64();
-    wide_task29<BF>(order[g], 0u, entries, off, toff, pts, partial, buckets29, low, handed, dbg);
-    if ((dbg & 128u) && (threadIdx.x & 63u) == 0) {         // per WAVE: start, end, hardware id, XCC id
-        u32 hw, xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        unsigned long long* tr = (unsigned long long*)partial + 4 * (size_t)(g >> 6);
-        const u32 key_ = order[g];
-        tr[0] = t_0; tr[1] = wall_clock64(); tr[2] = hw; tr[3] = (xcc & 0xffu) | ((unsigned long long)(off[key_ + 1] - off[key_]) << 32);
-    }
-}
-// xlist: [0] = number of extra chunks, then (key, chunk) pairs from word 2 on; a small persistent grid walks it (empty for unskewed scalars)
-template <class BF>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(112)))
-k_acc_wide_extra(const u32* __restrict__ entries, const u32* __restrict__ off, const u32* __restrict__ toff, const u32* __restrict__ xlist,
-                 const uint8_t* __restrict__ pts, uint8_t* __restrict__ partial, uint8_t* __restrict__ buckets29, u32 low, u32* __restrict__ handed) {
-    KH_HIGH_PRIO();
+    if (g < nkeys) { wide_task29<BF>(order[g], 0u, entries, off, toff, pts, partial, buckets29, low, handed); return; }
     const u32 count = xlist[0];
-    for (u32 it = blockIdx.x * blockDim.x + threadIdx.x; it < count; it += gridDim.x * blockDim.x)
+    for (u32 it = g - nkeys; it < count; it += WIDE_XB * 256u)
         wide_task29<BF>(xlist[2 + 2 * it], xlist[3 + 2 * it], entries, off, toff, pts, partial, buckets29, low, handed);
 }
 template <class BF>
@@ -1387,39 +1372,39 @@ k_marginal_fin_q(const uint8_t* __restrict__ marg, MargGeom g, uint8_t* __restri
 //     sum_t (t + 1) B_t  =  2^lo  sum_a a H_a  +  sum_b (b + 1) L_b,      H_a = sum_b B_(a,b),   L_b = sum_a B_(a,b)
 // -- every bucket goes into ONE hi-digit and ONE lo-digit marginal: 2 x 2^19 full additions, all of them in the lazy 29-bit arithmetic
 // (add29: ~1.4 mixed additions each), then 2^hi + 2^lo = 1536 marginals take the 5-bit digit-marginal tail of the narrow path.
-//   k_bucket_sum_wide  buckets that are not a single task's output (empty: identity record; split: exact sum of the wire partials; hot: the
-//                      two-phase big-bucket kernels, then k_big_to29)
+//   k_bucket_sum_wide  the split buckets of pass B's list (exact sum of the wire partials; hot ones: the two-phase big-bucket kernels, then
+//                      k_big_to29); empty buckets got their identity record from pass B, all others ARE a task's output
 //   k_wide_a1          thread (plane, marginal, chunk): the sum of r = 8 buckets, sequentially, B29 in -> B29 out (2^17 threads; plane 0 reads
 //                      r consecutive records, plane 1 a column: neighbouring lanes read neighbouring records).  A thread whose add29 cannot
-//                      exclude an exceptional case lists itself; k_wide_a1_exact redoes the listed chunks with the exact formulas.
+//                      exclude an exceptional case writes a marker record; k_wide_a2 redoes such a chunk with the exact formulas.
 //   k_wide_a2          wave per marginal: its 2^lo / r (or 2^hi / r) chunk sums, converted to the wire form, one or two per lane, then the
 //                      lane-cooperative tree of k_marginals_h.  Output: 2 x 2^lo wire records per MSM laid out as TWO bucket groups of 2^lo
 //                      buckets for k_marginals_q / k_marginal_fin_q -- group 0 holds H_a at slot a - 1 (weight a; H_0 has weight 0 and is
 //                      dropped, slots >= 2^hi - 1 are the identity), group 1 holds L_b at slot b.
 struct WideGeom { u32 nb, lo, hi, rlog; };
+// split buckets only (slist: pass B's list of buckets with more than one task; count in xlist[1]): a small persistent grid
 template <class BF>
 __global__ void __launch_bounds__(256)
-k_bucket_sum_wide(const u32* __restrict__ toff, size_t nkeys, const uint8_t* __restrict__ partial, uint8_t* __restrict__ buckets29,
-                  u32 low, u32* __restrict__ big, size_t cap, u32 SMALL_NT, u32* __restrict__ handed) {
+k_bucket_sum_wide(const u32* __restrict__ toff, const u32* __restrict__ xlist, const u32* __restrict__ slist, const uint8_t* __restrict__ partial,
+                  uint8_t* __restrict__ buckets29, u32 low, u32* __restrict__ big, size_t cap, u32 SMALL_NT) {
     KH_HIGH_PRIO();
-    size_t key = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (key == 0) handed[0] = 0;                           // the accumulation's hand-over list is consumed: k_wide_a1 starts its own
-    if (key >= nkeys) return;
-    u32 t0 = toff[key], nt = toff[key + 1] - t0;
-    if (nt == 1) return;                                   // written by the accumulation itself
-    uint8_t* const rec = buckets29 + (size_t)wide_true_bucket((u32)key, low) * B29_BYTES;
-    if (nt == 0) { store_b29_identity<BF>(rec); return; }
-    if (nt > SMALL_NT) {
-        u32 nch = (nt + CHUNK - 1) / CHUNK;
-        u32 slot = atomicAdd(&big[0], 1u);
-        u32 cbase = atomicAdd(&big[1], nch);
-        big[2 + slot] = (u32)key; big[2 + cap + slot] = cbase;
-        for (u32 j = 0; j < nch; j++) { big[2 + 2 * cap + cbase + j] = (u32)key; big[2 + 3 * cap + cbase + j] = j; }
-        return;
+    const u32 count = xlist[1];
+    for (u32 it = blockIdx.x * blockDim.x + threadIdx.x; it < count; it += gridDim.x * blockDim.x) {
+        const u32 key = slist[it];
+        const u32 t0 = toff[key], nt = toff[key + 1] - t0;
+        if (nt > SMALL_NT) {
+            u32 nch = (nt + CHUNK - 1) / CHUNK;
+            u32 slot = atomicAdd(&big[0], 1u);
+            u32 cbase = atomicAdd(&big[1], nch);
+            big[2 + slot] = key; big[2 + cap + slot] = cbase;
+            for (u32 j = 0; j < nch; j++) { big[2 + 2 * cap + cbase + j] = key; big[2 + 3 * cap + cbase + j] = j; }
+            continue;
+        }
+        Xyzz<BF> acc = Xyzz<BF>::load(partial + (size_t)t0 * 128);
+        for (u32 k = 1; k < nt; k++) acc = add<BF>(acc, Xyzz<BF>::load(partial + (size_t)(t0 + k) * 128));
+        uint8_t* const rec = buckets29 + (size_t)wide_true_bucket(key, low) * B29_BYTES;
+        if (acc.is_identity()) store_b29_identity<BF>(rec); else store_b29<BF>(rec, xyzz_to29<BF>(acc));
     }
-    Xyzz<BF> acc = Xyzz<BF>::load(partial + (size_t)t0 * 128);
-    for (u32 k = 1; k < nt; k++) acc = add<BF>(acc, Xyzz<BF>::load(partial + (size_t)(t0 + k) * 128));
-    store_b29<BF>(rec, xyzz_to29<BF>(acc));
 }
 template <class BF>
 __global__ void __launch_bounds__(64)
@@ -1428,26 +1413,34 @@ k_big_to29(const uint8_t* __restrict__ buckets, const u32* __restrict__ big, uin
     const u32 nbig = big[0];
     for (u32 bi = blockIdx.x * blockDim.x + threadIdx.x; bi < nbig; bi += gridDim.x * blockDim.x) {
         const u32 key = big[2 + bi];
-        store_b29<BF>(buckets29 + (size_t)wide_true_bucket(key, low) * B29_BYTES, xyzz_to29<BF>(Xyzz<BF>::load(buckets + (size_t)key * 128)));
+        const Xyzz<BF> v = Xyzz<BF>::load(buckets + (size_t)key * 128);
+        uint8_t* const rec = buckets29 + (size_t)wide_true_bucket(key, low) * B29_BYTES;
+        if (v.is_identity()) store_b29_identity<BF>(rec); else store_b29<BF>(rec, xyzz_to29<BF>(v));
     }
 }
-// work item u of a group: first bucket, bucket stride, output record
-__device__ __forceinline__ void wide_a1_item(const WideGeom& g, u32 u, u32& t0, u32& tstride, u32& out) {
+// work item `out` of a group (the index of its output record): first bucket and bucket stride of its chunk
+__device__ __forceinline__ void wide_a1_item(const WideGeom& g, u32 out, u32& t0, u32& tstride) {
     const u32 per = g.nb >> g.rlog;                        // items per plane
-    if (u < per) { t0 = u << g.rlog; tstride = 1u; out = u; return; }
-    const u32 v = u - per, b = v & ((1u << g.lo) - 1u), s = v >> g.lo;
-    t0 = ((s << g.rlog) << g.lo) + b; tstride = 1u << g.lo; out = per + b * ((1u << g.hi) >> g.rlog) + s;
+    if (out < per) { t0 = out << g.rlog; tstride = 1u; return; }
+    const u32 cpm = (1u << g.hi) >> g.rlog, v = out - per, b = v / cpm, s = v - b * cpm;      // chunks per lo-digit marginal
+    t0 = ((s << g.rlog) << g.lo) + b; tstride = 1u << g.lo;
 }
+// a record whose zz limb 0 is all ones (no normalised limb is): "this chunk's lazy sum met a possible exceptional case" -- k_wide_a2 redoes the chunk exactly
+template <class F>
+__device__ __forceinline__ bool is_marker29(const Acc29<F>& a) { return a.zz.v[0] == 0xffffffffu; }
 template <class BF>
 __global__ void __launch_bounds__(256)
-k_wide_a1(const uint8_t* __restrict__ buckets29, WideGeom g, u32 ngroups, uint8_t* __restrict__ out29, u32* __restrict__ handed) {
+k_wide_a1(const uint8_t* __restrict__ buckets29, WideGeom g, u32 ngroups, uint8_t* __restrict__ out29) {
     KH_HIGH_PRIO();
-    const u32 items = 2u * (g.nb >> g.rlog);
+    const u32 per = g.nb >> g.rlog, items = 2u * per;
     const u32 gid = blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= items * ngroups) return;
     const u32 q = gid / items, u = gid - q * items;
-    u32 t0, ts, out;
-    wide_a1_item(g, u, t0, ts, out);
+    // thread u -> output record: plane 0 in order; plane 1 with the lo digit fastest across lanes (neighbouring lanes read neighbouring buckets)
+    u32 out = u;
+    if (u >= per) { const u32 v = u - per, b = v & ((1u << g.lo) - 1u), sc = v >> g.lo; out = per + b * ((1u << g.hi) >> g.rlog) + sc; }
+    u32 t0, ts;
+    wide_a1_item(g, out, t0, ts);
     const uint8_t* B = buckets29 + ((size_t)q * g.nb + t0) * B29_BYTES;
     Acc29<BF> acc;
     bool have = false, ok = true;
@@ -1460,32 +1453,26 @@ k_wide_a1(const uint8_t* __restrict__ buckets29, WideGeom g, u32 ngroups, uint8_
         ok = add29<BF>(acc, b);
         if (!ok) break;
     }
-    if (!ok) { handed[1 + atomicAdd(&handed[0], 1u)] = gid; return; }
     uint8_t* o = out29 + ((size_t)q * items + out) * B29_BYTES;
+    if (!ok) { acc.zz.v[0] = 0xffffffffu; store_b29<BF>(o, acc); return; }
     if (have) store_b29<BF>(o, acc); else store_b29_identity<BF>(o);
 }
+// the exact sum of one chunk (k_wide_a2's rare path; kept out of line so that its registers do not weigh on the kernel)
 template <class BF>
-__global__ void __launch_bounds__(64)
-k_wide_a1_exact(const uint8_t* __restrict__ buckets29, WideGeom g, uint8_t* __restrict__ out29, const u32* __restrict__ handed) {
-    KH_HIGH_PRIO();
-    const u32 items = 2u * (g.nb >> g.rlog), count = handed[0], r = 1u << g.rlog;
-    for (u32 it = blockIdx.x * blockDim.x + threadIdx.x; it < count; it += gridDim.x * blockDim.x) {
-        const u32 gid = handed[1 + it], q = gid / items, u = gid - q * items;
-        u32 t0, ts, out;
-        wide_a1_item(g, u, t0, ts, out);
-        const uint8_t* B = buckets29 + ((size_t)q * g.nb + t0) * B29_BYTES;
-        Xyzz<BF> acc = Xyzz<BF>::identity();
-        for (u32 i = 0; i < r; i++) {
-            const Acc29<BF> b = load_b29<BF>(B + (size_t)i * ts * B29_BYTES);
-            if (!is_identity29<BF>(b)) acc = add<BF>(acc, xyzz_from29<BF>(b));
-        }
-        uint8_t* o = out29 + ((size_t)q * items + out) * B29_BYTES;
-        if (acc.is_identity()) store_b29_identity<BF>(o); else store_b29<BF>(o, xyzz_to29<BF>(acc));
+__device__ __attribute__((noinline)) Xyzz<BF> wide_chunk_exact(const uint8_t* __restrict__ buckets29g, WideGeom g, u32 out) {
+    u32 t0, ts;
+    wide_a1_item(g, out, t0, ts);
+    Xyzz<BF> acc = Xyzz<BF>::identity();
+    const u32 r = 1u << g.rlog;
+    for (u32 i = 0; i < r; i++) {
+        const Acc29<BF> b = load_b29<BF>(buckets29g + ((size_t)t0 + (size_t)i * ts) * B29_BYTES);
+        if (!is_identity29<BF>(b)) acc = add<BF>(acc, xyzz_from29<BF>(b));
     }
+    return acc;
 }
 template <class BF>
 __global__ void __launch_bounds__(64)
-k_wide_a2(const uint8_t* __restrict__ in29, WideGeom g, uint8_t* __restrict__ outw) {
+k_wide_a2(const uint8_t* __restrict__ in29, const uint8_t* __restrict__ buckets29, WideGeom g, uint8_t* __restrict__ outw) {
     KH_HIGH_PRIO();
     __shared__ u32 stage[32][64];                        // [word of the XYZZ record][lane]
     const u32 slot = blockIdx.x, q = blockIdx.y, plane = slot >> g.lo, sidx = slot & ((1u << g.lo) - 1u);
@@ -1502,7 +1489,8 @@ k_wide_a2(const uint8_t* __restrict__ in29, WideGeom g, uint8_t* __restrict__ ou
     Xyzz<BF> a = Xyzz<BF>::identity();
     for (u32 k = lane; k < cnt; k += 64) {
         const Acc29<BF> b = load_b29<BF>(src + (size_t)k * B29_BYTES);
-        if (!is_identity29<BF>(b)) a = add<BF>(a, xyzz_from29<BF>(b));
+        if (__builtin_expect(is_marker29<BF>(b), 0)) a = add<BF>(a, wide_chunk_exact<BF>(buckets29 + (size_t)q * g.nb * B29_BYTES, g, first + k));
+        else if (!is_identity29<BF>(b)) a = add<BF>(a, xyzz_from29<BF>(b));
     }
 #pragma unroll
     for (int k = 0; k < 8; k++) { stage[k][lane] = a.x.v[k]; stage[8 + k][lane] = a.y.v[k]; stage[16 + k][lane] = a.zz.v[k]; stage[24 + k][lane] = a.zzz.v[k]; }
@@ -1661,11 +1649,16 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
     if ((rc = C.ws_chunks.reserve(bigcap * 128))) return rc;
     if ((rc = C.ws_order.reserve((2 * (MAX_K + 1) + 3 * (nkeys + 2)) * sizeof(u32)))) return rc;
     WideGeom wg{};
-    const u32 wide_dbg = (getenv("KH_WIDE_DBG") ? (u32)atoi(getenv("KH_WIDE_DBG")) : 0u) | ((getenv("KH_WIDE_OG") ? (u32)atoi(getenv("KH_WIDE_OG")) : 1u) << 8);     // experiments on k_part2_sort (results are wrong with it)
+    // wide-path knobs (defaults = measured best, tools/wide_sweep.py): ranks of one partition side by side in the accumulation order; blocks of the
+    // accumulation per CU (held down with dynamic LDS); log2 of the chunk length of the first reduction level
+    static const u32 wide_og = getenv("KH_WIDE_OG") ? (u32)std::max(1, atoi(getenv("KH_WIDE_OG"))) : 16u;
+    static const u32 wide_acc_blocks = getenv("KH_WIDE_ACC_BLOCKS") ? (u32)std::max(2, atoi(getenv("KH_WIDE_ACC_BLOCKS"))) : 3u;
+    static const u32 wide_rlog = getenv("KH_WIDE_RLOG") ? (u32)atoi(getenv("KH_WIDE_RLOG")) : 4u;
+    const size_t wide_acc_lds = wide_acc_blocks >= 4 ? 0 : (size_t)(160 * 1024 / (wide_acc_blocks + 1) + 1024) & ~(size_t)1023;
     if (wide) {                                            // bucket = (hi digit, lo digit); chunks of 8 buckets in the first reduction level
-        if ((rc = C.ws_xlist.reserve((2 * max_tasks + 4) * sizeof(u32)))) return rc;
+        if ((rc = C.ws_xlist.reserve((3 * max_tasks + 8) * sizeof(u32)))) return rc;       // (key, chunk) pairs of the extra chunks, then the split buckets' keys
         if ((rc = C.ws_handed.reserve((2 * max_tasks + 4) * sizeof(u32)))) return rc;
-        wg.nb = nb; wg.lo = (u32)c / 2; wg.hi = (u32)(c - 1) - wg.lo; wg.rlog = 3;
+        wg.nb = nb; wg.lo = (u32)c / 2; wg.hi = (u32)(c - 1) - wg.lo; wg.rlog = wide_rlog;
         if ((rc = C.ws_b29.reserve(nkeys * B29_BYTES))) return rc;
         if ((rc = C.ws_a1.reserve(ngroups * 2 * (size_t)(nb >> wg.rlog) * B29_BYTES))) return rc;
         if ((rc = C.ws_a2.reserve(ngroups * 2 * ((size_t)1 << wg.lo) * 128))) return rc;
@@ -1810,10 +1803,11 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
             hipLaunchKernelGGL(k_part2_scatter, pgrid, dim3(PART_T), 0, s, C.ws_digits.as<int32_t>(), tot_e, part_nblk, part_low, C.ws_cnt.as<u32>(), C.ws_mid.as<u32>(), C.ws_xlist.as<u32>());
             // ... and the task plan (toff, the length-ranked order, roff): partition-local in pass B, made global by k_wide_fixup
             const WideTasks wt{room, kmin, (u32)nkeys, ktab};
+            u32* const slist = C.ws_xlist.as<u32>() + 2 + 2 * max_tasks;
             u32* const ptot = C.ws_ntask.as<u32>();        // k * 256 partition task totals (the narrow path's per-key task counts: unused here)
             hipLaunchKernelGGL(k_part2_sort, dim3(PART_P, (unsigned)k), dim3(PART_T), 0, s, C.ws_mid.as<u32>(), C.ws_cnt.as<u32>(), part_nblk, part_low, nb, tot_e, (u32)n,
                                tab_stride, offset, basis.batch_stride, (u32)(k - 1), part_size, wt, C.ws_off.as<u32>(), C.ws_entries.as<u32>(),
-                               C.ws_toff.as<u32>(), order, ptot, C.ws_xlist.as<u32>(), wide_dbg);
+                               C.ws_toff.as<u32>(), order, ptot, C.ws_xlist.as<u32>(), slist, C.ws_b29.as<uint8_t>(), wide_og);
             hipLaunchKernelGGL(k_wide_fixup, dim3((unsigned)(nkeys / 256 + 1)), dim3(256), 0, s, C.ws_toff.as<u32>(), ptot, (u32)(k * PART_P), part_low, (u32)nkeys,
                                C.ws_handed.as<u32>(), C.ws_biglist.as<u32>());
         } else {
@@ -1860,19 +1854,17 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
     const u32* handed = acc29 ? C.ws_handed.as<u32>() : nullptr;
     const dim3 agrid((unsigned)((max_tasks + 255) / 256));
     uint8_t* const b29 = wide ? C.ws_b29.as<uint8_t>() : nullptr;
-    if (wide) {                                            // thread per bucket in pass B's interleaved length order, then the listed extra chunks / exact redos
-        const dim3 wgrid((unsigned)(nkeys / 256));
+    if (wide) {                                            // thread per bucket in pass B's interleaved length order (+ the listed extra chunks), then the exact redos
+        const dim3 wgrid((unsigned)(nkeys / 256 + WIDE_XB));
         auto kern = k_acc_wide29<BF>;
         if (C.timer.enabled && C.timer.created && !gcap.active) {
-            hipExtLaunchKernelGGL(kern, wgrid, dim3(256), 0, s, C.timer.k0, C.timer.k1, 0, C.ws_entries.as<u32>(), C.ws_off.as<u32>(), C.ws_toff.as<u32>(), order, (u32)nkeys,
-                                  (const uint8_t*)tab_pts, C.ws_partial.as<uint8_t>(), b29, part_low, C.ws_handed.as<u32>(), wide_dbg);
+            hipExtLaunchKernelGGL(kern, wgrid, dim3(256), wide_acc_lds, s, C.timer.k0, C.timer.k1, 0, C.ws_entries.as<u32>(), C.ws_off.as<u32>(), C.ws_toff.as<u32>(), order, (u32)nkeys,
+                                  (const uint8_t*)tab_pts, C.ws_partial.as<uint8_t>(), b29, part_low, C.ws_handed.as<u32>(), C.ws_xlist.as<u32>());
             C.timer.kname = "k_acc_wide29";
         } else
-        hipLaunchKernelGGL(kern, wgrid, dim3(256), 0, s, C.ws_entries.as<u32>(), C.ws_off.as<u32>(), C.ws_toff.as<u32>(), order, (u32)nkeys,
-                           (const uint8_t*)tab_pts, C.ws_partial.as<uint8_t>(), b29, part_low, C.ws_handed.as<u32>(), wide_dbg);
-        hipLaunchKernelGGL((k_acc_wide_extra<BF>), dim3(256), dim3(256), 0, s, C.ws_entries.as<u32>(), C.ws_off.as<u32>(), C.ws_toff.as<u32>(), C.ws_xlist.as<u32>(),
-                           (const uint8_t*)tab_pts, C.ws_partial.as<uint8_t>(), b29, part_low, C.ws_handed.as<u32>());
-        hipLaunchKernelGGL((k_acc_wide_exact<BF>), dim3(128), dim3(256), 0, s, C.ws_entries.as<u32>(), C.ws_off.as<u32>(), C.ws_toff.as<u32>(), C.ws_handed.as<u32>(),
+        hipLaunchKernelGGL(kern, wgrid, dim3(256), wide_acc_lds, s, C.ws_entries.as<u32>(), C.ws_off.as<u32>(), C.ws_toff.as<u32>(), order, (u32)nkeys,
+                           (const uint8_t*)tab_pts, C.ws_partial.as<uint8_t>(), b29, part_low, C.ws_handed.as<u32>(), C.ws_xlist.as<u32>());
+        hipLaunchKernelGGL((k_acc_wide_exact<BF>), dim3(32), dim3(256), 0, s, C.ws_entries.as<u32>(), C.ws_off.as<u32>(), C.ws_toff.as<u32>(), C.ws_handed.as<u32>(),
                            (const uint8_t*)tab_pts, C.ws_partial.as<uint8_t>(), b29, part_low);
     } else
     if (acc29) {
@@ -1903,8 +1895,8 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
     static const bool bsum_quad = !getenv("KH_NO_BSUM_QUAD");
     static const size_t bsum_maxg = getenv("KH_QUAD_MAXG") ? (size_t)atol(getenv("KH_QUAD_MAXG")) : 8;     // 5 / 7 / 8 MSMs of 2^16: 0.94 / 1.09 / 1.14 -> 0.85 / 1.05 / 1.09 ms against 4
     if (wide)
-        hipLaunchKernelGGL((k_bucket_sum_wide<BF>), dim3((unsigned)((nkeys + 255) / 256)), dim3(256), 0, s,
-                           C.ws_toff.as<u32>(), nkeys, C.ws_partial.as<uint8_t>(), b29, part_low, C.ws_biglist.as<u32>(), bigcap, 16u, C.ws_handed.as<u32>());
+        hipLaunchKernelGGL((k_bucket_sum_wide<BF>), dim3(32), dim3(256), 0, s, C.ws_toff.as<u32>(), C.ws_xlist.as<u32>(), C.ws_xlist.as<u32>() + 2 + 2 * max_tasks,
+                           C.ws_partial.as<uint8_t>(), b29, part_low, C.ws_biglist.as<u32>(), bigcap, 16u);
     else if (precomp && ngroups <= bsum_maxg && bsum_quad)
         hipLaunchKernelGGL((k_bucket_sum_q<BF>), dim3((unsigned)((4 * nkeys + 255) / 256)), dim3(256), 0, s,
                            C.ws_toff.as<u32>(), nkeys, C.ws_partial.as<uint8_t>(), C.ws_buckets.as<uint8_t>(), C.ws_biglist.as<u32>(),
@@ -1923,10 +1915,9 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
     bool direct_out = false;                              // latency path: the last kernel writes the (768-byte) result to host memory itself -- no copy node
     if (wide) {
         const u32 items = 2u * (nb >> wg.rlog) * (u32)ngroups;
-        hipLaunchKernelGGL((k_wide_a1<BF>), dim3((items + 255) / 256), dim3(256), 0, s, b29, wg, (u32)ngroups, C.ws_a1.as<uint8_t>(), C.ws_handed.as<u32>());
-        hipLaunchKernelGGL((k_wide_a1_exact<BF>), dim3(64), dim3(64), 0, s, b29, wg, C.ws_a1.as<uint8_t>(), C.ws_handed.as<u32>());
+        hipLaunchKernelGGL((k_wide_a1<BF>), dim3((items + 255) / 256), dim3(256), 0, s, b29, wg, (u32)ngroups, C.ws_a1.as<uint8_t>());
         C.timer.mark("reduce_a1", s);
-        hipLaunchKernelGGL((k_wide_a2<BF>), dim3(2u << wg.lo, (unsigned)ngroups), dim3(64), 0, s, C.ws_a1.as<uint8_t>(), wg, C.ws_a2.as<uint8_t>());
+        hipLaunchKernelGGL((k_wide_a2<BF>), dim3(2u << wg.lo, (unsigned)ngroups), dim3(64), 0, s, C.ws_a1.as<uint8_t>(), b29, wg, C.ws_a2.as<uint8_t>());
         hipLaunchKernelGGL((k_marginals_q<BF>), dim3(32, 3, (unsigned)tail_groups), dim3(256), 0, s, C.ws_a2.as<uint8_t>(), mg, C.ws_seg.as<uint8_t>());
         hipLaunchKernelGGL((k_marginal_fin_q<BF>), dim3(3, (unsigned)tail_groups), dim3(128), 0, s, C.ws_seg.as<uint8_t>(), mg, (uint8_t*)C.pinned);
         direct_out = true;
@@ -2018,12 +2009,6 @@ int msm_finish(Context& C, MsmSlot& S, uint64_t* out_xy, uint8_t* out_inf) {
         KH_HIP(hipEventSynchronize(S.done));
     }
     S.busy = false;
-    if (getenv("KH_WIDE_TRACE") && S.wide_lo) {           // experiment: per-wave (start, end, hw id, xcc) records of k_acc_wide29 (KH_WIDE_DBG & 128)
-        const size_t nw = ((size_t)S.k << 19) / 64;
-        std::vector<unsigned long long> tr(4 * nw);
-        (void)hipMemcpy(tr.data(), S.ws_partial.p, tr.size() * 8, hipMemcpyDeviceToHost);
-        if (FILE* f = fopen(getenv("KH_WIDE_TRACE"), "wb")) { fwrite(tr.data(), 8, tr.size(), f); fclose(f); }
-    }
     static const bool fused_dbg = getenv("KH_FUSED_DEBUG") != nullptr;
     if (fused_dbg && S.ws_sync.p) {                       // phase timestamps of the last k_sort_fused on this slot (block 0)
         unsigned long long ts[12]; (void)hipMemcpy(ts, S.ws_sync.as<u32>() + 2 + 2 * FUSED_B, sizeof(ts), hipMemcpyDeviceToHost);

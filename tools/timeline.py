@@ -6,7 +6,7 @@ db = sqlite3.connect(sys.argv[1])
 cols = [r[1] for r in db.execute("pragma table_info(kernels)")]
 namecol = "name" if "name" in cols else [c for c in cols if "name" in c][0]
 rows = db.execute(f"select {namecol}, start, end from kernels order by start").fetchall()
-acc = [(s, e) for n, s, e in rows if "k_accumulate29" in n] or [(s, e) for n, s, e in rows if "k_accumulate" in n]
+acc = [(s, e) for n, s, e in rows if "k_accumulate29" in n or "k_acc_wide29" in n] or [(s, e) for n, s, e in rows if "k_accumulate" in n]
 acc = acc[4:-2]                                            # steady state
 t0, t1 = acc[0][0], acc[-1][1]
 ev = sorted([(s, 1) for s, e in acc] + [(e, -1) for s, e in acc])
@@ -24,7 +24,7 @@ for t, d in ev:
     last = t; cur += d
 others = {}
 for n, s, e in rows:
-    if "k_accumulate" in n: continue
+    if "k_accumulate" in n or "k_acc_wide29" in n: continue
     for gs, ge in gaps:
         o = min(e, ge) - max(s, gs)
         if o > 0: others[n.split("(")[0][-40:]] = others.get(n.split("(")[0][-40:], 0) + o
