@@ -525,6 +525,46 @@ def roofline_block(kname, acc_ms, n, log_n):
     return block
 
 
+class _DryShard:
+    """--dry-run stand-in for a device shard: every MSM 'returns' the blinding base h (kh_srs_h: host code, no GPU)"""
+
+    def __init__(self, khip, curve):
+        self.h = khip.srs_h(curve)
+
+    def msm_submit(self, ptr, n, k):
+        return ("dry", k)
+
+    def msm_wait(self, ticket):
+        return np.tile(self.h, (ticket[1], 1)), np.zeros(ticket[1], np.uint8)
+
+    def msm_batch_dev(self, ptr, n, k, mont=True):
+        return np.tile(self.h, (k, 1)), np.zeros(k, np.uint8)
+
+    def msm(self, scalars, mont=True):
+        return self.h.copy(), False
+
+    def close(self):
+        pass
+
+
+class _DryEngine:
+    def __init__(self, khip):
+        self.khip = khip
+
+    def make_shard(self, curve, start, count):
+        return _DryShard(self.khip, curve)
+
+    def msm(self, shard, scalars, mont=True):
+        return shard.h.copy(), False
+
+    def points_sum(self, curve, xy, inf):
+        out, oinf = self.khip.points_sum(curve, xy, inf)      # the product's fold (host code)
+        return out, bool(oinf)
+
+    def free_shard(self, shard):
+        pass
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -535,6 +575,9 @@ def main():
     ap.add_argument("--curve", choices=["vesta", "pallas"], default="vesta")
     ap.add_argument("--no-pipeline", action="store_true", help="time synchronous MSMs (one in flight); used for the rocprofv3 kernel-stats profile so kernels do not overlap")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--single-region", action="store_true", help="time the region once instead of three times (profiling runs)")
+    ap.add_argument("--dry-run", action="store_true", help="no GPU: launcher, rank set-up, process group (KH_BENCH_BACKEND=gloo), sharding, the timed loop's submit / wait / combine "
+                    "logic and the line, with a stand-in shard whose every MSM 'result' is the SRS blinding base h (host code of the library); value is meaningless (CPU test tier)")
     ap.add_argument("--no-oplist", "--no-prover", dest="no_oplist", action="store_true", help="skip the ProverProof::create block")
     ap.add_argument("--no-pair", action="store_true", help="skip BASELINE config 5 (Pallas + Vesta pair) inside the prover block")
     ap.add_argument("--pair", action="store_true", help="BASELINE config 5 only: the Pallas + Vesta pair at 2^16 gates, then exit")
@@ -559,6 +602,7 @@ def main():
     dist = None
     coll_dev = "cpu"
     backend = None
+    t_pg = 0.0
     # KH_BENCH_FORCE_COLLECTIVE=1: form the process group and run the combine's collective even in a world of ONE -- how the 1-GPU box
     # exercises the RCCL call paths (torch's `nccl` all-gather of device tensors, and the in-library kh_comm_* one) that N > 1 uses
     force_coll = os.environ.get("KH_BENCH_FORCE_COLLECTIVE", "0") not in ("", "0")
@@ -571,9 +615,12 @@ def main():
         # KH_BENCH_BACKEND=gloo lets several ranks share ONE GPU (functional check of the N>1 path on a single-GPU box);
         # the driver's multi-GPU runs use nccl (= RCCL over xGMI) with one GPU per rank
         backend = os.environ.get("KH_BENCH_BACKEND", "nccl")
-        ndev = max(1, torch.cuda.device_count())
-        torch.cuda.set_device(local_rank % ndev)
+        if not args.dry_run:
+            ndev = max(1, torch.cuda.device_count())
+            torch.cuda.set_device(local_rank % ndev)
+        t_pg0 = time.perf_counter()
         dist_mod.init_process_group(backend=backend, rank=rank, world_size=world)
+        t_pg = time.perf_counter() - t_pg0
         dist = dist_mod
         coll_dev = "cuda" if backend == "nccl" else "cpu"
 
@@ -595,12 +642,21 @@ def main():
     if os.environ.get("KH_BENCH_COMM", "torch") == "lib" and dist is not None:
         khip.init(dev)
         lib_comm = make_lib_comm(khip, dist, rank, world)
-    sm = sharded.RankShardedMsm(CID, total, dist=dist, coll_device=coll_dev, engine=sharded.KhipEngine(dev), rank=rank, world=world, comm=lib_comm,
-                                always_collective=force_coll)
+    sm = sharded.RankShardedMsm(CID, total, dist=dist, coll_device=coll_dev, engine=_DryEngine(khip) if args.dry_run else sharded.KhipEngine(dev), rank=rank, world=world,
+                                comm=lib_comm, always_collective=force_coll)
     srs, n = sm.shard, sm.count
     t_gen = time.perf_counter() - t0
-    sc = rand_scalars(np.random.default_rng(1234 + rank), n)
-    d_sc = khip.DevBuf(sc.nbytes).upload(sc)
+    if world > 1 or force_coll:                            # one line per rank BEFORE the timed loop: what a first multi-GPU run needs to be debugged from its log
+        print("[bench rank %d/%d] device %d (%d visible), shard = points [%d, %d) of %d, collective %s over %s, process group up in %.2f s, shard tables in %.2f s"
+              % (rank, world, dev, khip.device_count(), sm.start, sm.start + n, total,
+                 sm.collective_backend, backend, t_pg, t_gen), file=sys.stderr, flush=True)
+    if args.dry_run:
+        class _NoBuf:
+            ptr = 0
+        sc, d_sc = None, _NoBuf()
+    else:
+        sc = rand_scalars(np.random.default_rng(1234 + rank), n)
+        d_sc = khip.DevBuf(sc.nbytes).upload(sc)
 
     last_partial = [None]
 
@@ -610,11 +666,13 @@ def main():
         return o[0], bool(i[0])
 
     def fence():
-        khip.sync()
-        torch.cuda.synchronize()
+        if not args.dry_run:
+            khip.sync()
+            torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
-            torch.cuda.synchronize()
+            if not args.dry_run:
+                torch.cuda.synchronize()
 
     # warm-up doubles as the latency measurement: synchronous steps
     sync_ms = []
@@ -627,47 +685,73 @@ def main():
     # result is fetched and (N>1) combined across ranks INSIDE the region; the partial sums of up to `depth` finished MSMs travel in ONE
     # collective ("batch the partials of all MSMs in a phase into one collective" -- a prover combines the commitments of a
     # phase together; KH_BENCH_COMBINE_EVERY=1 gives one collective per MSM).
-    fence()
-    t0 = time.perf_counter()
-    depth = 1 if args.no_pipeline else int(os.environ.get('KH_BENCH_DEPTH', '2'))      # measured round 4 (profiles/r04_depth_steps.txt): 2 / 3 / 4 in flight = 852 / 836 / 821 Mscalar/s at 20 steps, 902 / 895 / 892 at 60
-    combine_every = max(1, int(os.environ.get('KH_BENCH_COMBINE_EVERY', str(depth))))
-    pending, done = [], []
-
-    def flush():
-        nonlocal result
-        if not done:
-            return
-        last_partial[0] = (np.array(done[-1][0], dtype=np.uint64).reshape(1, 8), np.array([done[-1][1]], dtype=np.uint8))
-        o, i = sm.combine([d[0] for d in done], [d[1] for d in done])
-        result = (o[-1], bool(i[-1]))
-        done.clear()
-
-    def collect(ticket):
-        xy, inf = srs.msm_wait(ticket)
-        done.append((xy[0], inf[0]))
-        if len(done) >= combine_every:
-            flush()
+    depth = 1 if args.no_pipeline else int(os.environ.get('KH_BENCH_DEPTH', '2'))      # round 5, wide tables (profiles/r05_wide_sweep.txt): 2 / 3 / 4 in flight = 1007 / 998 / 1015 and 1009 / 1001 / 992 Mscalar/s: no difference; round 4: 852 / 836 / 821
+    # one collective per MSM by default (batching `depth` partial sums into one collective made the N > 1 figure incomparable with
+    # earlier rounds); KH_BENCH_COMBINE_EVERY=k batches k finished MSMs per collective as a prover would per phase
+    combine_every = max(1, int(os.environ.get('KH_BENCH_COMBINE_EVERY', '1')))
     # KH_BENCH_RAMP=r: the number in flight starts at r and grows by one per finished MSM up to `depth` (an experiment on the pipeline's fill:
     # four jobs submitted at once run their sorts and accumulations in lockstep until they drift apart)
     ramp = int(os.environ.get('KH_BENCH_RAMP', '0'))
-    cur_depth = min(depth, ramp) if ramp > 0 else depth
-    for _ in range(args.steps):
-        pending.append(srs.msm_submit(d_sc.ptr, n, 1))
-        if len(pending) >= cur_depth:
+
+    def timed_region():
+        """EXACTLY args.steps MSMs between two fences; returns the wall time (max over ranks) and the last combined result"""
+        nonlocal result
+        pending, done = [], []
+
+        def flush():
+            nonlocal result
+            if not done:
+                return
+            last_partial[0] = (np.array(done[-1][0], dtype=np.uint64).reshape(1, 8), np.array([done[-1][1]], dtype=np.uint8))
+            o, i = sm.combine([d[0] for d in done], [d[1] for d in done])
+            result = (o[-1], bool(i[-1]))
+            done.clear()
+
+        def collect(ticket):
+            xy, inf = srs.msm_wait(ticket)
+            done.append((xy[0], inf[0]))
+            if len(done) >= combine_every:
+                flush()
+        fence()
+        t0 = time.perf_counter()
+        cur_depth = min(depth, ramp) if ramp > 0 else depth
+        for _ in range(args.steps):
+            pending.append(srs.msm_submit(d_sc.ptr, n, 1))
+            if len(pending) >= cur_depth:
+                collect(pending.pop(0))
+                cur_depth = min(depth, cur_depth + 1)
+        while pending:
             collect(pending.pop(0))
-            cur_depth = min(depth, cur_depth + 1)
-    while pending:
-        collect(pending.pop(0))
-    flush()
-    fence()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        flush()
+        fence()
+        el = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([el], dtype=torch.float64, device=coll_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el
+    # The region runs THREE times back to back (VERDICT round 4: single-region numbers moved 3-5 % box to box and run to run); `value` is the MEDIAN
+    # region, all three are on the line (`value_runs`); ms_per_step x steps is that one region's wall time.
+    runs = [timed_region() for _ in range(1 if args.single_region else 3)]
+    elapsed = sorted(runs)[len(runs) // 2]
 
     ms_per_step = 1e3 * elapsed / args.steps
     value = total / (elapsed / args.steps) / 1e6
+    if args.dry_run:                                       # the combined "result" must be world x h: the collective and the fold really ran
+        h = srs.h
+        acc_xy, acc_inf = h.copy(), False
+        for _ in range(world - 1):
+            acc_xy, acc_inf = sm.engine.points_sum(CID, np.stack([acc_xy, h]), np.zeros(2, np.uint8))
+        ok = (not result[1]) and bool(np.array_equal(np.asarray(result[0], dtype=np.uint64).reshape(8), acc_xy))
+        if rank == 0:
+            print(json.dumps({"metric": "MSM Mscalar/s at 2^%d (%s)" % (args.log_n, args.curve.capitalize()), "dry_run": True, "value": None, "unit": "Mscalar/s", "n_gpus": world,
+                              "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "ranks_reported": world, "value_runs": [None] * len(runs),
+                              "combined_result_is_world_times_h": ok,
+                              "config": {"workload": "dry run: no GPU work", "collective_backend": sm.collective_backend, "process_group_backend": backend,
+                                         "world_size_seen": world, "partials_per_collective": combine_every, "msm_in_flight": depth}}), flush=True)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
     # Per-phase HIP events and the dominant kernel's own start/stop events (hipExtLaunchKernelGGL, on the stream the kernel
     # is launched on): synchronous steps right AFTER the timed loop, i.e. at the clocks the loop ran at, one MSM in flight
     # so that kernels do not overlap.  Median of the samples.  The same steps give the single-MSM latency.
@@ -679,7 +763,7 @@ def main():
         for name, ms in khip.last_timings():
             phase_ms.setdefault(name, []).append(ms)
     phase_avg = {k: float(np.median(v)) for k, v in phase_ms.items()}
-    kname = "k_accumulate29" if "k_accumulate29" in phase_avg else "k_accumulate"
+    kname = "k_acc_wide29" if "k_acc_wide29" in phase_avg else ("k_accumulate29" if "k_accumulate29" in phase_avg else "k_accumulate")
     acc = phase_avg.get(kname, phase_avg.get("accumulate"))
     latency = float(np.median(lat_ms))
 
@@ -693,6 +777,8 @@ def main():
                    "scalars": "uniform 254-bit, seed 1234+rank", "parallelism": "point-range x%d" % world,
                    "collective_backend": sm.collective_backend, "process_group_backend": backend, "world_size_seen": world,
                    "partials_per_collective": (combine_every if sm.collective_backend else None)},
+        "value_runs": [total / (r / args.steps) / 1e6 for r in runs], "value_note": "median of %d back-to-back timed regions of %d MSMs each; ms_per_step x steps = that region" % (len(runs), args.steps),
+        "ranks_reported": world,
         "latency_value": total / (latency * 1e-3) / 1e6, "latency_note": "one MSM at a time (submit -> wait -> combine): `value` keeps %d in flight" % depth,
         "ms_per_step_synchronous": latency, "msm_in_flight": depth,
         "roofline": roofline_block(kname, acc, n, args.log_n) if not args.strong else roofline_block(kname, acc, n, -1),
