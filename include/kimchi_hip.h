@@ -505,8 +505,11 @@ int kh_lookup_sorted(const uint64_t *table, size_t lookup_rows, const uint64_t *
  *   count infinity flags; element sections give limbs = count x 4 and flags = NULL. */
 typedef struct kh_prover_index kh_prover_index_t;
 typedef struct kh_proof kh_proof_t;
-#define KH_PROVE_CHECK 1          /* assert the intermediate invariants (z ends at 1, zero remainders): costs three small downloads */
+#define KH_PROVE_CHECK 1          /* assert the intermediate invariants (z ends at 1, zero remainders) */
 #define KH_PROVE_ALL_GATES 2      /* evaluate the constraints of every always-present gate type, as the reference does */
+#define KH_PROVE_EAGER_CHECK 8    /* with KH_PROVE_CHECK: read every invariant back where it is produced and fail THERE, as the reference's ProverError returns do
+                                   * (prover.rs:913-917, permutation.rs:566-568, lookup/constraints.rs:325-331) -- one stream stall per check; by default the checks
+                                   * ride on the device and are read once after the opening (same errors, reported at the end of the call) */
 #define KH_PROVE_SHARED_CONTEXT 4 /* stay on the device's shared library context (default: a private one for the call, kh_private_context_begin) */
 #define KH_PROOF_W_COMM 0         /* 15 x num_chunks points */
 #define KH_PROOF_Z_COMM 1         /* num_chunks points */

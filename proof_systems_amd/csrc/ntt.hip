@@ -27,7 +27,6 @@
 
 #include "common.hpp"
 #include "field.cuh"
-#include "ntt29.cuh"
 #include "host_ec.hpp"
 #include "msm.hpp"
 
@@ -285,237 +284,6 @@ k_ntt_pass(PassArgs A) {
     for (int j = 0; j < 4; j++) if (st[j]) x[j].store(A.dst + 4 * dpos[j]);
 }
 
-// ------------------------------------------------------------------------------------ the same pass on nine 29-bit limbs (ntt29.cuh)
-// Identical tiling, digit handling and memory schedule; what changes is the arithmetic between the global load and the global store:
-// elements and stage twiddles live in the lazy form (nine u32 limb planes in LDS: 36 KiB of data + 4.5 KiB of twiddles per workgroup,
-// three workgroups per CU), every step keeps "normalised, < 2.1 p", the last step of a pass skips its unit twiddles and hands its
-// (un-reduced, < 11 p) outputs to the store, whose product with the WIRE-form inter-pass twiddle / 1/N / one is also the conversion back.
-template <class F>
-__device__ __forceinline__ Fe29<F> lds_get29(const u32* pl, u32 stride, u32 idx) {
-    Fe29<F> r;
-#pragma unroll
-    for (int k = 0; k < 9; k++) r.v[k] = pl[k * stride + idx];
-    return r;
-}
-template <class F>
-__device__ __forceinline__ void lds_put29(u32* pl, u32 stride, u32 idx, const Fe29<F>& a) {
-#pragma unroll
-    for (int k = 0; k < 9; k++) pl[k * stride + idx] = a.v[k];
-}
-template <class F, int THREADS>
-__global__ void __launch_bounds__(THREADS)
-k_ntt_pass29(PassArgs A) {
-    extern __shared__ u64 lds[];
-    const u32 R = 1u << A.log_R, T = 1u << A.log_T, RT = R * T;
-    u32* data = (u32*)lds;                 // 9 planes x RT
-    u32* twl = data + 9 * RT;              // 9 planes x (R/2) stage twiddles, lazy form
-    const u32 tid = threadIdx.x;
-    const u64 ntot = (u64)1 << A.log_ntot, n = (u64)1 << A.log_n;
-    const u32 log_B = A.log_L - A.log_R;
-    const u64 B = (u64)1 << log_B;
-
-    // ---- decode the tile (as k_ntt_pass)
-    u64 tile = blockIdx.x;
-    u64 batch_idx = 0, k0 = 0, sa = 0, bt = 0, rest = 0, dt = 0, Mrows = 1;
-    const bool row_mode = A.last != 0;
-    const bool flat_rows = row_mode && A.nd == 0;
-    if (!row_mode) {
-        u64 tiles_per_item = ntot >> (A.log_R + A.log_T);
-        batch_idx = tile / tiles_per_item; u64 r = tile % tiles_per_item;
-        u64 bt_count = B >> A.log_T;
-        bt = r % bt_count; r /= bt_count;
-        u64 subs = n >> A.log_L;
-        sa = r % subs; k0 = r / subs;
-    } else if (!flat_rows) {
-        u64 rows = ntot >> A.log_R;
-        u64 tiles_per_item = rows >> A.log_T;
-        batch_idx = tile / tiles_per_item; u64 r = tile % tiles_per_item;
-        Mrows = rows >> A.dig[0];
-        rest = r % Mrows; dt = r / Mrows;
-    }
-    const u64 total_rows_flat = A.batch;
-
-    // ---- stage twiddles w_R^i, i < R/2, into the lazy form (< 2 p)
-    for (u32 i = tid; i < R / 2; i += THREADS)
-        lds_put29<F>(twl, R / 2, i, lazy_from_wire<F>(Fe<F>::load(A.tw + 4 * ((u64)i << (A.log_ntot - A.log_R)))));
-
-    const u32 nq = RT >= 4 ? RT / 4 : 1;
-    const bool active = tid < nq;
-    int lh = (int)A.log_R - 1;
-    const bool odd = (A.log_R & 1) != 0;
-    u32 li[4];
-    bool ok01 = active, ok23 = active;
-    if (odd) {
-        const u32 h = 1u << lh;
-#pragma unroll
-        for (int p = 0; p < 2; p++) {
-            u32 pi = tid + p * nq;
-            u32 t = pi & (T - 1), pr = pi >> A.log_T;
-            u32 i = pr & (h - 1), grp = pr >> lh;
-            u32 lo = (grp << (lh + 1)) + i;
-            li[2 * p] = lo * T + t; li[2 * p + 1] = (lo + h) * T + t;
-        }
-        ok01 = active && tid < RT / 2;
-        ok23 = active && tid + nq < RT / 2;
-    } else {
-        const u32 q = 1u << (lh - 1);
-        u32 t = tid & (T - 1), pr = tid >> A.log_T;
-        u32 i = pr & (q - 1), grp = pr >> (lh - 1);
-        u32 lo = (grp << (lh + 1)) + i;
-#pragma unroll
-        for (int j = 0; j < 4; j++) li[j] = (lo + j * q) * T + t;
-    }
-
-    // ---- load (all four loads issued before anything waits), wire -> lazy
-    Fe29<F> x[4];
-    u64 ex[4];
-    {
-        Fe<F> xw[4];
-        u64 spos[4]; bool have[4];
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const u32 n1 = li[j] >> A.log_T, t = li[j] & (T - 1);
-            have[j] = j < 2 ? ok01 : ok23; ex[j] = 0;
-            if (!row_mode) {
-                u64 inner = sa * ((u64)1 << A.log_L) + (u64)n1 * B + bt * T + t;
-                spos[j] = A.src_is_coeffs ? (batch_idx * n + inner) : (batch_idx * ntot + k0 * n + inner);
-                ex[j] = inner * k0;
-            } else if (flat_rows) {
-                u64 g = tile * T + t;
-                have[j] = have[j] && g < total_rows_flat;
-                spos[j] = g * R + n1;
-            } else {
-                u64 a = (dt * T + t) * Mrows + rest;
-                u64 kk0 = A.log_blow ? (a >> (A.log_n - A.log_R)) : 0;
-                u64 inner = (A.log_blow ? (a & ((n >> A.log_R) - 1)) : a) * R + n1;
-                spos[j] = A.src_is_coeffs ? (batch_idx * n + inner) : (batch_idx * ntot + a * R + n1);
-                ex[j] = inner * kk0;
-            }
-            if (!have[j]) spos[j] = 0;
-        }
-#pragma unroll
-        for (int j = 0; j < 4; j++) xw[j] = Fe<F>::load(A.src + 4 * spos[j]);
-#pragma unroll
-        for (int j = 0; j < 4; j++) if (!have[j]) xw[j] = Fe<F>::zero();
-#pragma unroll
-        for (int j = 0; j < 4; j++) x[j] = lazy_from_wire<F>(xw[j]);
-    }
-    if (A.first && A.log_blow) {
-        Fe<F> w[4];
-#pragma unroll
-        for (int j = 0; j < 4; j++) w[j] = tw_get<F>(A.tw, A.log_ntot, ex[j]);
-#pragma unroll
-        for (int j = 0; j < 4; j++) if (ex[j]) x[j] = mul29<F>(x[j], pack29<F, 5>(w[j]));      // (< 2 p) (< 32 p) / 128 p + p < 1.5 p
-    }
-    __syncthreads();
-
-    // ---- the stages
-    if (odd) {
-        if (active) {
-            const u32 h = 1u << lh, sh = A.log_R - 1 - lh;
-#pragma unroll
-            for (int p = 0; p < 2; p++) {
-                u32 i = (li[2 * p] >> A.log_T) & (h - 1);
-                const Fe29<F> s = reduce29<F>(add29<F>(x[2 * p], x[2 * p + 1]));
-                const Fe29<F> d = mul29<F>(sub29<F, 4, 1>(x[2 * p], x[2 * p + 1]), lds_get29<F>(twl, R / 2, i << sh));
-                x[2 * p] = s; x[2 * p + 1] = d;
-            }
-        }
-        lh -= 1;
-    }
-    bool fresh = !odd;
-    while (lh >= 1) {
-        const u32 q = 1u << (lh - 1);
-        if (!fresh) {
-            if (active) {
-#pragma unroll
-                for (int j = 0; j < 4; j++) if (j < 2 ? ok01 : ok23) lds_put29<F>(data, RT, li[j], x[j]);
-            }
-            __syncthreads();
-            if (active) {
-                u32 t = tid & (T - 1), pr = tid >> A.log_T;
-                u32 i = pr & (q - 1), grp = pr >> (lh - 1);
-                u32 lo = (grp << (lh + 1)) + i;
-#pragma unroll
-                for (int j = 0; j < 4; j++) { li[j] = (lo + j * q) * T + t; x[j] = lds_get29<F>(data, RT, li[j]); }
-            }
-            ok01 = ok23 = active;
-        }
-        fresh = false;
-        if (active) {
-            const u32 i = (li[0] >> A.log_T) & (q - 1), sa_ = A.log_R - 1 - lh;
-            const Fe29<F> s0 = add29<F>(x[0], x[2]), s1 = add29<F>(x[1], x[3]);            // < 4.2 p, limbs < 2^30
-            Fe29<F> d0 = sub29<F, 4, 1>(x[0], x[2]), d1 = sub29<F, 4, 1>(x[1], x[3]);     // < 6.1 p, normalised
-            d1 = mul29<F>(d1, lds_get29<F>(twl, R / 2, (i + q) << sa_));                   // < 1.1 p
-            if (lh == 1) {
-                // q == 1: i == 0 for every quad, the three other twiddles are 1 -- this is the pass's last step, its outputs go straight to
-                // the store, which multiplies them anyway: no product, no reduction (values < 11 p, limbs < 2^31)
-                x[0] = add29<F>(s0, s1); x[1] = sub29<F, 6, 2>(s0, s1);
-                x[2] = add29<F>(d0, d1); x[3] = sub29<F, 4, 1>(d0, d1);
-            } else {
-                d0 = mul29<F>(d0, lds_get29<F>(twl, R / 2, i << sa_));
-                const Fe29<F> wb = lds_get29<F>(twl, R / 2, i << (sa_ + 1));
-                x[0] = reduce29<F>(add29<F>(s0, s1));
-                x[1] = mul29<F>(sub29<F, 6, 2>(s0, s1), wb);
-                x[2] = reduce29<F>(add29<F>(d0, d1));
-                x[3] = mul29<F>(sub29<F, 4, 1>(d0, d1), wb);
-            }
-        }
-        lh -= 2;
-    }
-
-    // ---- write out: the product with the wire-form factor (inter-pass twiddle -- entry 0 of the scaled table is 1/N itself --, 1/N, or one) is the conversion
-    u64 dpos[4]; bool st[4];
-    Fe<F> o[4];
-    if (!row_mode) {
-        u64 eo[4];
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const u32 n1 = li[j] >> A.log_T, t = li[j] & (T - 1);
-            const u32 k1 = bitrev(n1, A.log_R);
-            u64 b = bt * T + t;
-            eo[j] = (k1 && b) ? ((u64)k1 * b) << (A.log_ntot - A.log_L) : 0;
-            dpos[j] = batch_idx * ntot + k0 * n + sa * ((u64)1 << A.log_L) + (u64)k1 * B + b;
-            st[j] = j < 2 ? ok01 : ok23;
-        }
-        Fe<F> w[4];
-#pragma unroll
-        for (int j = 0; j < 4; j++) w[j] = tw_get<F>(A.tw_out, A.log_ntot, eo[j]);
-#pragma unroll
-        for (int j = 0; j < 4; j++) o[j] = wire_times<F>(x[j], w[j]);
-    } else {
-        Fe<F> fac = Fe<F>::one();
-        if (A.scale) {
-#pragma unroll
-            for (int i = 0; i < 8; i++) fac.v[i] = A.inv_n[i];
-        }
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const u32 n1 = li[j] >> A.log_T, t = li[j] & (T - 1);
-            const u32 k1 = bitrev(n1, A.log_R);
-            st[j] = j < 2 ? ok01 : ok23;
-            if (flat_rows) {
-                u64 g = tile * T + t;
-                st[j] = st[j] && g < total_rows_flat;
-                dpos[j] = g * R + k1;
-            } else {
-                u64 a = (dt * T + t) * Mrows + rest;
-                u64 rev = 0, wgt = 1;
-                u32 shift = A.log_ntot - A.log_R;
-                for (u32 d = 0; d < A.nd; d++) {
-                    shift -= A.dig[d];
-                    u64 digit = (a >> shift) & (((u64)1 << A.dig[d]) - 1);
-                    rev += digit * wgt; wgt <<= A.dig[d];
-                }
-                dpos[j] = batch_idx * ntot + rev + ((u64)k1 << (A.log_ntot - A.log_R));
-            }
-            o[j] = wire_times<F>(x[j], fac);
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < 4; j++) if (st[j]) o[j].store(A.dst + 4 * dpos[j]);
-}
-
 // tab[e] *= c  (the inverse transform's inter-pass twiddles carry the 1/N)
 template <class F>
 __global__ void k_scale_table(u64* dst, const u64* src, const u32* c8, u64 count) {
@@ -607,23 +375,11 @@ static std::vector<unsigned> split_passes(unsigned log_n) {
     return r;
 }
 
-// KH_NTT29=1: the passes on nine 29-bit limbs (k_ntt_pass29) instead of eight 32-bit limbs (k_ntt_pass).  MEASURED AND NOT THE DEFAULT (round 4,
-// profiles/r04_ntt29_*): bit-exact, but iNTT 2^16 x 19 0.122 against 0.115 ms and the 16-column extension 0.808 against 0.750 ms.  The product is
-// 166 instead of 254 instructions, yet an average launch issues 101.3 M VALU wave-instructions against 105.5 M: a butterfly has TWO linear
-// operations per product (the point addition of the MSM, where this arithmetic pays 30 %, has 0.7), each a nine-step carry sweep or a reduction
-// in the lazy form, and every element changes representation twice per pass (~130 instructions per change) because HBM and the twiddle tables
-// stay in wire form; the serial sweeps also run closer to the dependent-issue latency than the 32-bit kernel's carry chains (three workgroups
-// per CU: 41 KB of LDS).  Kept as the A/B switch the measurement was made with (tests/test_gpu_ntt29.py holds it bit-exact).
-static bool ntt29_on() { static const bool on = getenv("KH_NTT29") && atoi(getenv("KH_NTT29")) != 0; return on; }
+// (The passes on nine 29-bit limbs -- built, bit-exact and measured SLOWER in round 4: iNTT 2^16 x 19 0.122 against 0.115 ms, the 16-column extension
+// 0.808 against 0.750 ms, profiles/r04_ntt29_* -- live in tools/ntt29/ with their limb model; DESIGN.md section 4 has the analysis.)
 template <class F>
 static int launch_pass(Context& C, const PassArgs& A, u64 tiles) {
     static const size_t lds_pad = getenv("KH_NTT_LDS_PAD") ? (size_t)atol(getenv("KH_NTT_LDS_PAD")) : 0;      // (occupancy experiments: extra dynamic LDS per workgroup)
-    if (ntt29_on() && A.log_R >= 2) {
-        size_t lds29 = ((size_t)9 << (A.log_R + A.log_T)) * 4 + ((size_t)9 << (A.log_R - 1)) * 4 + lds_pad;
-        hipLaunchKernelGGL((k_ntt_pass29<F, NTT_THREADS>), dim3((unsigned)tiles), dim3(NTT_THREADS), lds29, C.stream, A);
-        KH_HIP(hipGetLastError());
-        return KH_OK;
-    }
     size_t lds = ((size_t)4 << (A.log_R + A.log_T)) * 8 + ((size_t)4 << (A.log_R ? A.log_R - 1 : 0)) * 8 + lds_pad;
     hipLaunchKernelGGL((k_ntt_pass<F, NTT_THREADS>), dim3((unsigned)tiles), dim3(NTT_THREADS), lds, C.stream, A);
     KH_HIP(hipGetLastError());

@@ -300,6 +300,8 @@ int kh_prove_full(kh_prover_index_t* ix, const uint64_t* witness, size_t rows, c
     if (!ix || !out || (!witness == !witness_dev)) { kh::set_error("kh_prove: give the witness either on the host or on the device"); return KH_E_INVALID; }
     if (n_prev && (!prev_chals || !prev_rounds || !prev_comm_xy || !prev_comm_inf || !prev_comm_chunks)) { kh::set_error("kh_prove_recursive: null previous-challenge argument"); return KH_E_INVALID; }
     const bool check = flags & KH_PROVE_CHECK, all_gates = flags & KH_PROVE_ALL_GATES;
+    static const bool eager_env = getenv("KH_PROVE_EAGER_CHECK") && atoi(getenv("KH_PROVE_EAGER_CHECK")) != 0;
+    const bool eager = check && ((flags & KH_PROVE_EAGER_CHECK) || eager_env);       // fail at the phase the reference fails at (a stream stall per check)
     const int fid = ix->fid, curve = ix->curve;
     const unsigned logn = ix->logn;
     const size_t n = ix->n, size = ix->size, nch = ix->nch, zk = ix->zk, nopt = ix->optional.size();
@@ -422,6 +424,17 @@ int kh_prove_full(kh_prover_index_t* ix, const uint64_t* witness, size_t rows, c
     KP(kh_dev_memset_zero(chk.p, 4 * 32));
     uint32_t* const chk_flags = (uint32_t*)chk.p;
     enum { CHK_AGG = 0, CHK_Z = 1, CHK_REM = 2, CHK_BND = 3 };
+    static const char* const chk_msg[4] = {"final value of the lookup aggregation is not 1 (lookup/constraints.rs:325-331)",
+                                           "final value of the permutation accumulator is not 1 (permutation.rs:566-568)",
+                                           "rest of division by vanishing polynomial (prover.rs:913-917): the witness does not satisfy the constraints",
+                                           "permutation boundary division rest (permutation.rs:301-321)"};
+    auto eager_check = [&](unsigned bit) -> int {      // KH_PROVE_EAGER_CHECK: the check queued just now, read back on the spot
+        if (!eager) return KH_OK;
+        uint32_t fl = 0;
+        int rc_ = kh_dev_download(&fl, chk.p, 4); if (rc_) return rc_;
+        if (fl & (1u << bit)) { kh::set_error("%s", chk_msg[bit]); return KH_E_INVALID; }
+        return KH_OK;
+    };
     auto set_const = [&](uint64_t* dst, const fe& val) {    // *dst = val, queued on the main stream (a one-row constant expression)
         const uint32_t prog[2] = {KH_TOK_CONST, 0};
         const uint64_t* c0[1] = {ev.p}; const size_t l0[1] = {n};
@@ -566,7 +579,7 @@ int kh_prove_full(kh_prover_index_t* ix, const uint64_t* witness, size_t rows, c
         const uint64_t* pc[2] = {num.p, den.p}; const size_t pl[2] = {n, n};
         KP(kh_expr_evaluations_dev(fid, prod, 3, pc, pl, 2, one.l, 1, n, 1, 1, 0, d_agg.p));
         KP(kh_field_scan_dev(fid, KH_SCAN_MUL, 0, d_agg.p, lookup_rows + 1));
-        if (check) KP(kh_check_equal_dev(d_agg.at(lookup_rows), 1, one.l, chk_flags, CHK_AGG));      // before the random rows overwrite anything: row lookup_rows = n - zk - 1 is not one of them
+        if (check) { KP(kh_check_equal_dev(d_agg.at(lookup_rows), 1, one.l, chk_flags, CHK_AGG)); KP(eager_check(CHK_AGG)); }      // before the random rows overwrite anything: row lookup_rows = n - zk - 1 is not one of them
         { const fe* rr = draw(zk); for (size_t j = 0; j < zk; j++) KP(set_const(d_agg.at(n - zk + j), rr[j])); }
         a_blind = draw(nch);
         std::vector<uint64_t> axy, acx; std::vector<uint8_t> ainf, aci;
@@ -603,7 +616,7 @@ int kh_prove_full(kh_prover_index_t* ix, const uint64_t* witness, size_t rows, c
         const uint64_t* pc[2] = {num.p, den.p}; const size_t pl[2] = {n, n};
         KP(kh_expr_evaluations_dev(fid, prod, 3, pc, pl, 2, one.l, 1, n, 1, 8, 0, zcol));
         KP(kh_field_scan_dev(fid, KH_SCAN_MUL, 0, zcol, n - zk + 1));
-        if (check) KP(kh_check_equal_dev(zcol + 4 * (n - zk), 1, one.l, chk_flags, CHK_Z));
+        if (check) { KP(kh_check_equal_dev(zcol + 4 * (n - zk), 1, one.l, chk_flags, CHK_Z)); KP(eager_check(CHK_Z)); }
         { const fe* rr = draw(2); KP(set_const(zcol + 4 * (n - zk + 1), rr[0])); KP(set_const(zcol + 4 * (n - zk + 2), rr[1])); }   // z's two random rows, in that order
         if (zk > 3) KP(kh_field_scan_dev(fid, KH_SCAN_MUL, 0, zcol + 4 * (n - zk + 2), zk - 2));
     }
@@ -709,7 +722,7 @@ int kh_prove_full(kh_prover_index_t* ix, const uint64_t* witness, size_t rows, c
     }
     Dev quot, rem; KP(quot.alloc(7 * NB)); KP(rem.alloc(NB));
     KP(kh_divide_by_vanishing_poly_dev(fid, t8.p, 8 * n, logn, quot.p, rem.p));
-    if (check) KP(kh_check_equal_dev(rem.p, n, nullptr, chk_flags, CHK_REM));
+    if (check) { KP(kh_check_equal_dev(rem.p, n, nullptr, chk_flags, CHK_REM)); KP(eager_check(CHK_REM)); }
     Dev zm1, b1, b2; KP(zm1.alloc(NB)); KP(b1.alloc(NB)); KP(b2.alloc(NB));
     {
         const uint64_t* ps[1] = {zc}; const size_t ls[1] = {n};
@@ -724,7 +737,7 @@ int kh_prove_full(kh_prover_index_t* ix, const uint64_t* witness, size_t rows, c
         uint64_t* dst[2] = {b1.p, b2.p};
         for (int i = 0; i < 2; i++) {                 // (z - 1) / (x - 1), (z - 1) / (x - omega^(n - zk)) (permutation.rs:301-321)
             KP(kh_divide_by_linear_async_dev(fid, zm1.p, n, pts2[i].l, dst[i], chk.at(1 + i)));
-            if (check) KP(kh_check_equal_dev(chk.at(1 + i), 1, nullptr, chk_flags, CHK_BND));
+            if (check) { KP(kh_check_equal_dev(chk.at(1 + i), 1, nullptr, chk_flags, CHK_BND)); KP(eager_check(CHK_BND)); }
         }
         const uint64_t* qs[3] = {quot.p, b1.p, b2.p}; const size_t ql[3] = {7 * n, n - 1, n - 1};
         fe sc[3] = {one, alphas[1], alphas[2]};
@@ -911,10 +924,7 @@ int kh_prove_full(kh_prover_index_t* ix, const uint64_t* witness, size_t rows, c
     if (check) {                                     // the deferred invariants, earliest first (the reference returns the first it meets)
         uint32_t fl = 0;
         KP(kh_dev_download(&fl, chk.p, 4));
-        KP_REQUIRE(!(fl & (1u << CHK_AGG)), "final value of the lookup aggregation is not 1 (lookup/constraints.rs:325-331)");
-        KP_REQUIRE(!(fl & (1u << CHK_Z)), "final value of the permutation accumulator is not 1 (permutation.rs:566-568)");
-        KP_REQUIRE(!(fl & (1u << CHK_REM)), "rest of division by vanishing polynomial (prover.rs:913-917): the witness does not satisfy the constraints");
-        KP_REQUIRE(!(fl & (1u << CHK_BND)), "permutation boundary division rest (permutation.rs:301-321)");
+        for (unsigned bit = 0; bit < 4; bit++) KP_REQUIRE(!(fl & (1u << bit)), "%s", chk_msg[bit]);
     }
     pr->set_points(KH_PROOF_LR, lr_xy.data(), lr_inf.data(), 2 * logs);
     pr->set_points(KH_PROOF_DELTA, delta, &dinf, 1);

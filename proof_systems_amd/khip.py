@@ -679,7 +679,7 @@ class Comm:
             _lib.kh_comm_free(self._h); self._h = C.c_void_p()
 
 
-PROVE_CHECK, PROVE_ALL_GATES, PROVE_SHARED_CONTEXT = 1, 2, 4
+PROVE_CHECK, PROVE_ALL_GATES, PROVE_SHARED_CONTEXT, PROVE_EAGER_CHECK = 1, 2, 4, 8
 PROOF_SECTIONS = {"w_comm": 0, "z_comm": 1, "t_comm": 2, "public_comm": 3, "evals": 4, "public_evals": 5, "ft_eval1": 6, "lr": 7, "delta": 8, "z1_z2": 9, "sg": 10,
                   "challenges": 11, "lookup_sorted_comm": 12, "lookup_aggreg_comm": 13, "lookup_runtime_comm": 14}
 LOOKUP_PATTERN_IDS = {"Xor": 0, "Lookup": 1, "RangeCheck": 2, "ForeignFieldMul": 3}

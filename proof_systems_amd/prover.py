@@ -348,10 +348,11 @@ def native_index(ix: "ProverIndex"):
 
 
 def create_proof_native(ix: "ProverIndex", witness, rng, timings=None, check: bool = True, witness_on_device=None, all_gates: bool = False, prev_challenges=(),
-                        runtime_tables=(), shared_context: bool = False):
+                        runtime_tables=(), shared_context: bool = False, eager_check: bool = False):
     """create_proof through kh_prove: the host loop in C++ (csrc/prover.cpp), same protocol, same draws from `rng` in the same order, same result
     dict.  rng=None: the library draws from the operating system's generator.  shared_context: stay on the device's one library context instead of
-    a private context (own streams, pools and pipeline slots) for the call."""
+    a private context (own streams, pools and pipeline slots) for the call.  eager_check: an unsatisfied witness fails at the phase the reference
+    fails at (KH_PROVE_EAGER_CHECK) instead of at the end of the call."""
     F, nch = ix.F, ix.num_chunks
     nx = native_index(ix)
     LI = getattr(ix, "lookup", None)
@@ -362,7 +363,7 @@ def create_proof_native(ix: "ProverIndex", witness, rng, timings=None, check: bo
         rtv = F.limbs_many([x for _i, d_ in runtime_tables for x in d_])
     on_host = witness_on_device is None
     rnd = F.limbs_many(F.rand_many(rng, nx.randomness_count(on_host))) if rng is not None else None
-    flags = (khip.PROVE_CHECK if check else 0) | (khip.PROVE_ALL_GATES if all_gates else 0) | (khip.PROVE_SHARED_CONTEXT if shared_context else 0)
+    flags = (khip.PROVE_CHECK if check else 0) | (khip.PROVE_ALL_GATES if all_gates else 0) | (khip.PROVE_SHARED_CONTEXT if shared_context else 0) | (khip.PROVE_EAGER_CHECK if eager_check else 0)
     sec, phases = nx.prove(witness=np.asarray(witness, dtype=np.uint64).reshape(COLUMNS, -1, 4) if on_host else None, witness_dev=witness_on_device,
                            randomness=rnd, flags=flags, prev=[(F.limbs_many(list(ch)), cm) for ch, cm in prev_challenges], runtime=rtv)
     comms = lambda key, k: [(sec[key][0][i * nch:(i + 1) * nch], sec[key][1][i * nch:(i + 1) * nch]) for i in range(k)]

@@ -119,6 +119,19 @@ def test_native_proof_over_the_gate_library(khip):
     bad = np.stack([F.limbs_many([wrows[r][c] for r in range(rows)]) for c in range(15)])
     with pytest.raises(khip.KhError, match="vanishing polynomial"):
         prover.create_proof_native(ix, bad, np.random.default_rng(12))
+    # KH_PROVE_EAGER_CHECK: the same error, raised at the quotient phase (prover.rs:913-917) instead of after the opening; a good witness is unaffected
+    import time
+    t0 = time.perf_counter()
+    with pytest.raises(khip.KhError, match="vanishing polynomial"):
+        prover.create_proof_native(ix, bad, np.random.default_rng(12), eager_check=True)
+    t_eager = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    with pytest.raises(khip.KhError, match="vanishing polynomial"):
+        prover.create_proof_native(ix, bad, np.random.default_rng(12))
+    t_deferred = time.perf_counter() - t0
+    assert t_eager < t_deferred, (t_eager, t_deferred)             # no opening behind the failed check
+    eproof = prover.create_proof_native(ix, wit, np.random.default_rng(12), eager_check=True)
+    assert V.device_views(ix, eproof)[2] == V.device_views(ix, nproof)[2]
     ix.free()
 
 
