@@ -275,31 +275,54 @@ def prover_block(khip, srs20, check_with_oracle=True, log_n=16, reps=5):
         best_c = dt if best_c is None else min(best_c, dt)
     for x in th:
         x.join()
+    def threaded(fs, reps=4):                                           # the callables at once, one (pre-started) thread each; best of the repeats after a warm-up
+        bar2 = threading.Barrier(len(fs) + 1); done2 = threading.Barrier(len(fs) + 1)
+
+        def w(f):
+            for _ in range(reps):
+                bar2.wait(); f(); done2.wait()
+        th2 = [threading.Thread(target=w, args=(f,)) for f in fs]
+        for x in th2:
+            x.start()
+        ts = []
+        for _ in range(reps):
+            bar2.wait(); t0 = time.perf_counter(); done2.wait(); ts.append(time.perf_counter() - t0)
+        for x in th2:
+            x.join()
+        return min(ts[1:])
+    # interpolate: Evaluations::interpolate transforms the caller's Vec in place (ifft_in_place); one column per call, from ONE thread and from 15 at once
+    # (prover.rs:370-381 is a par_iter over the 15 columns)
+    icol = [c.copy() for c in cols]
     best_n = None
     for _ in range(3):
         t0 = time.perf_counter()
         for i in range(15):
-            khip.ntt(khip.FP, cols[i], log_n, inverse=True)
+            khip.ntt(khip.FP, icol[i], log_n, inverse=True, in_place=True)
         dt = time.perf_counter() - t0
         best_n = dt if best_n is None else min(best_n, dt)
+    best_n_thr = threaded([(lambda i=i: khip.ntt(khip.FP, icol[i], log_n, inverse=True, in_place=True)) for i in range(15)])
     coeffs16 = np.ascontiguousarray(padded[:, :, :].copy()); coeffs16 = np.concatenate([coeffs16, coeffs16[:1]])     # 16 columns of n coefficients (15 w + z)
+    outs16 = [np.ones((1, 8 << log_n, 4), np.uint64) for _ in range(16)]                                            # the destination Vecs exist (no first-touch faults in the timing)
     best_l = None
     for _ in range(3):
         t0 = time.perf_counter()
         for i in range(16):
-            khip.lde(khip.FP, coeffs16[i:i + 1], log_n, 3)                   # evaluate_over_domain_by_ref(d8) of one column: n up, 8n down
+            khip.lde(khip.FP, coeffs16[i:i + 1], log_n, 3, out=outs16[i])    # evaluate_over_domain_by_ref(d8) of one column: n up, 8n down
         dt = time.perf_counter() - t0
         best_l = dt if best_l is None else min(best_l, dt)
+    best_l_thr = threaded([(lambda i=i: khip.lde(khip.FP, coeffs16[i:i + 1], log_n, 3, out=outs16[i])) for i in range(16)])       # constraints.rs:488-494: a par_iter over w and z
     t0 = time.perf_counter()
     batch = srs16.msm_batch(padded, basis=log_n)
     t_batch = time.perf_counter() - t0
     same = all(np.array_equal(res[i][0][0], batch[0][i]) for i in range(15))
     out["dropin"] = {"commit_15_threads_host_buffers_s": best_c, "commit_one_batched_call_host_buffers_s": t_batch, "threads_match_batch": bool(same),
-                     "interpolate_15_columns_one_call_each_host_buffers_s": best_n,
-                     "extend_16_columns_2^16_to_2^19_one_call_each_host_buffers_s": best_l,
-                     "swap_crates_only_total_s": best_c + best_n + best_l,
+                     "interpolate_15_columns_15_threads_host_buffers_s": best_n_thr, "interpolate_15_columns_one_thread_host_buffers_s": best_n,
+                     "extend_16_columns_2^16_to_2^19_16_threads_host_buffers_s": best_l_thr, "extend_16_columns_2^16_to_2^19_one_thread_host_buffers_s": best_l,
+                     "swap_crates_only_total_s": best_c + best_n_thr + best_l_thr, "swap_crates_only_total_one_thread_transforms_s": best_c + best_n + best_l,
                      "note": "what a Rust prover gets by only swapping in GpuSrs / the ark-poly patch (rust/ark-poly-patch: interpolate -> kh_ntt, evaluate_over_domain_by_ref -> kh_lde, "
-                             "the zero padding never crosses PCIe); witness commitments + interpolations + 8x extensions of one proof; PCIe-bound (pageable host memory)"}
+                             "the zero padding never crosses PCIe); witness commitments + interpolations + 8x extensions of one proof, called as the reference calls them (15 / 15 / 16 "
+                             "rayon workers at once; round 5: uploads and downloads run on the callers' own copy streams outside the library lock) and, for comparison, the transforms "
+                             "from one thread; PCIe-bound (pageable host memory)"}
     if check_with_oracle:
         out["proof_accepted_by_oracle_verifier"] = bool(oracle_verifies(khip, ix, proof))
         out["python_loop"]["proof_accepted_by_oracle_verifier"] = out["proof_accepted_by_oracle_verifier"]

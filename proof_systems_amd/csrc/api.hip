@@ -1842,22 +1842,73 @@ int kh_coset_ntt_dev(int field, const uint64_t* coeffs_dev, unsigned log2_n, con
     if (rc == KH_OK && hipEventRecord(C.order_ev, C.stream) == hipSuccess) C.main_dirty = true;
     return rc;
 }
+// Host-pointer transforms (what the ark-poly patch calls: interpolate -> kh_ntt, evaluate_over_domain_by_ref -> kh_lde).  The reference calls them from
+// 15 / 16 rayon workers at once (prover.rs:370-381, constraints.rs:488-494), one column each, and each call moves 2 + 2 (or 2 + 16) MB over PCIe around
+// ~10-50 us of kernels.  Until round 4 a call held the library lock across upload, transform, download and a stream synchronisation on the one shared
+// workspace: sixteen callers ran strictly one after the other at ~27 GB/s (profiles/r04_pcie_inclusive.txt).  Now a call owns pool buffers, moves its data
+// on the calling thread's own copy stream WITHOUT the lock (uploads, downloads and their pageable-memory staging of different callers overlap, and PCIe
+// runs both directions at once), and takes the lock only to queue its kernels on the main stream, ordered by events.  A batched call is cut into column
+// groups that go through the same three stages, so that group i's download runs under group i + 1's transform.
+}  // extern "C"
+namespace {
+struct HostXferEvents {
+    hipEvent_t up[KH_MAX_DEVICES] = {nullptr}, done[KH_MAX_DEVICES] = {nullptr};
+    ~HostXferEvents() { for (int d = 0; d < KH_MAX_DEVICES; d++) { if (up[d]) (void)hipEventDestroy(up[d]); if (done[d]) (void)hipEventDestroy(done[d]); } }
+};
+struct PoolBuf {                                           // a pooled device block for the duration of a call
+    void* p = nullptr;
+    ~PoolBuf() { if (p) (void)kh_dev_free(p); }
+};
+// in -> [upload] -> din -> run(din, dout, columns) -> dout -> [download] -> out, `batch` columns of in_col / out_col bytes, in groups
+template <class Run>
+int host_transform(const uint64_t* in, size_t in_col, uint64_t* out, size_t out_col, size_t batch, bool in_place, Run run) {
+    static thread_local HostXferEvents ev;
+    Context& C = ctx();
+    const int d = C.device >= 0 && C.device < KH_MAX_DEVICES ? C.device : 0;
+    hipStream_t cs = thread_copy_stream(); if (!cs) return KH_E_DEVICE;
+    if (!ev.up[d]) { KH_HIP(hipEventCreateWithFlags(&ev.up[d], hipEventDisableTiming)); KH_HIP(hipEventCreateWithFlags(&ev.done[d], hipEventDisableTiming)); }
+    // column groups: at most four, at least ~4 MB of output each (a group costs three stream hand-overs)
+    size_t groups = batch < 4 ? batch : 4;
+    while (groups > 1 && (batch / groups) * out_col < ((size_t)4 << 20)) groups--;
+    PoolBuf din, dout;
+    int rc;
+    if ((rc = kh_dev_alloc(&din.p, batch * in_col))) return rc;
+    if (!in_place && (rc = kh_dev_alloc(&dout.p, batch * out_col))) return rc;
+    char* const di = (char*)din.p; char* const dst_dev = in_place ? di : (char*)dout.p;
+    size_t c0 = 0;
+    for (size_t g = 0; g < groups; g++) {
+        const size_t c1 = batch * (g + 1) / groups, cols = c1 - c0;
+        KH_HIP(hipMemcpyAsync(di + c0 * in_col, (const char*)in + c0 * in_col, cols * in_col, hipMemcpyHostToDevice, cs));
+        KH_HIP(hipEventRecord(ev.up[d], cs));
+        {
+            std::lock_guard<std::mutex> lk(C.mu);
+            KH_HIP(hipStreamWaitEvent(C.stream, ev.up[d], 0));
+            if ((rc = run(C, (uint64_t*)(di + c0 * in_col), (uint64_t*)(dst_dev + c0 * out_col), cols))) return rc;
+            KH_HIP(hipEventRecord(ev.done[d], C.stream));
+            C.mark_async();
+        }
+        KH_HIP(hipStreamWaitEvent(cs, ev.done[d], 0));
+        KH_HIP(hipMemcpyAsync((char*)out + c0 * out_col, dst_dev + c0 * out_col, cols * out_col, hipMemcpyDeviceToHost, cs));
+        c0 = c1;
+    }
+    KH_HIP(hipStreamSynchronize(cs));                     // everything this call queued anywhere has finished: the pool blocks may go back
+    {
+        std::lock_guard<std::mutex> lk(C.mu);
+        collect_timings(C, C.timer);                       // (the phases of the LAST transform queued on this context: exact for a lone caller)
+    }
+    return KH_OK;
+}
+}  // namespace
+extern "C" {
 int kh_ntt(int field, uint64_t* data, unsigned log2_n, int inverse, size_t batch) {
     KH_REQUIRE(field == KH_FIELD_FP || field == KH_FIELD_FQ, "unknown field id %d", field);
     KH_REQUIRE(log2_n <= 28, "log2_n = %u too large", log2_n);
     KH_REQUIRE(data || batch == 0, "null data");
     int rc = ensure_init(); if (rc) return rc;
     if (batch == 0) return KH_OK;
-    Context& C = ctx();
-    std::lock_guard<std::mutex> lk(C.mu);
-    size_t bytes = (batch << log2_n) * 32;
-    if ((rc = C.ws_ntt_a.reserve(bytes))) return rc;
-    KH_HIP(hipMemcpyAsync(C.ws_ntt_a.p, data, bytes, hipMemcpyHostToDevice, C.stream));
-    if ((rc = ntt_run(C, field, C.ws_ntt_a.as<uint64_t>(), log2_n, inverse, batch))) return rc;
-    KH_HIP(hipMemcpyAsync(data, C.ws_ntt_a.p, bytes, hipMemcpyDeviceToHost, C.stream));
-    KH_HIP(hipStreamSynchronize(C.stream));
-    collect_timings(C, C.timer);
-    return KH_OK;
+    const size_t col = ((size_t)1 << log2_n) * 32;
+    return host_transform(data, col, data, col, batch, true,
+                          [&](Context& C, uint64_t* din, uint64_t*, size_t cols) { return ntt_run(C, field, din, log2_n, inverse, cols); });
 }
 int kh_lde(int field, const uint64_t* coeffs, unsigned log2_n, unsigned log2_blowup, uint64_t* out, size_t batch) {
     KH_REQUIRE(field == KH_FIELD_FP || field == KH_FIELD_FQ, "unknown field id %d", field);
@@ -1865,17 +1916,9 @@ int kh_lde(int field, const uint64_t* coeffs, unsigned log2_n, unsigned log2_blo
     KH_REQUIRE((coeffs && out) || batch == 0, "null data");
     int rc = ensure_init(); if (rc) return rc;
     if (batch == 0) return KH_OK;
-    Context& C = ctx();
-    std::lock_guard<std::mutex> lk(C.mu);
-    size_t in_bytes = (batch << log2_n) * 32, out_bytes = in_bytes << log2_blowup;
-    if ((rc = C.ws_ntt_a.reserve(in_bytes))) return rc;
-    if ((rc = C.ws_ntt_b.reserve(out_bytes))) return rc;
-    KH_HIP(hipMemcpyAsync(C.ws_ntt_a.p, coeffs, in_bytes, hipMemcpyHostToDevice, C.stream));
-    if ((rc = lde_run(C, field, C.ws_ntt_a.as<uint64_t>(), log2_n, log2_blowup, C.ws_ntt_b.as<uint64_t>(), batch))) return rc;
-    KH_HIP(hipMemcpyAsync(out, C.ws_ntt_b.p, out_bytes, hipMemcpyDeviceToHost, C.stream));
-    KH_HIP(hipStreamSynchronize(C.stream));
-    collect_timings(C, C.timer);
-    return KH_OK;
+    const size_t in_col = ((size_t)1 << log2_n) * 32, out_col = in_col << log2_blowup;
+    return host_transform(coeffs, in_col, out, out_col, batch, false,
+                          [&](Context& C, uint64_t* din, uint64_t* dout, size_t cols) { return lde_run(C, field, din, log2_n, log2_blowup, dout, cols); });
 }
 
 // ---------------------------------------------------------------------------------- device memory helpers

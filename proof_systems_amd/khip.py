@@ -398,15 +398,22 @@ def msm_points_batch(curve: int, xy, scalars, inf=None, mont: bool = True):
     return out, oinf
 
 
-def ntt(field: int, data, log2_n: int, inverse: bool = False):
-    d = np.array(data, dtype=np.uint64, copy=True).reshape(-1, 1 << log2_n, 4)
+def ntt(field: int, data, log2_n: int, inverse: bool = False, in_place: bool = False):
+    """in_place: transform `data` itself (a C-contiguous uint64 array) -- what ark-poly's ifft_in_place does to the caller's Vec"""
+    if in_place:
+        assert data.dtype == np.uint64 and data.flags["C_CONTIGUOUS"]
+        d = data.reshape(-1, 1 << log2_n, 4)
+    else:
+        d = np.array(data, dtype=np.uint64, copy=True).reshape(-1, 1 << log2_n, 4)
     _check(_lib.kh_ntt(field, _p64(d), log2_n, int(inverse), d.shape[0]))
     return d
 
 
-def lde(field: int, coeffs, log2_n: int, log2_blowup: int):
+def lde(field: int, coeffs, log2_n: int, log2_blowup: int, out=None):
     c = _c64(coeffs, (-1, 1 << log2_n, 4))
-    out = np.zeros((c.shape[0], 1 << (log2_n + log2_blowup), 4), dtype=np.uint64)
+    if out is None:
+        out = np.zeros((c.shape[0], 1 << (log2_n + log2_blowup), 4), dtype=np.uint64)
+    assert out.dtype == np.uint64 and out.flags["C_CONTIGUOUS"] and out.size == c.shape[0] * (4 << (log2_n + log2_blowup))
     _check(_lib.kh_lde(field, _p64(c), log2_n, log2_blowup, _p64(out), c.shape[0]))
     return out
 
