@@ -37,7 +37,11 @@ namespace kh {
 // count is a small multiple of the CU count (19 columns of 2^16: 0.131 -> 0.116 ms) and ties elsewhere (2^22: 0.512 vs 0.509 ms).
 static constexpr int NTT_THREADS = 256;
 static constexpr int NTT_LOG_TILE = 10;                 // R*T elements per workgroup = 4 per thread
-static constexpr int NTT_MAX_LOGR = 8;
+// Largest sub-transform of a pass, 2^9 (KH_NTT_MAX_LOGR, 4..10).  Round 5 measured the two-pass splits the kernel had never been given: 2^18 = 512 x 512
+// instead of 64^3 is 9 % faster (0.0503 -> 0.0457 ms); 2^19 = 1024 x 512 (one column per tile in the 1024-point pass: 32-byte accesses at a 16 KB
+// stride) does NOT pay -- iNTT 2^19 0.0792 -> 0.0781 ms, the 16-column extension 2^16 -> 2^19 0.731 -> 0.7405 ms against the 0.72 the experiment was
+// to beat: the inter-pass twiddle product it saves is cancelled by the lost coalescing -- so 2^19 stays 128 x 64 x 64 (gpurun_out / profiles: r05_ntt_split.txt).
+static constexpr int NTT_MAX_LOGR = 9;
 
 struct PassArgs {
     const u64* src; u64* dst; const u64* tw; const u64* tw_out;
@@ -369,7 +373,8 @@ static int get_twiddles(Context& C, int field, unsigned logn, int inverse, TwEnt
 static std::vector<unsigned> split_passes(unsigned log_n) {
     std::vector<unsigned> r;
     if (log_n == 0) return r;
-    unsigned P = (log_n + NTT_MAX_LOGR - 1) / NTT_MAX_LOGR;
+    static const unsigned max_logr = getenv("KH_NTT_MAX_LOGR") ? (unsigned)std::min(10, std::max(4, atoi(getenv("KH_NTT_MAX_LOGR")))) : (unsigned)NTT_MAX_LOGR;
+    unsigned P = (log_n + max_logr - 1) / max_logr;
     unsigned base = log_n / P, extra = log_n % P;
     for (unsigned i = 0; i < P; i++) r.push_back(base + (i < extra ? 1 : 0));
     return r;
