@@ -857,7 +857,7 @@ k_accumulate(const u32* __restrict__ entries, const u32* __restrict__ off, const
 // The same task in the lazy 29-bit-limb arithmetic of field29.cuh (186 instead of 254 instructions per product, no
 // carry chains in the subtractions).  Its values are not canonical, so it cannot decide the exceptional cases of the
 // group law; it only notices that one cannot be excluded (probability ~2^-25 per addition on random inputs), abandons
-// the task and flags it in handed[]: k_accumulate then redoes exactly those tasks with the exact formulas.  Finished
+// the lazy state and redoes the task on the spot with the exact formulas of curve.cuh.  Finished
 // tasks are converted to the canonical wire form, so everything downstream is unchanged and the result stays bit-exact.
 // Occupancy is CAPPED at 4 waves per SIMD although 92 VGPRs would allow 5: the sort kernels of the next job (k_hist / k_scatter:
 // 1024-thread blocks = 4 waves per SIMD, 128 KB of LDS) must find four free wave slots on every CU to run underneath this kernel;
@@ -901,9 +901,23 @@ k_accumulate29(const u32* __restrict__ entries, const u32* __restrict__ off, con
         ok = madd29<BF>(acc, pack29<BF, 5>(p.x), pack29<BF, 5>(p.y));
         if (!ok) break;
     }
-    if (!ok) { handed[1 + atomicAdd(&handed[0], 1u)] = (u32)t0; return; }      // the exact kernel redoes this task
     Xyzz<BF> r;
-    r.x = from29<BF>(acc.x); r.y = from29<BF>(acc.y); r.zz = from29<BF>(acc.zz); r.zzz = from29<BF>(acc.zzz);
+    if (__builtin_expect(!ok, 0)) {
+        // An exceptional case could not be excluded (~2^-25 per addition on random inputs; every time on degenerate bases): THIS lane redoes its task
+        // with the exact formulas while the rest of its wave waits.  (Until round 5 such tasks went to a list for a second kernel: an empty launch
+        // in every MSM -- 5 us in each of the 32 MSMs of an opening.)
+        e = entries[start];
+        p = Aff<BF>::load(pts + (size_t)(e & 0x7fffffffu) * 64);
+        if (e >> 31) p.y = neg<BF>(p.y);
+        r = Xyzz<BF>::from_affine(p);
+        for (u32 k = start + 1; k < end; k++) {
+            e = entries[k];
+            p = Aff<BF>::load(pts + (size_t)(e & 0x7fffffffu) * 64);
+            r = madd<BF>(r, p, (e >> 31) != 0);
+        }
+    } else {
+        r.x = from29<BF>(acc.x); r.y = from29<BF>(acc.y); r.zz = from29<BF>(acc.zz); r.zzz = from29<BF>(acc.zzz);
+    }
     r.store(partial + t * 128);
 }
 // ------------------------------------------------------------------------------------ 5w accumulate, wide windows
@@ -942,25 +956,34 @@ __device__ __forceinline__ void wide_task29(u32 key, u32 jt, const u32* __restri
         ok = madd29<BF>(acc, pack29<BF, 5>(p.x), pack29<BF, 5>(p.y));
         if (!ok) break;
     }
+    // (the exact redo stays a separate kernel here: inlined as in k_accumulate29 it raised this kernel from 92 to 127 VGPRs, and the sort kernels of the
+    //  neighbouring job no longer fitted beside three resident blocks: 1020 -> 985 Mscalar/s pipelined, profiles/r05_ab_inline_exact.txt)
     if (!ok) { const u32 slot = atomicAdd(&handed[0], 1u); handed[2 + 2 * slot] = key; handed[3 + 2 * slot] = jt; return; }
     if (nt == 1) { store_b29<BF>(buckets29 + (size_t)wide_true_bucket(key, low) * B29_BYTES, acc); return; }
     Xyzz<BF> r;
     r.x = from29<BF>(acc.x); r.y = from29<BF>(acc.y); r.zz = from29<BF>(acc.zz); r.zzz = from29<BF>(acc.zzz);
     r.store(partial + (size_t)(t0 + jt) * 128);
 }
-// Blocks [0, nkeys / 256): thread per bucket.  The WIDE_XB blocks behind them walk xlist ([0] = number of extra chunks, then (key, chunk) pairs
-// from word 2 on; empty for unskewed scalars).  Launched with enough dynamic LDS to hold the kernel to THREE blocks per CU (it is VALU-bound from
+// Thread per bucket.  Launched with enough dynamic LDS to hold the kernel to THREE blocks per CU (it is VALU-bound from
 // three waves per SIMD on; the fourth only keeps the neighbouring jobs' sort and reduction kernels off the CU: 886-930 -> 940-1000 Mscalar/s pipelined).
 static constexpr u32 WIDE_XB = 32;
 template <class BF>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(112), amdgpu_waves_per_eu(4, 4)))
 k_acc_wide29(const u32* __restrict__ entries, const u32* __restrict__ off, const u32* __restrict__ toff, const u32* __restrict__ order, u32 nkeys,
-             const uint8_t* __restrict__ pts, uint8_t* __restrict__ partial, uint8_t* __restrict__ buckets29, u32 low, u32* __restrict__ handed,
-             const u32* __restrict__ xlist) {
+             const uint8_t* __restrict__ pts, uint8_t* __restrict__ partial, uint8_t* __restrict__ buckets29, u32 low, u32* __restrict__ handed) {
     const u32 g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g < nkeys) { wide_task29<BF>(order[g], 0u, entries, off, toff, pts, partial, buckets29, low, handed); return; }
+    if (g < nkeys) wide_task29<BF>(order[g], 0u, entries, off, toff, pts, partial, buckets29, low, handed);
+}
+// the extra chunks of split buckets: a small persistent grid over xlist ([0] = their number, then (key, chunk) pairs from word 2 on; empty for unskewed
+// scalars).  A kernel of its own: walked by blocks of k_acc_wide29 the loop cost that kernel 13 VGPRs (92 -> 105), and with three resident blocks
+// per CU the neighbouring job's 1024-thread sort kernels (4 x 56 VGPRs per SIMD) no longer fitted beside them.
+template <class BF>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(112)))
+k_acc_wide_extra(const u32* __restrict__ entries, const u32* __restrict__ off, const u32* __restrict__ toff, const u32* __restrict__ xlist,
+                 const uint8_t* __restrict__ pts, uint8_t* __restrict__ partial, uint8_t* __restrict__ buckets29, u32 low, u32* __restrict__ handed) {
+    KH_HIGH_PRIO();
     const u32 count = xlist[0];
-    for (u32 it = g - nkeys; it < count; it += WIDE_XB * 256u)
+    for (u32 it = blockIdx.x * blockDim.x + threadIdx.x; it < count; it += gridDim.x * blockDim.x)
         wide_task29<BF>(xlist[2 + 2 * it], xlist[3 + 2 * it], entries, off, toff, pts, partial, buckets29, low, handed);
 }
 template <class BF>
@@ -1855,15 +1878,17 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
     const dim3 agrid((unsigned)((max_tasks + 255) / 256));
     uint8_t* const b29 = wide ? C.ws_b29.as<uint8_t>() : nullptr;
     if (wide) {                                            // thread per bucket in pass B's interleaved length order (+ the listed extra chunks), then the exact redos
-        const dim3 wgrid((unsigned)(nkeys / 256 + WIDE_XB));
+        const dim3 wgrid((unsigned)(nkeys / 256));
         auto kern = k_acc_wide29<BF>;
         if (C.timer.enabled && C.timer.created && !gcap.active) {
             hipExtLaunchKernelGGL(kern, wgrid, dim3(256), wide_acc_lds, s, C.timer.k0, C.timer.k1, 0, C.ws_entries.as<u32>(), C.ws_off.as<u32>(), C.ws_toff.as<u32>(), order, (u32)nkeys,
-                                  (const uint8_t*)tab_pts, C.ws_partial.as<uint8_t>(), b29, part_low, C.ws_handed.as<u32>(), C.ws_xlist.as<u32>());
+                                  (const uint8_t*)tab_pts, C.ws_partial.as<uint8_t>(), b29, part_low, C.ws_handed.as<u32>());
             C.timer.kname = "k_acc_wide29";
         } else
         hipLaunchKernelGGL(kern, wgrid, dim3(256), wide_acc_lds, s, C.ws_entries.as<u32>(), C.ws_off.as<u32>(), C.ws_toff.as<u32>(), order, (u32)nkeys,
-                           (const uint8_t*)tab_pts, C.ws_partial.as<uint8_t>(), b29, part_low, C.ws_handed.as<u32>(), C.ws_xlist.as<u32>());
+                           (const uint8_t*)tab_pts, C.ws_partial.as<uint8_t>(), b29, part_low, C.ws_handed.as<u32>());
+        hipLaunchKernelGGL((k_acc_wide_extra<BF>), dim3(WIDE_XB), dim3(256), 0, s, C.ws_entries.as<u32>(), C.ws_off.as<u32>(), C.ws_toff.as<u32>(), C.ws_xlist.as<u32>(),
+                           (const uint8_t*)tab_pts, C.ws_partial.as<uint8_t>(), b29, part_low, C.ws_handed.as<u32>());
         hipLaunchKernelGGL((k_acc_wide_exact<BF>), dim3(32), dim3(256), 0, s, C.ws_entries.as<u32>(), C.ws_off.as<u32>(), C.ws_toff.as<u32>(), C.ws_handed.as<u32>(),
                            (const uint8_t*)tab_pts, C.ws_partial.as<uint8_t>(), b29, part_low);
     } else
@@ -1878,9 +1903,6 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
         hipLaunchKernelGGL(kern, agrid, dim3(256), 0, s,
                            C.ws_entries.as<u32>(), C.ws_off.as<u32>(), C.ws_toff.as<u32>(), roff, order, nkeys,
                            (const uint8_t*)tab_pts, C.ws_partial.as<uint8_t>(), C.ws_handed.as<u32>(), abort_dev);
-        hipLaunchKernelGGL((k_accumulate<BF>), dim3(128), dim3(256), 0, s,
-                           C.ws_entries.as<u32>(), C.ws_off.as<u32>(), C.ws_toff.as<u32>(), roff, order, nkeys,
-                           (const uint8_t*)tab_pts, C.ws_partial.as<uint8_t>(), handed, abort_dev);
     } else if (C.timer.enabled && C.timer.created && !gcap.active) {
         hipExtLaunchKernelGGL((k_accumulate<BF>), agrid, dim3(256), 0, s, C.timer.k0, C.timer.k1, 0,
                               C.ws_entries.as<u32>(), C.ws_off.as<u32>(), C.ws_toff.as<u32>(), roff, order, nkeys,

@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libkimchi_hip.so")
+LIB_PATH = os.environ.get("KH_LIB") or os.path.join(_HERE, "libkimchi_hip.so")      # KH_LIB: another build of the library (same-box A/B of two builds)
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
