@@ -1548,6 +1548,7 @@ int kh_ipa_round_lr(kh_ipa_t* st, const uint64_t rand_l[4], const uint64_t rand_
     const int p = st->pp, q = p ^ 1;
     const bool had_fold = st->pending;
     // one launch: the recorded fold of the previous round (if any), this round's inner products and expanded scalars
+    // (round 5 also wrote the MSM's window digits from this kernel, saving the k_digits launch: measured, opening 5.76 vs 5.76 ms -- not kept)
     int rc = ipa_round_step(S.stream, st->field, st->pending ? 1 : 0, st->a[p].as<uint64_t>(), st->b[p].as<uint64_t>(), st->coef[p].as<uint64_t>(),
                             st->n, st->cur, st->pending ? st->ncoef / 2 : st->ncoef, st->u_p, st->ui_p,
                             st->a[q].as<uint64_t>(), st->b[q].as<uint64_t>(), st->coef[q].as<uint64_t>(), rand_l, rand_r,
@@ -1556,7 +1557,7 @@ int kh_ipa_round_lr(kh_ipa_t* st, const uint64_t rand_l[4], const uint64_t rand_
     if (st->pending) { st->pp = q; st->pending = false; }
     kh_srs_t* srs = st->srs;
     MsmBasis bs; bs.pts = st->round_tab; bs.inf = nullptr; bs.n = srs->g_stride; bs.stride = srs->g_stride; bs.precomp_c = st->round_c;
-    if ((rc = msm_enqueue(C, S, st->curve, bs, 0, st->sc->as<uint64_t>(), st->n + 2, 2, 1, /*use_graph=*/1))) return rc;
+    if ((rc = msm_enqueue(C, S, st->curve, bs, 0, st->sc->as<uint64_t>(), st->n + 2, 2, 1, MSM_REPEATS | MSM_SPREAD_SCALARS))) return rc;
     if (st->sg_want && st->cur == 2) { st->sg_want = false; ipa_sg_prelaunch_locked(st, C, p, had_fold); }
     if (!st->retired.empty()) {                           // the GPU is busy with this round for the next ~0.3 ms; other callers are not held up:
         std::vector<hipGraphExec_t> gone; gone.swap(st->retired);

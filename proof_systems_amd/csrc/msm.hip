@@ -130,23 +130,17 @@ int exclusive_scan_u32(const u32* in, u32* out, size_t n, DevBuf& tmp, hipStream
 }
 
 // ------------------------------------------------------------------------------------ 1 digits
+// s: the scalar, Montgomery (mont != 0) or canonical with at most one excess p; digits d_w in (-2^(c-1), 2^(c-1)] with sum_w d_w 2^(c w) = s,
+// written to dst[w * stride], w < W (all zero when `skip`)
 template <class SF>
-__global__ void k_digits(const u64* __restrict__ scalars, const uint8_t* __restrict__ inf, size_t inf_off,
-                         size_t inf_batch, size_t n, int mont, int c, int W, int32_t* __restrict__ digits) {
-    KH_HIGH_PRIO();
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    int j = blockIdx.y;
-    if (i >= n) return;
-    Fe<SF> s = Fe<SF>::load(scalars + ((size_t)j * n + i) * 4);
+__device__ __forceinline__ void emit_digits(Fe<SF> s, int mont, int c, int W, bool skip, int32_t* __restrict__ dst, size_t stride) {
     if (mont) s = from_mont<SF>(s);
-    else s = cond_sub_p<SF>(s.v);                         // tolerate one excess p in canonical input
-    bool skip = inf && inf[inf_off + (size_t)j * inf_batch + i];
+    else s = cond_sub_p<SF>(s.v);
     u32 l[8];
 #pragma unroll
     for (int t = 0; t < 8; t++) l[t] = s.v[t];
     const u32 half = 1u << (c - 1), mask = (1u << c) - 1u;
     u32 carry = 0;
-    int32_t* dj = digits + (size_t)j * W * n + i;
     for (int w = 0; w < W; w++) {
         u32 v = (l[0] & mask) + carry;
         int32_t d;
@@ -154,8 +148,18 @@ __global__ void k_digits(const u64* __restrict__ scalars, const uint8_t* __restr
 #pragma unroll
         for (int t = 0; t < 7; t++) l[t] = (l[t] >> c) | (l[t + 1] << (32 - c));
         l[7] >>= c;
-        dj[(size_t)w * n] = skip ? 0 : d;
+        dst[(size_t)w * stride] = skip ? 0 : d;
     }
+}
+template <class SF>
+__global__ void k_digits(const u64* __restrict__ scalars, const uint8_t* __restrict__ inf, size_t inf_off,
+                         size_t inf_batch, size_t n, int mont, int c, int W, int32_t* __restrict__ digits) {
+    KH_HIGH_PRIO();
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int j = blockIdx.y;
+    if (i >= n) return;
+    const bool skip = inf && inf[inf_off + (size_t)j * inf_batch + i];
+    emit_digits<SF>(Fe<SF>::load(scalars + ((size_t)j * n + i) * 4), mont, c, W, skip, digits + (size_t)j * W * n + i, n);     // (canonical input may carry one excess p)
 }
 
 // ------------------------------------------------------------------------------------ 2 histogram
@@ -1625,6 +1629,11 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
     // record (<= 65,536 digits per pass-A block, <= 1024 blocks).
     const bool wide = basis.wide_pts && basis.wide_c > 16 && basis.wide_c - 9 <= (int)PART2_MAXLOW && n >= msm_wide_min_n() && k <= 4 &&
                       (size_t)((256 + basis.wide_c - 1) / basis.wide_c) * n <= ((size_t)1 << 26);
+    // MSM_SPREAD_SCALARS: the caller vouches that the scalars are spread like random ones (the opening rounds: products with Fiat-Shamir challenges), so
+    // no bucket collects a large share of the entries: the two-phase hot-bucket kernels are not launched (two empty dependent launches per MSM, ~20 us of
+    // the ~340 us of an opening round) and a bucket's quad sums however many task partials it finds -- correct for any input, slow for a skewed one.
+    static const bool spread_on = !(getenv("KH_NO_SPREAD_HINT") && atoi(getenv("KH_NO_SPREAD_HINT")) != 0);
+    const bool spread = spread_on && (use_graph & MSM_SPREAD_SCALARS) != 0;
     const void* const tab_pts = wide ? basis.wide_pts : basis.pts;
     const int c = wide ? basis.wide_c : (basis.precomp_c ? basis.precomp_c : msm_pick_window(n));
     const int W = (256 + c - 1) / c;
@@ -1765,7 +1774,7 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
     uint64_t key = 0;
     CaptureGuard gcap{s};
     const bool timers_were = C.timer.enabled;
-    if (use_graph && !graphs_off && s != Ctx.stream) {       // never capture on the main stream: other host threads synchronise and launch on it
+    if ((use_graph & MSM_REPEATS) && !graphs_off && s != Ctx.stream) {       // never capture on the main stream: other host threads synchronise and launch on it
         key = 0xcbf29ce484222325ull;
         const uint64_t parts[] = {(uint64_t)(uintptr_t)basis.pts, (uint64_t)(uintptr_t)basis.inf, basis.n, basis.stride, basis.batch_stride, (uint64_t)basis.precomp_c,
                                   offset, (uint64_t)(uintptr_t)scalars_dev, n, k, (uint64_t)mont, (uint64_t)curve, (uint64_t)(uintptr_t)C.pinned,
@@ -1774,7 +1783,7 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
                                   (uint64_t)(uintptr_t)C.ws_buckets.p, (uint64_t)(uintptr_t)C.ws_seg.p, (uint64_t)(uintptr_t)C.ws_out.p, (uint64_t)(uintptr_t)C.ws_scan_tmp.p,
                                   (uint64_t)(uintptr_t)C.ws_biglist.p, (uint64_t)(uintptr_t)C.ws_order.p, (uint64_t)(uintptr_t)C.ws_chunks.p,
                                   (uint64_t)(uintptr_t)C.ws_handed.p, (uint64_t)(uintptr_t)C.ws_sync.p, (uint64_t)fused, (uint64_t)(uintptr_t)C.ws_mid.p, (uint64_t)part,
-                                  (uint64_t)(uintptr_t)tab_pts, (uint64_t)wide, (uint64_t)(uintptr_t)C.ws_xlist.p, (uint64_t)(uintptr_t)C.ws_b29.p, (uint64_t)(uintptr_t)C.ws_a1.p, (uint64_t)(uintptr_t)C.ws_a2.p,
+                                  (uint64_t)(uintptr_t)tab_pts, (uint64_t)wide, (uint64_t)spread, (uint64_t)(uintptr_t)C.ws_xlist.p, (uint64_t)(uintptr_t)C.ws_b29.p, (uint64_t)(uintptr_t)C.ws_a1.p, (uint64_t)(uintptr_t)C.ws_a2.p,
                                   DevBuf::generation().load()};
         for (uint64_t v : parts) key = fnv(key, v);
         if (C.gexec && C.gkey == key) {                    // replay
@@ -1922,15 +1931,17 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
     else if (precomp && ngroups <= bsum_maxg && bsum_quad)
         hipLaunchKernelGGL((k_bucket_sum_q<BF>), dim3((unsigned)((4 * nkeys + 255) / 256)), dim3(256), 0, s,
                            C.ws_toff.as<u32>(), nkeys, C.ws_partial.as<uint8_t>(), C.ws_buckets.as<uint8_t>(), C.ws_biglist.as<u32>(),
-                           bigcap, 16u, abort_dev);
+                           bigcap, spread ? 0xffffffffu : 16u, abort_dev);
     else
     hipLaunchKernelGGL((k_bucket_sum<BF>), dim3((unsigned)((nkeys + 255) / 256)), dim3(256), 0, s,
                        C.ws_toff.as<u32>(), nkeys, C.ws_partial.as<uint8_t>(), C.ws_buckets.as<uint8_t>(), C.ws_biglist.as<u32>(),
                        bigcap, nkeys <= 16384 ? 4u : 16u, abort_dev);
+    if (!(spread && !wide && precomp && ngroups <= bsum_maxg && bsum_quad)) {      // (the quad kernel took every bucket: nothing was listed)
     hipLaunchKernelGGL((k_bucket_chunk<BF>), dim3(2048), dim3(64), 0, s,
                        C.ws_toff.as<u32>(), C.ws_partial.as<uint8_t>(), C.ws_biglist.as<u32>(), bigcap, C.ws_chunks.as<uint8_t>(), abort_dev);
     hipLaunchKernelGGL((k_bucket_big<BF>), dim3(1024), dim3(256), 0, s,
                        C.ws_toff.as<u32>(), C.ws_chunks.as<uint8_t>(), C.ws_buckets.as<uint8_t>(), C.ws_biglist.as<u32>(), bigcap, abort_dev);
+    }
     if (wide) hipLaunchKernelGGL((k_big_to29<BF>), dim3(16), dim3(64), 0, s, C.ws_buckets.as<uint8_t>(), C.ws_biglist.as<u32>(), b29, part_low);
     C.timer.mark("bucket_sum", s);
     // 7 reduce

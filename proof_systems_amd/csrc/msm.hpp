@@ -26,8 +26,9 @@ size_t msm_wide_min_n();                          // MSMs of at least this many 
 static constexpr size_t MSM_PRECOMP_MIN_N = 1024; // smaller bases keep the plain per-window path
 static constexpr int IPA_ROUND_C = 16;            // window width of the opening rounds' table set (KH_IPA_C overrides; < 16: a second, narrower set)
 // enqueue all device work of k MSMs on slot S (returns immediately); msm_finish waits for it and does the host part
-// use_graph: the caller repeats this exact MSM (same buffers and sizes): from the second call on the launch sequence is
+// use_graph: flags.  MSM_REPEATS: the caller repeats this exact MSM (same buffers and sizes): from the second call on the launch sequence is
 // captured once into a hipGraph and replayed
+static constexpr int MSM_REPEATS = 1, MSM_SPREAD_SCALARS = 2;      // (MSM_SPREAD_SCALARS: msm.hip, "the caller vouches ...")
 int msm_enqueue(Context& C, MsmSlot& S, int curve, const MsmBasis& basis, size_t offset, const uint64_t* scalars_dev, size_t n, size_t k, int mont,
                 int use_graph = 0);
 int msm_finish(Context& C, MsmSlot& S, uint64_t* out_xy, uint8_t* out_inf);

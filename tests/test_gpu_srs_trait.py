@@ -300,12 +300,13 @@ def _run_opening(khip, srs, cid, a_l, b_l, U_l, rands_l, chals):
     return lr, us, a0, b0, sg, sginf
 
 
-@pytest.mark.parametrize("cid,logn", [(0, 5), (1, 5), (0, 10), (1, 10), (1, 3), (0, 1), (0, 0)])
-def test_ipa_opening_rounds_match_oracle(khip, cid, logn):
+@pytest.mark.parametrize("cid,logn,const_a", [(0, 5, False), (1, 5, False), (0, 10, False), (1, 10, False), (1, 3, False), (0, 1, False), (0, 0, False), (0, 10, True)])
+def test_ipa_opening_rounds_match_oracle(khip, cid, logn, const_a):
     """The device-resident folding loop of SRS::open (ipa.rs:929-1018) against the oracle's literal restatement
     (which folds the basis with combine_one_endo): every L, R, every challenge image, a0, b0 and sg bit for bit.
     2^10 runs on the precomputed-table path, the others on the per-window path; the polynomial is shorter than the
-    SRS (zero padding, ipa.rs:918-920)."""
+    SRS (zero padding, ipa.rs:918-920).  const_a: a polynomial whose coefficients are all EQUAL -- the first round's scalars then fall into one
+    bucket per window, against the "scalars are spread" hint the opening rounds give the MSM (csrc/msm.hip MSM_SPREAD_SCALARS: correct, only slower)."""
     c = P.CURVES[cid]; F = c.scalar
     n = 1 << logn
     rnd = np.random.default_rng(1000 + 7 * cid + logn)
@@ -318,6 +319,8 @@ def test_ipa_opening_rounds_match_oracle(khip, cid, logn):
     a_len = max(1, n - 3)
     ri = lambda: int.from_bytes(rnd.bytes(40), "little") % F.p
     a = [ri() for _ in range(a_len)]
+    if const_a:
+        a = [a[0]] * a_len
     x = ri()
     b = [pow(x, i, F.p) for i in range(n)]
     rands = [(ri(), ri()) for _ in range(logn)]
