@@ -773,27 +773,27 @@ k_part2_sort(const u32* __restrict__ mid, const u32* __restrict__ PO, u32 nblk, 
     }
     __syncthreads();
     const u32 pb0 = (u32)(pt_offset + (size_t)j * pt_batch);
-    u32 top = 1; while (top * 2 <= nblk) top *= 2;       // largest power of two <= nblk
-    for (u32 x0 = base + tid; x0 < end; x0 += 8 * PART_T) {
-        u32 m[8], blk[8];
+    // The partition's records are the concatenation of the pass-A blocks' runs (~n W / (256 nblk) records each): a WAVE takes whole runs, so the
+    // block that wrote a record -- and with it (window, point) of the record's position -- is wave-uniform (a per-record search through pstart cost
+    // ten LDS reads per record).  Four 64-record chunks of a run are loaded before any is scattered.
+    const u32 lane = tid & 63u, wv = tid >> 6;
+    for (u32 blk = wv; blk < nblk; blk += PART_T / 64) {
+        const u32 rs = pstart[blk], re = pstart[blk + 1];
+        const u32 w0 = bw0[blk], i0 = bi0[blk];
+        for (u32 x0 = rs; x0 < re; x0 += 256) {
+            u32 m[4];
 #pragma unroll
-        for (int u = 0; u < 8; u++) { const u32 x = x0 + u * PART_T; m[u] = mid[x < end ? x : end - 1]; blk[u] = 0; }
-        // the pass-A block that wrote record x: the largest blk with pstart[blk] <= x, all eight searches in lockstep (LDS latency overlaps)
-        for (u32 st = top; st >= 1; st >>= 1) {
+            for (int u = 0; u < 4; u++) { const u32 x = x0 + u * 64 + lane; m[u] = mid[x < re ? x : re - 1]; }
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const u32 x = x0 + u * PART_T, c = blk[u] + st;
-                if (c < nblk && pstart[c] <= (x < end ? x : end - 1)) blk[u] = c;
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const bool live = x0 + u * PART_T < end;
-            const u32 pos = lds_inc_agg(cur, m[u] >> 17, live);
-            if (live) {
-                u32 w = bw0[blk[u]], i = bi0[blk[u]] + (m[u] & 0xffffu);
-                while (i >= n) { i -= n; w++; }
-                entries[pos] = (pb0 + (u32)(w * pt_stride) + i) | ((m[u] & (1u << 16)) << 15);
+            for (int u = 0; u < 4; u++) {
+                const bool live = x0 + u * 64 + lane < re;
+                if (x0 + u * 64 >= re) break;              // (wave-uniform)
+                const u32 pos = lds_inc_agg(cur, m[u] >> 17, live);
+                if (live) {
+                    u32 w = w0, i = i0 + (m[u] & 0xffffu);
+                    while (i >= n) { i -= n; w++; }
+                    entries[pos] = (pb0 + (u32)(w * pt_stride) + i) | ((m[u] & (1u << 16)) << 15);
+                }
             }
         }
     }
