@@ -35,6 +35,7 @@ static thread_local int tl_hip_dev = -1;       // what this thread last passed t
 static thread_local Context* tl_private[KH_MAX_DEVICES];
 static std::vector<Context*> g_private_pool[KH_MAX_DEVICES];           // idle private contexts (guarded by g_ctx_mu)
 static std::atomic<int> g_private_made[KH_MAX_DEVICES];                 // private contexts ever created per device (they are never destroyed)
+static int g_private_active[KH_MAX_DEVICES];                             // threads between kh_private_context_begin and _end per device (guarded by g_ctx_mu)
 // a thread keeps the context it used last (its workspaces, captured graphs and staging ring stay warm for its next proof) and hands it to the pool when it
 // exits -- no HIP call in the destructor, only the list
 struct ThreadContextCache {
@@ -302,15 +303,20 @@ int kh_trim(void) {
         MsmSlot& S = C.slot[i];
         if (S.gexec) { (void)hipGraphExecDestroy(S.gexec); S.gexec = nullptr; S.gkey = 0; S.gseen = 0; }
         for (DevBuf* b : {&S.ws_scalars, &S.ws_digits, &S.ws_hist, &S.ws_cnt, &S.ws_off, &S.ws_ntask, &S.ws_toff, &S.ws_entries, &S.ws_partial, &S.ws_buckets,
-                          &S.ws_seg, &S.ws_out, &S.ws_scan_tmp, &S.ws_biglist, &S.ws_points, &S.ws_order, &S.ws_chunks, &S.ws_handed, &S.ws_sync, &S.ws_mid}) b->release();
+                          &S.ws_seg, &S.ws_out, &S.ws_scan_tmp, &S.ws_biglist, &S.ws_points, &S.ws_order, &S.ws_chunks, &S.ws_handed, &S.ws_sync, &S.ws_mid,
+                          &S.ws_b29, &S.ws_a1, &S.ws_a2, &S.ws_xlist}) b->release();
     }
     C.ws_ntt_a.release(); C.ws_ntt_b.release();
     dev_pool_trim(C.device);
     C.trim_scratch();
     // The twiddle tables belong to the DEVICE and are shared by every context on it: a private context of another thread may be between two
     // passes of a transform that reads them, and this call holds only its own context's lock.  They are dropped only while no private context
-    // exists on the device (a few MB per transform size otherwise stay cached until the process ends).
-    if (g_private_made[C.device >= 0 && C.device < KH_MAX_DEVICES ? C.device : 0].load() == 0) ntt_trim(C);
+    // is ACTIVE on the device, and the registry lock is held across the free so that none can begin meanwhile (the old test --
+    // "no private context was ever created" -- never became true again after the first kh_prove).
+    {
+        std::lock_guard<std::mutex> lk2(g_ctx_mu);
+        if (g_private_active[C.device >= 0 && C.device < KH_MAX_DEVICES ? C.device : 0] == 0) ntt_trim(C);
+    }
     return KH_OK;
 }
 
@@ -343,6 +349,7 @@ int kh_private_context_begin(void) {
     }
     c->mark_async();                                      // ... and this context's side slots wait for its main stream in turn
     tl_private[dev] = c;
+    { std::lock_guard<std::mutex> lk(g_ctx_mu); g_private_active[dev]++; }
     return KH_OK;
 }
 int kh_private_context_active(void) {
@@ -360,8 +367,11 @@ int kh_private_context_end(void) {
         c->main_dirty = false;
     }
     tl_private[dev] = nullptr;
-    if (!tl_ctx_cache.c[dev]) tl_ctx_cache.c[dev] = c;
-    else { std::lock_guard<std::mutex> lk(g_ctx_mu); g_private_pool[dev].push_back(c); }
+    {
+        std::lock_guard<std::mutex> lk(g_ctx_mu);
+        g_private_active[dev]--;
+        if (!tl_ctx_cache.c[dev]) tl_ctx_cache.c[dev] = c; else g_private_pool[dev].push_back(c);
+    }
     if (e != hipSuccess) { set_error("hipStreamSynchronize failed: %s", hipGetErrorString(e)); return KH_E_DEVICE; }
     return KH_OK;
 }
@@ -567,8 +577,12 @@ static int free_slot(Context& C) {
 // is itself blocked in here (or is the caller) -- nobody is left to call kh_msm_wait.
 static int acquire_slot(std::unique_lock<std::mutex>* lk, Context& C, bool side_first = false) {
     const auto me = std::this_thread::get_id();
-    const auto t_start = std::chrono::steady_clock::now();
+    auto t_start = std::chrono::steady_clock::now();
+    uint64_t seen = ~(uint64_t)0;                          // what the slots looked like at the last look: the deadline counts time WITHOUT progress
     for (;;) {
+        uint64_t sig = C.next_ticket;
+        for (int i = 0; i < MSM_SLOTS; i++) sig = sig * 1315423911ull + (C.slot[i].busy ? C.slot[i].ticket + 1 : 0);
+        if (sig != seen) { seen = sig; t_start = std::chrono::steady_clock::now(); }
         int si = -1;
         if (side_first) for (int i = MSM_SLOTS - 1; i >= 1; i--) if (!C.slot[i].busy) { si = i; break; }
         if (si < 0) si = free_slot(C);
@@ -588,6 +602,10 @@ static int acquire_slot(std::unique_lock<std::mutex>* lk, Context& C, bool side_
         C.blocked_owners.erase(C.blocked_owners.find(me));
     }
 }
+static const char* slot_error(int si) {
+    return si == -2 ? "no MSM pipeline slot came free and none changed hands for KH_SLOT_WAIT_S (default 30 s): a kh_msm_submit ticket was leaked (its owner never called kh_msm_wait)"
+                    : "every MSM pipeline slot holds an un-waited kh_msm_submit ticket of this thread (or of threads blocked behind it): kh_msm_wait first";
+}
 // enqueue on a free slot; returns the slot index through *slot_out
 static int msm_submit_locked(Context& C, kh_srs_t* srs, int basis, unsigned chunk, size_t offset, const uint64_t* scalars,
                              bool scalars_on_device, size_t n, size_t k, int mont, int* slot_out, std::unique_lock<std::mutex>* lk = nullptr) {
@@ -595,7 +613,7 @@ static int msm_submit_locked(Context& C, kh_srs_t* srs, int basis, unsigned chun
     KH_REQUIRE(offset <= b.n, "offset %zu beyond basis length %zu", offset, b.n);
     size_t use = n < b.n - offset ? n : b.n - offset;      // msm_bigint semantics: min(len) pairs
     int si = acquire_slot(lk, C);
-    KH_REQUIRE(si >= 0, "all %d MSM pipeline slots hold an un-waited job (kh_msm_wait first; a ticket whose owner never waits blocks later callers for KH_SLOT_WAIT_S, default 30 s, then fails them)", MSM_SLOTS);
+    KH_REQUIRE(si >= 0, "%s", slot_error(si));
     if (lk && (rc = resolve_basis(srs, basis, chunk, b))) return rc;     // acquire_slot may have dropped the lock: the basis map can have changed
     MsmSlot& S = C.slot[si];
     const uint64_t* sdev = scalars;
@@ -720,7 +738,7 @@ static int msm_common(kh_srs_t* srs, int basis, unsigned chunk, size_t offset, c
     auto run = [&]() -> int {
         MsmBasis b; int r;
         int si = acquire_slot(&lk, C);
-        KH_REQUIRE(si >= 0, "all %d MSM pipeline slots hold an un-waited job (kh_msm_wait first; a ticket whose owner never waits blocks later callers for KH_SLOT_WAIT_S, default 30 s, then fails them)", MSM_SLOTS);
+        KH_REQUIRE(si >= 0, "%s", slot_error(si));
         if ((r = resolve_basis(srs, basis, chunk, b))) return r;         // after the wait: the lock was dropped meanwhile
         MsmSlot& S = C.slot[si];
         if ((r = S.ws_scalars.reserve(kk * n * 32))) return r;
@@ -845,7 +863,7 @@ int kh_msm_points_batch(int curve, const uint64_t* xy, const uint8_t* inf, const
     if (n == 0 || k == 0) { for (size_t j = 0; j < k; j++) { memset(out_xy + 8 * j, 0, 64); out_is_inf[j] = 1; } return KH_OK; }
     const size_t tot = n * k;
     int si = acquire_slot(&lk, C);
-    KH_REQUIRE(si >= 0, "all %d MSM pipeline slots hold an un-waited job (kh_msm_wait first; a ticket whose owner never waits blocks later callers for KH_SLOT_WAIT_S, default 30 s, then fails them)", MSM_SLOTS);
+    KH_REQUIRE(si >= 0, "%s", slot_error(si));
     MsmSlot& S = C.slot[si];
     if ((rc = S.ws_points.reserve(tot * 64 + tot))) return rc;
     if ((rc = S.ws_scalars.reserve(tot * 32))) return rc;
@@ -1542,7 +1560,7 @@ int kh_ipa_round_lr(kh_ipa_t* st, const uint64_t rand_l[4], const uint64_t rand_
     Context& C = ctx();
     std::unique_lock<std::mutex> lk(C.mu);
     int si = acquire_slot(&lk, C, /*side_first=*/true);
-    KH_REQUIRE(si >= 0, "all %d MSM pipeline slots hold an un-waited job (kh_msm_wait first; a ticket whose owner never waits blocks later callers for KH_SLOT_WAIT_S, default 30 s, then fails them)", MSM_SLOTS);
+    KH_REQUIRE(si >= 0, "%s", slot_error(si));
     MsmSlot& S = C.slot[si];
     KH_HIP(hipStreamWaitEvent(S.stream, st->ev, 0));
     const int p = st->pp, q = p ^ 1;
@@ -1591,7 +1609,7 @@ static int ipa_finish_impl(kh_ipa_t* st, uint64_t a0[4], uint64_t b0[4], uint64_
     Context& C = ctx();
     std::unique_lock<std::mutex> lk(C.mu);
     int si = acquire_slot(&lk, C);
-    KH_REQUIRE(si >= 0, "all %d MSM pipeline slots hold an un-waited job (kh_msm_wait first; a ticket whose owner never waits blocks later callers for KH_SLOT_WAIT_S, default 30 s, then fails them)", MSM_SLOTS);
+    KH_REQUIRE(si >= 0, "%s", slot_error(si));
     MsmSlot& S = C.slot[si];
     KH_HIP(hipStreamWaitEvent(S.stream, st->ev, 0));
     int rc;
@@ -1943,12 +1961,25 @@ int kh_dev_alloc(void** ptr, size_t bytes) {
             P.free_blocks[d].erase(it);
             lk.unlock();
             if (prev && prev != me) {                                      // another context's block: order this context behind that one's queued work
+                // (behind its MAIN stream: a buffer handed to kh_msm_submit must not be freed before the ticket is waited for -- the side slots' streams
+                //  are not part of the hand-over.)  A failure here gives the block back to the pool and leaves *ptr null.
                 static thread_local hipEvent_t hand_over[KH_MAX_DEVICES] = {nullptr};
-                if (!hand_over[d]) KH_HIP(hipEventCreateWithFlags(&hand_over[d], hipEventDisableTiming));
-                std::lock_guard<std::mutex> g(me->mu);
-                KH_HIP(hipEventRecord(hand_over[d], prev->stream));         // (main streams are never captured into a graph: recording from here is fine)
-                KH_HIP(hipStreamWaitEvent(me->stream, hand_over[d], 0));
-                me->mark_async();                                          // ... and this context's side slots behind its main stream
+                hipError_t e = hipSuccess;
+                if (!hand_over[d]) e = hipEventCreateWithFlags(&hand_over[d], hipEventDisableTiming);
+                if (e == hipSuccess) {
+                    std::lock_guard<std::mutex> g(me->mu);
+                    e = hipEventRecord(hand_over[d], prev->stream);         // (main streams are never captured into a graph: recording from here is fine)
+                    if (e == hipSuccess) e = hipStreamWaitEvent(me->stream, hand_over[d], 0);
+                    if (e == hipSuccess) me->mark_async();                  // ... and this context's side slots behind its main stream
+                }
+                if (e != hipSuccess) {
+                    std::lock_guard<std::mutex> g2(P.mu);
+                    auto lv = P.live.find(*ptr);
+                    if (lv != P.live.end()) { P.free_blocks[d].emplace(lv->second.second, DevPool::Block{*ptr, prev}); P.cached[d] += lv->second.second; P.live.erase(lv); }
+                    *ptr = nullptr;
+                    set_error("kh_dev_alloc: ordering behind the previous owner of a pooled block failed: %s", hipGetErrorString(e));
+                    return KH_E_DEVICE;
+                }
             }
             return KH_OK;
         }
