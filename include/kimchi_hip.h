@@ -78,7 +78,7 @@ const char *kh_last_error(void);
  * uploads the n monomial-basis points once; Rust keeps owning its own copy. */
 int kh_srs_create(int curve, const uint64_t *g_xy /* n x 8 limbs */, size_t n, kh_srs_t **out);
 /* Tuning knob (process-wide): bases of at least n points get a SECOND window-table set with 20-bit windows when they are created (13 instead of 16
- * table additions per scalar, 2^19 buckets, +13/16 of the table memory), and single MSMs of at least n scalars over them take it.  Default 2^20
+ * table additions per scalar, 2^19 buckets, +13/16 of the table memory), and single MSMs of at least n scalars over them take it.  Default 2^19
  * (KH_WIDE_MIN_N), 0 = never.  Results are the same group elements either way; the tests lower it to run the wide path at small sizes. */
 int kh_msm_set_wide_min_n(size_t n);
 void kh_srs_free(kh_srs_t *srs);

@@ -1574,7 +1574,7 @@ struct VestaCfg { typedef FqParams Base; typedef FpParams Scalar; };
 struct PallasCfg { typedef FpParams Base; typedef FqParams Scalar; };
 
 static std::atomic<size_t>& wide_min_n_cell() {
-    static std::atomic<size_t> v{getenv("KH_WIDE_MIN_N") ? (size_t)strtoull(getenv("KH_WIDE_MIN_N"), nullptr, 0) : ((size_t)1 << 20)};
+    static std::atomic<size_t> v{getenv("KH_WIDE_MIN_N") ? (size_t)strtoull(getenv("KH_WIDE_MIN_N"), nullptr, 0) : ((size_t)1 << 19)};
     return v;
 }
 size_t msm_wide_min_n() { const size_t v = wide_min_n_cell().load(); return v ? v : ~(size_t)0; }
@@ -1896,7 +1896,10 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
         } else
         hipLaunchKernelGGL(kern, wgrid, dim3(256), wide_acc_lds, s, C.ws_entries.as<u32>(), C.ws_off.as<u32>(), C.ws_toff.as<u32>(), order, (u32)nkeys,
                            (const uint8_t*)tab_pts, C.ws_partial.as<uint8_t>(), b29, part_low, C.ws_handed.as<u32>());
-        hipLaunchKernelGGL((k_acc_wide_extra<BF>), dim3(WIDE_XB), dim3(256), 0, s, C.ws_entries.as<u32>(), C.ws_off.as<u32>(), C.ws_toff.as<u32>(), C.ws_xlist.as<u32>(),
+        // (the extra chunks: none for 2^19..2^21 uniform scalars; at 2^22 the 2^14 top-window buckets hold ~360 entries against K = 256 and split in two --
+        //  16 K extra chunks, for which 32 blocks took 2 ms)
+        const unsigned xgrid = M / nkeys >= 64 ? 2048u : WIDE_XB;
+        hipLaunchKernelGGL((k_acc_wide_extra<BF>), dim3(xgrid), dim3(256), 0, s, C.ws_entries.as<u32>(), C.ws_off.as<u32>(), C.ws_toff.as<u32>(), C.ws_xlist.as<u32>(),
                            (const uint8_t*)tab_pts, C.ws_partial.as<uint8_t>(), b29, part_low, C.ws_handed.as<u32>());
         hipLaunchKernelGGL((k_acc_wide_exact<BF>), dim3(32), dim3(256), 0, s, C.ws_entries.as<u32>(), C.ws_off.as<u32>(), C.ws_toff.as<u32>(), C.ws_handed.as<u32>(),
                            (const uint8_t*)tab_pts, C.ws_partial.as<uint8_t>(), b29, part_low);

@@ -22,7 +22,9 @@ int msm_precompute(Context& C, int curve, void* tables, const uint8_t* inf, size
 static constexpr int MSM_PRECOMP_C = 16;          // window width of the precomputed tables
 static constexpr int MSM_WIDE_C = 20;             // ... of the second table set big bases get: 13 windows, 2^19 buckets (msm.hip, "wide windows")
 void msm_set_wide_min_n(size_t n);
-size_t msm_wide_min_n();                          // MSMs of at least this many points take the wide tables (KH_WIDE_MIN_N, default 2^20; 0 = never)
+size_t msm_wide_min_n();                          // MSMs of at least this many points take the wide tables (KH_WIDE_MIN_N, default 2^19; 0 = never)
+                                                  // measured (tools/wide_ab.py, pipelined Mscalar/s narrow -> wide): 2^17 537 -> 400, 2^18 655 -> 685, 2^19 746 -> 815,
+                                                  // 2^20 896 -> 960..1000, 2^21 770 -> 976, 2^22 861 -> 992
 static constexpr size_t MSM_PRECOMP_MIN_N = 1024; // smaller bases keep the plain per-window path
 static constexpr int IPA_ROUND_C = 16;            // window width of the opening rounds' table set (KH_IPA_C overrides; < 16: a second, narrower set)
 // enqueue all device work of k MSMs on slot S (returns immediately); msm_finish waits for it and does the host part

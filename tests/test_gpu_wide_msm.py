@@ -1,5 +1,5 @@
 """The wide-window MSM path (csrc/msm.hip "wide windows": a second table set with 20-bit windows, 2^19 buckets, the lazy
-two-plane bucket reduction), bit-exact against the C oracle.  By default the path serves single MSMs of >= 2^20 scalars
+two-plane bucket reduction), bit-exact against the C oracle.  By default the path serves single MSMs of >= 2^19 scalars
 (tests/test_gpu_baseline_configs.py runs those at full size); here kh_msm_set_wide_min_n lowers the threshold so that
 every branch runs in seconds: the five scalar distributions of config 2 at 2^14 on both curves, batches of two, an MSM
 over a window of a longer basis, and the degenerate bases (one point repeated, two points, P / -P pairs) whose equal-point
@@ -24,7 +24,7 @@ def khip():
     k.init(0)
     k.set_wide_min_n(1 << 12)
     yield k
-    k.set_wide_min_n(1 << 20)
+    k.set_wide_min_n(1 << 19)
 
 
 def _rand_fe(rng, n):
