@@ -44,11 +44,11 @@ sys.path.insert(0, ROOT)
 LOG_N = 20
 ALG_BYTES_PER_PAIR = 96          # 64 B affine point + 32 B scalar, each read once
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec
-PMC_FILE = "r04_msm20_pmc.json"                 # tools/profile_msm.py (rocprofv3 PMC passes), keyed by the hash of csrc/
-MIX_FILE = "r04_k_accumulate29_valu_mix.json"   # tools/valu_mix.py (static opcode histogram of the loop body)
+PMC_FILE = "r05_msm20_pmc.json"                 # tools/profile_msm.py (rocprofv3 PMC passes), keyed by the hash of csrc/
+MIX_FILE = "r05_k_acc_wide29_valu_mix.json"   # tools/valu_mix.py (static opcode histogram of the loop body)
 RATES_FILE = "r04_valu_rates.json"              # per-opcode issue cycles measured by tools/microbench.hip
-NTT_PMC_FILE = "r04_ntt_pmc.json"               # tools/profile_msm.py --workload ntt (tools/bench_ntt.py --bench-shapes)
-NTT_MIX_FILE = "r04_k_ntt_pass_valu_mix.json"   # tools/valu_mix.py --kernel ntt
+NTT_PMC_FILE = "r05_ntt_pmc.json"               # tools/profile_msm.py --workload ntt (tools/bench_ntt.py --bench-shapes)
+NTT_MIX_FILE = "r05_k_ntt_pass_valu_mix.json"   # tools/valu_mix.py --kernel ntt
 
 
 def rand_scalars(rng, n):
@@ -275,7 +275,7 @@ def prover_block(khip, srs20, check_with_oracle=True, log_n=16, reps=5):
         best_c = dt if best_c is None else min(best_c, dt)
     for x in th:
         x.join()
-    def threaded(fs, reps=4):                                           # the callables at once, one (pre-started) thread each; best of the repeats after a warm-up
+    def threaded(fs, reps=7):                                           # the callables at once, one (pre-started) thread each; best of the repeats after a warm-up
         bar2 = threading.Barrier(len(fs) + 1); done2 = threading.Barrier(len(fs) + 1)
 
         def w(f):
@@ -289,7 +289,7 @@ def prover_block(khip, srs20, check_with_oracle=True, log_n=16, reps=5):
             bar2.wait(); t0 = time.perf_counter(); done2.wait(); ts.append(time.perf_counter() - t0)
         for x in th2:
             x.join()
-        return min(ts[1:])
+        return min(ts[2:])                                              # (the first repeats create the threads' copy streams and pin the fresh host pages)
     # interpolate: Evaluations::interpolate transforms the caller's Vec in place (ifft_in_place); one column per call, from ONE thread and from 15 at once
     # (prover.rs:370-381 is a par_iter over the 15 columns)
     icol = [c.copy() for c in cols]

@@ -1,21 +1,27 @@
 #!/bin/bash
-# Runs ON THE GPU BOX (gpurun -- 'bash tools/collect_profiles.sh r03'): every measurement profiles/ quotes, on one build, into gpurun_out/.
-# Afterwards, here: bash tools/install_profiles.sh r03
-R=${1:-r03}
-cd "$GRAFT_REPO_ROOT" || exit 1
-mkdir -p gpurun_out
-tools/microbench > gpurun_out/${R}_microbench.txt 2>&1
-python tools/profile_msm.py gpurun_out/${R}_msm20 > gpurun_out/${R}_profile_msm.log 2>&1
-python tools/profile_msm.py gpurun_out/${R}_ntt --workload ntt > gpurun_out/${R}_profile_ntt.log 2>&1
-python tools/profile_msm.py gpurun_out/${R}_gates --workload gates > gpurun_out/${R}_profile_gates.log 2>&1
-python bench.py > gpurun_out/${R}_bench_n1.json 2> gpurun_out/${R}_bench_n1.err
-( cd /tmp && export TMPDIR=/tmp && PYTHONPATH=$GRAFT_REPO_ROOT rocprofv3 --kernel-trace -d /tmp/pp_${R} -o pp -- python $GRAFT_REPO_ROOT/tools/prover_time.py 16 > $GRAFT_REPO_ROOT/gpurun_out/${R}_prover_time.txt 2>&1 )
-python tools/rocpd_stats.py /tmp/pp_${R}/pp_results.db gpurun_out/${R}_prover_kernel_stats.csv > /dev/null 2>&1
-python tools/prover_timeline.py /tmp/pp_${R}/pp_results.db --opening > gpurun_out/${R}_prover_timeline.txt 2>&1
-# the measurements DESIGN.md quotes beside the standard set: native prover latency / threads, gate kernels against the token machine, lookup proofs, task-length sweep
-python tools/prover_time.py 16 --native > gpurun_out/${R}_prover_native.txt 2>&1
-python tools/prover_concurrent.py 16 1 2 4 6 --native >> gpurun_out/${R}_prover_native.txt 2>&1
-python tools/gate_expr_time.py > gpurun_out/${R}_gate_kernels.txt 2>&1
-python tools/lookup_prover_time.py 16 > gpurun_out/${R}_lookup_prover.txt 2>&1
-bash tools/kmin_sweep.sh > gpurun_out/${R}_kmin_sweep.txt 2>&1
-tail -3 gpurun_out/${R}_prover_time.txt; tail -c 600 gpurun_out/${R}_bench_n1.json; ls -la gpurun_out | tail -20
+# Collects the round's committed evidence on the GPU box (run from the repo root through gpurun): rocprofv3 kernel stats + PMC passes for the MSM and the
+# NTT workloads (tools/profile_msm.py: every PMC pass its own run, never combined with a trace), the pipelined kernel trace + timeline, the static
+# opcode mixes, the A/B of the two table sets, the PCIe-inclusive rates, and finally bench.py's line (which then finds profiles of ITS OWN build).
+# Usage: tools/collect_profiles.sh r05
+R=${1:-r05}
+cd "$(dirname "$0")/.."
+export TMPDIR=/tmp
+mkdir -p gpurun_out/prof
+python tools/profile_msm.py gpurun_out/prof/${R}_msm20 > gpurun_out/prof/${R}_msm20_summary.txt 2>&1
+python tools/profile_msm.py gpurun_out/prof/${R}_ntt --workload ntt > gpurun_out/prof/${R}_ntt_summary.txt 2>&1
+python tools/valu_mix.py gpurun_out/prof/${R}_k_acc_wide29_valu_mix.json > /dev/null 2>&1
+python tools/valu_mix.py gpurun_out/prof/${R}_k_ntt_pass_valu_mix.json --kernel ntt > /dev/null 2>&1
+(cd /tmp && rocprofv3 --kernel-trace -d /tmp/pipe_$R -o t -- python $OLDPWD/tools/msm_loop.py wide pipe 40 20 2 > /dev/null 2>&1)
+DB=$(find /tmp/pipe_$R -name "*.db" | head -1)
+python tools/rocpd_stats.py $DB gpurun_out/prof/${R}_msm20_pipelined_kernel_stats.csv > /dev/null
+python tools/timeline.py $DB > gpurun_out/prof/${R}_msm20_pipelined_timeline.txt
+python tools/wide_ab.py 20 20 5 > gpurun_out/prof/${R}_wide_ab.txt 2>&1
+python tools/pcie_inclusive.py > gpurun_out/prof/${R}_pcie_inclusive.txt 2>&1
+python tools/bench_ntt.py > gpurun_out/prof/${R}_bench_ntt.txt 2>&1
+KH_IPA_TIMING=1 python tools/prover_time.py 16 --native > gpurun_out/prof/${R}_prover_time_ipa_timing.txt 2>&1
+# bench.py last: copy the fresh PMC / mix files where it looks for them
+cp gpurun_out/prof/${R}_msm20_pmc.json gpurun_out/prof/${R}_ntt_pmc.json gpurun_out/prof/${R}_k_acc_wide29_valu_mix.json gpurun_out/prof/${R}_k_ntt_pass_valu_mix.json profiles/ 2>/dev/null
+python bench.py > gpurun_out/prof/${R}_bench_stdout.txt 2> gpurun_out/prof/${R}_bench_stderr.txt
+grep '^{' gpurun_out/prof/${R}_bench_stdout.txt | tail -1 > gpurun_out/prof/${R}_bench_line.json
+rm -rf gpurun_out/prof/*_passes
+ls -la gpurun_out/prof | head -40

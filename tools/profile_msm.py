@@ -76,7 +76,7 @@ def main():
     outdir = out + "_passes"
     os.makedirs(outdir, exist_ok=True)
     if workload == "msm":
-        cmd = [sys.executable, "bench.py", "--no-pipeline", "--no-cpu-baseline", "--no-oplist", "--steps", "10", "--warmup", "2"]
+        cmd = [sys.executable, "bench.py", "--no-pipeline", "--single-region", "--no-cpu-baseline", "--no-oplist", "--steps", "10", "--warmup", "2"]
     elif workload == "gates":
         cmd = [sys.executable, "tools/gate_expr_time.py"]                   # every gate of the library on 2^19 rows: token machine and compiled kernel
     else:

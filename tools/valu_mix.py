@@ -22,7 +22,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 from profile_msm import source_hash  # noqa: E402
 
-KERNEL = "_ZN2kh14k_accumulate29INS_8FqParamsE"
+KERNEL = "_ZN2kh12k_acc_wide29INS_8FqParamsE"           # the accumulation of the wide-window path (round 5); --kernel narrow: k_accumulate29
+NARROW_KERNEL = "_ZN2kh14k_accumulate29INS_8FqParamsE"
 NTT_KERNEL = "_ZN2kh10k_ntt_passINS_8FpParamsELi256E"       # tools/valu_mix.py OUT --kernel ntt: the whole kernel (straight-line radix-4 steps)
 
 
@@ -44,7 +45,9 @@ def main():
         json.dump(res, open(out, "w"), indent=1)
         print(json.dumps(res, indent=1)[:600])
         return
-    start = next(i for i, l in enumerate(lines) if l.startswith(KERNEL) and l.split(";")[0].strip().endswith(":"))
+    narrow = "--kernel" in sys.argv and sys.argv[sys.argv.index("--kernel") + 1] == "narrow"
+    kern = NARROW_KERNEL if narrow else KERNEL
+    start = next(i for i, l in enumerate(lines) if l.startswith(kern) and l.split(";")[0].strip().endswith(":"))
     end = next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end"))
     blocks, cur = {"entry": []}, "entry"
     for l in lines[start + 1:end]:
@@ -57,7 +60,7 @@ def main():
             blocks[cur].append(l.split()[0])
     name, body = max(blocks.items(), key=lambda kv: sum(op == "v_mad_u64_u32" for op in kv[1]))
     hist = Counter(op for op in body if op.startswith("v_"))
-    res = {"source_sha256": source_hash(), "kernel": "k_accumulate29<FqParams>", "block": name, "block_instructions": len(body),
+    res = {"source_sha256": source_hash(), "kernel": ("k_accumulate29" if narrow else "k_acc_wide29") + "<FqParams>", "block": name, "block_instructions": len(body),
            "block_valu_instructions": sum(hist.values()), "valu_histogram": dict(sorted(hist.items(), key=lambda kv: -kv[1]))}
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res, indent=1))
