@@ -26,6 +26,14 @@ def test_madd29_limb_model():
     gen.check_madd(gen.P_FQ, "Fq", chains=6, length=30)
 
 
+def test_add29_limb_model():
+    """the full lazy addition of the wide MSM path's bucket reduction (field29.cuh add29): random sums of sums -- operands that are themselves results of
+    madd29 / add29 chains -- against affine arithmetic, value and limb bounds asserted, and the equal / opposite-point filter (A + A, the same point through
+    two routes, A + (-A) must be handed to the exact path)"""
+    gen.check_add(gen.P_FP, "Fp", trees=3, leaves=16)
+    gen.check_add(gen.P_FQ, "Fq", trees=3, leaves=16)
+
+
 def test_spread_constants_dominate_their_subtrahends():
     """a - b + K p is computed limb-wise as a_i + C_i - b_i: C must dominate every limb b can have at its stated value
     bound (madd29: x < 6p under S71, y < 4p under S51, PPP + 2Q < 3.3p with limbs <= 3 MASK under S44, rx < 5.4p under
