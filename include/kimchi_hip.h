@@ -70,6 +70,9 @@ int kh_get_device(void);              /* the calling thread's current device (-1
 int kh_private_context_begin(void);
 int kh_private_context_end(void);
 int kh_private_context_active(void);   /* 1 if the calling thread is between _begin and _end on its current device */
+/* per-phase HIP events behind kh_last_timings on the calling thread's current context (the private one between _begin and _end): OFF by default -- an event
+ * between two kernels costs the stream 6-10 us of idle time; tools that read kh_last_timings switch them on */
+int kh_set_phase_timers(int on);
 int kh_trim(void);                    /* current device: free cached twiddle tables, scratch and idle MSM workspaces (rebuilt on demand) */
 const char *kh_last_error(void);
 
@@ -409,6 +412,8 @@ int kh_dev_copy(void *dst_dev, const void *src_dev, size_t bytes);   /* device-t
 int kh_dev_memset_zero(void *dst_dev, size_t bytes);
 int kh_dev_upload(void *dst_dev, const void *src_host, size_t bytes);
 int kh_dev_download(void *dst_host, const void *src_dev, size_t bytes);
+/* count 32-byte records (field elements) at dst_dev set to `value`; asynchronous on the main stream, the value travels in the kernel's arguments */
+int kh_dev_fill_elements(uint64_t *dst_dev, const uint64_t value[4], size_t count);
 /* `rows` runs of `width` bytes, `src_pitch` / `dst_pitch` bytes apart: the witness columns of a prover ([Vec<F>; 15], each shorter than
  * the domain: kimchi/src/prover.rs:254-266) go into their padded device columns in one transfer. */
 int kh_dev_upload_2d(void *dst_dev, size_t dst_pitch, const void *src_host, size_t src_pitch, size_t width, size_t rows);

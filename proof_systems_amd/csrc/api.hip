@@ -66,10 +66,36 @@ static Context& ctx_of(int dev) {
 }
 Context& ctx() { return ctx_of(current_device()); }
 
+// Small host -> device uploads as a KERNEL whose argument block carries the data (<= 3.5 KB by value): queueing an asynchronous copy costs the host ~10 us
+// against ~5 us for a launch, and the vector steps of a proof -- token programs, pointer tables, constants: 20 such uploads before the opening -- are
+// bound by the host's submission rate (tools/proof_timeline.py: ~10 us of idle GPU in front of every small copy).
+namespace {
+struct StageBlob { uint32_t w[896]; };
+__global__ void k_stage_put(uint32_t* __restrict__ dst, StageBlob b, uint32_t nwords) {
+    for (uint32_t i = threadIdx.x; i < nwords; i += blockDim.x) dst[i] = b.w[i];
+}
+__global__ void k_zero_words(uint32_t* __restrict__ dst, size_t nwords) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nwords) dst[i] = 0u;
+}
+__global__ void k_fill_elements(uint64_t* __restrict__ dst, uint64_t v0, uint64_t v1, uint64_t v2, uint64_t v3, size_t count) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) { dst[4 * i] = v0; dst[4 * i + 1] = v1; dst[4 * i + 2] = v2; dst[4 * i + 3] = v3; }
+}
+}  // namespace
 int Context::stage_upload(void* dst_dev, std::initializer_list<std::pair<const void*, size_t>> parts) {
     size_t total = 0;
     for (const auto& pr : parts) total += pr.second;
     if (total == 0) return KH_OK;
+    static const bool put_kernel = !(getenv("KH_STAGE_PUT") && atoi(getenv("KH_STAGE_PUT")) == 0);
+    if (put_kernel && total <= sizeof(StageBlob) && total % 4 == 0 && ((uintptr_t)dst_dev & 3) == 0) {
+        StageBlob b;
+        size_t o = 0;
+        for (const auto& pr : parts) { if (pr.second) memcpy((char*)b.w + o, pr.first, pr.second); o += pr.second; }
+        hipLaunchKernelGGL(k_stage_put, dim3(1), dim3(256), 0, stream, (uint32_t*)dst_dev, b, (uint32_t)(total / 4));
+        KH_HIP(hipGetLastError());
+        return KH_OK;
+    }
     const size_t need = (total + 63) & ~(size_t)63;
     if (need > stage_cap / 4) {                       // a large table, or no ring yet: make room for many calls per turn
         const size_t cap = std::max<size_t>((size_t)1 << 20, 8 * need);
@@ -350,6 +376,17 @@ int kh_private_context_begin(void) {
     c->mark_async();                                      // ... and this context's side slots wait for its main stream in turn
     tl_private[dev] = c;
     { std::lock_guard<std::mutex> lk(g_ctx_mu); g_private_active[dev]++; }
+    return KH_OK;
+}
+// Per-phase HIP events (kh_last_timings) on the calling thread's current context (its private one between kh_private_context_begin and _end).  OFF by
+// default since round 5: an event recorded between two kernels costs the stream ~6-10 us of idle time (tools/proof_timeline.py) -- a proof queued ~60
+// of them (10.2 -> 9.9 ms without), the pipelined MSM loop lost 1-4 %.  The Python binding's init() switches them on (its users are tools and tests).
+int kh_set_phase_timers(int on) {
+    int rc = ensure_init(); if (rc) return rc;
+    Context& C = ctx();
+    std::lock_guard<std::mutex> lk(C.mu);
+    C.timer.enabled = on != 0; C.timer.n = 0;
+    for (int i = 0; i < MSM_SLOTS; i++) { C.slot[i].timer.enabled = on != 0; C.slot[i].timer.n = 0; }
     return KH_OK;
 }
 int kh_private_context_active(void) {
@@ -2026,8 +2063,23 @@ int kh_dev_memset_zero(void* dst_dev, size_t bytes) {
     KH_REQUIRE(dst_dev, "kh_dev_memset_zero: null pointer");
     Context& C = ctx();
     std::lock_guard<std::mutex> lk(C.mu);
-    KH_HIP(hipMemsetAsync(dst_dev, 0, bytes, C.stream));
+    if (bytes <= ((size_t)1 << 16) && bytes % 4 == 0 && ((uintptr_t)dst_dev & 3) == 0) {       // small: a launch is cheaper to queue than a memset node
+        hipLaunchKernelGGL(k_zero_words, dim3((unsigned)((bytes / 4 + 255) / 256)), dim3(256), 0, C.stream, (uint32_t*)dst_dev, bytes / 4);
+        KH_HIP(hipGetLastError());
+    } else KH_HIP(hipMemsetAsync(dst_dev, 0, bytes, C.stream));
     if (hipEventRecord(C.order_ev, C.stream) == hipSuccess) C.main_dirty = true;
+    return KH_OK;
+}
+// count field elements (or any 32-byte records) set to `value`, queued on the main stream: the value travels in the kernel's arguments (no staging copy)
+int kh_dev_fill_elements(uint64_t* dst_dev, const uint64_t value[4], size_t count) {
+    int rc = ensure_init(); if (rc) return rc;
+    if (count == 0) return KH_OK;
+    KH_REQUIRE(dst_dev && value, "kh_dev_fill_elements: null pointer");
+    Context& C = ctx();
+    std::lock_guard<std::mutex> lk(C.mu);
+    hipLaunchKernelGGL(k_fill_elements, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, C.stream, dst_dev, value[0], value[1], value[2], value[3], count);
+    KH_HIP(hipGetLastError());
+    C.mark_async();
     return KH_OK;
 }
 // The library's streams are non-blocking (they do not synchronise with the null stream hipMemcpy uses), so both copies

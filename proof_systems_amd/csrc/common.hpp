@@ -76,7 +76,7 @@ struct PhaseTimer {
     const char* names[MAXP];
     int n = 0;
     bool created = false;
-    bool enabled = true;
+    bool enabled = false;                     // kh_set_phase_timers: an event between two kernels costs the stream 6-10 us of idle time
     int init() {
         if (created) return KH_OK;
         for (int i = 0; i <= MAXP; i++) KH_HIP(hipEventCreate(&ev[i]));

@@ -368,6 +368,12 @@ __device__ __forceinline__ u32 pick_K(u32 total, u32 room, u32 kmin, const KTab&
     }
     return K < lo ? lo : (K > MAX_K ? MAX_K : K);
 }
+// the length histogram of the task ordering and the hot-bucket list's two counters, emptied for the launch sequence that follows
+__global__ void k_task_reset(u32* __restrict__ len_hist, u32* __restrict__ big) {
+    KH_HIGH_PRIO();
+    if (threadIdx.x <= MAX_K) len_hist[threadIdx.x] = 0;
+    if (threadIdx.x < 2) big[threadIdx.x] = 0;
+}
 __global__ void k_ntask(const u32* __restrict__ off, size_t nkeys, u32 room, u32 kmin, KTab ktab, u32* __restrict__ nt, u32* __restrict__ len_hist, u32* __restrict__ handed) {
     KH_HIGH_PRIO();
     __shared__ u32 h[MAX_K + 1];
@@ -1866,7 +1872,7 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
     }
     if (!fused && !wide) {
         // tasks
-        KH_HIP(hipMemsetAsync(len_hist, 0, (MAX_K + 1) * sizeof(u32), s));
+        hipLaunchKernelGGL(k_task_reset, dim3(1), dim3(320), 0, s, len_hist, C.ws_biglist.as<u32>());      // (two memset nodes cost the host ~10 us each to queue)
         hipLaunchKernelGGL(k_ntask, dim3((unsigned)((nkeys + 1 + 255) / 256)), dim3(256), 0, s, C.ws_off.as<u32>(), nkeys, room, kmin, ktab, C.ws_ntask.as<u32>(), len_hist, C.ws_handed.as<u32>());
         if ((rc = exclusive_scan_u32(C.ws_ntask.as<u32>(), C.ws_toff.as<u32>(), nkeys + 1, C.ws_scan_tmp, s))) return rc;
         static const int rank_min_log = getenv("KH_RANK_MIN_LOG") ? atoi(getenv("KH_RANK_MIN_LOG")) : 22;   // below ~4M entries the three extra launches cost more than the ordering saves
@@ -1877,7 +1883,6 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
         } else {                     // small problems are launch-latency bound: keep the key order
             order = nullptr; roff = C.ws_toff.as<u32>();
         }
-        KH_HIP(hipMemsetAsync(C.ws_biglist.p, 0, 2 * sizeof(u32), s));
         C.timer.mark("tasks", s);
     }
     // 5 accumulate: the lazy 29-bit-limb kernel, then the exact kernel over the (almost always zero) tasks it handed over

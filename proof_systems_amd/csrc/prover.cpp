@@ -315,7 +315,11 @@ int kh_prove_full(kh_prover_index_t* ix, const uint64_t* witness, size_t rows, c
         bool mine = false;
         ~PrivateContext() { if (mine) (void)kh_private_context_end(); }
     } private_context;
-    if (!(flags & KH_PROVE_SHARED_CONTEXT) && !kh_private_context_active()) { KP(kh_private_context_begin()); private_context.mine = true; }
+    if (!(flags & KH_PROVE_SHARED_CONTEXT) && !kh_private_context_active()) {
+        KP(kh_private_context_begin()); private_context.mine = true;
+        static const bool keep_timers = getenv("KH_PROVE_TIMERS") && atoi(getenv("KH_PROVE_TIMERS")) != 0;
+        KP(kh_set_phase_timers(keep_timers ? 1 : 0));    // (this context is ours for the call: no per-phase events between the kernels of the proof; a pooled context may come with them on)
+    }
     // ---- the randomness of the whole proof, in the reference's draw order
     const size_t need = kh_prove_randomness_count(ix, witness != nullptr);
     std::vector<fe> rnd(need + 64, fe{{0, 0, 0, 0}});   // (slack: a miscounted draw reads zeros, and the count check at the end reports it)
@@ -435,11 +439,7 @@ int kh_prove_full(kh_prover_index_t* ix, const uint64_t* witness, size_t rows, c
         if (fl & (1u << bit)) { kh::set_error("%s", chk_msg[bit]); return KH_E_INVALID; }
         return KH_OK;
     };
-    auto set_const = [&](uint64_t* dst, const fe& val) {    // *dst = val, queued on the main stream (a one-row constant expression)
-        const uint32_t prog[2] = {KH_TOK_CONST, 0};
-        const uint64_t* c0[1] = {ev.p}; const size_t l0[1] = {n};
-        return kh_expr_evaluations_dev(fid, prog, 1, c0, l0, 1, val.l, 1, 1, 1, 0, 0, dst);
-    };
+    auto set_const = [&](uint64_t* dst, const fe& val) { return kh_dev_fill_elements(dst, val.l, 1); };    // *dst = val, queued on the main stream
     // ---- witness commitments: one batched MSM per chunk of the Lagrange basis, queued before the columns are interpolated
     uint64_t& tk = tickets.t[3]; bool& have_tk = tickets.live[3];
     if (nch == 1) { KP(kh_msm_submit(srs, (int)logn, 0, 0, ev.p, n, COLUMNS, 1, &tk)); have_tk = true; }

@@ -30,7 +30,7 @@ MSM_SLOTS = 4          # KH_MSM_SLOTS: jobs kh_msm_submit accepts before kh_msm_
 SYMBOLS = [
     "kh_sponge_new", "kh_sponge_clone", "kh_sponge_free", "kh_sponge_absorb_g", "kh_sponge_absorb", "kh_sponge_absorb_fr", "kh_sponge_challenge",
     "kh_sponge_challenge_field", "kh_sponge_squeeze_field", "kh_sponge_digest",
-    "kh_group_map_to_group", "kh_dev_copy", "kh_dev_memset_zero", "kh_ipa_open",
+    "kh_group_map_to_group", "kh_dev_copy", "kh_dev_memset_zero", "kh_dev_fill_elements", "kh_set_phase_timers", "kh_ipa_open",
     "kh_device_count", "kh_init", "kh_set_device", "kh_get_device", "kh_trim", "kh_srs_device", "kh_last_error", "kh_srs_create", "kh_msm_set_wide_min_n", "kh_srs_free", "kh_srs_size",
     "kh_srs_set_lagrange", "kh_srs_compute_lagrange", "kh_srs_get_lagrange", "kh_srs_lagrange_chunks",
     "kh_msm", "kh_msm_batch", "kh_msm_points", "kh_ntt", "kh_lde",
@@ -68,6 +68,7 @@ _lib.kh_srs_free.restype = None
 _lib.kh_srs_free.argtypes = [C.c_void_p]
 _lib.kh_srs_create.argtypes = [C.c_int, U64P, C.c_size_t, C.POINTER(C.c_void_p)]
 _lib.kh_msm_set_wide_min_n.argtypes = [C.c_size_t]
+_lib.kh_dev_fill_elements.argtypes = [C.c_void_p, U64P, C.c_size_t]
 _lib.kh_srs_set_lagrange.argtypes = [C.c_void_p, C.c_uint, C.c_uint, U64P, U8P, C.c_size_t]
 _lib.kh_srs_compute_lagrange.argtypes = [C.c_void_p, C.c_uint]
 _lib.kh_srs_get_lagrange.argtypes = [C.c_void_p, C.c_uint, C.c_uint, U64P, U8P]
@@ -178,8 +179,12 @@ def device_count() -> int:
     return _lib.kh_device_count()
 
 
-def init(device: int = -1):
+def init(device: int = -1, timers: bool = True):
+    """kh_init; timers: switch the per-phase HIP events behind last_timings() on for the device's shared context (the library's default is off: they cost
+    the stream a few microseconds each; this binding's users are tools and tests that read them)"""
     _check(_lib.kh_init(device))
+    if timers:
+        _check(_lib.kh_set_phase_timers(1))
 
 
 def set_device(device: int):
@@ -193,6 +198,11 @@ def get_device() -> int:
 
 def trim():
     _check(_lib.kh_trim())
+
+
+def set_phase_timers(on: bool):
+    """per-phase HIP events behind last_timings() on the calling thread's current context (kh_set_phase_timers)"""
+    _check(_lib.kh_set_phase_timers(int(bool(on))))
 
 
 def set_wide_min_n(n: int):

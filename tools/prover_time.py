@@ -6,6 +6,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import proof_systems_amd.khip as khip
 from proof_systems_amd import prover
 khip.init(0)
+if not os.environ.get("KH_IPA_TIMING"):
+    khip.set_phase_timers(False)          # the Python loop runs on the shared context: as a latency-critical caller would
 logn = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 t0 = time.perf_counter()
 ix = prover.bench_circuit_index(khip.VESTA, logn)

@@ -38,6 +38,7 @@ def phases(reps=7):
 
 
 def pipelined(depth=2):
+    khip.set_phase_timers(False)                                   # as bench.py's timed regions
     khip.sync()
     t0 = time.perf_counter()
     pending = []
@@ -48,6 +49,7 @@ def pipelined(depth=2):
     while pending:
         srs.msm_wait(pending.pop(0))
     khip.sync()
+    khip.set_phase_timers(True)
     return (time.perf_counter() - t0) / steps
 
 

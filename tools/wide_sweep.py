@@ -45,6 +45,8 @@ def child(tag):
     ph = {k: np.median(v) * 1e3 for k, v in acc.items()}
     tot = sum(v for k, v in ph.items() if not k.startswith("k_"))
     r = []
+    if not os.environ.get("KH_SWEEP_TIMERS_ON"):
+        khip.set_phase_timers(False)                               # as bench.py's timed regions
     for depth in (2, 3, 4):
         pipelined(depth, 10)
         r.append(sorted(pipelined(depth) for _ in range(3))[1])
