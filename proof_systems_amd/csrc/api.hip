@@ -1901,9 +1901,10 @@ int kh_coset_ntt_dev(int field, const uint64_t* coeffs_dev, unsigned log2_n, con
 // Host-pointer transforms (what the ark-poly patch calls: interpolate -> kh_ntt, evaluate_over_domain_by_ref -> kh_lde).  The reference calls them from
 // 15 / 16 rayon workers at once (prover.rs:370-381, constraints.rs:488-494), one column each, and each call moves 2 + 2 (or 2 + 16) MB over PCIe around
 // ~10-50 us of kernels.  Until round 4 a call held the library lock across upload, transform, download and a stream synchronisation on the one shared
-// workspace: sixteen callers ran strictly one after the other at ~27 GB/s (profiles/r04_pcie_inclusive.txt).  Now a call owns pool buffers, moves its data
+// workspace: sixteen callers ran strictly one after the other at ~27 GB/s (profiles/r04_pcie_inclusive.txt).  Now a call uses the calling thread's own device buffers, moves its data
 // on the calling thread's own copy stream WITHOUT the lock (uploads, downloads and their pageable-memory staging of different callers overlap, and PCIe
-// runs both directions at once), and takes the lock only to queue its kernels on the main stream, ordered by events.  A batched call is cut into column
+// runs both directions at once), and takes the lock only to queue its kernels on the main stream, ordered by events.  (A call owns the calling thread's
+// transfer buffers, not blocks of the shared pool.)  A batched call is cut into column
 // groups that go through the same three stages, so that group i's download runs under group i + 1's transform.
 }  // extern "C"
 namespace {
@@ -1911,10 +1912,11 @@ struct HostXferEvents {
     hipEvent_t up[KH_MAX_DEVICES] = {nullptr}, done[KH_MAX_DEVICES] = {nullptr};
     ~HostXferEvents() { for (int d = 0; d < KH_MAX_DEVICES; d++) { if (up[d]) (void)hipEventDestroy(up[d]); if (done[d]) (void)hipEventDestroy(done[d]); } }
 };
-struct PoolBuf {                                           // a pooled device block for the duration of a call
-    void* p = nullptr;
-    ~PoolBuf() { if (p) (void)kh_dev_free(p); }
-};
+// The calling thread's own device buffers for these transfers, per device, grown on demand and kept until the thread ends (a rayon worker lives as long
+// as its pool): the shared block pool is the wrong place for them -- once a prover's buffers have filled it to its limit, a freed 16 MB block went
+// back to the driver (hipFree synchronises the device) and the next call allocated afresh: 16 concurrent extensions took 11.6 ms inside bench.py's
+// process against 5.2 ms in a fresh one.
+struct ThreadXferBufs { DevBuf in[KH_MAX_DEVICES], out[KH_MAX_DEVICES]; };
 // in -> [upload] -> din -> run(din, dout, columns) -> dout -> [download] -> out, `batch` columns of in_col / out_col bytes, in groups
 template <class Run>
 int host_transform(const uint64_t* in, size_t in_col, uint64_t* out, size_t out_col, size_t batch, bool in_place, Run run) {
@@ -1926,11 +1928,11 @@ int host_transform(const uint64_t* in, size_t in_col, uint64_t* out, size_t out_
     // column groups: at most four, at least ~4 MB of output each (a group costs three stream hand-overs)
     size_t groups = batch < 4 ? batch : 4;
     while (groups > 1 && (batch / groups) * out_col < ((size_t)4 << 20)) groups--;
-    PoolBuf din, dout;
+    static thread_local ThreadXferBufs bufs;
     int rc;
-    if ((rc = kh_dev_alloc(&din.p, batch * in_col))) return rc;
-    if (!in_place && (rc = kh_dev_alloc(&dout.p, batch * out_col))) return rc;
-    char* const di = (char*)din.p; char* const dst_dev = in_place ? di : (char*)dout.p;
+    if ((rc = bufs.in[d].reserve(batch * in_col))) return rc;
+    if (!in_place && (rc = bufs.out[d].reserve(batch * out_col))) return rc;
+    char* const di = (char*)bufs.in[d].p; char* const dst_dev = in_place ? di : (char*)bufs.out[d].p;
     size_t c0 = 0;
     for (size_t g = 0; g < groups; g++) {
         const size_t c1 = batch * (g + 1) / groups, cols = c1 - c0;
@@ -1947,7 +1949,7 @@ int host_transform(const uint64_t* in, size_t in_col, uint64_t* out, size_t out_
         KH_HIP(hipMemcpyAsync((char*)out + c0 * out_col, dst_dev + c0 * out_col, cols * out_col, hipMemcpyDeviceToHost, cs));
         c0 = c1;
     }
-    KH_HIP(hipStreamSynchronize(cs));                     // everything this call queued anywhere has finished: the pool blocks may go back
+    KH_HIP(hipStreamSynchronize(cs));                     // everything this call queued anywhere has finished: the buffers are free for the thread's next call
     {
         std::lock_guard<std::mutex> lk(C.mu);
         collect_timings(C, C.timer);                       // (the phases of the LAST transform queued on this context: exact for a lone caller)
