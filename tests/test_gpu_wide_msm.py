@@ -100,6 +100,32 @@ def test_wide_msm_batch_of_two_and_below_threshold(khip):
     assert not ginf[0] and np.array_equal(got[0], w)
 
 
+def test_wide_msm_ragged_sizes_and_digit_boundaries(khip):
+    """Sizes that are no power of two (the sort's blocks and runs end anywhere), and scalars built from the boundary digits of the signed 20-bit
+    decomposition: windows equal to 2^19 (the largest positive digit), 2^19 + 1 (the first that turns negative and carries), 2^20 - 1, 0, plus p - 1 and 1."""
+    p_s = P.Fp.p
+    rng = np.random.default_rng(99)
+    for n in (4097, 5000, 12345):
+        srs = khip.Srs.create(khip.VESTA, n)
+        g = srs.get_g()
+        vals = []
+        for i in range(n):
+            if i < 4:
+                vals.append([0, 1, p_s - 1, p_s - 2][i])
+                continue
+            v = 0
+            for w in range(13):
+                d = [1 << 19, (1 << 19) + 1, (1 << 20) - 1, 0, int(rng.integers(0, 1 << 20))][int(rng.integers(0, 5))]
+                v |= d << (20 * w)
+            vals.append(v % p_s)
+        sc = cref.ints_to_limbs(vals)
+        got, ginf = srs.msm(sc, mont=False)
+        assert _wide_ran(khip)
+        want, winf = cref.msm(0, g, sc, scalars_mont=False, threads=THREADS)
+        srs.close()
+        assert bool(ginf) == winf and (winf or np.array_equal(got, want)), n
+
+
 @pytest.mark.parametrize("cid", [0, 1])
 def test_wide_degenerate_bases(khip, cid):
     rng = np.random.default_rng(70 + cid)
