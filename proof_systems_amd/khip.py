@@ -480,6 +480,12 @@ class DevBuf:
         _check(_lib.kh_dev_memset_zero(C.c_void_p(self.ptr), self.nbytes))
         return self
 
+    def fill_elements(self, offset_elems: int, value, count: int):
+        """count 32-byte records from element offset_elems on set to `value` (4 limbs), queued on the main stream (kh_dev_fill_elements)"""
+        assert (offset_elems + count) * 32 <= self.nbytes
+        _check(_lib.kh_dev_fill_elements(C.c_void_p(self.ptr + 32 * offset_elems), _p64(_c64(value, (4,))), count))
+        return self
+
 
 class DevView:
     def __init__(self, ptr: int):
