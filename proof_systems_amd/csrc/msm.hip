@@ -399,14 +399,19 @@ __global__ void k_ntask(const u32* __restrict__ off, size_t nkeys, u32 room, u32
 // a wave run chains of (nearly) the same length (bucket sizes are Poisson-distributed: +-20 % at 32
 // entries per bucket) and the short tasks fill the end of the launch.
 // len_hist -> cursor[L] = first rank of length L (descending order)
-__global__ void k_len_starts(const u32* __restrict__ len_hist, u32* __restrict__ cursor) {
+__global__ void __launch_bounds__(320) k_len_starts(const u32* __restrict__ len_hist, u32* __restrict__ cursor) {
     KH_HIGH_PRIO();
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
+    // thread L: the number of keys with a longer task (one thread walking the 257 bins took 11 us of every batched MSM)
+    __shared__ u32 h[MAX_K + 1];
+    if (threadIdx.x <= MAX_K) h[threadIdx.x] = len_hist[threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x <= MAX_K) {
         u32 run = 0;
-        for (int L = (int)MAX_K; L >= 0; L--) { cursor[L] = run; run += len_hist[L]; }
+        for (u32 L = threadIdx.x + 1; L <= MAX_K; L++) run += h[L];
+        cursor[threadIdx.x] = run;
     }
 }
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 k_len_rank(const u32* __restrict__ off, const u32* __restrict__ nt, size_t nkeys,
            u32* __restrict__ cursor, u32* __restrict__ order, u32* __restrict__ rnt) {
     KH_HIGH_PRIO();
@@ -1873,12 +1878,13 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
     if (!fused && !wide) {
         // tasks
         hipLaunchKernelGGL(k_task_reset, dim3(1), dim3(320), 0, s, len_hist, C.ws_biglist.as<u32>());      // (two memset nodes cost the host ~10 us each to queue)
-        hipLaunchKernelGGL(k_ntask, dim3((unsigned)((nkeys + 1 + 255) / 256)), dim3(256), 0, s, C.ws_off.as<u32>(), nkeys, room, kmin, ktab, C.ws_ntask.as<u32>(), len_hist, C.ws_handed.as<u32>());
+        // (1024-thread blocks: the per-(block, length) global atomics of k_ntask / k_len_rank serialise on ~40 hot addresses -- 25 us each at 256 threads per block)
+        hipLaunchKernelGGL(k_ntask, dim3((unsigned)((nkeys + 1 + 1023) / 1024)), dim3(1024), 0, s, C.ws_off.as<u32>(), nkeys, room, kmin, ktab, C.ws_ntask.as<u32>(), len_hist, C.ws_handed.as<u32>());
         if ((rc = exclusive_scan_u32(C.ws_ntask.as<u32>(), C.ws_toff.as<u32>(), nkeys + 1, C.ws_scan_tmp, s))) return rc;
         static const int rank_min_log = getenv("KH_RANK_MIN_LOG") ? atoi(getenv("KH_RANK_MIN_LOG")) : 22;   // below ~4M entries the three extra launches cost more than the ordering saves
         if (M >= ((size_t)1 << rank_min_log)) {
-            hipLaunchKernelGGL(k_len_starts, dim3(1), dim3(64), 0, s, len_hist, cursor);
-            hipLaunchKernelGGL(k_len_rank, dim3((unsigned)((nkeys + 1 + 255) / 256)), dim3(256), 0, s, C.ws_off.as<u32>(), C.ws_ntask.as<u32>(), nkeys, cursor, order, rnt);
+            hipLaunchKernelGGL(k_len_starts, dim3(1), dim3(320), 0, s, len_hist, cursor);
+            hipLaunchKernelGGL(k_len_rank, dim3((unsigned)((nkeys + 1 + 1023) / 1024)), dim3(1024), 0, s, C.ws_off.as<u32>(), C.ws_ntask.as<u32>(), nkeys, cursor, order, rnt);
             if ((rc = exclusive_scan_u32(rnt, roff, nkeys + 1, C.ws_scan_tmp, s))) return rc;
         } else {                     // small problems are launch-latency bound: keep the key order
             order = nullptr; roff = C.ws_toff.as<u32>();
