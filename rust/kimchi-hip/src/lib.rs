@@ -442,10 +442,36 @@ where
         // `EFqSponge` is not `Clone` here (lib.rs:289-297 of poly-commitment: only `FqSponge`), so the sponge is swapped against a
         // fresh one (`FqSponge::new`, poseidon/src/sponge.rs:16) and -- like the vectors -- put back afterwards in the state the inner
         // verifier left it in, which is what the reference's own `verify` does to the caller's batch.
-        let mut inner: Vec<BatchEvaluationProof<G, EFqSponge, OpeningProof<G, FULL_ROUNDS>, FULL_ROUNDS>> = Vec::with_capacity(batch.len());
-        for b in batch.iter_mut() {
+        // The parts go back from a drop guard, so a panic inside the inner verifier (it `assert!`s on malformed batches) does not leave the
+        // caller's batch holding placeholder sponges and emptied vectors.
+        struct Restore<'s, 'a, G, S, const R: usize>
+        where
+            G: HipCurve + KimchiCurve<R>,
+            G::BaseField: PrimeField,
+            S: FqSponge<G::BaseField, G, G::ScalarField, R>,
+        {
+            batch: &'s mut [BatchEvaluationProof<'a, G, S, GpuOpeningProof<G, R>, R>],
+            inner: Vec<BatchEvaluationProof<'a, G, S, OpeningProof<G, R>, R>>,
+        }
+        impl<'s, 'a, G, S, const R: usize> Drop for Restore<'s, 'a, G, S, R>
+        where
+            G: HipCurve + KimchiCurve<R>,
+            G::BaseField: PrimeField,
+            S: FqSponge<G::BaseField, G, G::ScalarField, R>,
+        {
+            fn drop(&mut self) {
+                for (b, i) in self.batch.iter_mut().zip(self.inner.drain(..)) {
+                    b.sponge = i.sponge;
+                    b.evaluations = i.evaluations;
+                    b.evaluation_points = i.evaluation_points;
+                }
+            }
+        }
+        let mut guard: Restore<'_, '_, G, EFqSponge, FULL_ROUNDS> = Restore { inner: Vec::with_capacity(batch.len()), batch };
+        for k in 0..guard.batch.len() {
+            let b = &mut guard.batch[k];
             let opening: &GpuOpeningProof<G, FULL_ROUNDS> = b.opening; // `&'a Self` is `Copy`: not a borrow of `batch`
-            inner.push(BatchEvaluationProof {
+            let moved = BatchEvaluationProof {
                 sponge: core::mem::replace(&mut b.sponge, EFqSponge::new(G::other_curve_sponge_params())),
                 evaluations: core::mem::take(&mut b.evaluations),
                 evaluation_points: core::mem::take(&mut b.evaluation_points),
@@ -453,14 +479,11 @@ where
                 evalscale: b.evalscale,
                 opening: &opening.0,
                 combined_inner_product: b.combined_inner_product,
-            });
+            };
+            guard.inner.push(moved);
         }
-        let accepted = srs.inner.verify(group_map, &mut inner, rng);
-        for (b, i) in batch.iter_mut().zip(inner) {
-            b.sponge = i.sponge;
-            b.evaluations = i.evaluations;
-            b.evaluation_points = i.evaluation_points;
-        }
+        let accepted = srs.inner.verify(group_map, &mut guard.inner, rng);
+        drop(guard); // puts sponge / evaluations / evaluation_points back, in the state the inner verifier left them in
         accepted
     }
 }
