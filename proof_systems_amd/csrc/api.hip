@@ -1917,6 +1917,10 @@ struct HostXferEvents {
 // back to the driver (hipFree synchronises the device) and the next call allocated afresh: 16 concurrent extensions took 11.6 ms inside bench.py's
 // process against 5.2 ms in a fresh one.
 struct ThreadXferBufs { DevBuf in[KH_MAX_DEVICES], out[KH_MAX_DEVICES]; };
+static size_t xfer_keep_bytes() {                                  // per buffer, per thread (16 columns of 2^19 elements = 268 MB); KH_XFER_KEEP_MB overrides
+    static const size_t v = getenv("KH_XFER_KEEP_MB") ? (size_t)atol(getenv("KH_XFER_KEEP_MB")) << 20 : (size_t)1 << 30;
+    return v;
+}
 // in -> [upload] -> din -> run(din, dout, columns) -> dout -> [download] -> out, `batch` columns of in_col / out_col bytes, in groups
 template <class Run>
 int host_transform(const uint64_t* in, size_t in_col, uint64_t* out, size_t out_col, size_t batch, bool in_place, Run run) {
@@ -1933,23 +1937,40 @@ int host_transform(const uint64_t* in, size_t in_col, uint64_t* out, size_t out_
     if ((rc = bufs.in[d].reserve(batch * in_col))) return rc;
     if (!in_place && (rc = bufs.out[d].reserve(batch * out_col))) return rc;
     char* const di = (char*)bufs.in[d].p; char* const dst_dev = in_place ? di : (char*)bufs.out[d].p;
-    size_t c0 = 0;
-    for (size_t g = 0; g < groups; g++) {
-        const size_t c1 = batch * (g + 1) / groups, cols = c1 - c0;
-        KH_HIP(hipMemcpyAsync(di + c0 * in_col, (const char*)in + c0 * in_col, cols * in_col, hipMemcpyHostToDevice, cs));
-        KH_HIP(hipEventRecord(ev.up[d], cs));
-        {
-            std::lock_guard<std::mutex> lk(C.mu);
-            KH_HIP(hipStreamWaitEvent(C.stream, ev.up[d], 0));
-            if ((rc = run(C, (uint64_t*)(di + c0 * in_col), (uint64_t*)(dst_dev + c0 * out_col), cols))) return rc;
-            KH_HIP(hipEventRecord(ev.done[d], C.stream));
-            C.mark_async();
+    // (the queueing in a lambda: whatever fails, the copy stream is drained before this returns -- a caller that sees an error may free `in` / `out`
+    // at once, and a copy queued earlier in the call may still be reading or writing them)
+    auto queue_all = [&]() -> int {
+        size_t c0 = 0;
+        for (size_t g = 0; g < groups; g++) {
+            const size_t c1 = batch * (g + 1) / groups, cols = c1 - c0;
+            KH_HIP(hipMemcpyAsync(di + c0 * in_col, (const char*)in + c0 * in_col, cols * in_col, hipMemcpyHostToDevice, cs));
+            KH_HIP(hipEventRecord(ev.up[d], cs));
+            {
+                std::lock_guard<std::mutex> lk(C.mu);
+                KH_HIP(hipStreamWaitEvent(C.stream, ev.up[d], 0));
+                int rr;
+                if ((rr = run(C, (uint64_t*)(di + c0 * in_col), (uint64_t*)(dst_dev + c0 * out_col), cols))) return rr;
+                KH_HIP(hipEventRecord(ev.done[d], C.stream));
+                C.mark_async();
+            }
+            KH_HIP(hipStreamWaitEvent(cs, ev.done[d], 0));
+            KH_HIP(hipMemcpyAsync((char*)out + c0 * out_col, dst_dev + c0 * out_col, cols * out_col, hipMemcpyDeviceToHost, cs));
+            c0 = c1;
         }
-        KH_HIP(hipStreamWaitEvent(cs, ev.done[d], 0));
-        KH_HIP(hipMemcpyAsync((char*)out + c0 * out_col, dst_dev + c0 * out_col, cols * out_col, hipMemcpyDeviceToHost, cs));
-        c0 = c1;
+        return KH_OK;
+    };
+    rc = queue_all();
+    const hipError_t drained = hipStreamSynchronize(cs);  // everything this call queued anywhere has finished: the buffers are free for the thread's next call
+    if (rc == KH_OK && drained != hipSuccess) { set_error("hipStreamSynchronize (transfer stream): %s", hipGetErrorString(drained)); rc = KH_E_DEVICE; }
+    if (rc != KH_OK) {                                     // the transform kernels of a failed call may still be queued on the library stream, reading the buffers
+        std::lock_guard<std::mutex> lk(C.mu);
+        (void)hipStreamSynchronize(C.stream);
     }
-    KH_HIP(hipStreamSynchronize(cs));                     // everything this call queued anywhere has finished: the buffers are free for the thread's next call
+    // a thread keeps its two buffers for its next call -- up to a bound: after a huge batch they go back (the PCIe time of such a call dwarfs an allocation,
+    // and kh_trim cannot reach another thread's buffers)
+    if (bufs.in[d].cap > xfer_keep_bytes()) bufs.in[d].release();
+    if (bufs.out[d].cap > xfer_keep_bytes()) bufs.out[d].release();
+    if (rc != KH_OK) return rc;
     {
         std::lock_guard<std::mutex> lk(C.mu);
         collect_timings(C, C.timer);                       // (the phases of the LAST transform queued on this context: exact for a lone caller)

@@ -1698,7 +1698,7 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
     static const u32 wide_acc_blocks = getenv("KH_WIDE_ACC_BLOCKS") ? (u32)std::max(2, atoi(getenv("KH_WIDE_ACC_BLOCKS"))) : 3u;
     static const u32 wide_rlog = getenv("KH_WIDE_RLOG") ? (u32)atoi(getenv("KH_WIDE_RLOG")) : 4u;
     const size_t wide_acc_lds = wide_acc_blocks >= 4 ? 0 : (size_t)(160 * 1024 / (wide_acc_blocks + 1) + 1024) & ~(size_t)1023;
-    if (wide) {                                            // bucket = (hi digit, lo digit); chunks of 8 buckets in the first reduction level
+    if (wide) {                                            // bucket = (hi digit, lo digit); chunks of 2^rlog buckets in the first reduction level
         if ((rc = C.ws_xlist.reserve((3 * max_tasks + 8) * sizeof(u32)))) return rc;       // (key, chunk) pairs of the extra chunks, then the split buckets' keys
         if ((rc = C.ws_handed.reserve((2 * max_tasks + 4) * sizeof(u32)))) return rc;
         wg.nb = nb; wg.lo = (u32)c / 2; wg.hi = (u32)(c - 1) - wg.lo; wg.rlog = wide_rlog;

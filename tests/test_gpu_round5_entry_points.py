@@ -84,3 +84,32 @@ def test_argument_uploads_in_kernel_arguments_change_nothing():
         assert r.returncode == 0, r.stderr.decode()[-1500:]
         outs.append(r.stdout.decode().strip().splitlines()[-1])
     assert outs[0] == outs[1] and len(outs[0]) == 64
+
+
+XFER_WORKER = r"""
+import sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+import proof_systems_amd.khip as khip
+from oracle import cref
+khip.init(0)
+FP = khip.FP
+rng = np.random.default_rng(11)
+for rep in range(3):                                   # every call allocates afresh (the bound is 1 MB, the buffers are 2.3 / 18 MB) and gives them back
+    x = rng.integers(0, 1 << 62, size=(4, 1 << 14, 4), dtype=np.uint64)
+    ev = khip.ntt(FP, x, 14, False)
+    assert np.array_equal(ev, cref.ntt(FP, x, 14, False)), ("ntt", rep)
+    back = khip.ntt(FP, ev, 14, True)
+    assert np.array_equal(back, x), ("round trip", rep)
+    e8 = khip.lde(FP, x, 14, 3)
+    assert np.array_equal(e8, cref.lde(FP, x, 14, 3)), ("lde", rep)
+print("transforms ok")
+"""
+
+
+def test_host_buffer_transforms_release_oversized_thread_buffers():
+    """kh_ntt / kh_lde on host buffers keep two device buffers per calling thread -- up to a bound (1 GB each; KH_XFER_KEEP_MB overrides), above which a
+    call gives them back when it ends.  With the bound at 1 MB every call takes that path: same results, call after call."""
+    r = subprocess.run([sys.executable, "-c", XFER_WORKER, ROOT], env=dict(os.environ, KH_XFER_KEEP_MB="1"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-1500:]
+    assert r.stdout.decode().strip().endswith("transforms ok")
