@@ -674,17 +674,27 @@ static int msm_submit_locked(Context& C, kh_srs_t* srs, int basis, unsigned chun
 // The GPU wait happens WITHOUT the library lock: the slot stays busy (nobody else can take it), other threads can
 // enqueue on the remaining slots meanwhile (15 rayon workers call into the reference's SRS at once, prover.rs:329-351;
 // two provers can run their opening rounds side by side).  The short host part runs under the lock again.
+static thread_local double tl_last_wait_us = 0;           // spin / block part of the last wait_then_finish on this thread
 static int wait_then_finish(std::unique_lock<std::mutex>& lk, Context& C, MsmSlot& S, uint64_t* out_xy, uint8_t* out_inf) {
     hipEvent_t ev = S.done;
+    // completion by flag (MsmSlot::done_flag): what the job's last kernel will store, read while the context is still locked
+    const bool by_flag = S.done_by_flag && S.done_flag;
+    const uint32_t expect = S.done_expect;
     C.sync_inflight++;
     lk.unlock();
+    const auto tw0 = std::chrono::steady_clock::now();
     // a synchronous caller is latency-bound (an opening round is ~0.4 ms of GPU time, then ~40 us of transcript on this thread):
     // poll for up to a millisecond before blocking -- the blocking wait's wake-up alone costs 10-20 us
     static const long spin_us = getenv("KH_SPIN_US") ? atol(getenv("KH_SPIN_US")) : 1000;
     hipError_t e = hipErrorNotReady;
+    bool flag_seen = false;
     if (spin_us > 0) {
         const auto t0 = std::chrono::steady_clock::now();
-        for (;;) {
+        for (unsigned it = 0;; it++) {
+            if (by_flag) {                                 // the last kernel's own store (MsmSlot::done_flag); the event is looked at now and then, for errors
+                if (__atomic_load_n((const uint32_t*)S.done_flag, __ATOMIC_ACQUIRE) == expect) { flag_seen = true; e = hipSuccess; break; }
+                if ((it & 1023u) != 1023u) { __builtin_ia32_pause(); continue; }
+            }
             e = hipEventQuery(ev);
             if (e != hipErrorNotReady) break;
             if (std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > spin_us) break;
@@ -692,11 +702,12 @@ static int wait_then_finish(std::unique_lock<std::mutex>& lk, Context& C, MsmSlo
         }
     }
     if (e == hipErrorNotReady) { (void)hipGetLastError(); e = hipEventSynchronize(ev); }
+    tl_last_wait_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tw0).count();
     lk.lock();
     C.sync_inflight--;
     int rc;
     if (e != hipSuccess) { set_error("hipEventSynchronize: %s", hipGetErrorString(e)); S.busy = false; rc = KH_E_DEVICE; }
-    else rc = msm_finish(C, S, out_xy, out_inf);
+    else rc = msm_finish(C, S, out_xy, out_inf, flag_seen);
     C.cv.notify_all();
     return rc;
 }
@@ -1589,11 +1600,17 @@ static void ipa_sg_prelaunch_locked(kh_ipa_t* st, Context& C, int p, bool had_fo
     if (msm_enqueue(C, S, st->curve, bs, 0, srs->ipa_sg.as<uint64_t>(), st->n, 2, 1)) return;
     st->sg_slot = si;
 }
+// KH_IPA_TIMING: where a round's host time goes (accumulated per thread, printed and reset by kh_ipa_open)
+struct IpaRoundProf { double slot = 0, step = 0, enqueue = 0, wait = 0, finish = 0; };
+static thread_local IpaRoundProf tl_round_prof;
 int kh_ipa_round_lr(kh_ipa_t* st, const uint64_t rand_l[4], const uint64_t rand_r[4], uint64_t lr_xy[16], uint8_t lr_inf[2]) {
     kh::DeviceScope dev_scope_((st && st->srs) ? st->srs->device : -1);
     KH_REQUIRE(st && rand_l && rand_r && lr_xy && lr_inf, "kh_ipa_round_lr: null argument");
     KH_REQUIRE(st->cur > 1, "no round left: the vectors are folded to length 1");
     KH_REQUIRE(!st->lr_done, "kh_ipa_round_fold must follow kh_ipa_round_lr");
+    static const bool prof = getenv("KH_IPA_TIMING") != nullptr;
+    const auto pt0 = std::chrono::steady_clock::now();
+    auto us_since = [](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - a).count(); };
     Context& C = ctx();
     std::unique_lock<std::mutex> lk(C.mu);
     int si = acquire_slot(&lk, C, /*side_first=*/true);
@@ -1602,6 +1619,7 @@ int kh_ipa_round_lr(kh_ipa_t* st, const uint64_t rand_l[4], const uint64_t rand_
     KH_HIP(hipStreamWaitEvent(S.stream, st->ev, 0));
     const int p = st->pp, q = p ^ 1;
     const bool had_fold = st->pending;
+    const auto pt1 = std::chrono::steady_clock::now();
     // one launch: the recorded fold of the previous round (if any), this round's inner products and expanded scalars
     // (round 5 also wrote the MSM's window digits from this kernel, saving the k_digits launch: measured, opening 5.76 vs 5.76 ms -- not kept)
     int rc = ipa_round_step(S.stream, st->field, st->pending ? 1 : 0, st->a[p].as<uint64_t>(), st->b[p].as<uint64_t>(), st->coef[p].as<uint64_t>(),
@@ -1609,6 +1627,7 @@ int kh_ipa_round_lr(kh_ipa_t* st, const uint64_t rand_l[4], const uint64_t rand_
                             st->a[q].as<uint64_t>(), st->b[q].as<uint64_t>(), st->coef[q].as<uint64_t>(), rand_l, rand_r,
                             st->sc->as<uint64_t>(), st->partial->as<uint64_t>(), (unsigned*)(st->partial->as<uint64_t>() + st->partial_words));
     if (rc) return rc;
+    const auto pt2 = std::chrono::steady_clock::now();
     if (st->pending) { st->pp = q; st->pending = false; }
     kh_srs_t* srs = st->srs;
     MsmBasis bs; bs.pts = st->round_tab; bs.inf = nullptr; bs.n = srs->g_stride; bs.stride = srs->g_stride; bs.precomp_c = st->round_c;
@@ -1620,7 +1639,14 @@ int kh_ipa_round_lr(kh_ipa_t* st, const uint64_t rand_l[4], const uint64_t rand_
         for (hipGraphExec_t g : gone) (void)hipGraphExecDestroy(g);
         lk.lock();
     }
+    const auto pt3 = std::chrono::steady_clock::now();
     if ((rc = wait_then_finish(lk, C, S, lr_xy, lr_inf))) return rc;
+    if (prof) {
+        IpaRoundProf& P = tl_round_prof;
+        const double total_wait_finish = us_since(pt3);
+        P.slot += std::chrono::duration<double, std::micro>(pt1 - pt0).count(); P.step += std::chrono::duration<double, std::micro>(pt2 - pt1).count();
+        P.enqueue += std::chrono::duration<double, std::micro>(pt3 - pt2).count(); P.wait += tl_last_wait_us; P.finish += total_wait_finish - tl_last_wait_us;
+    }
     st->lr_done = true;
     return KH_OK;
 }
@@ -1848,6 +1874,9 @@ int kh_ipa_open(kh_srs_t* srs, const uint64_t* a_dev, size_t a_len, const uint64
     memcpy(z1, &z1v, 32); memcpy(z2, &z2v, 32);
     if (ipa_timing) {
         auto us = [](std::chrono::steady_clock::time_point x, std::chrono::steady_clock::time_point y) { return std::chrono::duration<double, std::micro>(y - x).count(); };
+        { const IpaRoundProf P = tl_round_prof; tl_round_prof = IpaRoundProf();
+          fprintf(stderr, "kh_ipa_open: per round inside launch + wait + finish: slot %.1f us, step kernel launch %.1f, MSM enqueue %.1f, wait %.1f, finish %.1f\n",
+                  P.slot / rounds, P.step / rounds, P.enqueue / rounds, P.wait / rounds, P.finish / rounds); }
         fprintf(stderr, "kh_ipa_open: begin %.0f us (of which shift + squeeze + to_group %.0f), %zu rounds %.0f us (per round: launch + wait + finish %.0f, sponge %.0f, to_field + inverse %.0f), sg %.0f us, delta / z1 / z2 %.0f us\n",
                 us(tp0, tp1), us(tp0, tp_map), rounds, us(tp1, tp2), t_lr / rounds, t_sponge / rounds, t_fold / rounds, us(tp2, tp3), us(tp3, std::chrono::steady_clock::now()));
     }

@@ -123,6 +123,13 @@ struct MsmSlot {
     // GPU they may never be -- its barriers then give up after a bounded spin, set this host-visible word, and msm_finish re-runs the job
     // with the multi-launch sort (the arguments of the pending job are kept for that) and disables the fused path for the process
     volatile uint32_t* host_abort = nullptr;          // pinned host memory, written by the kernel
+    // Completion by flag (round 5): when a job's LAST kernel is k_marginal_fin_q (it writes the result into `pinned` itself), the last block of that
+    // kernel to finish also stores the slot's launch count into done_flag (pinned).  A synchronous waiter polls that word instead of hipEventQuery:
+    // the host has the result ~5 us earlier (tools/latency/launch_latency.hip: 0.2 against 5.3 us after the kernel's last store).
+    volatile uint32_t* done_flag = nullptr;           // pinned host memory
+    DevBuf ws_done;                                    // [0] blocks finished in the running launch, [1] launches finished
+    uint32_t done_expect = 0;                          // launches enqueued with the flag so far (what done_flag shows when the newest one has ended)
+    bool done_by_flag = false, g_done_by_flag = false; // the job in flight (the captured graph) ends with the flag store
     bool fused_used = false, g_fused = false;
     struct { const void* pts; const uint8_t* inf; size_t bn, stride, batch_stride; int precomp_c; size_t offset; const uint64_t* scalars; size_t n, k; int mont, curve; } retry{};
 };

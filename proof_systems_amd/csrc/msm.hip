@@ -1369,7 +1369,7 @@ k_marginals_h(const uint8_t* __restrict__ buckets, MargGeom g, uint8_t* __restri
 // block (j, q), 128 threads = 32 quads, one per marginal: suffix scan + sum as in k_marginal_fin, exchanges through LDS
 template <class BF>
 __global__ void __launch_bounds__(128)
-k_marginal_fin_q(const uint8_t* __restrict__ marg, MargGeom g, uint8_t* __restrict__ out) {
+k_marginal_fin_q(const uint8_t* __restrict__ marg, MargGeom g, uint8_t* __restrict__ out, u32* __restrict__ done_ws, u32* __restrict__ done_flag) {
     KH_HIGH_PRIO();
     __shared__ u32 sh[32 * 32];
     const u32 j = blockIdx.x; const size_t q = blockIdx.y;
@@ -1402,6 +1402,20 @@ k_marginal_fin_q(const uint8_t* __restrict__ marg, MargGeom g, uint8_t* __restri
         r = quad_add<BF>(r, o);
     }
     if (threadIdx.x < 4) quad_store<BF>(out + (q * 3 + j) * 128, r);
+    if (done_ws) {                                         // completion by flag (common.hpp, MsmSlot::done_flag): `out` is pinned host memory
+        __threadfence_system();                            // this thread's result words are visible to the host ...
+        __syncthreads();
+        if (threadIdx.x == 0) {                            // ... before the launch count is, which the LAST block to get here stores
+            const u32 blocks = gridDim.x * gridDim.y;
+            if (__hip_atomic_fetch_add(done_ws, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == blocks - 1) {
+                __hip_atomic_store(done_ws, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // re-armed: launches on a slot are stream-ordered
+                const u32 e = done_ws[1] + 1;
+                done_ws[1] = e;
+                __threadfence_system();
+                __hip_atomic_store(done_flag, e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------ 6w / 7w wide windows: bucket sums + two-plane reduction
@@ -1780,6 +1794,16 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
             C.host_abort = (volatile uint32_t*)hp; *C.host_abort = 0;
         }
     }
+    // completion by flag (MsmSlot::done_flag): pinned word + two device words, once per slot
+    static const bool flag_off = getenv("KH_NO_DONE_FLAG") != nullptr;
+    const bool flag_on = !flag_off && (wide || planes);
+    if (flag_on && !C.done_flag) {
+        void* hp = nullptr;
+        KH_HIP(hipHostMalloc(&hp, 64, hipHostMallocDefault));
+        C.done_flag = (volatile uint32_t*)hp; *C.done_flag = 0; C.done_expect = 0;
+        if ((rc = C.ws_done.reserve(64))) return rc;
+        KH_HIP(hipMemset(C.ws_done.p, 0, 64));
+    }
     // hipGraph replay / capture (opt-in by the caller; the key covers everything the launches bake in)
     static const bool graphs_off = getenv("KH_NO_GRAPH") != nullptr;
     uint64_t key = 0;
@@ -1794,7 +1818,7 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
                                   (uint64_t)(uintptr_t)C.ws_buckets.p, (uint64_t)(uintptr_t)C.ws_seg.p, (uint64_t)(uintptr_t)C.ws_out.p, (uint64_t)(uintptr_t)C.ws_scan_tmp.p,
                                   (uint64_t)(uintptr_t)C.ws_biglist.p, (uint64_t)(uintptr_t)C.ws_order.p, (uint64_t)(uintptr_t)C.ws_chunks.p,
                                   (uint64_t)(uintptr_t)C.ws_handed.p, (uint64_t)(uintptr_t)C.ws_sync.p, (uint64_t)fused, (uint64_t)(uintptr_t)C.ws_mid.p, (uint64_t)part,
-                                  (uint64_t)(uintptr_t)tab_pts, (uint64_t)wide, (uint64_t)spread, (uint64_t)(uintptr_t)C.ws_xlist.p, (uint64_t)(uintptr_t)C.ws_b29.p, (uint64_t)(uintptr_t)C.ws_a1.p, (uint64_t)(uintptr_t)C.ws_a2.p,
+                                  (uint64_t)(uintptr_t)tab_pts, (uint64_t)wide, (uint64_t)spread, (uint64_t)(uintptr_t)C.ws_xlist.p, (uint64_t)(uintptr_t)C.ws_b29.p, (uint64_t)(uintptr_t)C.ws_a1.p, (uint64_t)(uintptr_t)C.ws_a2.p, (uint64_t)(uintptr_t)C.ws_done.p, (uint64_t)flag_on,
                                   DevBuf::generation().load()};
         for (uint64_t v : parts) key = fnv(key, v);
         if (C.gexec && C.gkey == key) {                    // replay
@@ -1802,6 +1826,7 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
             C.retry = {basis.pts, basis.inf, basis.n, basis.stride, basis.batch_stride, basis.precomp_c, offset, scalars_dev, n, k, mont, curve};
             KH_HIP(hipGraphLaunch(C.gexec, s));
             KH_HIP(hipEventRecord(C.done, s));
+            C.done_by_flag = C.g_done_by_flag; if (C.done_by_flag) C.done_expect++;
             C.busy = true; C.owner = std::this_thread::get_id(); C.ticket = Ctx.next_ticket++;
             C.curve = curve; C.W = C.g_W; C.c = C.g_c; C.precomp = C.g_precomp; C.k = k; C.ngroups = C.g_ngroups; C.planes = C.g_planes;
             C.plane_shift[0] = C.g_shift[0]; C.plane_shift[1] = C.g_shift[1]; C.wide_lo = C.g_wide_lo;
@@ -1959,6 +1984,7 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
     if (wide) hipLaunchKernelGGL((k_big_to29<BF>), dim3(16), dim3(64), 0, s, C.ws_buckets.as<uint8_t>(), C.ws_biglist.as<u32>(), b29, part_low);
     C.timer.mark("bucket_sum", s);
     // 7 reduce
+    u32* const done_ws = flag_on ? C.ws_done.as<u32>() : nullptr; u32* const done_flag = flag_on ? (u32*)C.done_flag : nullptr;
     bool direct_out = false;                              // latency path: the last kernel writes the (768-byte) result to host memory itself -- no copy node
     if (wide) {
         const u32 items = 2u * (nb >> wg.rlog) * (u32)ngroups;
@@ -1966,7 +1992,7 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
         C.timer.mark("reduce_a1", s);
         hipLaunchKernelGGL((k_wide_a2<BF>), dim3(2u << wg.lo, (unsigned)ngroups), dim3(64), 0, s, C.ws_a1.as<uint8_t>(), b29, wg, C.ws_a2.as<uint8_t>());
         hipLaunchKernelGGL((k_marginals_q<BF>), dim3(32, 3, (unsigned)tail_groups), dim3(256), 0, s, C.ws_a2.as<uint8_t>(), mg, C.ws_seg.as<uint8_t>());
-        hipLaunchKernelGGL((k_marginal_fin_q<BF>), dim3(3, (unsigned)tail_groups), dim3(128), 0, s, C.ws_seg.as<uint8_t>(), mg, (uint8_t*)C.pinned);
+        hipLaunchKernelGGL((k_marginal_fin_q<BF>), dim3(3, (unsigned)tail_groups), dim3(128), 0, s, C.ws_seg.as<uint8_t>(), mg, (uint8_t*)C.pinned, done_ws, done_flag);
         direct_out = true;
     } else if (planes) {
         // few groups: 256 threads per marginal (4 sequential additions + the tree: shortest chain); batches: one wave
@@ -1979,7 +2005,7 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
                 hipLaunchKernelGGL((k_marginals_h<BF>), dim3(32, 3, (unsigned)ngroups), dim3(256), 0, s, C.ws_buckets.as<uint8_t>(), mg, C.ws_seg.as<uint8_t>());
             else
             hipLaunchKernelGGL((k_marginals_q<BF>), dim3(32, 3, (unsigned)ngroups), dim3(quad_threads), 0, s, C.ws_buckets.as<uint8_t>(), mg, C.ws_seg.as<uint8_t>());
-            hipLaunchKernelGGL((k_marginal_fin_q<BF>), dim3(3, (unsigned)ngroups), dim3(128), 0, s, C.ws_seg.as<uint8_t>(), mg, (uint8_t*)C.pinned);   // straight into the pinned host staging
+            hipLaunchKernelGGL((k_marginal_fin_q<BF>), dim3(3, (unsigned)ngroups), dim3(128), 0, s, C.ws_seg.as<uint8_t>(), mg, (uint8_t*)C.pinned, done_ws, done_flag);   // straight into the pinned host staging
             direct_out = true;
         } else {
         static const bool marg_h_batch = !(getenv("KH_MARG_H_BATCH") && atoi(getenv("KH_MARG_H_BATCH")) == 0);
@@ -1990,7 +2016,7 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
         // the weighted tail is 3 x ngroups blocks however many MSMs there are: a pure latency chain (10 additions deep), so it takes the
         // lane-cooperative kernel for batches too (15 witness columns: 96 -> 35 us); the records have the same 128-byte layout
         static const bool fin_quad = !getenv("KH_NO_FIN_QUAD");
-        if (fin_quad) { hipLaunchKernelGGL((k_marginal_fin_q<BF>), dim3(3, (unsigned)ngroups), dim3(128), 0, s, C.ws_seg.as<uint8_t>(), mg, (uint8_t*)C.pinned); direct_out = true; }
+        if (fin_quad) { hipLaunchKernelGGL((k_marginal_fin_q<BF>), dim3(3, (unsigned)ngroups), dim3(128), 0, s, C.ws_seg.as<uint8_t>(), mg, (uint8_t*)C.pinned, done_ws, done_flag); direct_out = true; }
         else
         hipLaunchKernelGGL((k_marginal_fin<BF>), dim3(3, (unsigned)ngroups), dim3(64), 0, s, C.ws_seg.as<uint8_t>(), mg, C.ws_out.as<uint8_t>());
         }
@@ -2016,10 +2042,11 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
         if (g) (void)hipGraphDestroy(g);
         if (e != hipSuccess) { C.gexec = nullptr; set_error("hipGraph capture of the MSM launch sequence failed: %s", hipGetErrorString(e)); return KH_E_DEVICE; }
         C.gkey = key; C.gnout = nout; C.gscalars = scalars_dev; C.g_fused = fused;
-        C.g_W = W; C.g_c = c; C.g_precomp = precomp; C.g_planes = (int)planes; C.g_shift[0] = (int)mg.wd[0]; C.g_shift[1] = (int)mg.wd[1]; C.g_ngroups = ngroups; C.g_wide_lo = wide ? (int)wg.lo : 0;
+        C.g_W = W; C.g_c = c; C.g_precomp = precomp; C.g_planes = (int)planes; C.g_shift[0] = (int)mg.wd[0]; C.g_shift[1] = (int)mg.wd[1]; C.g_ngroups = ngroups; C.g_wide_lo = wide ? (int)wg.lo : 0; C.g_done_by_flag = direct_out && flag_on;
         KH_HIP(hipGraphLaunch(C.gexec, s));
     }
     KH_HIP(hipEventRecord(C.done, s));
+    C.done_by_flag = direct_out && flag_on; if (C.done_by_flag) C.done_expect++;
     C.busy = true; C.owner = std::this_thread::get_id(); C.ticket = Ctx.next_ticket++;
     C.curve = curve; C.W = W; C.c = c; C.precomp = precomp; C.k = k; C.ngroups = ngroups; C.planes = (int)planes; C.plane_shift[0] = (int)mg.wd[0]; C.plane_shift[1] = (int)mg.wd[1]; C.wide_lo = wide ? (int)wg.lo : 0;
     C.fused_used = fused;
@@ -2030,7 +2057,7 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
 int msm_enqueue(Context& C, MsmSlot& S, int curve, const MsmBasis& basis, size_t offset, const uint64_t* scalars_dev, size_t n, size_t k, int mont,
                 int use_graph) {
     if (n == 0 || k == 0) {          // nothing to launch: finish() emits k identities
-        S.busy = true; S.owner = std::this_thread::get_id(); S.ticket = C.next_ticket++; S.curve = curve; S.k = k; S.ngroups = 0; S.W = 0; S.c = 0; S.precomp = 1; S.planes = 0;
+        S.busy = true; S.owner = std::this_thread::get_id(); S.ticket = C.next_ticket++; S.curve = curve; S.k = k; S.ngroups = 0; S.W = 0; S.c = 0; S.precomp = 1; S.planes = 0; S.done_by_flag = false;
         KH_HIP(hipEventRecord(S.done, S.stream));
         return KH_OK;
     }
@@ -2039,8 +2066,9 @@ int msm_enqueue(Context& C, MsmSlot& S, int curve, const MsmBasis& basis, size_t
 }
 
 // 8 finish on the host: wait for the slot, Horner over the window sums (plain path), XYZZ -> affine
-int msm_finish(Context& C, MsmSlot& S, uint64_t* out_xy, uint8_t* out_inf) {
-    KH_HIP(hipEventSynchronize(S.done));
+int msm_finish(Context& C, MsmSlot& S, uint64_t* out_xy, uint8_t* out_inf, bool flag_seen) {
+    // (the per-phase events of a job -- tools only -- are read below: they need the event wait)
+    if (!(flag_seen && S.done_by_flag && S.timer.n == 0)) KH_HIP(hipEventSynchronize(S.done));
     if (S.fused_used && S.host_abort && *S.host_abort) {
         // the one-launch sort gave up at a grid barrier (its blocks were not all resident: the GPU is shared with another process):
         // everything behind it ran on garbage.  Re-run this job with the multi-launch sort and stay on it.

@@ -33,7 +33,8 @@ static constexpr int IPA_ROUND_C = 16;            // window width of the opening
 static constexpr int MSM_REPEATS = 1, MSM_SPREAD_SCALARS = 2;      // (MSM_SPREAD_SCALARS: msm.hip, "the caller vouches ...")
 int msm_enqueue(Context& C, MsmSlot& S, int curve, const MsmBasis& basis, size_t offset, const uint64_t* scalars_dev, size_t n, size_t k, int mont,
                 int use_graph = 0);
-int msm_finish(Context& C, MsmSlot& S, uint64_t* out_xy, uint8_t* out_inf);
+// flag_seen: the caller has read the job's launch count from S.done_flag (the result is in S.pinned): no wait on the event
+int msm_finish(Context& C, MsmSlot& S, uint64_t* out_xy, uint8_t* out_inf, bool flag_seen = false);
 int debug_field_op(Context& C, int field, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
 int debug_point_op(Context& C, int curve, int op, const uint64_t* p, const uint8_t* pinf, const uint64_t* q, const uint8_t* qinf, uint8_t* out, size_t n);
 
