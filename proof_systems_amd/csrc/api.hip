@@ -1631,7 +1631,11 @@ int kh_ipa_round_lr(kh_ipa_t* st, const uint64_t rand_l[4], const uint64_t rand_
     if (st->pending) { st->pp = q; st->pending = false; }
     kh_srs_t* srs = st->srs;
     MsmBasis bs; bs.pts = st->round_tab; bs.inf = nullptr; bs.n = srs->g_stride; bs.stride = srs->g_stride; bs.precomp_c = st->round_c;
-    if ((rc = msm_enqueue(C, S, st->curve, bs, 0, st->sc->as<uint64_t>(), st->n + 2, 2, 1, MSM_REPEATS | MSM_SPREAD_SCALARS))) return rc;
+    // Plain launches by default since round 5: the round's MSM is down to six launches (digits, one-launch sort, accumulation, bucket sums, two reduction
+    // kernels) which the host queues in ~25 us while the step kernel runs; replaying a captured graph (KH_IPA_GRAPH=1, rounds 2-4's way: every opening
+    // captures afresh in its second round) measured 5.58 / 5.53 / 5.65 ms per opening against 5.49 / 5.47 / 5.51 plain, alternated on one box.
+    static const int round_flags = ((getenv("KH_IPA_GRAPH") && atoi(getenv("KH_IPA_GRAPH")) != 0) ? MSM_REPEATS : 0) | MSM_SPREAD_SCALARS;
+    if ((rc = msm_enqueue(C, S, st->curve, bs, 0, st->sc->as<uint64_t>(), st->n + 2, 2, 1, round_flags))) return rc;
     if (st->sg_want && st->cur == 2) { st->sg_want = false; ipa_sg_prelaunch_locked(st, C, p, had_fold); }
     if (!st->retired.empty()) {                           // the GPU is busy with this round for the next ~0.3 ms; other callers are not held up:
         std::vector<hipGraphExec_t> gone; gone.swap(st->retired);
