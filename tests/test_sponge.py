@@ -83,3 +83,41 @@ def test_fq_sponge_transcript_matches_oracle(khip, cid):
             got = V(curve.scalar, c1.digest())
             x = c2.challenge_fq()
             assert got == (x if x < curve.scalar.p else 0)
+
+
+PERM_WORKER = r"""
+import sys, hashlib
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+import proof_systems_amd.khip as khip
+from oracle import pasta as P
+rng = np.random.default_rng(2024)
+h = hashlib.sha256()
+for kind, curve in ((khip.Sponge.FR, khip.VESTA), (khip.Sponge.FR, khip.PALLAS)):       # the two fields' permutations
+    sp = khip.Sponge(kind, curve)
+    for rep in range(40):
+        x = rng.integers(0, 1 << 64, size=(int(rng.integers(1, 9)), 4), dtype=np.uint64)
+        x[:, 3] &= np.uint64((1 << 61) - 1)
+        if rep % 7 == 0:
+            x[0] = 0                                   # zero ...
+        if rep % 5 == 0:                               # ... and the largest canonical limb pattern (p - 1 in the wire's Montgomery form is some value; as limbs: p - 1 itself is canonical too)
+            x[-1] = np.array(P.to_limbs((P.Fp if curve == khip.VESTA else P.Fq).p - 1), dtype=np.uint64)
+        sp.absorb(x)
+        h.update(sp.squeeze_field().tobytes())
+        h.update(sp.digest().tobytes())
+print(h.hexdigest())
+"""
+
+
+def test_ifma_and_scalar_permutations_agree():
+    """The AVX-512 IFMA permutation (three lanes, 52-bit limbs, R' = 2^260) and the scalar mulx one (KH_NO_IFMA=1) squeeze the same elements from
+    the same random transcripts, both fields.  On a CPU without IFMA both runs take the scalar path (the test is then trivially true); the
+    reference vectors above run on whichever path the CPU gives."""
+    import subprocess
+    import sys
+    outs = []
+    for no_ifma in ("0", "1"):
+        r = subprocess.run([sys.executable, "-c", PERM_WORKER, ROOT], env=dict(os.environ, KH_NO_IFMA=no_ifma), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        assert r.returncode == 0, r.stderr.decode()[-1500:]
+        outs.append(r.stdout.decode().strip().splitlines()[-1])
+    assert outs[0] == outs[1] and len(outs[0]) == 64
