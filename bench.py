@@ -339,7 +339,7 @@ def prover_block(khip, srs20, check_with_oracle=True, log_n=16, reps=5):
         out["proof_accepted_by_oracle_verifier"] = bool(oracle_verifies(khip, ix, nproof))
         out["cpu_baseline"] = prover_cpu_baseline(khip, ix, padded, log_n)
     # several provers in flight (one host thread and one SRS handle each): a single proof is mostly latency chains, independent proofs overlap
-    T, per = 4, 5
+    T, per = 4, 10                                       # (5 per thread until round 5: 20 proofs in ~0.1 s moved 165-207 proofs/s from run to run)
     ixs = [ix] + [prover.bench_circuit_index(khip.VESTA, log_n) for _ in range(T - 1)]
     for j in ixs[1:]:
         prover.create_proof(j, wit, np.random.default_rng(2), check=False)
