@@ -775,9 +775,20 @@ int kh_prove_full(kh_prover_index_t* ix, const uint64_t* witness, size_t rows, c
     const size_t npoly = polys.size();
     const fe pts[2] = {zeta, zetaw};
     std::vector<fe> E(npoly * 2 * nch);               // polynomial j: E[(2 j + p) nch + c]
+    // The same launch evaluates the chunks of sigma_6 and of the quotient t at both points: ft = perm_scalar sigma_6 - (zeta^n - 1) t is linear in
+    // them, so ft(zeta), ft(zeta omega) -- the Fr-sponge absorbs the latter FIRST -- are known without a second launch + download behind the host's
+    // computation of perm_scalar (round 5: ~0.1 ms of idle GPU between the two evaluation launches).
+    std::vector<fe> E_ft(2 * 8 * nch);               // sigma_6: [p][c], c < nch; then t: [p][c], c < 7 nch
+    const uint64_t* const sig6_c = ix->colc(COLUMNS + 2 + PERMUTS - 1);
     {
+        std::vector<const uint64_t*> ev(polys); ev.push_back(sig6_c); ev.push_back(quot.at(0));
         std::vector<size_t> lens(npoly, n), chs(npoly, nch);
-        KP(kh_evaluate_chunks_batch_dev(fid, polys.data(), lens.data(), chs.data(), npoly, size, (const uint64_t*)pts, 2, (uint64_t*)E.data()));
+        lens.push_back(n); chs.push_back(nch);
+        lens.push_back(7 * n); chs.push_back(7 * nch);
+        std::vector<fe> all(E.size() + E_ft.size());
+        KP(kh_evaluate_chunks_batch_dev(fid, ev.data(), lens.data(), chs.data(), npoly + 2, size, (const uint64_t*)pts, 2, (uint64_t*)all.data()));
+        std::copy(all.begin(), all.begin() + E.size(), E.begin());
+        std::copy(all.begin() + E.size(), all.end(), E_ft.begin());
     }
     std::vector<fe> pub_eval(2 * nch, zero);
     if (pub_c.p) KP(kh_evaluate_chunks_dev(fid, pub_c.p, n, size, nch, (const uint64_t*)pts, 2, (uint64_t*)pub_eval.data()));
@@ -795,7 +806,7 @@ int kh_prove_full(kh_prover_index_t* ix, const uint64_t* witness, size_t rows, c
     Dev ft; KP(ft.alloc(ft_len));
     {
         std::vector<const uint64_t*> segs; std::vector<size_t> lens; std::vector<fe> scs;
-        const uint64_t* sig6 = ix->colc(COLUMNS + 2 + PERMUTS - 1);
+        const uint64_t* sig6 = sig6_c;
         fe pw = one;
         for (size_t c = 0; c < nch; c++) {            // f_chunked.linearize(zeta^srs_len)
             if (c * size < n) { const size_t ln = n - c * size < size ? n - c * size : size; segs.push_back(sig6 + 4 * c * size); lens.push_back(ln); scs.push_back(F.mul(scal, pw)); }
@@ -808,8 +819,9 @@ int kh_prove_full(kh_prover_index_t* ix, const uint64_t* witness, size_t rows, c
         }
         KP(kh_poly_lincomb_dev(fid, segs.data(), lens.data(), (const uint64_t*)scs.data(), segs.size(), ft.p, ft_len));
     }
-    fe fte[2];
-    KP(kh_evaluate_chunks_dev(fid, ft.p, ft_len, ft_len, 1, (const uint64_t*)pts, 2, (uint64_t*)fte));
+    fe fte[2];                                        // ft at zeta, zeta omega from the chunk evaluations (the polynomial itself is only needed by the opening)
+    for (int p = 0; p < 2; p++)
+        fte[p] = F.add(F.mul(scal, horner(F, &E_ft[p * nch], nch, zeta_srs)), F.mul(m1, horner(F, &E_ft[2 * nch + p * 7 * nch], 7 * nch, zeta_srs)));
     const fe blinding_ft = F.mul(m1, horner(F, t_blind, ntb, zeta_srs));
     // ---- Fr-sponge: v, u (prover.rs:1206-1250, plonk_sponge.rs:92-155)
     fe v, u;
