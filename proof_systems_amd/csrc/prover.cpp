@@ -779,19 +779,20 @@ int kh_prove_full(kh_prover_index_t* ix, const uint64_t* witness, size_t rows, c
     // them, so ft(zeta), ft(zeta omega) -- the Fr-sponge absorbs the latter FIRST -- are known without a second launch + download behind the host's
     // computation of perm_scalar (round 5: ~0.1 ms of idle GPU between the two evaluation launches).
     std::vector<fe> E_ft(2 * 8 * nch);               // sigma_6: [p][c], c < nch; then t: [p][c], c < 7 nch
+    std::vector<fe> pub_eval(2 * nch, zero);
     const uint64_t* const sig6_c = ix->colc(COLUMNS + 2 + PERMUTS - 1);
     {
         std::vector<const uint64_t*> ev(polys); ev.push_back(sig6_c); ev.push_back(quot.at(0));
         std::vector<size_t> lens(npoly, n), chs(npoly, nch);
         lens.push_back(n); chs.push_back(nch);
         lens.push_back(7 * n); chs.push_back(7 * nch);
-        std::vector<fe> all(E.size() + E_ft.size());
-        KP(kh_evaluate_chunks_batch_dev(fid, ev.data(), lens.data(), chs.data(), npoly + 2, size, (const uint64_t*)pts, 2, (uint64_t*)all.data()));
+        if (pub_c.p) { ev.push_back(pub_c.p); lens.push_back(n); chs.push_back(nch); }      // ... and the public-input polynomial's, when there is one
+        std::vector<fe> all(E.size() + E_ft.size() + (pub_c.p ? 2 * nch : 0));
+        KP(kh_evaluate_chunks_batch_dev(fid, ev.data(), lens.data(), chs.data(), ev.size(), size, (const uint64_t*)pts, 2, (uint64_t*)all.data()));
         std::copy(all.begin(), all.begin() + E.size(), E.begin());
-        std::copy(all.begin() + E.size(), all.end(), E_ft.begin());
+        std::copy(all.begin() + E.size(), all.begin() + E.size() + E_ft.size(), E_ft.begin());
+        if (pub_c.p) std::copy(all.begin() + E.size() + E_ft.size(), all.end(), pub_eval.begin());
     }
-    std::vector<fe> pub_eval(2 * nch, zero);
-    if (pub_c.p) KP(kh_evaluate_chunks_dev(fid, pub_c.p, n, size, nch, (const uint64_t*)pts, 2, (uint64_t*)pub_eval.data()));
     // ---- ft = perm_scalar sigma_6 - (zeta^n - 1) t, chunk-linearised with zeta^max_poly_size (Maller; prover.rs:1147-1200)
     const fe zeta1 = fpow(F, zeta, n), zeta_srs = fpow(F, zeta, size), zetaw_srs = fpow(F, zetaw, size);
     auto comb = [&](size_t j, int p) { return horner(F, &E[(2 * j + p) * nch], nch, p ? zetaw_srs : zeta_srs); };
