@@ -705,6 +705,9 @@ static int wait_then_finish(std::unique_lock<std::mutex>& lk, Context& C, MsmSlo
     tl_last_wait_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tw0).count();
     lk.lock();
     C.sync_inflight--;
+    // the job ended by its event without the completion word ever showing its launch count: the host's count had run ahead of the device's (an enqueue
+    // that failed after counting, a job whose last kernel was not the flagged one) -- take the device's, or every later wait would go by the event
+    if (by_flag && !flag_seen && e == hipSuccess) S.done_expect = __atomic_load_n((const uint32_t*)S.done_flag, __ATOMIC_ACQUIRE);
     int rc;
     if (e != hipSuccess) { set_error("hipEventSynchronize: %s", hipGetErrorString(e)); S.busy = false; rc = KH_E_DEVICE; }
     else rc = msm_finish(C, S, out_xy, out_inf, flag_seen);

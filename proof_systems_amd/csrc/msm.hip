@@ -1824,9 +1824,11 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
         if (C.gexec && C.gkey == key) {                    // replay
             C.fused_used = C.g_fused;
             C.retry = {basis.pts, basis.inf, basis.n, basis.stride, basis.batch_stride, basis.precomp_c, offset, scalars_dev, n, k, mont, curve};
+            // (the host's launch count moves BEFORE the launch that will move the device's: whatever fails in between, the host is never
+            // behind -- a stale equality would end a later wait early -- and a host that is ahead only falls back to the event, then resyncs)
+            C.done_by_flag = C.g_done_by_flag; if (C.done_by_flag) C.done_expect++;
             KH_HIP(hipGraphLaunch(C.gexec, s));
             KH_HIP(hipEventRecord(C.done, s));
-            C.done_by_flag = C.g_done_by_flag; if (C.done_by_flag) C.done_expect++;
             C.busy = true; C.owner = std::this_thread::get_id(); C.ticket = Ctx.next_ticket++;
             C.curve = curve; C.W = C.g_W; C.c = C.g_c; C.precomp = C.g_precomp; C.k = k; C.ngroups = C.g_ngroups; C.planes = C.g_planes;
             C.plane_shift[0] = C.g_shift[0]; C.plane_shift[1] = C.g_shift[1]; C.wide_lo = C.g_wide_lo;
@@ -1985,6 +1987,7 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
     C.timer.mark("bucket_sum", s);
     // 7 reduce
     u32* const done_ws = flag_on ? C.ws_done.as<u32>() : nullptr; u32* const done_flag = flag_on ? (u32*)C.done_flag : nullptr;
+    if (flag_on) C.done_expect++;                        // before the launch that stores it (see the replay branch); every flag_on job ends in k_marginal_fin_q
     bool direct_out = false;                              // latency path: the last kernel writes the (768-byte) result to host memory itself -- no copy node
     if (wide) {
         const u32 items = 2u * (nb >> wg.rlog) * (u32)ngroups;
@@ -2046,7 +2049,7 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
         KH_HIP(hipGraphLaunch(C.gexec, s));
     }
     KH_HIP(hipEventRecord(C.done, s));
-    C.done_by_flag = direct_out && flag_on; if (C.done_by_flag) C.done_expect++;
+    C.done_by_flag = direct_out && flag_on;
     C.busy = true; C.owner = std::this_thread::get_id(); C.ticket = Ctx.next_ticket++;
     C.curve = curve; C.W = W; C.c = c; C.precomp = precomp; C.k = k; C.ngroups = ngroups; C.planes = (int)planes; C.plane_shift[0] = (int)mg.wd[0]; C.plane_shift[1] = (int)mg.wd[1]; C.wide_lo = wide ? (int)wg.lo : 0;
     C.fused_used = fused;
