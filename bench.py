@@ -317,7 +317,8 @@ def prover_block(khip, srs20, check_with_oracle=True, log_n=16, reps=5):
             khip.lde(khip.FP, coeffs16[i:i + 1], log_n, 3, out=outs16[i])    # evaluate_over_domain_by_ref(d8) of one column: n up, 8n down
         dt = time.perf_counter() - t0
         best_l = dt if best_l is None else min(best_l, dt)
-    best_l_thr = threaded([(lambda i=i: khip.lde(khip.FP, coeffs16[i:i + 1], log_n, 3, out=outs16[i])) for i in range(16)])       # constraints.rs:488-494: a par_iter over w and z
+    # (24 repetitions: single repetitions of this call run 2x slow on busy hosts -- tools/latency/numa_extend.py -- and two of round 5's collections had all of 7 in that mode)
+    best_l_thr = threaded([(lambda i=i: khip.lde(khip.FP, coeffs16[i:i + 1], log_n, 3, out=outs16[i])) for i in range(16)], reps=24)       # constraints.rs:488-494: a par_iter over w and z
     t_batch = None
     for _ in range(3):                                                   # (the first call of this shape sizes the slot's scalar workspace)
         t0 = time.perf_counter()
