@@ -113,3 +113,38 @@ def test_host_buffer_transforms_release_oversized_thread_buffers():
     r = subprocess.run([sys.executable, "-c", XFER_WORKER, ROOT], env=dict(os.environ, KH_XFER_KEEP_MB="1"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert r.returncode == 0, r.stderr.decode()[-1500:]
     assert r.stdout.decode().strip().endswith("transforms ok")
+
+
+FLAG_WORKER = r"""
+import sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+import proof_systems_amd.khip as khip
+from oracle import cref
+khip.init(0)
+khip.set_phase_timers(False)                         # the library's default: completion by flag where the last kernel stores it
+rng = np.random.default_rng(21)
+n = 1 << 13
+srs = khip.Srs.create(khip.VESTA, n)
+g = srs.get_g()
+for rep in range(6):
+    k = 1 + rep % 3
+    sc = rng.integers(0, 1 << 64, size=(k, n, 4), dtype=np.uint64); sc[:, :, 3] &= np.uint64((1 << 61) - 1)
+    d = khip.DevBuf(sc.nbytes).upload(sc)
+    xy, inf = srs.msm_batch_dev(d.ptr, n, k)
+    d.free()
+    for j in range(k):
+        want, winf = cref.msm(khip.VESTA, g, sc[j], scalars_mont=True, threads=2)
+        assert bool(inf[j]) == bool(winf) and (winf or np.array_equal(np.asarray(xy[j]).reshape(8), want)), (rep, j)
+srs.close()
+print("msm ok")
+"""
+
+
+@pytest.mark.parametrize("env", [{}, {"KH_NO_DONE_FLAG": "1"}, {"KH_NO_FIN_QUAD": "1"}])
+def test_completion_flag_and_its_fallbacks(env):
+    """Synchronous MSMs with the completion word (default), without it (KH_NO_DONE_FLAG: the event), and with a last kernel that does NOT store it
+    (KH_NO_FIN_QUAD: the host's launch count runs ahead, every wait falls back to the event and resyncs): the same results against the oracle."""
+    r = subprocess.run([sys.executable, "-c", FLAG_WORKER, ROOT], env=dict(os.environ, **env), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-1500:]
+    assert r.stdout.decode().strip().endswith("msm ok")
