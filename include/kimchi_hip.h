@@ -84,6 +84,12 @@ int kh_srs_create(int curve, const uint64_t *g_xy /* n x 8 limbs */, size_t n, k
  * table additions per scalar, 2^19 buckets, +13/16 of the table memory), and single MSMs of at least n scalars over them take it.  Default 2^19
  * (KH_WIDE_MIN_N), 0 = never.  Results are the same group elements either way; the tests lower it to run the wide path at small sizes. */
 int kh_msm_set_wide_min_n(size_t n);
+/* The wide set is OPTIONAL: if it does not fit in device memory when the handle is created, the handle is created without it (the narrow tables serve every
+ * MSM, ~8 % slower at 2^20) and no error is reported.  kh_srs_set_wide_tables(srs, 0) gives an existing wide set back (832 MiB at 2^20 points, 3.3 GiB at
+ * 2^22) -- no MSM over the handle may be in flight, as for kh_srs_free --, (srs, 1) builds it now whatever the threshold says and fails with KH_E_NOMEM if it
+ * does not fit; kh_srs_has_wide_tables tells which state the handle is in. */
+int kh_srs_set_wide_tables(kh_srs_t *srs, int on);
+int kh_srs_has_wide_tables(const kh_srs_t *srs);
 void kh_srs_free(kh_srs_t *srs);
 size_t kh_srs_size(const kh_srs_t *srs);
 int kh_srs_curve(const kh_srs_t *srs);    /* KH_CURVE_VESTA / KH_CURVE_PALLAS */
@@ -386,6 +392,9 @@ int kh_domain_generator(int field, unsigned log2_n, uint64_t out[4]);
  * data: batch x 2^log2_n x 4 limbs, Montgomery, natural order in and out, in place;
  * inverse != 0 includes the 1/N scaling (ark-poly ifft). */
 int kh_ntt(int field, uint64_t *data, unsigned log2_n, int inverse, size_t batch);
+/* Tuning knob (process-wide): the largest sub-transform of one pass is 2^max_logr points (4..10; 0 = the default, 9; KH_NTT_MAX_LOGR at start-up).
+ * A transform of 2^k points runs in ceil(k / max_logr) passes; results are identical for every setting (the tests run the parity cases under 8, 9, 10). */
+int kh_ntt_set_max_logr(unsigned max_logr);
 
 /* DensePolynomial::evaluate_over_domain_by_ref(d8/d4) (kimchi/src/circuits/
  * constraints.rs:490-495; prover.rs:436,617,668): n = 2^log2_n coefficients,
@@ -447,6 +456,11 @@ int kh_sync(void);
  * kh_ntt*_dev / kh_lde*_dev call on this thread, split per phase.  names/ms arrays of
  * capacity cap; returns the number of phases written. */
 int kh_last_timings(const char **names, float *ms, int cap);
+/* Process-wide event counters (how often a rare path ran): "spread_retry" (an opening round's MSM met a hot bucket and was re-run with the hot-bucket
+ * kernels), "fused_retry" (the one-launch sort gave up), "graph_replay" / "graph_capture" (replayed / captured launch sequences), "round_coalesced" /
+ * "round_solo" (opening rounds that shared / did not share a batched MSM with another prover's round), "wide_rare" (wide-path MSMs that launched the
+ * split / hot-bucket kernels).  Unknown names read 0. */
+uint64_t kh_counter(const char *name);
 
 /* Test hooks (field ops on the device; op: 0 mul, 1 add, 2 sub, 3 to_mont, 4 from_mont,
  * 5 sqr, 6 neg).  Used by the parity tests to pin the device arithmetic itself. */

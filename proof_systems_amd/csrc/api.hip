@@ -120,6 +120,7 @@ static int bind_thread(int dev) {
     if (tl_hip_dev != dev) { KH_HIP(hipSetDevice(dev)); tl_hip_dev = dev; }
     return KH_OK;
 }
+std::atomic<uint64_t>& counter(CounterId id) { static std::atomic<uint64_t> c[CNT_COUNT]; return c[id]; }
 DeviceScope::DeviceScope(int device) : prev(tl_dev) {
     if (device >= 0) { tl_dev = device; if (tl_hip_dev != device && hipSetDevice(device) == hipSuccess) tl_hip_dev = device; }
 }
@@ -138,6 +139,8 @@ static int init_context(Context& C, int device_id) {
     hipDeviceProp_t prop;
     KH_HIP(hipGetDeviceProperties(&prop, device_id));
     C.num_cus = prop.multiProcessorCount;
+    C.lds_per_cu = prop.maxSharedMemoryPerMultiProcessor ? (size_t)prop.maxSharedMemoryPerMultiProcessor : (size_t)64 << 10;
+    C.lds_per_block = prop.sharedMemPerBlock ? (size_t)prop.sharedMemPerBlock : (size_t)64 << 10;
     int rc = C.timer.init(); if (rc) return rc;
     C.device = device_id;
     C.ready = true;
@@ -287,6 +290,35 @@ struct DevPool {
 DevPool& dev_pool() { static DevPool p; return p; }
 size_t pool_limit() { static const size_t lim = (getenv("KH_POOL_MAX_MB") ? (size_t)atol(getenv("KH_POOL_MAX_MB")) : 2048) << 20; return lim; }
 }  // namespace
+// transfer buffers of the host-pointer transforms (kh_ntt / kh_lde: host_transform below)
+struct XferPair { DevBuf in, out; bool busy = false, owned = false; XferPair() { in.graph_keyed = false; out.graph_keyed = false; } };
+static std::mutex g_xfer_mu;
+static std::vector<std::unique_ptr<XferPair>>& xfer_registry(int d) {     // (never destroyed: no hipFree from a static destructor after the runtime has gone)
+    static auto* r = new std::vector<std::unique_ptr<XferPair>>[KH_MAX_DEVICES];
+    return r[d];
+}
+struct ThreadXfer {
+    XferPair* p[KH_MAX_DEVICES] = {nullptr};
+    ~ThreadXfer() { std::lock_guard<std::mutex> lk(g_xfer_mu); for (XferPair* q : p) if (q) { q->owned = false; q->busy = false; } }
+};
+static XferPair* xfer_acquire(int d) {
+    static thread_local ThreadXfer tl;
+    std::lock_guard<std::mutex> lk(g_xfer_mu);
+    if (!tl.p[d]) {
+        for (auto& q : xfer_registry(d)) if (!q->owned) { tl.p[d] = q.get(); break; }
+        if (!tl.p[d]) { xfer_registry(d).emplace_back(new XferPair); tl.p[d] = xfer_registry(d).back().get(); }
+        tl.p[d]->owned = true;
+    }
+    tl.p[d]->busy = true;
+    return tl.p[d];
+}
+static void xfer_release(XferPair* q) { std::lock_guard<std::mutex> lk(g_xfer_mu); q->busy = false; }
+struct XferGuard { XferPair* q; ~XferGuard() { xfer_release(q); } };
+static void xfer_trim(int d) {              // kh_trim: every pair that is not inside a call right now gives its memory back
+    if (d < 0 || d >= KH_MAX_DEVICES) return;
+    std::lock_guard<std::mutex> lk(g_xfer_mu);
+    for (auto& q : xfer_registry(d)) if (!q->busy) { q->in.release(); q->out.release(); }
+}
 static void dev_pool_trim(int device) {
     DevPool& P = dev_pool();
     std::lock_guard<std::mutex> lk(P.mu);
@@ -333,6 +365,7 @@ int kh_trim(void) {
                           &S.ws_b29, &S.ws_a1, &S.ws_a2, &S.ws_xlist}) b->release();
     }
     C.ws_ntt_a.release(); C.ws_ntt_b.release();
+    xfer_trim(C.device);
     dev_pool_trim(C.device);
     C.trim_scratch();
     // The twiddle tables belong to the DEVICE and are shared by every context on it: a private context of another thread may be between two
@@ -414,15 +447,49 @@ int kh_private_context_end(void) {
 }
 const char* kh_last_error(void) { return g_err.c_str(); }
 
-// the wide-window table set of a big basis (table 0 = a copy of the basis; H / U slots unused)
-static int build_wide_tables(Context& C, kh_srs* s) {
-    if (!s->g_precomp_c || s->n < msm_wide_min_n()) return KH_OK;
+// the wide-window table set of a big basis (table 0 = a copy of the basis; H / U slots unused).  It is a throughput optimisation on top of the narrow tables
+// (+13/16 of their memory: 832 MiB at 2^20 points, 3.3 GiB at 2^22), so a handle whose second set does not fit is still a working handle: `required` = false
+// gives the memory back, clears the error and leaves the narrow tables to serve every MSM.
+static int build_wide_tables(Context& C, kh_srs* s, bool required) {
+    if (s->g_wide_c) return KH_OK;
+    if (!s->g_precomp_c || (!required && s->n < msm_wide_min_n())) return KH_OK;
     const int W = (256 + MSM_WIDE_C - 1) / MSM_WIDE_C;
-    int rc;
-    if ((rc = s->g_wide.reserve(s->g_stride * 64 * (size_t)W))) return rc;
-    KH_HIP(hipMemcpyAsync(s->g_wide.p, s->g.p, s->g_stride * 64, hipMemcpyDeviceToDevice, C.stream));
-    if ((rc = msm_precompute(C, s->curve, s->g_wide.p, nullptr, s->g_stride, MSM_WIDE_C))) return rc;
+    int rc = s->g_wide.reserve(s->g_stride * 64 * (size_t)W);
+    if (!rc) {
+        hipError_t e = hipMemcpyAsync(s->g_wide.p, s->g.p, s->g_stride * 64, hipMemcpyDeviceToDevice, C.stream);
+        if (e != hipSuccess) { set_error("hipMemcpyAsync failed: %s", hipGetErrorString(e)); rc = KH_E_DEVICE; }
+    }
+    if (!rc) rc = msm_precompute(C, s->curve, s->g_wide.p, nullptr, s->g_stride, MSM_WIDE_C);
+    if (rc) {
+        (void)hipStreamSynchronize(C.stream);
+        s->g_wide.release(); s->g_wide_c = 0;
+        if (required || rc != KH_E_NOMEM) return rc;
+        (void)hipGetLastError();              // an allocation that did not fit is not an error of the handle
+        set_error("");
+        return KH_OK;
+    }
     s->g_wide_c = MSM_WIDE_C;
+    return KH_OK;
+}
+int kh_srs_has_wide_tables(const kh_srs_t* srs) { return srs && srs->g_wide_c ? 1 : 0; }
+int kh_srs_set_wide_tables(kh_srs_t* srs, int on) {
+    KH_ON_DEVICE_OF(srs);
+    KH_REQUIRE(srs != nullptr, "null SRS handle");
+    int rc = ensure_init(); if (rc) return rc;
+    Context& C = ctx();
+    std::lock_guard<std::mutex> lk(C.mu);
+    if (on) {
+        KH_REQUIRE(srs->g_precomp_c, "kh_srs_set_wide_tables: the handle has no window tables (fewer than %d points)", (int)MSM_PRECOMP_MIN_N);
+        if ((rc = build_wide_tables(C, srs, true))) return rc;
+        KH_HIP(hipStreamSynchronize(C.stream));
+        return KH_OK;
+    }
+    for (int i = 0; i < MSM_SLOTS; i++) {
+        KH_REQUIRE(!C.slot[i].busy, "kh_srs_set_wide_tables: an MSM is in flight (kh_msm_wait first)");
+        if (C.slot[i].stream) KH_HIP(hipStreamSynchronize(C.slot[i].stream));
+    }
+    srs->g_wide_c = 0;
+    srs->g_wide.release();
     return KH_OK;
 }
 int kh_msm_set_wide_min_n(size_t n) { msm_set_wide_min_n(n); return KH_OK; }
@@ -445,7 +512,7 @@ int kh_srs_create(int curve, const uint64_t* g_xy, size_t n, kh_srs_t** out) {
     if (pre) {
         if ((rc = msm_precompute(C, curve, s->g.p, nullptr, s->g_stride, MSM_PRECOMP_C))) return rc;
         s->g_precomp_c = MSM_PRECOMP_C;
-        if ((rc = build_wide_tables(C, s.get()))) return rc;
+        if ((rc = build_wide_tables(C, s.get(), false))) return rc;
     }
     // tables are per HANDLE, streams per context: another context (kh_private_context_begin on another thread) may use the handle at once, so it is
     // handed out complete (a one-time cost)
@@ -475,7 +542,7 @@ int kh_srs_create_device_range(int curve, size_t start, size_t depth, kh_srs_t**
     if (pre) {
         if ((rc = msm_precompute(C, curve, s->g.p, nullptr, s->g_stride, MSM_PRECOMP_C))) return rc;
         s->g_precomp_c = MSM_PRECOMP_C;
-        if ((rc = build_wide_tables(C, s.get()))) return rc;
+        if ((rc = build_wide_tables(C, s.get(), false))) return rc;
     }
     // tables are per HANDLE, streams per context: another context (kh_private_context_begin on another thread) may use the handle at once, so it is
     // handed out complete (a one-time cost)
@@ -1498,6 +1565,7 @@ static int ipa_begin_common(kh_srs_t* srs, const uint64_t* a, size_t a_len, cons
     } claim{srs};
     Context& C = ctx();
     std::unique_lock<std::mutex> lk(C.mu);
+    C.spread_suspended = false;                         // a new opening has new scalars: its rounds run under MSM_SPREAD_SCALARS again until one of them disproves it
     // A graph of the round MSM is captured and replayed WITHIN one opening only (nothing allocates or frees device memory
     // between the rounds of an opening); replaying it after the caller has freed and allocated buffers in between faulted
     // on ROCm 7.2 when another HIP user (PyTorch) shared the process.  Re-capturing costs one extra un-graphed round.
@@ -1948,14 +2016,15 @@ struct HostXferEvents {
     hipEvent_t up[KH_MAX_DEVICES] = {nullptr}, done[KH_MAX_DEVICES] = {nullptr};
     ~HostXferEvents() { for (int d = 0; d < KH_MAX_DEVICES; d++) { if (up[d]) (void)hipEventDestroy(up[d]); if (done[d]) (void)hipEventDestroy(done[d]); } }
 };
-// The calling thread's own device buffers for these transfers, per device, grown on demand and kept until the thread ends (a rayon worker lives as long
-// as its pool): the shared block pool is the wrong place for them -- once a prover's buffers have filled it to its limit, a freed 16 MB block went
-// back to the driver (hipFree synchronises the device) and the next call allocated afresh: 16 concurrent extensions took 11.6 ms inside bench.py's
-// process against 5.2 ms in a fresh one.
-struct ThreadXferBufs { DevBuf in[KH_MAX_DEVICES], out[KH_MAX_DEVICES]; };
-static size_t xfer_keep_bytes() {                                  // per buffer, per thread (16 columns of 2^19 elements = 268 MB); KH_XFER_KEEP_MB overrides
-    static const size_t v = getenv("KH_XFER_KEEP_MB") ? (size_t)atol(getenv("KH_XFER_KEEP_MB")) << 20 : (size_t)1 << 30;
-    return v;
+// The calling thread's own device buffers for these transfers, per device, grown on demand: the shared block pool is the wrong place for them -- once a
+// prover's buffers have filled it to its limit, a freed 16 MB block went back to the driver (hipFree synchronises the device) and the next call allocated
+// afresh: 16 concurrent extensions took 11.6 ms inside bench.py's process against 5.2 ms in a fresh one.  The buffers live in a per-device REGISTRY, not in
+// thread-local storage: a thread holds a pair while it exists (a rayon worker lives as long as its pool) and hands it back at exit without
+// freeing anything (no hipFree from a TLS destructor); the next new thread adopts it; kh_trim frees every pair that is not inside a call at that moment.
+// They are not part of the hipGraph key (no captured launch sequence reads them): growing or freeing one does not retire the MSM graphs.
+static size_t xfer_keep_bytes() {          // per buffer, per thread; KH_XFER_KEEP_MB overrides.  64 MB holds what the reference's callers hand over one column at
+    static const size_t v = getenv("KH_XFER_KEEP_MB") ? (size_t)atol(getenv("KH_XFER_KEEP_MB")) << 20 : (size_t)64 << 20;   // a time (2 MB in, 16 MB out at 2^16 -> 2^19) and a
+    return v;                              // few columns batched; a 16-column batched extension (268 MB out) pays its allocation each time (~5 ms of PCIe beside it)
 }
 // in -> [upload] -> din -> run(din, dout, columns) -> dout -> [download] -> out, `batch` columns of in_col / out_col bytes, in groups
 template <class Run>
@@ -1968,11 +2037,12 @@ int host_transform(const uint64_t* in, size_t in_col, uint64_t* out, size_t out_
     // column groups: at most four, at least ~4 MB of output each (a group costs three stream hand-overs)
     size_t groups = batch < 4 ? batch : 4;
     while (groups > 1 && (batch / groups) * out_col < ((size_t)4 << 20)) groups--;
-    static thread_local ThreadXferBufs bufs;
+    XferPair* const bufs = xfer_acquire(d);
+    XferGuard guard{bufs};
     int rc;
-    if ((rc = bufs.in[d].reserve(batch * in_col))) return rc;
-    if (!in_place && (rc = bufs.out[d].reserve(batch * out_col))) return rc;
-    char* const di = (char*)bufs.in[d].p; char* const dst_dev = in_place ? di : (char*)bufs.out[d].p;
+    if ((rc = bufs->in.reserve(batch * in_col))) return rc;
+    if (!in_place && (rc = bufs->out.reserve(batch * out_col))) return rc;
+    char* const di = (char*)bufs->in.p; char* const dst_dev = in_place ? di : (char*)bufs->out.p;
     // (the queueing in a lambda: whatever fails, the copy stream is drained before this returns -- a caller that sees an error may free `in` / `out`
     // at once, and a copy queued earlier in the call may still be reading or writing them)
     auto queue_all = [&]() -> int {
@@ -2002,10 +2072,9 @@ int host_transform(const uint64_t* in, size_t in_col, uint64_t* out, size_t out_
         std::lock_guard<std::mutex> lk(C.mu);
         (void)hipStreamSynchronize(C.stream);
     }
-    // a thread keeps its two buffers for its next call -- up to a bound: after a huge batch they go back (the PCIe time of such a call dwarfs an allocation,
-    // and kh_trim cannot reach another thread's buffers)
-    if (bufs.in[d].cap > xfer_keep_bytes()) bufs.in[d].release();
-    if (bufs.out[d].cap > xfer_keep_bytes()) bufs.out[d].release();
+    // a thread keeps its two buffers for its next call -- up to a bound: after a huge batch they go back (the PCIe time of such a call dwarfs an allocation)
+    if (bufs->in.cap > xfer_keep_bytes()) bufs->in.release();
+    if (bufs->out.cap > xfer_keep_bytes()) bufs->out.release();
     if (rc != KH_OK) return rc;
     {
         std::lock_guard<std::mutex> lk(C.mu);
@@ -2015,6 +2084,7 @@ int host_transform(const uint64_t* in, size_t in_col, uint64_t* out, size_t out_
 }
 }  // namespace
 extern "C" {
+int kh_ntt_set_max_logr(unsigned max_logr) { return ntt_set_max_logr(max_logr); }
 int kh_ntt(int field, uint64_t* data, unsigned log2_n, int inverse, size_t batch) {
     KH_REQUIRE(field == KH_FIELD_FP || field == KH_FIELD_FQ, "unknown field id %d", field);
     KH_REQUIRE(log2_n <= 28, "log2_n = %u too large", log2_n);
@@ -2183,6 +2253,11 @@ int kh_sync(void) {
     if (C.timer.n > 0) collect_timings(C, C.timer);
     C.timer.n = 0;
     return KH_OK;
+}
+uint64_t kh_counter(const char* name) {
+    if (!name) return 0;
+    for (int i = 0; i < CNT_COUNT; i++) if (!strcmp(name, COUNTER_NAMES[i])) return counter((CounterId)i).load(std::memory_order_relaxed);
+    return 0;
 }
 int kh_last_timings(const char** names, float* ms, int cap) {
     Context& C = ctx();

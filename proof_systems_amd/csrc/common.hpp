@@ -54,9 +54,10 @@ struct DevBuf {
     // never be replayed across a reallocation -- not even one that hands the same address back (defence in depth: every pointer the
     // launches bake in is in the key as well)
     static std::atomic<uint64_t>& generation() { static std::atomic<uint64_t> g{1}; return g; }
+    bool graph_keyed = true;                  // false: a buffer no captured launch sequence ever reads (the host-pointer transforms' transfer buffers)
     int reserve(size_t bytes) {
         if (bytes <= cap) return KH_OK;
-        generation()++;
+        if (graph_keyed) generation()++;
         if (p) { hipError_t e = hipFree(p); (void)e; p = nullptr; cap = 0; }
         size_t want = bytes + bytes / 8;
         hipError_t e = hipMalloc(&p, want);
@@ -64,7 +65,7 @@ struct DevBuf {
         cap = want;
         return KH_OK;
     }
-    void release() { if (p) { hipError_t e = hipFree(p); (void)e; generation()++; } p = nullptr; cap = 0; }
+    void release() { if (p) { hipError_t e = hipFree(p); (void)e; if (graph_keyed) generation()++; } p = nullptr; cap = 0; }
     template <class T> T* as() const { return (T*)p; }
 };
 
@@ -123,6 +124,12 @@ struct MsmSlot {
     // GPU they may never be -- its barriers then give up after a bounded spin, set this host-visible word, and msm_finish re-runs the job
     // with the multi-launch sort (the arguments of the pending job are kept for that) and disables the fused path for the process
     volatile uint32_t* host_abort = nullptr;          // pinned host memory, written by the kernel
+    // MSM_SPREAD_SCALARS was a wrong promise: k_bucket_sum_q met a bucket with more task partials than a quad may sum in sequence, stored this word
+    // (pinned) and left the bucket empty; msm_finish re-runs the job with the hot-bucket kernels and suspends the hint (Context::spread_suspended)
+    volatile uint32_t* spread_abort = nullptr;
+    bool spread_used = false, g_spread = false;
+    bool flag_unavailable = false;                     // no coherent host allocation for done_flag / pinned: completion by event
+    bool pinned_coherent = false;
     // Completion by flag (round 5): when a job's LAST kernel is k_marginal_fin_q (it writes the result into `pinned` itself), the last block of that
     // kernel to finish also stores the slot's launch count into done_flag (pinned).  A synchronous waiter polls that word instead of hipEventQuery:
     // the host has the result ~5 us earlier (tools/latency/launch_latency.hip: 0.2 against 5.3 us after the kernel's last store).
@@ -146,6 +153,8 @@ struct Context {
     bool main_dirty = false;           // asynchronous work was queued on the main stream since the last kh_sync
     hipEvent_t order_ev = nullptr;     // orders device-resident producers on the main stream before an MSM on another slot's stream
     int num_cus = 256;
+    size_t lds_per_cu = (size_t)160 << 10, lds_per_block = (size_t)64 << 10;    // hipDeviceProp: what holds k_acc_wide29 to a block count per CU
+    bool spread_suspended = false;     // an MSM under MSM_SPREAD_SCALARS met a hot bucket: the hint is ignored until the caller's next opening (kh_ipa_begin)
     bool fused_disabled = false;       // a k_sort_fused launch could not get all its blocks resident (shared GPU): multi-launch sort from then on
     PhaseTimer timer;                  // NTT / LDE phases (MSM phases are per slot)
     // last timings (filled after a sync)
@@ -189,6 +198,10 @@ struct DeviceScope {               // run the rest of this scope on `device` (no
     ~DeviceScope();
 };
 void collect_timings(Context& c, PhaseTimer& t);
+// process-wide event counters behind kh_counter (tests and tools read them: how often a rare path ran).  `name` must be one of COUNTER_NAMES.
+enum CounterId { CNT_SPREAD_RETRY = 0, CNT_FUSED_RETRY, CNT_GRAPH_REPLAY, CNT_GRAPH_CAPTURE, CNT_ROUND_COALESCED, CNT_ROUND_SOLO, CNT_WIDE_RARE, CNT_COUNT };
+static constexpr const char* COUNTER_NAMES[CNT_COUNT] = {"spread_retry", "fused_retry", "graph_replay", "graph_capture", "round_coalesced", "round_solo", "wide_rare"};
+std::atomic<uint64_t>& counter(CounterId id);
 
 // device exclusive scan of n u32 values (in may alias out); tmp is workspace
 int exclusive_scan_u32(const uint32_t* in, uint32_t* out, size_t n, DevBuf& tmp, hipStream_t s);

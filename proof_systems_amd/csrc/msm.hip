@@ -1252,7 +1252,8 @@ k_marginal_fin(const uint8_t* __restrict__ marg, MargGeom g, uint8_t* __restrict
 template <class BF>
 __global__ void __launch_bounds__(256)
 k_bucket_sum_q(const u32* __restrict__ toff, size_t nkeys, const uint8_t* __restrict__ partial,
-               uint8_t* __restrict__ buckets, u32* __restrict__ big, size_t cap, u32 SMALL_NT, const u32* __restrict__ abort_dev) {
+               uint8_t* __restrict__ buckets, u32* __restrict__ big, size_t cap, u32 SMALL_NT, const u32* __restrict__ abort_dev,
+               u32* __restrict__ spread_abort) {
     KH_HIGH_PRIO();
     if (sort_gave_up(abort_dev)) return;
     size_t key = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
@@ -1262,6 +1263,9 @@ k_bucket_sum_q(const u32* __restrict__ toff, size_t nkeys, const uint8_t* __rest
     u32 t0 = toff[key], nt = toff[key + 1] - t0;
     Fe<BF> acc = Fe<BF>::zero();
     if (nt > SMALL_NT) {
+        if (spread_abort) {                                // no hot-bucket kernels behind this launch (MSM_SPREAD_SCALARS): tell the host, which re-runs the job with them
+            if (live && role == 0) __hip_atomic_store(spread_abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        } else
         if (live && role == 0) {
             u32 nch = (nt + CHUNK - 1) / CHUNK;
             u32 slot = atomicAdd(&big[0], 1u);
@@ -1657,8 +1661,12 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
     // MSM_SPREAD_SCALARS: the caller vouches that the scalars are spread like random ones (the opening rounds: products with Fiat-Shamir challenges), so
     // no bucket collects a large share of the entries: the two-phase hot-bucket kernels are not launched (two empty dependent launches per MSM, ~20 us of
     // the ~340 us of an opening round) and a bucket's quad sums however many task partials it finds -- correct for any input, slow for a skewed one.
+    // The promise is checked, not trusted: a bucket with more than SPREAD_MAX_NT task partials (a constant or sparse polynomial from a
+    // degenerate or adversarial witness puts n / K of them into one bucket per window) is left empty and reported through a pinned word; msm_finish re-runs
+    // the job with the hot-bucket kernels and suspends the hint for the rest of the opening (Context::spread_suspended, reset by kh_ipa_begin).
     static const bool spread_on = !(getenv("KH_NO_SPREAD_HINT") && atoi(getenv("KH_NO_SPREAD_HINT")) != 0);
-    const bool spread = spread_on && (use_graph & MSM_SPREAD_SCALARS) != 0;
+    static const u32 SPREAD_MAX_NT = getenv("KH_SPREAD_MAX_NT") ? (u32)atoi(getenv("KH_SPREAD_MAX_NT")) : 256u;
+    const bool spread = spread_on && (use_graph & MSM_SPREAD_SCALARS) != 0 && !Ctx.spread_suspended;
     const void* const tab_pts = wide ? basis.wide_pts : basis.pts;
     const int c = wide ? basis.wide_c : (basis.precomp_c ? basis.precomp_c : msm_pick_window(n));
     const int W = (256 + c - 1) / c;
@@ -1709,10 +1717,17 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
     // wide-path knobs (defaults = measured best, tools/wide_sweep.py): ranks of one partition side by side in the accumulation order; blocks of the
     // accumulation per CU (held down with dynamic LDS); log2 of the chunk length of the first reduction level
     static const u32 wide_og = getenv("KH_WIDE_OG") ? (u32)std::max(1, atoi(getenv("KH_WIDE_OG"))) : 16u;
-    static const u32 wide_acc_blocks = getenv("KH_WIDE_ACC_BLOCKS") ? (u32)std::max(2, atoi(getenv("KH_WIDE_ACC_BLOCKS"))) : 3u;
+    static const u32 wide_acc_blocks = getenv("KH_WIDE_ACC_BLOCKS") ? (u32)std::max(1, atoi(getenv("KH_WIDE_ACC_BLOCKS"))) : 3u;
     static const u32 wide_rlog = getenv("KH_WIDE_RLOG") ? (u32)atoi(getenv("KH_WIDE_RLOG")) : 4u;
-    const size_t wide_acc_lds = wide_acc_blocks >= 4 ? 0 : (size_t)(160 * 1024 / (wide_acc_blocks + 1) + 1024) & ~(size_t)1023;
-    if (wide) {                                            // bucket = (hi digit, lo digit); chunks of 2^rlog buckets in the first reduction level
+    // dynamic LDS that leaves room for exactly wide_acc_blocks blocks on a CU, from the device's own LDS size (160 KB on gfx950), never more than one block
+    // may ask for: where the request cannot hold the count down the kernel simply runs at its register-limited occupancy
+    size_t wide_acc_lds = wide_acc_blocks >= 4 ? 0 : (Ctx.lds_per_cu / (wide_acc_blocks + 1) + 1024) & ~(size_t)1023;
+    if (wide_acc_lds > Ctx.lds_per_block) wide_acc_lds = Ctx.lds_per_block & ~(size_t)1023;
+    if (wide) {
+        // k_part2_sort interleaves `og` consecutive ranks of a partition: og must divide the 2^low buckets of a partition; k_wide_a1 / _a2 cut both digit
+        // planes into chunks of 2^rlog buckets: rlog <= min(lo, hi)
+        KH_REQUIRE(wide_og >= 1 && (wide_og & (wide_og - 1)) == 0 && wide_og <= (1u << ((u32)c - 9)), "KH_WIDE_OG = %u must be a power of two <= %u", wide_og, 1u << ((u32)c - 9));
+        KH_REQUIRE(wide_rlog >= 1 && wide_rlog <= std::min((u32)c / 2, (u32)(c - 1) - (u32)c / 2), "KH_WIDE_RLOG = %u must be in 1..%u", wide_rlog, std::min((u32)c / 2, (u32)(c - 1) - (u32)c / 2));                                            // bucket = (hi digit, lo digit); chunks of 2^rlog buckets in the first reduction level
         if ((rc = C.ws_xlist.reserve((3 * max_tasks + 8) * sizeof(u32)))) return rc;       // (key, chunk) pairs of the extra chunks, then the split buckets' keys
         if ((rc = C.ws_handed.reserve((2 * max_tasks + 4) * sizeof(u32)))) return rc;
         wg.nb = nb; wg.lo = (u32)c / 2; wg.hi = (u32)(c - 1) - wg.lo; wg.rlog = wide_rlog;
@@ -1745,7 +1760,9 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
     if (C.pinned_cap < nout * 128) {                     // host staging of the group sums; the host part runs in msm_finish
         if (C.pinned) (void)hipHostFree(C.pinned);
         C.pinned = nullptr; C.pinned_cap = 0;
-        KH_HIP(hipHostMalloc(&C.pinned, nout * 128 + 4096, hipHostMallocDefault));
+        // coherent + mapped, explicitly: the completion-by-flag path reads these lines with no runtime synchronisation in between
+        C.pinned_coherent = hipHostMalloc(&C.pinned, nout * 128 + 4096, hipHostMallocCoherent | hipHostMallocMapped) == hipSuccess;
+        if (!C.pinned_coherent) { (void)hipGetLastError(); C.pinned = nullptr; KH_HIP(hipHostMalloc(&C.pinned, nout * 128 + 4096, hipHostMallocDefault)); }
         C.pinned_cap = nout * 128 + 4096;
     }
     if (Ctx.once("msm_attr")) {
@@ -1790,19 +1807,27 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
         }
         if (!C.host_abort) {
             void* hp = nullptr;
-            KH_HIP(hipHostMalloc(&hp, 64, hipHostMallocDefault));
+            KH_HIP(hipHostMalloc(&hp, 64, hipHostMallocCoherent | hipHostMallocMapped));
             C.host_abort = (volatile uint32_t*)hp; *C.host_abort = 0;
         }
     }
+    if (spread && !C.spread_abort) {
+        void* hp = nullptr;
+        KH_HIP(hipHostMalloc(&hp, 64, hipHostMallocCoherent | hipHostMallocMapped));
+        C.spread_abort = (volatile uint32_t*)hp; *C.spread_abort = 0;
+    }
     // completion by flag (MsmSlot::done_flag): pinned word + two device words, once per slot
     static const bool flag_off = getenv("KH_NO_DONE_FLAG") != nullptr;
-    const bool flag_on = !flag_off && (wide || planes);
+    bool flag_on = !flag_off && (wide || planes) && !C.flag_unavailable && C.pinned_coherent;
     if (flag_on && !C.done_flag) {
         void* hp = nullptr;
-        KH_HIP(hipHostMalloc(&hp, 64, hipHostMallocDefault));
-        C.done_flag = (volatile uint32_t*)hp; *C.done_flag = 0; C.done_expect = 0;
-        if ((rc = C.ws_done.reserve(64))) return rc;
-        KH_HIP(hipMemset(C.ws_done.p, 0, 64));
+        if (hipHostMalloc(&hp, 64, hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) {      // no coherent word: completion by event on this slot
+            (void)hipGetLastError(); C.flag_unavailable = true; flag_on = false;
+        } else {
+            C.done_flag = (volatile uint32_t*)hp; *C.done_flag = 0; C.done_expect = 0;
+            if ((rc = C.ws_done.reserve(64))) return rc;
+            KH_HIP(hipMemsetAsync(C.ws_done.p, 0, 64, s));           // ordered in front of the slot's first launch that counts in it
+        }
     }
     // hipGraph replay / capture (opt-in by the caller; the key covers everything the launches bake in)
     static const bool graphs_off = getenv("KH_NO_GRAPH") != nullptr;
@@ -1826,8 +1851,10 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
             C.retry = {basis.pts, basis.inf, basis.n, basis.stride, basis.batch_stride, basis.precomp_c, offset, scalars_dev, n, k, mont, curve};
             // (the host's launch count moves BEFORE the launch that will move the device's: whatever fails in between, the host is never
             // behind -- a stale equality would end a later wait early -- and a host that is ahead only falls back to the event, then resyncs)
+            C.spread_used = C.g_spread;
             C.done_by_flag = C.g_done_by_flag; if (C.done_by_flag) C.done_expect++;
             KH_HIP(hipGraphLaunch(C.gexec, s));
+            counter(CNT_GRAPH_REPLAY)++;
             KH_HIP(hipEventRecord(C.done, s));
             C.busy = true; C.owner = std::this_thread::get_id(); C.ticket = Ctx.next_ticket++;
             C.curve = curve; C.W = C.g_W; C.c = C.g_c; C.precomp = C.g_precomp; C.k = k; C.ngroups = C.g_ngroups; C.planes = C.g_planes;
@@ -1972,7 +1999,7 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
     else if (precomp && ngroups <= bsum_maxg && bsum_quad)
         hipLaunchKernelGGL((k_bucket_sum_q<BF>), dim3((unsigned)((4 * nkeys + 255) / 256)), dim3(256), 0, s,
                            C.ws_toff.as<u32>(), nkeys, C.ws_partial.as<uint8_t>(), C.ws_buckets.as<uint8_t>(), C.ws_biglist.as<u32>(),
-                           bigcap, spread ? 0xffffffffu : 16u, abort_dev);
+                           bigcap, spread ? SPREAD_MAX_NT : 16u, abort_dev, spread ? (u32*)C.spread_abort : nullptr);
     else
     hipLaunchKernelGGL((k_bucket_sum<BF>), dim3((unsigned)((nkeys + 255) / 256)), dim3(256), 0, s,
                        C.ws_toff.as<u32>(), nkeys, C.ws_partial.as<uint8_t>(), C.ws_buckets.as<uint8_t>(), C.ws_biglist.as<u32>(),
@@ -2044,7 +2071,7 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
         if (e == hipSuccess && g) e = hipGraphInstantiate(&C.gexec, g, nullptr, nullptr, 0);
         if (g) (void)hipGraphDestroy(g);
         if (e != hipSuccess) { C.gexec = nullptr; set_error("hipGraph capture of the MSM launch sequence failed: %s", hipGetErrorString(e)); return KH_E_DEVICE; }
-        C.gkey = key; C.gnout = nout; C.gscalars = scalars_dev; C.g_fused = fused;
+        C.gkey = key; C.gnout = nout; C.gscalars = scalars_dev; C.g_fused = fused; C.g_spread = spread && !wide && precomp && ngroups <= bsum_maxg && bsum_quad;
         C.g_W = W; C.g_c = c; C.g_precomp = precomp; C.g_planes = (int)planes; C.g_shift[0] = (int)mg.wd[0]; C.g_shift[1] = (int)mg.wd[1]; C.g_ngroups = ngroups; C.g_wide_lo = wide ? (int)wg.lo : 0; C.g_done_by_flag = direct_out && flag_on;
         KH_HIP(hipGraphLaunch(C.gexec, s));
     }
@@ -2053,6 +2080,7 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
     C.busy = true; C.owner = std::this_thread::get_id(); C.ticket = Ctx.next_ticket++;
     C.curve = curve; C.W = W; C.c = c; C.precomp = precomp; C.k = k; C.ngroups = ngroups; C.planes = (int)planes; C.plane_shift[0] = (int)mg.wd[0]; C.plane_shift[1] = (int)mg.wd[1]; C.wide_lo = wide ? (int)wg.lo : 0;
     C.fused_used = fused;
+    C.spread_used = spread && !wide && precomp && ngroups <= bsum_maxg && bsum_quad;
     C.retry = {basis.pts, basis.inf, basis.n, basis.stride, basis.batch_stride, basis.precomp_c, offset, scalars_dev, n, k, mont, curve};
     return KH_OK;
 }
@@ -2060,7 +2088,7 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
 int msm_enqueue(Context& C, MsmSlot& S, int curve, const MsmBasis& basis, size_t offset, const uint64_t* scalars_dev, size_t n, size_t k, int mont,
                 int use_graph) {
     if (n == 0 || k == 0) {          // nothing to launch: finish() emits k identities
-        S.busy = true; S.owner = std::this_thread::get_id(); S.ticket = C.next_ticket++; S.curve = curve; S.k = k; S.ngroups = 0; S.W = 0; S.c = 0; S.precomp = 1; S.planes = 0; S.done_by_flag = false;
+        S.busy = true; S.owner = std::this_thread::get_id(); S.ticket = C.next_ticket++; S.curve = curve; S.k = k; S.ngroups = 0; S.W = 0; S.c = 0; S.precomp = 1; S.planes = 0; S.done_by_flag = false; S.fused_used = false; S.spread_used = false;
         KH_HIP(hipEventRecord(S.done, S.stream));
         return KH_OK;
     }
@@ -2078,7 +2106,21 @@ int msm_finish(Context& C, MsmSlot& S, uint64_t* out_xy, uint8_t* out_inf, bool 
         *S.host_abort = 0;
         if (!C.fused_disabled) fprintf(stderr, "libkimchi_hip: k_sort_fused could not get its blocks co-resident (shared GPU?): using the multi-launch sort from now on\n");
         C.fused_disabled = true;
+        counter(CNT_FUSED_RETRY)++;
         KH_HIP(hipMemsetAsync(S.ws_sync.p, 0, (2 + 2 * FUSED_B + 32 + 2) * sizeof(u32), S.stream));
+        const uint64_t ticket = S.ticket; const auto owner = S.owner;
+        MsmBasis b; b.pts = S.retry.pts; b.inf = S.retry.inf; b.n = S.retry.bn; b.stride = S.retry.stride; b.batch_stride = S.retry.batch_stride; b.precomp_c = S.retry.precomp_c;
+        int rc = msm_enqueue(C, S, S.retry.curve, b, S.retry.offset, S.retry.scalars, S.retry.n, S.retry.k, S.retry.mont, 0);
+        S.ticket = ticket; S.owner = owner; C.next_ticket--;
+        if (rc) { S.busy = false; return rc; }
+        KH_HIP(hipEventSynchronize(S.done));
+    }
+    if (S.spread_used && S.spread_abort && *S.spread_abort) {
+        // MSM_SPREAD_SCALARS did not hold (a bucket with more task partials than a quad may sum in sequence): the buckets that said so were left empty.
+        // Re-run this job with the hot-bucket kernels; the hint stays off until the caller begins its next opening.
+        *S.spread_abort = 0;
+        C.spread_suspended = true;
+        counter(CNT_SPREAD_RETRY)++;
         const uint64_t ticket = S.ticket; const auto owner = S.owner;
         MsmBasis b; b.pts = S.retry.pts; b.inf = S.retry.inf; b.n = S.retry.bn; b.stride = S.retry.stride; b.batch_stride = S.retry.batch_stride; b.precomp_c = S.retry.precomp_c;
         int rc = msm_enqueue(C, S, S.retry.curve, b, S.retry.offset, S.retry.scalars, S.retry.n, S.retry.k, S.retry.mont, 0);

@@ -87,6 +87,8 @@ int srs_generate_device(Context& C, int curve, size_t start, size_t count, void*
 // lagrange.hip
 int lagrange_run(Context& C, int curve, const void* g_dev, size_t srs_size, unsigned log_n, unsigned chunk, void* out_xy_dev, uint8_t* out_inf_dev);
 khost::fe ntt_host_root(int field, unsigned logn, int inverse);   // omega_{2^logn} (or its inverse), Montgomery
+unsigned ntt_max_logr();
+int ntt_set_max_logr(unsigned v);            // 4..10, 0 = default (kh_ntt_set_max_logr)
 int ntt_run(Context& C, int field, uint64_t* data_dev, unsigned log2_n, int inverse, size_t batch);
 int lde_run(Context& C, int field, const uint64_t* coeffs_dev, unsigned log2_n, unsigned log2_blowup, uint64_t* out_dev, size_t batch);
 

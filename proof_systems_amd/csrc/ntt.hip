@@ -369,11 +369,25 @@ static int get_twiddles(Context& C, int field, unsigned logn, int inverse, TwEnt
     return KH_OK;
 }
 
-// split log_n into passes of at most NTT_MAX_LOGR bits, most significant (first pass) first
+// Largest sub-transform of a pass: KH_NTT_MAX_LOGR at start-up, kh_ntt_set_max_logr afterwards (4..10; 0 = back to the default).  The twiddle tables hold every
+// power of the root, so they do not depend on the split and a change takes effect with the next transform.
+static std::atomic<unsigned>& max_logr_cell() {
+    static std::atomic<unsigned> v(getenv("KH_NTT_MAX_LOGR") ? (unsigned)std::min(10, std::max(4, atoi(getenv("KH_NTT_MAX_LOGR")))) : (unsigned)NTT_MAX_LOGR);
+    return v;
+}
+unsigned ntt_max_logr() { return max_logr_cell().load(std::memory_order_relaxed); }
+int ntt_set_max_logr(unsigned v) {
+    if (v == 0) v = NTT_MAX_LOGR;
+    if (v < 4 || v > 10) { set_error("kh_ntt_set_max_logr: %u is outside 4..10", v); return KH_E_INVALID; }
+    max_logr_cell().store(v, std::memory_order_relaxed);
+    return KH_OK;
+}
+
+// split log_n into passes of at most ntt_max_logr() bits, most significant (first pass) first
 static std::vector<unsigned> split_passes(unsigned log_n) {
     std::vector<unsigned> r;
     if (log_n == 0) return r;
-    static const unsigned max_logr = getenv("KH_NTT_MAX_LOGR") ? (unsigned)std::min(10, std::max(4, atoi(getenv("KH_NTT_MAX_LOGR")))) : (unsigned)NTT_MAX_LOGR;
+    const unsigned max_logr = ntt_max_logr();
     unsigned P = (log_n + max_logr - 1) / max_logr;
     unsigned base = log_n / P, extra = log_n % P;
     for (unsigned i = 0; i < P; i++) r.push_back(base + (i < extra ? 1 : 0));

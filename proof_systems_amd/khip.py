@@ -31,7 +31,7 @@ SYMBOLS = [
     "kh_sponge_new", "kh_sponge_clone", "kh_sponge_free", "kh_sponge_absorb_g", "kh_sponge_absorb", "kh_sponge_absorb_fr", "kh_sponge_challenge",
     "kh_sponge_challenge_field", "kh_sponge_squeeze_field", "kh_sponge_digest",
     "kh_group_map_to_group", "kh_dev_copy", "kh_dev_memset_zero", "kh_dev_fill_elements", "kh_set_phase_timers", "kh_ipa_open",
-    "kh_device_count", "kh_init", "kh_set_device", "kh_get_device", "kh_trim", "kh_srs_device", "kh_last_error", "kh_srs_create", "kh_msm_set_wide_min_n", "kh_srs_free", "kh_srs_size",
+    "kh_device_count", "kh_init", "kh_set_device", "kh_get_device", "kh_trim", "kh_srs_device", "kh_last_error", "kh_srs_create", "kh_msm_set_wide_min_n", "kh_ntt_set_max_logr", "kh_counter", "kh_srs_set_wide_tables", "kh_srs_has_wide_tables", "kh_srs_free", "kh_srs_size",
     "kh_srs_set_lagrange", "kh_srs_compute_lagrange", "kh_srs_get_lagrange", "kh_srs_lagrange_chunks",
     "kh_msm", "kh_msm_batch", "kh_msm_points", "kh_ntt", "kh_lde",
     "kh_dev_alloc", "kh_dev_free", "kh_dev_upload", "kh_dev_download", "kh_dev_upload_2d",
@@ -68,6 +68,11 @@ _lib.kh_srs_free.restype = None
 _lib.kh_srs_free.argtypes = [C.c_void_p]
 _lib.kh_srs_create.argtypes = [C.c_int, U64P, C.c_size_t, C.POINTER(C.c_void_p)]
 _lib.kh_msm_set_wide_min_n.argtypes = [C.c_size_t]
+_lib.kh_ntt_set_max_logr.argtypes = [C.c_uint]
+_lib.kh_counter.argtypes = [C.c_char_p]
+_lib.kh_counter.restype = C.c_uint64
+_lib.kh_srs_set_wide_tables.argtypes = [C.c_void_p, C.c_int]
+_lib.kh_srs_has_wide_tables.argtypes = [C.c_void_p]
 _lib.kh_dev_fill_elements.argtypes = [C.c_void_p, U64P, C.c_size_t]
 _lib.kh_srs_set_lagrange.argtypes = [C.c_void_p, C.c_uint, C.c_uint, U64P, U8P, C.c_size_t]
 _lib.kh_srs_compute_lagrange.argtypes = [C.c_void_p, C.c_uint]
@@ -235,6 +240,13 @@ class Srs:
         out = np.zeros((count, 8), dtype=np.uint64)
         _check(_lib.kh_srs_get_g(self._h, offset, count, _p64(out)))
         return out
+
+    def has_wide_tables(self) -> bool:
+        return bool(_lib.kh_srs_has_wide_tables(self._h))
+
+    def set_wide_tables(self, on: bool):
+        """Build (True) or give back (False) the optional 20-bit-window table set of this handle (kh_srs_set_wide_tables)."""
+        _check(_lib.kh_srs_set_wide_tables(self._h, int(on)))
 
     def close(self):
         if self._h:
@@ -406,6 +418,16 @@ def msm_points_batch(curve: int, xy, scalars, inf=None, mont: bool = True):
     oinf = np.zeros(k, dtype=np.uint8)
     _check(_lib.kh_msm_points_batch(curve, _p64(xy), _p8(inf), _p64(sc), n, k, int(mont), _p64(out), _p8(oinf)))
     return out, oinf
+
+
+def counter(name: str) -> int:
+    """Process-wide event counter of the library (kh_counter): spread_retry, fused_retry, graph_replay, graph_capture, round_coalesced, round_solo, wide_rare."""
+    return int(_lib.kh_counter(name.encode()))
+
+
+def set_ntt_max_logr(v: int):
+    """Largest sub-transform of an NTT pass = 2^v points (kh_ntt_set_max_logr: 4..10, 0 = default); same results under every setting."""
+    _check(_lib.kh_ntt_set_max_logr(v))
 
 
 def ntt(field: int, data, log2_n: int, inverse: bool = False, in_place: bool = False):

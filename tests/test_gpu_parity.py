@@ -290,8 +290,10 @@ def test_msm_batch_and_lagrange(khip, cid):
 
 # ------------------------------------------------------------------ NTT
 @pytest.mark.parametrize("fid", [0, 1])
-@pytest.mark.parametrize("logn", [0, 1, 2, 3, 5, 8, 9, 10, 11, 12, 13, 16, 17])
+@pytest.mark.parametrize("logn", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19])
 def test_ntt_sizes(khip, fid, logn):
+    """Every size from 2^0 to 2^19 (2^20 .. 2^22: test_ntt_large_sizes), both fields, both directions, directly against the oracle's DFT
+    ("bit-exact vs oracle for log n in [3, 22], both fields")."""
     rng = np.random.default_rng(31 * logn + fid)
     n = 1 << logn
     batch = 3 if logn <= 13 else 2
@@ -305,7 +307,7 @@ def test_ntt_sizes(khip, fid, logn):
 
 
 @pytest.mark.parametrize("fid", [0, 1])
-@pytest.mark.parametrize("logn,logb", [(1, 3), (3, 3), (6, 3), (8, 2), (10, 3), (12, 3), (13, 1), (16, 3)])
+@pytest.mark.parametrize("logn,logb", [(1, 3), (3, 3), (6, 3), (8, 2), (10, 3), (12, 3), (13, 1), (14, 2), (15, 3), (16, 2), (16, 3), (17, 3), (18, 3), (19, 1)])
 def test_lde(khip, fid, logn, logb):
     rng = np.random.default_rng(77 * logn + logb + fid)
     n = 1 << logn
@@ -699,21 +701,66 @@ def test_hip_path_against_derived_vectors(khip):
         assert c.base.from_mont(P.from_limbs(out[4:])) == int(v["result"][1], 16)
 
 
-def test_ntt_large_sizes(khip):
-    """Three-pass decompositions: 2^20 against the oracle, 2^22 by round trip + linearity, LDE 2^18 -> 2^21."""
-    rng = np.random.default_rng(4242)
-    x = rand_fe_fast(rng, 1 << 20).reshape(1, 1 << 20, 4)
-    f = khip.ntt(1, x, 20, False)
-    assert np.array_equal(f, cref.ntt(1, x, 20, False, threads=8))
-    assert np.array_equal(khip.ntt(1, f, 20, True), x)
+@pytest.mark.parametrize("fid", [0, 1])
+@pytest.mark.parametrize("logn", [20, 21, 22])
+def test_ntt_large_sizes(khip, fid, logn):
+    """2^20, 2^21, 2^22 directly against the oracle's DFT, forward and inverse, both fields (a transform with a wrong root of unity or a consistent
+    output permutation passes a round trip and a linearity check: those are extras here, not the gate)."""
+    rng = np.random.default_rng(4242 + 2 * logn + fid)
+    n = 1 << logn
+    x = rand_fe_fast(rng, n).reshape(1, n, 4)
+    x[0, rng.integers(0, n, size=64)] = 0
+    f = khip.ntt(fid, x, logn, False)
+    assert np.array_equal(f, cref.ntt(fid, x, logn, False, threads=8)), ("forward", logn)
+    i = khip.ntt(fid, x, logn, True)
+    assert np.array_equal(i, cref.ntt(fid, x, logn, True, threads=8)), ("inverse", logn)
+    assert np.array_equal(khip.ntt(fid, f, logn, True), x)
+
+
+def test_ntt_large_properties(khip):
+    """Size-independent properties at the largest shapes: linearity at 2^22, and the 2^18 -> 2^21 extension against the oracle and back."""
+    rng = np.random.default_rng(4243)
     y = rand_fe_fast(rng, 1 << 22).reshape(1, 1 << 22, 4)
     z = rand_fe_fast(rng, 1 << 22).reshape(1, 1 << 22, 4)
     fy, fz = khip.ntt(0, y, 22, False), khip.ntt(0, z, 22, False)
-    assert np.array_equal(khip.ntt(0, fy, 22, True), y)
     s = cref.field_op(0, "add", y.reshape(-1, 4), z.reshape(-1, 4)).reshape(1, 1 << 22, 4)
     assert np.array_equal(khip.ntt(0, s, 22, False).reshape(-1, 4), cref.field_op(0, "add", fy.reshape(-1, 4), fz.reshape(-1, 4)))
     c = rand_fe_fast(rng, 1 << 18).reshape(1, 1 << 18, 4)
     e = khip.lde(0, c, 18, 3)
-    assert np.array_equal(e[:, ::8], khip.ntt(0, c, 18, False))
+    assert np.array_equal(e, cref.lde(0, c, 18, 3, threads=8))
     back = khip.ntt(0, e, 21, True)
     assert np.array_equal(back[:, : 1 << 18], c) and not back[:, 1 << 18:].any()
+
+
+@pytest.fixture
+def max_logr(khip, request):
+    khip.set_ntt_max_logr(request.param)
+    yield request.param
+    khip.set_ntt_max_logr(0)
+
+
+@pytest.mark.parametrize("max_logr", [8, 9, 10], indirect=True)
+@pytest.mark.parametrize("fid", [0, 1])
+def test_ntt_pass_shapes(khip, fid, max_logr):
+    """The alternative pass decompositions (kh_ntt_set_max_logr / KH_NTT_MAX_LOGR: sub-transforms of up to 2^8, 2^9 = the default, 2^10 points) give the
+    same bits: every size class of the splitter (one, two, three passes; even and ragged splits) for NTT, iNTT and the extension, against the oracle."""
+    rng = np.random.default_rng(1000 * max_logr + fid)
+    for logn in (3, 7, 8, 9, 10, 11, 13, 15, 16, 17, 18, 19, 20, 21):
+        n = 1 << logn
+        batch = 3 if logn <= 11 else (2 if logn <= 17 else 1)
+        x = rand_fe_fast(rng, batch * n).reshape(batch, n, 4)
+        for inverse in (False, True):
+            assert np.array_equal(khip.ntt(fid, x, logn, inverse), cref.ntt(fid, x, logn, inverse, threads=8)), (max_logr, logn, inverse)
+    for logn, logb in ((3, 3), (8, 2), (10, 3), (13, 1), (15, 3), (16, 3), (17, 3), (18, 3), (19, 1)):
+        n = 1 << logn
+        batch = 2 if logn <= 16 else 1
+        c = rand_fe_fast(rng, batch * n).reshape(batch, n, 4)
+        assert np.array_equal(khip.lde(fid, c, logn, logb), cref.lde(fid, c, logn, logb, threads=8)), (max_logr, logn, logb)
+
+
+def test_ntt_max_logr_is_validated(khip):
+    with pytest.raises(Exception):
+        khip.set_ntt_max_logr(3)
+    with pytest.raises(Exception):
+        khip.set_ntt_max_logr(11)
+    khip.set_ntt_max_logr(0)

@@ -354,6 +354,47 @@ def test_ipa_opening_rounds_match_oracle(khip, cid, logn, const_a):
     srs.close()
 
 
+def test_spread_hint_is_checked_not_trusted(khip):
+    """the opening rounds promise the MSM spread scalars (MSM_SPREAD_SCALARS: no hot-bucket kernels behind the quad bucket sums).  A constant
+    polynomial at 2^15 breaks the promise in the first round (2^14 equal scalars per window fall into one bucket: 512 .. 4096 task partials, whatever
+    task length the planner picks, against the cap of 256): the kernel reports it, the host re-runs that MSM with the hot-bucket kernels (counter "spread_retry") and suspends the hint for the rest of the
+    opening -- and L, R of every round are still the oracle's MSMs over the folded vectors (first round checked against the C oracle directly)."""
+    cid, logn = 0, 15
+    c = P.CURVES[cid]; F = c.scalar
+    n = 1 << logn
+    rnd = np.random.default_rng(515)
+    srs = khip.Srs.create(cid, n)
+    g_l = srs.get_g(0, n)
+    U_l = khip.srs_generate(cid, 1 << 20, 1)[0]
+    h_l = khip.srs_h(cid)
+    ri = lambda: int.from_bytes(rnd.bytes(40), "little") % F.p
+    a0 = ri()
+    a = [a0] * n
+    x = ri()
+    b = [1]
+    for _ in range(n - 1):
+        b.append(b[-1] * x % F.p)
+    rands = [(ri(), ri()) for _ in range(logn)]
+    chals = [int.from_bytes(rnd.bytes(16), "little") for _ in range(logn)]
+    before = khip.counter("spread_retry")
+    lr, us, a_fin, b_fin, sg, sginf = _run_opening(khip, srs, cid, _limbs(F, a), _limbs(F, b), U_l,
+                                                   [(_limbs(F, [rl])[0], _limbs(F, [rr])[0]) for rl, rr in rands], chals)
+    assert khip.counter("spread_retry") == before + 1, "exactly one re-run: the hint stays suspended for the later rounds of this opening"
+    # round 1 (ipa.rs:943-961): L = <a_hi, g_lo> + rand_l h + <a_hi, b_lo> U, R = <a_lo, g_hi> + rand_r h + <a_lo, b_hi> U
+    half = n // 2
+    ip = lambda u, v: sum(p * q for p, q in zip(u, v)) % F.p
+    for side, (asl, gsl, bsl, r) in enumerate([(a[half:], g_l[:half], b[:half], rands[0][0]), (a[:half], g_l[half:], b[half:], rands[0][1])]):
+        pts = np.concatenate([gsl, h_l.reshape(1, 8), U_l.reshape(1, 8)])
+        sc = _limbs(F, list(asl) + [r, ip(asl, bsl)])
+        want, winf = cref.msm(cid, pts, sc, threads=8)
+        assert not winf and not lr[0][1][side] and np.array_equal(lr[0][0][side], want), ("round 1", side)
+    # a second opening on the same context starts under the hint again (and breaks it again)
+    lr2, *_ = _run_opening(khip, srs, cid, _limbs(F, a), _limbs(F, b), U_l, [(_limbs(F, [rl])[0], _limbs(F, [rr])[0]) for rl, rr in rands], chals)
+    assert khip.counter("spread_retry") == before + 2
+    assert all(np.array_equal(p[0], q[0]) and np.array_equal(p[1], q[1]) for p, q in zip(lr, lr2))
+    srs.close()
+
+
 def test_two_openings_side_by_side(khip):
     """Two provers on two SRS handles run their opening rounds from two host threads at once (the library lock is
     released while a round's MSM runs): same L, R, a0, b0, sg as when run alone."""

@@ -162,3 +162,32 @@ def test_wide_degenerate_bases(khip, cid):
                     w, winf = cref.msm(cid, g, scs[j * n:(j + 1) * n], scalars_mont=False, threads=8)
                     assert bool(ginf[j]) == bool(winf) and (winf or np.array_equal(got[j], w)), (variant, bits, k, j)
         srs.close()
+
+
+def test_wide_tables_are_optional(khip):
+    """the 20-bit-window table set is a throughput optimisation, not part of a handle's contract -- kh_srs_set_wide_tables gives it back
+    (the narrow tables then serve the same MSM, same group element) and builds it again on request; kh_srs_has_wide_tables reports the state."""
+    n = 1 << 13
+    rng = np.random.default_rng(99)
+    g = cref.srs_generate(0, 0, n, threads=THREADS)
+    sc = _rand_fe(rng, n)
+    want, winf = cref.msm(0, g, sc, threads=THREADS)
+    srs = khip.Srs(khip.VESTA, g)
+    assert srs.has_wide_tables()
+    got, ginf = srs.msm(sc)
+    assert _wide_ran(khip) and ginf == winf and np.array_equal(got, want)
+    srs.set_wide_tables(False)
+    assert not srs.has_wide_tables()
+    got, ginf = srs.msm(sc)
+    assert not _wide_ran(khip) and ginf == winf and np.array_equal(got, want)
+    srs.set_wide_tables(True)
+    assert srs.has_wide_tables()
+    got, ginf = srs.msm(sc)
+    assert _wide_ran(khip) and ginf == winf and np.array_equal(got, want)
+    srs.close()
+    # a basis too small for any window tables cannot get the wide set either
+    small = khip.Srs(khip.VESTA, g[:512])
+    assert not small.has_wide_tables()
+    with pytest.raises(Exception):
+        small.set_wide_tables(True)
+    small.close()
