@@ -600,7 +600,172 @@ class _DryEngine:
         pass
 
 
+def host_scalars_block(khip, srs, sc, n, steps, depth, want):
+    """The same MSM from HOST scalars (pageable memory: what SRS::commit_non_hiding(&DensePolynomial) hands over, poly-commitment/src/ipa.rs:638-683) -- never
+    `value`: pipelined through kh_msm_submit_host / kh_msm_wait (`depth` in flight, the upload of MSM i + 1 under the accumulation of MSM i; two distinct host
+    buffers, as a caller's polynomials are), and one at a time through kh_msm (two half-range jobs with chunked uploads).  Median of three regions."""
+    bufs = [sc, sc.copy()]
+    out, inf = srs.msm(bufs[1])                            # warm: sizes the slots' scalar workspaces, pins nothing
+    ok = (bool(inf) == bool(want[1])) and (bool(inf) or bool(np.array_equal(out, want[0])))
+    vals = []
+    for _ in range(3):
+        q = []
+        t0 = time.perf_counter()
+        for i in range(steps):
+            if len(q) >= depth:
+                o, f = srs.msm_wait(q.pop(0))
+                ok = ok and (bool(f[0]) == bool(want[1])) and (bool(f[0]) or bool(np.array_equal(o[0], want[0])))
+            q.append(srs.msm_submit_host(bufs[i & 1]))
+        while q:
+            o, f = srs.msm_wait(q.pop(0))
+            ok = ok and (bool(f[0]) == bool(want[1])) and (bool(f[0]) or bool(np.array_equal(o[0], want[0])))
+        vals.append(n * steps / (time.perf_counter() - t0) / 1e6)
+    lat = []
+    for i in range(7):
+        t0 = time.perf_counter(); srs.msm(bufs[i & 1]); lat.append(1e3 * (time.perf_counter() - t0))
+    return {"value_host_scalars": sorted(vals)[1], "value_host_scalars_runs": vals, "ms_per_msm_host_scalars_synchronous": float(np.median(lat)),
+            "host_scalars_results_match": bool(ok),
+            "host_scalars_note": "PCIe-inclusive, pageable host memory, never `value`: %d MSMs per region through kh_msm_submit_host with %d in flight; synchronous = kh_msm" % (steps, depth)}
+
+
+def gpu_locality(pci_bus_id):
+    """(numa_node, cpus) of the PCIe device `pci_bus_id` ("0000:c1:00.0") from sysfs, or (None, None) where the kernel does not say."""
+    base = "/sys/bus/pci/devices/%s/" % pci_bus_id.lower()
+    try:
+        node = int(open(base + "numa_node").read())
+    except (OSError, ValueError):
+        node = None
+    cpus = None
+    try:
+        cpus = set()
+        for part in open(base + "local_cpulist").read().strip().split(","):
+            if part:
+                a, _, b = part.partition("-")
+                cpus.update(range(int(a), int(b or a) + 1))
+    except (OSError, ValueError):
+        cpus = None
+    return (node if node is not None and node >= 0 else None), (cpus or None)
+
+
+def bind_rank_to_gpu(torch, device_index, world):
+    """One process per GPU: keep this rank's host threads (submit loop, combiner, the library's helper thread, the runtime's staging copies) on the CPUs of
+    the NUMA node its GPU hangs off -- a rank on the far socket pays the cross-socket hop on every doorbell, completion word and 72-byte partial.  Only at
+    N > 1 (a lone rank keeps the scheduler's choice: that is how the N = 1 line has always been measured), only when sysfs names the locality and it
+    intersects the CPUs the container may use; KH_BENCH_NO_AFFINITY=1 switches it off.  Returns what the rank banner prints."""
+    info = {"pci": None, "numa_node": None, "cpus_bound": None}
+    try:
+        pr = torch.cuda.get_device_properties(device_index)
+        info["pci"] = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+    except Exception:                                      # noqa: BLE001 -- diagnostics only
+        return info
+    node, cpus = gpu_locality(info["pci"])
+    info["numa_node"] = node
+    if world <= 1 or cpus is None or os.environ.get("KH_BENCH_NO_AFFINITY", "0") not in ("", "0"):
+        return info
+    mine = cpus & os.sched_getaffinity(0)
+    if mine:
+        try:
+            os.sched_setaffinity(0, mine)
+            info["cpus_bound"] = len(mine)
+        except OSError:
+            pass
+    return info
+
+
+class Watchdog:
+    """A rank that hangs (a collective whose peer died, a kernel that never ends) must end the RUN, with a line that says where: every phase of main() arms a
+    deadline; when one passes, this rank prints a JSON line with an `error` field (stdout, like the result line: the driver reads it instead of a time-out) and
+    leaves with os._exit -- torch.distributed.run then takes the other ranks down.  KH_BENCH_WATCHDOG_S scales the deadlines (0 = off)."""
+
+    def __init__(self, rank, world, base):
+        self.rank, self.world, self.base = rank, world, base
+        self.scale = float(os.environ.get("KH_BENCH_WATCHDOG_S", "1") or 0)
+        self.deadline, self.name = None, None
+        self.lock = threading.Lock()
+        if self.scale > 0:
+            threading.Thread(target=self._run, daemon=True).start()
+
+    def phase(self, name, seconds):
+        with self.lock:
+            self.name, self.deadline = name, (time.monotonic() + seconds * self.scale) if seconds else None
+
+    def _run(self):
+        while True:
+            time.sleep(0.25)
+            with self.lock:
+                late = self.deadline is not None and time.monotonic() > self.deadline
+                name = self.name
+            if late:
+                emit_error(self.base, self.rank, self.world, "watchdog: phase '%s' exceeded its deadline on rank %d" % (name, self.rank))
+                os._exit(4)
+
+
+def emit_error(base, rank, world, msg):
+    """ONE JSON line with an `error` field instead of a result (any rank may be the one that knows)"""
+    line = dict(base)
+    line.update({"value": None, "n_gpus": world, "error": msg, "error_rank": rank})
+    sys.stdout.write(json.dumps(line) + "\n"); sys.stdout.flush()
+    print("[bench rank %d/%d] ERROR: %s" % (rank, world, msg), file=sys.stderr, flush=True)
+
+
+class Combiner:
+    """The cross-rank combine of finished MSMs (all-gather of the 72-byte partial sums + local fold) on its OWN thread, in submission order: the thread that
+    submits MSM i + 1 no longer waits inside the collective of MSM i.  Every rank pushes the same sequence, so the collectives match
+    up rank to rank.  At N = 1 (no collective) the combine stays inline."""
+
+    def __init__(self, sm, torch_mod, cuda_dev):
+        import queue
+        self.sm, self.q, self.last, self.err = sm, queue.Queue(), None, None
+        self.torch, self.cuda_dev = torch_mod, cuda_dev
+        self.th = threading.Thread(target=self._run, daemon=True)
+        self.th.start()
+
+    def _run(self):
+        if self.cuda_dev is not None:
+            self.torch.cuda.set_device(self.cuda_dev)      # the current device is per thread
+        while True:
+            item = self.q.get()
+            try:
+                if item is not None and self.err is None:
+                    o, i = self.sm.combine(item[0], item[1])
+                    self.last = (o[-1], bool(i[-1]))
+            except Exception as e:                        # noqa: BLE001 -- re-raised on the submitting thread by drain()
+                self.err = e
+            finally:
+                self.q.task_done()
+            if item is None:
+                return
+
+    def push(self, xys, infs):
+        self.q.put((xys, infs))
+
+    def drain(self):
+        self.q.join()
+        if self.err is not None:
+            raise self.err
+        return self.last
+
+    def close(self):
+        self.q.put(None)
+        self.th.join(5)
+
+
 def main():
+    base = {"metric": "MSM Mscalar/s at 2^%d (Vesta)" % LOG_N, "unit": "Mscalar/s", "higher_is_better": True}
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    try:
+        _main(base)
+    except SystemExit:
+        raise
+    except BaseException as e:                             # noqa: BLE001 -- a failed rank ends the run with a line that says why
+        import traceback
+        traceback.print_exc()
+        emit_error(base, rank, world, "%s: %s" % (type(e).__name__, e))
+        sys.stdout.flush(); sys.stderr.flush()
+        os._exit(1)
+
+
+def _main(base):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -632,6 +797,9 @@ def main():
     if args.strong and args.log_n == LOG_N:
         args.log_n = 22
     total = (1 << args.log_n) if args.strong else world << args.log_n
+    base["metric"] = "MSM Mscalar/s at 2^%d (%s)" % (args.log_n, args.curve.capitalize())
+    wd = Watchdog(rank, world, base)
+    wd.phase("process group", 300)
 
     import torch
     dist = None
@@ -653,6 +821,8 @@ def main():
         if not args.dry_run:
             ndev = max(1, torch.cuda.device_count())
             torch.cuda.set_device(local_rank % ndev)
+        if os.environ.get("KH_BENCH_FAIL_RANK") == str(rank):            # test hook (tests/test_bench_dry.py): this rank dies before the process group forms
+            raise RuntimeError("KH_BENCH_FAIL_RANK: rank %d fails on purpose" % rank)
         t_pg0 = time.perf_counter()
         dist_mod.init_process_group(backend=backend, rank=rank, world_size=world)
         t_pg = time.perf_counter() - t_pg0
@@ -673,18 +843,47 @@ def main():
     CID = khip.VESTA if args.curve == "vesta" else khip.PALLAS
     # KH_BENCH_COMM=lib: the combine of the timed loop through the library's OWN collective (kh_comm_allgather_points + kh_points_sum = what
     # kh_msm_allreduce does and a Rust / C caller gets; librccl by dlopen, no torch in the data path) instead of torch.distributed's all_gather
-    lib_comm = None
-    if os.environ.get("KH_BENCH_COMM", "torch") == "lib" and dist is not None:
+    # Round 6: the in-library collective is the DEFAULT carrier of the timed loop whenever the process group is RCCL (`nccl`), torch's all_gather the
+    # cross-check (other_collective_check) -- KH_BENCH_COMM=torch swaps the roles.  The communicator is formed under a time limit and the ranks then AGREE
+    # (an all-reduce over the torch group) on whether every one of them has it: a rank that could not load librccl or join falls everybody back to torch.
+    lib_comm, lib_note = None, None
+    want_lib = os.environ.get("KH_BENCH_COMM", "lib" if backend == "nccl" else "torch") == "lib"
+    affinity = {"pci": None, "numa_node": None, "cpus_bound": None}
+    if not args.dry_run:
+        affinity = bind_rank_to_gpu(torch, dev, world)
+    if want_lib and dist is not None and not args.dry_run:
+        wd.phase("in-library communicator", 240)
         khip.init(dev)
-        lib_comm = make_lib_comm(khip, dist, rank, world)
+        box = {}
+
+        def form():
+            try:
+                torch.cuda.set_device(dev)
+                box["comm"] = make_lib_comm(khip, dist, rank, world)
+            except Exception as e:                        # noqa: BLE001 -- reported, the torch collective takes over
+                box["err"] = "%s: %s" % (type(e).__name__, e)
+        th_ = threading.Thread(target=form, daemon=True); th_.start(); th_.join(120)
+        ok_t = torch.tensor([1 if "comm" in box else 0], dtype=torch.int32, device=coll_dev)
+        if th_.is_alive():
+            lib_note = "kh_comm_init did not return within 120 s on rank %d" % rank       # (its thread holds the torch group inside a broadcast: nothing more can be agreed)
+            raise RuntimeError(lib_note)
+        dist.all_reduce(ok_t, op=dist.ReduceOp.MIN)
+        if int(ok_t.item()) == 1:
+            lib_comm = box["comm"]
+        else:
+            lib_note = "in-library communicator not formed on every rank (%s): torch.distributed carries the loop" % box.get("err", "another rank failed")
+            if "comm" in box:
+                box["comm"].free()
+    wd.phase("shard tables", 300)
     sm = sharded.RankShardedMsm(CID, total, dist=dist, coll_device=coll_dev, engine=_DryEngine(khip) if args.dry_run else sharded.KhipEngine(dev), rank=rank, world=world,
                                 comm=lib_comm, always_collective=force_coll)
     srs, n = sm.shard, sm.count
     t_gen = time.perf_counter() - t0
     if world > 1 or force_coll:                            # one line per rank BEFORE the timed loop: what a first multi-GPU run needs to be debugged from its log
-        print("[bench rank %d/%d] device %d (%d visible), shard = points [%d, %d) of %d, collective %s over %s, process group up in %.2f s, shard tables in %.2f s"
-              % (rank, world, dev, khip.device_count(), sm.start, sm.start + n, total,
-                 sm.collective_backend, backend, t_pg, t_gen), file=sys.stderr, flush=True)
+        print("[bench rank %d/%d] device %d (%d visible, pci %s, numa node %s, host threads bound to %s of its CPUs), shard = points [%d, %d) of %d, collective %s over %s, "
+              "process group up in %.2f s, shard tables in %.2f s%s"
+              % (rank, world, dev, khip.device_count(), affinity["pci"], affinity["numa_node"], affinity["cpus_bound"], sm.start, sm.start + n, total,
+                 "rccl-lib" if lib_comm is not None else ("%s-torch" % backend), backend, t_pg, t_gen, ("; " + lib_note) if lib_note else ""), file=sys.stderr, flush=True)
     if args.dry_run:
         class _NoBuf:
             ptr = 0
@@ -693,12 +892,14 @@ def main():
         sc = rand_scalars(np.random.default_rng(1234 + rank), n)
         d_sc = khip.DevBuf(sc.nbytes).upload(sc)
 
-    last_partial = [None]
-
-    def combine(out, inf):
-        last_partial[0] = (np.array(out[:1], dtype=np.uint64).reshape(1, 8), np.array(inf[:1], dtype=np.uint8).reshape(1))
-        o, i = sm.combine(out[:1], inf[:1])          # all-gather of the partial sums + local fold (no-op at N = 1)
-        return o[0], bool(i[0])
+    depth = 1 if args.no_pipeline else int(os.environ.get('KH_BENCH_DEPTH', '2'))      # round 5, wide tables (profiles/r05_wide_sweep.txt): 2 / 3 / 4 in flight = 1007 / 998 / 1015 and 1009 / 1001 / 992 Mscalar/s: no difference; round 4: 852 / 836 / 821
+    # one collective per MSM by default (ADVICE round 4: batching `depth` partial sums into one collective made the N > 1 figure incomparable with
+    # earlier rounds); KH_BENCH_COMBINE_EVERY=k batches k finished MSMs per collective as a prover would per phase (SURVEY 8e)
+    combine_every = max(1, int(os.environ.get('KH_BENCH_COMBINE_EVERY', '1')))
+    # KH_BENCH_RAMP=r: the number in flight starts at r and grows by one per finished MSM up to `depth` (an experiment on the pipeline's fill:
+    # four jobs submitted at once run their sorts and accumulations in lockstep until they drift apart)
+    ramp = int(os.environ.get('KH_BENCH_RAMP', '0'))
+    cuda_dev = torch.cuda.current_device() if (coll_dev == "cuda" and not args.dry_run) else None
 
     def fence():
         if not args.dry_run:
@@ -709,70 +910,126 @@ def main():
             if not args.dry_run:
                 torch.cuda.synchronize()
 
-    # warm-up doubles as the latency measurement: synchronous steps
-    sync_ms = []
-    for _ in range(max(1, args.warmup)):
-        ts = time.perf_counter()
-        result = combine(*srs.msm_batch_dev(d_sc.ptr, n, 1))
-        sync_ms.append(1e3 * (time.perf_counter() - ts))
-    # timed region: EXACTLY `steps` MSMs, `depth` in flight (kh_msm_submit / kh_msm_wait; two by default): the sort of step i+1 and the
-    # bucket-reduction tail of step i-1 run underneath the accumulation of step i.  Every step is a full MSM whose affine
-    # result is fetched and (N>1) combined across ranks INSIDE the region; the partial sums of up to `depth` finished MSMs travel in ONE
-    # collective ("batch the partials of all MSMs in a phase into one collective" -- a prover combines the commitments of a
-    # phase together; KH_BENCH_COMBINE_EVERY=1 gives one collective per MSM).
-    depth = 1 if args.no_pipeline else int(os.environ.get('KH_BENCH_DEPTH', '2'))      # round 5, wide tables (profiles/r05_wide_sweep.txt): 2 / 3 / 4 in flight = 1007 / 998 / 1015 and 1009 / 1001 / 992 Mscalar/s: no difference; round 4: 852 / 836 / 821
-    # one collective per MSM by default (ADVICE round 4: batching `depth` partial sums into one collective made the N > 1 figure incomparable with
-    # earlier rounds); KH_BENCH_COMBINE_EVERY=k batches k finished MSMs per collective as a prover would per phase (SURVEY 8e)
-    combine_every = max(1, int(os.environ.get('KH_BENCH_COMBINE_EVERY', '1')))
-    # KH_BENCH_RAMP=r: the number in flight starts at r and grows by one per finished MSM up to `depth` (an experiment on the pipeline's fill:
-    # four jobs submitted at once run their sorts and accumulations in lockstep until they drift apart)
-    ramp = int(os.environ.get('KH_BENCH_RAMP', '0'))
+    def measure(sm_, srs_, d_sc_, n_, nregions, label):
+        """warm-up (synchronous steps: the latency), then `nregions` timed regions of EXACTLY args.steps MSMs each over the shard `srs_` of `sm_`; returns
+        (region wall times -- max over ranks --, last combined result, last local partial, synchronous step times).  Timed region: `depth` MSMs in flight
+        (kh_msm_submit / kh_msm_wait; two by default): the sort of step i+1 and the bucket-reduction tail of step i-1 run underneath the accumulation of
+        step i.  Every step is a full MSM whose affine result is fetched and (N>1) combined across ranks INSIDE the region -- on the combiner thread, in
+        submission order, so that the submitting thread is never inside a collective (round 6) --, one collective per MSM (combine_every)."""
+        state = {"result": None, "partial": None}
+        combiner = Combiner(sm_, torch, cuda_dev) if (dist is not None and (world > 1 or force_coll) and os.environ.get("KH_BENCH_INLINE_COMBINE", "0") in ("", "0")) else None
 
-    def timed_region():
-        """EXACTLY args.steps MSMs between two fences; returns the wall time (max over ranks) and the last combined result"""
-        nonlocal result
-        pending, done = [], []
+        def combine_now(out, inf):
+            state["partial"] = (np.array(out[:1], dtype=np.uint64).reshape(1, 8), np.array(inf[:1], dtype=np.uint8).reshape(1))
+            o, i = sm_.combine(out[:1], inf[:1])          # all-gather of the partial sums + local fold (no-op at N = 1)
+            return o[0], bool(i[0])
+        wd.phase(label + ": warm-up", 180)
+        sync_ms_ = []
+        for _ in range(max(1, args.warmup)):               # warm-up doubles as the latency measurement: synchronous steps
+            ts = time.perf_counter()
+            state["result"] = combine_now(*srs_.msm_batch_dev(d_sc_.ptr, n_, 1))
+            sync_ms_.append(1e3 * (time.perf_counter() - ts))
 
-        def flush():
-            nonlocal result
-            if not done:
-                return
-            last_partial[0] = (np.array(done[-1][0], dtype=np.uint64).reshape(1, 8), np.array([done[-1][1]], dtype=np.uint8))
-            o, i = sm.combine([d[0] for d in done], [d[1] for d in done])
-            result = (o[-1], bool(i[-1]))
-            done.clear()
+        def timed_region():
+            pending, done = [], []
 
-        def collect(ticket):
-            xy, inf = srs.msm_wait(ticket)
-            done.append((xy[0], inf[0]))
-            if len(done) >= combine_every:
-                flush()
-        fence()
-        t0 = time.perf_counter()
-        cur_depth = min(depth, ramp) if ramp > 0 else depth
-        for _ in range(args.steps):
-            pending.append(srs.msm_submit(d_sc.ptr, n, 1))
-            if len(pending) >= cur_depth:
+            def flush():
+                if not done:
+                    return
+                state["partial"] = (np.array(done[-1][0], dtype=np.uint64).reshape(1, 8), np.array([done[-1][1]], dtype=np.uint8))
+                xs, fs = [d[0] for d in done], [d[1] for d in done]
+                done.clear()
+                if combiner is not None:
+                    combiner.push(xs, fs)
+                else:
+                    o, i = sm_.combine(xs, fs)
+                    state["result"] = (o[-1], bool(i[-1]))
+
+            def collect(ticket):
+                xy, inf = srs_.msm_wait(ticket)
+                done.append((xy[0], inf[0]))
+                if len(done) >= combine_every:
+                    flush()
+            fence()
+            t0 = time.perf_counter()
+            cur_depth = min(depth, ramp) if ramp > 0 else depth
+            for _ in range(args.steps):
+                pending.append(srs_.msm_submit(d_sc_.ptr, n_, 1))
+                if len(pending) >= cur_depth:
+                    collect(pending.pop(0))
+                    cur_depth = min(depth, cur_depth + 1)
+            while pending:
                 collect(pending.pop(0))
-                cur_depth = min(depth, cur_depth + 1)
-        while pending:
-            collect(pending.pop(0))
-        flush()
-        fence()
-        el = time.perf_counter() - t0
-        if dist is not None:
-            t = torch.tensor([el], dtype=torch.float64, device=coll_dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            el = float(t.item())
-        return el
-    # The region runs THREE times back to back (VERDICT round 4: single-region numbers moved 3-5 % box to box and run to run); `value` is the MEDIAN
-    # region, all three are on the line (`value_runs`); ms_per_step x steps is that one region's wall time.
-    if not args.dry_run:
-        khip.set_phase_timers(False)                       # no per-phase HIP events inside the timed regions (the library's default; khip.init switches them on for tools)
-    runs = [timed_region() for _ in range(1 if args.single_region else 3)]
+            flush()
+            if combiner is not None:
+                state["result"] = combiner.drain()         # every combine of the region has landed before the clock stops
+            fence()
+            el = time.perf_counter() - t0
+            if dist is not None:
+                t = torch.tensor([el], dtype=torch.float64, device=coll_dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                el = float(t.item())
+            return el
+        # The region runs THREE times back to back (VERDICT round 4: single-region numbers moved 3-5 % box to box and run to run); `value` is the MEDIAN
+        # region, all three are on the line (`value_runs`); ms_per_step x steps is that one region's wall time.
+        if not args.dry_run:
+            khip.set_phase_timers(False)                   # no per-phase HIP events inside the timed regions (the library's default; khip.init switches them on for tools)
+        runs_ = []
+        for r_ in range(nregions):
+            wd.phase("%s: timed region %d" % (label, r_), 180)
+            runs_.append(timed_region())
+        if not args.dry_run:
+            khip.set_phase_timers(True)                    # ... the synchronous steps below read them
+        if combiner is not None:
+            combiner.close()
+        return runs_, state["result"], state["partial"], sync_ms_, combine_now
+
+    nreg = 1 if args.single_region else 3
+    runs, result, last_p, sync_ms, combine = measure(sm, srs, d_sc, n, nreg, "strong" if args.strong else "weak")
+    last_partial = [last_p]
     elapsed = sorted(runs)[len(runs) // 2]
-    if not args.dry_run:
-        khip.set_phase_timers(True)                        # ... the synchronous steps below read them
+
+    # BOTH scalings from one invocation (round 6): at N > 1 the weak run above is followed by BASELINE config 4 -- ONE 2^22-point MSM whose point range is cut
+    # over the ranks (2^22 / N points each) -- with its own shard tables, warm-up and timed regions; it rides in the line as `strong` (KH_BENCH_NO_STRONG=1
+    # skips it; `--strong` alone still makes config 4 the line's own workload).
+    strong_block = None
+    if world > 1 and not args.strong and os.environ.get("KH_BENCH_NO_STRONG", "0") in ("", "0"):
+        wd.phase("strong: shard tables", 300)
+        s_total = 1 << int(os.environ.get("KH_BENCH_STRONG_LOG_N", "22"))
+        sm2 = sharded.RankShardedMsm(CID, s_total, dist=dist, coll_device=coll_dev, engine=sm.engine, rank=rank, world=world, comm=lib_comm, always_collective=force_coll)
+        if args.dry_run:
+            sc2, d_sc2 = None, d_sc
+        else:
+            sc2 = rand_scalars(np.random.default_rng(4321 + rank), sm2.count)
+            d_sc2 = khip.DevBuf(sc2.nbytes).upload(sc2)
+        runs2, result2, _, sync2, _ = measure(sm2, sm2.shard, d_sc2, sm2.count, nreg, "strong")
+        el2 = sorted(runs2)[len(runs2) // 2]
+        strong_block = {"workload": "msm_2^%d_%s_srs_sharded" % (s_total.bit_length() - 1, args.curve), "scaling": "strong", "points_total": s_total, "points_per_gpu": sm2.count,
+                        "value": None if args.dry_run else s_total / (el2 / args.steps) / 1e6, "unit": "Mscalar/s", "ms_per_step": 1e3 * el2 / args.steps,
+                        "value_runs": [None if args.dry_run else s_total / (r / args.steps) / 1e6 for r in runs2], "ms_per_step_synchronous": float(np.median(sync2)),
+                        "collective_backend": sm2.collective_backend}
+        if args.dry_run:
+            h = sm2.shard.h
+            acc_xy, acc_inf = h.copy(), False
+            for _ in range(world - 1):
+                acc_xy, acc_inf = sm.engine.points_sum(CID, np.stack([acc_xy, h]), np.zeros(2, np.uint8))
+            strong_block["combined_result_is_world_times_h"] = (not result2[1]) and bool(np.array_equal(np.asarray(result2[0], dtype=np.uint64).reshape(8), acc_xy))
+        elif not args.no_cpu_baseline:
+            wd.phase("strong: parity against the oracle", 600)
+            from oracle import cref          # checker leg only
+            want2, winf2 = cref.msm(CID, sm2.shard.get_g(), sc2, scalars_mont=True, threads=max(1, usable_threads() // world))
+            mine = torch.from_numpy(np.concatenate([want2, np.array([int(winf2)], dtype=np.uint64)]).view(np.int64).copy()).to(coll_dev)
+            allp = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(allp, mine)
+            parts = torch.stack(allp).cpu().numpy().view(np.uint64)
+            accp, ainf = parts[0, :8].copy(), bool(parts[0, 8])
+            for r in range(1, world):
+                accp, ainf = cref.point_add(CID, accp, parts[r, :8].copy(), ainf, bool(parts[r, 8]))
+            strong_block["combined_result_matches_oracle"] = bool((ainf == result2[1]) and (ainf or bool(np.array_equal(accp, result2[0]))))
+        if not args.dry_run:
+            d_sc2.free()
+        sm2.close()
+    wd.phase("after the timed regions", 900)
 
     ms_per_step = 1e3 * elapsed / args.steps
     value = total / (elapsed / args.steps) / 1e6
@@ -785,7 +1042,8 @@ def main():
         if rank == 0:
             print(json.dumps({"metric": "MSM Mscalar/s at 2^%d (%s)" % (args.log_n, args.curve.capitalize()), "dry_run": True, "value": None, "unit": "Mscalar/s", "n_gpus": world,
                               "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "ranks_reported": world, "value_runs": [None] * len(runs),
-                              "combined_result_is_world_times_h": ok,
+                              "combined_result_is_world_times_h": ok, "strong": strong_block,
+                              "combine_thread": bool(dist is not None and (world > 1 or force_coll) and os.environ.get("KH_BENCH_INLINE_COMBINE", "0") in ("", "0")),
                               "config": {"workload": "dry run: no GPU work", "collective_backend": sm.collective_backend, "process_group_backend": backend,
                                          "world_size_seen": world, "partials_per_collective": combine_every, "msm_in_flight": depth}}), flush=True)
         if dist is not None:
@@ -822,11 +1080,21 @@ def main():
         "ms_per_step_synchronous": latency, "msm_in_flight": depth,
         "roofline": roofline_block(kname, acc, n, args.log_n) if not args.strong else roofline_block(kname, acc, n, -1),
         "phases_ms": phase_avg, "srs_create_device_s": t_gen,
+        "combine_thread": bool(dist is not None and (world > 1 or force_coll) and os.environ.get("KH_BENCH_INLINE_COMBINE", "0") in ("", "0")),
+        "rank0_locality": affinity,
     }
+    if lib_note:
+        line["collective_note"] = lib_note
+    if strong_block is not None:
+        line["strong"] = strong_block
+    if world == 1 and not args.strong:
+        wd.phase("host-scalar pipeline", 300)
+        line.update(host_scalars_block(khip, srs, sc, n, args.steps, depth, result))
 
     # parity at full size, every rank: its partial against the oracle on its own slice; rank 0 then folds the oracle's
     # partials with the oracle's group law and compares with the combined GPU result
     if not args.no_cpu_baseline:
+        wd.phase("parity against the oracle / cpu baseline", 900)
         from oracle import cref          # cpu_baseline / checker leg only
         g = srs.get_g()
         threads = max(1, usable_threads() // world)
@@ -853,6 +1121,7 @@ def main():
         if rank == 0 and not ok:
             line["parity_error"] = "GPU result differs from the CPU oracle"
 
+    wd.phase("transform and prover blocks", 1800)
     if rank == 0 and world == 1 and not args.no_oplist and args.curve == "vesta" and not args.strong:
         line["ntt_kernels"] = ntt_block(khip)
         line["prover"] = prover_block(khip, srs, check_with_oracle=not args.no_cpu_baseline)
@@ -863,8 +1132,17 @@ def main():
     # must land on the same point -- the driver's N > 1 runs thereby execute the in-library RCCL path too.  Guarded by a watchdog: a collective
     # that hangs costs the check, not the line.
     hung = False
+    wd.phase("the other collective", 240)
     if dist is not None and backend == "nccl" and last_partial[0] is not None:
         line["other_collective"], hung = other_collective_check(khip, dist, sm, lib_comm, last_partial[0], result, rank, world, coll_dev)
+    wd.phase("teardown", 120)
+    # LAST on the line (the driver's record keeps the tail of the output): both halves of BASELINE's metric and what pins them
+    pr = line.get("prover") or {}
+    line["summary"] = {"msm_Mscalar_per_s": value, "msm_Mscalar_per_s_host_scalars": line.get("value_host_scalars"), "n_gpus": world,
+                       "prover_seconds": pr.get("seconds"), "prover_constraints_per_s": pr.get("constraints_per_s"), "prover_gpu_busy_frac": pr.get("gpu_busy_frac"),
+                       "prover_byte_identical_to_oracle": pr.get("byte_identical_to_oracle"), "proofs_per_s_concurrent": (pr.get("concurrent") or {}).get("proofs_per_s"),
+                       "msm_gpu_result_matches_oracle": (line.get("cpu_baseline") or {}).get("gpu_result_matches", (line.get("multi_gpu_parity") or {}).get("combined_result_matches_oracle")),
+                       "cpu_baseline_cores": (line.get("cpu_baseline") or {}).get("cores"), "strong_Mscalar_per_s": (strong_block or {}).get("value")}
     if rank == 0:
         print(json.dumps(line), flush=True)
     if hung:

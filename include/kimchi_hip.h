@@ -441,6 +441,13 @@ int kh_msm_submit(kh_srs_t *srs, int basis, unsigned chunk, size_t offset,
                   const uint64_t *scalars_dev, size_t n, size_t k, int scalars_are_montgomery,
                   uint64_t *ticket);
 int kh_msm_wait(uint64_t ticket, uint64_t *out_xy /* host, k x 8 */, uint8_t *out_is_inf /* host, k */);
+/* The same pipeline from HOST scalars -- what SRS::commit_non_hiding(&DensePolynomial) hands over (poly-commitment/src/ipa.rs:638-683): the upload is cut
+ * into chunks on the calling thread's copy stream and each chunk's digit pass is queued behind it, so with two MSMs in flight the PCIe transfer of MSM i + 1
+ * runs underneath the accumulation of MSM i.  Returns when the scalars have been taken (pageable or pinned memory: the caller may reuse the buffer at once);
+ * the job itself keeps running; kh_msm_wait collects it. */
+int kh_msm_submit_host(kh_srs_t *srs, int basis, unsigned chunk, size_t offset,
+                       const uint64_t *scalars /* host, k x n x 4 limbs */, size_t n, size_t k, int scalars_are_montgomery,
+                       uint64_t *ticket);
 int kh_ntt_dev(int field, uint64_t *data_dev, unsigned log2_n, int inverse, size_t batch);
 int kh_lde_dev(int field, const uint64_t *coeffs_dev, unsigned log2_n, unsigned log2_blowup,
                uint64_t *out_dev, size_t batch);

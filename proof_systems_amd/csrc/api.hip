@@ -268,6 +268,20 @@ static hipStream_t thread_copy_stream() {
     return tl.s[d];
 }
 
+// events of the chunked scalar upload (MsmHostScalars), per (host thread, device)
+static constexpr int UPLOAD_CHUNKS = 8;
+struct ThreadUploadEvents {
+    hipEvent_t e[KH_MAX_DEVICES][UPLOAD_CHUNKS] = {{nullptr}};
+    ~ThreadUploadEvents() { for (auto& row : e) for (hipEvent_t x : row) if (x) (void)hipEventDestroy(x); }
+};
+static hipEvent_t* thread_upload_events() {
+    static thread_local ThreadUploadEvents tl;
+    const int d = kh::ctx().device >= 0 && kh::ctx().device < KH_MAX_DEVICES ? kh::ctx().device : 0;
+    for (int i = 0; i < UPLOAD_CHUNKS; i++)
+        if (!tl.e[d][i] && hipEventCreateWithFlags(&tl.e[d][i], hipEventDisableTiming) != hipSuccess) { kh::set_error("hipEventCreate for an upload event failed"); return nullptr; }
+    return tl.e[d];
+}
+
 // kh_dev_alloc / kh_dev_free go through a small caching pool: hipFree synchronises the device and takes ~0.25 ms, and a prover frees
 // ~15 column buffers per proof (3.8 ms of a 16 ms proof, measured with cProfile on proof_systems_amd/prover.py).  Freed blocks are
 // kept per device, keyed by their (4 KiB-rounded) size, and handed out again to a request of nearly that size.  Within ONE context reuse is
@@ -712,7 +726,8 @@ static const char* slot_error(int si) {
 }
 // enqueue on a free slot; returns the slot index through *slot_out
 static int msm_submit_locked(Context& C, kh_srs_t* srs, int basis, unsigned chunk, size_t offset, const uint64_t* scalars,
-                             bool scalars_on_device, size_t n, size_t k, int mont, int* slot_out, std::unique_lock<std::mutex>* lk = nullptr) {
+                             bool scalars_on_device, size_t n, size_t k, int mont, int* slot_out, std::unique_lock<std::mutex>* lk = nullptr,
+                             bool host_async = false) {
     MsmBasis b; int rc = resolve_basis(srs, basis, chunk, b); if (rc) return rc;
     KH_REQUIRE(offset <= b.n, "offset %zu beyond basis length %zu", offset, b.n);
     size_t use = n < b.n - offset ? n : b.n - offset;      // msm_bigint semantics: min(len) pairs
@@ -721,11 +736,26 @@ static int msm_submit_locked(Context& C, kh_srs_t* srs, int basis, unsigned chun
     if (lk && (rc = resolve_basis(srs, basis, chunk, b))) return rc;     // acquire_slot may have dropped the lock: the basis map can have changed
     MsmSlot& S = C.slot[si];
     const uint64_t* sdev = scalars;
+    // a big single MSM from host scalars: upload and digit pass in chunks on the calling thread's copy stream (MsmHostScalars) -- the other slots' jobs keep
+    // the GPU busy meanwhile (kh_msm_submit_host: two in flight hide the whole upload), and a lone MSM hides its digit pass
+    static const size_t chunked_min = getenv("KH_HOST_CHUNK_MIN") ? (size_t)atol(getenv("KH_HOST_CHUNK_MIN")) : ((size_t)1 << 17);     // scalars; 0 = never
+    MsmHostScalars hs{}; const MsmHostScalars* hsp = nullptr;
+    if (!scalars_on_device && k == 1 && chunked_min && use >= chunked_min) {
+        if ((rc = S.ws_scalars.reserve(use * 32))) return rc;
+        hs.host = scalars; hs.cs = thread_copy_stream(); hs.ev = thread_upload_events();
+        if (!hs.cs || !hs.ev) return KH_E_DEVICE;
+        hs.nev = (int)std::min<size_t>(UPLOAD_CHUNKS, std::max<size_t>(1, use >> 16));       // >= 2 MB per chunk
+        hsp = &hs; sdev = S.ws_scalars.as<uint64_t>();
+    } else
     if (!scalars_on_device && use > 0 && k > 0) {
         if ((rc = S.ws_scalars.reserve(k * use * 32))) return rc;
-        if (use == n) KH_HIP(hipMemcpyAsync(S.ws_scalars.p, scalars, k * n * 32, hipMemcpyHostToDevice, S.stream));
+        // (host_async: kh_msm_submit_host returns while the job runs -- its copies go on the calling thread's copy stream, which that call waits for)
+        hipStream_t up = S.stream; hipEvent_t* uev = nullptr;
+        if (host_async) { up = thread_copy_stream(); uev = thread_upload_events(); if (!up || !uev) return KH_E_DEVICE; }
+        if (use == n) KH_HIP(hipMemcpyAsync(S.ws_scalars.p, scalars, k * n * 32, hipMemcpyHostToDevice, up));
         else for (size_t j = 0; j < k; j++)
-            KH_HIP(hipMemcpyAsync((char*)S.ws_scalars.p + j * use * 32, scalars + j * n * 4, use * 32, hipMemcpyHostToDevice, S.stream));
+            KH_HIP(hipMemcpyAsync((char*)S.ws_scalars.p + j * use * 32, scalars + j * n * 4, use * 32, hipMemcpyHostToDevice, up));
+        if (host_async) { KH_HIP(hipEventRecord(uev[0], up)); KH_HIP(hipStreamWaitEvent(S.stream, uev[0], 0)); }
         sdev = S.ws_scalars.as<uint64_t>();
     } else if (scalars_on_device) {
         KH_REQUIRE(use == n || k == 1, "device-resident batched scalars must not exceed the basis window");
@@ -733,8 +763,11 @@ static int msm_submit_locked(Context& C, kh_srs_t* srs, int basis, unsigned chun
         // the event recorded right behind the last such producer (NOT for whatever else slot 0's stream has queued since)
         if (C.main_dirty && S.stream != C.stream) KH_HIP(hipStreamWaitEvent(S.stream, C.order_ev, 0));
     }
-    rc = msm_enqueue(C, S, srs->curve, b, offset, sdev, use, k, mont);
-    if (rc) return rc;
+    rc = msm_enqueue(C, S, srs->curve, b, offset, sdev, use, k, mont, 0, hsp);
+    if (rc) {
+        if (hsp) (void)hipStreamSynchronize(hs.cs);      // a caller that sees an error may free its scalars at once: no copy may still be reading them
+        return rc;
+    }
     *slot_out = si;
     return KH_OK;
 }
@@ -817,6 +850,28 @@ static int msm_common(kh_srs_t* srs, int basis, unsigned chunk, size_t offset, c
     const bool burst = C.last_sync_msm_arrival.time_since_epoch().count() != 0 &&
                        std::chrono::duration_cast<std::chrono::microseconds>(now - C.last_sync_msm_arrival).count() < 200;
     C.last_sync_msm_arrival = now;
+    // A lone big MSM from host scalars runs as TWO half-range MSMs on two slots (the point range cut in the middle, each half with its own chunked upload):
+    // the second half's PCIe transfer and sort run underneath the first half's accumulation, the host adds the two partial sums.  2^20 Vesta scalars from
+    // pageable memory: 1.99 ms as one job (0.75 ms of un-overlapped upload) -- see profiles/r06_pcie_inclusive.txt for this path.  KH_HOST_SPLIT_MIN (scalars).
+    static const size_t split_min = getenv("KH_HOST_SPLIT_MIN") ? (size_t)atol(getenv("KH_HOST_SPLIT_MIN")) : ((size_t)1 << 20);
+    if (!scalars_on_device && k == 1 && srs != nullptr && !burst && split_min && n >= split_min) {
+        MsmBasis b;
+        if (resolve_basis(srs, basis, chunk, b) == KH_OK && offset <= b.n && b.precomp_c) {
+            const size_t use = n < b.n - offset ? n : b.n - offset, h = use / 2;
+            if (h >= MSM_PRECOMP_MIN_N) {
+                int s0 = -1, s1 = -1;
+                if ((rc = msm_submit_locked(C, srs, basis, chunk, offset, scalars, false, h, 1, mont, &s0, &lk))) return rc;
+                uint64_t xy[16]; uint8_t inf[2] = {1, 1};
+                rc = msm_submit_locked(C, srs, basis, chunk, offset + h, scalars + 4 * h, false, use - h, 1, mont, &s1, &lk);
+                const int rc0 = wait_then_finish(lk, C, C.slot[s0], xy, inf);          // (whatever the second submit said: the first job is in flight)
+                if (rc) return rc;
+                if ((rc = wait_then_finish(lk, C, C.slot[s1], xy + 8, inf + 1))) return rc;
+                if (rc0) return rc0;
+                lk.unlock();
+                return kh_points_sum(srs->curve, xy, inf, 2, out_xy, out_inf);
+            }
+        }
+    }
     bool eligible = coalesce_on && !scalars_on_device && k == 1 && n >= MSM_PRECOMP_MIN_N && srs != nullptr;
     if (eligible) {                                       // whole-window MSMs only (the ragged tail of a chunked polynomial goes alone)
         MsmBasis b; if (resolve_basis(srs, basis, chunk, b) != KH_OK || offset > b.n || n > b.n - offset) eligible = false;
@@ -885,6 +940,26 @@ int kh_msm_submit(kh_srs_t* srs, int basis, unsigned chunk, size_t offset, const
     int si = -1;
     if ((rc = msm_submit_locked(C, srs, basis, chunk, offset, scalars_dev, true, n, k, scalars_are_montgomery, &si, &lk))) return rc;
     *ticket = C.slot[si].ticket | ((uint64_t)C.device << 56);      // the device rides in the top byte: kh_msm_wait may run on any thread
+    return KH_OK;
+}
+int kh_msm_submit_host(kh_srs_t* srs, int basis, unsigned chunk, size_t offset, const uint64_t* scalars, size_t n, size_t k,
+                       int scalars_are_montgomery, uint64_t* ticket) {
+    KH_ON_DEVICE_OF(srs);
+    KH_REQUIRE(ticket, "null ticket pointer");
+    KH_REQUIRE(scalars || n == 0 || k == 0, "null scalars");
+    int rc = ensure_init(); if (rc) return rc;
+    Context& C = ctx();
+    std::unique_lock<std::mutex> lk(C.mu);
+    int si = -1;
+    rc = msm_submit_locked(C, srs, basis, chunk, offset, scalars, false, n, k, scalars_are_montgomery, &si, &lk, true);
+    if (rc) { lk.unlock(); hipStream_t cs0 = thread_copy_stream(); if (cs0) (void)hipStreamSynchronize(cs0); return rc; }
+    *ticket = C.slot[si].ticket | ((uint64_t)C.device << 56);
+    lk.unlock();
+    // The scalars belong to the caller again when this returns: hipMemcpyAsync from pageable memory returns once the runtime has taken the data, but a
+    // caller may hand over pinned (hipHostMalloc / hipHostRegister) memory, whose copies are truly asynchronous -- so wait for the calling thread's copy
+    // stream, which carried every upload of this call (the kernels queued behind them on the slot's stream keep running).
+    hipStream_t cs = thread_copy_stream();
+    if (cs) KH_HIP(hipStreamSynchronize(cs));
     return KH_OK;
 }
 int kh_msm_wait(uint64_t ticket, uint64_t* out_xy, uint8_t* out_is_inf) {

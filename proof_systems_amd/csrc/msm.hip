@@ -153,11 +153,11 @@ __device__ __forceinline__ void emit_digits(Fe<SF> s, int mont, int c, int W, bo
 }
 template <class SF>
 __global__ void k_digits(const u64* __restrict__ scalars, const uint8_t* __restrict__ inf, size_t inf_off,
-                         size_t inf_batch, size_t n, int mont, int c, int W, int32_t* __restrict__ digits) {
+                         size_t inf_batch, size_t n, int mont, int c, int W, int32_t* __restrict__ digits, size_t i0, size_t i1) {
     KH_HIGH_PRIO();
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t i = i0 + (size_t)blockIdx.x * blockDim.x + threadIdx.x;          // scalars [i0, i1) of the n (a chunk of an upload still in flight, or all of them)
     int j = blockIdx.y;
-    if (i >= n) return;
+    if (i >= i1) return;
     const bool skip = inf && inf[inf_off + (size_t)j * inf_batch + i];
     emit_digits<SF>(Fe<SF>::load(scalars + ((size_t)j * n + i) * 4), mont, c, W, skip, digits + (size_t)j * W * n + i, n);     // (canonical input may carry one excess p)
 }
@@ -1651,7 +1651,7 @@ static inline uint64_t fnv(uint64_t h, uint64_t v) { for (int i = 0; i < 8; i++)
 
 template <class CFG>
 static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t offset, const u64* scalars_dev, size_t n, size_t k,
-                         int mont, int curve, int use_graph) {
+                         int mont, int curve, int use_graph, const MsmHostScalars* hs) {
     typedef typename CFG::Base BF; typedef typename CFG::Scalar SF;
     hipStream_t s = C.stream;
     // wide windows (a second table set, c = 20: msm.hpp) for big single MSMs: 13 instead of 16 additions per scalar.  Needs the wide sort's
@@ -1874,8 +1874,19 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
 
     C.timer.begin(s);
     // 1 digits
+    if (hs && hs->nev > 0 && k == 1 && !gcap.active) {    // upload and digit pass chunk by chunk (MsmHostScalars)
+        for (int ch = 0; ch < hs->nev; ch++) {
+            const size_t c0 = n * (size_t)ch / hs->nev, c1 = n * (size_t)(ch + 1) / hs->nev;
+            if (c1 == c0) continue;
+            KH_HIP(hipMemcpyAsync((char*)scalars_dev + c0 * 32, (const char*)hs->host + c0 * 32, (c1 - c0) * 32, hipMemcpyHostToDevice, hs->cs));
+            KH_HIP(hipEventRecord(hs->ev[ch], hs->cs));
+            KH_HIP(hipStreamWaitEvent(s, hs->ev[ch], 0));
+            hipLaunchKernelGGL((k_digits<SF>), dim3((unsigned)((c1 - c0 + 255) / 256), 1u), dim3(256), 0, s,
+                               scalars_dev, basis.inf, offset, basis.batch_stride, n, mont, c, W, C.ws_digits.as<int32_t>(), c0, c1);
+        }
+    } else
     hipLaunchKernelGGL((k_digits<SF>), dim3((unsigned)((n + 255) / 256), (unsigned)k), dim3(256), 0, s,
-                       scalars_dev, basis.inf, offset, basis.batch_stride, n, mont, c, W, C.ws_digits.as<int32_t>());
+                       scalars_dev, basis.inf, offset, basis.batch_stride, n, mont, c, W, C.ws_digits.as<int32_t>(), (size_t)0, n);
     C.timer.mark("digits", s);
     u32* len_hist = C.ws_order.as<u32>();                       // [MAX_K+1] histogram, [MAX_K+1] cursors, then order / rnt / roff
     u32* cursor = len_hist + (MAX_K + 1);
@@ -2086,14 +2097,15 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
 }
 
 int msm_enqueue(Context& C, MsmSlot& S, int curve, const MsmBasis& basis, size_t offset, const uint64_t* scalars_dev, size_t n, size_t k, int mont,
-                int use_graph) {
+                int use_graph, const MsmHostScalars* hs) {
     if (n == 0 || k == 0) {          // nothing to launch: finish() emits k identities
         S.busy = true; S.owner = std::this_thread::get_id(); S.ticket = C.next_ticket++; S.curve = curve; S.k = k; S.ngroups = 0; S.W = 0; S.c = 0; S.precomp = 1; S.planes = 0; S.done_by_flag = false; S.fused_used = false; S.spread_used = false;
         KH_HIP(hipEventRecord(S.done, S.stream));
         return KH_OK;
     }
-    if (curve == KH_CURVE_VESTA) return msm_enqueue_t<VestaCfg>(C, S, basis, offset, scalars_dev, n, k, mont, curve, use_graph);
-    return msm_enqueue_t<PallasCfg>(C, S, basis, offset, scalars_dev, n, k, mont, curve, use_graph);
+    if (hs) use_graph &= ~MSM_REPEATS;                     // (a captured launch sequence cannot contain the host's staging)
+    if (curve == KH_CURVE_VESTA) return msm_enqueue_t<VestaCfg>(C, S, basis, offset, scalars_dev, n, k, mont, curve, use_graph, hs);
+    return msm_enqueue_t<PallasCfg>(C, S, basis, offset, scalars_dev, n, k, mont, curve, use_graph, hs);
 }
 
 // 8 finish on the host: wait for the slot, Horner over the window sums (plain path), XYZZ -> affine

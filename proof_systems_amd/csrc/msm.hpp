@@ -31,8 +31,13 @@ static constexpr int IPA_ROUND_C = 16;            // window width of the opening
 // use_graph: flags.  MSM_REPEATS: the caller repeats this exact MSM (same buffers and sizes): from the second call on the launch sequence is
 // captured once into a hipGraph and replayed
 static constexpr int MSM_REPEATS = 1, MSM_SPREAD_SCALARS = 2;      // (MSM_SPREAD_SCALARS: msm.hip, "the caller vouches ...")
+// Host scalars of ONE MSM (k == 1) that are still on their way: msm_enqueue uploads them to scalars_dev itself, in `nev` chunks on the copy stream `cs`
+// (pageable memory: the runtime stages each chunk while the previous one's k_digits already runs on the slot's stream), each chunk's digits launched
+// behind its own event -- the digit pass of a 2^20 MSM hides under the upload, and with two MSMs in flight the whole upload hides under the other
+// job's accumulation (kh_msm_submit_host).
+struct MsmHostScalars { const uint64_t* host; hipStream_t cs; hipEvent_t* ev; int nev; };
 int msm_enqueue(Context& C, MsmSlot& S, int curve, const MsmBasis& basis, size_t offset, const uint64_t* scalars_dev, size_t n, size_t k, int mont,
-                int use_graph = 0);
+                int use_graph = 0, const MsmHostScalars* hs = nullptr);
 // flag_seen: the caller has read the job's launch count from S.done_flag (the result is in S.pinned): no wait on the event
 int msm_finish(Context& C, MsmSlot& S, uint64_t* out_xy, uint8_t* out_inf, bool flag_seen = false);
 int debug_field_op(Context& C, int field, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);

@@ -31,7 +31,7 @@ SYMBOLS = [
     "kh_sponge_new", "kh_sponge_clone", "kh_sponge_free", "kh_sponge_absorb_g", "kh_sponge_absorb", "kh_sponge_absorb_fr", "kh_sponge_challenge",
     "kh_sponge_challenge_field", "kh_sponge_squeeze_field", "kh_sponge_digest",
     "kh_group_map_to_group", "kh_dev_copy", "kh_dev_memset_zero", "kh_dev_fill_elements", "kh_set_phase_timers", "kh_ipa_open",
-    "kh_device_count", "kh_init", "kh_set_device", "kh_get_device", "kh_trim", "kh_srs_device", "kh_last_error", "kh_srs_create", "kh_msm_set_wide_min_n", "kh_ntt_set_max_logr", "kh_counter", "kh_srs_set_wide_tables", "kh_srs_has_wide_tables", "kh_srs_free", "kh_srs_size",
+    "kh_device_count", "kh_init", "kh_set_device", "kh_get_device", "kh_trim", "kh_srs_device", "kh_last_error", "kh_srs_create", "kh_msm_set_wide_min_n", "kh_ntt_set_max_logr", "kh_msm_submit_host", "kh_counter", "kh_srs_set_wide_tables", "kh_srs_has_wide_tables", "kh_srs_free", "kh_srs_size",
     "kh_srs_set_lagrange", "kh_srs_compute_lagrange", "kh_srs_get_lagrange", "kh_srs_lagrange_chunks",
     "kh_msm", "kh_msm_batch", "kh_msm_points", "kh_ntt", "kh_lde",
     "kh_dev_alloc", "kh_dev_free", "kh_dev_upload", "kh_dev_download", "kh_dev_upload_2d",
@@ -345,6 +345,13 @@ class Srs:
         """Enqueue k MSMs (device-resident scalars) on a free pipeline slot; returns a ticket for msm_wait."""
         t = C.c_uint64(0)
         _check(_lib.kh_msm_submit(self._h, basis, chunk, offset, C.c_void_p(scalars_dev), n, k, int(mont), C.byref(t)))
+        return (t.value, k)
+
+    def msm_submit_host(self, scalars, k: int = 1, basis: int = BASIS_G, chunk: int = 0, offset: int = 0, mont: bool = True):
+        """kh_msm_submit_host: the same pipeline from HOST scalars (k x n x 4 limbs); the buffer is the caller's again when this returns."""
+        sc = _c64(scalars, (k, -1, 4))
+        t = C.c_uint64(0)
+        _check(_lib.kh_msm_submit_host(self._h, basis, chunk, offset, _p64(sc), sc.shape[1], k, int(mont), C.byref(t)))
         return (t.value, k)
 
     @staticmethod
