@@ -22,6 +22,7 @@ use kimchi::{
         wires::{COLUMNS, PERMUTS},
     },
     curve::KimchiCurve,
+    prover_index::ProverIndex,
     proof::{LookupCommitments, PointEvaluations, ProofEvaluations, ProverCommitments, ProverProof, RecursionChallenge},
 };
 use kimchi_hip_sys as sys;
@@ -90,6 +91,18 @@ impl<G: HipCurve> GpuProver<G>
 where
     G::BaseField: PrimeField,
 {
+    /// From the reference's own `ProverIndex` instantiated with `GpuSrs<G>` as its SRS type (kimchi/src/prover_index.rs:26-57): the constraint system
+    /// (`cs`), the SRS handle (`srs`) and the verifier-index digest the index caches (`verifier_index_digest`: `compute_verifier_index_digest`,
+    /// prover_index.rs:103-123, must have run -- the prover absorbs it first, prover.rs:259-262).  `max_poly_size` is the SRS's own (prover_index.rs:86-87).
+    pub fn from_index<const FULL_ROUNDS: usize>(index: &ProverIndex<FULL_ROUNDS, G, GpuSrs<G>>) -> Self
+    where
+        G: KimchiCurve<FULL_ROUNDS>,
+    {
+        let digest = index.verifier_index_digest.expect("ProverIndex::compute_verifier_index_digest has not run");
+        assert_eq!(index.max_poly_size, poly_commitment::SRS::max_poly_size(&*index.srs), "the index was built for another SRS");
+        Self::new(&index.cs, (*index.srs).clone(), digest)
+    }
+
     /// `cs`: the constraint system of `ProverIndex::cs`; `digest`: `ProverIndex::verifier_index_digest` (prover_index.rs:130-146).
     pub fn new(cs: &ConstraintSystem<G::ScalarField>, srs: GpuSrs<G>, digest: G::BaseField) -> Self {
         // the lookup constraint system is built lazily (constraints.rs:230, 239-240); a build error is the caller's, as in prover.rs:386-390

@@ -310,6 +310,18 @@ def test_fields_read_from_reference_values_exist():
         for f in fields:
             assert f in have, (struct, f, have)
     src = _strip(open(RUST_FILES[2]).read())
+    # GpuProver::from_index reads the reference's ProverIndex (kimchi/src/prover_index.rs:26-57): every `index.<field>` must be one of its pub fields,
+    # and the three the shim relies on must be there with the types it assumes (Arc<ConstraintSystem>, Arc<Srs>, usize, Option<G::BaseField>)
+    pix = _struct_fields("kimchi/src/prover_index.rs", "ProverIndex")
+    reads = set(m.group(1) for m in re.finditer(r"\bindex\.(\w+)\b(?!\s*\()", src))
+    assert {"cs", "srs", "max_poly_size", "verifier_index_digest"} <= reads, reads
+    for f in reads:
+        assert f in pix, ("ProverIndex", f, pix)
+    ref = _strip(open(os.path.join(REF, "kimchi/src/prover_index.rs")).read())
+    for decl in (r"pub\s+cs\s*:\s*Arc\s*<\s*ConstraintSystem\s*<\s*G::ScalarField\s*>\s*>", r"pub\s+srs\s*:\s*Arc\s*<\s*Srs\s*>", r"pub\s+max_poly_size\s*:\s*usize",
+                 r"pub\s+verifier_index_digest\s*:\s*Option\s*<\s*G::BaseField\s*>"):
+        assert re.search(decl, ref), decl
+    assert re.search(r"pub\s+struct\s+ProverIndex\s*<\s*const\s+FULL_ROUNDS\s*:\s*usize\s*,\s*G\s*:\s*KimchiCurve\s*<\s*FULL_ROUNDS\s*>\s*,\s*Srs\s*>", ref)
     for m in re.finditer(r"\blcs\.(\w+)\b(?!\s*\()", src):
         assert m.group(1) in _struct_fields("kimchi/src/circuits/lookup/index.rs", "LookupConstraintSystem"), m.group(1)
     for m in re.finditer(r"\bcs\.(\w+)\b(?!\s*\()", src):
