@@ -49,6 +49,7 @@ MIX_FILE = "r05_k_acc_wide29_valu_mix.json"   # tools/valu_mix.py (static opcode
 RATES_FILE = "r04_valu_rates.json"              # per-opcode issue cycles measured by tools/microbench.hip
 NTT_PMC_FILE = "r05_ntt_pmc.json"               # tools/profile_msm.py --workload ntt (tools/bench_ntt.py --bench-shapes)
 NTT_MIX_FILE = "r05_k_ntt_pass_valu_mix.json"   # tools/valu_mix.py --kernel ntt
+BUSY_FILE = "r06_proof_busy.json"               # tools/proof_busy.py (rocprofv3 kernel trace of one 2^16 proof): kernel time / wall
 
 
 def rand_scalars(rng, n):
@@ -250,6 +251,14 @@ def prover_block(khip, srs20, check_with_oracle=True, log_n=16, reps=5):
            "reference_readme_seconds": 6.3, "reference_note": "o1-labs README figure for 2^16 gates, hardware unspecified; not measured here (no Rust toolchain)",
            "note": "complete proof: 15 + 1 + 7 commitments, 16 + 2 iNTT, 16 LDE, generic + permutation rows, division by Z_H (zero remainder asserted), 43 x 2 evaluations, ft, "
                    "16 opening rounds; sponges native on the host; constraints of the five gate types whose selectors are zero for this circuit are not evaluated (they add 0)"}
+    busy = load_profile(BUSY_FILE)
+    if busy and busy.get("source_sha256") == source_hash():
+        out["gpu_busy_frac"] = busy["gpu_busy_frac"]
+        out["gpu_busy"] = {k: busy[k] for k in ("wall_us", "busy_us", "pre_opening", "opening", "note") if k in busy}
+        out["gpu_busy"]["source"] = "profiles/" + BUSY_FILE
+    else:
+        out["gpu_busy_frac"] = None
+        out["gpu_busy_note"] = "profiles/%s was not collected on this build: withheld" % BUSY_FILE
     if check_with_oracle and log_n == 16:
         out.update(fixture_parity(khip, ix, wit))
     # ---- the reference's call pattern, unchanged: host buffers, 15 concurrent callers
@@ -1089,7 +1098,7 @@ def _main(base):
         line["strong"] = strong_block
     if world == 1 and not args.strong:
         wd.phase("host-scalar pipeline", 300)
-        line.update(host_scalars_block(khip, srs, sc, n, args.steps, depth, result))
+        line.update(host_scalars_block(khip, srs, sc, n, args.steps, int(os.environ.get("KH_BENCH_HOST_DEPTH", "3")), result))     # 2 / 3 in flight: 798-849 / 901-933 Mscalar/s (profiles/r06_host_msm.txt)
 
     # parity at full size, every rank: its partial against the oracle on its own slice; rank 0 then folds the oracle's
     # partials with the oracle's group law and compares with the combined GPU result

@@ -463,15 +463,19 @@ int kh_sync(void);
  * kh_ntt*_dev / kh_lde*_dev call on this thread, split per phase.  names/ms arrays of
  * capacity cap; returns the number of phases written. */
 int kh_last_timings(const char **names, float *ms, int cap);
-/* Process-wide event counters (how often a rare path ran): "spread_retry" (an opening round's MSM met a hot bucket and was re-run with the hot-bucket
- * kernels), "fused_retry" (the one-launch sort gave up), "graph_replay" / "graph_capture" (replayed / captured launch sequences), "round_coalesced" /
- * "round_solo" (opening rounds that shared / did not share a batched MSM with another prover's round), "wide_rare" (wide-path MSMs that launched the
- * split / hot-bucket kernels).  Unknown names read 0. */
+/* Process-wide event counters (how often a path ran): "spread_retry" (an opening round's MSM met a hot bucket and was re-run with the hot-bucket
+ * kernels), "fused_retry" (the one-launch sort gave up), "graph_replay" / "graph_capture" (replayed / captured launch sequences), "rebase_launch" /
+ * "rebase_switch" / "rebase_abandon" (openings that started materialising the folded basis of their late rounds, switched over to it, gave it up),
+ * "rebased_rounds" (rounds that ran over a materialised basis).  Unknown names read 0. */
 uint64_t kh_counter(const char *name);
 
 /* Test hooks (field ops on the device; op: 0 mul, 1 add, 2 sub, 3 to_mont, 4 from_mont,
  * 5 sqr, 6 neg).  Used by the parity tests to pin the device arithmetic itself. */
 int kh_debug_field_op(int field, int op, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t n);
+/* Test hook of the opening's rebase (csrc/rebase.hip; the folded basis of poly-commitment/src/ipa.rs:985-1003 after several rounds at once):
+ * out[i] = sum_{q < Q} coef[q] * g[q N + i] for i < N = n / Q (N a multiple of 64), from the handle's c = 16 window tables; coef Montgomery, out affine.
+ * *out_fail != 0: an output was the point at infinity (the rebase is then abandoned; out is incomplete). */
+int kh_debug_rebase_points(kh_srs_t *srs, const uint64_t *coef, size_t Q, uint64_t *out_xy, uint32_t *out_fail);
 /* Point ops on the device through the XYZZ formulas: op 0 = P + Q (affine in, affine out),
  * op 1 = 2P, op 2 = P + Q via the mixed addition. inf flags in/out. */
 int kh_debug_point_op(int curve, int op, const uint64_t *p_xy, const uint8_t *p_inf,

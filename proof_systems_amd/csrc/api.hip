@@ -207,6 +207,12 @@ struct kh_srs {
     // workspace of the opening rounds, kept across openings (hipMalloc / hipFree cost ~0.1 ms each: 1 ms per proof)
     DevBuf ipa_a[2], ipa_b[2], ipa_coef[2], ipa_sc, ipa_partial, ipa_sg;
     hipEvent_t ipa_ev = nullptr;
+    // the late rounds' materialised folded basis (csrc/rebase.hip): its window tables, the materialisation's workspaces, a low-priority side stream, the
+    // events that order it against the rounds, a pinned "an output was the identity" word
+    DevBuf ipa_rb_tab, ipa_rb_B, ipa_rb_part, ipa_rb_lists, ipa_rb_scratch;
+    hipStream_t ipa_rb_stream = nullptr;
+    hipEvent_t ipa_rb_go = nullptr, ipa_rb_snap = nullptr, ipa_rb_done = nullptr;
+    uint32_t* ipa_rb_fail = nullptr;
     uint64_t h[8];
     // fixed-base table of the blinding base: h_table[i * 255 + (j - 1)] = j * 2^(8 i) * h (XYZZ), built on first use:
     // SRS::mask_custom is one scalar multiplication by h per chunk (ipa.rs:605-622) -- 32 additions instead of 255
@@ -222,7 +228,14 @@ struct kh_srs {
     std::mutex map_mu;
     std::mutex ipa_mu; std::condition_variable ipa_cv;
     std::map<unsigned, std::vector<std::unique_ptr<LagrangeChunk>>> lagrange;
-    ~kh_srs() { if (ipa_ev) (void)hipEventDestroy(ipa_ev); }      // the DevBufs free themselves
+    ~kh_srs() {                                                     // the DevBufs free themselves
+        if (ipa_ev) (void)hipEventDestroy(ipa_ev);
+        if (ipa_rb_go) (void)hipEventDestroy(ipa_rb_go);
+        if (ipa_rb_snap) (void)hipEventDestroy(ipa_rb_snap);
+        if (ipa_rb_done) (void)hipEventDestroy(ipa_rb_done);
+        if (ipa_rb_stream) { (void)hipStreamSynchronize(ipa_rb_stream); (void)hipStreamDestroy(ipa_rb_stream); }
+        if (ipa_rb_fail) (void)hipHostFree(ipa_rb_fail);
+    }
 };
 #define KH_ON_DEVICE_OF(srs) kh::DeviceScope dev_scope_((srs) ? (srs)->device : -1)
 
@@ -738,7 +751,9 @@ static int msm_submit_locked(Context& C, kh_srs_t* srs, int basis, unsigned chun
     const uint64_t* sdev = scalars;
     // a big single MSM from host scalars: upload and digit pass in chunks on the calling thread's copy stream (MsmHostScalars) -- the other slots' jobs keep
     // the GPU busy meanwhile (kh_msm_submit_host: two in flight hide the whole upload), and a lone MSM hides its digit pass
-    static const size_t chunked_min = getenv("KH_HOST_CHUNK_MIN") ? (size_t)atol(getenv("KH_HOST_CHUNK_MIN")) : ((size_t)1 << 17);     // scalars; 0 = never
+    // (KH_HOST_CHUNK_MIN=n switches it on for MSMs of >= n scalars; off by default: at 2^20 the chunked upload measured level with the single copy -- what
+    // pipelines the PCIe transfer under the neighbouring job's accumulation is kh_msm_submit_host itself, not the chunking: profiles/r06_host_msm*.txt)
+    static const size_t chunked_min = getenv("KH_HOST_CHUNK_MIN") ? (size_t)atol(getenv("KH_HOST_CHUNK_MIN")) : 0;     // scalars; 0 = never
     MsmHostScalars hs{}; const MsmHostScalars* hsp = nullptr;
     if (!scalars_on_device && k == 1 && chunked_min && use >= chunked_min) {
         if ((rc = S.ws_scalars.reserve(use * 32))) return rc;
@@ -850,10 +865,11 @@ static int msm_common(kh_srs_t* srs, int basis, unsigned chunk, size_t offset, c
     const bool burst = C.last_sync_msm_arrival.time_since_epoch().count() != 0 &&
                        std::chrono::duration_cast<std::chrono::microseconds>(now - C.last_sync_msm_arrival).count() < 200;
     C.last_sync_msm_arrival = now;
-    // A lone big MSM from host scalars runs as TWO half-range MSMs on two slots (the point range cut in the middle, each half with its own chunked upload):
-    // the second half's PCIe transfer and sort run underneath the first half's accumulation, the host adds the two partial sums.  2^20 Vesta scalars from
-    // pageable memory: 1.99 ms as one job (0.75 ms of un-overlapped upload) -- see profiles/r06_pcie_inclusive.txt for this path.  KH_HOST_SPLIT_MIN (scalars).
-    static const size_t split_min = getenv("KH_HOST_SPLIT_MIN") ? (size_t)atol(getenv("KH_HOST_SPLIT_MIN")) : ((size_t)1 << 20);
+    // KH_HOST_SPLIT_MIN=n (experiment, off by default): a lone host-scalar MSM of >= n scalars as TWO half-range MSMs on two slots, each with its own upload.
+    // Measured (round 6, profiles/r06_host_msm*.txt): no gain -- 1.91-1.98 ms either way at 2^20.  The host thread stages the two uploads one after the
+    // other (~0.45 ms each incl. the pinning of the pageable pages), so the second half's kernels cannot start before ~1.2 ms and then need 0.75 ms: the
+    // bound is (all uploads) + (the last piece's whole pipeline), and an uneven cut would reach ~1.75 ms at best.
+    static const size_t split_min = getenv("KH_HOST_SPLIT_MIN") ? (size_t)atol(getenv("KH_HOST_SPLIT_MIN")) : 0;
     if (!scalars_on_device && k == 1 && srs != nullptr && !burst && split_min && n >= split_min) {
         MsmBasis b;
         if (resolve_basis(srs, basis, chunk, b) == KH_OK && offset <= b.n && b.precomp_c) {
@@ -1614,6 +1630,14 @@ struct kh_ipa {
     bool sg_want = false;                 // kh_ipa_open asks the last kh_ipa_round_lr to launch them
     std::vector<hipGraphExec_t> retired;  // the previous opening's executable graphs: destroyed underneath the first round's GPU time
     void* round_tab = nullptr; int round_c = 0;   // table set the round MSMs run over (the SRS's own, or its narrower-window second set)
+    size_t tab_stride = 0;                        // points per window table of that set (the SRS's g_stride; N + 2 after the rebase)
+    // Rebase (csrc/rebase.hip): after rb_j0 rounds the folded basis of rb_N = n / 2^rb_j0 points is materialised on a side stream while the rounds go on
+    // over the original tables; the first round that finds it ready switches over (n, ncoef, round_tab, round_c, tab_stride change; a, b, coef do not).
+    int rb_state = 0;                             // 0: not planned, 1: planned (launch behind round rb_j0 + 1's step kernel), 2: running, 3: switched, -1: abandoned
+    unsigned rb_j0 = 0, round_no = 0;             // round_no: kh_ipa_round_lr calls so far
+    size_t rb_N = 0; int rb_c = 0;
+    uint64_t u_xy[8] = {0};                       // the U base of this opening (its multiples go into the rebased tables' last slot)
+    uint64_t hu_stage[16] = {0};                  // H | U, staged for the asynchronous upload into those tables (lives as long as the opening)
 };
 
 static int ipa_begin_common(kh_srs_t* srs, const uint64_t* a, size_t a_len, const uint64_t* b, size_t b_len, const uint64_t u_base_xy[8], kh_ipa_t** out,
@@ -1686,7 +1710,44 @@ static int ipa_begin_common(kh_srs_t* srs, const uint64_t* a, size_t a_len, cons
     const int rc_c = second ? srs->g2_c : srs->g_precomp_c;                        // window width of the rounds' tables
     void* const round_tab = second ? srs->g2.p : srs->g.p;
     std::vector<uint64_t>& hm = second ? srs->h_multiples2 : srs->h_multiples;
-    st->round_tab = round_tab; st->round_c = rc_c;
+    st->round_tab = round_tab; st->round_c = rc_c; st->tab_stride = srs->g_stride;
+    memcpy(st->u_xy, u_base_xy, 64);
+    // Plan the rebase (csrc/rebase.hip): the folded basis of N = 2^KH_IPA_REBASE_LOGN points (default 2^11; at least three rounds folded into it, at least 64
+    // points) with window tables of KH_IPA_REBASE_C bits (default 13: 20 windows, 2^12 buckets), materialised from the c = 16 tables.  KH_IPA_REBASE=0: never.
+    {
+        static const bool rb_on = !(getenv("KH_IPA_REBASE") && atoi(getenv("KH_IPA_REBASE")) == 0);
+        static const unsigned rb_logn = getenv("KH_IPA_REBASE_LOGN") ? (unsigned)atoi(getenv("KH_IPA_REBASE_LOGN")) : 11u;     // 2^16 proof, opening: 5.39 (off) / 5.26 (2^9) / 5.17 (2^10) / 5.11 (2^11) / 5.34 (2^12) ms: profiles/r06_rebase_sweep.txt
+        static const int rb_c = getenv("KH_IPA_REBASE_C") ? std::min(16, std::max(7, atoi(getenv("KH_IPA_REBASE_C")))) : 13;     // 13: 20 windows, the top one still 8 bits wide (12, 14: a 3-bit top window = hot buckets)
+        unsigned logn = 0; while (((size_t)1 << logn) < n) logn++;
+        if (rb_on && !second && srs->g_precomp_c == 16 && logn >= 9) {
+            const unsigned ln = std::max(6u, std::min(rb_logn, logn - 3));
+            const size_t N = (size_t)1 << ln, Q = n >> ln;
+            const int W2 = (256 + rb_c - 1) / rb_c;
+            bool ok = srs->ipa_rb_tab.reserve((N + 2) * 64 * (size_t)W2) == KH_OK && srs->ipa_rb_B.reserve(rebase_bucket_bytes(N)) == KH_OK &&
+                      srs->ipa_rb_part.reserve(rebase_part_bytes(N)) == KH_OK && srs->ipa_rb_lists.reserve(rebase_list_bytes(Q) + 256) == KH_OK &&       // (+ H | U, affine)
+                      srs->ipa_rb_scratch.reserve((size_t)W2 * (N + 2) * 128) == KH_OK;
+            if (ok && !srs->ipa_rb_stream) {
+                int lo = 0, hi = 0;
+                (void)hipDeviceGetStreamPriorityRange(&lo, &hi);                 // lo = the numerically largest = the LEAST urgent
+                // KH_IPA_REBASE_CUS=k: the side stream may only use the first k compute units (a CU-masked stream), so that the rounds' own kernels find
+                // the rest of the chip untouched; 0 (default): no mask, lowest stream priority
+                static const unsigned rb_cus = getenv("KH_IPA_REBASE_CUS") ? (unsigned)atoi(getenv("KH_IPA_REBASE_CUS")) : 0u;
+                bool made = false;
+                if (rb_cus > 0 && rb_cus < (unsigned)C.num_cus) {
+                    std::vector<uint32_t> mask(((size_t)C.num_cus + 31) / 32, 0u);
+                    for (unsigned cu = 0; cu < rb_cus; cu++) mask[cu / 32] |= 1u << (cu % 32);
+                    made = hipExtStreamCreateWithCUMask(&srs->ipa_rb_stream, (uint32_t)mask.size(), mask.data()) == hipSuccess;
+                    if (!made) { (void)hipGetLastError(); srs->ipa_rb_stream = nullptr; }
+                }
+                ok = (made || hipStreamCreateWithPriority(&srs->ipa_rb_stream, hipStreamNonBlocking, lo) == hipSuccess) &&
+                     hipEventCreateWithFlags(&srs->ipa_rb_go, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&srs->ipa_rb_snap, hipEventDisableTiming) == hipSuccess &&
+                     hipEventCreateWithFlags(&srs->ipa_rb_done, hipEventDisableTiming) == hipSuccess &&
+                     hipHostMalloc((void**)&srs->ipa_rb_fail, 64, hipHostMallocCoherent | hipHostMallocMapped) == hipSuccess;
+            }
+            if (ok) { *srs->ipa_rb_fail = 0; st->rb_state = 1; st->rb_j0 = logn - ln; st->rb_N = N; st->rb_c = rb_c; }
+            else { (void)hipGetLastError(); set_error(""); }                     // no memory for it: the rounds stay on the original tables
+        }
+    }
     const int W = rc_c ? (256 + rc_c - 1) / rc_c : 1;
     std::vector<uint64_t>& tab = st->tab;                  // lives as long as the opening: no synchronisation before returning
     std::vector<uint64_t> col((size_t)W * 8);
@@ -1743,6 +1804,7 @@ static void ipa_sg_prelaunch_locked(kh_ipa_t* st, Context& C, int p, bool had_fo
     if (hipStreamWaitEvent(S.stream, st->ev, 0) != hipSuccess) return;
     if (ipa_sg_split(S.stream, st->field, st->coef[p].as<uint64_t>(), st->n, had_fold ? 1 : 0, st->u_p, srs->ipa_sg.as<uint64_t>())) return;
     MsmBasis bs; bs.pts = srs->g.p; bs.inf = nullptr; bs.n = srs->n; bs.stride = srs->g_stride; bs.precomp_c = srs->g_precomp_c;
+    if (st->rb_state == 3) { bs.pts = st->round_tab; bs.n = st->n; bs.stride = st->tab_stride; bs.precomp_c = st->round_c; }     // sg = <coef_rel, g'>
     if (msm_enqueue(C, S, st->curve, bs, 0, srs->ipa_sg.as<uint64_t>(), st->n, 2, 1)) return;
     st->sg_slot = si;
 }
@@ -1763,6 +1825,29 @@ int kh_ipa_round_lr(kh_ipa_t* st, const uint64_t rand_l[4], const uint64_t rand_
     KH_REQUIRE(si >= 0, "%s", slot_error(si));
     MsmSlot& S = C.slot[si];
     KH_HIP(hipStreamWaitEvent(S.stream, st->ev, 0));
+    kh_srs_t* const srs = st->srs;
+    st->round_no++;
+    // the rebase (csrc/rebase.hip): switch to the materialised folded basis as soon as its tables are complete
+    if (st->rb_state == 2) {
+        static const bool rb_wait = getenv("KH_IPA_REBASE_WAIT") && atoi(getenv("KH_IPA_REBASE_WAIT")) != 0;      // tests: the earliest possible switch, deterministically
+        if (rb_wait) KH_HIP(hipEventSynchronize(srs->ipa_rb_done));
+        const hipError_t qe = hipEventQuery(srs->ipa_rb_done);
+        if (qe == hipSuccess) {
+            if (__atomic_load_n(srs->ipa_rb_fail, __ATOMIC_ACQUIRE) != 0) { st->rb_state = -1; counter(CNT_REBASE_ABANDON)++; }
+            else {
+                KH_HIP(hipStreamWaitEvent(S.stream, srs->ipa_rb_done, 0));
+                st->n = st->rb_N; st->ncoef >>= st->rb_j0;
+                st->round_tab = srs->ipa_rb_tab.p; st->round_c = st->rb_c; st->tab_stride = st->rb_N + 2;
+                st->rb_state = 3; counter(CNT_REBASE_SWITCH)++;
+                static const bool rb_say = getenv("KH_IPA_TIMING") != nullptr;
+                if (rb_say) fprintf(stderr, "kh_ipa: round %u runs over the rebased tables (%zu points, c = %d, %u rounds folded in)\n", st->round_no, st->rb_N, st->rb_c, st->rb_j0);
+            }
+        } else if (qe != hipErrorNotReady) { KH_HIP(qe); }
+        else (void)hipGetLastError();
+        // the step kernel of round j0 + 3 is the first to overwrite the challenge tensor the plan kernel reads (ping-pong buffers): order it behind the plan
+        if (st->rb_state == 2 && st->round_no == st->rb_j0 + 3) KH_HIP(hipStreamWaitEvent(S.stream, srs->ipa_rb_snap, 0));
+    }
+    if (st->rb_state == 3) counter(CNT_REBASED_ROUNDS)++;
     const int p = st->pp, q = p ^ 1;
     const bool had_fold = st->pending;
     const auto pt1 = std::chrono::steady_clock::now();
@@ -1775,12 +1860,28 @@ int kh_ipa_round_lr(kh_ipa_t* st, const uint64_t rand_l[4], const uint64_t rand_
     if (rc) return rc;
     const auto pt2 = std::chrono::steady_clock::now();
     if (st->pending) { st->pp = q; st->pending = false; }
-    kh_srs_t* srs = st->srs;
-    MsmBasis bs; bs.pts = st->round_tab; bs.inf = nullptr; bs.n = srs->g_stride; bs.stride = srs->g_stride; bs.precomp_c = st->round_c;
+    if (st->rb_state == 1 && st->round_no == st->rb_j0 + 1) {
+        // this round's step kernel has just written the tensor of the first j0 challenges (2^j0 entries, st->coef[st->pp]): materialise the folded basis
+        // and its window tables behind it on the side stream, H and U in the two extra slots
+        const size_t N = st->rb_N, Q = (size_t)1 << st->rb_j0;
+        hipStream_t rs = srs->ipa_rb_stream;
+        bool ok = hipEventRecord(srs->ipa_rb_go, S.stream) == hipSuccess && hipStreamWaitEvent(rs, srs->ipa_rb_go, 0) == hipSuccess;
+        uint32_t* const lists = srs->ipa_rb_lists.as<uint32_t>();
+        if (ok) ok = rebase_points(rs, st->curve, st->coef[st->pp].as<uint64_t>(), Q, srs->g.p, srs->g_stride, N, srs->ipa_rb_B.p, srs->ipa_rb_part.p, lists,
+                                   srs->ipa_rb_snap) == KH_OK;                   // (ipa_rb_snap: behind the plan kernel, the tensor's only reader)
+        memcpy(st->hu_stage, srs->h, 64); memcpy(st->hu_stage + 8, st->u_xy, 64);
+        void* const hu_dev = (char*)srs->ipa_rb_lists.p + ((rebase_list_bytes(Q) + 63) & ~(size_t)63);
+        if (ok) ok = hipMemcpyAsync(hu_dev, st->hu_stage, 128, hipMemcpyHostToDevice, rs) == hipSuccess;
+        if (ok) ok = rebase_tables(rs, st->curve, srs->ipa_rb_part.p, N, hu_dev, 2, st->rb_c, srs->ipa_rb_scratch.p, srs->ipa_rb_tab.p, srs->ipa_rb_fail) == KH_OK;
+        if (ok) ok = hipEventRecord(srs->ipa_rb_done, rs) == hipSuccess;
+        if (ok) { st->rb_state = 2; counter(CNT_REBASE_LAUNCH)++; }
+        else { (void)hipGetLastError(); (void)hipStreamSynchronize(rs); st->rb_state = -1; counter(CNT_REBASE_ABANDON)++; }
+    }
+    MsmBasis bs; bs.pts = st->round_tab; bs.inf = nullptr; bs.n = st->tab_stride; bs.stride = st->tab_stride; bs.precomp_c = st->round_c;
     // Plain launches by default since round 5: the round's MSM is down to six launches (digits, one-launch sort, accumulation, bucket sums, two reduction
     // kernels) which the host queues in ~25 us while the step kernel runs; replaying a captured graph (KH_IPA_GRAPH=1, rounds 2-4's way: every opening
     // captures afresh in its second round) measured 5.58 / 5.53 / 5.65 ms per opening against 5.49 / 5.47 / 5.51 plain, alternated on one box.
-    static const int round_flags = ((getenv("KH_IPA_GRAPH") && atoi(getenv("KH_IPA_GRAPH")) != 0) ? MSM_REPEATS : 0) | MSM_SPREAD_SCALARS;
+    static const int round_flags = ((getenv("KH_IPA_GRAPH") && atoi(getenv("KH_IPA_GRAPH")) != 0) ? MSM_REPEATS : 0) | MSM_SPREAD_SCALARS | MSM_LATENCY;
     if ((rc = msm_enqueue(C, S, st->curve, bs, 0, st->sc->as<uint64_t>(), st->n + 2, 2, 1, round_flags))) return rc;
     if (st->sg_want && st->cur == 2) { st->sg_want = false; ipa_sg_prelaunch_locked(st, C, p, had_fold); }
     if (!st->retired.empty()) {                           // the GPU is busy with this round for the next ~0.3 ms; other callers are not held up:
@@ -1839,6 +1940,7 @@ static int ipa_finish_impl(kh_ipa_t* st, uint64_t a0[4], uint64_t b0[4], uint64_
     KH_HIP(hipMemcpyAsync(b0, st->b[p].p, 32, hipMemcpyDeviceToHost, S.stream));
     kh_srs_t* srs = st->srs;
     MsmBasis bs; bs.pts = srs->g.p; bs.inf = nullptr; bs.n = srs->n; bs.stride = srs->g_stride; bs.precomp_c = srs->g_precomp_c;
+    if (st->rb_state == 3) { bs.pts = st->round_tab; bs.n = st->n; bs.stride = st->tab_stride; bs.precomp_c = st->round_c; }     // sg = <coef_rel, g'>
     if (!sg_xy) { KH_HIP(hipStreamSynchronize(S.stream)); return KH_OK; }
     if ((rc = msm_enqueue(C, S, st->curve, bs, 0, st->coef[p].as<uint64_t>(), st->n, 1, 1))) return rc;   // sg = <coef, G>
     return wait_then_finish(lk, C, S, sg_xy, sg_inf);
@@ -1920,6 +2022,7 @@ void kh_ipa_free(kh_ipa_t* st) {
     std::lock_guard<std::mutex> lk(C.mu);
     (void)hipStreamSynchronize(C.stream);                 // a fold may still be in flight on the library stream
     kh_srs_t* const srs = st->srs;
+    if (srs && st->rb_state >= 2 && srs->ipa_rb_stream) (void)hipStreamSynchronize(srs->ipa_rb_stream);      // a materialisation that was never switched to: the handle's next opening reuses its buffers
     delete st;
     if (srs) {                                            // an opening another thread wants to begin on this handle can start
         { std::lock_guard<std::mutex> hl(srs->ipa_mu); srs->ipa_live = false; }
@@ -2343,6 +2446,28 @@ int kh_last_timings(const char** names, float* ms, int cap) {
 }
 
 // ---------------------------------------------------------------------------------- test hooks
+// test hook of csrc/rebase.hip: g'[i] = sum_{q < Q} coef[q] * g[q N + i], i < N = n / Q, from the handle's c = 16 window tables (affine out)
+int kh_debug_rebase_points(kh_srs_t* srs, const uint64_t* coef, size_t Q, uint64_t* out_xy, uint32_t* out_fail) {
+    KH_ON_DEVICE_OF(srs);
+    KH_REQUIRE(srs && coef && out_xy && out_fail, "kh_debug_rebase_points: null argument");
+    KH_REQUIRE(srs->g_precomp_c == 16, "the handle has no c = 16 window tables");
+    KH_REQUIRE(Q >= 1 && srs->n % Q == 0 && (srs->n / Q) % 64 == 0, "Q = %zu must divide the SRS size %zu into a multiple of 64", Q, srs->n);
+    int rc = ensure_init(); if (rc) return rc;
+    Context& C = ctx();
+    std::lock_guard<std::mutex> lk(C.mu);
+    const size_t N = srs->n / Q;
+    DevBuf B, part, lists, out, dcoef, fail, scratch;
+    if ((rc = B.reserve(rebase_bucket_bytes(N))) || (rc = part.reserve(rebase_part_bytes(N))) || (rc = lists.reserve(rebase_list_bytes(Q))) || (rc = out.reserve(N * 64)) ||
+        (rc = dcoef.reserve(Q * 32)) || (rc = fail.reserve(64)) || (rc = scratch.reserve(N * 128))) return rc;
+    KH_HIP(hipMemcpyAsync(dcoef.p, coef, Q * 32, hipMemcpyHostToDevice, C.stream));
+    KH_HIP(hipMemsetAsync(fail.p, 0, 64, C.stream));
+    if ((rc = rebase_points(C.stream, srs->curve, dcoef.as<uint64_t>(), Q, srs->g.p, srs->g_stride, N, B.p, part.p, lists.p))) return rc;
+    if ((rc = rebase_tables(C.stream, srs->curve, part.p, N, nullptr, 0, 256, scratch.p, out.p, fail.as<uint32_t>()))) return rc;      // (c = 256: one level = the points themselves, affine)
+    KH_HIP(hipMemcpyAsync(out_xy, out.p, N * 64, hipMemcpyDeviceToHost, C.stream));
+    KH_HIP(hipMemcpyAsync(out_fail, fail.p, 4, hipMemcpyDeviceToHost, C.stream));
+    KH_HIP(hipStreamSynchronize(C.stream));
+    return KH_OK;
+}
 int kh_debug_field_op(int field, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
     KH_REQUIRE(a && out, "null argument");
     int rc = ensure_init(); if (rc) return rc;

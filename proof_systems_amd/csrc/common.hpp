@@ -199,8 +199,8 @@ struct DeviceScope {               // run the rest of this scope on `device` (no
 };
 void collect_timings(Context& c, PhaseTimer& t);
 // process-wide event counters behind kh_counter (tests and tools read them: how often a rare path ran).  `name` must be one of COUNTER_NAMES.
-enum CounterId { CNT_SPREAD_RETRY = 0, CNT_FUSED_RETRY, CNT_GRAPH_REPLAY, CNT_GRAPH_CAPTURE, CNT_ROUND_COALESCED, CNT_ROUND_SOLO, CNT_WIDE_RARE, CNT_COUNT };
-static constexpr const char* COUNTER_NAMES[CNT_COUNT] = {"spread_retry", "fused_retry", "graph_replay", "graph_capture", "round_coalesced", "round_solo", "wide_rare"};
+enum CounterId { CNT_SPREAD_RETRY = 0, CNT_FUSED_RETRY, CNT_GRAPH_REPLAY, CNT_GRAPH_CAPTURE, CNT_REBASE_LAUNCH, CNT_REBASE_SWITCH, CNT_REBASE_ABANDON, CNT_REBASED_ROUNDS, CNT_COUNT };
+static constexpr const char* COUNTER_NAMES[CNT_COUNT] = {"spread_retry", "fused_retry", "graph_replay", "graph_capture", "rebase_launch", "rebase_switch", "rebase_abandon", "rebased_rounds"};
 std::atomic<uint64_t>& counter(CounterId id);
 
 // device exclusive scan of n u32 values (in may alias out); tmp is workspace

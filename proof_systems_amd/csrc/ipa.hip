@@ -215,6 +215,7 @@ k_ipa_step(const u64* __restrict__ a, const u64* __restrict__ b, const u64* __re
            Fe4 rand_l, Fe4 rand_r, u64* __restrict__ sc, u64* __restrict__ partial, unsigned* __restrict__ counter) {
     __shared__ u32 sh[8 * 8];
     __shared__ unsigned is_last;
+    __builtin_amdgcn_s_setprio(3);                         // the head of a round's dependent chain: above whatever throughput work shares the CUs (msm.hip, KH_HIGH_PRIO)
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t m = cur2 / 2;
     const Fe<F> u = Fe<F>::load(u4.l), ui = Fe<F>::load(ui4.l);

@@ -717,8 +717,9 @@ __global__ void __launch_bounds__(PART_T)
 k_part2_sort(const u32* __restrict__ mid, const u32* __restrict__ PO, u32 nblk, u32 low, u32 nb, u32 tot_e, u32 n, size_t pt_stride, size_t pt_offset,
              size_t pt_batch, u32 last_group, size_t total_idx, WideTasks ta, u32* __restrict__ off, u32* __restrict__ entries,
              u32* __restrict__ toff, u32* __restrict__ order, u32* __restrict__ ptot, u32* __restrict__ xlist, u32* __restrict__ slist,
-             uint8_t* __restrict__ buckets29, u32 og) {
+             uint8_t* __restrict__ buckets29, u32 og_) {
     KH_HIGH_PRIO();
+    const u32 og = og_ & 0x7fffffffu;
     __shared__ u32 cur[1u << PART2_MAXLOW], pstart[1025], bi0[1024], bw0[1024], lh[MAX_K + 2], sh[PART_T / 64 + 1];
     __shared__ u32 xl_key[1u << PART2_MAXLOW], xl_nt[1u << PART2_MAXLOW], xl_base[1u << PART2_MAXLOW], xl_n;
     const u32 pidx = blockIdx.x, j = blockIdx.y, tid = threadIdx.x;
@@ -803,6 +804,7 @@ k_part2_sort(const u32* __restrict__ mid, const u32* __restrict__ PO, u32 nblk, 
                 if (live) {
                     u32 w = w0, i = i0 + (m[u] & 0xffffu);
                     while (i >= n) { i -= n; w++; }
+                    if (!(og_ & 0x80000000u) || pos == 0xffffffffu)          // (KH_DEBUG_PART2_NOSTORE: experiment -- is pass B bound by its scattered stores?)
                     entries[pos] = (pb0 + (u32)(w * pt_stride) + i) | ((m[u] & (1u << 16)) << 15);
                 }
             }
@@ -882,7 +884,10 @@ template <class BF>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(112), amdgpu_waves_per_eu(4, 4)))
 k_accumulate29(const u32* __restrict__ entries, const u32* __restrict__ off, const u32* __restrict__ toff,
                const u32* __restrict__ roff, const u32* __restrict__ order,
-               size_t nkeys, const uint8_t* __restrict__ pts, uint8_t* __restrict__ partial, u32* __restrict__ handed, const u32* __restrict__ abort_dev) {
+               size_t nkeys, const uint8_t* __restrict__ pts, uint8_t* __restrict__ partial, u32* __restrict__ handed, const u32* __restrict__ abort_dev, u32 hi_prio) {
+    // MSM_LATENCY: the job is somebody's critical path (an opening round) and throughput work of the SAME process may be running underneath it at the
+    // default priority (the rebase's side stream: a precompute wave sharing the SIMD is older and won every issue slot -- 90 -> 590 us, round 6 trace)
+    if (hi_prio) __builtin_amdgcn_s_setprio(2);
     if (sort_gave_up(abort_dev)) return;
     const size_t t0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     u32 NT = roff[nkeys];
@@ -1843,7 +1848,7 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
                                   (uint64_t)(uintptr_t)C.ws_buckets.p, (uint64_t)(uintptr_t)C.ws_seg.p, (uint64_t)(uintptr_t)C.ws_out.p, (uint64_t)(uintptr_t)C.ws_scan_tmp.p,
                                   (uint64_t)(uintptr_t)C.ws_biglist.p, (uint64_t)(uintptr_t)C.ws_order.p, (uint64_t)(uintptr_t)C.ws_chunks.p,
                                   (uint64_t)(uintptr_t)C.ws_handed.p, (uint64_t)(uintptr_t)C.ws_sync.p, (uint64_t)fused, (uint64_t)(uintptr_t)C.ws_mid.p, (uint64_t)part,
-                                  (uint64_t)(uintptr_t)tab_pts, (uint64_t)wide, (uint64_t)spread, (uint64_t)(uintptr_t)C.ws_xlist.p, (uint64_t)(uintptr_t)C.ws_b29.p, (uint64_t)(uintptr_t)C.ws_a1.p, (uint64_t)(uintptr_t)C.ws_a2.p, (uint64_t)(uintptr_t)C.ws_done.p, (uint64_t)flag_on,
+                                  (uint64_t)(uintptr_t)tab_pts, (uint64_t)wide, (uint64_t)spread, (uint64_t)(uintptr_t)C.ws_xlist.p, (uint64_t)(uintptr_t)C.ws_b29.p, (uint64_t)(uintptr_t)C.ws_a1.p, (uint64_t)(uintptr_t)C.ws_a2.p, (uint64_t)(uintptr_t)C.ws_done.p, (uint64_t)flag_on, (uint64_t)(use_graph & MSM_LATENCY),
                                   DevBuf::generation().load()};
         for (uint64_t v : parts) key = fnv(key, v);
         if (C.gexec && C.gkey == key) {                    // replay
@@ -1915,7 +1920,7 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
             u32* const ptot = C.ws_ntask.as<u32>();        // k * 256 partition task totals (the narrow path's per-key task counts: unused here)
             hipLaunchKernelGGL(k_part2_sort, dim3(PART_P, (unsigned)k), dim3(PART_T), 0, s, C.ws_mid.as<u32>(), C.ws_cnt.as<u32>(), part_nblk, part_low, nb, tot_e, (u32)n,
                                tab_stride, offset, basis.batch_stride, (u32)(k - 1), part_size, wt, C.ws_off.as<u32>(), C.ws_entries.as<u32>(),
-                               C.ws_toff.as<u32>(), order, ptot, C.ws_xlist.as<u32>(), slist, C.ws_b29.as<uint8_t>(), wide_og);
+                               C.ws_toff.as<u32>(), order, ptot, C.ws_xlist.as<u32>(), slist, C.ws_b29.as<uint8_t>(), wide_og | (getenv("KH_DEBUG_PART2_NOSTORE") ? 0x80000000u : 0u));
             hipLaunchKernelGGL(k_wide_fixup, dim3((unsigned)(nkeys / 256 + 1)), dim3(256), 0, s, C.ws_toff.as<u32>(), ptot, (u32)(k * PART_P), part_low, (u32)nkeys,
                                C.ws_handed.as<u32>(), C.ws_biglist.as<u32>());
         } else {
@@ -1961,6 +1966,7 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
     const u32* abort_dev = fused ? C.ws_sync.as<u32>() + 2 + 2 * FUSED_B + 32 : nullptr;     // the fused sort's give-up word (sort_gave_up)
     const u32* handed = acc29 ? C.ws_handed.as<u32>() : nullptr;
     const dim3 agrid((unsigned)((max_tasks + 255) / 256));
+    const u32 acc_prio = (use_graph & MSM_LATENCY) ? 1u : 0u;
     uint8_t* const b29 = wide ? C.ws_b29.as<uint8_t>() : nullptr;
     if (wide) {                                            // thread per bucket in pass B's interleaved length order (+ the listed extra chunks), then the exact redos
         const dim3 wgrid((unsigned)(nkeys / 256));
@@ -1985,12 +1991,12 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
         if (C.timer.enabled && C.timer.created && !gcap.active) {     // the dominant kernel's own start / stop timestamps (bench.py roofline)
             hipExtLaunchKernelGGL(kern, agrid, dim3(256), 0, s, C.timer.k0, C.timer.k1, 0,
                                   C.ws_entries.as<u32>(), C.ws_off.as<u32>(), C.ws_toff.as<u32>(), roff, order, nkeys,
-                                  (const uint8_t*)tab_pts, C.ws_partial.as<uint8_t>(), C.ws_handed.as<u32>(), abort_dev);
+                                  (const uint8_t*)tab_pts, C.ws_partial.as<uint8_t>(), C.ws_handed.as<u32>(), abort_dev, acc_prio);
             C.timer.kname = "k_accumulate29";
         } else
         hipLaunchKernelGGL(kern, agrid, dim3(256), 0, s,
                            C.ws_entries.as<u32>(), C.ws_off.as<u32>(), C.ws_toff.as<u32>(), roff, order, nkeys,
-                           (const uint8_t*)tab_pts, C.ws_partial.as<uint8_t>(), C.ws_handed.as<u32>(), abort_dev);
+                           (const uint8_t*)tab_pts, C.ws_partial.as<uint8_t>(), C.ws_handed.as<u32>(), abort_dev, acc_prio);
     } else if (C.timer.enabled && C.timer.created && !gcap.active) {
         hipExtLaunchKernelGGL((k_accumulate<BF>), agrid, dim3(256), 0, s, C.timer.k0, C.timer.k1, 0,
                               C.ws_entries.as<u32>(), C.ws_off.as<u32>(), C.ws_toff.as<u32>(), roff, order, nkeys,
@@ -2215,6 +2221,15 @@ int msm_finish(Context& C, MsmSlot& S, uint64_t* out_xy, uint8_t* out_inf, bool 
     return KH_OK;
 }
 
+// the same on a caller's stream, with a caller's scratch buffer ((W - 1) x n x 128 bytes), no synchronisation: the opening's rebased tables (rebase.hip)
+int msm_precompute_on(hipStream_t s, int curve, void* tables, size_t n, int c, void* scratch) {
+    const int W = (256 + c - 1) / c;
+    dim3 grid((unsigned)((n + 63) / 64));                  // small blocks: the chain of 255 doublings per point is pure latency, one wave per SIMD is the fastest
+    if (curve == KH_CURVE_VESTA) hipLaunchKernelGGL((k_precompute<FqParams>), grid, dim3(64), 0, s, (uint8_t*)tables, (const uint8_t*)nullptr, n, c, W, (uint8_t*)scratch);
+    else hipLaunchKernelGGL((k_precompute<FpParams>), grid, dim3(64), 0, s, (uint8_t*)tables, (const uint8_t*)nullptr, n, c, W, (uint8_t*)scratch);
+    KH_HIP(hipGetLastError());
+    return KH_OK;
+}
 int msm_precompute(Context& C, int curve, void* tables, const uint8_t* inf, size_t n, int c) {
     const int W = (256 + c - 1) / c;
     DevBuf& scratch = C.scratch("precompute");

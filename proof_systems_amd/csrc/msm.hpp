@@ -19,6 +19,15 @@ struct MsmBasis {
 int msm_pick_window(size_t n);
 // builds the window tables 2^(c*w) * P_i in place: `tables` holds W x n x 64 B with table 0 = the basis
 int msm_precompute(Context& C, int curve, void* tables, const uint8_t* inf, size_t n, int c);
+int msm_precompute_on(hipStream_t s, int curve, void* tables, size_t n, int c, void* scratch);      // asynchronous, scratch = (W - 1) x n x 128 bytes
+// rebase.hip: the folded basis of the opening's late rounds, materialised from the c = 16 tables (see there)
+int rebase_points(hipStream_t s, int curve, const uint64_t* coef, size_t Q, const void* tables, size_t stride, size_t N, void* B, void* part, void* lists,
+                  hipEvent_t after_plan = nullptr);
+const void* rebase_outputs(const void* part, size_t N);          // the N materialised points (XYZZ, 128 bytes each) inside `part`
+int rebase_tables(hipStream_t s, int curve, const void* part, size_t N, const void* extra_affine, size_t extra, int c, void* scratch, void* tables, uint32_t* fail);
+size_t rebase_bucket_bytes(size_t N);
+size_t rebase_part_bytes(size_t N);
+size_t rebase_list_bytes(size_t Q);
 static constexpr int MSM_PRECOMP_C = 16;          // window width of the precomputed tables
 static constexpr int MSM_WIDE_C = 20;             // ... of the second table set big bases get: 13 windows, 2^19 buckets (msm.hip, "wide windows")
 void msm_set_wide_min_n(size_t n);
@@ -31,6 +40,7 @@ static constexpr int IPA_ROUND_C = 16;            // window width of the opening
 // use_graph: flags.  MSM_REPEATS: the caller repeats this exact MSM (same buffers and sizes): from the second call on the launch sequence is
 // captured once into a hipGraph and replayed
 static constexpr int MSM_REPEATS = 1, MSM_SPREAD_SCALARS = 2;      // (MSM_SPREAD_SCALARS: msm.hip, "the caller vouches ...")
+static constexpr int MSM_LATENCY = 4;                              // the caller's critical path: the accumulation runs above the default wave priority too
 // Host scalars of ONE MSM (k == 1) that are still on their way: msm_enqueue uploads them to scalars_dev itself, in `nev` chunks on the copy stream `cs`
 // (pageable memory: the runtime stages each chunk while the previous one's k_digits already runs on the slot's stream), each chunk's digits launched
 // behind its own event -- the digit pass of a 2^20 MSM hides under the upload, and with two MSMs in flight the whole upload hides under the other

@@ -31,7 +31,7 @@ SYMBOLS = [
     "kh_sponge_new", "kh_sponge_clone", "kh_sponge_free", "kh_sponge_absorb_g", "kh_sponge_absorb", "kh_sponge_absorb_fr", "kh_sponge_challenge",
     "kh_sponge_challenge_field", "kh_sponge_squeeze_field", "kh_sponge_digest",
     "kh_group_map_to_group", "kh_dev_copy", "kh_dev_memset_zero", "kh_dev_fill_elements", "kh_set_phase_timers", "kh_ipa_open",
-    "kh_device_count", "kh_init", "kh_set_device", "kh_get_device", "kh_trim", "kh_srs_device", "kh_last_error", "kh_srs_create", "kh_msm_set_wide_min_n", "kh_ntt_set_max_logr", "kh_msm_submit_host", "kh_counter", "kh_srs_set_wide_tables", "kh_srs_has_wide_tables", "kh_srs_free", "kh_srs_size",
+    "kh_device_count", "kh_init", "kh_set_device", "kh_get_device", "kh_trim", "kh_srs_device", "kh_last_error", "kh_srs_create", "kh_msm_set_wide_min_n", "kh_ntt_set_max_logr", "kh_debug_rebase_points", "kh_msm_submit_host", "kh_counter", "kh_srs_set_wide_tables", "kh_srs_has_wide_tables", "kh_srs_free", "kh_srs_size",
     "kh_srs_set_lagrange", "kh_srs_compute_lagrange", "kh_srs_get_lagrange", "kh_srs_lagrange_chunks",
     "kh_msm", "kh_msm_batch", "kh_msm_points", "kh_ntt", "kh_lde",
     "kh_dev_alloc", "kh_dev_free", "kh_dev_upload", "kh_dev_download", "kh_dev_upload_2d",
@@ -123,6 +123,7 @@ _lib.kh_points_sum.argtypes = [C.c_int, U64P, U8P, C.c_size_t, U64P, U8P]
 _lib.kh_points_add.argtypes = [C.c_int, U64P, U8P, U64P, U8P, C.c_size_t, U64P, U8P]
 _lib.kh_msm_submit.argtypes = [C.c_void_p, C.c_int, C.c_uint, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.POINTER(C.c_uint64)]
 _lib.kh_msm_wait.argtypes = [C.c_uint64, U64P, U8P]
+_lib.kh_msm_submit_host.argtypes = [C.c_void_p, C.c_int, C.c_uint, C.c_size_t, U64P, C.c_size_t, C.c_size_t, C.c_int, C.POINTER(C.c_uint64)]
 _lib.kh_msm_points_batch.argtypes = [C.c_int, U64P, U8P, U64P, C.c_size_t, C.c_size_t, C.c_int, U64P, U8P]
 _lib.kh_ntt.argtypes = [C.c_int, U64P, C.c_uint, C.c_int, C.c_size_t]
 _lib.kh_lde.argtypes = [C.c_int, U64P, C.c_uint, C.c_uint, U64P, C.c_size_t]
@@ -150,6 +151,40 @@ _lib.kh_srs_get_blinding_base.argtypes = [C.c_void_p, U64P]
 _lib.kh_mask_custom.argtypes = [C.c_void_p, U64P, U8P, C.c_size_t, U64P, C.c_size_t, U64P, U8P]
 _lib.kh_domain_generator.argtypes = [C.c_int, C.c_uint, U64P]
 E_BLINDERS = -5
+
+
+def _declare_remaining_argtypes():
+    """ctypes passes an undeclared Python int as a 32-bit C int: every function whose argument list is not declared above gets it from the header's own
+    prototype (include/kimchi_hip.h): int / unsigned / size_t / uint64_t by value, every pointer or array as void* (which takes ctypes pointers, byref(),
+    arrays, addresses and None alike).  Round 6: kh_msm_submit_host, called with a bare Python int for its size_t n, asked hipMalloc for 6.6 EB."""
+    import re
+    hdr = os.path.join(os.path.dirname(_HERE), "include", "kimchi_hip.h")
+    try:
+        src = re.sub(r"/\*.*?\*/", "", open(hdr).read(), flags=re.S)
+    except OSError:
+        return
+    by_value = {"int": C.c_int, "unsigned": C.c_uint, "size_t": C.c_size_t, "uint64_t": C.c_uint64, "uint32_t": C.c_uint32, "double": C.c_double, "float": C.c_float}
+    for m in re.finditer(r"\b(kh_[a-z_0-9]+)\s*\(([^;{}]*?)\)\s*;", src):
+        name, args = m.group(1), " ".join(m.group(2).split())
+        fn = getattr(_lib, name, None)
+        if fn is None or fn.argtypes is not None or args in ("", "void"):
+            continue
+        types = []
+        for a in args.split(","):
+            a = a.strip()
+            if "*" in a or "[" in a:
+                types.append(C.c_void_p)
+                continue
+            base = [t for t in a.split()[:-1] if t != "const"]
+            if len(base) != 1 or base[0] not in by_value:
+                types = None
+                break
+            types.append(by_value[base[0]])
+        if types is not None:
+            fn.argtypes = types
+
+
+_declare_remaining_argtypes()
 
 
 class KhError(RuntimeError):
@@ -239,6 +274,16 @@ class Srs:
         count = self.n - offset if count is None else count
         out = np.zeros((count, 8), dtype=np.uint64)
         _check(_lib.kh_srs_get_g(self._h, offset, count, _p64(out)))
+        return out
+
+    def debug_rebase_points(self, coef):
+        """kh_debug_rebase_points: the folded basis sum_q coef[q] g[q N + i] (csrc/rebase.hip), affine; raises if an output was the identity."""
+        c = _c64(coef, (-1, 4))
+        N = self.n // c.shape[0]
+        out = np.zeros((N, 8), dtype=np.uint64); fail = C.c_uint32(0)
+        _check(_lib.kh_debug_rebase_points(self._h, _p64(c), c.shape[0], _p64(out), C.byref(fail)))
+        if fail.value:
+            raise KhError("rebase: an output is the point at infinity")
         return out
 
     def has_wide_tables(self) -> bool:
@@ -428,7 +473,7 @@ def msm_points_batch(curve: int, xy, scalars, inf=None, mont: bool = True):
 
 
 def counter(name: str) -> int:
-    """Process-wide event counter of the library (kh_counter): spread_retry, fused_retry, graph_replay, graph_capture, round_coalesced, round_solo, wide_rare."""
+    """Process-wide event counter of the library (kh_counter): spread_retry, fused_retry, graph_replay, graph_capture, rebase_launch, rebase_switch, rebase_abandon, rebased_rounds."""
     return int(_lib.kh_counter(name.encode()))
 
 

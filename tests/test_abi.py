@@ -33,6 +33,27 @@ def test_header_symbols_exported(khip):
     assert sorted(khip.SYMBOLS) == decl
 
 
+def test_binding_declares_the_argument_types_of_every_wide_argument(khip):
+    """ctypes passes an undeclared Python int as a 32-bit C int: a function with a size_t / uint64_t / pointer parameter that the binding calls without
+    `argtypes` gets garbage in the upper halves (round 6: kh_msm_submit_host asked hipMalloc for 6.6 EB).  Every function of the header that has such a
+    parameter and that the binding CALLS must have its argument list declared, with the header's arity."""
+    src = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "kimchi_hip.h")).read(), flags=re.S)
+    decls = {m.group(1): m.group(2) for m in re.finditer(r"\b(kh_[a-z_0-9]+)\s*\(([^;{}]*?)\)\s*;", src)}
+    py = open(os.path.join(ROOT, "proof_systems_amd", "khip.py")).read()
+    called = set(re.findall(r"_lib\.(kh_[a-z_0-9]+)\(", py))
+    lib = khip.raw()
+    for name in sorted(called):
+        args = decls[name].strip()
+        if args in ("", "void"):
+            continue
+        wide = any(t in args for t in ("size_t", "uint64_t", "*", "["))
+        at = getattr(lib, name).argtypes
+        if wide:
+            assert at is not None, f"{name}({args}): argtypes not declared in proof_systems_amd/khip.py"
+        if at is not None:
+            assert len(at) == len([a for a in args.split(",") if a.strip()]), f"{name}: {len(at)} argtypes for ({args})"
+
+
 def test_no_oracle_in_product():
     """The product path must never route through the oracle or any CPU fallback."""
     pkg = os.path.join(ROOT, "proof_systems_amd")

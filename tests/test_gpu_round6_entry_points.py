@@ -1,6 +1,7 @@
 """Round-6 entry points on the device against the C oracle: kh_msm_submit_host (the MSM pipeline from HOST scalars -- what
 SRS::commit_non_hiding(&DensePolynomial) hands over, poly-commitment/src/ipa.rs:638-683) in its chunked and un-chunked forms, and the lone big host MSM
-that runs as two half-range jobs."""
+(the chunked upload -- KH_HOST_CHUNK_MIN -- and the two half-range jobs of a lone big MSM -- KH_HOST_SPLIT_MIN -- are
+experiments that measured level and are off by default: the tests below run them in a subprocess)."""
 import os
 
 import numpy as np
@@ -82,3 +83,30 @@ def test_msm_submit_host_from_pinned_memory(khip):
         out, inf = khip.Srs.msm_wait(t)
         assert not inf[0] and np.array_equal(out[0], want)
     srs.close()
+
+
+def test_chunked_upload_and_split_experiments_stay_bit_exact():
+    """KH_HOST_CHUNK_MIN / KH_HOST_SPLIT_MIN (off by default) in a fresh process: the same MSMs against the C oracle."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "from oracle import cref\n"
+        "import proof_systems_amd.khip as k\n"
+        "k.init(0)\n"
+        "rng = np.random.default_rng(5)\n"
+        "n = 1 << 17\n"
+        "g = cref.srs_generate(0, 0, n, threads=8)\n"
+        "srs = k.Srs(0, g)\n"
+        "for m in (n, n - 77, 1 << 16):\n"
+        "    sc = rng.integers(0, 1 << 64, size=(m, 4), dtype=np.uint64); sc[:, 3] &= np.uint64((1 << 61) - 1)\n"
+        "    w, winf = cref.msm(0, g[:m], sc, threads=8)\n"
+        "    o, i = srs.msm(sc)\n"
+        "    assert not i and np.array_equal(o, w), ('sync', m)\n"
+        "    o, i = k.Srs.msm_wait(srs.msm_submit_host(sc))\n"
+        "    assert not i[0] and np.array_equal(o[0], w), ('submit_host', m)\n"
+        "print('ok')\n" % root)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, KH_HOST_CHUNK_MIN="4096", KH_HOST_SPLIT_MIN="65536"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0 and b"ok" in r.stdout, r.stderr.decode()[-1500:]

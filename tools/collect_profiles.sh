@@ -18,9 +18,14 @@ python tools/timeline.py $DB > gpurun_out/prof/${R}_msm20_pipelined_timeline.txt
 python tools/wide_ab.py 20 20 5 > gpurun_out/prof/${R}_wide_ab.txt 2>&1
 python tools/pcie_inclusive.py > gpurun_out/prof/${R}_pcie_inclusive.txt 2>&1
 python tools/bench_ntt.py > gpurun_out/prof/${R}_bench_ntt.txt 2>&1
+(cd /tmp && rocprofv3 --kernel-trace -d /tmp/proof_$R -o t -- python $OLDPWD/tools/prover_time.py 16 --native > /dev/null 2>&1)
+PDB=$(find /tmp/proof_$R -name "*.db" | head -1)
+python tools/proof_timeline.py $PDB > gpurun_out/prof/${R}_proof_timeline.txt 2>&1
+python tools/round_timeline.py $PDB > gpurun_out/prof/${R}_round_timeline.txt 2>&1
+python tools/proof_busy.py $PDB gpurun_out/prof/${R}_proof_busy.json > /dev/null 2>&1
 KH_IPA_TIMING=1 python tools/prover_time.py 16 --native > gpurun_out/prof/${R}_prover_time_ipa_timing.txt 2>&1
 # bench.py last: copy the fresh PMC / mix files where it looks for them
-cp gpurun_out/prof/${R}_msm20_pmc.json gpurun_out/prof/${R}_ntt_pmc.json gpurun_out/prof/${R}_k_acc_wide29_valu_mix.json gpurun_out/prof/${R}_k_ntt_pass_valu_mix.json profiles/ 2>/dev/null
+cp gpurun_out/prof/${R}_proof_busy.json gpurun_out/prof/${R}_msm20_pmc.json gpurun_out/prof/${R}_ntt_pmc.json gpurun_out/prof/${R}_k_acc_wide29_valu_mix.json gpurun_out/prof/${R}_k_ntt_pass_valu_mix.json profiles/ 2>/dev/null
 python bench.py > gpurun_out/prof/${R}_bench_stdout.txt 2> gpurun_out/prof/${R}_bench_stderr.txt
 grep '^{' gpurun_out/prof/${R}_bench_stdout.txt | tail -1 > gpurun_out/prof/${R}_bench_line.json
 rm -rf gpurun_out/prof/*_passes
