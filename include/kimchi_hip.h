@@ -84,6 +84,10 @@ int kh_srs_create(int curve, const uint64_t *g_xy /* n x 8 limbs */, size_t n, k
  * table additions per scalar, 2^19 buckets, +13/16 of the table memory), and single MSMs of at least n scalars over them take it.  Default 2^19
  * (KH_WIDE_MIN_N), 0 = never.  Results are the same group elements either way; the tests lower it to run the wide path at small sizes. */
 int kh_msm_set_wide_min_n(size_t n);
+/* Tuning knob (process-wide) of the wide path's sort: the second sorting pass collects a partition's entries in LDS and writes them out as coalesced runs, in
+ * at most `max_passes` passes of `entries` entries each (default 28,672 and 2: KH_PART2_STAGE / KH_PART2_MAXPASS); a partition that would need more passes, or
+ * entries = 0, takes the direct scatter.  Same results under every setting; the tests shrink it to run the multi-pass and the fallback branches at small sizes. */
+int kh_msm_set_sort_staging(unsigned entries, unsigned max_passes);
 /* The wide set is OPTIONAL: if it does not fit in device memory when the handle is created, the handle is created without it (the narrow tables serve every
  * MSM, ~8 % slower at 2^20) and no error is reported.  kh_srs_set_wide_tables(srs, 0) gives an existing wide set back (832 MiB at 2^20 points, 3.3 GiB at
  * 2^22) -- no MSM over the handle may be in flight, as for kh_srs_free --, (srs, 1) builds it now whatever the threshold says and fails with KH_E_NOMEM if it

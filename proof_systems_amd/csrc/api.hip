@@ -520,6 +520,10 @@ int kh_srs_set_wide_tables(kh_srs_t* srs, int on) {
     return KH_OK;
 }
 int kh_msm_set_wide_min_n(size_t n) { msm_set_wide_min_n(n); return KH_OK; }
+int kh_msm_set_sort_staging(unsigned entries, unsigned max_passes) {
+    if (max_passes > 8) { set_error("kh_msm_set_sort_staging: at most 8 passes (got %u)", max_passes); return KH_E_INVALID; }
+    msm_set_sort_staging(entries, max_passes); return KH_OK;
+}
 int kh_srs_create(int curve, const uint64_t* g_xy, size_t n, kh_srs_t** out) {
     KH_REQUIRE(out && g_xy && n > 0, "kh_srs_create: null argument or n == 0");
     KH_REQUIRE(curve == KH_CURVE_VESTA || curve == KH_CURVE_PALLAS, "unknown curve id %d", curve);

@@ -681,7 +681,7 @@ k_sort_fused(const int32_t* __restrict__ digits, FusedGeom g, u32* __restrict__ 
 // BLOCK instead (16 bits: a block reads a contiguous run of <= 65,536 digits of the [w][i] matrix): pass B knows from the scanned block matrix PO
 // which block wrote the record it is looking at (the partition's run is the concatenation of the blocks' runs, in block order) and rebuilds
 // (window, point) from block start + local position.
-static constexpr u32 PART2_MAXLOW = 11;
+static constexpr u32 PART2_MAXLOW = 11, PART2_MAXPASS = 8;  // (array bound; the launch's max_pass decides: 2 by default)
 __global__ void __launch_bounds__(PART_T)
 k_part2_scatter(const int32_t* __restrict__ digits, u32 tot_e, u32 nblk, u32 low, const u32* __restrict__ PO, u32* __restrict__ mid, u32* __restrict__ xlist) {
     KH_HIGH_PRIO();
@@ -717,11 +717,14 @@ __global__ void __launch_bounds__(PART_T)
 k_part2_sort(const u32* __restrict__ mid, const u32* __restrict__ PO, u32 nblk, u32 low, u32 nb, u32 tot_e, u32 n, size_t pt_stride, size_t pt_offset,
              size_t pt_batch, u32 last_group, size_t total_idx, WideTasks ta, u32* __restrict__ off, u32* __restrict__ entries,
              u32* __restrict__ toff, u32* __restrict__ order, u32* __restrict__ ptot, u32* __restrict__ xlist, u32* __restrict__ slist,
-             uint8_t* __restrict__ buckets29, u32 og_) {
+             uint8_t* __restrict__ buckets29, u32 og, u32 stage_cap, u32 max_pass) {
     KH_HIGH_PRIO();
-    const u32 og = og_ & 0x7fffffffu;
     __shared__ u32 cur[1u << PART2_MAXLOW], pstart[1025], bi0[1024], bw0[1024], lh[MAX_K + 2], sh[PART_T / 64 + 1];
-    __shared__ u32 xl_key[1u << PART2_MAXLOW], xl_nt[1u << PART2_MAXLOW], xl_base[1u << PART2_MAXLOW], xl_n;
+    __shared__ u32 xl_n, pfirst[PART2_MAXPASS], plast[PART2_MAXPASS];
+    // dynamic LDS: the staging area of the final scatter (stage_cap entries, then one pass id per bucket); the planning phase's split-bucket lists live in
+    // its first 3 x 2^PART2_MAXLOW words (dead before the scatter starts)
+    extern __shared__ u32 stage[];
+    u32* const xl_key = stage; u32* const xl_nt = stage + (1u << PART2_MAXLOW); u32* const xl_base = stage + (2u << PART2_MAXLOW);
     const u32 pidx = blockIdx.x, j = blockIdx.y, tid = threadIdx.x;
     const size_t q = (size_t)j * PART_P + pidx;
     const u32 nparts = gridDim.x * gridDim.y;
@@ -788,26 +791,62 @@ k_part2_sort(const u32* __restrict__ mid, const u32* __restrict__ PO, u32 nblk, 
     // The partition's records are the concatenation of the pass-A blocks' runs (~n W / (256 nblk) records each): a WAVE takes whole runs, so the
     // block that wrote a record -- and with it (window, point) of the record's position -- is wave-uniform (a per-record search through pstart cost
     // ten LDS reads per record).  Four 64-record chunks of a run are loaded before any is scattered.
+    //
+    // Where the entries go (round 6).  A partition's ~53 K entries cover 212 KB and 256 partitions are in flight: a 4-byte store to a random place in that
+    // range leaves the L2 as a partial line long before its neighbours arrive -- 391 MB written for 54.5 MB of entries (profiles/r05_msm20_summary.txt), and
+    // the kernel without these stores took 109 instead of 226 us in its phase (KH_DEBUG_PART2_NOSTORE, round 6).  So the scatter runs in PASSES over
+    // consecutive bucket ranges of at most stage_cap - 1024 entries each: a pass scatters its buckets' entries into LDS and writes them out as one coalesced
+    // run.  Every pass re-reads the partition's records (coalesced, L2-resident).  A bucket that straddles the staging area's end (longer than the 1024
+    // margin: skew) has its tail stored directly.  Sweep (profiles/r06_part2_stage_sweep.txt, _sizes.txt; sort phase / pipelined rate, direct -> staged): 2^20 with
+    // 14336 / 20480 / 28672 entries (4 / 3 / 2 passes) 231 -> 249 / 196 / 166 us, 1004 -> 984 / 1018 / 1035 Mscalar/s; 2^19 (one pass) 118 -> 83 us, 926 -> 961;
+    // 2^21 (four passes) 491 -> 456 us but 1049 -> 1031; 2^22 (eight) 1112 -> 1398 us: every pass re-reads and re-filters the partition's records, so more than
+    // max_pass passes (two by default: KH_PART2_MAXPASS) fall back to the direct scatter.
     const u32 lane = tid & 63u, wv = tid >> 6;
-    for (u32 blk = wv; blk < nblk; blk += PART_T / 64) {
-        const u32 rs = pstart[blk], re = pstart[blk + 1];
-        const u32 w0 = bw0[blk], i0 = bi0[blk];
-        for (u32 x0 = rs; x0 < re; x0 += 256) {
-            u32 m[4];
+    const u32 S_eff = stage_cap > 2048u ? stage_cap - 1024u : 0u;
+    const u32 npass = S_eff ? (end - base + S_eff - 1u) / S_eff : 0u;
+    const bool staged = S_eff != 0u && npass >= 1u && npass <= max_pass;
+    uint8_t* const bpass = (uint8_t*)(stage + stage_cap);
+    if (staged) {
+        if (tid < PART2_MAXPASS) { pfirst[tid] = 0xffffffffu; plast[tid] = 0u; }
+        __syncthreads();
+        for (u32 b = tid; b < nbl; b += PART_T) {          // cur[b] = the bucket's first entry position (set above)
+            const u32 o = cur[b], oe = b + 1 < nbl ? cur[b + 1] : end, pb = (o - base) / S_eff;
+            bpass[b] = (uint8_t)pb;
+            if (oe > o) { atomicMin(&pfirst[pb], o); atomicMax(&plast[pb], oe); }
+        }
+        __syncthreads();
+    }
+    for (u32 pass = 0; pass < (staged ? npass : 1u); pass++) {
+        const u32 p0 = staged ? pfirst[pass] : 0u, p1 = staged ? plast[pass] : 0u;
+        if (staged && p0 == 0xffffffffu) continue;         // (no bucket starts in this slice: block-uniform)
+        for (u32 blk = wv; blk < nblk; blk += PART_T / 64) {
+            const u32 rs = pstart[blk], re = pstart[blk + 1];
+            const u32 w0 = bw0[blk], i0 = bi0[blk];
+            for (u32 x0 = rs; x0 < re; x0 += 256) {
+                u32 m[4];
 #pragma unroll
-            for (int u = 0; u < 4; u++) { const u32 x = x0 + u * 64 + lane; m[u] = mid[x < re ? x : re - 1]; }
+                for (int u = 0; u < 4; u++) { const u32 x = x0 + u * 64 + lane; m[u] = mid[x < re ? x : re - 1]; }
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const bool live = x0 + u * 64 + lane < re;
-                if (x0 + u * 64 >= re) break;              // (wave-uniform)
-                const u32 pos = lds_inc_agg(cur, m[u] >> 17, live);
-                if (live) {
-                    u32 w = w0, i = i0 + (m[u] & 0xffffu);
-                    while (i >= n) { i -= n; w++; }
-                    if (!(og_ & 0x80000000u) || pos == 0xffffffffu)          // (KH_DEBUG_PART2_NOSTORE: experiment -- is pass B bound by its scattered stores?)
-                    entries[pos] = (pb0 + (u32)(w * pt_stride) + i) | ((m[u] & (1u << 16)) << 15);
+                for (int u = 0; u < 4; u++) {
+                    if (x0 + u * 64 >= re) break;          // (wave-uniform)
+                    const u32 bk = m[u] >> 17;
+                    const bool live = x0 + u * 64 + lane < re && (!staged || bpass[bk] == pass);
+                    const u32 pos = lds_inc_agg(cur, bk, live);
+                    if (live) {
+                        u32 w = w0, i = i0 + (m[u] & 0xffffu);
+                        while (i >= n) { i -= n; w++; }
+                        const u32 val = (pb0 + (u32)(w * pt_stride) + i) | ((m[u] & (1u << 16)) << 15);
+                        if (staged && pos - p0 < stage_cap) stage[pos - p0] = val;
+                        else entries[pos] = val;
+                    }
                 }
             }
+        }
+        if (staged) {
+            __syncthreads();
+            const u32 cnt = p1 - p0 < stage_cap ? p1 - p0 : stage_cap;
+            for (u32 k = tid; k < cnt; k += PART_T) entries[p0 + k] = stage[k];
+            __syncthreads();
         }
     }
 }
@@ -1611,6 +1650,12 @@ static std::atomic<size_t>& wide_min_n_cell() {
     static std::atomic<size_t> v{getenv("KH_WIDE_MIN_N") ? (size_t)strtoull(getenv("KH_WIDE_MIN_N"), nullptr, 0) : ((size_t)1 << 19)};
     return v;
 }
+// the staged scatter of k_part2_sort: [0] entries per pass in LDS (KH_PART2_STAGE, 0 = the direct scatter), [1] the most passes a partition may take (KH_PART2_MAXPASS)
+static std::atomic<u32>& sort_staging_cell(int i) {
+    static std::atomic<u32> v[2] = {{getenv("KH_PART2_STAGE") ? (u32)atoi(getenv("KH_PART2_STAGE")) : 28672u}, {getenv("KH_PART2_MAXPASS") ? (u32)atoi(getenv("KH_PART2_MAXPASS")) : 2u}};
+    return v[i];
+}
+void msm_set_sort_staging(unsigned entries, unsigned max_passes) { sort_staging_cell(0).store(entries); sort_staging_cell(1).store(max_passes); }
 size_t msm_wide_min_n() { const size_t v = wide_min_n_cell().load(); return v ? v : ~(size_t)0; }
 void msm_set_wide_min_n(size_t n) { wide_min_n_cell().store(n); }
 int msm_pick_window(size_t n) {
@@ -1849,7 +1894,7 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
                                   (uint64_t)(uintptr_t)C.ws_biglist.p, (uint64_t)(uintptr_t)C.ws_order.p, (uint64_t)(uintptr_t)C.ws_chunks.p,
                                   (uint64_t)(uintptr_t)C.ws_handed.p, (uint64_t)(uintptr_t)C.ws_sync.p, (uint64_t)fused, (uint64_t)(uintptr_t)C.ws_mid.p, (uint64_t)part,
                                   (uint64_t)(uintptr_t)tab_pts, (uint64_t)wide, (uint64_t)spread, (uint64_t)(uintptr_t)C.ws_xlist.p, (uint64_t)(uintptr_t)C.ws_b29.p, (uint64_t)(uintptr_t)C.ws_a1.p, (uint64_t)(uintptr_t)C.ws_a2.p, (uint64_t)(uintptr_t)C.ws_done.p, (uint64_t)flag_on, (uint64_t)(use_graph & MSM_LATENCY),
-                                  DevBuf::generation().load()};
+                                  ((uint64_t)sort_staging_cell(0).load() << 8) | sort_staging_cell(1).load(), DevBuf::generation().load()};
         for (uint64_t v : parts) key = fnv(key, v);
         if (C.gexec && C.gkey == key) {                    // replay
             C.fused_used = C.g_fused;
@@ -1918,9 +1963,17 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
             const WideTasks wt{room, kmin, (u32)nkeys, ktab};
             u32* const slist = C.ws_xlist.as<u32>() + 2 + 2 * max_tasks;
             u32* const ptot = C.ws_ntask.as<u32>();        // k * 256 partition task totals (the narrow path's per-key task counts: unused here)
-            hipLaunchKernelGGL(k_part2_sort, dim3(PART_P, (unsigned)k), dim3(PART_T), 0, s, C.ws_mid.as<u32>(), C.ws_cnt.as<u32>(), part_nblk, part_low, nb, tot_e, (u32)n,
+            // staged scatter (round 6): KH_PART2_STAGE = entries per pass in LDS (0: the direct scatter); the dynamic LDS also holds the planning phase's lists
+            const u32 part2_stage = sort_staging_cell(0).load(), part2_maxpass = std::min<u32>(PART2_MAXPASS, sort_staging_cell(1).load());
+            // (clamped to the 128 KB the attribute below asks for; an MSM whose partitions cannot make it in max_pass passes does not ask for the LDS at all)
+            u32 stage_now = std::min<u32>(part2_stage, (131072u - (1u << PART2_MAXLOW)) / 4u);
+            if (stage_now <= 2048u || (size_t)W * n / PART_P > (size_t)part2_maxpass * (stage_now - 1024u)) stage_now = 0;
+            const u32 stage_words = std::max<u32>(stage_now, 3u << PART2_MAXLOW);
+            const size_t part2_lds = (size_t)stage_words * 4 + (stage_now ? ((size_t)1 << PART2_MAXLOW) : 0);
+            if (Ctx.once("part2_attr")) KH_HIP(hipFuncSetAttribute((const void*)k_part2_sort, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+            hipLaunchKernelGGL(k_part2_sort, dim3(PART_P, (unsigned)k), dim3(PART_T), part2_lds, s, C.ws_mid.as<u32>(), C.ws_cnt.as<u32>(), part_nblk, part_low, nb, tot_e, (u32)n,
                                tab_stride, offset, basis.batch_stride, (u32)(k - 1), part_size, wt, C.ws_off.as<u32>(), C.ws_entries.as<u32>(),
-                               C.ws_toff.as<u32>(), order, ptot, C.ws_xlist.as<u32>(), slist, C.ws_b29.as<uint8_t>(), wide_og | (getenv("KH_DEBUG_PART2_NOSTORE") ? 0x80000000u : 0u));
+                               C.ws_toff.as<u32>(), order, ptot, C.ws_xlist.as<u32>(), slist, C.ws_b29.as<uint8_t>(), wide_og, stage_now, part2_maxpass);
             hipLaunchKernelGGL(k_wide_fixup, dim3((unsigned)(nkeys / 256 + 1)), dim3(256), 0, s, C.ws_toff.as<u32>(), ptot, (u32)(k * PART_P), part_low, (u32)nkeys,
                                C.ws_handed.as<u32>(), C.ws_biglist.as<u32>());
         } else {

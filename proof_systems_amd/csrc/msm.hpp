@@ -31,6 +31,7 @@ size_t rebase_list_bytes(size_t Q);
 static constexpr int MSM_PRECOMP_C = 16;          // window width of the precomputed tables
 static constexpr int MSM_WIDE_C = 20;             // ... of the second table set big bases get: 13 windows, 2^19 buckets (msm.hip, "wide windows")
 void msm_set_wide_min_n(size_t n);
+void msm_set_sort_staging(unsigned entries, unsigned max_passes);   // k_part2_sort's staged scatter (kh_msm_set_sort_staging)
 size_t msm_wide_min_n();                          // MSMs of at least this many points take the wide tables (KH_WIDE_MIN_N, default 2^19; 0 = never)
                                                   // measured (tools/wide_ab.py, pipelined Mscalar/s narrow -> wide): 2^17 537 -> 400, 2^18 655 -> 685, 2^19 746 -> 815,
                                                   // 2^20 896 -> 960..1000, 2^21 770 -> 976, 2^22 861 -> 992

@@ -191,3 +191,32 @@ def test_wide_tables_are_optional(khip):
     with pytest.raises(Exception):
         small.set_wide_tables(True)
     small.close()
+
+
+@pytest.mark.parametrize("stage,passes", [(0, 2), (2560, 8), (4096, 3), (3000, 1), (28672, 2)])
+def test_wide_sort_staging_settings(khip, stage, passes):
+    """k_part2_sort's staged scatter (round 6: a partition's entries are collected in LDS and written out as coalesced runs, in passes over consecutive bucket
+    ranges) under settings that force, at 2^15..2^16 scalars (1.7-3.3 K entries per partition): several passes, the fall-back to the direct scatter when a partition would
+    need more passes than allowed, buckets longer than the 1024-entry margin that straddle the end of the staging area (all_equal / bench_witness: one bucket
+    holds a window's every entry) and the direct scatter itself.  Same group element under every setting."""
+    khip.set_sort_staging(stage, passes)
+    try:
+        for n, kinds in ((1 << 15, ["uniform", "all_equal", "bench_witness", "top_window"]), (1 << 16, ["uniform", "bits20"]), (40000, ["uniform"])):
+            srs = khip.Srs.create(khip.VESTA, n)
+            g = srs.get_g()
+            for kind in kinds:
+                sc, mont = _scalars(kind, n, np.random.default_rng(stage + passes + len(kind)))
+                want, winf = cref.msm(0, g, sc, scalars_mont=mont, threads=THREADS)
+                for rep in range(3):                              # (the third call replays the captured launch sequence)
+                    got, ginf = srs.msm(sc, mont=mont)
+                    assert _wide_ran(khip) or rep > 0
+                    assert bool(ginf) == winf and (winf or np.array_equal(got, want)), (kind, n, rep)
+            srs.close()
+    finally:
+        khip.set_sort_staging()
+
+
+def test_sort_staging_rejects_too_many_passes(khip):
+    with pytest.raises(Exception):
+        khip.set_sort_staging(4096, 9)
+    khip.set_sort_staging()

@@ -18,7 +18,7 @@ CONFIGS = [("default (og16, 3 blk/CU, r16)", {}), ("og4", {"KH_WIDE_OG": "4"}), 
 
 def child(tag):
     import proof_systems_amd.khip as khip
-    n = 1 << 20
+    n = 1 << int(os.environ.get("KH_SWEEP_LOGN", "20"))
     khip.init(0)
     srs = khip.Srs.create(khip.VESTA, n)
     sc = np.random.default_rng(1).integers(0, 1 << 64, size=(n, 4), dtype=np.uint64)
