@@ -430,6 +430,10 @@ int kh_dev_fill_elements(uint64_t *dst_dev, const uint64_t value[4], size_t coun
 /* `rows` runs of `width` bytes, `src_pitch` / `dst_pitch` bytes apart: the witness columns of a prover ([Vec<F>; 15], each shorter than
  * the domain: kimchi/src/prover.rs:254-266) go into their padded device columns in one transfer. */
 int kh_dev_upload_2d(void *dst_dev, size_t dst_pitch, const void *src_host, size_t src_pitch, size_t width, size_t rows);
+/* The same transfer WITHOUT waiting for the work queued on the main stream first: for a destination that nothing queued reads or writes (a freshly allocated
+ * column).  Returns when the bytes are on the device; kernels queued earlier keep running underneath it -- kh_prove sends the witness in column groups this way,
+ * each group's interpolation and extension running under the next group's transfer. */
+int kh_dev_upload_2d_unordered(void *dst_dev, size_t dst_pitch, const void *src_host, size_t src_pitch, size_t width, size_t rows);
 int kh_msm_batch_dev(kh_srs_t *srs, int basis, unsigned chunk, size_t offset,
                      const uint64_t *scalars_dev, size_t n, size_t k, int scalars_are_montgomery,
                      uint64_t *out_xy /* host, k x 8 */, uint8_t *out_is_inf /* host, k */);

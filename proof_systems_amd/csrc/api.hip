@@ -2417,6 +2417,15 @@ int kh_dev_upload_2d(void* dst_dev, size_t dst_pitch, const void* src_host, size
     KH_HIP(hipStreamSynchronize(cs));
     return KH_OK;
 }
+int kh_dev_upload_2d_unordered(void* dst_dev, size_t dst_pitch, const void* src_host, size_t src_pitch, size_t width, size_t rows) {
+    int rc = ensure_init(); if (rc) return rc;
+    if (width == 0 || rows == 0) return KH_OK;
+    KH_REQUIRE(dst_dev && src_host && dst_pitch >= width && src_pitch >= width, "kh_dev_upload_2d_unordered: bad argument");
+    hipStream_t cs = thread_copy_stream(); if (!cs) return KH_E_DEVICE;
+    KH_HIP(hipMemcpy2DAsync(dst_dev, dst_pitch, src_host, src_pitch, width, rows, hipMemcpyHostToDevice, cs));
+    KH_HIP(hipStreamSynchronize(cs));
+    return KH_OK;
+}
 int kh_dev_download(void* dst_host, const void* src_dev, size_t bytes) {
     int rc = ensure_init(); if (rc) return rc;
     if (bytes == 0) return KH_OK;

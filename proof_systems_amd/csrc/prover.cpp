@@ -387,6 +387,27 @@ int kh_prove_full(kh_prover_index_t* ix, const uint64_t* witness, size_t rows, c
         ~Tickets() { for (int i = 0; i < 4; i++) if (live[i]) { uint64_t xy[8 * COLUMNS]; uint8_t inf[COLUMNS]; (void)kh_msm_wait(t[i], xy, inf); } }
         int wait(int i, uint64_t* xy, uint8_t* inf) { live[i] = false; return kh_msm_wait(t[i], xy, inf); }
     } tickets;
+    // The witness arrives over PCIe in 0.6 ms at 2^16 rows (31 MB), and nothing of the proof can start without it -- except the columns' own interpolation and
+    // extension, which need one column each.  So the columns travel in groups (KH_PROVE_UPLOAD_GROUPS, default 3; 1 = one transfer as before) and every group but
+    // the last has its copy -> iNTT -> LDE queued behind its transfer: that work (2/3 of 0.37 ms) runs underneath the next group's transfer instead of underneath
+    // the commitment, the permutation aggregation finds an idle stream ~0.25 ms earlier.  The commitment stays ONE batched MSM behind the last group (submitting
+    // it per group was measured in round 4: three submits cost more than the overlap gave back).
+    Dev cf; KP(cf.alloc(16 * NB));                    // coefficient forms [w | z]
+    Dev e8; KP(e8.alloc(16 * N8));
+    const bool any_lib = (ix->live != 0) || nopt > 0;
+    const size_t w8 = (!any_lib && !all_gates) ? PERMUTS : COLUMNS;     // generic + permutation read w0..w6 only
+    // The witness extension (0.35 ms of throughput work) either right behind the interpolation -- it then runs underneath the transfer / the witness commitment, and the
+    // small kernels of the permutation aggregation queue behind it -- or (KH_LDE_LATE=1) behind the aggregation, underneath the z commitment.
+    static const bool lde_late = getenv("KH_LDE_LATE") && atoi(getenv("KH_LDE_LATE")) != 0;
+    auto interpolate_extend = [&](size_t c0, size_t c1) -> int {       // columns c0 .. c1-1: evaluations -> coefficients -> d8
+        if (c1 <= c0) return KH_OK;
+        int rc_ = kh_dev_copy(cf.at(c0 * NB), ev.at(c0 * NB), (c1 - c0) * NB * 32); if (rc_) return rc_;
+        rc_ = kh_ntt_dev(fid, cf.at(c0 * NB), logn, 1, c1 - c0); if (rc_) return rc_;
+        const size_t e1 = c1 < w8 ? c1 : w8;
+        if (!lde_late && e1 > c0) rc_ = kh_lde_dev(fid, cf.at(c0 * NB), logn, 3, e8.at(c0 * N8), e1 - c0);
+        return rc_;
+    };
+    size_t cols_pending = 0;                           // first column whose interpolation / extension is not queued yet
     if (witness) {
         KP_REQUIRE(rows + zk <= n, "NoRoomForZkInWitness: %zu rows + %zu zero-knowledge rows > %zu", rows, zk, n);
         if (rows + zk < n) KP(kh_dev_memset_zero(ev.p, 16 * NB * 32));
@@ -394,9 +415,15 @@ int kh_prove_full(kh_prover_index_t* ix, const uint64_t* witness, size_t rows, c
         std::vector<fe> zkr(COLUMNS * zk);
         for (size_t c = 0; c < COLUMNS; c++) for (size_t j = 0; j < zk; j++) zkr[c * zk + j] = z[c * zk + (zk - 1 - j)];
         KP(kh_dev_upload_2d(ev.at(n - zk), NB * 32, zkr.data(), zk * 32, zk * 32, COLUMNS));
-        // (uploading in column groups with each group's commitment submitted behind it was measured: three submits cost the host 0.2 ms each,
-        // which delays the next transfer more than the overlap gives back -- 10.86 against 10.48 ms per proof)
-        if (rows) KP(kh_dev_upload_2d(ev.p, NB * 32, witness, rows * 32, rows * 32, COLUMNS));
+        static const size_t groups_env = getenv("KH_PROVE_UPLOAD_GROUPS") ? (size_t)atoi(getenv("KH_PROVE_UPLOAD_GROUPS")) : 3;
+        const size_t groups = (rows == 0 || groups_env < 1 || nch != 1 || n < 4096) ? 1 : (groups_env > COLUMNS ? COLUMNS : groups_env);
+        for (size_t g = 0; g < groups && rows; g++) {
+            const size_t c0 = COLUMNS * g / groups, c1 = COLUMNS * (g + 1) / groups;
+            // (the destination rows are touched by nothing that is queued: no wait for the main stream, which holds the previous group's transforms)
+            if (groups > 1) KP(kh_dev_upload_2d_unordered(ev.at(c0 * NB), NB * 32, witness + 4 * c0 * rows, rows * 32, rows * 32, c1 - c0));
+            else KP(kh_dev_upload_2d(ev.p, NB * 32, witness, rows * 32, rows * 32, COLUMNS));
+            if (g + 1 < groups) { KP(interpolate_extend(c0, c1)); cols_pending = c1; }
+        }
     } else KP(kh_dev_copy(ev.p, witness_dev, COLUMNS * NB * 32));
     mark();
     SpongeH fq; KP(kh_sponge_new(KH_SPONGE_FQ, curve, &fq.s));
@@ -443,16 +470,7 @@ int kh_prove_full(kh_prover_index_t* ix, const uint64_t* witness, size_t rows, c
     // ---- witness commitments: one batched MSM per chunk of the Lagrange basis, queued before the columns are interpolated
     uint64_t& tk = tickets.t[3]; bool& have_tk = tickets.live[3];
     if (nch == 1) { KP(kh_msm_submit(srs, (int)logn, 0, 0, ev.p, n, COLUMNS, 1, &tk)); have_tk = true; }
-    Dev cf; KP(cf.alloc(16 * NB));                    // coefficient forms [w | z]
-    KP(kh_dev_copy(cf.p, ev.p, COLUMNS * NB * 32));
-    KP(kh_ntt_dev(fid, cf.p, logn, 1, COLUMNS));
-    Dev e8; KP(e8.alloc(16 * N8));
-    bool any_lib = (ix->live != 0) || nopt > 0;
-    const size_t w8 = (!any_lib && !all_gates) ? PERMUTS : COLUMNS;     // generic + permutation read w0..w6 only
-    // The witness extension (0.35 ms of throughput work) either right behind the interpolation -- it then runs underneath the witness commitment, and the
-    // small kernels of the permutation aggregation queue behind it -- or (KH_LDE_LATE=1) behind the aggregation, underneath the z commitment.
-    static const bool lde_late = getenv("KH_LDE_LATE") && atoi(getenv("KH_LDE_LATE")) != 0;
-    if (!lde_late) KP(kh_lde_dev(fid, cf.p, logn, 3, e8.p, w8));
+    KP(interpolate_extend(cols_pending, COLUMNS));
     std::vector<uint64_t> wxy, wbx; std::vector<uint8_t> winf, wbi;
     const fe* w_blind = draw(COLUMNS * nch);          // blinder(num_chunks) per column, column by column (prover.rs:316-327)
     KP(blinding_points(w_blind, COLUMNS * nch, wbx, wbi));              // (underneath the MSM)

@@ -34,7 +34,7 @@ SYMBOLS = [
     "kh_device_count", "kh_init", "kh_set_device", "kh_get_device", "kh_trim", "kh_srs_device", "kh_last_error", "kh_srs_create", "kh_msm_set_wide_min_n", "kh_msm_set_sort_staging", "kh_ntt_set_max_logr", "kh_debug_rebase_points", "kh_msm_submit_host", "kh_counter", "kh_srs_set_wide_tables", "kh_srs_has_wide_tables", "kh_srs_free", "kh_srs_size",
     "kh_srs_set_lagrange", "kh_srs_compute_lagrange", "kh_srs_get_lagrange", "kh_srs_lagrange_chunks",
     "kh_msm", "kh_msm_batch", "kh_msm_points", "kh_ntt", "kh_lde",
-    "kh_dev_alloc", "kh_dev_free", "kh_dev_upload", "kh_dev_download", "kh_dev_upload_2d",
+    "kh_dev_alloc", "kh_dev_free", "kh_dev_upload", "kh_dev_download", "kh_dev_upload_2d", "kh_dev_upload_2d_unordered",
     "kh_msm_batch_dev", "kh_ntt_dev", "kh_lde_dev", "kh_coset_ntt_dev", "kh_sync", "kh_last_timings",
     "kh_debug_field_op", "kh_debug_point_op", "kh_srs_generate", "kh_srs_h",
     "kh_msm_sharded", "kh_msm_sharded_dev", "kh_gate_count", "kh_gate_name", "kh_gate_num_constants", "kh_gate_evaluations_dev", "kh_gate_constants", "kh_srs_curve", "kh_lookup_sorted", "kh_private_context_begin", "kh_private_context_end", "kh_private_context_active", "kh_comm_unique_id", "kh_comm_init", "kh_comm_free", "kh_comm_world_size", "kh_comm_rank", "kh_comm_allgather_points",
@@ -136,6 +136,7 @@ _lib.kh_dev_free.argtypes = [C.c_void_p]
 _lib.kh_dev_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
 _lib.kh_dev_download.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
 _lib.kh_dev_upload_2d.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t]
+_lib.kh_dev_upload_2d_unordered.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t]
 _lib.kh_last_timings.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int]
 _lib.kh_debug_field_op.argtypes = [C.c_int, C.c_int, U64P, U64P, U64P, C.c_size_t]
 _lib.kh_debug_point_op.argtypes = [C.c_int, C.c_int, U64P, U8P, U64P, U8P, U64P, U8P, C.c_size_t]
