@@ -683,11 +683,11 @@ k_sort_fused(const int32_t* __restrict__ digits, FusedGeom g, u32* __restrict__ 
 // (window, point) from block start + local position.
 static constexpr u32 PART2_MAXLOW = 11, PART2_MAXPASS = 8;  // (array bound; the launch's max_pass decides: 2 by default)
 __global__ void __launch_bounds__(PART_T)
-k_part2_scatter(const int32_t* __restrict__ digits, u32 tot_e, u32 nblk, u32 low, const u32* __restrict__ PO, u32* __restrict__ mid, u32* __restrict__ xlist) {
+k_part2_scatter(const int32_t* __restrict__ digits, u32 tot_e, u32 nblk, u32 low, const u32* __restrict__ PO, u32* __restrict__ mid, u32* __restrict__ xlist, u32* __restrict__ big) {
     KH_HIGH_PRIO();
     __shared__ u32 cur[PART_P];
     const u32 blk = blockIdx.x, j = blockIdx.y, tid = threadIdx.x;
-    if (blk == 0 && j == 0 && tid == 0) { xlist[0] = 0; xlist[1] = 0; }      // the split-bucket lists pass B appends to
+    if (blk == 0 && j == 0 && tid == 0) { xlist[0] = 0; xlist[1] = 0; big[0] = 0; }      // the split-bucket and hot-bucket lists pass B appends to
     if (tid < PART_P) cur[tid] = PO[((size_t)j * PART_P + tid) * nblk + blk];
     __syncthreads();
     const u32 e_lo = (u32)((u64)tot_e * blk / nblk), e_hi = (u32)((u64)tot_e * (blk + 1) / nblk);
@@ -717,7 +717,7 @@ __global__ void __launch_bounds__(PART_T)
 k_part2_sort(const u32* __restrict__ mid, const u32* __restrict__ PO, u32 nblk, u32 low, u32 nb, u32 tot_e, u32 n, size_t pt_stride, size_t pt_offset,
              size_t pt_batch, u32 last_group, size_t total_idx, WideTasks ta, u32* __restrict__ off, u32* __restrict__ entries,
              u32* __restrict__ toff, u32* __restrict__ order, u32* __restrict__ ptot, u32* __restrict__ xlist, u32* __restrict__ slist,
-             uint8_t* __restrict__ buckets29, u32 og, u32 stage_cap, u32 max_pass) {
+             uint8_t* __restrict__ buckets29, u32 og, u32 stage_cap, u32 max_pass, u32* __restrict__ big, u32 bigcap, u32 hot_nt) {
     KH_HIGH_PRIO();
     __shared__ u32 cur[1u << PART2_MAXLOW], pstart[1025], bi0[1024], bw0[1024], lh[MAX_K + 2], sh[PART_T / 64 + 1];
     __shared__ u32 xl_n, pfirst[PART2_MAXPASS], plast[PART2_MAXPASS];
@@ -767,6 +767,9 @@ k_part2_sort(const u32* __restrict__ mid, const u32* __restrict__ PO, u32 nblk, 
         if (i0 + 1 < nbl) atomicAdd(&lh[lb], 1u);
         if (nta > 1) { const u32 sl = atomicAdd(&xl_n, 1u); xl_key[sl] = (u32)key0; xl_nt[sl] = nta; xl_base[sl] = atomicAdd(&xlist[0], nta - 1u); slist[atomicAdd(&xlist[1], 1u)] = (u32)key0; }
         if (ntb > 1) { const u32 sl = atomicAdd(&xl_n, 1u); xl_key[sl] = (u32)key0 + 1u; xl_nt[sl] = ntb; xl_base[sl] = atomicAdd(&xlist[0], ntb - 1u); slist[atomicAdd(&xlist[1], 1u)] = (u32)key0 + 1u; }
+        // hot buckets (more partials than one thread should add up): big[0] = their number, big[2 + i] = key, big[2 + bigcap + i] = the arrival counter of k_bucket_sum_wide
+        if (nta > hot_nt) { const u32 sl = atomicAdd(&big[0], 1u); big[2 + sl] = (u32)key0; big[2 + bigcap + sl] = 0u; }
+        if (ntb > hot_nt) { const u32 sl = atomicAdd(&big[0], 1u); big[2 + sl] = (u32)key0 + 1u; big[2 + bigcap + sl] = 0u; }
         // an empty bucket's record is the identity (true bucket number = local index << 8 | partition)
         if (i0 < nbl && a == 0) { uint4* rec = (uint4*)(buckets29 + ((size_t)j * nb + ((size_t)i0 << 8 | pidx)) * B29_BYTES); _Pragma("unroll") for (int t = 0; t < 9; t++) rec[t] = make_uint4(0u, 0u, 0u, 0u); }
         if (i0 + 1 < nbl && b == 0) { uint4* rec = (uint4*)(buckets29 + ((size_t)j * nb + ((size_t)(i0 + 1) << 8 | pidx)) * B29_BYTES); _Pragma("unroll") for (int t = 0; t < 9; t++) rec[t] = make_uint4(0u, 0u, 0u, 0u); }
@@ -866,7 +869,7 @@ k_wide_fixup(u32* __restrict__ toff, const u32* __restrict__ ptot, u32 nparts, u
     const u32 bs = sh[0] + sh[1] + sh[2] + sh[3];
     if (key < nkeys) toff[key] += bs;
     else if (key == nkeys) toff[key] = bs;
-    if (key == 0) { handed[0] = 0; big[0] = 0; big[1] = 0; }
+    if (key == 0) handed[0] = 0;                           // (big[0], the hot-bucket count, belongs to pass B on this path)
 }
 // ------------------------------------------------------------------------------------ 5 accumulate
 template <class BF>
@@ -984,19 +987,20 @@ k_accumulate29(const u32* __restrict__ entries, const u32* __restrict__ off, con
 // bucket of every partition, then the second longest of every partition, ...: the 64 lanes of a wave run chains of nearly one length, and the launch
 // as a whole runs longest-first -- with two rounds of resident blocks that order is worth 30 % of the kernel).  The bucket's only task writes the bucket
 // itself, as a lazy B29 record (field29.cuh), into buckets29[key]: the two-plane reduction reads those.  A bucket above K entries (skewed scalars) is split
-// as on the narrow path: thread g runs its first chunk, the others are listed by k_part2_sort as (key, chunk) pairs for k_acc_wide_extra; split
+// as on the narrow path: thread g runs its first chunk, the others are listed by k_part2_sort as (key, chunk) pairs for k_acc_wide_rest; split
 // buckets write wire-form partials for k_bucket_sum_wide.  Tasks whose lazy arithmetic cannot exclude an exceptional case are listed as (key, chunk)
-// pairs too and redone by k_acc_wide_exact.
+// pairs too and redone exactly by k_acc_wide_rest.
 // permuted key of the wide sort -> index of the bucket's B29 record (group * nb + true bucket number)
 __device__ __forceinline__ u32 wide_true_bucket(u32 key, u32 low) {
     const u32 nbl = 1u << low, grp = key >> (low + 8), kk = key & ((nbl << 8) - 1u);
     return (grp << (low + 8)) | ((kk & (nbl - 1u)) << 8) | (kk >> low);
 }
+// (returns false only when the lazy arithmetic gave up AND there is no hand-over list: the caller redoes the task itself)
 template <class BF>
-__device__ __forceinline__ void wide_task29(u32 key, u32 jt, const u32* __restrict__ entries, const u32* __restrict__ off, const u32* __restrict__ toff,
+__device__ __forceinline__ bool wide_task29(u32 key, u32 jt, const u32* __restrict__ entries, const u32* __restrict__ off, const u32* __restrict__ toff,
                                             const uint8_t* __restrict__ pts, uint8_t* __restrict__ partial, uint8_t* __restrict__ buckets29, u32 low, u32* __restrict__ handed) {
     const u32 o0 = off[key], cnt = off[key + 1] - o0;
-    if (cnt == 0) return;
+    if (cnt == 0) return true;
     const u32 t0 = toff[key], nt = toff[key + 1] - t0;
     const u32 start = o0 + (u32)(((u64)jt * cnt) / nt), end = o0 + (u32)(((u64)(jt + 1) * cnt) / nt);
     u32 e = entries[start];
@@ -1017,58 +1021,63 @@ __device__ __forceinline__ void wide_task29(u32 key, u32 jt, const u32* __restri
     }
     // (the exact redo stays a separate kernel here: inlined as in k_accumulate29 it raised this kernel from 92 to 127 VGPRs, and the sort kernels of the
     //  neighbouring job no longer fitted beside three resident blocks: 1020 -> 985 Mscalar/s pipelined, profiles/r05_ab_inline_exact.txt)
-    if (!ok) { const u32 slot = atomicAdd(&handed[0], 1u); handed[2 + 2 * slot] = key; handed[3 + 2 * slot] = jt; return; }
-    if (nt == 1) { store_b29<BF>(buckets29 + (size_t)wide_true_bucket(key, low) * B29_BYTES, acc); return; }
+    if (!ok) { if (!handed) return false; const u32 slot = atomicAdd(&handed[0], 1u); handed[2 + 2 * slot] = key; handed[3 + 2 * slot] = jt; return true; }
+    if (nt == 1) { store_b29<BF>(buckets29 + (size_t)wide_true_bucket(key, low) * B29_BYTES, acc); return true; }
     Xyzz<BF> r;
     r.x = from29<BF>(acc.x); r.y = from29<BF>(acc.y); r.zz = from29<BF>(acc.zz); r.zzz = from29<BF>(acc.zzz);
     r.store(partial + (size_t)(t0 + jt) * 128);
+    return true;
+}
+// the same task with the exact formulas (complete addition: equal points, opposite points, the identity)
+template <class BF>
+__device__ __forceinline__ void wide_task_exact(u32 key, u32 jt, const u32* __restrict__ entries, const u32* __restrict__ off, const u32* __restrict__ toff,
+                                                const uint8_t* __restrict__ pts, uint8_t* __restrict__ partial, uint8_t* __restrict__ buckets29, u32 low) {
+    const u32 o0 = off[key], cnt = off[key + 1] - o0, t0 = toff[key], nt = toff[key + 1] - t0;
+    if (cnt == 0) return;
+    const u32 start = o0 + (u32)(((u64)jt * cnt) / nt), end = o0 + (u32)(((u64)(jt + 1) * cnt) / nt);
+    u32 e = entries[start];
+    Aff<BF> p = Aff<BF>::load(pts + (size_t)(e & 0x7fffffffu) * 64);
+    if (e >> 31) p.y = neg<BF>(p.y);
+    Xyzz<BF> acc = Xyzz<BF>::from_affine(p);
+    for (u32 k = start + 1; k < end; k++) {
+        e = entries[k];
+        p = Aff<BF>::load(pts + (size_t)(e & 0x7fffffffu) * 64);
+        acc = madd<BF>(acc, p, (e >> 31) != 0);
+    }
+    if (nt == 1) {
+        uint8_t* const rec = buckets29 + (size_t)wide_true_bucket(key, low) * B29_BYTES;
+        if (acc.is_identity()) store_b29_identity<BF>(rec); else store_b29<BF>(rec, xyzz_to29<BF>(acc));
+    } else acc.store(partial + (size_t)(t0 + jt) * 128);
 }
 // Thread per bucket.  Launched with enough dynamic LDS to hold the kernel to THREE blocks per CU (it is VALU-bound from
 // three waves per SIMD on; the fourth only keeps the neighbouring jobs' sort and reduction kernels off the CU: 886-930 -> 940-1000 Mscalar/s pipelined).
-static constexpr u32 WIDE_XB = 32;
+static constexpr u32 WIDE_XB = 32, WIDE_HOT_NT = 16;       // (a split bucket with more partials than WIDE_HOT_NT is summed by many waves)
 template <class BF>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(112), amdgpu_waves_per_eu(4, 4)))
 k_acc_wide29(const u32* __restrict__ entries, const u32* __restrict__ off, const u32* __restrict__ toff, const u32* __restrict__ order, u32 nkeys,
              const uint8_t* __restrict__ pts, uint8_t* __restrict__ partial, uint8_t* __restrict__ buckets29, u32 low, u32* __restrict__ handed) {
     const u32 g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g < nkeys) wide_task29<BF>(order[g], 0u, entries, off, toff, pts, partial, buckets29, low, handed);
+    if (g < nkeys) (void)wide_task29<BF>(order[g], 0u, entries, off, toff, pts, partial, buckets29, low, handed);
 }
-// the extra chunks of split buckets: a small persistent grid over xlist ([0] = their number, then (key, chunk) pairs from word 2 on; empty for unskewed
-// scalars).  A kernel of its own: walked by blocks of k_acc_wide29 the loop cost that kernel 13 VGPRs (92 -> 105), and with three resident blocks
-// per CU the neighbouring job's 1024-thread sort kernels (4 x 56 VGPRs per SIMD) no longer fitted beside them.
+// Everything k_acc_wide29 left behind, in ONE launch (round 6; until then two: the extra chunks, then the exact redos -- each an empty dependent launch for
+// unskewed scalars): a small persistent grid walks (a) xlist, the extra chunks of split buckets ([0] = their number, then (key, chunk) pairs from word 2 on;
+// empty for unskewed scalars) -- in the lazy arithmetic, and a chunk that gives up is redone exactly by the same thread, nothing is appended to `handed`
+// here --, then (b) `handed`, the tasks k_acc_wide29 gave up on (complete before this kernel starts).  A kernel of its own: walked by blocks of k_acc_wide29
+// the loop cost that kernel 13 VGPRs (92 -> 105) and the inline exact redo 35 more, and with three resident blocks per CU the neighbouring job's 1024-thread
+// sort kernels (4 x 56 VGPRs per SIMD) no longer fitted beside them (1020 -> 985 Mscalar/s pipelined, profiles/r05_ab_inline_exact.txt).
 template <class BF>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(112)))
-k_acc_wide_extra(const u32* __restrict__ entries, const u32* __restrict__ off, const u32* __restrict__ toff, const u32* __restrict__ xlist,
-                 const uint8_t* __restrict__ pts, uint8_t* __restrict__ partial, uint8_t* __restrict__ buckets29, u32 low, u32* __restrict__ handed) {
+__global__ void __launch_bounds__(256)
+k_acc_wide_rest(const u32* __restrict__ entries, const u32* __restrict__ off, const u32* __restrict__ toff, const u32* __restrict__ xlist, const u32* __restrict__ handed,
+                const uint8_t* __restrict__ pts, uint8_t* __restrict__ partial, uint8_t* __restrict__ buckets29, u32 low) {
     KH_HIGH_PRIO();
-    const u32 count = xlist[0];
-    for (u32 it = blockIdx.x * blockDim.x + threadIdx.x; it < count; it += gridDim.x * blockDim.x)
-        wide_task29<BF>(xlist[2 + 2 * it], xlist[3 + 2 * it], entries, off, toff, pts, partial, buckets29, low, handed);
-}
-template <class BF>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(112)))
-k_acc_wide_exact(const u32* __restrict__ entries, const u32* __restrict__ off, const u32* __restrict__ toff, const u32* __restrict__ handed,
-                 const uint8_t* __restrict__ pts, uint8_t* __restrict__ partial, uint8_t* __restrict__ buckets29, u32 low) {
-    KH_HIGH_PRIO();
-    const u32 count = handed[0];
-    for (u32 it = blockIdx.x * blockDim.x + threadIdx.x; it < count; it += gridDim.x * blockDim.x) {
-        const u32 key = handed[2 + 2 * it], jt = handed[3 + 2 * it];
-        const u32 o0 = off[key], cnt = off[key + 1] - o0, t0 = toff[key], nt = toff[key + 1] - t0;
-        const u32 start = o0 + (u32)(((u64)jt * cnt) / nt), end = o0 + (u32)(((u64)(jt + 1) * cnt) / nt);
-        u32 e = entries[start];
-        Aff<BF> p = Aff<BF>::load(pts + (size_t)(e & 0x7fffffffu) * 64);
-        if (e >> 31) p.y = neg<BF>(p.y);
-        Xyzz<BF> acc = Xyzz<BF>::from_affine(p);
-        for (u32 k = start + 1; k < end; k++) {
-            e = entries[k];
-            p = Aff<BF>::load(pts + (size_t)(e & 0x7fffffffu) * 64);
-            acc = madd<BF>(acc, p, (e >> 31) != 0);
-        }
-        if (nt == 1) {
-            uint8_t* const rec = buckets29 + (size_t)wide_true_bucket(key, low) * B29_BYTES;
-            if (acc.is_identity()) store_b29_identity<BF>(rec); else store_b29<BF>(rec, xyzz_to29<BF>(acc));
-        } else acc.store(partial + (size_t)(t0 + jt) * 128);
+    const u32 nx = xlist[0], nh = handed[0];
+    for (u32 it = blockIdx.x * blockDim.x + threadIdx.x; it < nx; it += gridDim.x * blockDim.x) {
+        const u32 key = xlist[2 + 2 * it], jt = xlist[3 + 2 * it];
+        if (!wide_task29<BF>(key, jt, entries, off, toff, pts, partial, buckets29, low, nullptr))
+            wide_task_exact<BF>(key, jt, entries, off, toff, pts, partial, buckets29, low);
     }
+    for (u32 it = blockIdx.x * blockDim.x + threadIdx.x; it < nh; it += gridDim.x * blockDim.x)
+        wide_task_exact<BF>(handed[2 + 2 * it], handed[3 + 2 * it], entries, off, toff, pts, partial, buckets29, low);
 }
 // ------------------------------------------------------------------------------------ 6 bucket sums
 // buckets with more partials than this go to the wave-per-bucket tree (k_bucket_big); the threshold is a
@@ -1472,8 +1481,8 @@ k_marginal_fin_q(const uint8_t* __restrict__ marg, MargGeom g, uint8_t* __restri
 //     sum_t (t + 1) B_t  =  2^lo  sum_a a H_a  +  sum_b (b + 1) L_b,      H_a = sum_b B_(a,b),   L_b = sum_a B_(a,b)
 // -- every bucket goes into ONE hi-digit and ONE lo-digit marginal: 2 x 2^19 full additions, all of them in the lazy 29-bit arithmetic
 // (add29: ~1.4 mixed additions each), then 2^hi + 2^lo = 1536 marginals take the 5-bit digit-marginal tail of the narrow path.
-//   k_bucket_sum_wide  the split buckets of pass B's list (exact sum of the wire partials; hot ones: the two-phase big-bucket kernels, then
-//                      k_big_to29); empty buckets got their identity record from pass B, all others ARE a task's output
+//   k_bucket_sum_wide  the split buckets of pass B's list (exact sum of the wire partials; hot ones by the whole block, lane-cooperatively);
+//                      empty buckets got their identity record from pass B, all others ARE a task's output
 //   k_wide_a1          thread (plane, marginal, chunk): the sum of r = 8 buckets, sequentially, B29 in -> B29 out (2^17 threads; plane 0 reads
 //                      r consecutive records, plane 1 a column: neighbouring lanes read neighbouring records).  A thread whose add29 cannot
 //                      exclude an exceptional case writes a marker record; k_wide_a2 redoes such a chunk with the exact formulas.
@@ -1482,40 +1491,63 @@ k_marginal_fin_q(const uint8_t* __restrict__ marg, MargGeom g, uint8_t* __restri
 //                      buckets for k_marginals_q / k_marginal_fin_q -- group 0 holds H_a at slot a - 1 (weight a; H_0 has weight 0 and is
 //                      dropped, slots >= 2^hi - 1 are the identity), group 1 holds L_b at slot b.
 struct WideGeom { u32 nb, lo, hi, rlog; };
-// split buckets only (slist: pass B's list of buckets with more than one task; count in xlist[1]): a small persistent grid
+// split buckets only (slist: pass B's list of buckets with more than one task; count in xlist[1]), ONE launch (round 6; until then this kernel listed the hot
+// buckets for k_bucket_chunk / k_bucket_big and k_big_to29 converted their sums: three more empty dependent launches for unskewed scalars).
+//   (1) a thread sums a bucket of up to SMALL_NT partials by itself (2^22 uniform scalars: 16 K buckets of two partials);
+//   (2) the hot buckets are on a list of their own (pass B wrote it: big[0] = count, big[2 + i] = key, big[2 + cap + i] = 0).  EVERY wave of the grid walks that
+//       list and takes a strided share of every bucket's chunks of CHUNK partials (one bucket may hold all 2^20 entries of a window: 32 K partials at K = 32 --
+//       a single block on it took 3.2 ms): 16 quads, lane-cooperative additions (coop.cuh), 8 sequential + 4 tree levels per chunk, the chunk's sum to
+//       chunk_out.  The wave that brings a bucket's LAST chunk in (a counter per bucket, fenced on both sides) adds the chunk sums up and writes the B29 record:
+//       no second kernel, no grid barrier.
 template <class BF>
 __global__ void __launch_bounds__(256)
 k_bucket_sum_wide(const u32* __restrict__ toff, const u32* __restrict__ xlist, const u32* __restrict__ slist, const uint8_t* __restrict__ partial,
-                  uint8_t* __restrict__ buckets29, u32 low, u32* __restrict__ big, size_t cap, u32 SMALL_NT) {
+                  uint8_t* __restrict__ buckets29, u32 low, u32 SMALL_NT, u32* __restrict__ big, u32 cap, uint8_t* __restrict__ chunk_out) {
     KH_HIGH_PRIO();
-    const u32 count = xlist[1];
+    __shared__ __attribute__((aligned(16))) uint8_t total[4 * 128];
+    const u32 count = xlist[1], nhot = big[0];
     for (u32 it = blockIdx.x * blockDim.x + threadIdx.x; it < count; it += gridDim.x * blockDim.x) {
         const u32 key = slist[it];
         const u32 t0 = toff[key], nt = toff[key + 1] - t0;
-        if (nt > SMALL_NT) {
-            u32 nch = (nt + CHUNK - 1) / CHUNK;
-            u32 slot = atomicAdd(&big[0], 1u);
-            u32 cbase = atomicAdd(&big[1], nch);
-            big[2 + slot] = key; big[2 + cap + slot] = cbase;
-            for (u32 j = 0; j < nch; j++) { big[2 + 2 * cap + cbase + j] = key; big[2 + 3 * cap + cbase + j] = j; }
-            continue;
-        }
+        if (nt > SMALL_NT) continue;
         Xyzz<BF> acc = Xyzz<BF>::load(partial + (size_t)t0 * 128);
         for (u32 k = 1; k < nt; k++) acc = add<BF>(acc, Xyzz<BF>::load(partial + (size_t)(t0 + k) * 128));
         uint8_t* const rec = buckets29 + (size_t)wide_true_bucket(key, low) * B29_BYTES;
         if (acc.is_identity()) store_b29_identity<BF>(rec); else store_b29<BF>(rec, xyzz_to29<BF>(acc));
     }
-}
-template <class BF>
-__global__ void __launch_bounds__(64)
-k_big_to29(const uint8_t* __restrict__ buckets, const u32* __restrict__ big, uint8_t* __restrict__ buckets29, u32 low) {
-    KH_HIGH_PRIO();
-    const u32 nbig = big[0];
-    for (u32 bi = blockIdx.x * blockDim.x + threadIdx.x; bi < nbig; bi += gridDim.x * blockDim.x) {
-        const u32 key = big[2 + bi];
-        const Xyzz<BF> v = Xyzz<BF>::load(buckets + (size_t)key * 128);
-        uint8_t* const rec = buckets29 + (size_t)wide_true_bucket(key, low) * B29_BYTES;
-        if (v.is_identity()) store_b29_identity<BF>(rec); else store_b29<BF>(rec, xyzz_to29<BF>(v));
+    if (nhot == 0) return;
+    const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u, quad = lane >> 2;
+    const u32 gw = blockIdx.x * (blockDim.x >> 6) + wave, GW = gridDim.x * (blockDim.x >> 6);
+    u32 cbase = 0;                                         // first chunk slot of bucket h: the running sum of the chunk counts (the same in every wave)
+    for (u32 h = 0; h < nhot; h++) {
+        const u32 key = big[2 + h];
+        const u32 t0 = toff[key], nt = toff[key + 1] - t0, nch = (nt + CHUNK - 1) / CHUNK;
+        for (u32 c = (gw + GW - cbase % GW) % GW; c < nch; c += GW) {      // (chunk slot cbase + c belongs to wave (cbase + c) mod GW: thirteen buckets of 256 chunks spread over all waves, not over the first 256 thirteen times)
+            const u32 lo = c * CHUNK, hi = lo + CHUNK < nt ? lo + CHUNK : nt;
+            Fe<BF> acc = quad_identity<BF>();
+            for (u32 k = lo + quad; k < hi; k += 16) acc = quad_add<BF>(acc, quad_load<BF>(partial + (size_t)(t0 + k) * 128));
+            for (int d = 8; d >= 1; d >>= 1) acc = quad_add<BF>(acc, quad_shfl_down<BF>(acc, d));
+            if (lane < 4) quad_store<BF>(chunk_out + (size_t)(cbase + c) * 128, acc);
+            __threadfence();                               // the chunk sum is visible device-wide before the arrival is counted
+            u32 arrived = 0;
+            if (lane == 0) arrived = __hip_atomic_fetch_add(&big[2 + cap + h], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+            arrived = __shfl(arrived, 0, 64);
+            if (arrived == nch) {                          // (wave-uniform) last one in: add up the chunk sums
+                __threadfence();
+                Fe<BF> o = quad_identity<BF>();
+                for (u32 k = quad; k < nch; k += 16) o = quad_add<BF>(o, quad_load<BF>(chunk_out + (size_t)(cbase + k) * 128));
+                for (int d = 8; d >= 1; d >>= 1) o = quad_add<BF>(o, quad_shfl_down<BF>(o, d));
+                if (lane < 4) quad_store<BF>(total + 128 * wave, o);
+                __builtin_amdgcn_wave_barrier();
+                if (lane == 0) {
+                    const Xyzz<BF> v = Xyzz<BF>::load(total + 128 * wave);
+                    uint8_t* const rec = buckets29 + (size_t)wide_true_bucket(key, low) * B29_BYTES;
+                    if (v.is_identity()) store_b29_identity<BF>(rec); else store_b29<BF>(rec, xyzz_to29<BF>(v));
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        cbase += nch;
     }
 }
 // work item `out` of a group (the index of its output record): first bucket and bucket stride of its chunk
@@ -1958,7 +1990,7 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
         if ((rc = exclusive_scan_u32(C.ws_hist.as<u32>(), C.ws_cnt.as<u32>(), part_size + 1, C.ws_scan_tmp, s))) return rc;
         C.timer.mark("scan", s);
         if (wide) {
-            hipLaunchKernelGGL(k_part2_scatter, pgrid, dim3(PART_T), 0, s, C.ws_digits.as<int32_t>(), tot_e, part_nblk, part_low, C.ws_cnt.as<u32>(), C.ws_mid.as<u32>(), C.ws_xlist.as<u32>());
+            hipLaunchKernelGGL(k_part2_scatter, pgrid, dim3(PART_T), 0, s, C.ws_digits.as<int32_t>(), tot_e, part_nblk, part_low, C.ws_cnt.as<u32>(), C.ws_mid.as<u32>(), C.ws_xlist.as<u32>(), C.ws_biglist.as<u32>());
             // ... and the task plan (toff, the length-ranked order, roff): partition-local in pass B, made global by k_wide_fixup
             const WideTasks wt{room, kmin, (u32)nkeys, ktab};
             u32* const slist = C.ws_xlist.as<u32>() + 2 + 2 * max_tasks;
@@ -1973,7 +2005,7 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
             if (Ctx.once("part2_attr")) KH_HIP(hipFuncSetAttribute((const void*)k_part2_sort, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
             hipLaunchKernelGGL(k_part2_sort, dim3(PART_P, (unsigned)k), dim3(PART_T), part2_lds, s, C.ws_mid.as<u32>(), C.ws_cnt.as<u32>(), part_nblk, part_low, nb, tot_e, (u32)n,
                                tab_stride, offset, basis.batch_stride, (u32)(k - 1), part_size, wt, C.ws_off.as<u32>(), C.ws_entries.as<u32>(),
-                               C.ws_toff.as<u32>(), order, ptot, C.ws_xlist.as<u32>(), slist, C.ws_b29.as<uint8_t>(), wide_og, stage_now, part2_maxpass);
+                               C.ws_toff.as<u32>(), order, ptot, C.ws_xlist.as<u32>(), slist, C.ws_b29.as<uint8_t>(), wide_og, stage_now, part2_maxpass, C.ws_biglist.as<u32>(), (u32)bigcap, WIDE_HOT_NT);
             hipLaunchKernelGGL(k_wide_fixup, dim3((unsigned)(nkeys / 256 + 1)), dim3(256), 0, s, C.ws_toff.as<u32>(), ptot, (u32)(k * PART_P), part_low, (u32)nkeys,
                                C.ws_handed.as<u32>(), C.ws_biglist.as<u32>());
         } else {
@@ -2034,10 +2066,8 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
         // (the extra chunks: none for 2^19..2^21 uniform scalars; at 2^22 the 2^14 top-window buckets hold ~360 entries against K = 256 and split in two --
         //  16 K extra chunks, for which 32 blocks took 2 ms)
         const unsigned xgrid = M / nkeys >= 64 ? 2048u : WIDE_XB;
-        hipLaunchKernelGGL((k_acc_wide_extra<BF>), dim3(xgrid), dim3(256), 0, s, C.ws_entries.as<u32>(), C.ws_off.as<u32>(), C.ws_toff.as<u32>(), C.ws_xlist.as<u32>(),
-                           (const uint8_t*)tab_pts, C.ws_partial.as<uint8_t>(), b29, part_low, C.ws_handed.as<u32>());
-        hipLaunchKernelGGL((k_acc_wide_exact<BF>), dim3(32), dim3(256), 0, s, C.ws_entries.as<u32>(), C.ws_off.as<u32>(), C.ws_toff.as<u32>(), C.ws_handed.as<u32>(),
-                           (const uint8_t*)tab_pts, C.ws_partial.as<uint8_t>(), b29, part_low);
+        hipLaunchKernelGGL((k_acc_wide_rest<BF>), dim3(xgrid), dim3(256), 0, s, C.ws_entries.as<u32>(), C.ws_off.as<u32>(), C.ws_toff.as<u32>(), C.ws_xlist.as<u32>(),
+                           C.ws_handed.as<u32>(), (const uint8_t*)tab_pts, C.ws_partial.as<uint8_t>(), b29, part_low);
     } else
     if (acc29) {
         auto kern = k_accumulate29<BF>;
@@ -2063,9 +2093,9 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
     // 6 bucket sums
     static const bool bsum_quad = !getenv("KH_NO_BSUM_QUAD");
     static const size_t bsum_maxg = getenv("KH_QUAD_MAXG") ? (size_t)atol(getenv("KH_QUAD_MAXG")) : 8;     // 5 / 7 / 8 MSMs of 2^16: 0.94 / 1.09 / 1.14 -> 0.85 / 1.05 / 1.09 ms against 4
-    if (wide)
-        hipLaunchKernelGGL((k_bucket_sum_wide<BF>), dim3(32), dim3(256), 0, s, C.ws_toff.as<u32>(), C.ws_xlist.as<u32>(), C.ws_xlist.as<u32>() + 2 + 2 * max_tasks,
-                           C.ws_partial.as<uint8_t>(), b29, part_low, C.ws_biglist.as<u32>(), bigcap, 16u);
+    if (wide)                                              // (the split buckets' sums, hot ones included: one launch; 2^22: 16 K split buckets of two partials)
+        hipLaunchKernelGGL((k_bucket_sum_wide<BF>), dim3(256), dim3(256), 0, s, C.ws_toff.as<u32>(), C.ws_xlist.as<u32>(), C.ws_xlist.as<u32>() + 2 + 2 * max_tasks,
+                           C.ws_partial.as<uint8_t>(), b29, part_low, WIDE_HOT_NT, C.ws_biglist.as<u32>(), (u32)bigcap, C.ws_chunks.as<uint8_t>());
     else if (precomp && ngroups <= bsum_maxg && bsum_quad)
         hipLaunchKernelGGL((k_bucket_sum_q<BF>), dim3((unsigned)((4 * nkeys + 255) / 256)), dim3(256), 0, s,
                            C.ws_toff.as<u32>(), nkeys, C.ws_partial.as<uint8_t>(), C.ws_buckets.as<uint8_t>(), C.ws_biglist.as<u32>(),
@@ -2074,13 +2104,12 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
     hipLaunchKernelGGL((k_bucket_sum<BF>), dim3((unsigned)((nkeys + 255) / 256)), dim3(256), 0, s,
                        C.ws_toff.as<u32>(), nkeys, C.ws_partial.as<uint8_t>(), C.ws_buckets.as<uint8_t>(), C.ws_biglist.as<u32>(),
                        bigcap, nkeys <= 16384 ? 4u : 16u, abort_dev);
-    if (!(spread && !wide && precomp && ngroups <= bsum_maxg && bsum_quad)) {      // (the quad kernel took every bucket: nothing was listed)
+    if (!wide && !(spread && precomp && ngroups <= bsum_maxg && bsum_quad)) {     // (the quad kernel took every bucket: nothing was listed; the wide path's kernel sums its hot buckets itself)
     hipLaunchKernelGGL((k_bucket_chunk<BF>), dim3(2048), dim3(64), 0, s,
                        C.ws_toff.as<u32>(), C.ws_partial.as<uint8_t>(), C.ws_biglist.as<u32>(), bigcap, C.ws_chunks.as<uint8_t>(), abort_dev);
     hipLaunchKernelGGL((k_bucket_big<BF>), dim3(1024), dim3(256), 0, s,
                        C.ws_toff.as<u32>(), C.ws_chunks.as<uint8_t>(), C.ws_buckets.as<uint8_t>(), C.ws_biglist.as<u32>(), bigcap, abort_dev);
     }
-    if (wide) hipLaunchKernelGGL((k_big_to29<BF>), dim3(16), dim3(64), 0, s, C.ws_buckets.as<uint8_t>(), C.ws_biglist.as<u32>(), b29, part_low);
     C.timer.mark("bucket_sum", s);
     // 7 reduce
     u32* const done_ws = flag_on ? C.ws_done.as<u32>() : nullptr; u32* const done_flag = flag_on ? (u32*)C.done_flag : nullptr;

@@ -4,7 +4,7 @@ two-plane bucket reduction), bit-exact against the C oracle.  By default the pat
 every branch runs in seconds: the five scalar distributions of config 2 at 2^14 on both curves, batches of two, an MSM
 over a window of a longer basis, and the degenerate bases (one point repeated, two points, P / -P pairs) whose equal-point
 doublings and cancellations force the hand-over lists of the lazy accumulation AND of the lazy reduction (add29 ->
-k_wide_a1_exact), the split / hot bucket kernels and k_big_to29.  Reference behaviour: the MSM of
+k_wide_a1_exact) and the split / hot bucket branches of k_acc_wide_rest / k_bucket_sum_wide.  Reference behaviour: the MSM of
 poly-commitment/src/ipa.rs:638-683 / commitment.rs:350-394 is a unique group element whatever the window width."""
 import os
 
