@@ -1805,6 +1805,10 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
     // may ask for: where the request cannot hold the count down the kernel simply runs at its register-limited occupancy
     size_t wide_acc_lds = wide_acc_blocks >= 4 ? 0 : (Ctx.lds_per_cu / (wide_acc_blocks + 1) + 1024) & ~(size_t)1023;
     if (wide_acc_lds > Ctx.lds_per_block) wide_acc_lds = Ctx.lds_per_block & ~(size_t)1023;
+    // the narrow accumulation held to fewer blocks per CU the same way (KH_ACC_BLOCKS, experiment: room for the latency kernels of OTHER provers' chains; 0 = no limit)
+    static const unsigned acc_blocks = getenv("KH_ACC_BLOCKS") ? (unsigned)atoi(getenv("KH_ACC_BLOCKS")) : 0u;
+    size_t acc_lds = (acc_blocks == 0 || acc_blocks >= 4) ? 0 : (Ctx.lds_per_cu / (acc_blocks + 1) + 1024) & ~(size_t)1023;
+    if (acc_lds > 65536) acc_lds = 65536;
     if (wide) {
         // k_part2_sort interleaves `og` consecutive ranks of a partition: og must divide the 2^low buckets of a partition; k_wide_a1 / _a2 cut both digit
         // planes into chunks of 2^rlog buckets: rlog <= min(lo, hi)
@@ -2072,12 +2076,12 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
     if (acc29) {
         auto kern = k_accumulate29<BF>;
         if (C.timer.enabled && C.timer.created && !gcap.active) {     // the dominant kernel's own start / stop timestamps (bench.py roofline)
-            hipExtLaunchKernelGGL(kern, agrid, dim3(256), 0, s, C.timer.k0, C.timer.k1, 0,
+            hipExtLaunchKernelGGL(kern, agrid, dim3(256), acc_lds, s, C.timer.k0, C.timer.k1, 0,
                                   C.ws_entries.as<u32>(), C.ws_off.as<u32>(), C.ws_toff.as<u32>(), roff, order, nkeys,
                                   (const uint8_t*)tab_pts, C.ws_partial.as<uint8_t>(), C.ws_handed.as<u32>(), abort_dev, acc_prio);
             C.timer.kname = "k_accumulate29";
         } else
-        hipLaunchKernelGGL(kern, agrid, dim3(256), 0, s,
+        hipLaunchKernelGGL(kern, agrid, dim3(256), acc_lds, s,
                            C.ws_entries.as<u32>(), C.ws_off.as<u32>(), C.ws_toff.as<u32>(), roff, order, nkeys,
                            (const uint8_t*)tab_pts, C.ws_partial.as<uint8_t>(), C.ws_handed.as<u32>(), abort_dev, acc_prio);
     } else if (C.timer.enabled && C.timer.created && !gcap.active) {

@@ -408,6 +408,8 @@ int kh_prove_full(kh_prover_index_t* ix, const uint64_t* witness, size_t rows, c
         return rc_;
     };
     size_t cols_pending = 0;                           // first column whose interpolation / extension is not queued yet
+    static const bool commit_per_group = getenv("KH_PROVE_COMMIT_PER_GROUP") && atoi(getenv("KH_PROVE_COMMIT_PER_GROUP")) != 0;
+    size_t commit_groups = 0, group_c0[4] = {0, 0, 0, 0};
     if (witness) {
         KP_REQUIRE(rows + zk <= n, "NoRoomForZkInWitness: %zu rows + %zu zero-knowledge rows > %zu", rows, zk, n);
         if (rows + zk < n) KP(kh_dev_memset_zero(ev.p, 16 * NB * 32));
@@ -423,6 +425,10 @@ int kh_prove_full(kh_prover_index_t* ix, const uint64_t* witness, size_t rows, c
             if (groups > 1) KP(kh_dev_upload_2d_unordered(ev.at(c0 * NB), NB * 32, witness + 4 * c0 * rows, rows * 32, rows * 32, c1 - c0));
             else KP(kh_dev_upload_2d(ev.p, NB * 32, witness, rows * 32, rows * 32, COLUMNS));
             if (g + 1 < groups) { KP(interpolate_extend(c0, c1)); cols_pending = c1; }
+            // KH_PROVE_COMMIT_PER_GROUP=1 (experiment): the group's share of the witness commitment behind its transfer as well (a batch of its own)
+            if (commit_per_group && groups > 1 && groups <= 3) {
+                KP(kh_msm_submit(srs, (int)logn, 0, 0, ev.at(c0 * NB), n, c1 - c0, 1, &tickets.t[g])); tickets.live[g] = true; group_c0[g] = c0; group_c0[g + 1] = c1; commit_groups = g + 1;
+            }
         }
     } else KP(kh_dev_copy(ev.p, witness_dev, COLUMNS * NB * 32));
     mark();
@@ -469,12 +475,15 @@ int kh_prove_full(kh_prover_index_t* ix, const uint64_t* witness, size_t rows, c
     auto set_const = [&](uint64_t* dst, const fe& val) { return kh_dev_fill_elements(dst, val.l, 1); };    // *dst = val, queued on the main stream
     // ---- witness commitments: one batched MSM per chunk of the Lagrange basis, queued before the columns are interpolated
     uint64_t& tk = tickets.t[3]; bool& have_tk = tickets.live[3];
-    if (nch == 1) { KP(kh_msm_submit(srs, (int)logn, 0, 0, ev.p, n, COLUMNS, 1, &tk)); have_tk = true; }
+    if (nch == 1 && !commit_groups) { KP(kh_msm_submit(srs, (int)logn, 0, 0, ev.p, n, COLUMNS, 1, &tk)); have_tk = true; }
     KP(interpolate_extend(cols_pending, COLUMNS));
     std::vector<uint64_t> wxy, wbx; std::vector<uint8_t> winf, wbi;
     const fe* w_blind = draw(COLUMNS * nch);          // blinder(num_chunks) per column, column by column (prover.rs:316-327)
     KP(blinding_points(w_blind, COLUMNS * nch, wbx, wbi));              // (underneath the MSM)
-    if (have_tk) { wxy.resize(8 * COLUMNS); winf.resize(COLUMNS); KP(tickets.wait(3, wxy.data(), winf.data())); }
+    if (commit_groups) {
+        wxy.resize(8 * COLUMNS); winf.resize(COLUMNS);
+        for (size_t g = 0; g < commit_groups; g++) KP(tickets.wait((int)g, &wxy[8 * group_c0[g]], &winf[group_c0[g]]));
+    } else if (have_tk) { wxy.resize(8 * COLUMNS); winf.resize(COLUMNS); KP(tickets.wait(3, wxy.data(), winf.data())); }
     else KP(commit_evals(ev.p, COLUMNS, wxy, winf));
     std::vector<uint64_t> wcx; std::vector<uint8_t> wci;
     KP(mask_with(wxy, winf, wbx, wbi, wcx, wci));

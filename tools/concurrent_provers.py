@@ -34,11 +34,20 @@ def run(t):
     bar.wait()
 
 
+def cpu_stat():
+    try:
+        d = dict(l.split() for l in open("/sys/fs/cgroup/cpu.stat"))
+        return int(d.get("throttled_usec", 0)), int(d.get("usage_usec", 0)), int(d.get("nr_throttled", 0))
+    except OSError:
+        return 0, 0, 0
+
+
 for rep in range(3):
     th = [threading.Thread(target=run, args=(t,)) for t in range(T)]
     for t_ in th:
         t_.start()
-    bar.wait(); t0 = time.perf_counter(); bar.wait(); dt = time.perf_counter() - t0
+    bar.wait(); c0 = cpu_stat(); t0 = time.perf_counter(); bar.wait(); dt = time.perf_counter() - t0; c1 = cpu_stat()
     for t_ in th:
         t_.join()
-    print(f"{T} provers in flight, {per} proofs each: {T * per / dt:.1f} proofs/s", flush=True)
+    print(f"{T} provers in flight, {per} proofs each: {T * per / dt:.1f} proofs/s   (host: {(c1[1] - c0[1]) / 1e6 / dt:.1f} cores busy on average, "
+          f"cgroup throttled {c1[2] - c0[2]} times / {(c1[0] - c0[0]) / 1e3:.1f} ms in {dt * 1e3:.0f} ms)", flush=True)
