@@ -635,13 +635,14 @@ int kh_prove_full(kh_prover_index_t* ix, const uint64_t* witness, size_t rows, c
             tok(dt, KH_TOK_CELL, 2 * i); tok(dt, KH_TOK_CELL, 2 * (7 + i)); tok(dt, KH_TOK_CONST, 1); tok(dt, KH_TOK_MUL, 0); tok(dt, KH_TOK_ADD, 0);
             tok(dt, KH_TOK_CONST, 0); tok(dt, KH_TOK_ADD, 0); if (i) tok(dt, KH_TOK_MUL, 0);
         }
-        KP(set_const(num.p, one)); KP(set_const(den.p, one));
-        KP(kh_expr_evaluations_dev(fid, nt.data(), nt.size() / 2, cols, lens, 15, (const uint64_t*)consts, 9, n - 1, 1, 8, 0, num.at(1)));
-        KP(kh_expr_evaluations_dev(fid, dt.data(), dt.size() / 2, cols, lens, 15, (const uint64_t*)consts, 9, n - 1, 1, 8, 0, den.at(1)));
-        KP(kh_batch_inversion_dev(fid, den.at(1), n - 1));
+        // z_0 = 1, z_(i+1) = z_i num_i / den_i: the quotients of rows 0 .. n-2 go to z's rows 1 .. n-1 and the running product does the rest
+        KP(kh_expr_evaluations_dev(fid, nt.data(), nt.size() / 2, cols, lens, 15, (const uint64_t*)consts, 9, n - 1, 1, 8, 0, num.p));
+        KP(kh_expr_evaluations_dev(fid, dt.data(), dt.size() / 2, cols, lens, 15, (const uint64_t*)consts, 9, n - 1, 1, 8, 0, den.p));
+        KP(kh_batch_inversion_dev(fid, den.p, n - 1));
         const uint32_t prod[6] = {KH_TOK_CELL, 0, KH_TOK_CELL, 2, KH_TOK_MUL, 0};
-        const uint64_t* pc[2] = {num.p, den.p}; const size_t pl[2] = {n, n};
-        KP(kh_expr_evaluations_dev(fid, prod, 3, pc, pl, 2, one.l, 1, n, 1, 8, 0, zcol));
+        const uint64_t* pc[2] = {num.p, den.p}; const size_t pl[2] = {n - 1, n - 1};
+        KP(set_const(zcol, one));
+        KP(kh_expr_evaluations_dev(fid, prod, 3, pc, pl, 2, one.l, 1, n - 1, 1, 8, 0, zcol + 4));
         KP(kh_field_scan_dev(fid, KH_SCAN_MUL, 0, zcol, n - zk + 1));
         if (check) { KP(kh_check_equal_dev(zcol + 4 * (n - zk), 1, one.l, chk_flags, CHK_Z)); KP(eager_check(CHK_Z)); }
         { const fe* rr = draw(2); KP(set_const(zcol + 4 * (n - zk + 1), rr[0])); KP(set_const(zcol + 4 * (n - zk + 2), rr[1])); }   // z's two random rows, in that order
