@@ -2,8 +2,8 @@
 # Collects the round's committed evidence on the GPU box (run from the repo root through gpurun): rocprofv3 kernel stats + PMC passes for the MSM and the
 # NTT workloads (tools/profile_msm.py: every PMC pass its own run, never combined with a trace), the pipelined kernel trace + timeline, the static
 # opcode mixes, the A/B of the two table sets, the PCIe-inclusive rates, and finally bench.py's line (which then finds profiles of ITS OWN build).
-# Usage: tools/collect_profiles.sh r05
-R=${1:-r05}
+# Usage: tools/collect_profiles.sh r06
+R=${1:-r06}
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 mkdir -p gpurun_out/prof
