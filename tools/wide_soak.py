@@ -50,6 +50,9 @@ while time.time() < t_end:
         srs = khip.Srs.create(cid, n_srs)
         g = srs.get_g()
     for _ in range(4):
+        # the sort's staging (round 6): the default, and settings that force several passes / straddling buckets / the fall-back at these sizes
+        stage, passes = [(28672, 2), (2560, 8), (4096, 3), (0, 2), (3000, 1), (2304, 2)][int(rng.integers(0, 6))]
+        khip.set_sort_staging(stage, passes)
         kind = ["uniform", "few", "small", "sparse", "window", "equal"][int(rng.integers(0, 6))]
         off = int(rng.integers(0, n_srs - 4096 + 1))
         n = int(rng.integers(4096, n_srs - off + 1))
@@ -62,7 +65,8 @@ while time.time() < t_end:
         assert any(nm == "reduce_a1" for nm, _ in khip.last_timings()), "not the wide path"
         for j in range(k):
             want, winf = cref.msm(cid, g[off:off + n], sc[j * n:(j + 1) * n], scalars_mont=mont, threads=16)
-            assert bool(ginf[j]) == bool(winf) and (winf or np.array_equal(got[j], want)), (cid, n_srs, kind, off, n, k, j, mont)
+            assert bool(ginf[j]) == bool(winf) and (winf or np.array_equal(got[j], want)), (cid, n_srs, kind, off, n, k, j, mont, stage, passes)
         runs += 1
     srs.close()
+khip.set_sort_staging()
 print(f"wide soak: {runs} MSMs bit-exact")
