@@ -1873,10 +1873,8 @@ int kh_ipa_round_lr(kh_ipa_t* st, const uint64_t rand_l[4], const uint64_t rand_
         uint32_t* const lists = srs->ipa_rb_lists.as<uint32_t>();
         if (ok) ok = rebase_points(rs, st->curve, st->coef[st->pp].as<uint64_t>(), Q, srs->g.p, srs->g_stride, N, srs->ipa_rb_B.p, srs->ipa_rb_part.p, lists,
                                    srs->ipa_rb_snap) == KH_OK;                   // (ipa_rb_snap: behind the plan kernel, the tensor's only reader)
-        memcpy(st->hu_stage, srs->h, 64); memcpy(st->hu_stage + 8, st->u_xy, 64);
-        void* const hu_dev = (char*)srs->ipa_rb_lists.p + ((rebase_list_bytes(Q) + 63) & ~(size_t)63);
-        if (ok) ok = hipMemcpyAsync(hu_dev, st->hu_stage, 128, hipMemcpyHostToDevice, rs) == hipSuccess;
-        if (ok) ok = rebase_tables(rs, st->curve, srs->ipa_rb_part.p, N, hu_dev, 2, st->rb_c, srs->ipa_rb_scratch.p, srs->ipa_rb_tab.p, srs->ipa_rb_fail) == KH_OK;
+        memcpy(st->hu_stage, srs->h, 64); memcpy(st->hu_stage + 8, st->u_xy, 64);       // (H | U travel in the table kernel's arguments: rebase.hip, RbExtra)
+        if (ok) ok = rebase_tables(rs, st->curve, srs->ipa_rb_part.p, N, st->hu_stage, 2, st->rb_c, srs->ipa_rb_scratch.p, srs->ipa_rb_tab.p, srs->ipa_rb_fail) == KH_OK;
         if (ok) ok = hipEventRecord(srs->ipa_rb_done, rs) == hipSuccess;
         if (ok) { st->rb_state = 2; counter(CNT_REBASE_LAUNCH)++; }
         else { (void)hipGetLastError(); (void)hipStreamSynchronize(rs); st->rb_state = -1; counter(CNT_REBASE_ABANDON)++; }
@@ -2074,7 +2072,7 @@ int kh_ipa_open(kh_srs_t* srs, const uint64_t* a_dev, size_t a_len, const uint64
     struct Guard { kh_ipa_t* s; ~Guard() { kh_ipa_free(s); } } guard{st};
     khost::fe r_prime = fe_of(blinding_factor);
     const auto tp1 = std::chrono::steady_clock::now();
-    double t_lr = 0, t_sponge = 0, t_fold = 0;
+    double t_lr = 0, t_sponge = 0, t_fold = 0, per_round_us[32] = {0};
     static const bool sg_split = getenv("KH_NO_SG_SPLIT") == nullptr;
     uint64_t u_last[4] = {0, 0, 0, 0}, chal_last[2] = {0, 0};
     for (size_t r = 0; r < rounds; r++) {
@@ -2091,6 +2089,7 @@ int kh_ipa_open(kh_srs_t* srs, const uint64_t* a_dev, size_t a_len, const uint64
         memcpy(u_last, u, 32); chal_last[0] = chal[0]; chal_last[1] = chal[1];
         if (ipa_timing) {
             const auto q3 = std::chrono::steady_clock::now();
+            if (r < 32) per_round_us[r] = std::chrono::duration<double, std::micro>(q1 - q0).count();
             t_lr += std::chrono::duration<double, std::micro>(q1 - q0).count(); t_sponge += std::chrono::duration<double, std::micro>(q2 - q1).count();
             t_fold += std::chrono::duration<double, std::micro>(q3 - q2).count();
         }
@@ -2134,6 +2133,8 @@ int kh_ipa_open(kh_srs_t* srs, const uint64_t* a_dev, size_t a_len, const uint64
         { const IpaRoundProf P = tl_round_prof; tl_round_prof = IpaRoundProf();
           fprintf(stderr, "kh_ipa_open: per round inside launch + wait + finish: slot %.1f us, step kernel launch %.1f, MSM enqueue %.1f, wait %.1f, finish %.1f\n",
                   P.slot / rounds, P.step / rounds, P.enqueue / rounds, P.wait / rounds, P.finish / rounds); }
+        { char line[512]; int o = 0; for (size_t r = 0; r < rounds && r < 32; r++) o += snprintf(line + o, sizeof line - o, " %.0f", per_round_us[r]);
+          fprintf(stderr, "kh_ipa_open: launch + wait + finish per round, us:%s\n", line); }
         fprintf(stderr, "kh_ipa_open: begin %.0f us (of which shift + squeeze + to_group %.0f), %zu rounds %.0f us (per round: launch + wait + finish %.0f, sponge %.0f, to_field + inverse %.0f), sg %.0f us, delta / z1 / z2 %.0f us\n",
                 us(tp0, tp1), us(tp0, tp_map), rounds, us(tp1, tp2), t_lr / rounds, t_sponge / rounds, t_fold / rounds, us(tp2, tp3), us(tp3, std::chrono::steady_clock::now()));
     }

@@ -24,7 +24,7 @@ int msm_precompute_on(hipStream_t s, int curve, void* tables, size_t n, int c, v
 int rebase_points(hipStream_t s, int curve, const uint64_t* coef, size_t Q, const void* tables, size_t stride, size_t N, void* B, void* part, void* lists,
                   hipEvent_t after_plan = nullptr);
 const void* rebase_outputs(const void* part, size_t N);          // the N materialised points (XYZZ, 128 bytes each) inside `part`
-int rebase_tables(hipStream_t s, int curve, const void* part, size_t N, const void* extra_affine, size_t extra, int c, void* scratch, void* tables, uint32_t* fail);
+int rebase_tables(hipStream_t s, int curve, const void* part, size_t N, const void* extra_affine_host, size_t extra, int c, void* scratch, void* tables, uint32_t* fail);
 size_t rebase_bucket_bytes(size_t N);
 size_t rebase_part_bytes(size_t N);
 size_t rebase_list_bytes(size_t Q);

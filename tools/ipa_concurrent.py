@@ -1,7 +1,7 @@
 """Throughput of the opening loop with T provers in flight (one host thread and one SRS handle each), 2^16."""
 import sys, time, threading
 import numpy as np
-sys.path.insert(0, '.')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from proof_systems_amd import khip
 khip.init(0)
 n = 1 << 16

@@ -1,7 +1,7 @@
 """Times the device-resident opening loop (kh_ipa_*) at 2^16 on Vesta: per-round wall time and the MSM phases."""
-import sys, time
+import os, sys, time
 import numpy as np
-sys.path.insert(0, '.')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from proof_systems_amd import khip
 khip.init(0)
 logn = int(sys.argv[1]) if len(sys.argv) > 1 else 16

@@ -38,3 +38,6 @@ if "--native" in sys.argv or os.environ.get("KH_TIME_NATIVE"):      # the same p
             if best is None or t["total"] < best["total"]:
                 best = t
         print(f"native check={check}: " + "  ".join(f"{k} {1e3 * v:.2f} ms" for k, v in best.items()), f" -> {(1 << logn) / best['total'] / 1e6:.2f} M constraints/s")
+    sw = khip.counter("rebase_switch")
+    if sw:
+        print(f"opening rounds over the folded basis: {khip.counter('rebased_rounds') / sw:.2f} per opening that switched ({sw} of {khip.counter('rebase_launch')} launched; {khip.counter('rebase_abandon')} abandoned)")
