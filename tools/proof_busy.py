@@ -57,11 +57,23 @@ def main():
     pre = rows[start_i:first_step]
     pre_busy, pre_gaps = union_busy(pre)
     pre_wall = (rows[first_step][1] - t0) / 1e3
+    # the same stretch counted from the witness commitment's first kernel: since round 6 the proof's first kernels (the first column groups' transforms) run
+    # UNDER the witness transfer, so the stretch above contains the transfer's ~0.65 ms; the commitment is queued behind the last group
+    dig = next((i for i in range(start_i, first_step) if "k_digits" in rows[i][0]), start_i)
+    post = rows[dig:first_step]
+    post_busy, post_gaps = union_busy(post)
+    post_wall = (rows[first_step][1] - rows[dig][1]) / 1e3
     out = {"source_sha256": source_hash(), "workload": "last proof of tools/prover_time.py 16 --native under rocprofv3 --kernel-trace",
            "kernels": len(proof), "wall_us": (t1 - t0) / 1e3, "busy_us": busy, "gpu_busy_frac": busy / ((t1 - t0) / 1e3),
            "pre_opening": {"wall_us": pre_wall, "busy_us": pre_busy, "idle_us": pre_wall - pre_busy, "kernels": len(pre),
                            "idle_in_gaps_under_12us": sum(g for g in pre_gaps if g < 12), "gaps_under_12us": sum(1 for g in pre_gaps if g < 12),
                            "idle_in_gaps_over_12us": sum(g for g in pre_gaps if g >= 12), "gaps_over_12us": sum(1 for g in pre_gaps if g >= 12)},
+           "pre_opening_after_transfer": {"wall_us": post_wall, "busy_us": post_busy, "idle_us": post_wall - post_busy, "kernels": len(post),
+                                          "idle_in_gaps_under_12us": sum(g for g in post_gaps if g < 12), "gaps_under_12us": sum(1 for g in post_gaps if g < 12),
+                                          "idle_in_gaps_over_12us": sum(g for g in post_gaps if g >= 12), "gaps_over_12us": sum(1 for g in post_gaps if g >= 12),
+                                          "note": "from the witness commitment's first kernel (queued behind the last column group's transfer) to the first opening round; gaps under 12 us "
+                                                  "are dispatch-sized -- under the tracer every plainly launched kernel starts ~5 us late (tools/latency/chain_gap: 1.0-1.6 us "
+                                                  "without it) --, gaps over 12 us are the host's (transcript absorbs, the batch inversion's turn, the evaluations' download)"},
            "opening": {"wall_us": (t1 - rows[first_step][1]) / 1e3, "busy_us": busy - pre_busy},
            "note": "wall = first kernel start to last kernel end of the proof (the witness upload in front and the host's last few us behind are outside); under the "
                    "profiler every launch costs the host a little more than in a plain run, so the fraction is a lower bound"}
