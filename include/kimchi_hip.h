@@ -484,6 +484,10 @@ int kh_debug_field_op(int field, int op, const uint64_t *a, const uint64_t *b, u
  * out[i] = sum_{q < Q} coef[q] * g[q N + i] for i < N = n / Q (N a multiple of 64), from the handle's c = 16 window tables; coef Montgomery, out affine.
  * *out_fail != 0: an output was the point at infinity (the rebase is then abandoned; out is incomplete). */
 int kh_debug_rebase_points(kh_srs_t *srs, const uint64_t *coef, size_t Q, uint64_t *out_xy, uint32_t *out_fail);
+/* Test hook of the GLV split the folded basis's MSMs use (csrc/msm.hip glv_split; constants: tools/gen_glv_params.py): for n CANONICAL scalars of the given
+ * scalar field, out[10 i .. 10 i + 9] = |k1| (4 x 32-bit limbs), |k2| (4), sign of k1, sign of k2 with k = k1 + k2 lambda (mod r), lambda = the scalar-field
+ * endomorphism eigenvalue of kh_endos (endo_r).  kh_scalar_challenge_to_field's curve ids pick the field: KH_FIELD_FP = Vesta's scalars, KH_FIELD_FQ = Pallas's. */
+int kh_debug_glv_split(int scalar_field, const uint64_t *scalars, size_t n, uint32_t *out);
 /* Point ops on the device through the XYZZ formulas: op 0 = P + Q (affine in, affine out),
  * op 1 = 2P, op 2 = P + Q via the mixed addition. inf flags in/out. */
 int kh_debug_point_op(int curve, int op, const uint64_t *p_xy, const uint8_t *p_inf,

@@ -1633,6 +1633,7 @@ struct kh_ipa {
     int sg_slot = -1;                     // pipeline slot holding the two half-sums of sg launched during the last round (kh_ipa_open), -1: none
     bool sg_want = false;                 // kh_ipa_open asks the last kh_ipa_round_lr to launch them
     std::vector<hipGraphExec_t> retired;  // the previous opening's executable graphs: destroyed underneath the first round's GPU time
+    bool rb_glv = false;                          // the folded basis's tables are GLV tables (half the doubling chain; MsmBasis::glv)
     void* round_tab = nullptr; int round_c = 0;   // table set the round MSMs run over (the SRS's own, or its narrower-window second set)
     size_t tab_stride = 0;                        // points per window table of that set (the SRS's g_stride; N + 2 after the rebase)
     // Rebase (csrc/rebase.hip): after rb_j0 rounds the folded basis of rb_N = n / 2^rb_j0 points is materialised on a side stream while the rounds go on
@@ -1726,7 +1727,17 @@ static int ipa_begin_common(kh_srs_t* srs, const uint64_t* a, size_t a_len, cons
         if (rb_on && !second && srs->g_precomp_c == 16 && logn >= 9) {
             const unsigned ln = std::max(6u, std::min(rb_logn, logn - 3));
             const size_t N = (size_t)1 << ln, Q = n >> ln;
-            const int W2 = (256 + rb_c - 1) / rb_c;
+            // KH_IPA_REBASE_GLV (default on): tables for the lower 128 bits and phi of them; off when the generated constants' eigenvalue is not this curve's endo_r
+            static const bool glv_env = !(getenv("KH_IPA_REBASE_GLV") && atoi(getenv("KH_IPA_REBASE_GLV")) == 0);
+            bool glv_ok = glv_env;
+            if (glv_ok) {
+                khost::Fld SFc(khost::scalar_field_id(srs->curve));
+                khost::fe er; memcpy(&er, cached_endos(srs->curve).r, 32);
+                const khost::fe can = SFc.from_mont(er);
+                glv_ok = memcmp(can.l, msm_glv_lambda(khost::scalar_field_id(srs->curve)), 32) == 0;
+            }
+            st->rb_glv = glv_ok;
+            const int W2 = std::max((256 + rb_c - 1) / rb_c, 2 * ((128 + rb_c - 1) / rb_c));
             bool ok = srs->ipa_rb_tab.reserve((N + 2) * 64 * (size_t)W2) == KH_OK && srs->ipa_rb_B.reserve(rebase_bucket_bytes(N)) == KH_OK &&
                       srs->ipa_rb_part.reserve(rebase_part_bytes(N)) == KH_OK && srs->ipa_rb_lists.reserve(rebase_list_bytes(Q) + 256) == KH_OK &&       // (+ H | U, affine)
                       srs->ipa_rb_scratch.reserve((size_t)W2 * (N + 2) * 128) == KH_OK;
@@ -1808,7 +1819,7 @@ static void ipa_sg_prelaunch_locked(kh_ipa_t* st, Context& C, int p, bool had_fo
     if (hipStreamWaitEvent(S.stream, st->ev, 0) != hipSuccess) return;
     if (ipa_sg_split(S.stream, st->field, st->coef[p].as<uint64_t>(), st->n, had_fold ? 1 : 0, st->u_p, srs->ipa_sg.as<uint64_t>())) return;
     MsmBasis bs; bs.pts = srs->g.p; bs.inf = nullptr; bs.n = srs->n; bs.stride = srs->g_stride; bs.precomp_c = srs->g_precomp_c;
-    if (st->rb_state == 3) { bs.pts = st->round_tab; bs.n = st->n; bs.stride = st->tab_stride; bs.precomp_c = st->round_c; }     // sg = <coef_rel, g'>
+    if (st->rb_state == 3) { bs.pts = st->round_tab; bs.n = st->n; bs.stride = st->tab_stride; bs.precomp_c = st->round_c; bs.glv = st->rb_glv; }     // sg = <coef_rel, g'>
     if (msm_enqueue(C, S, st->curve, bs, 0, srs->ipa_sg.as<uint64_t>(), st->n, 2, 1)) return;
     st->sg_slot = si;
 }
@@ -1874,12 +1885,13 @@ int kh_ipa_round_lr(kh_ipa_t* st, const uint64_t rand_l[4], const uint64_t rand_
         if (ok) ok = rebase_points(rs, st->curve, st->coef[st->pp].as<uint64_t>(), Q, srs->g.p, srs->g_stride, N, srs->ipa_rb_B.p, srs->ipa_rb_part.p, lists,
                                    srs->ipa_rb_snap) == KH_OK;                   // (ipa_rb_snap: behind the plan kernel, the tensor's only reader)
         memcpy(st->hu_stage, srs->h, 64); memcpy(st->hu_stage + 8, st->u_xy, 64);       // (H | U travel in the table kernel's arguments: rebase.hip, RbExtra)
-        if (ok) ok = rebase_tables(rs, st->curve, srs->ipa_rb_part.p, N, st->hu_stage, 2, st->rb_c, srs->ipa_rb_scratch.p, srs->ipa_rb_tab.p, srs->ipa_rb_fail) == KH_OK;
+        if (ok) ok = rebase_tables(rs, st->curve, srs->ipa_rb_part.p, N, st->hu_stage, 2, st->rb_c, srs->ipa_rb_scratch.p, srs->ipa_rb_tab.p, srs->ipa_rb_fail,
+                                   st->rb_glv ? cached_endos(st->curve).q : nullptr) == KH_OK;
         if (ok) ok = hipEventRecord(srs->ipa_rb_done, rs) == hipSuccess;
         if (ok) { st->rb_state = 2; counter(CNT_REBASE_LAUNCH)++; }
         else { (void)hipGetLastError(); (void)hipStreamSynchronize(rs); st->rb_state = -1; counter(CNT_REBASE_ABANDON)++; }
     }
-    MsmBasis bs; bs.pts = st->round_tab; bs.inf = nullptr; bs.n = st->tab_stride; bs.stride = st->tab_stride; bs.precomp_c = st->round_c;
+    MsmBasis bs; bs.pts = st->round_tab; bs.inf = nullptr; bs.n = st->tab_stride; bs.stride = st->tab_stride; bs.precomp_c = st->round_c; bs.glv = st->rb_state == 3 && st->rb_glv;
     // Plain launches by default since round 5: the round's MSM is down to six launches (digits, one-launch sort, accumulation, bucket sums, two reduction
     // kernels) which the host queues in ~25 us while the step kernel runs; replaying a captured graph (KH_IPA_GRAPH=1, rounds 2-4's way: every opening
     // captures afresh in its second round) measured 5.58 / 5.53 / 5.65 ms per opening against 5.49 / 5.47 / 5.51 plain, alternated on one box.
@@ -1942,7 +1954,7 @@ static int ipa_finish_impl(kh_ipa_t* st, uint64_t a0[4], uint64_t b0[4], uint64_
     KH_HIP(hipMemcpyAsync(b0, st->b[p].p, 32, hipMemcpyDeviceToHost, S.stream));
     kh_srs_t* srs = st->srs;
     MsmBasis bs; bs.pts = srs->g.p; bs.inf = nullptr; bs.n = srs->n; bs.stride = srs->g_stride; bs.precomp_c = srs->g_precomp_c;
-    if (st->rb_state == 3) { bs.pts = st->round_tab; bs.n = st->n; bs.stride = st->tab_stride; bs.precomp_c = st->round_c; }     // sg = <coef_rel, g'>
+    if (st->rb_state == 3) { bs.pts = st->round_tab; bs.n = st->n; bs.stride = st->tab_stride; bs.precomp_c = st->round_c; bs.glv = st->rb_glv; }     // sg = <coef_rel, g'>
     if (!sg_xy) { KH_HIP(hipStreamSynchronize(S.stream)); return KH_OK; }
     if ((rc = msm_enqueue(C, S, st->curve, bs, 0, st->coef[p].as<uint64_t>(), st->n, 1, 1))) return rc;   // sg = <coef, G>
     return wait_then_finish(lk, C, S, sg_xy, sg_inf);
@@ -2479,6 +2491,21 @@ int kh_debug_rebase_points(kh_srs_t* srs, const uint64_t* coef, size_t Q, uint64
     if ((rc = rebase_tables(C.stream, srs->curve, part.p, N, nullptr, 0, 256, scratch.p, out.p, fail.as<uint32_t>()))) return rc;      // (c = 256: one level = the points themselves, affine)
     KH_HIP(hipMemcpyAsync(out_xy, out.p, N * 64, hipMemcpyDeviceToHost, C.stream));
     KH_HIP(hipMemcpyAsync(out_fail, fail.p, 4, hipMemcpyDeviceToHost, C.stream));
+    KH_HIP(hipStreamSynchronize(C.stream));
+    return KH_OK;
+}
+int kh_debug_glv_split(int scalar_field, const uint64_t* scalars, size_t n, uint32_t* out) {
+    KH_REQUIRE(scalar_field == KH_FIELD_FP || scalar_field == KH_FIELD_FQ, "unknown field id %d", scalar_field);
+    KH_REQUIRE(scalars && out, "kh_debug_glv_split: null argument");
+    int rc = ensure_init(); if (rc) return rc;
+    if (n == 0) return KH_OK;
+    Context& C = ctx();
+    std::lock_guard<std::mutex> lk(C.mu);
+    DevBuf din, dout;
+    if ((rc = din.reserve(n * 32)) || (rc = dout.reserve(n * 40))) return rc;
+    KH_HIP(hipMemcpyAsync(din.p, scalars, n * 32, hipMemcpyHostToDevice, C.stream));
+    if ((rc = msm_debug_glv_split(C.stream, scalar_field, din.as<uint64_t>(), n, dout.as<uint32_t>()))) return rc;
+    KH_HIP(hipMemcpyAsync(out, dout.p, n * 40, hipMemcpyDeviceToHost, C.stream));
     KH_HIP(hipStreamSynchronize(C.stream));
     return KH_OK;
 }

@@ -138,7 +138,7 @@ struct MsmSlot {
     uint32_t done_expect = 0;                          // launches enqueued with the flag so far (what done_flag shows when the newest one has ended)
     bool done_by_flag = false, g_done_by_flag = false; // the job in flight (the captured graph) ends with the flag store
     bool fused_used = false, g_fused = false;
-    struct { const void* pts; const uint8_t* inf; size_t bn, stride, batch_stride; int precomp_c; size_t offset; const uint64_t* scalars; size_t n, k; int mont, curve; } retry{};
+    struct { const void* pts; const uint8_t* inf; size_t bn, stride, batch_stride; int precomp_c; size_t offset; const uint64_t* scalars; size_t n, k; int mont, curve; bool glv; } retry{};
 };
 static constexpr int MSM_SLOTS = 4;
 

@@ -151,6 +151,130 @@ __device__ __forceinline__ void emit_digits(Fe<SF> s, int mont, int c, int W, bo
         dst[(size_t)w * stride] = skip ? 0 : d;
     }
 }
+// ---- GLV split for tables that hold 2^(c w) P and phi(2^(c w) P) (the opening's folded basis, csrc/rebase.hip): k = k1 + k2 lambda (mod r), |k1|, |k2| < 2^127,
+// so the window tables need only the doublings of the lower 128 bits -- the chain that builds them is half as long.  The identity holds for ANY rounding of
+// c1, c2 (the basis vectors are lattice points: tools/gen_glv_params.py); the rounding only decides the size of k1, k2 (largest seen: 2^126.8).
+#include "glv_params.inc"
+// c = (k g + 2^383) >> 384, k of 8 limbs, g of 9: five limbs (< 2^130)
+__device__ __forceinline__ void glv_mulshift(const u32 k[8], const u32 g[9], u32 c[5]) {
+    u32 prod[17];
+#pragma unroll
+    for (int t = 0; t < 17; t++) prod[t] = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        u64 carry = 0;
+#pragma unroll
+        for (int j = 0; j < 9; j++) {
+            const u64 t = (u64)k[i] * g[j] + prod[i + j] + carry;
+            prod[i + j] = (u32)t; carry = t >> 32;
+        }
+        prod[i + 9] = (u32)carry;
+    }
+    u64 t = (u64)prod[11] + 0x80000000u;                   // + 2^383: round to nearest
+    u32 carry = (u32)(t >> 32);
+#pragma unroll
+    for (int i = 12; i < 17; i++) { t = (u64)prod[i] + carry; c[i - 12] = (u32)t; carry = (u32)(t >> 32); }
+}
+// acc (8 limbs, modulo 2^256) +/-= x (5 limbs) * y (4 limbs)
+__device__ __forceinline__ void glv_muladd(u32 acc[8], const u32 x[5], const u32 y[4], bool add) {
+    u32 p[8];
+#pragma unroll
+    for (int t = 0; t < 8; t++) p[t] = 0;
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+        u64 carry = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (i + j < 8) { const u64 t = (u64)x[i] * y[j] + p[i + j] + carry; p[i + j] = (u32)t; carry = t >> 32; }
+        }
+        if (i + 4 < 8) p[i + 4] = (u32)carry;
+    }
+    if (add) { u64 c = 0; _Pragma("unroll") for (int t = 0; t < 8; t++) { const u64 v = (u64)acc[t] + p[t] + c; acc[t] = (u32)v; c = v >> 32; } }
+    else { u64 b = 0; _Pragma("unroll") for (int t = 0; t < 8; t++) { const u64 v = (u64)acc[t] - p[t] - b; acc[t] = (u32)v; b = (v >> 32) & 1u; } }
+}
+// two's complement (8 limbs) -> magnitude (low 4 limbs; the upper four are zero for every scalar: |k_i| < 2^127) and sign
+__device__ __forceinline__ bool glv_abs(u32 v[8], u32 mag[4]) {
+    const bool neg = (v[7] >> 31) != 0;
+    if (neg) { u64 c = 1; _Pragma("unroll") for (int t = 0; t < 8; t++) { const u64 w = (u64)(~v[t]) + c; v[t] = (u32)w; c = w >> 32; } }
+#pragma unroll
+    for (int t = 0; t < 4; t++) mag[t] = v[t];
+    return neg;
+}
+template <class SF>
+__device__ __forceinline__ void glv_split(const u32 k[8], u32 k1[4], bool& n1, u32 k2[4], bool& n2) {
+    const GlvK& G = glv_k<SF>();
+    u32 g1[9], g2[9], a1[4], b1[4], a2[4], b2[4];
+#pragma unroll
+    for (int t = 0; t < 9; t++) { g1[t] = G.g1[t]; g2[t] = G.g2[t]; }
+#pragma unroll
+    for (int t = 0; t < 4; t++) { a1[t] = G.a1[t]; b1[t] = G.b1[t]; a2[t] = G.a2[t]; b2[t] = G.b2[t]; }
+    const u32 neg = G.neg;
+    const bool a1n = neg & 1u, b1n = (neg >> 1) & 1u, a2n = (neg >> 2) & 1u, b2n = (neg >> 3) & 1u, g1n = (neg >> 4) & 1u, g2n = (neg >> 5) & 1u;
+    u32 c1[5], c2[5];
+    glv_mulshift(k, g1, c1); glv_mulshift(k, g2, c2);      // |c1|, |c2|; their signs: g1n, g2n (k >= 0)
+    u32 t1[8], t2[8];
+#pragma unroll
+    for (int t = 0; t < 8; t++) { t1[t] = k[t]; t2[t] = 0; }
+    // k1 = k - c1 a1 - c2 a2: a product whose sign is negative is ADDED; k2 = -(c1 b1 + c2 b2) likewise
+    glv_muladd(t1, c1, a1, g1n != a1n); glv_muladd(t1, c2, a2, g2n != a2n);
+    glv_muladd(t2, c1, b1, g1n != b1n); glv_muladd(t2, c2, b2, g2n != b2n);
+    n1 = glv_abs(t1, k1); n2 = glv_abs(t2, k2);
+}
+// W = 2 Wh rows: Wh signed c-bit digits of k1 (rows 0 .. Wh-1, over the tables 2^(c w) P) and Wh of k2 (rows Wh .. 2 Wh - 1, over phi of them)
+template <class SF>
+__device__ __forceinline__ void emit_digits_glv(Fe<SF> s, int mont, int c, int Wh, bool skip, int32_t* __restrict__ dst, size_t stride) {
+    if (mont) s = from_mont<SF>(s);
+    else s = cond_sub_p<SF>(s.v);
+    u32 k[8], mag[2][4]; bool neg[2];
+#pragma unroll
+    for (int t = 0; t < 8; t++) k[t] = s.v[t];
+    glv_split<SF>(k, mag[0], neg[0], mag[1], neg[1]);
+    const u32 half = 1u << (c - 1), mask = (1u << c) - 1u;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        u32 l[5] = {mag[h][0], mag[h][1], mag[h][2], mag[h][3], 0u};
+        u32 carry = 0;
+        for (int w = 0; w < Wh; w++) {
+            const u32 v = (l[0] & mask) + carry;
+            int32_t d;
+            if (v > half) { d = (int32_t)v - (int32_t)(1u << c); carry = 1; } else { d = (int32_t)v; carry = 0; }
+#pragma unroll
+            for (int t = 0; t < 4; t++) l[t] = (l[t] >> c) | (l[t + 1] << (32 - c));
+            dst[(size_t)(h * Wh + w) * stride] = skip ? 0 : (neg[h] ? -d : d);
+        }
+    }
+}
+template <class SF>
+__global__ void k_digits_glv(const u64* __restrict__ scalars, const uint8_t* __restrict__ inf, size_t inf_off,
+                             size_t inf_batch, size_t n, int mont, int c, int W, int32_t* __restrict__ digits) {
+    KH_HIGH_PRIO();
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = blockIdx.y;
+    if (i >= n) return;
+    const bool skip = inf && inf[inf_off + (size_t)j * inf_batch + i];
+    emit_digits_glv<SF>(Fe<SF>::load(scalars + ((size_t)j * n + i) * 4), mont, c, W / 2, skip, digits + (size_t)j * W * n + i, n);
+}
+// test hook: the split of n canonical scalars (kh_debug_glv_split)
+template <class SF>
+__global__ void k_glv_split_test(const u64* __restrict__ scalars, size_t n, u32* __restrict__ out /* n x (4 + 4 + 2) words */) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const Fe<SF> s = Fe<SF>::load(scalars + 4 * i);
+    u32 k[8], m1[4], m2[4]; bool n1, n2;
+#pragma unroll
+    for (int t = 0; t < 8; t++) k[t] = s.v[t];
+    glv_split<SF>(k, m1, n1, m2, n2);
+#pragma unroll
+    for (int t = 0; t < 4; t++) { out[10 * i + t] = m1[t]; out[10 * i + 4 + t] = m2[t]; }
+    out[10 * i + 8] = n1 ? 1u : 0u; out[10 * i + 9] = n2 ? 1u : 0u;
+}
+int msm_debug_glv_split(hipStream_t s, int field, const uint64_t* scalars_dev, size_t n, uint32_t* out_dev) {
+    if (field == KH_FIELD_FP) hipLaunchKernelGGL((k_glv_split_test<FpParams>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, scalars_dev, n, out_dev);
+    else hipLaunchKernelGGL((k_glv_split_test<FqParams>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, scalars_dev, n, out_dev);
+    KH_HIP(hipGetLastError());
+    return KH_OK;
+}
+const uint32_t* msm_glv_lambda(int scalar_field) { return scalar_field == KH_FIELD_FP ? GLV_HOST_FP.lambda : GLV_HOST_FQ.lambda; }
 template <class SF>
 __global__ void k_digits(const u64* __restrict__ scalars, const uint8_t* __restrict__ inf, size_t inf_off,
                          size_t inf_batch, size_t n, int mont, int c, int W, int32_t* __restrict__ digits, size_t i0, size_t i1) {
@@ -1751,7 +1875,8 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
     const bool spread = spread_on && (use_graph & MSM_SPREAD_SCALARS) != 0 && !Ctx.spread_suspended;
     const void* const tab_pts = wide ? basis.wide_pts : basis.pts;
     const int c = wide ? basis.wide_c : (basis.precomp_c ? basis.precomp_c : msm_pick_window(n));
-    const int W = (256 + c - 1) / c;
+    const bool glv = basis.glv && !wide && basis.precomp_c != 0;      // rows 0 .. W/2-1: 2^(c w) P, rows W/2 .. W-1: phi of them (csrc/rebase.hip)
+    const int W = glv ? 2 * ((128 + c - 1) / c) : (256 + c - 1) / c;
     const u32 nb = 1u << (c - 1);
     const int precomp = (wide || basis.precomp_c) ? 1 : 0;
     // slices per (window, msm): enough blocks to fill the chip (~512), no more -- the per-slice histograms
@@ -1929,12 +2054,12 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
                                   (uint64_t)(uintptr_t)C.ws_buckets.p, (uint64_t)(uintptr_t)C.ws_seg.p, (uint64_t)(uintptr_t)C.ws_out.p, (uint64_t)(uintptr_t)C.ws_scan_tmp.p,
                                   (uint64_t)(uintptr_t)C.ws_biglist.p, (uint64_t)(uintptr_t)C.ws_order.p, (uint64_t)(uintptr_t)C.ws_chunks.p,
                                   (uint64_t)(uintptr_t)C.ws_handed.p, (uint64_t)(uintptr_t)C.ws_sync.p, (uint64_t)fused, (uint64_t)(uintptr_t)C.ws_mid.p, (uint64_t)part,
-                                  (uint64_t)(uintptr_t)tab_pts, (uint64_t)wide, (uint64_t)spread, (uint64_t)(uintptr_t)C.ws_xlist.p, (uint64_t)(uintptr_t)C.ws_b29.p, (uint64_t)(uintptr_t)C.ws_a1.p, (uint64_t)(uintptr_t)C.ws_a2.p, (uint64_t)(uintptr_t)C.ws_done.p, (uint64_t)flag_on, (uint64_t)(use_graph & MSM_LATENCY),
+                                  (uint64_t)(uintptr_t)tab_pts, (uint64_t)wide, (uint64_t)spread, (uint64_t)(uintptr_t)C.ws_xlist.p, (uint64_t)(uintptr_t)C.ws_b29.p, (uint64_t)(uintptr_t)C.ws_a1.p, (uint64_t)(uintptr_t)C.ws_a2.p, (uint64_t)(uintptr_t)C.ws_done.p, (uint64_t)flag_on, (uint64_t)(use_graph & MSM_LATENCY), (uint64_t)glv,
                                   ((uint64_t)sort_staging_cell(0).load() << 8) | sort_staging_cell(1).load(), DevBuf::generation().load()};
         for (uint64_t v : parts) key = fnv(key, v);
         if (C.gexec && C.gkey == key) {                    // replay
             C.fused_used = C.g_fused;
-            C.retry = {basis.pts, basis.inf, basis.n, basis.stride, basis.batch_stride, basis.precomp_c, offset, scalars_dev, n, k, mont, curve};
+            C.retry = {basis.pts, basis.inf, basis.n, basis.stride, basis.batch_stride, basis.precomp_c, offset, scalars_dev, n, k, mont, curve, basis.glv};
             // (the host's launch count moves BEFORE the launch that will move the device's: whatever fails in between, the host is never
             // behind -- a stale equality would end a later wait early -- and a host that is ahead only falls back to the event, then resyncs)
             C.spread_used = C.g_spread;
@@ -1970,7 +2095,10 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
             hipLaunchKernelGGL((k_digits<SF>), dim3((unsigned)((c1 - c0 + 255) / 256), 1u), dim3(256), 0, s,
                                scalars_dev, basis.inf, offset, basis.batch_stride, n, mont, c, W, C.ws_digits.as<int32_t>(), c0, c1);
         }
-    } else
+    } else if (glv)
+    hipLaunchKernelGGL((k_digits_glv<SF>), dim3((unsigned)((n + 255) / 256), (unsigned)k), dim3(256), 0, s,
+                       scalars_dev, basis.inf, offset, basis.batch_stride, n, mont, c, W, C.ws_digits.as<int32_t>());
+    else
     hipLaunchKernelGGL((k_digits<SF>), dim3((unsigned)((n + 255) / 256), (unsigned)k), dim3(256), 0, s,
                        scalars_dev, basis.inf, offset, basis.batch_stride, n, mont, c, W, C.ws_digits.as<int32_t>(), (size_t)0, n);
     C.timer.mark("digits", s);
@@ -2184,7 +2312,7 @@ static int msm_enqueue_t(Context& Ctx, MsmSlot& C, const MsmBasis& basis, size_t
     C.curve = curve; C.W = W; C.c = c; C.precomp = precomp; C.k = k; C.ngroups = ngroups; C.planes = (int)planes; C.plane_shift[0] = (int)mg.wd[0]; C.plane_shift[1] = (int)mg.wd[1]; C.wide_lo = wide ? (int)wg.lo : 0;
     C.fused_used = fused;
     C.spread_used = spread && !wide && precomp && ngroups <= bsum_maxg && bsum_quad;
-    C.retry = {basis.pts, basis.inf, basis.n, basis.stride, basis.batch_stride, basis.precomp_c, offset, scalars_dev, n, k, mont, curve};
+    C.retry = {basis.pts, basis.inf, basis.n, basis.stride, basis.batch_stride, basis.precomp_c, offset, scalars_dev, n, k, mont, curve, basis.glv};
     return KH_OK;
 }
 
@@ -2213,7 +2341,7 @@ int msm_finish(Context& C, MsmSlot& S, uint64_t* out_xy, uint8_t* out_inf, bool 
         counter(CNT_FUSED_RETRY)++;
         KH_HIP(hipMemsetAsync(S.ws_sync.p, 0, (2 + 2 * FUSED_B + 32 + 2) * sizeof(u32), S.stream));
         const uint64_t ticket = S.ticket; const auto owner = S.owner;
-        MsmBasis b; b.pts = S.retry.pts; b.inf = S.retry.inf; b.n = S.retry.bn; b.stride = S.retry.stride; b.batch_stride = S.retry.batch_stride; b.precomp_c = S.retry.precomp_c;
+        MsmBasis b; b.pts = S.retry.pts; b.inf = S.retry.inf; b.n = S.retry.bn; b.stride = S.retry.stride; b.batch_stride = S.retry.batch_stride; b.precomp_c = S.retry.precomp_c; b.glv = S.retry.glv;
         int rc = msm_enqueue(C, S, S.retry.curve, b, S.retry.offset, S.retry.scalars, S.retry.n, S.retry.k, S.retry.mont, 0);
         S.ticket = ticket; S.owner = owner; C.next_ticket--;
         if (rc) { S.busy = false; return rc; }
@@ -2226,7 +2354,7 @@ int msm_finish(Context& C, MsmSlot& S, uint64_t* out_xy, uint8_t* out_inf, bool 
         C.spread_suspended = true;
         counter(CNT_SPREAD_RETRY)++;
         const uint64_t ticket = S.ticket; const auto owner = S.owner;
-        MsmBasis b; b.pts = S.retry.pts; b.inf = S.retry.inf; b.n = S.retry.bn; b.stride = S.retry.stride; b.batch_stride = S.retry.batch_stride; b.precomp_c = S.retry.precomp_c;
+        MsmBasis b; b.pts = S.retry.pts; b.inf = S.retry.inf; b.n = S.retry.bn; b.stride = S.retry.stride; b.batch_stride = S.retry.batch_stride; b.precomp_c = S.retry.precomp_c; b.glv = S.retry.glv;
         int rc = msm_enqueue(C, S, S.retry.curve, b, S.retry.offset, S.retry.scalars, S.retry.n, S.retry.k, S.retry.mont, 0);
         S.ticket = ticket; S.owner = owner; C.next_ticket--;
         if (rc) { S.busy = false; return rc; }

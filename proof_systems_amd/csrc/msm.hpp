@@ -14,6 +14,7 @@ struct MsmBasis {
     size_t batch_stride = 0;         // >0: MSM j of a batch uses points [j*batch_stride, ...) (independent bases)
     const void* wide_pts = nullptr;  // a second table set of the SAME basis with wide windows (same stride), used for big single MSMs
     int wide_c = 0;
+    bool glv = false;                // the tables hold 2^(c w) P for the lower 128 bits and phi(2^(c w) P) behind them: scalars are split k = k1 + k2 lambda (rebase.hip)
 };
 
 int msm_pick_window(size_t n);
@@ -24,7 +25,10 @@ int msm_precompute_on(hipStream_t s, int curve, void* tables, size_t n, int c, v
 int rebase_points(hipStream_t s, int curve, const uint64_t* coef, size_t Q, const void* tables, size_t stride, size_t N, void* B, void* part, void* lists,
                   hipEvent_t after_plan = nullptr);
 const void* rebase_outputs(const void* part, size_t N);          // the N materialised points (XYZZ, 128 bytes each) inside `part`
-int rebase_tables(hipStream_t s, int curve, const void* part, size_t N, const void* extra_affine_host, size_t extra, int c, void* scratch, void* tables, uint32_t* fail);
+int rebase_tables(hipStream_t s, int curve, const void* part, size_t N, const void* extra_affine_host, size_t extra, int c, void* scratch, void* tables, uint32_t* fail,
+                  const uint64_t* glv_beta = nullptr);      // glv_beta (Montgomery, base field): build W/2 levels and phi of them
+int msm_debug_glv_split(hipStream_t s, int field, const uint64_t* scalars_dev, size_t n, uint32_t* out_dev);
+const uint32_t* msm_glv_lambda(int scalar_field);         // the eigenvalue the split's constants were generated for (canonical, 8 x 32-bit limbs)
 size_t rebase_bucket_bytes(size_t N);
 size_t rebase_part_bytes(size_t N);
 size_t rebase_list_bytes(size_t Q);

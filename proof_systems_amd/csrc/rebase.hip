@@ -154,6 +154,7 @@ k_rb_reduce2(const uint8_t* __restrict__ part, u32 N, uint8_t* __restrict__ out)
 //      scratch[w][i] = 2^(c w) P_i as XYZZ for w < W: c lane-cooperative doublings per level (4 product rounds each: the chain of ~250 doublings is
 //      pure latency, one lane per point measured 1.29 ms for it).  k_rb_normalize then brings every level to affine with ONE inversion per point.
 __device__ __forceinline__ void rb_setprio(int p) { if (p == 3) __builtin_amdgcn_s_setprio(3); else if (p == 2) __builtin_amdgcn_s_setprio(2); else if (p == 1) __builtin_amdgcn_s_setprio(1); }
+struct RbBeta { u64 l[4]; };
 struct RbExtra { u64 xy[2][8]; };                       // up to two extra affine points (H, U), in the kernel's ARGUMENTS: a copy from the caller's pageable memory
                                                           // queued behind the materialisation made the HOST wait for it (hipMemcpyAsync from pageable memory returns when
                                                           // the stream has reached the copy): ~1 ms of the round that launched the rebase, in every opening, until found
@@ -182,7 +183,7 @@ k_rb_tables(const uint8_t* __restrict__ outs, RbExtra hu, u32 N, u32 npts, int c
 // over the levels, as msm.hip's k_precompute does); a point at infinity has no affine form: *fail is set and the caller keeps the original basis
 template <class BF>
 __global__ void __launch_bounds__(64)
-k_rb_normalize(const uint8_t* __restrict__ scratch, u32 npts, int W, uint8_t* __restrict__ tables, u32* __restrict__ fail, int prio) {
+k_rb_normalize(const uint8_t* __restrict__ scratch, u32 npts, int W, uint8_t* __restrict__ tables, u32* __restrict__ fail, int prio, RbBeta beta, int glv) {
     rb_setprio(prio);                                      // (33 waves, one inversion deep: as k_rb_tables)
     const u32 i = blockIdx.x * 64 + threadIdx.x;
     if (i >= npts) return;
@@ -199,8 +200,13 @@ k_rb_normalize(const uint8_t* __restrict__ scratch, u32 npts, int W, uint8_t* __
         const Fe<BF> izzz = mul<BF>(iv, Fe<BF>::load(tables + ((size_t)w * npts + i) * 64));       // times the product of the levels below
         iv = mul<BF>(iv, Q.zzz);
         const Fe<BF> izz = sqr<BF>(mul<BF>(izzz, Q.zz));     // (ZZ / ZZZ)^2 = 1 / ZZ
-        mul<BF>(Q.x, izz).store(tables + ((size_t)w * npts + i) * 64);
-        mul<BF>(Q.y, izzz).store(tables + ((size_t)w * npts + i) * 64 + 32);
+        const Fe<BF> ax = mul<BF>(Q.x, izz), ay = mul<BF>(Q.y, izzz);
+        ax.store(tables + ((size_t)w * npts + i) * 64);
+        ay.store(tables + ((size_t)w * npts + i) * 64 + 32);
+        if (glv) {                                         // phi(x, y) = (beta x, y) = [lambda] (x, y): the level the second half-scalar's digits index
+            mul<BF>(ax, Fe<BF>::load(beta.l)).store(tables + ((size_t)(w + W) * npts + i) * 64);
+            ay.store(tables + ((size_t)(w + W) * npts + i) * 64 + 32);
+        }
     }
 }
 
@@ -238,9 +244,14 @@ const void* rebase_outputs(const void* part, size_t N) { return (const uint8_t*)
 // The window tables (width c) of the N materialised points and of the `extra` (<= 2) affine points `extra_affine_host` (HOST memory, 64 bytes each: H and U) behind
 // them: tables[w][i] = 2^(c w) P_i, affine, W x (N + extra) entries; scratch = W x (N + extra) x 128 bytes.  *fail != 0 afterwards: some point was the
 // identity (no affine form).
-int rebase_tables(hipStream_t s, int curve, const void* part, size_t N, const void* extra_affine_host, size_t extra, int c, void* scratch, void* tables, uint32_t* fail) {
+int rebase_tables(hipStream_t s, int curve, const void* part, size_t N, const void* extra_affine_host, size_t extra, int c, void* scratch, void* tables, uint32_t* fail,
+                  const uint64_t* glv_beta) {
     KH_REQUIRE(extra <= 2 && (extra == 0 || extra_affine_host), "rebase_tables: at most two extra points");
-    const int W = (256 + c - 1) / c;
+    // glv_beta: W = the levels built by doubling (the lower 128 bits: HALF the chain); the kernel that normalises them writes phi of every level W levels further up
+    const int glv = glv_beta ? 1 : 0;
+    const int W = glv ? (128 + c - 1) / c : (256 + c - 1) / c;
+    RbBeta beta; memset(&beta, 0, sizeof beta);
+    if (glv) memcpy(beta.l, glv_beta, 32);
     const u32 npts = (u32)(N + extra);
     static const int rb_prio = getenv("KH_IPA_REBASE_PRIO") ? atoi(getenv("KH_IPA_REBASE_PRIO")) : 0;
     RbExtra hu; memset(&hu, 0, sizeof hu);
@@ -248,10 +259,10 @@ int rebase_tables(hipStream_t s, int curve, const void* part, size_t N, const vo
     const uint8_t* outs = (const uint8_t*)rebase_outputs(part, N);
     if (curve == KH_CURVE_VESTA) {
         hipLaunchKernelGGL((k_rb_tables<FqParams>), dim3((npts + 15) / 16), dim3(64), 0, s, outs, hu, (u32)N, npts, c, W, (uint8_t*)scratch, rb_prio);
-        hipLaunchKernelGGL((k_rb_normalize<FqParams>), dim3((npts + 63) / 64), dim3(64), 0, s, (const uint8_t*)scratch, npts, W, (uint8_t*)tables, fail, rb_prio);
+        hipLaunchKernelGGL((k_rb_normalize<FqParams>), dim3((npts + 63) / 64), dim3(64), 0, s, (const uint8_t*)scratch, npts, W, (uint8_t*)tables, fail, rb_prio, beta, glv);
     } else {
         hipLaunchKernelGGL((k_rb_tables<FpParams>), dim3((npts + 15) / 16), dim3(64), 0, s, outs, hu, (u32)N, npts, c, W, (uint8_t*)scratch, rb_prio);
-        hipLaunchKernelGGL((k_rb_normalize<FpParams>), dim3((npts + 63) / 64), dim3(64), 0, s, (const uint8_t*)scratch, npts, W, (uint8_t*)tables, fail, rb_prio);
+        hipLaunchKernelGGL((k_rb_normalize<FpParams>), dim3((npts + 63) / 64), dim3(64), 0, s, (const uint8_t*)scratch, npts, W, (uint8_t*)tables, fail, rb_prio, beta, glv);
     }
     KH_HIP(hipGetLastError());
     return KH_OK;

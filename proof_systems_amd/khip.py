@@ -31,7 +31,7 @@ SYMBOLS = [
     "kh_sponge_new", "kh_sponge_clone", "kh_sponge_free", "kh_sponge_absorb_g", "kh_sponge_absorb", "kh_sponge_absorb_fr", "kh_sponge_challenge",
     "kh_sponge_challenge_field", "kh_sponge_squeeze_field", "kh_sponge_digest",
     "kh_group_map_to_group", "kh_dev_copy", "kh_dev_memset_zero", "kh_dev_fill_elements", "kh_set_phase_timers", "kh_ipa_open",
-    "kh_device_count", "kh_init", "kh_set_device", "kh_get_device", "kh_trim", "kh_srs_device", "kh_last_error", "kh_srs_create", "kh_msm_set_wide_min_n", "kh_msm_set_sort_staging", "kh_ntt_set_max_logr", "kh_debug_rebase_points", "kh_msm_submit_host", "kh_counter", "kh_srs_set_wide_tables", "kh_srs_has_wide_tables", "kh_srs_free", "kh_srs_size",
+    "kh_device_count", "kh_init", "kh_set_device", "kh_get_device", "kh_trim", "kh_srs_device", "kh_last_error", "kh_srs_create", "kh_msm_set_wide_min_n", "kh_msm_set_sort_staging", "kh_ntt_set_max_logr", "kh_debug_rebase_points", "kh_debug_glv_split", "kh_msm_submit_host", "kh_counter", "kh_srs_set_wide_tables", "kh_srs_has_wide_tables", "kh_srs_free", "kh_srs_size",
     "kh_srs_set_lagrange", "kh_srs_compute_lagrange", "kh_srs_get_lagrange", "kh_srs_lagrange_chunks",
     "kh_msm", "kh_msm_batch", "kh_msm_points", "kh_ntt", "kh_lde",
     "kh_dev_alloc", "kh_dev_free", "kh_dev_upload", "kh_dev_download", "kh_dev_upload_2d", "kh_dev_upload_2d_unordered",
@@ -250,6 +250,20 @@ def set_phase_timers(on: bool):
 def set_sort_staging(entries: int = 28672, max_passes: int = 2):
     """The wide path's staged scatter (kh_msm_set_sort_staging): entries per pass in LDS (0 = direct scatter) and the most passes a partition may take."""
     _check(_lib.kh_msm_set_sort_staging(entries, max_passes))
+
+
+def glv_split(scalar_field: int, scalars):
+    """kh_debug_glv_split: for canonical scalars (n, 4) u64 -> (|k1|, |k2|) as Python ints and their signs, k = k1 + k2 lambda (mod r)."""
+    a = np.ascontiguousarray(scalars, dtype=np.uint64)
+    n = a.shape[0]
+    out = np.zeros((n, 10), np.uint32)
+    _lib.kh_debug_glv_split.argtypes = [C.c_int, U64P, C.c_size_t, C.POINTER(C.c_uint32)]
+    _check(_lib.kh_debug_glv_split(scalar_field, _p64(a), n, out.ctypes.data_as(C.POINTER(C.c_uint32))))
+    res = []
+    for row in out:
+        m1 = sum(int(row[t]) << (32 * t) for t in range(4)); m2 = sum(int(row[4 + t]) << (32 * t) for t in range(4))
+        res.append((-m1 if row[8] else m1, -m2 if row[9] else m2))
+    return res
 
 
 def set_wide_min_n(n: int):

@@ -116,3 +116,33 @@ def test_openings_are_the_same_bytes_with_and_without_the_rebase(khip):
         assert early[k] == off[k], ("early switch", k)
         assert free[k] == off[k], ("free-running switch", k)
         assert small[k] == off[k], ("64-point basis, c = 8", k)
+
+
+@pytest.mark.parametrize("cid", [0, 1])
+def test_glv_split_of_the_folded_basis_msms(cid):
+    """The folded basis's window tables are built for 128-bit half-scalars (half the doubling chain) and the digit pass splits every scalar k = k1 + k2 lambda
+    (csrc/msm.hip glv_split, constants from tools/gen_glv_params.py): the identity modulo r and the size bound, on the device, for edge values and 200,000 random
+    scalars of both fields; lambda is the curve's endo_r (oracle.pasta.endos = poly-commitment/src/ipa.rs:214-231)."""
+    import proof_systems_amd.khip as khip
+    from oracle import cref
+    from oracle import pasta as P
+    khip.init(0)
+    curve = P.CURVES[cid]
+    r = curve.scalar.p
+    _, lam = P.endos(curve)
+    rng = np.random.default_rng(11 + cid)
+    vals = [0, 1, 2, r - 1, r - 2, lam, r - lam, (r - 1) // 2, (r + 1) // 2] + [1 << i for i in range(255)] + [(1 << i) - 1 for i in range(1, 255)]
+    vals = [v % r for v in vals]
+    rnd = rng.integers(0, 1 << 64, size=(200000, 4), dtype=np.uint64)
+    rnd[:, 3] &= np.uint64((1 << 62) - 1)
+    rnd_int = [int(a) | int(b) << 64 | int(c) << 128 | int(d) << 192 for a, b, c, d in rnd[:2000]]      # (2000 of them checked in Python integers, all of them for size)
+    rnd_int = [v % r for v in rnd_int]
+    sc = cref.ints_to_limbs(vals + rnd_int)
+    field = khip.FP if r == P.Fp.p else khip.FQ
+    got = khip.glv_split(field, sc)
+    for k, (k1, k2) in zip(vals + rnd_int, got):
+        assert (k1 + k2 * lam - k) % r == 0, hex(k)
+        assert abs(k1) < 1 << 127 and abs(k2) < 1 << 127, (hex(k), k1.bit_length(), k2.bit_length())
+    # the bulk: canonical inputs below 2^254 < r
+    big = khip.glv_split(field, rnd)
+    assert max(max(abs(a), abs(b)) for a, b in big) < 1 << 127
