@@ -237,7 +237,9 @@ __device__ __forceinline__ void emit_digits_glv(Fe<SF> s, int mont, int c, int W
         for (int w = 0; w < Wh; w++) {
             const u32 v = (l[0] & mask) + carry;
             int32_t d;
-            if (v > half) { d = (int32_t)v - (int32_t)(1u << c); carry = 1; } else { d = (int32_t)v; carry = 0; }
+            // the digits that reach the sort lie in (-2^(c-1), 2^(c-1)] as emit_digits' do (a NEGATIVE digit of magnitude 2^(c-1) would pack, at c = 16, into the
+            // sort's 0xffff = "no entry"): a magnitude that will be negated takes its own digits from [-2^(c-1), 2^(c-1))
+            if (neg[h] ? v >= half : v > half) { d = (int32_t)v - (int32_t)(1u << c); carry = 1; } else { d = (int32_t)v; carry = 0; }
 #pragma unroll
             for (int t = 0; t < 4; t++) l[t] = (l[t] >> c) | (l[t + 1] << (32 - c));
             dst[(size_t)(h * Wh + w) * stride] = skip ? 0 : (neg[h] ? -d : d);
